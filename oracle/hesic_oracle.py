@@ -1,0 +1,420 @@
+"""CPU oracle for the HESIC / HESIC+ hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this file.  The product path (``hesic_amd``) never does:
+it fails loudly when the HIP library is missing.
+
+What it is: a functional, module-free restatement of the reference's algorithm
+for the path ``HSIC.forward`` (``ywz/mywork/newnet1.py:724-783``) and the HESIC+
+variant (``ywz/mywork/newnet1_joint.py:675-753``), written against plain CPU
+tensors in NCHW.  Parameters arrive as a flat ``{state_dict key: tensor}`` dict
+with the reference's key names.  The contractions themselves
+(``F.conv2d`` / ``F.conv_transpose2d`` / ``F.grid_sample``) are the same L1
+PyTorch primitives the reference calls; everything above them is restated here.
+
+Pinning: every function below is checked in ``tests/test_oracle_golden.py``
+against golden vectors produced by importing the reference itself in the build
+container (``tests/golden/make_golden.py``).  One exception, stated in
+DESIGN.md: ``warp_perspective`` comes from the third-party ``kornia`` package,
+which is neither vendored in the reference nor installed; its two historical
+semantics are restated from its published definition -> *parity unpinned* for
+that op only.
+
+Reference files are cited as path:line relative to the reference root.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+LIKELIHOOD_BOUND = 1e-9          # compressai/entropy_models/entropy_models.py:66
+SCALE_BOUND = 0.11               # compressai/entropy_models/entropy_models.py:446,587
+REPARAM_OFFSET = 2.0 ** -18      # compressai/ops/parametrizers.py:27
+PEDESTAL = REPARAM_OFFSET ** 2
+
+
+# --------------------------------------------------------------------------- ops
+class _LowerBoundFn(torch.autograd.Function):
+    """max(x, b) whose gradient passes where x >= b or the step moves x up
+    (compressai/ops/bound_ops.py:19-31)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x)
+        ctx.bound = bound
+        return x.clamp(min=bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        keep = (x >= ctx.bound) | (g < 0)
+        return g * keep.to(g.dtype), None
+
+
+def lower_bound(x, bound: float):
+    b = float(torch.tensor(bound, dtype=torch.float32))   # the reference stores the bound as fp32
+    return _LowerBoundFn.apply(x, b)
+
+
+def nonneg(theta, minimum: float = 0.0):
+    """NonNegativeParametrizer.forward (compressai/ops/parametrizers.py:41-44)."""
+    bound = (minimum + PEDESTAL) ** 0.5
+    ped = float(torch.tensor(PEDESTAL, dtype=torch.float32))
+    return lower_bound(theta, bound) ** 2 - ped
+
+
+def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+    """GDN / IGDN (compressai/layers/gdn.py:55-70)."""
+    C = x.shape[1]
+    b = nonneg(beta, beta_min)
+    g = nonneg(gamma).reshape(C, C, 1, 1)
+    norm = F.conv2d(x * x, g, b)
+    return x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+
+
+def conv(x, w, b, stride=2):
+    """conv() factory: Conv2d(k, stride, padding=k//2) (compressai/models/utils.py:104-109)."""
+    return F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
+
+
+def deconv(x, w, b, stride=2):
+    """deconv() factory: ConvTranspose2d(k, stride, output_padding=stride-1, padding=k//2)
+    (compressai/models/utils.py:112-118)."""
+    return F.conv_transpose2d(x, w, b, stride=stride, padding=w.shape[-1] // 2,
+                              output_padding=stride - 1)
+
+
+def masked_conv(x, w, b, mask_type="A"):
+    """MaskedConv2d (compressai/layers/layers.py:21-45): taps at/after the centre are zeroed."""
+    kh, kw = w.shape[-2:]
+    m = torch.ones_like(w)
+    m[:, :, kh // 2, kw // 2 + (mask_type == "B"):] = 0
+    m[:, :, kh // 2 + 1:] = 0
+    return F.conv2d(x, w * m, b, stride=1, padding=kh // 2)
+
+
+def quantize(x, mode, means=None, noise=None):
+    """EntropyModel._quantize (compressai/entropy_models/entropy_models.py:98-125).
+    ``noise`` replaces the reference's U(-1/2,1/2) draw so runs are reproducible."""
+    if mode not in ("noise", "dequantize", "symbols"):
+        raise ValueError(f'Invalid quantization mode: "{mode}"')
+    if mode == "noise":
+        return x + noise
+    v = x if means is None else x - means
+    v = torch.round(v)
+    if mode == "dequantize":
+        return v if means is None else v + means
+    return v.int()
+
+
+def std_cumulative(x):
+    """Phi(x) = erfc(-x/sqrt2)/2 (entropy_models.py:485-490)."""
+    return 0.5 * torch.erfc(-(2 ** -0.5) * x)
+
+
+# ------------------------------------------------------------------ entropy models
+def eb_logits_cumulative(P, prefix, v, stop_gradient=False):
+    """EntropyBottleneck._logits_cumulative (entropy_models.py:350-369). v: (C,1,L)."""
+    n = sum(1 for k in P if k.startswith(prefix + "_matrices."))
+    h = v
+    for i in range(n):
+        m = P[f"{prefix}_matrices.{i}"]
+        b = P[f"{prefix}_biases.{i}"]
+        if stop_gradient:
+            m, b = m.detach(), b.detach()
+        h = torch.matmul(F.softplus(m), h) + b
+        if i < n - 1:
+            f = P[f"{prefix}_factors.{i}"]
+            if stop_gradient:
+                f = f.detach()
+            h = h + torch.tanh(f) * torch.tanh(h)
+    return h
+
+
+def eb_forward(P, prefix, x, training=False, noise=None):
+    """EntropyBottleneck.forward (entropy_models.py:384-411). Returns (x_hat, likelihood)."""
+    B, C, H, W = x.shape
+    v = x.permute(1, 2, 3, 0).reshape(C, 1, -1)
+    med = P[prefix + "quantiles"][:, :, 1:2]
+    if training:
+        nz = noise.permute(1, 2, 3, 0).reshape(C, 1, -1)
+        out = quantize(v, "noise", med, nz)
+    else:
+        out = quantize(v, "dequantize", med)
+    lo = eb_logits_cumulative(P, prefix, out - 0.5)
+    up = eb_logits_cumulative(P, prefix, out + 0.5)
+    sign = -torch.sign(lo + up).detach()
+    lik = torch.abs(torch.sigmoid(sign * up) - torch.sigmoid(sign * lo))
+    lik = lower_bound(lik, LIKELIHOOD_BOUND)
+    back = lambda t: t.reshape(C, H, W, B).permute(3, 0, 1, 2).contiguous()
+    return back(out), back(lik)
+
+
+def eb_aux_loss(P, prefix):
+    """EntropyBottleneck.loss (entropy_models.py:345-348)."""
+    t = math.log(2 / 1e-9 - 1)
+    target = torch.tensor([-t, 0.0, t], dtype=P[prefix + "quantiles"].dtype)
+    logits = eb_logits_cumulative(P, prefix, P[prefix + "quantiles"], stop_gradient=True)
+    return torch.abs(logits - target).sum()
+
+
+def gaussian_likelihood(y_hat, scales, means=None):
+    """GaussianConditional._likelihood (entropy_models.py:528-544), without the final bound."""
+    v = y_hat if means is None else y_hat - means
+    s = lower_bound(scales, SCALE_BOUND)
+    v = torch.abs(v)
+    return std_cumulative((0.5 - v) / s) - std_cumulative((-0.5 - v) / s)
+
+
+def gc_forward(y, scales, means=None, training=False, noise=None):
+    """GaussianConditional.forward (entropy_models.py:546-554)."""
+    out = quantize(y, "noise", means, noise) if training else quantize(y, "dequantize", means)
+    return out, lower_bound(gaussian_likelihood(out, scales, means), LIKELIHOOD_BOUND)
+
+
+def gmm_forward(y, scales, means, weights, K, training=False, noise=None):
+    """GaussianMixtureConditional.forward (entropy_models.py:661-702): quantise WITHOUT
+    means, likelihood = sum_k w[:,kM:(k+1)M] * (Phi(u_k) - Phi(l_k))."""
+    M = y.shape[1]
+    out = quantize(y, "noise", None, noise) if training else quantize(y, "dequantize", None)
+    lik = None
+    for k in range(K):
+        sl = slice(M * k, M * (k + 1))
+        term = gaussian_likelihood(out, scales[:, sl], means[:, sl]) * weights[:, sl]
+        lik = term if lik is None else lik + term
+    return out, lower_bound(lik, LIKELIHOOD_BOUND)
+
+
+# ----------------------------------------------------------------------- geometry
+def warp_perspective(src, Mat, dsize, align_corners=True):
+    """kornia.warp_perspective(src, M, dsize) restated (third party).
+
+    ``Mat`` (B,3,3) maps source pixel coords to destination pixel coords.
+    align_corners=True  : kornia >= 0.5 default == exact inverse-map bilinear with zero
+                          padding (also cv2.warpPerspective).
+    align_corners=False : kornia <= 0.4 default: the same normalised grid handed to
+                          grid_sample(align_corners=False), i.e. sampling at
+                          xs*W/(W-1) - 1/2.
+    """
+    B, C, H, W = src.shape
+    Ho, Wo = dsize
+    Minv = torch.linalg.inv(Mat.double())
+    ys, xs = torch.meshgrid(torch.arange(Ho, dtype=torch.float64),
+                            torch.arange(Wo, dtype=torch.float64), indexing="ij")
+    ones = torch.ones_like(xs)
+    pts = torch.stack([xs, ys, ones], 0).reshape(1, 3, -1)
+    s = Minv @ pts
+    sx = (s[:, 0] / s[:, 2]).reshape(B, Ho, Wo)
+    sy = (s[:, 1] / s[:, 2]).reshape(B, Ho, Wo)
+    gx = 2.0 * sx / (W - 1) - 1.0
+    gy = 2.0 * sy / (H - 1) - 1.0
+    grid = torch.stack([gx, gy], -1).to(src.dtype)
+    return F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros",
+                         align_corners=align_corners)
+
+
+def upsample_bilinear_x4(x):
+    """nn.UpsamplingBilinear2d(scale_factor=4) == align_corners=True (newnet1.py:524)."""
+    return F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)
+
+
+# --------------------------------------------------------------------- sub-networks
+def _cv(P, key, x, stride=2):
+    return conv(x, P[key + ".weight"], P[key + ".bias"], stride)
+
+
+def _dc(P, key, x, stride=2):
+    return deconv(x, P[key + ".weight"], P[key + ".bias"], stride)
+
+
+def _gdn(P, key, x, inverse=False):
+    return gdn(x, P[key + ".beta"], P[key + ".gamma"], inverse)
+
+
+def g_a(P, pre, x):
+    """Encoder1 stack (newnet1.py:580-601); also the tail of Encoder2."""
+    x = _gdn(P, pre + "g_a_gdn1", _cv(P, pre + "g_a_conv1", x))
+    x = _gdn(P, pre + "g_a_gdn2", _cv(P, pre + "g_a_conv2", x))
+    x = _gdn(P, pre + "g_a_gdn3", _cv(P, pre + "g_a_conv3", x))
+    return _cv(P, pre + "g_a_conv4", x)
+
+
+def g_s(P, pre, y):
+    """Decoder1 stack (newnet1.py:603-624); also the head of Decoder2."""
+    y = _gdn(P, pre + "g_s_gdn1", _dc(P, pre + "g_s_conv1", y), True)
+    y = _gdn(P, pre + "g_s_gdn2", _dc(P, pre + "g_s_conv2", y), True)
+    y = _gdn(P, pre + "g_s_gdn3", _dc(P, pre + "g_s_conv3", y), True)
+    return _dc(P, pre + "g_s_conv4", y)
+
+
+def encoder2(P, x1_warp, x2):
+    """Encoder2.forward (newnet1.py:626-655)."""
+    t = _cv(P, "encoder2.pre_conv", torch.cat((x1_warp, x2), 1), stride=1)
+    t = _gdn(P, "encoder2.pre_gdn", t)
+    return g_a(P, "encoder2.", t)
+
+
+def decoder2(P, y_hat, x1_hat_warp):
+    """Decoder2.forward (newnet1.py:657-692)."""
+    t = _gdn(P, "decoder2.after_gdn", g_s(P, "decoder2.", y_hat), True)
+    return _dc(P, "decoder2.after_conv", torch.cat((t, x1_hat_warp), 1), stride=1)
+
+
+def encode_hyper(P, pre, y):
+    """encode_hyper.forward (newnet1.py:420-437)."""
+    t = F.relu(_cv(P, pre + "encode_hyper.0", torch.abs(y), 1))
+    t = F.relu(_cv(P, pre + "encode_hyper.2", t))
+    return _cv(P, pre + "encode_hyper.4", t)
+
+
+def _mix_weights(t, K, M):
+    """(B,K*M,1,1) logits -> softmax over K with channel = k*M+m (newnet1.py:510-512)."""
+    B = t.shape[0]
+    return F.softmax(t.reshape(B, K, M, 1, 1), dim=1).reshape(B, K * M, 1, 1)
+
+
+def gmm_hyper_y1(P, z_hat, K, M):
+    """gmm_hyper_y1.forward (newnet1.py:456-514)."""
+    p = "_h_s1."
+    s = F.relu(_dc(P, p + "gmm_sigma.0", z_hat))
+    s = F.relu(_dc(P, p + "gmm_sigma.2", s))
+    s = F.relu(_cv(P, p + "gmm_sigma.4", s, 1))
+    m = F.leaky_relu(_dc(P, p + "gmm_means.0", z_hat), 0.01)
+    m = F.leaky_relu(_dc(P, p + "gmm_means.2", m), 0.01)
+    m = _cv(P, p + "gmm_means.4", m, 1)
+    w = F.leaky_relu(_dc(P, p + "gmm_weights.0", z_hat), 0.01)
+    w = _dc(P, p + "gmm_weights.2", w)
+    w = F.leaky_relu(torch.amax(w, dim=(2, 3), keepdim=True), 0.01)   # spatial_pool2d :441-453
+    w = _cv(P, p + "gmm_weights.5", w, 1)
+    return s, m, _mix_weights(w, K, M)
+
+
+def gmm_hyper_y2(P, z_hat, y1, K, M):
+    """gmm_hyper_y2.forward (newnet1.py:517-577)."""
+    p = "_h_s2."
+    c = torch.cat((upsample_bilinear_x4(z_hat), y1), 1)
+    s = F.relu(_cv(P, p + "gmm_sigma.0", c, 1))
+    s = F.relu(_cv(P, p + "gmm_sigma.2", s, 1))
+    s = F.relu(_cv(P, p + "gmm_sigma.4", s, 1))
+    m = F.leaky_relu(_cv(P, p + "gmm_means.0", c, 1), 0.01)
+    m = F.leaky_relu(_cv(P, p + "gmm_means.2", m, 1), 0.01)
+    m = _cv(P, p + "gmm_means.4", m, 1)
+    w = F.leaky_relu(_cv(P, p + "gmm_weights.0", c, 1), 0.01)
+    w = _cv(P, p + "gmm_weights.2", w, 1)
+    w = F.leaky_relu(torch.amax(w, dim=(2, 3), keepdim=True), 0.01)
+    w = _cv(P, p + "gmm_weights.5", w, 1)
+    return s, m, _mix_weights(w, K, M)
+
+
+# -------------------------------------------------------------------- whole models
+def hsic_forward(P, x1, x2, Hm, K=5, M=192, training=False, noise=None, align_corners=True):
+    """HSIC.forward (ywz/mywork/newnet1.py:724-783).
+
+    ``noise`` (training only): dict with keys z1,y1,y1w,z2,y2 -- the five U(-1/2,1/2)
+    draws in the order the reference makes them (SURVEY.md §7 hard parts).
+    """
+    nz = noise or {}
+    size = x1.shape[-2:]
+    y1 = g_a(P, "encoder1.", x1)
+    z1 = encode_hyper(P, "_h_a1.", y1)
+    z1_hat, z1_lik = eb_forward(P, "entropy_bottleneck1.", z1, training, nz.get("z1"))
+    s1, m1, w1 = gmm_hyper_y1(P, z1_hat, K, M)
+    y1_hat, y1_lik = gmm_forward(y1, s1, m1, w1, K, training, nz.get("y1"))
+    x1_hat = g_s(P, "decoder1.", y1_hat)
+
+    x1_warp = warp_perspective(x1, Hm, size, align_corners)
+    y2 = encoder2(P, x1_warp, x2)
+    x1_hat_warp = warp_perspective(x1_hat, Hm, size, align_corners)     # :753 == :767
+    y1_w = g_a(P, "encoder1.", x1_hat_warp)
+    y1_hat_w = quantize(y1_w, "noise", None, nz.get("y1w")) if training else quantize(y1_w, "dequantize")
+
+    z2 = encode_hyper(P, "_h_a2.", y2)
+    z2_hat, z2_lik = eb_forward(P, "entropy_bottleneck2.", z2, training, nz.get("z2"))
+    s2, m2, w2 = gmm_hyper_y2(P, z2_hat, y1_hat_w, K, M)
+    y2_hat, y2_lik = gmm_forward(y2, s2, m2, w2, K, training, nz.get("y2"))
+    x2_hat = decoder2(P, y2_hat, x1_hat_warp)
+    return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+            "z1_hat": z1_hat, "z2_hat": z2_hat,
+            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+def _seq(P, pre, x, spec):
+    """Run a reference nn.Sequential given as [(index, kind, stride)], LeakyReLU(0.01) between."""
+    for j, (idx, kind, stride) in enumerate(spec):
+        key = f"{pre}.{idx}"
+        if kind == "conv":
+            x = _cv(P, key, x, stride)
+        elif kind == "deconv":
+            x = _dc(P, key, x, stride)
+        else:  # plain nn.Conv2d 1x1
+            x = F.conv2d(x, P[key + ".weight"], P[key + ".bias"])
+        if j < len(spec) - 1:
+            x = F.leaky_relu(x, 0.01)
+    return x
+
+
+_H_A = [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)]
+_H_S = [(0, "deconv", 2), (2, "deconv", 2), (4, "conv", 1)]
+_EP = [(0, "1x1", 1), (2, "1x1", 1), (4, "1x1", 1)]
+
+
+def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=True):
+    """HESIC+ forward (ywz/mywork/newnet1_joint.py:675-753)."""
+    nz = noise or {}
+    size = x1.shape[-2:]
+    q = (lambda t, k: quantize(t, "noise", None, nz.get(k))) if training else (lambda t, k: quantize(t, "dequantize"))
+    y1 = g_a(P, "encoder1.", x1)
+    z1 = _seq(P, "h_a1", y1, _H_A)
+    z1_hat, z1_lik = eb_forward(P, "entropy_bottleneck1.", z1, training, nz.get("z1"))
+    params1 = _seq(P, "h_s1", z1_hat, _H_S)
+    y1_hat = q(y1, "y1")
+    ctx1 = masked_conv(y1_hat, P["context_prediction1.weight"], P["context_prediction1.bias"])
+    gp1 = _seq(P, "entropy_parameters1", torch.cat((params1, ctx1), 1), _EP)
+    sc1, mu1 = gp1.chunk(2, 1)
+    _, y1_lik = gc_forward(y1, sc1, mu1, training, nz.get("y1b"))
+    x1_hat = g_s(P, "decoder1.", y1_hat)
+
+    x1_warp = warp_perspective(x1, Hm, size, align_corners)
+    y2 = encoder2(P, x1_warp, x2)
+    z2 = _seq(P, "h_a2", y2, _H_A)
+    z2_hat, z2_lik = eb_forward(P, "entropy_bottleneck2.", z2, training, nz.get("z2"))
+    x1_hat_warp = warp_perspective(x1_hat, Hm, size, align_corners)
+    y1_hat_w = q(g_a(P, "encoder1.", x1_hat_warp), "y1w")
+    params2 = _seq(P, "h_s2", z2_hat, _H_S)
+    y2_hat = q(y2, "y2")
+    ctx2 = masked_conv(y2_hat, P["context_prediction2.weight"], P["context_prediction2.bias"])
+    gp2 = _seq(P, "entropy_parameters2", torch.cat((params2, ctx2, y1_hat_w), 1), _EP)
+    sc2, mu2 = gp2.chunk(2, 1)
+    _, y2_lik = gc_forward(y2, sc2, mu2, training, nz.get("y2b"))
+    x2_hat = decoder2(P, y2_hat, x1_hat_warp)
+    return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+            "z1_hat": z1_hat, "z2_hat": z2_hat,
+            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+# --------------------------------------------------------------- loss and metrics
+def rd_loss(out, x1, x2, lmbda):
+    """RateDistortionLoss (ywz/mywork/newtrain1.py:37-56)."""
+    n, _, h, w = x1.shape
+    bpp = sum(torch.log(l).sum() / (-math.log(2) * n * h * w) for l in out["likelihoods"].values())
+    mse = F.mse_loss(out["x1_hat"], x1) + F.mse_loss(out["x2_hat"], x2)
+    return {"bpp_loss": bpp, "mse_loss": mse, "loss": lmbda * 255 ** 2 * mse + bpp}
+
+
+def metrics(out, x1, x2):
+    """PSNR / bpp conventions (ywz/mywork/test3real.py:69-72,110-122; newtrain1.py:141-142)."""
+    n, _, h, w = x1.shape
+    bits = {k: float(torch.log(v.double()).sum() / -math.log(2)) for k, v in out["likelihoods"].items()}
+    mse1 = float(F.mse_loss(out["x1_hat"].double(), x1.double()))
+    mse2 = float(F.mse_loss(out["x2_hat"].double(), x2.double()))
+    psnr1, psnr2 = 10 * math.log10(1 / mse1), 10 * math.log10(1 / mse2)
+    bpp_loss = sum(bits.values()) / (n * h * w)
+    return {"bits": bits, "bpp_loss": bpp_loss, "bpp": bpp_loss / 2, "mse1": mse1, "mse2": mse2,
+            "psnr1": psnr1, "psnr2": psnr2, "psnr": (psnr1 + psnr2) / 2}
+
+
+def aux_loss(P):
+    """CompressionModel.aux_loss (newnet1.py:56-62)."""
+    return eb_aux_loss(P, "entropy_bottleneck1.") + eb_aux_loss(P, "entropy_bottleneck2.")
