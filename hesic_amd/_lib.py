@@ -1,0 +1,138 @@
+"""ctypes binding of ``libhesic_hip.so`` (C ABI: ``include/hesic_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C hesic_amd/csrc``.
+There is NO fallback: if the shared object is missing or a kernel call fails, the caller gets
+an exception -- the product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhesic_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hesic_hip.h")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+EB_PARAM_STRIDE = 64
+
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, _i32) for n in (
+        "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "transposed", "dtype", "act",
+        "in_abs", "x_pix_stride", "x_c_off", "y_pix_stride", "y_c_off", "tap_mask_lo")]
+
+
+class SConvDesc(C.Structure):
+    _fields_ = [(n, _i32) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
+                                    "transposed", "x_dtype", "y_dtype", "act")] + \
+               [("_pad", _i32)] + \
+               [(n, _i64) for n in ("xs_b", "xs_c", "xs_y", "xs_x", "ys_b", "ys_c", "ys_y", "ys_x")]
+
+
+class WarpDesc(C.Structure):
+    _fields_ = [(n, _i32) for n in ("B", "C", "H", "W", "Ho", "Wo", "align_corners", "src_dtype", "dst_dtype")] + \
+               [("_pad", _i32)] + \
+               [(n, _i64) for n in ("ss_b", "ss_c", "ss_y", "ss_x", "ds_b", "ds_c", "ds_y", "ds_x")]
+
+
+class GmmDesc(C.Structure):
+    _fields_ = [(n, _i32) for n in ("B", "HW", "M", "K", "dtype", "use_means_in_quant", "sm_pix_stride",
+                                    "s_c_off", "m_c_off")] + [("scale_bound", _f32), ("lik_bound", _f32)]
+
+
+_P = C.POINTER
+_SIGS = {
+    "hesic_abi_version": ([], _i32),
+    "hesic_last_error": ([], C.c_char_p),
+    "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_conv2d_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_conv2d_wgrad_ws_bytes": ([_P(ConvDesc)], _i64),
+    "hesic_conv2d_wgrad": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i32),
+    "hesic_unpack_conv_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_sconv2d_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_dgrad": ([_P(SConvDesc), _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_wgrad": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_gdn_forward": ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
+    "hesic_gdn_backward_ws_bytes": ([_i64, _i32], _i64),
+    "hesic_gdn_backward": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
+    "hesic_warp_perspective_forward": ([_P(WarpDesc), _vp, _vp, _vp, _vp], _i32),
+    "hesic_warp_perspective_backward": ([_P(WarpDesc), _vp, _vp, _vp, _vp], _i32),
+    "hesic_eb_forward": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    "hesic_eb_backward": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    "hesic_gmm_forward": ([_P(GmmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_gmm_backward": ([_P(GmmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_upsample4_forward": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_upsample4_backward": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_copy_channels": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_spatial_max": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_mix_weights_forward": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_softmax_k_forward": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_softmax_k_backward": ([_vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_sum_log2": ([_vp, _i64, _vp, _vp], _i32),
+    "hesic_sum_sq_diff": ([_vp, _i32, _P(_i64), _vp, _i32, _P(_i64), _i32, _i32, _i32, _i32, _vp, _vp], _i32),
+    "hesic_act_backward": ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    "hesic_cast": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Every ``hesic_*`` function declared in include/hesic_hip.h (used by the ABI test)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(hesic_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"hesic_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C hesic_amd/csrc`. There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = args, res
+        if l.hesic_abi_version() != 1:
+            raise RuntimeError("hesic_amd: libhesic_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib().hesic_last_error().decode()}")
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise TypeError(f"hesic_amd: unsupported dtype {d} (float32 or bfloat16)")
+
+
+def ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hesic_amd: the HIP path needs tensors on a ROCm device (no CPU fallback); "
+                               f"got a tensor on {t.device}")

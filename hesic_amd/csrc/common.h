@@ -1,0 +1,88 @@
+// Shared device/host helpers for libhesic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hesic_hip.h"
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- error plumbing (host)
+void hesic_set_error(const char* fmt, ...);
+#define HESIC_CHECK_ARG(cond, ...)                  \
+    do {                                            \
+        if (!(cond)) {                              \
+            hesic_set_error(__VA_ARGS__);           \
+            return HESIC_EINVAL;                    \
+        }                                           \
+    } while (0)
+#define HESIC_LAUNCH_RETURN(name)                                              \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            hesic_set_error("%s: %s", name, hipGetErrorString(e__));           \
+            return (int)e__;                                                   \
+        }                                                                      \
+        return 0;                                                              \
+    } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even, NaN kept quiet)
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// dtype-erased scalar access for the strided (image-side) kernels
+__device__ __forceinline__ float ld_any(const void* p, int64_t i, int dtype) {
+    return dtype == HESIC_BF16 ? bf2f(((const bf16_t*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t i, int dtype, float v) {
+    if (dtype == HESIC_BF16) ((bf16_t*)p)[i] = f2bf(v);
+    else ((float*)p)[i] = v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == HESIC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == HESIC_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int grid_for(int64_t n, int block, int max_blocks = 256 * 8) {
+    int64_t g = cdiv64(n, block);
+    if (g > max_blocks) g = max_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}

@@ -1,0 +1,420 @@
+// Implicit-GEMM convolution / transposed convolution on the CDNA4 matrix cores.
+//
+// Replaces nn.Conv2d / nn.ConvTranspose2d of conv()/deconv() (compressai/models/utils.py:104-118) for
+// the wide layers of the HESIC stacks (ywz/mywork/newnet1.py:420-692): Cin % 32 == 0, Cout % 8 == 0.
+//
+// GEMM view:  Y[cout, pixel] = sum_{tap, ci} Wp[tap][cout][ci] * X[pixel shifted by tap][ci]
+//   M = Cout tile (BN rows of the weight panel)   -> MFMA "A" operand
+//   N = 128 output pixels (an 8x16-ish 2-D patch) -> MFMA "B" operand
+//   K = taps x Cin, walked in steps of 32 channels of one tap.
+// With the weights on the A side every lane ends up holding 4 consecutive output channels of one
+// pixel, so the epilogue can pack and stage a pixel-major tile in LDS and write full NHWC rows.
+//
+// A transposed stride-2 conv is run as its 4 output phases (sub-pixel decomposition): phase (py,px)
+// is an ordinary stride-1 gather over 3x3 / 3x2 / 2x3 / 2x2 taps, so no zero-inserted input exists.
+//
+// Storage T is bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain,
+// used for the tight-parity mode); accumulation is fp32 in both.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;      // pixels per block
+constexpr int BK = 32;       // channels per K-step
+constexpr int NTHREADS = 256;
+constexpr int MAX_TAPS = 25;
+
+struct IgemmArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    void* y;
+    int B, H, W, Cin, x_ps, x_co;
+    int QH, QW, TH, TW, tw_shift, tiles_y, tiles_x;
+    int in_step, out_step;
+    int Ho, Wo, Cout, y_ps, y_co;
+    int act, in_abs;
+    int n_tiles, nphase;
+    int ntaps[4];
+    int8_t oy_off[4], ox_off[4];
+    int8_t dy[4][MAX_TAPS], dx[4][MAX_TAPS], wt[4][MAX_TAPS];
+};
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> {
+    static constexpr int CE = 8;    // elements per 16-byte chunk
+    static constexpr int CPR = 4;   // chunks per LDS row (BK*2/16)
+    static constexpr int RPB = 4;   // LDS rows per 256-byte bank row
+};
+template <> struct Cfg<float> {
+    static constexpr int CE = 4;
+    static constexpr int CPR = 8;
+    static constexpr int RPB = 2;
+};
+
+template <typename T>
+__device__ __forceinline__ int lds_off(int row, int slot) {
+    // byte offset of 16-byte slot `slot` of row `row`, XOR-swizzled so that the 16-lane groups of a
+    // ds_read_b128 (rows r..r+3, r+12.., r+20..) land on distinct bank quads
+    const int sw = slot ^ ((row / Cfg<T>::RPB) & (Cfg<T>::CPR - 1));
+    return (row * Cfg<T>::CPR + sw) * 16;
+}
+
+__device__ __forceinline__ u32x4 abs_chunk(u32x4 v, bf16_t) {
+    return u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
+}
+__device__ __forceinline__ u32x4 abs_chunk(u32x4 v, float) {
+    return u32x4{v.x & 0x7fffffffu, v.y & 0x7fffffffu, v.z & 0x7fffffffu, v.w & 0x7fffffffu};
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a) {
+    using C = Cfg<T>;
+    constexpr int LA = BM * C::CPR / NTHREADS;              // x-tile 16B loads per thread per step
+    constexpr int LB = (BN * C::CPR) / NTHREADS;            // w-tile loads per thread per step (>=1)
+    static_assert(LB >= 1, "BN too small");
+    constexpr int XT = BM * BK * (int)sizeof(T);            // bytes of one x stage
+    constexpr int WT = BN * BK * (int)sizeof(T);
+    constexpr int OROW = BN * (int)sizeof(T) + 16;          // padded epilogue row
+    constexpr int STAGE = 2 * (XT + WT);
+    constexpr int EPI = BM * OROW;
+    constexpr int LDS_BYTES = STAGE > EPI ? STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // ---- XCD-aware block remap: consecutive logical tiles share an L2
+    int bid;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % a.n_tiles;
+    int rest = bid / a.n_tiles;
+    const int tx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int ty = rest % a.tiles_y;
+    rest /= a.tiles_y;
+    const int b = rest % a.B;
+    const int ph = rest / a.B;
+    const int n0 = nt * BN;
+    const int ntaps = a.ntaps[ph];
+    const int kchunks = a.Cin / BK;
+    const int nsteps = ntaps * kchunks;
+
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+
+    // ---- per-thread staging coordinates (fixed over the K loop)
+    const int slot = tid % C::CPR;
+    const T* xrow[LA];
+    int iy0[LA], ix0[LA];
+    bool rowok[LA];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int row = tid / C::CPR + j * (NTHREADS / C::CPR);
+        const int qy = ty * a.TH + (row >> a.tw_shift);
+        const int qx = tx * a.TW + (row & (a.TW - 1));
+        rowok[j] = (qy < a.QH) && (qx < a.QW);
+        iy0[j] = qy * a.in_step;
+        ix0[j] = qx * a.in_step;
+        xrow[j] = xg + (((int64_t)b * a.H + iy0[j]) * a.W + ix0[j]) * a.x_ps + a.x_co + slot * C::CE;
+    }
+    const T* wrow[LB];
+    bool wok[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int n = tid / C::CPR + j * (NTHREADS / C::CPR);
+        wok[j] = (n0 + n) < a.Cout;
+        wrow[j] = wg + (int64_t)(n0 + n) * a.Cin + slot * C::CE;
+    }
+
+    u32x4 xr[LA], wr[LB];
+    auto load_step = [&](int step) {
+        const int t = step / kchunks;
+        const int c0 = (step - t * kchunks) * BK;
+        const int dy = a.dy[ph][t], dx = a.dx[ph][t];
+        const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps + c0;
+        const int64_t wo = (int64_t)a.wt[ph][t] * a.Cout * a.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const bool ok = rowok[j] && (unsigned)(iy0[j] + dy) < (unsigned)a.H && (unsigned)(ix0[j] + dx) < (unsigned)a.W;
+            xr[j] = ok ? *(const u32x4*)(xrow[j] + xo) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) wr[j] = wok[j] ? *(const u32x4*)(wrow[j] + wo) : u32x4{0, 0, 0, 0};
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* xs = smem + buf * (XT + WT);
+        unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int row = tid / C::CPR + j * (NTHREADS / C::CPR);
+            u32x4 v = xr[j];
+            if (a.in_abs) v = abs_chunk(v, T());
+            *(u32x4*)(xs + lds_off<T>(row, slot)) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int row = tid / C::CPR + j * (NTHREADS / C::CPR);
+            *(u32x4*)(ws + lds_off<T>(row, slot)) = wr[j];
+        }
+    };
+
+    // ---- wave tiling: 2 (cout halves) x 2 (pixel halves)
+    constexpr int MI = BN / 64;          // 32-cout tiles per wave
+    constexpr int NI = 2;                // 32-pixel tiles per wave
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);
+        const unsigned char* xs = smem + buf * (XT + WT);
+        const unsigned char* ws = xs + XT;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[MI], xf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    wf[i] = *(const bf16x8*)(ws + lds_off<T>(wm * (BN / 2) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    xf[j] = *(const bf16x8*)(xs + lds_off<T>(wn * 64 + j * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane half h owns k = 16h..16h+15 of the step (any consistent k order is a valid GEMM)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f32x4 wf[MI], xf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    wf[i] = *(const f32x4*)(ws + lds_off<T>(wm * (BN / 2) + i * 32 + frow, fh * 4 + s));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    xf[j] = *(const f32x4*)(xs + lds_off<T>(wn * 64 + j * 32 + frow, fh * 4 + s));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation, pack, stage pixel-major in LDS, write NHWC rows
+    // C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wm * (BN / 2) + i * 32 + 8 * g + 4 * fh;   // first of 4 consecutive couts
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int prow = wn * 64 + j * 32 + frow;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
+                unsigned char* dst = smem + prow * OROW + cl * (int)sizeof(T);
+                if constexpr (sizeof(T) == 2) {
+                    *(u32x2*)dst = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                } else {
+                    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPO = BN * (int)sizeof(T) / 16;           // 16B chunks per output row
+        constexpr int TOT = BM * CPO;
+        T* __restrict__ yg = (T*)a.y;
+        const int oyo = a.oy_off[ph], oxo = a.ox_off[ph];
+#pragma unroll
+        for (int c = tid; c < TOT; c += NTHREADS) {
+            const int prow = c / CPO, cc = c % CPO;
+            const int qy = ty * a.TH + (prow >> a.tw_shift);
+            const int qx = tx * a.TW + (prow & (a.TW - 1));
+            const int ch = n0 + cc * C::CE;
+            if (qy < a.QH && qx < a.QW && ch < a.Cout) {
+                const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
+                const int64_t off = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + ch;
+                *(u32x4*)(yg + off) = *(const u32x4*)(smem + prow * OROW + cc * 16);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ mask, T* __restrict__ wp,
+                                   int Cout, int Cin, int KH, int KW, int transposed, int flip) {
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = i % Cin;
+        int64_t r = i / Cin;
+        const int co = r % Cout;
+        const int tap = r / Cout;
+        int ky = tap / KW, kx = tap % KW;
+        if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
+        const int64_t src = transposed ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx
+                                       : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
+        float v = w[src];
+        if (mask) v *= mask[src];
+        elem<T>::st(wp + i, v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ mask, float* __restrict__ dw,
+                                    int Cout, int Cin, int KH, int KW, int transposed) {
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the PyTorch layout so the writes are coalesced
+        int64_t r = i;
+        const int kx = r % KW; r /= KW;
+        const int ky = r % KH; r /= KH;
+        int co, ci;
+        if (transposed) { co = r % Cout; ci = r / Cout; } else { ci = r % Cin; co = r / Cin; }
+        float v = dwp[((int64_t)(ky * KW + kx) * Cout + co) * Cin + ci];
+        if (mask) v *= mask[i];
+        dw[i] = v;
+    }
+}
+
+int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- C ABI
+extern "C" int hesic_pack_conv_weight(const float* w, const float* mask, void* wp, int Cout, int Cin, int KH, int KW,
+                                      int transposed, int flip, int dtype, void* stream) {
+    HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "pack_conv_weight: bad arguments");
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    const int g = grid_for(n, 256);
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (bf16_t*)wp,
+                           Cout, Cin, KH, KW, transposed, flip);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (float*)wp,
+                           Cout, Cin, KH, KW, transposed, flip);
+    HESIC_LAUNCH_RETURN("pack_conv_weight");
+}
+
+extern "C" int hesic_unpack_conv_wgrad(const float* dwp, const float* mask, float* dw, int Cout, int Cin, int KH, int KW,
+                                       int transposed, void* stream) {
+    HESIC_CHECK_ARG(dwp && dw, "unpack_conv_wgrad: null pointer");
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dwp, mask, dw, Cout,
+                       Cin, KH, KW, transposed);
+    HESIC_LAUNCH_RETURN("unpack_conv_wgrad");
+}
+
+extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                    void* y, void* stream) {
+    HESIC_CHECK_ARG(d && x && w_packed && y, "conv2d_forward: null pointer");
+    HESIC_CHECK_ARG(d->Cin % BK == 0, "conv2d_forward: Cin=%d must be a multiple of %d (use hesic_sconv2d_forward)", d->Cin, BK);
+    const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
+    HESIC_CHECK_ARG(d->Cout % ce == 0 && d->y_c_off % ce == 0 && d->y_pix_stride % ce == 0 && d->x_c_off % ce == 0 &&
+                        d->x_pix_stride % ce == 0,
+                    "conv2d_forward: channel counts/offsets must be multiples of %d", ce);
+    HESIC_CHECK_ARG(d->KH * d->KW <= MAX_TAPS, "conv2d_forward: at most %d taps", MAX_TAPS);
+    HESIC_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv2d_forward: stride must be 1 or 2");
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 || d->dtype == HESIC_F32, "conv2d_forward: bad dtype");
+    HESIC_CHECK_ARG(d->x_c_off + d->Cin <= d->x_pix_stride && d->y_c_off + d->Cout <= d->y_pix_stride,
+                    "conv2d_forward: channel slice out of range");
+
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
+    a.act = d->act; a.in_abs = d->in_abs;
+    const int s = d->stride, p = d->pad;
+    if (!d->transposed) {
+        HESIC_CHECK_ARG(d->Ho == (d->H + 2 * p - d->KH) / s + 1 && d->Wo == (d->W + 2 * p - d->KW) / s + 1,
+                        "conv2d_forward: output size does not match");
+        a.QH = d->Ho; a.QW = d->Wo; a.in_step = s; a.out_step = 1; a.nphase = 1;
+        int n = 0;
+        for (int ky = 0; ky < d->KH; ++ky)
+            for (int kx = 0; kx < d->KW; ++kx) {
+                const int t = ky * d->KW + kx;
+                if (d->tap_mask_lo && !((d->tap_mask_lo >> t) & 1)) continue;
+                a.dy[0][n] = (int8_t)(ky - p); a.dx[0][n] = (int8_t)(kx - p); a.wt[0][n] = (int8_t)t; ++n;
+            }
+        a.ntaps[0] = n;
+        HESIC_CHECK_ARG(n > 0, "conv2d_forward: no live taps");
+    } else {
+        HESIC_CHECK_ARG(d->Ho == d->H * s && d->Wo == d->W * s, "conv2d_forward: transposed output must be H*stride");
+        HESIC_CHECK_ARG(!d->tap_mask_lo, "conv2d_forward: tap mask unsupported for transposed conv");
+        // output o = q*s + r gets input i = q + (r + p - k)/s for taps k == (r+p) mod s
+        a.QH = d->H; a.QW = d->W; a.in_step = 1; a.out_step = s; a.nphase = s * s;
+        int order[4] = {0, 1, 2, 3};
+        int cnt[4] = {0, 0, 0, 0};
+        for (int ph = 0; ph < s * s; ++ph) {
+            const int ry = ph / s, rx = ph % s;
+            int n = 0;
+            for (int ky = (ry + p) % s; ky < d->KH; ky += s)
+                for (int kx = (rx + p) % s; kx < d->KW; kx += s) {
+                    a.dy[ph][n] = (int8_t)((ry + p - ky) / s);
+                    a.dx[ph][n] = (int8_t)((rx + p - kx) / s);
+                    a.wt[ph][n] = (int8_t)(ky * d->KW + kx);
+                    ++n;
+                }
+            a.ntaps[ph] = n; cnt[ph] = n;
+            a.oy_off[ph] = (int8_t)ry; a.ox_off[ph] = (int8_t)rx;
+            HESIC_CHECK_ARG((ry + p - ((ry + p) % s)) % s == 0, "conv2d_forward: internal phase error");
+        }
+        (void)order; (void)cnt;  // phases are already heaviest-first for k=5,p=2,s=2 (9,6,6,4 taps)
+    }
+    // 2-D pixel patch of 128: as square as the q-grid allows
+    int TW = 16;
+    while (TW > 1 && TW / 2 >= a.QW) TW /= 2;
+    if (a.QW >= 32 && a.QH < 8) TW = 32;
+    int TH = BM / TW;
+    a.TW = TW; a.TH = TH; a.tw_shift = ilog2(TW);
+    a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
+
+    // cout tile: 128 unless 64 wastes less
+    const int pad128 = ((d->Cout + 127) / 128) * 128, pad64 = ((d->Cout + 63) / 64) * 64;
+    const int BN = (pad64 < pad128) ? 64 : 128;
+    a.n_tiles = (d->Cout + BN - 1) / BN;
+    const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase;
+    HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
+    const dim3 grid((unsigned)nblocks), block(NTHREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == HESIC_BF16) {
+        if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 128>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 64>), grid, block, 0, st, a);
+    } else {
+        if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<float, 128>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((igemm_conv_kernel<float, 64>), grid, block, 0, st, a);
+    }
+    HESIC_LAUNCH_RETURN("conv2d_forward");
+}

@@ -1,0 +1,365 @@
+// Fused quantise + likelihood kernels of the entropy models (forward and backward):
+//   EntropyBottleneck.forward          compressai/entropy_models/entropy_models.py:384-411 (+ :350-382)
+//   GaussianConditional.forward        :546-554 (+ :528-544)
+//   GaussianMixtureConditional.forward :661-702   (the HESIC addition)
+// The reference runs ~30 (EB) / ~60 (GMM, K=5) tiny ATen kernels; here each latent is read once and
+// y_hat / likelihood / symbols are written once.  All arithmetic is fp32; erfc/exp/tanh use the full
+// precision device functions (no fast-math) because the likelihood floors at 1e-9.
+#include "common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------- EntropyBottleneck
+// packed per-channel parameters (raw, i.e. before softplus / tanh), stride HESIC_EB_PARAM_STRIDE:
+//   [0,3)   M0 (3x1)   [3,12) M1 (3x3)  [12,21) M2  [21,30) M3  [30,33) M4 (1x3)
+//   [33,36) b0  [36,39) b1  [39,42) b2  [42,45) b3  [45] b4
+//   [46,49) f0  [49,52) f1  [52,55) f2  [55,58) f3      [58] median
+constexpr int EB_M0 = 0, EB_M1 = 3, EB_M4 = 30, EB_B0 = 33, EB_B4 = 45, EB_F0 = 46, EB_MED = 58, EB_NP = 58;
+
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float signf(float x) { return (x > 0.f) - (x < 0.f); }
+
+struct EBParams {
+    float sp[33];    // softplus(matrices)
+    float b[13];
+    float tf[12];    // tanh(factors)
+};
+
+__device__ __forceinline__ void eb_load(const float* p, EBParams& q) {
+#pragma unroll
+    for (int i = 0; i < 33; ++i) q.sp[i] = softplusf(p[i]);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) q.b[i] = p[EB_B0 + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q.tf[i] = tanhf(p[EB_F0 + i]);
+}
+
+// forward of the 1-3-3-3-3-1 cumulative; keeps pre-activations when `pre` != nullptr (backward)
+__device__ __forceinline__ float eb_logits(const EBParams& q, float v, float (*pre)[3], float (*hin)[3]) {
+    float h[3], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        t[r] = q.sp[EB_M0 + r] * v + q.b[r];
+        if (pre) pre[0][r] = t[r];
+        h[r] = t[r] + q.tf[r] * tanhf(t[r]);
+    }
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+        if (hin) { hin[l][0] = h[0]; hin[l][1] = h[1]; hin[l][2] = h[2]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* m = q.sp + EB_M1 + (l - 1) * 9 + r * 3;
+            t[r] = m[0] * h[0] + m[1] * h[1] + m[2] * h[2] + q.b[3 * l + r];
+            if (pre) pre[l][r] = t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) h[r] = t[r] + q.tf[3 * l + r] * tanhf(t[r]);
+    }
+    if (hin) { hin[4][0] = h[0]; hin[4][1] = h[1]; hin[4][2] = h[2]; }
+    return q.sp[EB_M4] * h[0] + q.sp[EB_M4 + 1] * h[1] + q.sp[EB_M4 + 2] * h[2] + q.b[12];
+}
+
+template <typename T>
+__global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+                              T* __restrict__ zhat, float* __restrict__ lik, int32_t* __restrict__ sym, int64_t P, int C) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    EBParams q;
+    eb_load(params + (int64_t)c * HESIC_EB_PARAM_STRIDE, q);
+    const float med = params[(int64_t)c * HESIC_EB_PARAM_STRIDE + EB_MED];
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t i = p * C + c;
+        const float zv = elem<T>::ld(z + i);
+        float v;
+        if (noise) {
+            v = zv + elem<T>::ld(noise + i);
+        } else {
+            const float r = rintf(zv - med);
+            if (sym) sym[i] = (int32_t)r;
+            v = r + med;
+        }
+        const float lo = eb_logits(q, v - 0.5f, nullptr, nullptr), up = eb_logits(q, v + 0.5f, nullptr, nullptr);
+        const float s = -signf(lo + up);
+        const float l = fabsf(sigmoidf(s * up) - sigmoidf(s * lo));
+        elem<T>::st(zhat + i, v);
+        lik[i] = fmaxf(l, 1e-9f);
+    }
+}
+
+// backward through one logits evaluation: accumulates d(params) into gp[58] and returns d/dv
+__device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* raw, float v, float gout, float* gp) {
+    float pre[4][3], hin[5][3];
+    eb_logits(q, v, pre, hin);
+    // layer 4: out = sp4 . h3 + b4
+    float dh[3];
+    gp[EB_B4] += gout;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gp[EB_M4 + j] += gout * hin[4][j] * sigmoidf(raw[EB_M4 + j]);
+        dh[j] = gout * q.sp[EB_M4 + j];
+    }
+#pragma unroll
+    for (int l = 3; l >= 1; --l) {
+        float dpre[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float th = tanhf(pre[l][r]);
+            const float tf = q.tf[3 * l + r];
+            gp[EB_F0 + 3 * l + r] += dh[r] * th * (1.f - tf * tf);
+            dpre[r] = dh[r] * (1.f + tf * (1.f - th * th));
+            gp[EB_B0 + 3 * l + r] += dpre[r];
+        }
+        float nh[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = EB_M1 + (l - 1) * 9 + r * 3 + j;
+                gp[k] += dpre[r] * hin[l][j] * sigmoidf(raw[k]);
+                nh[j] += q.sp[k] * dpre[r];
+            }
+        dh[0] = nh[0]; dh[1] = nh[1]; dh[2] = nh[2];
+    }
+    float dv = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float th = tanhf(pre[0][r]);
+        const float tf = q.tf[r];
+        gp[EB_F0 + r] += dh[r] * th * (1.f - tf * tf);
+        const float dpre = dh[r] * (1.f + tf * (1.f - th * th));
+        gp[EB_B0 + r] += dpre;
+        gp[EB_M0 + r] += dpre * v * sigmoidf(raw[EB_M0 + r]);
+        dv += dpre * q.sp[EB_M0 + r];
+    }
+    return dv;
+}
+
+template <typename T>
+__global__ void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+                              const float* __restrict__ glik, const T* __restrict__ gzhat, T* __restrict__ dz,
+                              float* __restrict__ dparams, int64_t P, int C) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* raw = params + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    EBParams q;
+    eb_load(raw, q);
+    const float med = raw[EB_MED];
+    float gp[EB_NP + 1];
+#pragma unroll
+    for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t i = p * C + c;
+        const float zv = elem<T>::ld(z + i);
+        const float v = noise ? zv + elem<T>::ld(noise + i) : rintf(zv - med) + med;
+        const float lo = eb_logits(q, v - 0.5f, nullptr, nullptr), up = eb_logits(q, v + 0.5f, nullptr, nullptr);
+        const float s = -signf(lo + up);
+        const float A = sigmoidf(s * up), Bv = sigmoidf(s * lo), dlt = A - Bv;
+        float g = glik[i];
+        if (!(fabsf(dlt) >= 1e-9f || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
+        const float sg = signf(dlt) * g;
+        const float gU = sg * A * (1.f - A) * s, gL = -sg * Bv * (1.f - Bv) * s;
+        float dv = eb_logits_bwd(q, raw, v + 0.5f, gU, gp) + eb_logits_bwd(q, raw, v - 0.5f, gL, gp);
+        if (gzhat) dv += elem<T>::ld(gzhat + i);
+        if (noise) {
+            elem<T>::st(dz + i, dv);
+        } else {
+            elem<T>::st(dz + i, 0.f);     // round() has zero gradient; "+ median" passes it to the median
+            gp[EB_MED] += dv;
+        }
+    }
+    float* out = dparams + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+#pragma unroll
+    for (int i = 0; i <= EB_NP; ++i) atomicAdd(out + i, gp[i]);
+}
+
+// ------------------------------------------------------------------- Gaussian / Gaussian mixture
+__device__ __forceinline__ float phi_cdf(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
+__device__ __forceinline__ float phi_pdf(float x) { return 0.39894228040143267794f * expf(-0.5f * x * x); }
+
+constexpr int GMM_MAXK = 8;
+
+template <typename T>
+__global__ void gmm_fwd_kernel(const hesic_gmm_desc d, const T* __restrict__ y, const T* __restrict__ scales,
+                               const T* __restrict__ means, const float* __restrict__ weights, const T* __restrict__ noise,
+                               T* __restrict__ yhat, float* __restrict__ lik, int32_t* __restrict__ sym) {
+    const int64_t total = (int64_t)d.B * d.HW * d.M;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = i % d.M;
+        const int64_t p = i / d.M;
+        const int b = p / d.HW;
+        const float yv = elem<T>::ld(y + i);
+        const int64_t sm = p * d.sm_pix_stride + m;
+        float v;
+        if (noise) {
+            v = yv + elem<T>::ld(noise + i);
+        } else if (d.use_means_in_quant) {
+            const float mu = elem<T>::ld(means + sm + d.m_c_off);
+            const float r = rintf(yv - mu);
+            if (sym) sym[i] = (int32_t)r;
+            v = r + mu;
+        } else {
+            v = rintf(yv);
+            if (sym) sym[i] = (int32_t)v;
+        }
+        float acc = 0.f;
+        for (int k = 0; k < d.K; ++k) {
+            const float mu = elem<T>::ld(means + sm + d.m_c_off + k * d.M);
+            const float s = fmaxf(elem<T>::ld(scales + sm + d.s_c_off + k * d.M), d.scale_bound);
+            const float a = fabsf(v - mu);
+            const float pk = phi_cdf((0.5f - a) / s) - phi_cdf((-0.5f - a) / s);
+            acc += weights ? pk * weights[(int64_t)b * d.K * d.M + k * d.M + m] : pk;
+        }
+        elem<T>::st(yhat + i, v);
+        lik[i] = fmaxf(acc, d.lik_bound);
+    }
+}
+
+// block = 64 channels x 4 pixel lanes; grid = (M/64, pixel chunks, B): dweights reduced in-block first
+template <typename T>
+__global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, const T* __restrict__ y,
+                                                      const T* __restrict__ scales, const T* __restrict__ means,
+                                                      const float* __restrict__ weights, const T* __restrict__ noise,
+                                                      const float* __restrict__ glik, const T* __restrict__ gyhat,
+                                                      T* __restrict__ dy, T* __restrict__ dscales, T* __restrict__ dmeans,
+                                                      float* __restrict__ dweights, int pix_per_block) {
+    __shared__ float red[4][64][GMM_MAXK];
+    const int ml = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + ml;
+    const int b = blockIdx.z;
+    const int hw0 = blockIdx.y * pix_per_block;
+    float dw[GMM_MAXK];
+#pragma unroll
+    for (int k = 0; k < GMM_MAXK; ++k) dw[k] = 0.f;
+    if (m < d.M) {
+        for (int hw = hw0 + pl; hw < hw0 + pix_per_block && hw < d.HW; hw += 4) {
+            const int64_t p = (int64_t)b * d.HW + hw;
+            const int64_t i = p * d.M + m;
+            const int64_t sm = p * d.sm_pix_stride + m;
+            const float yv = elem<T>::ld(y + i);
+            float v;
+            if (noise) v = yv + elem<T>::ld(noise + i);
+            else if (d.use_means_in_quant) { const float mu = elem<T>::ld(means + sm + d.m_c_off); v = rintf(yv - mu) + mu; }
+            else v = rintf(yv);
+            float pk[GMM_MAXK], mu[GMM_MAXK], s[GMM_MAXK], sraw[GMM_MAXK], wk[GMM_MAXK];
+            float L = 0.f;
+            for (int k = 0; k < d.K; ++k) {
+                mu[k] = elem<T>::ld(means + sm + d.m_c_off + k * d.M);
+                sraw[k] = elem<T>::ld(scales + sm + d.s_c_off + k * d.M);
+                s[k] = fmaxf(sraw[k], d.scale_bound);
+                wk[k] = weights ? weights[(int64_t)b * d.K * d.M + k * d.M + m] : 1.f;
+                const float a = fabsf(v - mu[k]);
+                pk[k] = phi_cdf((0.5f - a) / s[k]) - phi_cdf((-0.5f - a) / s[k]);
+                L += wk[k] * pk[k];
+            }
+            float g = glik[i];
+            if (!(L >= d.lik_bound || g < 0.f)) g = 0.f;
+            float dv_sum = 0.f;
+            for (int k = 0; k < d.K; ++k) {
+                dw[k] += g * pk[k];
+                const float df = v - mu[k];
+                const float a = fabsf(df), sg = signf(df);
+                const float u = (0.5f - a) / s[k], l = (-0.5f - a) / s[k];
+                const float ak = g * wk[k] * phi_pdf(u), ck = -g * wk[k] * phi_pdf(l);
+                const float dvk = -(ak + ck) / s[k];                      // d/d|v-mu|
+                float dsk = -(ak * u + ck * l) / s[k];
+                if (!(sraw[k] >= d.scale_bound || dsk < 0.f)) dsk = 0.f;  // LowerBound on the scale
+                float dmu = -dvk * sg;
+                dv_sum += dvk * sg;
+                if (!noise && d.use_means_in_quant) dmu += dvk * sg;      // v = round(y-mu)+mu: dv/dmu = 1
+                elem<T>::st(dscales + sm + d.s_c_off + k * d.M, dsk);
+                elem<T>::st(dmeans + sm + d.m_c_off + k * d.M, dmu);
+            }
+            if (gyhat) {
+                const float gy = elem<T>::ld(gyhat + i);
+                dv_sum += gy;
+                if (!noise && d.use_means_in_quant) {
+                    // y_hat = round(y-mu)+mu also feeds mu directly (K == 1)
+                    elem<T>::st(dmeans + sm + d.m_c_off, elem<T>::ld(dmeans + sm + d.m_c_off) + gy);
+                }
+            }
+            elem<T>::st(dy + i, noise ? dv_sum : 0.f);
+        }
+    }
+    if (dweights) {
+#pragma unroll
+        for (int k = 0; k < GMM_MAXK; ++k) red[pl][ml][k] = dw[k];
+        __syncthreads();
+        if (pl == 0 && m < d.M)
+            for (int k = 0; k < d.K; ++k)
+                atomicAdd(dweights + (int64_t)b * d.K * d.M + k * d.M + m, red[0][ml][k] + red[1][ml][k] + red[2][ml][k] + red[3][ml][k]);
+    }
+}
+
+int check_gmm(const hesic_gmm_desc* d, const char* who) {
+    HESIC_CHECK_ARG(d && d->B > 0 && d->HW > 0 && d->M > 0 && d->K >= 1 && d->K <= GMM_MAXK, "%s: bad geometry (K <= %d)", who, GMM_MAXK);
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 || d->dtype == HESIC_F32, "%s: bad dtype", who);
+    HESIC_CHECK_ARG(!d->use_means_in_quant || d->K == 1, "%s: use_means_in_quant needs K == 1", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,
+                                int64_t P, int C, int dtype, void* stream) {
+    HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward: bad arguments");
+    const int bx = C >= 128 ? 128 : 64;
+    const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(eb_fwd_kernel<bf16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const bf16_t*)z, params,
+                           (const bf16_t*)noise, (bf16_t*)z_hat, lik, symbols, P, C);
+    else
+        hipLaunchKernelGGL(eb_fwd_kernel<float>, grid, dim3(bx), 0, (hipStream_t)stream, (const float*)z, params,
+                           (const float*)noise, (float*)z_hat, lik, symbols, P, C);
+    HESIC_LAUNCH_RETURN("eb_forward");
+}
+
+extern "C" int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
+                                 void* dz, float* dparams, int64_t P, int C, int dtype, void* stream) {
+    HESIC_CHECK_ARG(z && params && g_lik && dz && dparams && P > 0 && C > 0, "eb_backward: bad arguments");
+    const int bx = 64;
+    const dim3 grid((unsigned)(P < 256 ? P : 256), (C + bx - 1) / bx);
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const bf16_t*)z, params,
+                           (const bf16_t*)noise, g_lik, (const bf16_t*)g_zhat, (bf16_t*)dz, dparams, P, C);
+    else
+        hipLaunchKernelGGL(eb_bwd_kernel<float>, grid, dim3(bx), 0, (hipStream_t)stream, (const float*)z, params,
+                           (const float*)noise, g_lik, (const float*)g_zhat, (float*)dz, dparams, P, C);
+    HESIC_LAUNCH_RETURN("eb_backward");
+}
+
+extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
+                                 const float* weights, const void* noise, void* y_hat, float* lik, int32_t* symbols,
+                                 void* stream) {
+    if (int e = check_gmm(d, "gmm_forward")) return e;
+    HESIC_CHECK_ARG(y && scales && means && y_hat && lik, "gmm_forward: null pointer");
+    HESIC_CHECK_ARG(weights || d->K == 1, "gmm_forward: weights required for K > 1");
+    const int64_t total = (int64_t)d->B * d->HW * d->M;
+    const dim3 grid(grid_for(total, 256));
+    if (d->dtype == HESIC_BF16)
+        hipLaunchKernelGGL(gmm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
+                           (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols);
+    else
+        hipLaunchKernelGGL(gmm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
+                           (const float*)scales, (const float*)means, weights, (const float*)noise, (float*)y_hat, lik, symbols);
+    HESIC_LAUNCH_RETURN("gmm_forward");
+}
+
+extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
+                                  const float* weights, const void* noise, const float* g_lik, const void* g_yhat, void* dy,
+                                  void* dscales, void* dmeans, float* dweights, void* stream) {
+    if (int e = check_gmm(d, "gmm_backward")) return e;
+    HESIC_CHECK_ARG(y && scales && means && g_lik && dy && dscales && dmeans, "gmm_backward: null pointer");
+    HESIC_CHECK_ARG((weights && dweights) || d->K == 1, "gmm_backward: weights/dweights required for K > 1");
+    const int ppb = 64;
+    const dim3 grid((d->M + 63) / 64, (d->HW + ppb - 1) / ppb, d->B);
+    if (d->dtype == HESIC_BF16)
+        hipLaunchKernelGGL(gmm_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
+                           (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
+                           (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
+    else
+        hipLaunchKernelGGL(gmm_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
+                           (const float*)scales, (const float*)means, weights, (const float*)noise, g_lik,
+                           (const float*)g_yhat, (float*)dy, (float*)dscales, (float*)dmeans, dweights, ppb);
+    HESIC_LAUNCH_RETURN("gmm_backward");
+}

@@ -1,0 +1,303 @@
+// Glue of the hyper-synthesis heads and the loss reductions:
+// bilinear x4 upsample fused with the concat write, channel-slice copy, global spatial max + LeakyReLU,
+// the 1x1 conv + softmax-over-K mixture-weight head, sum(log2 likelihood), sum of squared differences,
+// activation backward and dtype cast.  All are single-pass, HBM-bound kernels.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+void hesic_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* hesic_last_error(void) { return g_err; }
+extern "C" int hesic_abi_version(void) { return HESIC_ABI_VERSION; }
+
+namespace {
+
+// nn.UpsamplingBilinear2d(scale_factor=4): align_corners=True, src = dst*(in-1)/(out-1) (newnet1.py:524)
+template <typename T>
+__global__ void upsample4_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int yps, int yco) {
+    const int Ho = 4 * H, Wo = 4 * W;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        int64_t r = i / C;
+        const int ox = r % Wo; r /= Wo;
+        const int oy = r % Ho;
+        const int b = r / Ho;
+        const float sy = ry * oy, sx = rx * ox;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = sy - y0, lx = sx - x0;
+        const T* xb = x + (int64_t)b * H * W * C + c;
+        const float v00 = elem<T>::ld(xb + ((int64_t)y0 * W + x0) * C), v01 = elem<T>::ld(xb + ((int64_t)y0 * W + x1) * C);
+        const float v10 = elem<T>::ld(xb + ((int64_t)y1 * W + x0) * C), v11 = elem<T>::ld(xb + ((int64_t)y1 * W + x1) * C);
+        const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        elem<T>::st(y + (((int64_t)b * Ho + oy) * Wo + ox) * yps + yco + c, v);
+    }
+}
+
+// gather form of the transpose: each input cell sums the <= 8x8 outputs that reference it (no atomics)
+template <typename T>
+__global__ void upsample4_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int yps, int yco) {
+    const int Ho = 4 * H, Wo = 4 * W;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        int64_t r = i / C;
+        const int ix = r % W; r /= W;
+        const int iy = r % H;
+        const int b = r / H;
+        float acc = 0.f;
+        // outputs whose y0 or y1 equals iy lie within +-5 output rows of 4*iy
+        for (int oy = max(0, 4 * iy - 5); oy <= min(Ho - 1, 4 * iy + 5); ++oy) {
+            const float sy = ry * oy;
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float ly = sy - y0;
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = max(0, 4 * ix - 5); ox <= min(Wo - 1, 4 * ix + 5); ++ox) {
+                const float sx = rx * ox;
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx = sx - x0;
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x1 == ix) wx += lx;
+                if (wx == 0.f) continue;
+                acc += wy * wx * elem<T>::ld(dy + (((int64_t)b * Ho + oy) * Wo + ox) * yps + yco + c);
+            }
+        }
+        elem<T>::st(dx + i, acc);
+    }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t P, int C, int xps, int xco, int yps, int yco) {
+    const int64_t total = P * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const int64_t p = i / C;
+        y[p * yps + yco + c] = x[p * xps + xco + c];
+    }
+}
+
+// spatial_pool2d (+ LeakyReLU): block = 64 channels x 4 pixel lanes, grid = (C/64, B)
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_max_kernel(const T* __restrict__ x, float* __restrict__ out, int32_t* __restrict__ arg,
+                                                          int HW, int C, int leaky) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float best = -INFINITY;
+    int bi = 0;
+    if (c < C)
+        for (int p = pl; p < HW; p += 4) {
+            const float v = elem<T>::ld(x + ((int64_t)b * HW + p) * C + c);
+            if (v > best) { best = v; bi = p; }
+        }
+    sv[pl][cl] = best; si[pl][cl] = bi;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 4; ++k)
+            if (sv[k][cl] > best || (sv[k][cl] == best && si[k][cl] < bi)) { best = sv[k][cl]; bi = si[k][cl]; }
+        out[(int64_t)b * C + c] = leaky ? (best > 0.f ? best : 0.01f * best) : best;
+        if (arg) arg[(int64_t)b * C + c] = bi;
+    }
+}
+
+// logits[b,n] = sum_j w[n,j] * pooled[b,j] + bias[n]: one wave per output
+__global__ __launch_bounds__(256) void mix_logits_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ logits, int B, int N) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * N) return;
+    const int n = wave % N, b = wave / N;
+    float acc = 0.f;
+    for (int j = lane; j < N; j += 64) acc += w[(int64_t)n * N + j] * pooled[(int64_t)b * N + j];
+    acc = wave_sum(acc);
+    if (lane == 0) logits[(int64_t)b * N + n] = acc + (bias ? bias[n] : 0.f);
+}
+
+__global__ void softmax_k_kernel(const float* __restrict__ logits, float* __restrict__ weights, int B, int K, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * M) return;
+    const int m = i % M, b = i / M;
+    const float* l = logits + (int64_t)b * K * M + m;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, l[k * M]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(l[k * M] - mx);
+    for (int k = 0; k < K; ++k) weights[(int64_t)b * K * M + k * M + m] = expf(l[k * M] - mx) / s;
+}
+
+__global__ void softmax_k_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ dl, int B, int K, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * M) return;
+    const int m = i % M, b = i / M;
+    const int64_t o = (int64_t)b * K * M + m;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += g[o + k * M] * w[o + k * M];
+    for (int k = 0; k < K; ++k) dl[o + k * M] = w[o + k * M] * (g[o + k * M] - dot);
+}
+
+__global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__ lik, int64_t n, double* __restrict__ out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)log2f(lik[i]);
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct SqArgs {
+    const void* a; const void* b; int a_dt, b_dt; int64_t as[4], bs[4]; int B, C, H, W; double* out;
+};
+__global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
+    __shared__ double red[4];
+    const int64_t n = (int64_t)q.B * q.C * q.H * q.W;
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int x = r % q.W; r /= q.W;
+        const int y = r % q.H; r /= q.H;
+        const int c = r % q.C;
+        const int b = r / q.C;
+        const float va = ld_any(q.a, b * q.as[0] + c * q.as[1] + y * q.as[2] + x * q.as[3], q.a_dt);
+        const float vb = ld_any(q.b, b * q.bs[0] + c * q.bs[1] + y * q.bs[2] + x * q.bs[3], q.b_dt);
+        const float df = va - vb;
+        acc += (double)(df * df);
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(q.out, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float yv = elem<T>::ld(y + i), g = elem<T>::ld(dy + i);
+        float o = g;
+        if (act == HESIC_ACT_RELU) o = yv > 0.f ? g : 0.f;
+        else if (act == HESIC_ACT_LEAKY) o = yv > 0.f ? g : 0.01f * g;
+        elem<T>::st(dx + i, o);
+    }
+}
+
+__global__ void cast_kernel(const void* __restrict__ x, int xd, void* __restrict__ y, int yd, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st_any(y, i, yd, ld_any(x, i, xd));
+}
+
+}  // namespace
+
+extern "C" int hesic_upsample4_forward(const void* x, void* y, int B, int H, int W, int C, int yps, int yco, int dtype, void* stream) {
+    HESIC_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && yco + C <= yps, "upsample4_forward: bad arguments");
+    const int64_t total = (int64_t)B * 16 * H * W * C;
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(upsample4_fwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C, yps, yco);
+    else
+        hipLaunchKernelGGL(upsample4_fwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, B, H, W, C, yps, yco);
+    HESIC_LAUNCH_RETURN("upsample4_forward");
+}
+
+extern "C" int hesic_upsample4_backward(const void* dy, void* dx, int B, int H, int W, int C, int yps, int yco, int dtype, void* stream) {
+    HESIC_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && yco + C <= yps, "upsample4_backward: bad arguments");
+    const int64_t total = (int64_t)B * H * W * C;
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(upsample4_bwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, yps, yco);
+    else
+        hipLaunchKernelGGL(upsample4_bwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dy, (float*)dx, B, H, W, C, yps, yco);
+    HESIC_LAUNCH_RETURN("upsample4_backward");
+}
+
+extern "C" int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int xps, int xco, int yps, int yco, int dtype, void* stream) {
+    HESIC_CHECK_ARG(x && y && P > 0 && C > 0 && xco + C <= xps && yco + C <= yps, "copy_channels: bad arguments");
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(P * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, P, C, xps, xco, yps, yco);
+    else
+        hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(P * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, P, C, xps, xco, yps, yco);
+    HESIC_LAUNCH_RETURN("copy_channels");
+}
+
+extern "C" int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW, int C, int dtype, int leaky, void* stream) {
+    HESIC_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "spatial_max: bad arguments");
+    const dim3 grid((C + 63) / 64, B);
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(spatial_max_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, argmax, HW, C, leaky);
+    else
+        hipLaunchKernelGGL(spatial_max_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, argmax, HW, C, leaky);
+    HESIC_LAUNCH_RETURN("spatial_max");
+}
+
+extern "C" int hesic_mix_weights_forward(const float* pooled, const float* w, const float* bias, float* logits, float* weights,
+                                         int B, int K, int M, void* stream) {
+    HESIC_CHECK_ARG(pooled && w && logits && weights && B > 0 && K > 0 && M > 0, "mix_weights_forward: bad arguments");
+    const int N = K * M;
+    const int64_t waves = (int64_t)B * N;
+    hipLaunchKernelGGL(mix_logits_kernel, dim3((unsigned)cdiv64(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, pooled, w, bias, logits, B, N);
+    hipLaunchKernelGGL(softmax_k_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, weights, B, K, M);
+    HESIC_LAUNCH_RETURN("mix_weights_forward");
+}
+
+extern "C" int hesic_softmax_k_forward(const float* logits, float* weights, int B, int K, int M, void* stream) {
+    HESIC_CHECK_ARG(logits && weights && B > 0 && K > 0 && M > 0, "softmax_k_forward: bad arguments");
+    hipLaunchKernelGGL(softmax_k_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, weights, B, K, M);
+    HESIC_LAUNCH_RETURN("softmax_k_forward");
+}
+
+extern "C" int hesic_softmax_k_backward(const float* weights, const float* g, float* dlogits, int B, int K, int M, void* stream) {
+    HESIC_CHECK_ARG(weights && g && dlogits && B > 0 && K > 0 && M > 0, "softmax_k_backward: bad arguments");
+    hipLaunchKernelGGL(softmax_k_bwd_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights, g, dlogits, B, K, M);
+    HESIC_LAUNCH_RETURN("softmax_k_backward");
+}
+
+extern "C" int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream) {
+    HESIC_CHECK_ARG(lik && out && n > 0, "sum_log2: bad arguments");
+    hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
+    HESIC_LAUNCH_RETURN("sum_log2");
+}
+
+extern "C" int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
+                                 const int64_t b_strides[4], int B, int C, int H, int W, double* out, void* stream) {
+    HESIC_CHECK_ARG(a && b && out && a_strides && b_strides && B > 0 && C > 0 && H > 0 && W > 0, "sum_sq_diff: bad arguments");
+    SqArgs q;
+    q.a = a; q.b = b; q.a_dt = a_dtype; q.b_dt = b_dtype; q.B = B; q.C = C; q.H = H; q.W = W; q.out = out;
+    for (int i = 0; i < 4; ++i) { q.as[i] = a_strides[i]; q.bs[i] = b_strides[i]; }
+    hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * C * H * W, 256, 512)), dim3(256), 0, (hipStream_t)stream, q);
+    HESIC_LAUNCH_RETURN("sum_sq_diff");
+}
+
+extern "C" int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream) {
+    HESIC_CHECK_ARG(y && dy && dx && n > 0, "act_backward: bad arguments");
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           (const bf16_t*)dy, (bf16_t*)dx, n, act);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                           (const float*)dy, (float*)dx, n, act);
+    HESIC_LAUNCH_RETURN("act_backward");
+}
+
+extern "C" int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream) {
+    HESIC_CHECK_ARG(x && y && n > 0, "cast: bad arguments");
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n);
+    HESIC_LAUNCH_RETURN("cast");
+}

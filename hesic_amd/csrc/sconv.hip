@@ -1,0 +1,306 @@
+// Convolutions whose image side has only a few channels (3 or 6): g_a_conv1 (3->N, newnet1.py:583),
+// pre_conv (6->3, :629), g_s_conv4 (N->3 transposed, :612), after_conv (6->3 transposed s1, :670).
+// They are HBM / VALU bound (SURVEY.md 7 "hard parts"), so they run on the vector ALU with the
+// weights broadcast from LDS; the image side is addressed through explicit element strides so NCHW
+// planar fp32 images are consumed / produced without a layout copy.
+//
+//   narrow_to_wide : Conv2d,           Cin <= 8, Cout % 32 == 0, y channels contiguous (NHWC)
+//   wide_to_narrow : ConvTranspose2d,  5x5 s2,   Cout <= 4, Cin % 8 == 0, x channels contiguous (NHWC)
+//   generic        : anything else (also the fallback used by the odd-shape parity tests)
+#include "common.h"
+
+namespace {
+
+struct SArgs {
+    const void* x; const float* w; const float* bias; void* y;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed, x_dtype, y_dtype, act;
+    int64_t xs_b, xs_c, xs_y, xs_x, ys_b, ys_c, ys_y, ys_x;
+};
+
+// weight element for (co, ci, ky, kx) in either PyTorch layout
+__device__ __forceinline__ float w_at(const float* w, int co, int ci, int ky, int kx, int Cout, int Cin, int KH, int KW,
+                                      int transposed) {
+    return transposed ? w[(((int64_t)ci * Cout + co) * KH + ky) * KW + kx] : w[(((int64_t)co * Cin + ci) * KH + ky) * KW + kx];
+}
+
+// ---------------------------------------------------------------- generic: one thread = one pixel x 4 couts
+__global__ void sconv_generic_kernel(const SArgs a) {
+    const int cog = (a.Cout + 3) / 4;
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * cog;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int ox = r % a.Wo; r /= a.Wo;
+        const int oy = r % a.Ho; r /= a.Ho;
+        const int g = r % cog;
+        const int b = r / cog;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < a.KH; ++ky) {
+            int iy;
+            if (!a.transposed) {
+                iy = oy * a.stride - a.pad + ky;
+            } else {
+                const int t = oy + a.pad - ky;
+                if (t % a.stride) continue;
+                iy = t / a.stride;
+            }
+            if (iy < 0 || iy >= a.H) continue;
+            for (int kx = 0; kx < a.KW; ++kx) {
+                int ix;
+                if (!a.transposed) {
+                    ix = ox * a.stride - a.pad + kx;
+                } else {
+                    const int t = ox + a.pad - kx;
+                    if (t % a.stride) continue;
+                    ix = t / a.stride;
+                }
+                if (ix < 0 || ix >= a.W) continue;
+                const int64_t xb = b * a.xs_b + iy * a.xs_y + ix * a.xs_x;
+                for (int ci = 0; ci < a.Cin; ++ci) {
+                    const float xv = ld_any(a.x, xb + ci * a.xs_c, a.x_dtype);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = g * 4 + e;
+                        if (co < a.Cout) acc[e] += xv * w_at(a.w, co, ci, ky, kx, a.Cout, a.Cin, a.KH, a.KW, a.transposed);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = g * 4 + e;
+            if (co < a.Cout) {
+                const float v = apply_act(acc[e] + (a.bias ? a.bias[co] : 0.f), a.act);
+                st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- narrow -> wide (conv1 class)
+// block: 64 output pixels (8x8) x Cout; thread = pixel (tid%64) x 32-cout group (tid/64 + 4*pass).
+// weights live in LDS as [tap*Cin+ci][Cout] fp32: a wave shares its cout group -> broadcast reads.
+constexpr int NW_MAXK = 8 * 25;
+__global__ __launch_bounds__(256) void sconv_narrow_to_wide_kernel(const SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [KK][Cout]
+    const int KK = a.KH * a.KW * a.Cin;
+    for (int i = threadIdx.x; i < KK * a.Cout; i += 256) {
+        const int co = i % a.Cout, k = i / a.Cout;
+        const int ci = k % a.Cin, tap = k / a.Cin;
+        wl[i] = w_at(a.w, co, ci, tap / a.KW, tap % a.KW, a.Cout, a.Cin, a.KH, a.KW, a.transposed);
+    }
+    __syncthreads();
+    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int p = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int oy = ty * 8 + (p >> 3), ox = tx * 8 + (p & 7);
+    const bool ok = oy < a.Ho && ox < a.Wo;
+    // gather the receptive field once (<= 200 values would not fit registers: keep per-row reuse instead)
+    for (int cg = grp; cg * 32 < a.Cout; cg += 4) {
+        float acc[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+        if (ok) {
+            for (int ky = 0; ky < a.KH; ++ky) {
+                const int iy = oy * a.stride - a.pad + ky;
+                if (iy < 0 || iy >= a.H) continue;
+                for (int kx = 0; kx < a.KW; ++kx) {
+                    const int ix = ox * a.stride - a.pad + kx;
+                    if (ix < 0 || ix >= a.W) continue;
+                    const int64_t xb = b * a.xs_b + iy * a.xs_y + ix * a.xs_x;
+                    for (int ci = 0; ci < a.Cin; ++ci) {
+                        const float xv = ld_any(a.x, xb + ci * a.xs_c, a.x_dtype);
+                        const float* wr = wl + ((ky * a.KW + kx) * a.Cin + ci) * a.Cout + cg * 32;
+#pragma unroll
+                        for (int e = 0; e < 32; e += 4) {
+                            const f32x4 wv = *(const f32x4*)(wr + e);
+                            acc[e] += xv * wv.x; acc[e + 1] += xv * wv.y; acc[e + 2] += xv * wv.z; acc[e + 3] += xv * wv.w;
+                        }
+                    }
+                }
+            }
+            const int64_t yb = b * a.ys_b + oy * a.ys_y + ox * a.ys_x + cg * 32;   // ys_c == 1
+            if (a.y_dtype == HESIC_BF16) {
+                bf16_t* yp = (bf16_t*)a.y + yb;
+#pragma unroll
+                for (int e = 0; e < 32; e += 8) {
+                    u32x4 o;
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = apply_act(acc[e + k] + (a.bias ? a.bias[cg * 32 + e + k] : 0.f), a.act);
+                    o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+                    *(u32x4*)(yp + e) = o;
+                }
+            } else {
+                float* yp = (float*)a.y + yb;
+#pragma unroll
+                for (int e = 0; e < 32; e += 4) {
+                    f32x4 o;
+                    o.x = apply_act(acc[e] + (a.bias ? a.bias[cg * 32 + e] : 0.f), a.act);
+                    o.y = apply_act(acc[e + 1] + (a.bias ? a.bias[cg * 32 + e + 1] : 0.f), a.act);
+                    o.z = apply_act(acc[e + 2] + (a.bias ? a.bias[cg * 32 + e + 2] : 0.f), a.act);
+                    o.w = apply_act(acc[e + 3] + (a.bias ? a.bias[cg * 32 + e + 3] : 0.f), a.act);
+                    *(f32x4*)(yp + e) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- wide -> narrow (g_s_conv4 class)
+// ConvTranspose2d 5x5 s2 p2 op1, Cout <= 4.  thread = one input-grid cell q -> its 2x2 output quad.
+// out(2q+r) gets x[q + d] * w[k] with k = r + 2 - 2d, d in {-1,0,1} (k in range).  Weights in LDS as
+// [tap][ci][4] fp32 (zero padded couts), read as one broadcast float4 per (tap, ci).
+template <typename T>
+__global__ __launch_bounds__(256) void sconv_wide_to_narrow_kernel(const SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [25][Cin][4]
+    for (int i = threadIdx.x; i < 25 * a.Cin * 4; i += 256) {
+        const int co = i & 3, ci = (i >> 2) % a.Cin, tap = (i >> 2) / a.Cin;
+        wl[i] = co < a.Cout ? w_at(a.w, co, ci, tap / 5, tap % 5, a.Cout, a.Cin, 5, 5, 1) : 0.f;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)a.B * a.H * a.W;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int qx = i % a.W, qy = (i / a.W) % a.H, b = i / ((int64_t)a.W * a.H);
+    float acc[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][s][c] = 0.f;
+    const T* xg = (const T*)a.x;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = qy + dy;
+        if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = qx + dx;
+            if (ix < 0 || ix >= a.W) continue;
+            const T* xp = xg + b * a.xs_b + iy * a.xs_y + ix * a.xs_x;   // xs_c == 1
+            for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+                float xv[8];
+                if constexpr (sizeof(T) == 2) {
+                    const u32x4 raw = *(const u32x4*)(xp + c0);
+                    xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
+                    xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
+                    xv[4] = __uint_as_float(raw.z << 16); xv[5] = __uint_as_float(raw.z & 0xffff0000u);
+                    xv[6] = __uint_as_float(raw.w << 16); xv[7] = __uint_as_float(raw.w & 0xffff0000u);
+                } else {
+                    const f32x4 r0 = *(const f32x4*)(xp + c0), r1 = *(const f32x4*)(xp + c0 + 4);
+                    xv[0] = r0.x; xv[1] = r0.y; xv[2] = r0.z; xv[3] = r0.w; xv[4] = r1.x; xv[5] = r1.y; xv[6] = r1.z; xv[7] = r1.w;
+                }
+#pragma unroll
+                for (int ry = 0; ry < 2; ++ry) {
+                    const int ky = ry + 2 - 2 * dy;
+                    if (ky < 0 || ky > 4) continue;
+#pragma unroll
+                    for (int rx = 0; rx < 2; ++rx) {
+                        const int kx = rx + 2 - 2 * dx;
+                        if (kx < 0 || kx > 4) continue;
+                        const float* wr = wl + ((ky * 5 + kx) * a.Cin + c0) * 4;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const f32x4 wv = *(const f32x4*)(wr + e * 4);
+                            acc[ry][rx][0] += xv[e] * wv.x; acc[ry][rx][1] += xv[e] * wv.y;
+                            acc[ry][rx][2] += xv[e] * wv.z; acc[ry][rx][3] += xv[e] * wv.w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+        for (int rx = 0; rx < 2; ++rx)
+            for (int co = 0; co < a.Cout; ++co) {
+                const float v = apply_act(acc[ry][rx][co] + (a.bias ? a.bias[co] : 0.f), a.act);
+                st_any(a.y, b * a.ys_b + co * a.ys_c + (2 * qy + ry) * a.ys_y + (2 * qx + rx) * a.ys_x, a.y_dtype, v);
+            }
+}
+
+int launch_forward(const SArgs& a, hipStream_t st) {
+    if (!a.transposed && a.Cin <= 8 && a.Cout % 32 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 &&
+        (a.ys_b % 8) == 0 && a.KH * a.KW * a.Cin * a.Cout * 4 <= 60 * 1024) {
+        const int tiles = ((a.Wo + 7) / 8) * ((a.Ho + 7) / 8) * a.B;
+        const size_t lds = (size_t)a.KH * a.KW * a.Cin * a.Cout * 4;
+        hipLaunchKernelGGL(sconv_narrow_to_wide_kernel, dim3(tiles), dim3(256), lds, st, a);
+    } else if (a.transposed && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Cout <= 4 && a.Cin % 8 == 0 &&
+               a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Cin <= 128) {
+        const int64_t total = (int64_t)a.B * a.H * a.W;
+        const size_t lds = (size_t)25 * a.Cin * 16;
+        if (a.x_dtype == HESIC_BF16)
+            hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+    } else {
+        const int64_t total = (int64_t)a.B * a.Ho * a.Wo * ((a.Cout + 3) / 4);
+        hipLaunchKernelGGL(sconv_generic_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, a);
+    }
+    return 0;
+}
+
+int check_desc(const hesic_sconv_desc* d, const char* who) {
+    HESIC_CHECK_ARG(d, "%s: null descriptor", who);
+    HESIC_CHECK_ARG(d->stride >= 1 && d->KH > 0 && d->KW > 0 && d->B > 0, "%s: bad geometry", who);
+    if (!d->transposed)
+        HESIC_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                        "%s: conv output size mismatch", who);
+    else
+        HESIC_CHECK_ARG(d->Ho == (d->H - 1) * d->stride - 2 * d->pad + d->KH + d->stride - 1 &&
+                            d->Wo == (d->W - 1) * d->stride - 2 * d->pad + d->KW + d->stride - 1,
+                        "%s: transposed output size mismatch", who);
+    return 0;
+}
+
+SArgs make_args(const hesic_sconv_desc* d) {
+    SArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
+    a.x_dtype = d->x_dtype; a.y_dtype = d->y_dtype; a.act = d->act;
+    a.xs_b = d->xs_b; a.xs_c = d->xs_c; a.xs_y = d->xs_y; a.xs_x = d->xs_x;
+    a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
+                                     void* stream) {
+    if (int e = check_desc(d, "sconv2d_forward")) return e;
+    HESIC_CHECK_ARG(x && w && y, "sconv2d_forward: null pointer");
+    SArgs a = make_args(d);
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    launch_forward(a, (hipStream_t)stream);
+    HESIC_LAUNCH_RETURN("sconv2d_forward");
+}
+
+// dx of y = op(x): the opposite op (conv <-> transposed conv) applied to dy with the same weight tensor:
+// a Conv2d weight (Cout,Cin,k,k) read as a ConvTranspose2d weight maps Cout -> Cin, and vice versa.
+extern "C" int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream) {
+    if (int e = check_desc(d, "sconv2d_dgrad")) return e;
+    HESIC_CHECK_ARG(dy && w && dx, "sconv2d_dgrad: null pointer");
+    SArgs a = make_args(d);
+    a.transposed = !d->transposed;
+    a.Cin = d->Cout; a.Cout = d->Cin; a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W;
+    a.x_dtype = d->y_dtype; a.y_dtype = d->x_dtype; a.act = HESIC_ACT_NONE;
+    a.xs_b = d->ys_b; a.xs_c = d->ys_c; a.xs_y = d->ys_y; a.xs_x = d->ys_x;
+    a.ys_b = d->xs_b; a.ys_c = d->xs_c; a.ys_y = d->xs_y; a.ys_x = d->xs_x;
+    a.x = dy; a.w = w; a.bias = nullptr; a.y = dx;
+    // when the forward op is a stride-s conv whose input size is not "Ho*s", the transposed op's natural
+    // output is smaller than H: the generic kernel handles any (H, Ho) pair by pure index arithmetic.
+    const bool natural = a.transposed ? (a.Ho == (a.H - 1) * a.stride - 2 * a.pad + a.KH + a.stride - 1 &&
+                                         a.Wo == (a.W - 1) * a.stride - 2 * a.pad + a.KW + a.stride - 1)
+                                      : true;
+    if (natural) {
+        launch_forward(a, (hipStream_t)stream);
+    } else {
+        const int64_t total = (int64_t)a.B * a.Ho * a.Wo * ((a.Cout + 3) / 4);
+        hipLaunchKernelGGL(sconv_generic_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    HESIC_LAUNCH_RETURN("sconv2d_dgrad");
+}

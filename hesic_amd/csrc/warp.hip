@@ -1,0 +1,113 @@
+// warp_perspective: projective bilinear resample with zero padding, the build's replacement for
+// kornia.warp_perspective(src, M, dsize) (third party; call sites ywz/mywork/newnet1.py:746,753,767).
+//
+// One thread per destination pixel: invert M (3x3, fp64 -- it is 40 flops), map (x',y') back to the
+// source, gather the 4 neighbours of every channel.  Neighbouring lanes hit neighbouring source pixels,
+// so the gather is wavefront-coalesced; the kernel moves 2*C*H*W elements and is HBM / latency bound.
+#include "common.h"
+
+namespace {
+
+struct WArgs {
+    hesic_warp_desc d;
+    const void* src; const float* M; void* dst; float* dsrc;
+};
+
+__device__ __forceinline__ bool src_coords(const hesic_warp_desc& d, const float* M, int b, int ox, int oy, float& sx, float& sy) {
+    const float* m = M + b * 9;
+    const double a = m[0], bb = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double A = e * i - f * h, B = -(dd * i - f * g), Cc = dd * h - e * g;
+    const double det = a * A + bb * B + c * Cc;
+    const double inv = 1.0 / det;
+    // adjugate / det
+    const double i00 = A * inv, i01 = -(bb * i - c * h) * inv, i02 = (bb * f - c * e) * inv;
+    const double i10 = B * inv, i11 = (a * i - c * g) * inv, i12 = -(a * f - c * dd) * inv;
+    const double i20 = Cc * inv, i21 = -(a * h - bb * g) * inv, i22 = (a * e - bb * dd) * inv;
+    const double X = i00 * ox + i01 * oy + i02, Y = i10 * ox + i11 * oy + i12, Z = i20 * ox + i21 * oy + i22;
+    double x = X / Z, y = Y / Z;
+    if (!d.align_corners) {   // kornia <= 0.4: normalised with (W-1), sampled with align_corners=False
+        x = x * d.W / (double)(d.W - 1) - 0.5;
+        y = y * d.H / (double)(d.H - 1) - 0.5;
+    }
+    sx = (float)x; sy = (float)y;
+    return isfinite(sx) && isfinite(sy);
+}
+
+__global__ void warp_fwd_kernel(const WArgs a) {
+    const hesic_warp_desc& d = a.d;
+    const int64_t total = (int64_t)d.B * d.Ho * d.Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = i % d.Wo, oy = (i / d.Wo) % d.Ho, b = i / ((int64_t)d.Wo * d.Ho);
+        float sx, sy;
+        const bool fin = src_coords(d, a.M, b, ox, oy, sx, sy);
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
+        const int x0 = big ? -10 : (int)fx0, y0 = big ? -10 : (int)fy0;
+        const bool vx0 = x0 >= 0 && x0 < d.W, vx1 = x0 + 1 >= 0 && x0 + 1 < d.W;
+        const bool vy0 = y0 >= 0 && y0 < d.H, vy1 = y0 + 1 >= 0 && y0 + 1 < d.H;
+        const int64_t sb = b * d.ss_b + y0 * d.ss_y + x0 * d.ss_x;
+        const int64_t db = b * d.ds_b + oy * d.ds_y + ox * d.ds_x;
+        for (int c = 0; c < d.C; ++c) {
+            const int64_t s = sb + c * d.ss_c;
+            float v = 0.f;
+            if (vy0 && vx0) v += ld_any(a.src, s, d.src_dtype) * (wx0 * wy0);
+            if (vy0 && vx1) v += ld_any(a.src, s + d.ss_x, d.src_dtype) * (wx1 * wy0);
+            if (vy1 && vx0) v += ld_any(a.src, s + d.ss_y, d.src_dtype) * (wx0 * wy1);
+            if (vy1 && vx1) v += ld_any(a.src, s + d.ss_y + d.ss_x, d.src_dtype) * (wx1 * wy1);
+            st_any(a.dst, db + c * d.ds_c, d.dst_dtype, v);
+        }
+    }
+}
+
+// transpose of the gather: scatter-add of the same four weights into d_src (fp32)
+__global__ void warp_bwd_kernel(const WArgs a) {
+    const hesic_warp_desc& d = a.d;
+    const int64_t total = (int64_t)d.B * d.Ho * d.Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = i % d.Wo, oy = (i / d.Wo) % d.Ho, b = i / ((int64_t)d.Wo * d.Ho);
+        float sx, sy;
+        const bool fin = src_coords(d, a.M, b, ox, oy, sx, sy);
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
+        const int x0 = big ? -10 : (int)fx0, y0 = big ? -10 : (int)fy0;
+        const bool vx0 = x0 >= 0 && x0 < d.W, vx1 = x0 + 1 >= 0 && x0 + 1 < d.W;
+        const bool vy0 = y0 >= 0 && y0 < d.H, vy1 = y0 + 1 >= 0 && y0 + 1 < d.H;
+        const int64_t sb = b * d.ss_b + y0 * d.ss_y + x0 * d.ss_x;
+        const int64_t db = b * d.ds_b + oy * d.ds_y + ox * d.ds_x;
+        for (int c = 0; c < d.C; ++c) {
+            const float g = ld_any(a.dst, db + c * d.ds_c, d.dst_dtype);
+            const int64_t s = sb + c * d.ss_c;
+            if (vy0 && vx0) atomicAdd(a.dsrc + s, g * (wx0 * wy0));
+            if (vy0 && vx1) atomicAdd(a.dsrc + s + d.ss_x, g * (wx1 * wy0));
+            if (vy1 && vx0) atomicAdd(a.dsrc + s + d.ss_y, g * (wx0 * wy1));
+            if (vy1 && vx1) atomicAdd(a.dsrc + s + d.ss_y + d.ss_x, g * (wx1 * wy1));
+        }
+    }
+}
+
+int check(const hesic_warp_desc* d, const char* who) {
+    HESIC_CHECK_ARG(d && d->B > 0 && d->C > 0 && d->H > 1 && d->W > 1 && d->Ho > 0 && d->Wo > 0, "%s: bad geometry", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hesic_warp_perspective_forward(const hesic_warp_desc* d, const void* src, const float* M, void* dst,
+                                              void* stream) {
+    if (int e = check(d, "warp_perspective_forward")) return e;
+    HESIC_CHECK_ARG(src && M && dst, "warp_perspective_forward: null pointer");
+    WArgs a; a.d = *d; a.src = src; a.M = M; a.dst = dst; a.dsrc = nullptr;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)d->B * d->Ho * d->Wo, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("warp_perspective_forward");
+}
+
+extern "C" int hesic_warp_perspective_backward(const hesic_warp_desc* d, const void* d_dst, const float* M, float* d_src,
+                                               void* stream) {
+    if (int e = check(d, "warp_perspective_backward")) return e;
+    HESIC_CHECK_ARG(d_dst && M && d_src, "warp_perspective_backward: null pointer");
+    WArgs a; a.d = *d; a.src = nullptr; a.M = M; a.dst = (void*)d_dst; a.dsrc = d_src;
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(grid_for((int64_t)d->B * d->Ho * d->Wo, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("warp_perspective_backward");
+}

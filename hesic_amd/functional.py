@@ -1,0 +1,558 @@
+"""Host-side operators over the C ABI (``include/hesic_hip.h``) as ``torch.autograd.Function``s.
+
+Tensors keep the reference's logical NCHW shape; wide feature maps are stored ``channels_last``
+(= NHWC in memory, what the kernels want), 3-channel images keep whatever strides they have.
+PyTorch is used for device memory, streams and autograd bookkeeping only -- every number on the
+path is produced by a HIP kernel of ``libhesic_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_CL = torch.channels_last
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """Storage type of the wide feature maps: torch.float32 (exact-fp32 MFMA, parity mode) or
+    torch.bfloat16 (bf16 MFMA, fp32 accumulate)."""
+    global _compute_dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dtype
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+def _nhwc(x):
+    return x if x.is_contiguous(memory_format=_CL) else x.contiguous(memory_format=_CL)
+
+
+def _empty_nhwc(b, c, h, w, dtype, device):
+    return torch.empty((b, c, h, w), dtype=dtype, device=device, memory_format=_CL)
+
+
+def _is_narrow(c):
+    return c <= 8
+
+
+# ------------------------------------------------------------------------------ packing cache
+class PackedWeight:
+    """Device copy of a conv weight in the kernels' [tap][Cout][Cin] layout, refreshed when the
+    parameter's version counter moves (optimizer steps are in-place)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, weight, mask, cout, cin, kh, kw, transposed, flip, dtype):
+        key = (transposed, flip, dtype, cout, cin)
+        tag = (weight.data_ptr(), weight._version, None if mask is None else mask._version)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        wp = torch.empty(kh * kw * cout * cin, dtype=dtype, device=weight.device)
+        L.call("hesic_pack_conv_weight", L.ptr(weight.detach()), L.ptr(mask), L.ptr(wp), cout, cin, kh, kw,
+               int(transposed), int(flip), L.dt(dtype), L.stream())
+        self._cache[key] = (tag, wp)
+        return wp
+
+
+def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, act=0, in_abs=0, tap_mask=0,
+               out=None, out_c_off=0, x_c_off=0):
+    """Launch the implicit-GEMM kernel. ``x`` NHWC (may be wider than Cin), returns / fills NHWC ``out``."""
+    dtype = x.dtype
+    if out is None:
+        out = _empty_nhwc(B, Cout, Ho, Wo, dtype, x.device)
+    d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(dtype), act, in_abs,
+                   x.shape[1], x_c_off, out.shape[1], out_c_off, tap_mask)
+    L.call("hesic_conv2d_forward", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.stream())
+    return out
+
+
+def _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act=0):
+    B, _, H, W = x.shape
+    _, _, Ho, Wo = y.shape
+    xs, ys = x.stride(), y.stride()
+    return L.SConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), L.dt(y), act, 0,
+                       xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3])
+
+
+def _out_hw(H, W, k, stride, pad, transposed):
+    if transposed:
+        f = lambda n: (n - 1) * stride - 2 * pad + k + stride - 1
+    else:
+        f = lambda n: (n + 2 * pad - k) // stride + 1
+    return f(H), f(W)
+
+
+class _ConvFn(torch.autograd.Function):
+    """conv()/deconv() of compressai/models/utils.py:104-118 (+ MaskedConv2d, layers.py:21-45)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        L.require_cuda(x, weight)
+        k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
+        if transposed:
+            Cin, Cout = weight.shape[0], weight.shape[1]
+        else:
+            Cout, Cin = weight.shape[0], weight.shape[1]
+        B, Cx, H, W = x.shape
+        if Cx != Cin:
+            raise RuntimeError(f"conv: expected {Cin} input channels, got {Cx}")
+        Ho, Wo = _out_hw(H, W, k, stride, pad, transposed)
+        narrow = _is_narrow(Cin) or _is_narrow(Cout) or Cin % 32 or Cout % 8 or (transposed and (Ho != H * stride))
+        ctx.cfg, ctx.narrow, ctx.dims = cfg, narrow, (B, H, W, Cin, Ho, Wo, Cout)
+        if narrow:
+            ydt = torch.float32 if _is_narrow(Cout) else (_compute_dtype if _is_narrow(Cin) else x.dtype)
+            if not _is_narrow(Cin):
+                x = _nhwc(x)
+            y = _empty_nhwc(B, Cout, Ho, Wo, ydt, x.device) if not _is_narrow(Cout) else \
+                torch.empty((B, Cout, Ho, Wo), dtype=ydt, device=x.device)
+            w = weight.detach() if mask is None else (weight.detach() * mask)
+            d = _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act)
+            L.call("hesic_sconv2d_forward", C.byref(d), L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(y), L.stream())
+        else:
+            x = _nhwc(x)
+            wp = packer.get(weight, mask, Cout, Cin, k, k, transposed, False, x.dtype)
+            y = _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, act, in_abs, tap_mask)
+        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y_act = ctx.saved_tensors
+        k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = ctx.cfg
+        B, H, W, Cin, Ho, Wo, Cout = ctx.dims
+        if act:
+            g2 = torch.empty_like(y_act)
+            gyc = gy.to(y_act.dtype)
+            gyc = _nhwc(gyc) if y_act.is_contiguous(memory_format=_CL) and y_act.dim() == 4 and not _is_narrow(Cout) else gyc.contiguous()
+            L.call("hesic_act_backward", L.ptr(y_act), L.ptr(gyc), L.ptr(g2), y_act.numel(), act, L.dt(y_act), L.stream())
+            gy = g2
+        dx = dw = db = None
+        if ctx.narrow:
+            ydt = torch.float32 if _is_narrow(Cout) else (_compute_dtype if _is_narrow(Cin) else x.dtype)
+            gy = gy.to(ydt)
+            gy = gy.contiguous() if _is_narrow(Cout) else _nhwc(gy)
+            w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
+            d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
+                if in_abs:
+                    dx = dx * torch.sign(x)
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight, dtype=torch.float32)
+                db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.stream())
+                if mask is not None:
+                    dw = dw * mask
+        else:
+            gy = _nhwc(gy.to(x.dtype))
+            if ctx.needs_input_grad[0]:
+                # data gradient = the opposite op with the same weight tensor read in the other layout
+                wp = packer.get(weight, mask, Cin, Cout, k, k, not transposed, False, x.dtype)
+                dx = _wide_conv(gy, wp, None, B, Ho, Wo, Cout, H, W, Cin, k, stride, pad, not transposed)
+                if in_abs:
+                    dx = dx * torch.sign(x)
+            if ctx.needs_input_grad[1]:
+                dwp = torch.empty(k * k * Cout * Cin, dtype=torch.float32, device=x.device)
+                db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, in_abs,
+                               x.shape[1], 0, gy.shape[1], 0, tap_mask)
+                nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
+                ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+                L.call("hesic_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dwp), L.ptr(db), L.ptr(ws), nws, L.stream())
+                dw = torch.empty_like(weight, dtype=torch.float32)
+                L.call("hesic_unpack_conv_wgrad", L.ptr(dwp), L.ptr(mask), L.ptr(dw), Cout, Cin, k, k, int(transposed),
+                       L.stream())
+        if not ctx.has_bias:
+            db = None
+        return dx, dw, db, None
+
+
+def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, in_abs=False,
+           tap_mask=0, packer=None, mask=None):
+    packer = packer if packer is not None else PackedWeight()
+    return _ConvFn.apply(x, weight, bias, (kernel_size, stride, padding, transposed, act, int(in_abs), tap_mask, packer, mask))
+
+
+# ------------------------------------------------------------------------------------ GDN
+class _GdnFn(torch.autograd.Function):
+    """GDN.forward (compressai/layers/gdn.py:55-70), reparametrisation included."""
+
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_min):
+        L.require_cuda(x, beta, gamma)
+        B, Cc, H, W = x.shape
+        x = _nhwc(x)
+        y = torch.empty_like(x, memory_format=_CL)
+        L.call("hesic_gdn_forward", L.ptr(x), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(y),
+               B * H * W, Cc, int(inverse), float(beta_min), L.dt(x), L.stream())
+        ctx.save_for_backward(x, beta, gamma)
+        ctx.inverse, ctx.beta_min = inverse, beta_min
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, beta, gamma = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        P = B * H * W
+        gy = _nhwc(gy.to(x.dtype))
+        dx = torch.empty_like(x, memory_format=_CL)
+        dbeta = torch.zeros_like(beta, dtype=torch.float32)
+        dgamma = torch.zeros_like(gamma, dtype=torch.float32)
+        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=x.device)
+        L.call("hesic_gdn_backward", L.ptr(x), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
+               L.ptr(dx), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cc, int(ctx.inverse), float(ctx.beta_min),
+               L.dt(x), L.stream())
+        return dx, dbeta, dgamma, None, None
+
+
+def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+    return _GdnFn.apply(x, beta, gamma, inverse, beta_min)
+
+
+# ----------------------------------------------------------------------------------- warp
+class _WarpFn(torch.autograd.Function):
+    """kornia.warp_perspective(src, M, dsize) (third party; call sites newnet1.py:746,753,767)."""
+
+    @staticmethod
+    def forward(ctx, src, M, dsize, align_corners):
+        L.require_cuda(src, M)
+        B, Cc, H, W = src.shape
+        Ho, Wo = int(dsize[0]), int(dsize[1])
+        if src.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("warp_perspective: float32 or bfloat16 only")
+        Mf = M.detach().to(torch.float32).contiguous()
+        dst = torch.empty((B, Cc, Ho, Wo), dtype=src.dtype, device=src.device)
+        ss, ds = src.stride(), dst.stride()
+        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, int(align_corners), L.dt(src), L.dt(dst), 0, ss[0], ss[1], ss[2], ss[3],
+                       ds[0], ds[1], ds[2], ds[3])
+        L.call("hesic_warp_perspective_forward", C.byref(d), L.ptr(src), L.ptr(Mf), L.ptr(dst), L.stream())
+        ctx.save_for_backward(Mf)
+        ctx.meta = (src.shape, src.dtype, Ho, Wo, int(align_corners))
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        (Mf,) = ctx.saved_tensors
+        shape, sdt, Ho, Wo, ac = ctx.meta
+        B, Cc, H, W = shape
+        g = g.contiguous()
+        dsrc = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        ss, ds = dsrc.stride(), g.stride()
+        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, ac, L.F32, L.dt(g), 0, ss[0], ss[1], ss[2], ss[3], ds[0], ds[1], ds[2], ds[3])
+        L.call("hesic_warp_perspective_backward", C.byref(d), L.ptr(g), L.ptr(Mf), L.ptr(dsrc), L.stream())
+        return dsrc.to(sdt), None, None, None
+
+
+def warp_perspective(src, M, dsize, align_corners=True):
+    return _WarpFn.apply(src, M, dsize, align_corners)
+
+
+# ---------------------------------------------------------------------- entropy bottleneck
+def eb_pack_params(matrices, biases, factors, quantiles):
+    """[C][64] fp32 table read by hesic_eb_forward/backward (layout in csrc/entropy.hip)."""
+    Cc = quantiles.shape[0]
+    cols = [m.reshape(Cc, -1) for m in matrices] + [b.reshape(Cc, -1) for b in biases] + \
+           [f.reshape(Cc, -1) for f in factors] + [quantiles[:, 0, 1:2]]
+    t = torch.cat(cols, 1).to(torch.float32)
+    assert t.shape[1] == 59, "EntropyBottleneck kernels are specialised for filters=(3,3,3,3)"
+    return torch.nn.functional.pad(t, (0, L.EB_PARAM_STRIDE - 59)).contiguous()
+
+
+def eb_unpack_grads(dparams, matrices, biases, factors, quantiles):
+    out, o = [], 0
+    for group in (matrices, biases, factors):
+        for p in group:
+            n = p[0].numel()
+            out.append(dparams[:, o:o + n].reshape(p.shape).to(p.dtype))
+            o += n
+    dq = torch.zeros_like(quantiles)
+    dq[:, 0, 1] = dparams[:, 58]
+    return out, dq
+
+
+class _EbFn(torch.autograd.Function):
+    """EntropyBottleneck.forward (entropy_models.py:384-411): returns (z_hat, likelihood)."""
+
+    @staticmethod
+    def forward(ctx, z, noise, quantiles, n_mat, *params):
+        L.require_cuda(z)
+        matrices, biases, factors = params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:]
+        B, Cc, H, W = z.shape
+        z = _nhwc(z)
+        table = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
+                               [f.detach() for f in factors], quantiles.detach())
+        zh = torch.empty_like(z, memory_format=_CL)
+        lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
+        nz = None if noise is None else _nhwc(noise.to(z.dtype))
+        L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), L.ptr(nz), L.ptr(zh), L.ptr(lik), None, B * H * W, Cc,
+               L.dt(z), L.stream())
+        ctx.save_for_backward(z, table, nz, quantiles, *params)
+        ctx.n_mat = n_mat
+        return zh, lik
+
+    @staticmethod
+    def backward(ctx, g_zh, g_lik):
+        z, table, nz, quantiles, *params = ctx.saved_tensors
+        n_mat = ctx.n_mat
+        B, Cc, H, W = z.shape
+        dz = torch.empty_like(z, memory_format=_CL)
+        dpar = torch.zeros_like(table)
+        g_lik = _nhwc(g_lik.to(torch.float32))
+        g_zh = None if g_zh is None else _nhwc(g_zh.to(z.dtype))
+        L.call("hesic_eb_backward", L.ptr(z), L.ptr(table), L.ptr(nz), L.ptr(g_lik), L.ptr(g_zh), L.ptr(dz), L.ptr(dpar),
+               B * H * W, Cc, L.dt(z), L.stream())
+        grads, dq = eb_unpack_grads(dpar, params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:], quantiles)
+        return (dz, None, dq, None, *grads)
+
+
+def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None):
+    return _EbFn.apply(z, noise, quantiles, len(matrices), *matrices, *biases, *factors)
+
+
+# ------------------------------------------------------------ Gaussian (mixture) conditional
+class _GmmFn(torch.autograd.Function):
+    """GaussianMixtureConditional.forward (entropy_models.py:661-702) for K>1 with weights, and
+    GaussianConditional.forward (:546-554) for K==1 (means optional, used in the quantiser)."""
+
+    @staticmethod
+    def forward(ctx, y, scales, means, weights, noise, K, use_means_in_quant, scale_bound, lik_bound):
+        L.require_cuda(y, scales, means)
+        B, M, H, W = y.shape
+        y = _nhwc(y)
+        if means is None:
+            means = torch.zeros_like(scales)
+        # scales / means may be the two halves of one tensor (chunk(2,1)): keep them in place
+        same = (scales.dim() == 4 and means.dim() == 4 and scales._base is not None and scales._base is means._base
+                and scales._base.is_contiguous(memory_format=_CL) and scales._base.dtype == y.dtype)
+        ok = False
+        if same:
+            base = scales._base
+            ps = base.shape[1]
+            s_off = scales.storage_offset() - base.storage_offset()
+            m_off = means.storage_offset() - base.storage_offset()
+            sp = mp = base
+            ok = 0 <= s_off < ps and 0 <= m_off < ps and base.shape[0] == B and base.shape[2:] == y.shape[2:]
+        if not ok:
+            scales, means = _nhwc(scales.to(y.dtype)), _nhwc(means.to(y.dtype))
+            ps, s_off, m_off, sp, mp = K * M, 0, 0, scales, means
+        wts = None if weights is None else weights.detach().reshape(B, K * M).to(torch.float32).contiguous()
+        yh = torch.empty_like(y, memory_format=_CL)
+        lik = _empty_nhwc(B, M, H, W, torch.float32, y.device)
+        nz = None if noise is None else _nhwc(noise.to(y.dtype))
+        d = L.GmmDesc(B, H * W, M, K, L.dt(y), int(use_means_in_quant), ps, 0, 0, float(scale_bound), float(lik_bound))
+        sptr = C.c_void_p(sp.data_ptr() + s_off * sp.element_size())
+        mptr = C.c_void_p(mp.data_ptr() + m_off * mp.element_size())
+        L.call("hesic_gmm_forward", C.byref(d), L.ptr(y), sptr, mptr, L.ptr(wts), L.ptr(nz), L.ptr(yh), L.ptr(lik), None,
+               L.stream())
+        ctx.save_for_backward(y, scales, means, wts, nz)
+        ctx.meta = (K, int(use_means_in_quant), float(scale_bound), float(lik_bound), weights is not None)
+        return yh, lik
+
+    @staticmethod
+    def backward(ctx, g_yh, g_lik):
+        y, scales, means, wts, nz = ctx.saved_tensors
+        K, umq, sb, lb, has_w = ctx.meta
+        B, M, H, W = y.shape
+        scales, means = _nhwc(scales.to(y.dtype)), _nhwc(means.to(y.dtype))
+        dy = torch.empty_like(y, memory_format=_CL)
+        dsc = torch.empty_like(scales, memory_format=_CL)
+        dmu = torch.empty_like(means, memory_format=_CL)
+        dw = torch.zeros((B, K * M), dtype=torch.float32, device=y.device) if has_w else None
+        g_lik = _nhwc(g_lik.to(torch.float32))
+        g_yh = None if g_yh is None else _nhwc(g_yh.to(y.dtype))
+        d = L.GmmDesc(B, H * W, M, K, L.dt(y), umq, K * M, 0, 0, sb, lb)
+        L.call("hesic_gmm_backward", C.byref(d), L.ptr(y), L.ptr(scales), L.ptr(means), L.ptr(wts), L.ptr(nz), L.ptr(g_lik),
+               L.ptr(g_yh), L.ptr(dy), L.ptr(dsc), L.ptr(dmu), L.ptr(dw), L.stream())
+        if dw is not None:
+            dw = dw.reshape(B, K * M, 1, 1)
+        return dy, dsc, dmu, dw, None, None, None, None, None
+
+
+def gaussian_mixture(y, scales, means, weights, K, noise=None, scale_bound=0.11, lik_bound=1e-9):
+    return _GmmFn.apply(y, scales, means, weights, noise, K, False, scale_bound, lik_bound)
+
+
+def gaussian_conditional(y, scales, means=None, noise=None, scale_bound=0.11, lik_bound=1e-9):
+    return _GmmFn.apply(y, scales, means, None, noise, 1, means is not None, scale_bound, lik_bound)
+
+
+def quantize_symbols(y, means=None):
+    """EntropyModel._quantize(x, 'symbols', means) (entropy_models.py:98-125): int32 indices."""
+    L.require_cuda(y)
+    B, M, H, W = y.shape
+    y = _nhwc(y)
+    sc = torch.ones_like(y, memory_format=_CL)
+    mu = torch.zeros_like(y, memory_format=_CL) if means is None else _nhwc(means.to(y.dtype).expand_as(y))
+    yh = torch.empty_like(y, memory_format=_CL)
+    lik = _empty_nhwc(B, M, H, W, torch.float32, y.device)
+    sym = torch.empty((B, M, H, W), dtype=torch.int32, device=y.device).contiguous(memory_format=_CL)
+    d = L.GmmDesc(B, H * W, M, 1, L.dt(y), int(means is not None), M, 0, 0, 0.11, 1e-9)
+    L.call("hesic_gmm_forward", C.byref(d), L.ptr(y), L.ptr(sc), L.ptr(mu), None, None, L.ptr(yh), L.ptr(lik), L.ptr(sym),
+           L.stream())
+    return sym
+
+
+# ----------------------------------------------------------------------------------- glue
+class _Upsample4CatFn(torch.autograd.Function):
+    """cat(UpsamplingBilinear2d(x4)(z), y1, dim=1) (newnet1.py:524,556-557) in one buffer."""
+
+    @staticmethod
+    def forward(ctx, z, y1):
+        L.require_cuda(z, y1)
+        B, Cz, H, W = z.shape
+        _, Cy, Hy, Wy = y1.shape
+        if (Hy, Wy) != (4 * H, 4 * W):
+            raise RuntimeError("upsample4_cat: y1 must be 4x the size of z")
+        z, y1 = _nhwc(z), _nhwc(y1.to(z.dtype))
+        out = _empty_nhwc(B, Cz + Cy, Hy, Wy, z.dtype, z.device)
+        L.call("hesic_upsample4_forward", L.ptr(z), L.ptr(out), B, H, W, Cz, Cz + Cy, 0, L.dt(z), L.stream())
+        L.call("hesic_copy_channels", L.ptr(y1), L.ptr(out), B * Hy * Wy, Cy, Cy, 0, Cz + Cy, Cz, L.dt(z), L.stream())
+        ctx.dims = (B, Cz, H, W, Cy)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cz, H, W, Cy = ctx.dims
+        g = _nhwc(g)
+        dz = _empty_nhwc(B, Cz, H, W, g.dtype, g.device)
+        dy1 = _empty_nhwc(B, Cy, 4 * H, 4 * W, g.dtype, g.device)
+        L.call("hesic_upsample4_backward", L.ptr(g), L.ptr(dz), B, H, W, Cz, Cz + Cy, 0, L.dt(g), L.stream())
+        L.call("hesic_copy_channels", L.ptr(g), L.ptr(dy1), B * 16 * H * W, Cy, Cz + Cy, Cz, Cy, 0, L.dt(g), L.stream())
+        return dz, dy1
+
+
+def upsample4_cat(z, y1):
+    return _Upsample4CatFn.apply(z, y1)
+
+
+class _Upsample4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        L.require_cuda(z)
+        B, Cz, H, W = z.shape
+        z = _nhwc(z)
+        out = _empty_nhwc(B, Cz, 4 * H, 4 * W, z.dtype, z.device)
+        L.call("hesic_upsample4_forward", L.ptr(z), L.ptr(out), B, H, W, Cz, Cz, 0, L.dt(z), L.stream())
+        ctx.dims = (B, Cz, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cz, H, W = ctx.dims
+        g = _nhwc(g)
+        dz = _empty_nhwc(B, Cz, H, W, g.dtype, g.device)
+        L.call("hesic_upsample4_backward", L.ptr(g), L.ptr(dz), B, H, W, Cz, Cz, 0, L.dt(g), L.stream())
+        return dz
+
+
+def upsample4(z):
+    return _Upsample4Fn.apply(z)
+
+
+class _SpatialMaxFn(torch.autograd.Function):
+    """spatial_pool2d (newnet1.py:441-453) [+ LeakyReLU :497]: (B,C,H,W) -> (B,C,1,1) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, leaky):
+        L.require_cuda(x)
+        B, Cc, H, W = x.shape
+        x = _nhwc(x)
+        out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, Cc), dtype=torch.int32, device=x.device)
+        L.call("hesic_spatial_max", L.ptr(x), L.ptr(out), L.ptr(arg), B, H * W, Cc, L.dt(x), int(leaky), L.stream())
+        ctx.save_for_backward(arg, out)
+        ctx.meta = (x.shape, x.dtype, leaky)
+        return out.reshape(B, Cc, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, out = ctx.saved_tensors
+        shape, dtype, leaky = ctx.meta
+        B, Cc, H, W = shape
+        g = g.reshape(B, Cc).to(torch.float32)
+        if leaky:
+            g = torch.where(out > 0, g, 0.01 * g)
+        dx = torch.zeros((B, H * W, Cc), dtype=dtype, device=g.device)
+        dx.scatter_(1, arg.long().unsqueeze(1), g.to(dtype).unsqueeze(1))
+        return dx.reshape(B, H, W, Cc).permute(0, 3, 1, 2), None
+
+
+def spatial_max(x, leaky=False):
+    return _SpatialMaxFn.apply(x, leaky)
+
+
+class _SoftmaxKFn(torch.autograd.Function):
+    """softmax over K of a (B, K*M, 1, 1) tensor with channel k*M+m (newnet1.py:510-512)."""
+
+    @staticmethod
+    def forward(ctx, logits, K, M):
+        L.require_cuda(logits)
+        B = logits.shape[0]
+        lg = logits.reshape(B, K * M).to(torch.float32).contiguous()
+        w = torch.empty_like(lg)
+        L.call("hesic_softmax_k_forward", L.ptr(lg), L.ptr(w), B, K, M, L.stream())
+        ctx.save_for_backward(w)
+        ctx.meta = (K, M, logits.dtype, logits.shape)
+        return w.reshape(B, K * M, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        K, M, dtype, shape = ctx.meta
+        B = w.shape[0]
+        g = g.reshape(B, K * M).to(torch.float32).contiguous()
+        dl = torch.empty_like(w)
+        L.call("hesic_softmax_k_backward", L.ptr(w), L.ptr(g), L.ptr(dl), B, K, M, L.stream())
+        return dl.reshape(shape).to(dtype), None, None
+
+
+def softmax_k(logits, K, M):
+    return _SoftmaxKFn.apply(logits, K, M)
+
+
+def mix_weights(pooled, weight, bias, K, M):
+    """conv1x1(K*M -> K*M) on the pooled vector + softmax over K (newnet1.py:500,510-512).
+    Forward-only HIP kernel; under autograd the caller uses the differentiable torch fallback
+    below because the op is 0.001 GMAC."""
+    L.require_cuda(pooled, weight)
+    B = pooled.shape[0]
+    p = pooled.reshape(B, K * M).to(torch.float32).contiguous()
+    w = weight.detach().reshape(K * M, K * M).to(torch.float32).contiguous()
+    logits = torch.empty((B, K * M), dtype=torch.float32, device=p.device)
+    out = torch.empty((B, K * M), dtype=torch.float32, device=p.device)
+    L.call("hesic_mix_weights_forward", L.ptr(p), L.ptr(w), L.ptr(None if bias is None else bias.detach()), L.ptr(logits),
+           L.ptr(out), B, K, M, L.stream())
+    return out.reshape(B, K * M, 1, 1)
+
+
+# ----------------------------------------------------------------------------- reductions
+def sum_log2(lik, out=None):
+    """sum(log2(lik)) as an fp64 device scalar (bits = -sum)."""
+    L.require_cuda(lik)
+    lik = lik.contiguous() if not lik.is_contiguous(memory_format=_CL) else lik
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=lik.device)
+    L.call("hesic_sum_log2", L.ptr(lik), lik.numel(), L.ptr(out), L.stream())
+    return out
+
+
+def sum_sq_diff(a, b, out=None):
+    L.require_cuda(a, b)
+    B, Cc, H, W = a.shape
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=a.device)
+    sa = (C.c_int64 * 4)(*a.stride())
+    sb = (C.c_int64 * 4)(*b.stride())
+    L.call("hesic_sum_sq_diff", L.ptr(a), L.dt(a), sa, L.ptr(b), L.dt(b), sb, B, Cc, H, W, L.ptr(out), L.stream())
+    return out

@@ -1,0 +1,193 @@
+/*
+ * hesic_hip.h -- C ABI of libhesic_hip.so: the MI355X (gfx950) kernels behind the HESIC / HESIC+
+ * forward + backward hot path.
+ *
+ * The reference has no FFI for this path: its "plugin interface" is the Python operator surface
+ * (compressai.layers / compressai.entropy_models / compressai.models.utils).  This
+ * header is the boundary a maintainer binds with ctypes (INTEGRATION.md shows the stub); every entry
+ * point names the reference operator it replaces.  Citations are path:line inside the reference repo.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; sizes are element counts
+ *  - feature maps are NHWC ("channels_last"): element (b,y,x,c) at ((b*H+y)*W+x)*pix_stride + c_off + c
+ *  - 3-channel images use explicit element strides (sb, sc, sy, sx) so NCHW planar inputs need no copy
+ *  - dtype: HESIC_F32 or HESIC_BF16 storage; all arithmetic accumulates in fp32
+ *  - `stream` is a hipStream_t (0 = the null stream); calls are asynchronous on it
+ *  - return value: 0 on success, otherwise a hipError_t (> 0) or HESIC_EINVAL (-1) for bad arguments;
+ *    hesic_last_error() returns a static description of the last failure on the calling thread
+ */
+#ifndef HESIC_HIP_H
+#define HESIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HESIC_ABI_VERSION 1
+#define HESIC_EINVAL (-1)
+
+enum { HESIC_F32 = 0, HESIC_BF16 = 1 };
+enum { HESIC_ACT_NONE = 0, HESIC_ACT_RELU = 1, HESIC_ACT_LEAKY = 2 /* slope 0.01 */ };
+
+int hesic_abi_version(void);
+const char* hesic_last_error(void);
+
+/* ------------------------------------------------------------------ convolution (rows A1,A2,A4-A7,A11)
+ * Replaces nn.Conv2d / nn.ConvTranspose2d as built by conv()/deconv()
+ * (compressai/models/utils.py:104-118) and MaskedConv2d (compressai/layers/layers.py:21-45).       */
+typedef struct {
+    int32_t B, H, W, Cin;           /* input  (NHWC)                                               */
+    int32_t Ho, Wo, Cout;           /* output (NHWC); transposed: Ho = H*stride, Wo = W*stride       */
+    int32_t KH, KW, stride, pad;    /* pad = k/2; transposed => output_padding = stride-1            */
+    int32_t transposed;             /* 0: Conv2d   1: ConvTranspose2d                                */
+    int32_t dtype;                  /* storage type of x, packed weights and y                       */
+    int32_t act;                    /* fused activation on the output (HESIC_ACT_*)                  */
+    int32_t in_abs;                 /* 1: |x| on load (encode_hyper, newnet1.py:434)                 */
+    int32_t x_pix_stride, x_c_off;  /* channels per pixel of the x buffer, first channel used        */
+    int32_t y_pix_stride, y_c_off;  /* same for y: lets a conv write straight into a concat buffer   */
+    int32_t tap_mask_lo;            /* bit t set => tap t (ky*KW+kx) is live; 0 = all (MaskedConv2d) */
+} hesic_conv_desc;
+
+/* Repack an fp32 PyTorch weight into the kernels' layout [KH*KW][Cout][Cin] of `dtype`.
+ * transposed=0: w is (Cout,Cin,KH,KW)  (nn.Conv2d);  transposed=1: w is (Cin,Cout,KH,KW)
+ * (nn.ConvTranspose2d).  flip=1 mirrors the taps (used for stride-1 transposed conv == conv with the
+ * flipped kernel, and by the data-gradient kernels).  mask (may be NULL): (Cout,Cin,KH,KW) multiplier. */
+int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, int Cout, int Cin, int KH, int KW,
+                           int transposed, int flip, int dtype, void* stream);
+
+/* y = act(conv(x, w) + bias).  bias may be NULL.  w_packed from hesic_pack_conv_weight. */
+int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                         void* y, void* stream);
+
+/* Weight gradient of the same op: dw_packed[KH*KW][Cout][Cin] (fp32, packed layout) = sum over pixels of
+ * dy (x) x; dbias (Cout, fp32) may be NULL.  Pixels are split over blocks; the partial tiles live in `ws`
+ * (hesic_conv2d_wgrad_ws_bytes(d) bytes) and are summed in a fixed order, so the result is deterministic.
+ * Unpack to the PyTorch layout with hesic_unpack_conv_wgrad.                                           */
+int64_t hesic_conv2d_wgrad_ws_bytes(const hesic_conv_desc* d);
+int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
+                       void* ws, int64_t ws_bytes, void* stream);
+int hesic_unpack_conv_wgrad(const float* dw_packed, const float* mask, float* dw, int Cout, int Cin, int KH, int KW,
+                            int transposed, void* stream);
+
+/* 3-channel image convs with arbitrary element strides on the image side (conv1 3->N, pre_conv 6->3,
+ * g_s_conv4 N->3, after_conv 6->3: newnet1.py:583,629,612,670).  `img_*` strides describe the tensor
+ * with the small channel count (input for Conv2d here, output for ConvTranspose2d).                   */
+typedef struct {
+    int32_t B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed;
+    int32_t x_dtype, y_dtype, act;
+    int64_t xs_b, xs_c, xs_y, xs_x;   /* element strides of x */
+    int64_t ys_b, ys_c, ys_y, ys_x;   /* element strides of y */
+} hesic_sconv_desc;
+/* w is the raw fp32 PyTorch weight ((Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW)). */
+int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
+                          void* stream);
+/* dx of the same op (dy has y's strides, dx has x's strides). */
+int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream);
+/* dw (raw PyTorch layout, fp32) and dbias (may be NULL). */
+int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------ GDN / IGDN (row A3)
+ * Replaces GDN.forward (compressai/layers/gdn.py:55-70).  beta/gamma are the RAW parameters (reparam
+ * domain); the NonNegativeParametrizer (compressai/ops/parametrizers.py:41-44) is applied inside.
+ * x, y: NHWC with C channels, P = B*H*W pixels.                                                       */
+int hesic_gdn_forward(const void* x, const float* beta, const float* gamma, void* y, int64_t P, int C,
+                      int inverse, float beta_min, int dtype, void* stream);
+/* dx (same dtype as x), dbeta (C) and dgamma (C*C) fp32, gradients w.r.t. the RAW parameters
+ * (LowerBound rule of compressai/ops/bound_ops.py:28-31 included).  ws: fp32 workspace of
+ * hesic_gdn_backward_ws_bytes(P,C) bytes.                                                             */
+int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C);
+int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const float* gamma, void* dx,
+                       float* dbeta, float* dgamma, void* ws, int64_t P, int C, int inverse, float beta_min,
+                       int dtype, void* stream);
+
+/* ------------------------------------------------------------------- warp_perspective (row A10)
+ * Replaces kornia.warp_perspective(src, M, dsize) (third party; call sites newnet1.py:746,753,767).
+ * M_src_to_dst: (B,3,3) fp32 row-major on the DEVICE, maps source pixel -> destination pixel; the kernel
+ * inverts it.  align_corners=1: exact inverse-map bilinear, zeros outside (kornia >= 0.5);
+ * align_corners=0: kornia <= 0.4 default (samples at xs*W/(W-1) - 1/2).                              */
+typedef struct {
+    int32_t B, C, H, W, Ho, Wo, align_corners, src_dtype, dst_dtype;
+    int64_t ss_b, ss_c, ss_y, ss_x;   /* src element strides */
+    int64_t ds_b, ds_c, ds_y, ds_x;   /* dst element strides */
+} hesic_warp_desc;
+int hesic_warp_perspective_forward(const hesic_warp_desc* d, const void* src, const float* M_src_to_dst, void* dst,
+                                   void* stream);
+/* d_src (fp32, same strides as src, must be zero-filled by the caller) += transpose of the gather. */
+int hesic_warp_perspective_backward(const hesic_warp_desc* d, const void* d_dst, const float* M_src_to_dst,
+                                    float* d_src, void* stream);
+
+/* ------------------------------------------------------------ EntropyBottleneck (row A8)
+ * Replaces EntropyBottleneck.forward (compressai/entropy_models/entropy_models.py:384-411) for the
+ * default filters=(3,3,3,3).  params: fp32 [C][64] packed by hesic_eb_pack_params: 58 MLP values
+ * (softplus / tanh NOT yet applied) + median.  z: NHWC (P pixels, C channels).  noise: NULL => eval
+ * (round(z-med)+med), else training (z+noise).  z_hat in z's dtype, lik fp32 NHWC.                   */
+#define HESIC_EB_PARAM_STRIDE 64
+int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,
+                     int64_t P, int C, int dtype, void* stream);
+/* dz (z dtype) and dparams [C][64] fp32 (zero-filled by caller; atomically accumulated).
+ * g_lik: fp32 gradient of lik, g_zhat: gradient of z_hat (may be NULL).                              */
+int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
+                      void* dz, float* dparams, int64_t P, int C, int dtype, void* stream);
+
+/* ------------------------------------------------- GaussianMixtureConditional (row A9) / Gaussian (A11)
+ * Replaces GaussianMixtureConditional.forward (entropy_models.py:661-702) and
+ * GaussianConditional.forward (:546-554).  y: NHWC M channels; scales, means: NHWC K*M channels with
+ * channel k*M+m; weights: (B, K*M) fp32 (K==1 && weights==NULL => plain Gaussian).
+ * use_means_in_quant: 0 => y_hat=round(y) (GMM), 1 => round(y-mu)+mu (GaussianConditional, K==1).
+ * noise NULL => eval.  Outputs: y_hat (y dtype), lik fp32, symbols int32 (may be NULL).              */
+typedef struct {
+    int32_t B, HW, M, K, dtype, use_means_in_quant;
+    int32_t sm_pix_stride, s_c_off, m_c_off;   /* scales/means may live in one buffer (chunk(2,1))   */
+    float scale_bound, lik_bound;
+} hesic_gmm_desc;
+int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
+                      const float* weights, const void* noise, void* y_hat, float* lik, int32_t* symbols,
+                      void* stream);
+/* Gradients: dy (y dtype; only meaningful in noise mode), dscales/dmeans (scales dtype, same layout),
+ * dweights (B,K*M) fp32 zero-filled by caller (atomic accumulate).                                   */
+int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
+                       const float* weights, const void* noise, const float* g_lik, const void* g_yhat, void* dy,
+                       void* dscales, void* dmeans, float* dweights, void* stream);
+
+/* -------------------------------------------------------------------------------- glue (rows A6,A7,A12)
+ * Bilinear x4 upsample, align_corners=True (nn.UpsamplingBilinear2d, newnet1.py:524), written into
+ * channels [y_c_off, y_c_off+C) of an NHWC buffer with y_pix_stride channels (fused torch.cat :557). */
+int hesic_upsample4_forward(const void* x, void* y, int B, int H, int W, int C, int y_pix_stride, int y_c_off,
+                            int dtype, void* stream);
+int hesic_upsample4_backward(const void* dy, void* dx, int B, int H, int W, int C, int y_pix_stride, int y_c_off,
+                             int dtype, void* stream);
+/* Copy an NHWC tensor into a channel slice of a wider NHWC buffer (the other half of torch.cat). */
+int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int x_pix_stride, int x_c_off, int y_pix_stride,
+                        int y_c_off, int dtype, void* stream);
+/* spatial_pool2d + LeakyReLU (newnet1.py:441-453,497): out[b,c] = leaky(max_{hw} x[b,hw,c]); argmax kept
+ * for the backward.  out fp32 (B,C).                                                                  */
+int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW, int C, int dtype, int leaky,
+                      void* stream);
+/* The 1x1 conv + softmax-over-K head (newnet1.py:500,510-512): logits (B,K*M) = W (KM,KM) @ pooled + b;
+ * weights[b, k*M+m] = softmax_k.  All fp32.                                                          */
+int hesic_mix_weights_forward(const float* pooled, const float* w, const float* bias, float* logits, float* weights,
+                              int B, int K, int M, void* stream);
+
+/* softmax over K of logits laid out (B, K*M) with channel k*M+m, and its backward
+ * dlogits = w * (g - sum_k g*w).                                                                       */
+int hesic_softmax_k_forward(const float* logits, float* weights, int B, int K, int M, void* stream);
+int hesic_softmax_k_backward(const float* weights, const float* g, float* dlogits, int B, int K, int M, void* stream);
+
+/* -------------------------------------------------------------------------------- reductions (rows T,M)
+ * out[0] += sum(log2(lik)) over n fp32 values (bits = -out[0]);  fp64 accumulator on device.          */
+int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream);
+/* out[0] += sum((a-b)^2) with a, b given by element strides over a (B,C,H,W) index space.             */
+int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
+                      const int64_t b_strides[4], int B, int C, int H, int W, double* out, void* stream);
+
+/* elementwise helpers used by the autograd wrappers */
+int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream);
+int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HESIC_HIP_H */

@@ -1,0 +1,354 @@
+"""Operator parity on a real MI355X: every op goes through the C ABI (libhesic_hip.so) and is compared
+with the CPU oracle on the same seeded inputs and with the reference-generated golden vectors.
+
+Bars: integer symbols / rounded latents bit-exact; fp32 storage (exact-fp32 MFMA) within 1e-4 of the
+fp32 CPU result (summation order differs); bf16 storage within 2e-2 of the output scale against the
+oracle run on the bf16-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+from hesic_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _imp():
+    from hesic_amd import functional as Fn
+    from oracle import hesic_oracle as O
+    return Fn, O
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0):
+    return synthetic._uniform("t." + name, shape, lo, hi)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+CONV_CASES = [
+    # tag, Cin, Cout, k, stride, transposed, (B,H,W)
+    ("c5s2_128", 128, 128, 5, 2, 0, (2, 32, 32)),
+    ("c5s2_128_192", 128, 192, 5, 2, 0, (1, 16, 24)),
+    ("c5s1_192_128", 192, 128, 5, 1, 0, (2, 8, 8)),
+    ("c5s1_320_128", 320, 128, 5, 1, 0, (1, 12, 12)),
+    ("c5s1_128_960", 128, 960, 5, 1, 0, (1, 8, 8)),
+    ("c3s1_288_384", 288, 384, 3, 1, 0, (1, 8, 8)),
+    ("c1_768_640", 768, 640, 1, 1, 0, (2, 4, 4)),
+    ("c5s2_tiny", 128, 128, 5, 2, 0, (2, 2, 2)),
+    ("c5s2_64_72", 64, 72, 5, 2, 0, (1, 10, 6)),
+    ("d5s2_128", 128, 128, 5, 2, 1, (2, 16, 16)),
+    ("d5s2_192_128", 192, 128, 5, 2, 1, (1, 4, 4)),
+    ("d5s2_128_288", 128, 288, 5, 2, 1, (1, 8, 4)),
+    ("d5s2_1x1", 128, 128, 5, 2, 1, (2, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_wide_conv_forward_backward(case, dtype):
+    Fn, O = _imp()
+    tag, Cin, Cout, k, s, tr, (B, H, W) = case
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    fan = Cin * k * k / (4 if tr and s == 2 else 1)
+    w = rnd(tag + "w", wshape) * (3.0 / fan) ** 0.5
+    b = rnd(tag + "b", (Cout,), -0.1, 0.1)
+    x = rnd(tag + "x", (B, Cin, H, W))
+    if dtype == torch.bfloat16:
+        x, w = bf(x), bf(w)
+    xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yo = (O.deconv if tr else O.conv)(xo, wo, bo, s)
+    gy = rnd(tag + "g", yo.shape)
+    if dtype == torch.bfloat16:
+        gy = bf(gy)
+    yo.backward(gy)
+
+    xd = x.to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd, bd = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = Fn.conv2d(xd, wd, bd, kernel_size=k, stride=s, padding=k // 2, transposed=bool(tr))
+    assert y.shape == yo.shape and y.dtype == dtype
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(y, yo) < tol
+    y.backward(gy.to(DEV, dtype))
+    assert rel_err(xd.grad, xo.grad) < tol
+    assert rel_err(wd.grad, wo.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert rel_err(bd.grad, bo.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_wide_conv_fused_abs_act_and_concat_write():
+    Fn, O = _imp()
+    from hesic_amd import _lib as L
+    import ctypes as C
+    x = rnd("fa_x", (2, 192, 8, 8), -2, 2)
+    w = rnd("fa_w", (128, 192, 5, 5)) * 0.02
+    b = rnd("fa_b", (128,), -0.1, 0.1)
+    ref = torch.relu(O.conv(x.abs(), w, b, 1))
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    y = Fn.conv2d(xd, w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, act=L.ACT_RELU, in_abs=True)
+    assert rel_err(y, ref) < 1e-4
+    # same conv written into channels [64,192) of a 256-channel buffer
+    buf = torch.zeros((2, 256, 8, 8), device=DEV).contiguous(memory_format=torch.channels_last)
+    wp = Fn.PackedWeight().get(w.to(DEV), None, 128, 192, 5, 5, False, False, torch.float32)
+    Fn._wide_conv(xd, wp, b.to(DEV), 2, 8, 8, 192, 8, 8, 128, 5, 1, 2, False, act=L.ACT_RELU, in_abs=1, out=buf, out_c_off=64)
+    assert rel_err(buf[:, 64:192], ref) < 1e-4
+    assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 192:].abs().max()) == 0
+
+
+def test_masked_conv_matches_golden(ops_golden):
+    Fn, O = _imp()
+    g = ops_golden
+    # golden case is 8->16 (narrow path); the wide path is checked against the oracle
+    x = rnd("mc_x", (1, 192, 8, 8), -3, 3).round()
+    w = rnd("mc_w", (384, 192, 5, 5)) * 0.02
+    b = rnd("mc_b", (384,), -0.1, 0.1)
+    ref = O.masked_conv(x, w, b, "A")
+    mask = torch.ones_like(w)
+    mask[:, :, 2, 2:] = 0
+    mask[:, :, 3:] = 0
+    y = Fn.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, tap_mask=(1 << 12) - 1,
+                  mask=mask.to(DEV))
+    assert rel_err(y, ref) < 1e-4
+    for mt in ("A", "B"):
+        mk = T(g[f"mc{mt}_mask"]).to(DEV)
+        y = Fn.conv2d(T(g[f"mc{mt}_x"]).to(DEV), T(g[f"mc{mt}_w"]).to(DEV), T(g[f"mc{mt}_b"]).to(DEV), kernel_size=5,
+                      stride=1, padding=2, mask=mk)
+        assert rel_err(y, T(g[f"mc{mt}_y"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag,stride,tr", [("c5s2", 2, 0), ("c5s1", 1, 0), ("c3s1", 1, 0), ("d5s2", 2, 1),
+                                           ("d5s1", 1, 1), ("c5s2_32", 2, 0), ("d5s2_32", 2, 1)])
+def test_conv_golden_fwd_bwd(ops_golden, tag, stride, tr):
+    """The reference-generated conv()/deconv() vectors (odd sizes, narrow channels) through the HIP path."""
+    Fn, _ = _imp()
+    g = ops_golden
+    x, w, b = (T(g[f"{tag}_{k}"]).to(DEV).requires_grad_() for k in ("x", "w", "b"))
+    k = w.shape[-1]
+    y = Fn.conv2d(x, w, b, kernel_size=k, stride=stride, padding=k // 2, transposed=bool(tr))
+    assert rel_err(y, T(g[tag + "_y"])) < 1e-4
+    y.backward(T(g[tag + "_gy"]).to(DEV).to(y.dtype))
+    assert rel_err(x.grad, T(g[tag + "_dx"])) < 2e-4
+    assert rel_err(w.grad, T(g[tag + "_dw"])) < 2e-4
+    assert rel_err(b.grad, T(g[tag + "_db"])) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_image_side_convs(dtype):
+    """g_a_conv1 (3->128 s2), g_s_conv4 (128->3 transposed), pre_conv / after_conv (6->3 s1)."""
+    Fn, O = _imp()
+    Fn.set_compute_dtype(dtype)
+    try:
+        tol = 1e-4 if dtype == torch.float32 else 2e-2
+        x = rnd("ic_x", (2, 3, 32, 48), 0, 1)
+        w = rnd("ic_w", (128, 3, 5, 5)) * 0.2
+        b = rnd("ic_b", (128,), -0.1, 0.1)
+        y = Fn.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=2, padding=2)
+        assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+        assert rel_err(y, O.conv(x, w, b, 2)) < tol
+        f = rnd("ic_f", (2, 128, 16, 24))
+        wt = rnd("ic_wt", (128, 3, 5, 5)) * 0.05
+        bt = rnd("ic_bt", (3,), -0.1, 0.1)
+        fi = bf(f) if dtype == torch.bfloat16 else f
+        yt = Fn.conv2d(fi.to(DEV, dtype), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        assert yt.dtype == torch.float32 and yt.shape == (2, 3, 32, 48)
+        assert rel_err(yt, O.deconv(fi, wt, bt, 2)) < 1e-4
+        x6 = rnd("ic_x6", (2, 6, 16, 16), 0, 1)
+        w6 = rnd("ic_w6", (3, 6, 5, 5)) * 0.1
+        assert rel_err(Fn.conv2d(x6.to(DEV), w6.to(DEV), None, kernel_size=5, stride=1, padding=2), O.conv(x6, w6, None, 1)) < 1e-4
+        w6t = rnd("ic_w6t", (6, 3, 5, 5)) * 0.1
+        assert rel_err(Fn.conv2d(x6.to(DEV), w6t.to(DEV), None, kernel_size=5, stride=1, padding=2, transposed=True),
+                       O.deconv(x6, w6t, None, 1)) < 1e-4
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("C", [3, 128])
+@pytest.mark.parametrize("inv", [False, True])
+def test_gdn_golden(ops_golden, C, inv):
+    Fn, _ = _imp()
+    g, t = ops_golden, f"gdn_C{C}_{'inv' if inv else 'fwd'}_"
+    x = T(g[t + "x"]).to(DEV).requires_grad_()
+    beta, gamma = T(g[t + "beta"]).to(DEV).requires_grad_(), T(g[t + "gamma"]).to(DEV).requires_grad_()
+    y = Fn.gdn(x, beta, gamma, inv)
+    assert rel_err(y, T(g[t + "y"])) < 1e-5
+    y.backward(T(g[t + "gy"]).to(DEV))
+    assert rel_err(x.grad, T(g[t + "dx"])) < 1e-4
+    assert rel_err(beta.grad, T(g[t + "dbeta"])) < 1e-4
+    assert rel_err(gamma.grad, T(g[t + "dgamma"])) < 1e-4
+
+
+@pytest.mark.parametrize("inv", [False, True])
+def test_gdn128_large_bf16_and_f32(inv):
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=3)
+    x = rnd("gdnL", (2, 128, 24, 20), -3, 3)          # 960 pixels: not a multiple of the 128-pixel tile
+    ref = O.gdn(x, sd["g.beta"], sd["g.gamma"], inv)
+    y = Fn.gdn(x.to(DEV), sd["g.beta"].to(DEV), sd["g.gamma"].to(DEV), inv)
+    assert rel_err(y, ref) < 1e-5
+    xb = bf(x)
+    refb = O.gdn(xb, sd["g.beta"], sd["g.gamma"], inv)
+    yb = Fn.gdn(xb.to(DEV, torch.bfloat16), sd["g.beta"].to(DEV), sd["g.gamma"].to(DEV), inv)
+    assert yb.dtype == torch.bfloat16 and rel_err(yb, refb) < 1.5e-2
+
+
+@pytest.mark.parametrize("ac", [True, False])
+def test_warp_golden(warp_golden, ac):
+    Fn, _ = _imp()
+    g = warp_golden
+    src = T(g["src"]).to(DEV).requires_grad_()
+    out = Fn.warp_perspective(src, T(g["H"]).to(DEV), (24, 32), align_corners=ac)
+    assert rel_err(out, T(g[f"out_ac{int(ac)}"])) < 1e-4
+    out.backward(T(g["g"]).to(DEV))
+    assert rel_err(src.grad, T(g[f"dsrc_ac{int(ac)}"])) < 1e-3
+
+
+def test_warp_identity_and_layouts():
+    Fn, O = _imp()
+    x = rnd("wi", (2, 3, 40, 56), 0, 1)
+    eye = torch.eye(3).repeat(2, 1, 1)
+    assert torch.equal(Fn.warp_perspective(x.to(DEV), eye.to(DEV), (40, 56)).cpu(), x)        # identity is exact
+    Hm = torch.from_numpy(np.stack([synthetic.homography(i) for i in range(2)])).float()
+    ref = O.warp_perspective(x, Hm, (40, 56))
+    for src in (x.to(DEV), x.to(DEV).contiguous(memory_format=torch.channels_last)):
+        assert rel_err(Fn.warp_perspective(src, Hm.to(DEV), (40, 56)), ref) < 1e-4
+
+
+@pytest.mark.parametrize("C", [8, 128])
+def test_entropy_bottleneck_golden(ops_golden, C):
+    Fn, _ = _imp()
+    g, t = ops_golden, f"eb_C{C}_"
+    def params():
+        m = [T(g[f"{t}p__matrices.{i}"]).to(DEV).requires_grad_() for i in range(5)]
+        b = [T(g[f"{t}p__biases.{i}"]).to(DEV).requires_grad_() for i in range(5)]
+        f = [T(g[f"{t}p__factors.{i}"]).to(DEV).requires_grad_() for i in range(4)]
+        q = T(g[t + "p_quantiles"]).to(DEV).requires_grad_()
+        return m, b, f, q
+    m, b, f, q = params()
+    x = T(g[t + "x"]).to(DEV).requires_grad_()
+    zh, lik = Fn.entropy_bottleneck(x, m, b, f, q)
+    assert torch.equal(zh.detach().cpu(), T(g[t + "eval_xhat"]))                       # round(z-med)+med: bit-exact
+    torch.testing.assert_close(lik.detach().cpu().contiguous(), T(g[t + "eval_lik"]), rtol=2e-4, atol=1e-9)
+    (lik * T(g[t + "g_lik"]).to(DEV)).sum().backward()
+    names = [f"_matrices.{i}" for i in range(5)] + [f"_biases.{i}" for i in range(5)] + [f"_factors.{i}" for i in range(4)]
+    for n, p in zip(names, m + b + f):
+        assert rel_err(p.grad, T(g[t + "eval_d_" + n])) < 2e-3, n
+    assert rel_err(q.grad, T(g[t + "eval_d_quantiles"])) < 2e-3
+    # training mode with the injected noise
+    m, b, f, q = params()
+    x = T(g[t + "x"]).to(DEV).requires_grad_()
+    B, _, H, W = x.shape
+    noise = T(g[t + "noise"]).reshape(C, H, W, B).permute(3, 0, 1, 2).contiguous().to(DEV)
+    zt, lt = Fn.entropy_bottleneck(x, m, b, f, q, noise=noise)
+    torch.testing.assert_close(zt.detach().cpu().contiguous(), T(g[t + "train_xhat"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(lt.detach().cpu().contiguous(), T(g[t + "train_lik"]), rtol=2e-4, atol=1e-9)
+    ((lt * T(g[t + "g_lik"]).to(DEV)).sum() + (zt * T(g[t + "g_xhat"]).to(DEV)).sum()).backward()
+    assert rel_err(x.grad, T(g[t + "train_dx"])) < 2e-3
+    for n, p in zip(names, m + b + f):
+        assert rel_err(p.grad, T(g[t + "train_d_" + n])) < 2e-3, n
+
+
+def test_gmm_golden(ops_golden):
+    Fn, _ = _imp()
+    g = ops_golden
+    ins = [T(g[k]).to(DEV).requires_grad_() for k in ("gmm_y", "gmm_scales", "gmm_means", "gmm_weights")]
+    yh, lik = Fn.gaussian_mixture(*ins, K=5)
+    assert torch.equal(yh.detach().cpu(), T(g["gmm_eval_yhat"]))
+    assert torch.equal(Fn.quantize_symbols(ins[0].detach()).cpu(), T(g["gmm_symbols"]))      # int32, bit-exact
+    torch.testing.assert_close(lik.detach().cpu().contiguous(), T(g["gmm_eval_lik"]), rtol=1e-4, atol=1e-9)
+    (lik * T(g["gmm_g_lik"]).to(DEV)).sum().backward()
+    assert rel_err(ins[1].grad, T(g["gmm_eval_dscales"])) < 1e-3
+    assert rel_err(ins[2].grad, T(g["gmm_eval_dmeans"])) < 1e-3
+    assert rel_err(ins[3].grad, T(g["gmm_eval_dweights"])) < 1e-3
+    ins = [T(g[k]).to(DEV).requires_grad_() for k in ("gmm_y", "gmm_scales", "gmm_means", "gmm_weights")]
+    yh, lik = Fn.gaussian_mixture(*ins, K=5, noise=T(g["gmm_noise"]).to(DEV))
+    torch.testing.assert_close(lik.detach().cpu().contiguous(), T(g["gmm_train_lik"]), rtol=1e-4, atol=1e-9)
+    ((lik * T(g["gmm_g_lik"]).to(DEV)).sum() + (yh * T(g["gmm_g_yhat"]).to(DEV)).sum()).backward()
+    for t_, k in zip(ins, ("dy", "dscales", "dmeans", "dweights")):
+        assert rel_err(t_.grad, T(g["gmm_train_" + k])) < 1e-3, k
+
+
+def test_gaussian_conditional_golden(ops_golden):
+    Fn, _ = _imp()
+    g = ops_golden
+    y = T(g["gmm_y"]).to(DEV)
+    sc, mu = T(g["gmm_scales"])[:, :16].contiguous().to(DEV), T(g["gmm_means"])[:, :16].contiguous().to(DEV)
+    ins = [y.clone().requires_grad_(), sc.clone().requires_grad_(), mu.clone().requires_grad_()]
+    yh, lik = Fn.gaussian_conditional(*ins)
+    torch.testing.assert_close(yh.detach().cpu().contiguous(), T(g["gc_eval_yhat"]), rtol=0, atol=0)
+    assert torch.equal(Fn.quantize_symbols(y, mu).cpu(), T(g["gc_symbols"]))
+    torch.testing.assert_close(lik.detach().cpu().contiguous(), T(g["gc_eval_lik"]), rtol=1e-4, atol=1e-9)
+    (lik * T(g["gmm_g_lik"]).to(DEV)).sum().backward()
+    assert rel_err(ins[1].grad, T(g["gc_eval_dscales"])) < 1e-3
+    assert float((ins[2].grad.cpu() - T(g["gc_eval_dmeans"])).abs().max()) < 1e-6
+    ins = [y.clone().requires_grad_(), sc.clone().requires_grad_(), mu.clone().requires_grad_()]
+    yh, lik = Fn.gaussian_conditional(*ins, noise=T(g["gmm_noise"]).to(DEV))
+    ((lik * T(g["gmm_g_lik"]).to(DEV)).sum() + (yh * T(g["gmm_g_yhat"]).to(DEV)).sum()).backward()
+    torch.testing.assert_close(lik.detach().cpu().contiguous(), T(g["gc_train_lik"]), rtol=1e-4, atol=1e-9)
+    for t_, k in zip(ins, ("dy", "dscales", "dmeans")):
+        assert rel_err(t_.grad, T(g["gc_train_" + k])) < 1e-3, k
+    # scales / means as the two halves of one tensor (the chunk(2,1) of HESIC+)
+    both = torch.cat((sc, mu), 1).contiguous(memory_format=torch.channels_last)
+    s2, m2 = both.chunk(2, 1)
+    _, lik2 = Fn.gaussian_conditional(y, s2, m2)
+    torch.testing.assert_close(lik2.cpu().contiguous(), T(g["gc_eval_lik"]), rtol=1e-4, atol=1e-9)
+
+
+def test_hyper_glue(ops_golden):
+    Fn, O = _imp()
+    g = ops_golden
+    z = T(g["hy1_z"])
+    up = Fn.upsample4(z.to(DEV))
+    assert rel_err(up, T(g["hy2_up"])) < 1e-5
+    y1 = T(g["hy2_y1"])
+    zc = z.to(DEV).requires_grad_()
+    yc = y1.to(DEV).requires_grad_()
+    cat = Fn.upsample4_cat(zc, yc)
+    ref = torch.cat((T(g["hy2_up"]), y1), 1)
+    assert rel_err(cat, ref) < 1e-5
+    gg = rnd("hg_g", ref.shape)
+    cat.backward(gg.to(DEV))
+    zo = z.clone().requires_grad_()
+    O.upsample_bilinear_x4(zo).backward(gg[:, :z.shape[1]])
+    assert rel_err(zc.grad, zo.grad) < 1e-5 and rel_err(yc.grad, gg[:, z.shape[1]:]) == 0
+    x = rnd("hg_p", (3, 960, 9, 7), -2, 2)
+    ref = torch.nn.functional.leaky_relu(torch.amax(x, dim=(2, 3), keepdim=True), 0.01)
+    xd = x.to(DEV).requires_grad_()
+    out = Fn.spatial_max(xd, leaky=True)
+    assert torch.equal(out.cpu(), ref)
+    out.backward(torch.ones_like(out))
+    xo = x.clone().requires_grad_()
+    torch.nn.functional.leaky_relu(torch.amax(xo, dim=(2, 3), keepdim=True), 0.01).sum().backward()
+    assert rel_err(xd.grad, xo.grad) < 1e-6
+    K, M = 5, 192
+    w = rnd("hg_w", (K * M, K * M, 1, 1)) * 0.05
+    b = rnd("hg_b", (K * M,))
+    pooled = rnd("hg_pool", (3, K * M, 1, 1), -2, 2)
+    refw = O._mix_weights(torch.nn.functional.conv2d(pooled, w, b), K, M)
+    assert rel_err(Fn.mix_weights(pooled.to(DEV), w.to(DEV), b.to(DEV), K, M), refw) < 1e-5
+    lg = torch.nn.functional.conv2d(pooled, w, b).to(DEV).requires_grad_()
+    sw = Fn.softmax_k(lg, K, M)
+    assert rel_err(sw, refw) < 1e-5
+    gw = rnd("hg_gw", refw.shape)
+    sw.backward(gw.to(DEV))
+    lo = torch.nn.functional.conv2d(pooled, w, b).requires_grad_()
+    O._mix_weights(lo, K, M).backward(gw)
+    assert rel_err(lg.grad, lo.grad) < 1e-5
+
+
+def test_reductions():
+    Fn, _ = _imp()
+    lik = rnd("red_l", (2, 192, 16, 16), 1e-9, 1.0)
+    ref = float(torch.log2(lik.double()).sum())
+    assert abs(float(Fn.sum_log2(lik.to(DEV))) - ref) < 1e-3 * abs(ref) * 1e-3 + 1e-2
+    a, b = rnd("red_a", (2, 3, 64, 48)), rnd("red_b", (2, 3, 64, 48))
+    ref = float(((a.double() - b.double()) ** 2).sum())
+    got = float(Fn.sum_sq_diff(a.to(DEV), b.to(DEV).contiguous(memory_format=torch.channels_last)))
+    assert abs(got - ref) < 1e-5 * ref
