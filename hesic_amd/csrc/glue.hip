@@ -56,8 +56,10 @@ __global__ void upsample4_bwd_kernel(const T* __restrict__ dy, T* __restrict__ d
         const int iy = r % H;
         const int b = r / H;
         float acc = 0.f;
-        // outputs whose y0 or y1 equals iy lie within +-5 output rows of 4*iy
-        for (int oy = max(0, 4 * iy - 5); oy <= min(Ho - 1, 4 * iy + 5); ++oy) {
+        // outputs whose y0 or y1 equals iy have src coordinate in (iy-1, iy+1): oy in ((iy-1)/ry, (iy+1)/ry)
+        const int oy_lo = ry > 0.f ? max(0, (int)floorf((iy - 1) / ry)) : 0, oy_hi = ry > 0.f ? min(Ho - 1, (int)ceilf((iy + 1) / ry)) : Ho - 1;
+        const int ox_lo = rx > 0.f ? max(0, (int)floorf((ix - 1) / rx)) : 0, ox_hi = rx > 0.f ? min(Wo - 1, (int)ceilf((ix + 1) / rx)) : Wo - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             const float sy = ry * oy;
             const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
             const float ly = sy - y0;
@@ -65,7 +67,7 @@ __global__ void upsample4_bwd_kernel(const T* __restrict__ dy, T* __restrict__ d
             if (y0 == iy) wy += 1.f - ly;
             if (y1 == iy) wy += ly;
             if (wy == 0.f) continue;
-            for (int ox = max(0, 4 * ix - 5); ox <= min(Wo - 1, 4 * ix + 5); ++ox) {
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 const float sx = rx * ox;
                 const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
                 const float lx = sx - x0;

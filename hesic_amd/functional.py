@@ -158,8 +158,14 @@ class _ConvFn(torch.autograd.Function):
             gy = _nhwc(gy.to(x.dtype))
             if ctx.needs_input_grad[0]:
                 # data gradient = the opposite op with the same weight tensor read in the other layout
-                wp = packer.get(weight, mask, Cin, Cout, k, k, not transposed, False, x.dtype)
-                dx = _wide_conv(gy, wp, None, B, Ho, Wo, Cout, H, W, Cin, k, stride, pad, not transposed)
+                if Cout % 32 == 0 and Cin % 8 == 0:
+                    wp = packer.get(weight, mask, Cin, Cout, k, k, not transposed, False, x.dtype)
+                    dx = _wide_conv(gy, wp, None, B, Ho, Wo, Cout, H, W, Cin, k, stride, pad, not transposed)
+                else:   # odd channel counts (parity tests only): strided VALU kernel
+                    w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
+                    dx = torch.empty_like(x, memory_format=_CL)
+                    d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
+                    L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
                 if in_abs:
                     dx = dx * torch.sign(x)
             if ctx.needs_input_grad[1]:
