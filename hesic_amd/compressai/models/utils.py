@@ -1,0 +1,103 @@
+"""conv()/deconv() factories and state-dict helpers (reference: compressai/models/utils.py).
+
+``conv`` / ``deconv`` are *the* hook where the HIP convolutions are substituted: they
+return real ``nn.Conv2d`` / ``nn.ConvTranspose2d`` subclasses (same ``.weight`` / ``.bias``, same
+state-dict keys, ``isinstance`` checks and ``nn.Sequential`` indexing keep working) whose forward
+launches the implicit-GEMM MFMA kernel (csrc/conv_igemm.hip) or, for the 3-channel image side, the
+strided VALU kernels (csrc/sconv.hip).
+"""
+import torch
+import torch.nn as nn
+
+from hesic_amd import functional as Fn
+from hesic_amd import _lib as L
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d (square kernel, stride 1|2, padding k//2, no dilation/groups) on the HIP path."""
+
+    def _check(self):
+        k, s, p = self.kernel_size, self.stride, self.padding
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or self.dilation != (1, 1) or self.groups != 1 \
+                or self.padding_mode != "zeros":
+            raise NotImplementedError("hesic_amd conv: square kernel, equal strides, zero padding, no dilation/groups")
+
+    def run(self, x, act=L.ACT_NONE, in_abs=False, mask=None, tap_mask=0):
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                         padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
+                         mask=mask, tap_mask=tap_mask)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d with output_padding = stride-1 (what ``deconv`` builds) on the HIP path."""
+
+    def _check(self):
+        k, s, p, op = self.kernel_size, self.stride, self.padding, self.output_padding
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or op != (s[0] - 1, s[0] - 1) or self.dilation != (1, 1) \
+                or self.groups != 1:
+            raise NotImplementedError("hesic_amd deconv: square kernel, output_padding = stride-1, no dilation/groups")
+
+    def run(self, x, act=L.ACT_NONE):
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                         padding=self.padding[0], transposed=True, act=act, packer=self._packer)
+
+    def forward(self, x, output_size=None):
+        if output_size is not None:
+            raise NotImplementedError("hesic_amd deconv: output_size is fixed by output_padding = stride-1")
+        return self.run(x)
+
+
+def conv(in_channels, out_channels, kernel_size=5, stride=2):
+    return HipConv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
+
+
+def deconv(in_channels, out_channels, kernel_size=5, stride=2):
+    return HipConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              output_padding=stride - 1, padding=kernel_size // 2)
+
+
+# ---- state-dict helpers for the entropy-model buffers that change size on update()
+def find_named_module(module, query):
+    return next((m for n, m in module.named_modules() if n == query), None)
+
+
+def find_named_buffer(module, query):
+    return next((b for n, b in module.named_buffers() if n == query), None)
+
+
+def _update_registered_buffer(module, buffer_name, state_dict_key, state_dict, policy="resize_if_empty",
+                              dtype=torch.int):
+    new_size = state_dict[state_dict_key].size()
+    registered_buf = find_named_buffer(module, buffer_name)
+    if policy in ("resize_if_empty", "resize"):
+        if registered_buf is None:
+            raise RuntimeError(f'buffer "{buffer_name}" was not registered')
+        if policy == "resize" or registered_buf.numel() == 0:
+            registered_buf.resize_(new_size)
+    elif policy == "register":
+        if registered_buf is not None:
+            raise RuntimeError(f'buffer "{buffer_name}" was already registered')
+        module.register_buffer(buffer_name, torch.empty(new_size, dtype=dtype).fill_(0))
+    else:
+        raise ValueError(f'Invalid policy "{policy}"')
+
+
+def update_registered_buffers(module, module_name, buffer_names, state_dict, policy="resize_if_empty",
+                              dtype=torch.int):
+    """Resize / register ``buffer_names`` of ``module`` so a checkpoint whose CDF tables were filled by
+    ``update()`` loads strictly (reference: compressai/models/utils.py:70-101)."""
+    valid = [n for n, _ in module.named_buffers()]
+    for name in buffer_names:
+        if name not in valid:
+            raise ValueError(f'Invalid buffer name "{name}"')
+    for name in buffer_names:
+        _update_registered_buffer(module, name, f"{module_name}.{name}", state_dict, policy, dtype)

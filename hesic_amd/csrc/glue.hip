@@ -186,6 +186,23 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
     if (threadIdx.x == 0) atomicAdd(q.out, red[0] + red[1] + red[2] + red[3]);
 }
 
+__global__ void log_bwd_kernel(const float* __restrict__ lik, float scale, float* __restrict__ g, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] = scale / lik[i];
+}
+__global__ void sq_diff_bwd_kernel(const SqArgs q, float scale, float* __restrict__ g) {
+    const int64_t n = (int64_t)q.B * q.C * q.H * q.W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int x = r % q.W; r /= q.W;
+        const int y = r % q.H; r /= q.H;
+        const int c = r % q.C;
+        const int b = r / q.C;
+        const float va = ld_any(q.a, b * q.as[0] + c * q.as[1] + y * q.as[2] + x * q.as[3], q.a_dt);
+        const float vb = ld_any(q.b, b * q.bs[0] + c * q.bs[1] + y * q.bs[2] + x * q.bs[3], q.b_dt);
+        g[i] = scale * (va - vb);
+    }
+}
+
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, int act) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -285,6 +302,22 @@ extern "C" int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_str
     for (int i = 0; i < 4; ++i) { q.as[i] = a_strides[i]; q.bs[i] = b_strides[i]; }
     hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * C * H * W, 256, 512)), dim3(256), 0, (hipStream_t)stream, q);
     HESIC_LAUNCH_RETURN("sum_sq_diff");
+}
+
+extern "C" int hesic_log_backward(const float* lik, float scale, float* g_lik, int64_t n, void* stream) {
+    HESIC_CHECK_ARG(lik && g_lik && n > 0, "log_backward: bad arguments");
+    hipLaunchKernelGGL(log_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, lik, scale, g_lik, n);
+    HESIC_LAUNCH_RETURN("log_backward");
+}
+
+extern "C" int hesic_sq_diff_backward(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
+                                      const int64_t b_strides[4], int B, int C, int H, int W, float scale, float* g_a, void* stream) {
+    HESIC_CHECK_ARG(a && b && g_a && a_strides && b_strides && B > 0 && C > 0 && H > 0 && W > 0, "sq_diff_backward: bad arguments");
+    SqArgs q;
+    q.a = a; q.b = b; q.a_dt = a_dtype; q.b_dt = b_dtype; q.B = B; q.C = C; q.H = H; q.W = W; q.out = nullptr;
+    for (int i = 0; i < 4; ++i) { q.as[i] = a_strides[i]; q.bs[i] = b_strides[i]; }
+    hipLaunchKernelGGL(sq_diff_bwd_kernel, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, q, scale, g_a);
+    HESIC_LAUNCH_RETURN("sq_diff_backward");
 }
 
 extern "C" int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream) {

@@ -1,0 +1,161 @@
+// Host-side entropy-coding helpers (see hesic_host.h).  Sequential by nature (rANS is a serial state
+// machine); they sit on the bit-stream path, not on the throughput path.
+#include "hesic_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+constexpr int kPrecision = 16;        // probability bits of the model CDFs
+constexpr int kBypassBits = 4;        // raw-bit escape width
+constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1;
+constexpr uint64_t kLow = 1ull << 31; // normalisation interval lower bound (ryg rans64)
+
+struct Item { uint16_t start, range; bool raw; };
+
+// state update for a modelled symbol / for `bits` raw bits (freq = 2^(16-bits) in 16-bit terms)
+inline void put(uint64_t& x, std::vector<uint32_t>& words, uint32_t start, uint32_t freq, uint32_t scale_bits) {
+    const uint64_t x_max = ((kLow >> scale_bits) << 32) * freq;
+    if (x >= x_max) { words.push_back((uint32_t)x); x >>= 32; }
+    x = ((x / freq) << scale_bits) + (x % freq) + start;
+}
+inline void put_bits(uint64_t& x, std::vector<uint32_t>& words, uint32_t val, uint32_t nbits) {
+    const uint64_t x_max = ((kLow >> 16) << 32) * (uint64_t)(1u << (16 - nbits));
+    if (x >= x_max) { words.push_back((uint32_t)x); x >>= 32; }
+    x = (x << nbits) | val;
+}
+}  // namespace
+
+struct hesic_rans_encoder { std::vector<Item> q; };
+struct hesic_rans_decoder { std::vector<uint32_t> words; size_t pos = 0; uint64_t x = 0; bool ready = false; };
+
+extern "C" int hesic_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf) {
+    if (!pmf || !cdf || n < 1 || precision < 1 || precision > 31) return -1;
+    const uint32_t one = 1u << precision;
+    // 1) integer frequencies, 2) rescale so they sum to ~2^precision, 3) prefix sum, 4) repair zero-width bins
+    uint32_t total = 0;
+    cdf[0] = 0;
+    for (int i = 0; i < n; ++i) { cdf[i + 1] = (uint32_t)std::round(pmf[i] * (float)one); total += cdf[i + 1]; }
+    if (total == 0) return -1;
+    uint32_t run = 0;
+    for (int i = 0; i <= n; ++i) { run += (uint32_t)(((uint64_t)one * cdf[i]) / total); cdf[i] = run; }
+    cdf[n] = one;
+    for (int i = 0; i < n; ++i) {
+        if (cdf[i] != cdf[i + 1]) continue;
+        // steal one count from the narrowest bin that can spare it (width > 1), first such bin wins ties
+        uint32_t best = ~0u;
+        int donor = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t wdt = cdf[j + 1] - cdf[j];
+            if (wdt > 1 && wdt < best) { best = wdt; donor = j; }
+        }
+        if (donor < 0) return -1;
+        if (donor < i) for (int j = donor + 1; j <= i; ++j) cdf[j]--;
+        else for (int j = i + 1; j <= donor; ++j) cdf[j]++;
+    }
+    return 0;
+}
+
+extern "C" hesic_rans_encoder* hesic_rans_encoder_new(void) { return new hesic_rans_encoder(); }
+extern "C" void hesic_rans_encoder_free(hesic_rans_encoder* e) { delete e; }
+
+extern "C" int hesic_rans_encoder_push(hesic_rans_encoder* e, const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                       const int32_t* cdfs, int ncdf, int stride, const int32_t* sizes, const int32_t* offsets) {
+    if (!e || !symbols || !indexes || !cdfs || !sizes || !offsets || n < 0) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = indexes[i];
+        if (ci < 0 || ci >= ncdf || sizes[ci] < 2 || sizes[ci] > stride) return -1;
+        const int32_t* cdf = cdfs + (int64_t)ci * stride;
+        const int32_t last = sizes[ci] - 2;          // index of the escape bin
+        int32_t v = symbols[i] - offsets[ci];
+        uint32_t raw = 0;
+        if (v < 0) { raw = (uint32_t)(-2 * v - 1); v = last; }        // odd  => below the support
+        else if (v >= last) { raw = (uint32_t)(2 * (v - last)); v = last; }  // even => at/above it
+        e->q.push_back({(uint16_t)cdf[v], (uint16_t)(cdf[v + 1] - cdf[v]), false});
+        if (v == last) {
+            int32_t nib = 0;
+            while ((raw >> (nib * kBypassBits)) != 0) ++nib;
+            int32_t c = nib;                          // nibble count in unary-ish base-15 chunks
+            while (c >= (int32_t)kBypassMax) { e->q.push_back({(uint16_t)kBypassMax, (uint16_t)(kBypassMax + 1), true}); c -= kBypassMax; }
+            e->q.push_back({(uint16_t)c, (uint16_t)(c + 1), true});
+            for (int32_t j = 0; j < nib; ++j) {
+                const uint16_t d = (uint16_t)((raw >> (j * kBypassBits)) & kBypassMax);
+                e->q.push_back({d, (uint16_t)(d + 1), true});
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t hesic_rans_encoder_flush(hesic_rans_encoder* e, uint8_t* out, int64_t cap) {
+    if (!e) return -1;
+    uint64_t x = kLow;
+    std::vector<uint32_t> w;          // words in emission order; the stream is their reverse
+    w.reserve(e->q.size() / 2 + 4);
+    for (size_t i = e->q.size(); i-- > 0;) {
+        const Item& s = e->q[i];
+        if (s.raw) put_bits(x, w, s.start, kBypassBits);
+        else put(x, w, s.start, s.range, kPrecision);
+    }
+    w.push_back((uint32_t)(x >> 32));
+    w.push_back((uint32_t)x);
+    const int64_t nbytes = (int64_t)w.size() * 4;
+    if (!out || cap < nbytes) return nbytes;
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    for (size_t i = 0; i < w.size(); ++i) { const uint32_t v = w[w.size() - 1 - i]; std::memcpy(o + i, &v, 4); }
+    e->q.clear();
+    return nbytes;
+}
+
+extern "C" hesic_rans_decoder* hesic_rans_decoder_new(void) { return new hesic_rans_decoder(); }
+extern "C" void hesic_rans_decoder_free(hesic_rans_decoder* d) { delete d; }
+
+extern "C" int hesic_rans_decoder_set_stream(hesic_rans_decoder* d, const uint8_t* bytes, int64_t nbytes) {
+    if (!d || !bytes || nbytes < 8 || nbytes % 4) return -1;
+    d->words.resize((size_t)nbytes / 4);
+    std::memcpy(d->words.data(), bytes, (size_t)nbytes);
+    d->x = (uint64_t)d->words[0] | ((uint64_t)d->words[1] << 32);
+    d->pos = 2;
+    d->ready = true;
+    return 0;
+}
+
+namespace {
+inline uint32_t next_word(hesic_rans_decoder* d) { return d->pos < d->words.size() ? d->words[d->pos++] : 0u; }
+inline uint32_t get_bits(hesic_rans_decoder* d, uint32_t nbits) {
+    const uint32_t v = (uint32_t)(d->x & ((1u << nbits) - 1));
+    d->x >>= nbits;
+    if (d->x < kLow) d->x = (d->x << 32) | next_word(d);
+    return v;
+}
+}  // namespace
+
+extern "C" int hesic_rans_decoder_decode(hesic_rans_decoder* d, const int32_t* indexes, int64_t n, const int32_t* cdfs, int ncdf,
+                                         int stride, const int32_t* sizes, const int32_t* offsets, int32_t* out) {
+    if (!d || !d->ready || !indexes || !cdfs || !sizes || !offsets || !out || n < 0) return -1;
+    const uint32_t mask = (1u << kPrecision) - 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = indexes[i];
+        if (ci < 0 || ci >= ncdf || sizes[ci] < 2 || sizes[ci] > stride) return -1;
+        const int32_t* cdf = cdfs + (int64_t)ci * stride;
+        const int32_t last = sizes[ci] - 2;
+        const uint32_t slot = (uint32_t)(d->x & mask);
+        int32_t s = 0;                                 // largest s with cdf[s] <= slot
+        while (s + 1 < sizes[ci] && (uint32_t)cdf[s + 1] <= slot) ++s;
+        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+        d->x = (uint64_t)freq * (d->x >> kPrecision) + slot - start;
+        if (d->x < kLow) d->x = (d->x << 32) | next_word(d);
+        int32_t v = s;
+        if (s == last) {
+            int32_t c = (int32_t)get_bits(d, kBypassBits), nib = c;
+            while (c == (int32_t)kBypassMax) { c = (int32_t)get_bits(d, kBypassBits); nib += c; }
+            uint32_t raw = 0;
+            for (int32_t j = 0; j < nib; ++j) raw |= get_bits(d, kBypassBits) << (j * kBypassBits);
+            v = (int32_t)(raw >> 1);
+            v = (raw & 1) ? -v - 1 : v + last;
+        }
+        out[i] = v + offsets[ci];
+    }
+    return 0;
+}

@@ -1,0 +1,40 @@
+/* hesic_host.h -- C ABI of libhesic_host.so: the host-side (CPU, sequential) entropy-coding helpers that
+ * the reference ships as two pybind11 extensions and imports at module load time:
+ *   compressai._CXX.pmf_to_quantized_cdf   (compressai/cpp_exts/ops/ops.cpp:24-81)
+ *   compressai.ans.{BufferedRansEncoder,RansEncoder,RansDecoder} (compressai/cpp_exts/rans/rans_interface.cpp)
+ * Byte-exact with the reference coder: 64-bit rANS state, 32-bit word emission, lower bound 2^31,
+ * 16-bit probabilities, 4-bit bypass escape for symbols outside the CDF support.
+ * All pointers are HOST pointers.  Return value 0 = ok, -1 = bad argument.                              */
+#ifndef HESIC_HOST_H
+#define HESIC_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cdf_out has n+1 entries; cdf_out[0]=0, cdf_out[n]=1<<precision, strictly increasing. */
+int hesic_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf_out);
+
+typedef struct hesic_rans_encoder hesic_rans_encoder;
+typedef struct hesic_rans_decoder hesic_rans_decoder;
+
+hesic_rans_encoder* hesic_rans_encoder_new(void);
+void hesic_rans_encoder_free(hesic_rans_encoder*);
+/* Queue n symbols.  cdfs: [ncdf][cdf_stride] int32 row-major; cdf_sizes/offsets: [ncdf]. */
+int hesic_rans_encoder_push(hesic_rans_encoder*, const int32_t* symbols, const int32_t* indexes, int64_t n,
+                            const int32_t* cdfs, int ncdf, int cdf_stride, const int32_t* cdf_sizes,
+                            const int32_t* offsets);
+/* Encode everything queued (last symbol first) and reset.  Returns the stream size in bytes; copies it to
+ * out if cap is large enough (call with out=NULL to size the buffer: the queue is kept in that case).   */
+int64_t hesic_rans_encoder_flush(hesic_rans_encoder*, uint8_t* out, int64_t cap);
+
+hesic_rans_decoder* hesic_rans_decoder_new(void);
+void hesic_rans_decoder_free(hesic_rans_decoder*);
+int hesic_rans_decoder_set_stream(hesic_rans_decoder*, const uint8_t* bytes, int64_t nbytes);
+int hesic_rans_decoder_decode(hesic_rans_decoder*, const int32_t* indexes, int64_t n, const int32_t* cdfs, int ncdf,
+                              int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -562,3 +562,53 @@ def sum_sq_diff(a, b, out=None):
     sb = (C.c_int64 * 4)(*b.stride())
     L.call("hesic_sum_sq_diff", L.ptr(a), L.dt(a), sa, L.ptr(b), L.dt(b), sb, B, Cc, H, W, L.ptr(out), L.stream())
     return out
+
+
+class _RdLossFn(torch.autograd.Function):
+    """RateDistortionLoss (ywz/mywork/newtrain1.py:37-56) as two kinds of HIP reductions:
+    loss = lmbda*255^2*(MSE1+MSE2) + sum_t sum(log lik_t)/(-ln2 * B*H*W).  Returns (loss, bpp, mse)."""
+
+    @staticmethod
+    def forward(ctx, lmbda, x1, x2, x1_hat, x2_hat, *liks):
+        import math
+        B, Cc, H, W = x1.shape
+        npix = B * H * W
+        acc = torch.zeros(3, dtype=torch.float64, device=x1.device)
+        liks = tuple(l if (l.is_contiguous() or l.is_contiguous(memory_format=_CL)) else l.contiguous() for l in liks)
+        for l in liks:
+            sum_log2(l, acc[0:1])
+        sum_sq_diff(x1_hat, x1, acc[1:2])
+        sum_sq_diff(x2_hat, x2, acc[2:3])
+        bpp = -acc[0] / npix
+        mse = (acc[1] + acc[2]) / (B * Cc * H * W)
+        loss = lmbda * 255.0 ** 2 * mse + bpp
+        ctx.save_for_backward(x1, x2, x1_hat, x2_hat, *liks)
+        ctx.meta = (float(lmbda), npix, B * Cc * H * W, -1.0 / (math.log(2.0) * npix))
+        return loss.float(), bpp.float(), mse.float()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_bpp, g_mse):
+        x1, x2, x1_hat, x2_hat, *liks = ctx.saved_tensors
+        lmbda, npix, numel, lik_scale = ctx.meta
+        g = 1.0   # the loss is the root of the graph (loss.backward()); reading g_loss would force a host sync
+        B, Cc, H, W = x1.shape
+        grads = []
+        for xh, x in ((x1_hat, x1), (x2_hat, x2)):
+            gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+            sa, sb = (C.c_int64 * 4)(*xh.stride()), (C.c_int64 * 4)(*x.stride())
+            L.call("hesic_sq_diff_backward", L.ptr(xh), L.dt(xh), sa, L.ptr(x), L.dt(x), sb, B, Cc, H, W,
+                   g * lmbda * 255.0 ** 2 * 2.0 / numel, L.ptr(gx), L.stream())
+            grads.append(gx)
+        gl = []
+        for l in liks:
+            o = torch.empty_like(l)
+            L.call("hesic_log_backward", L.ptr(l), g * lik_scale, L.ptr(o), l.numel(), L.stream())
+            gl.append(o)
+        return (None, None, None, grads[0], grads[1], *gl)
+
+
+def rd_loss(out, x1, x2, lmbda):
+    """dict(loss, bpp_loss, mse_loss) like the reference's criterion; differentiable through ``loss``."""
+    lk = out["likelihoods"]
+    loss, bpp, mse = _RdLossFn.apply(lmbda, x1, x2, out["x1_hat"], out["x2_hat"], lk["y1"], lk["y2"], lk["z1"], lk["z2"])
+    return {"loss": loss, "bpp_loss": bpp.detach(), "mse_loss": mse.detach()}

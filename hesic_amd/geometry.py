@@ -1,0 +1,45 @@
+"""The two ``kornia`` calls of the HESIC path (third party, neither vendored by the reference nor
+installed here): ``warp_perspective`` (hot path, ywz/mywork/newnet1.py:746,753,767) and
+``get_perspective_transform`` (the step before it in the ``_real`` scripts,
+ywz/mywork/newtrain1_real.py:113-131).
+
+Semantics: kornia's default changed across releases and the reference does not pin a
+version.  ``DEFAULT_ALIGN_CORNERS = True`` selects the exact inverse-map bilinear resample
+(kornia >= 0.5, == cv2.warpPerspective); pass ``align_corners=False`` for the <= 0.4 behaviour.
+"""
+import torch
+
+from . import functional as Fn
+
+DEFAULT_ALIGN_CORNERS = True
+
+
+def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_corners=None):
+    """dst(x', y') = bilinear(src, M^-1 (x', y', 1)), zeros outside.  src (B,C,H,W), M (B,3,3) maps source
+    pixels to destination pixels, dsize = (H_out, W_out).  HIP kernel: csrc/warp.hip."""
+    if flags != "bilinear":
+        raise NotImplementedError("hesic_amd.warp_perspective: bilinear only")
+    if border_mode not in (None, "zeros"):
+        raise NotImplementedError("hesic_amd.warp_perspective: zero padding only")
+    if src.dim() != 4 or M.shape[-2:] != (3, 3):
+        raise ValueError(f"warp_perspective: expected src (B,C,H,W) and M (B,3,3), got {tuple(src.shape)}, {tuple(M.shape)}")
+    ac = DEFAULT_ALIGN_CORNERS if align_corners is None else bool(align_corners)
+    if M.shape[0] != src.shape[0]:
+        M = M.expand(src.shape[0], 3, 3)
+    return Fn.warp_perspective(src, M, dsize, ac)
+
+
+def get_perspective_transform(src, dst):
+    """4-point DLT: (B,4,2) x (B,4,2) -> (B,3,3) with M @ [x,y,1] ~ [x',y',1].  An 8x8 solve per pair --
+    host-side plumbing upstream of the path."""
+    if src.shape[-2:] != (4, 2) or dst.shape != src.shape:
+        raise ValueError("get_perspective_transform: expected (B,4,2) point sets")
+    B = src.shape[0]
+    x, y, u, v = src[..., 0], src[..., 1], dst[..., 0], dst[..., 1]
+    zeros, ones = torch.zeros_like(x), torch.ones_like(x)
+    ax = torch.stack([x, y, ones, zeros, zeros, zeros, -x * u, -y * u], -1)
+    ay = torch.stack([zeros, zeros, zeros, x, y, ones, -x * v, -y * v], -1)
+    A = torch.cat([ax, ay], 1).double()
+    b = torch.cat([u, v], 1).double().unsqueeze(-1)
+    h = torch.linalg.solve(A, b).squeeze(-1)
+    return torch.cat([h, torch.ones(B, 1, dtype=h.dtype, device=h.device)], 1).reshape(B, 3, 3).to(src.dtype)

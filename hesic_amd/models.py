@@ -1,0 +1,363 @@
+"""HESIC (``HSIC``) and HESIC+ (``HSICJoint``): the build's counterparts of the reference model files
+``ywz/mywork/newnet1.py`` and ``ywz/mywork/newnet1_joint.py``.
+
+Same module tree, parameter names and shapes (reference checkpoints load with ``strict=True``), same
+forward semantics including its quirks, but the forward is written against the fused
+operators of ``hesic_amd.functional``: activations and ``abs`` ride in the conv kernels, the
+``Upsample x4 + cat`` is one buffer, the Python double loop of ``spatial_pool2d`` is one reduction, the
+1x1 conv + softmax head is one kernel, and the duplicated ``warp(x1_hat)`` (:753 == :767) runs once.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from compressai.entropy_models import EntropyBottleneck, GaussianConditional, GaussianMixtureConditional
+from compressai.layers import GDN, MaskedConv2d
+from compressai.models.utils import HipConv2d, conv, deconv
+
+from . import _lib as L
+from . import functional as Fn
+from .geometry import warp_perspective
+
+RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
+
+
+class StereoCompressionModel(nn.Module):
+    """Base with TWO entropy bottlenecks (reference newnet1.py:36-104): ``parameters()`` skips them,
+    ``aux_parameters()`` yields only them; conv weights get kaiming init only if built before this ctor
+    runs (they are not, as in the reference, so PyTorch default init stays -- SURVEY.md 8a)."""
+
+    def __init__(self, entropy_bottleneck_channels, init_weights=True):
+        super().__init__()
+        self.entropy_bottleneck1 = EntropyBottleneck(entropy_bottleneck_channels)
+        self.entropy_bottleneck2 = EntropyBottleneck(entropy_bottleneck_channels)
+        if init_weights:
+            self._initialize_weights()
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def parameters(self, recurse=True):
+        for m in self.children():
+            if not isinstance(m, EntropyBottleneck):
+                yield from m.parameters()
+
+    def aux_parameters(self):
+        for m in self.children():
+            if isinstance(m, EntropyBottleneck):
+                yield from m.parameters()
+
+    def update(self, force=False):
+        for m in self.children():
+            if isinstance(m, EntropyBottleneck):
+                m.update(force=force)
+
+
+# ------------------------------------------------------------------------------ analysis / synthesis
+class Encoder1(nn.Module):
+    """g_a: conv5s2 -> GDN x3 -> conv5s2 (newnet1.py:580-601)."""
+
+    def __init__(self, N, M):
+        super().__init__()
+        self.g_a_conv1, self.g_a_gdn1 = conv(3, N), GDN(N)
+        self.g_a_conv2, self.g_a_gdn2 = conv(N, N), GDN(N)
+        self.g_a_conv3, self.g_a_gdn3 = conv(N, N), GDN(N)
+        self.g_a_conv4 = conv(N, M)
+
+    def stack(self, x):
+        x = self.g_a_gdn1(self.g_a_conv1(x))
+        x = self.g_a_gdn2(self.g_a_conv2(x))
+        x = self.g_a_gdn3(self.g_a_conv3(x))
+        return self.g_a_conv4(x)
+
+    def forward(self, x):
+        return self.stack(x)
+
+
+class Encoder2(Encoder1):
+    """cat(x1_warp, x2) -> conv5s1(6->3) -> GDN(3) -> g_a (newnet1.py:626-655)."""
+
+    def __init__(self, N, M):
+        nn.Module.__init__(self)
+        self.pre_conv = conv(6, 3, stride=1)
+        self.pre_gdn = GDN(3)
+        self.g_a_conv1, self.g_a_gdn1 = conv(3, N), GDN(N)
+        self.g_a_conv2, self.g_a_gdn2 = conv(N, N), GDN(N)
+        self.g_a_conv3, self.g_a_gdn3 = conv(N, N), GDN(N)
+        self.g_a_conv4 = conv(N, M)
+
+    def forward(self, x1_warp, x2):
+        t = self.pre_gdn(self.pre_conv(torch.cat((x1_warp.float(), x2.float()), 1)))
+        return self.stack(t)
+
+
+class Decoder1(nn.Module):
+    """g_s: deconv5s2 -> IGDN x3 -> deconv5s2 (newnet1.py:603-624)."""
+
+    def __init__(self, N, M):
+        super().__init__()
+        self.g_s_conv1, self.g_s_gdn1 = deconv(M, N), GDN(N, inverse=True)
+        self.g_s_conv2, self.g_s_gdn2 = deconv(N, N), GDN(N, inverse=True)
+        self.g_s_conv3, self.g_s_gdn3 = deconv(N, N), GDN(N, inverse=True)
+        self.g_s_conv4 = deconv(N, 3)
+
+    def stack(self, y):
+        y = self.g_s_gdn1(self.g_s_conv1(y))
+        y = self.g_s_gdn2(self.g_s_conv2(y))
+        y = self.g_s_gdn3(self.g_s_conv3(y))
+        return self.g_s_conv4(y)
+
+    def forward(self, y_hat):
+        return self.stack(y_hat)
+
+
+class Decoder2(Decoder1):
+    """g_s -> IGDN(3) -> cat(., x1_hat_warp) -> deconv5s1(6->3) (newnet1.py:657-692)."""
+
+    def __init__(self, N, M):
+        super().__init__(N, M)
+        self.after_gdn = GDN(3, inverse=True)
+        self.after_conv = deconv(6, 3, stride=1)
+
+    def forward(self, y_hat, x1_hat_warp):
+        t = self.after_gdn(self.stack(y_hat))
+        return self.after_conv(torch.cat((t, x1_hat_warp.float()), 1))
+
+
+# ----------------------------------------------------------------------------------- hyper networks
+class encode_hyper(nn.Module):
+    """|y| -> conv5s1+ReLU -> conv5s2+ReLU -> conv5s2 (newnet1.py:420-437); abs and ReLUs are fused."""
+
+    def __init__(self, N, M):
+        super().__init__()
+        self.encode_hyper = nn.Sequential(conv(M, N, kernel_size=5, stride=1), nn.ReLU(), conv(N, N, kernel_size=5),
+                                          nn.ReLU(), conv(N, N, kernel_size=5))
+
+    def forward(self, y):
+        s = self.encode_hyper
+        t = s[0].run(y, act=RELU, in_abs=True)
+        t = s[2].run(t, act=RELU)
+        return s[4].run(t)
+
+
+class spatial_pool2d(nn.Module):
+    """Global spatial max per (sample, channel) (newnet1.py:441-453) as one reduction kernel."""
+
+    def forward(self, X):
+        return Fn.spatial_max(X, leaky=False)
+
+
+def _mixture_weights(head, feat, K, M):
+    """spatial max -> LeakyReLU -> conv1x1 -> softmax over K (newnet1.py:496-512), channel = k*M+m."""
+    pooled = Fn.spatial_max(feat, leaky=True)
+    c1 = head[5]
+    if torch.is_grad_enabled() and (pooled.requires_grad or c1.weight.requires_grad):
+        return Fn.softmax_k(c1.run(pooled), K, M)
+    return Fn.mix_weights(pooled, c1.weight, c1.bias, K, M)
+
+
+class gmm_hyper_y1(nn.Module):
+    """z1_hat -> (sigma, means, weights), each K*M channels at 4x the resolution (newnet1.py:456-514)."""
+
+    def __init__(self, N, M, K):
+        super().__init__()
+        self.N, self.M, self.K = N, M, K
+        self.gmm_sigma = nn.Sequential(deconv(N, N, kernel_size=5), nn.ReLU(), deconv(N, N, kernel_size=5), nn.ReLU(),
+                                       conv(N, M * K, kernel_size=5, stride=1), nn.ReLU())
+        self.gmm_means = nn.Sequential(deconv(N, N, kernel_size=5), nn.LeakyReLU(), deconv(N, N, kernel_size=5),
+                                       nn.LeakyReLU(), conv(N, M * K, kernel_size=5, stride=1))
+        self.gmm_weights = nn.Sequential(deconv(N, N, kernel_size=5), nn.LeakyReLU(), deconv(N, M * K, kernel_size=5),
+                                         spatial_pool2d(), nn.LeakyReLU(), conv(M * K, M * K, kernel_size=1, stride=1))
+
+    def forward(self, z):
+        s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        sigma = s[4].run(s[2].run(s[0].run(z, act=RELU), act=RELU), act=RELU)
+        means = m[4].run(m[2].run(m[0].run(z, act=LEAKY), act=LEAKY))
+        feat = w[2].run(w[0].run(z, act=LEAKY))
+        return sigma, means, _mixture_weights(w, feat, self.K, self.M)
+
+
+class gmm_hyper_y2(nn.Module):
+    """(z2_hat, y1_hat_warp) -> (sigma, means, weights) (newnet1.py:517-577); upsample + cat fused."""
+
+    def __init__(self, N, M, K):
+        super().__init__()
+        self.N, self.M, self.K = N, M, K
+        self.upsample_layer = nn.UpsamplingBilinear2d(scale_factor=4)   # no parameters; kept for the module tree
+        self.gmm_sigma = nn.Sequential(conv(N + M, N, kernel_size=5, stride=1), nn.ReLU(), conv(N, N, kernel_size=5, stride=1),
+                                       nn.ReLU(), conv(N, M * K, kernel_size=5, stride=1), nn.ReLU())
+        self.gmm_means = nn.Sequential(conv(N + M, N, kernel_size=5, stride=1), nn.LeakyReLU(),
+                                       conv(N, N, kernel_size=5, stride=1), nn.LeakyReLU(),
+                                       conv(N, M * K, kernel_size=5, stride=1))
+        self.gmm_weights = nn.Sequential(conv(N + M, N, kernel_size=5, stride=1), nn.LeakyReLU(),
+                                         conv(N, M * K, kernel_size=5, stride=1), spatial_pool2d(), nn.LeakyReLU(),
+                                         conv(M * K, M * K, kernel_size=1, stride=1))
+
+    def forward(self, z2, y1):
+        c = Fn.upsample4_cat(z2, y1)
+        s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        sigma = s[4].run(s[2].run(s[0].run(c, act=RELU), act=RELU), act=RELU)
+        means = m[4].run(m[2].run(m[0].run(c, act=LEAKY), act=LEAKY))
+        feat = w[2].run(w[0].run(c, act=LEAKY))
+        return sigma, means, _mixture_weights(w, feat, self.K, self.M)
+
+
+def _noise(nz, key, like, training):
+    if not training:
+        return None
+    if nz is not None and key in nz:
+        return nz[key].to(like.device)
+    return torch.empty_like(like).uniform_(-0.5, 0.5)
+
+
+def _quant(model, y, nz, key, training):
+    """EntropyModel._quantize(y, 'noise' | 'dequantize') without means (newnet1.py:755)."""
+    if training:
+        return y + _noise(nz, key, y, True).to(y.dtype)
+    return model._quantize(y, "dequantize")
+
+
+# --------------------------------------------------------------------------------------------- HESIC
+class HSIC(StereoCompressionModel):
+    """HESIC (reference ``HSIC``, ywz/mywork/newnet1.py:696-783)."""
+
+    def __init__(self, N=128, M=192, K=5, **kwargs):
+        super().__init__(entropy_bottleneck_channels=N, **kwargs)
+        self.gaussian1 = GaussianMixtureConditional(K=K)
+        self.gaussian2 = GaussianMixtureConditional(K=K)
+        self.N, self.M, self.K = int(N), int(M), int(K)
+        self.encoder1, self.encoder2 = Encoder1(N, M), Encoder2(N, M)
+        self.decoder1, self.decoder2 = Decoder1(N, M), Decoder2(N, M)
+        self._h_a1, self._h_a2 = encode_hyper(N=N, M=M), encode_hyper(N=N, M=M)
+        self._h_s1, self._h_s2 = gmm_hyper_y1(N=N, M=M, K=K), gmm_hyper_y2(N=N, M=M, K=K)
+
+    def forward(self, x1, x2, h_matrix, noise=None):
+        """``noise`` (training only, optional): dict z1,y1,y1w,z2,y2 of U(-1/2,1/2) draws, in the order the
+        reference makes them; absent keys are drawn on the device."""
+        tr = self.training
+        size = (x1.shape[-2], x1.shape[-1])
+        y1 = self.encoder1(x1)
+        z1 = self._h_a1(y1)
+        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, _noise(noise, "z1", z1, tr))
+        s1, m1, w1 = self._h_s1(z1_hat)
+        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, w1, noise=_noise(noise, "y1", y1, tr))
+        x1_hat = self.decoder1(y1_hat)
+
+        x1_warp = warp_perspective(x1, h_matrix, size)
+        y2 = self.encoder2(x1_warp, x2)
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)          # :753 and :767 are the same tensor
+        y1_hat_w = _quant(self.gaussian1, self.encoder1(x1_hat_warp), noise, "y1w", tr)
+
+        z2 = self._h_a2(y2)
+        z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, _noise(noise, "z2", z2, tr))
+        s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w)
+        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2, noise=_noise(noise, "y2", y2, tr))
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+                "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+# -------------------------------------------------------------------------------------------- HESIC+
+def _seq3(seq, x, last_act=NONE):
+    """conv/deconv -> LeakyReLU -> conv/deconv -> LeakyReLU -> conv (the h_a / h_s / entropy_parameters
+    Sequentials of newnet1_joint.py:611-665) with the activations fused."""
+    return seq[4].run(seq[2].run(seq[0].run(x, act=LEAKY), act=LEAKY), act=last_act)
+
+
+class HSICJoint(StereoCompressionModel):
+    """HESIC+ (reference ``HSIC`` of ywz/mywork/newnet1_joint.py:585-753): Minnen-style hyperprior +
+    masked-conv context model + 1x1 entropy-parameter nets + single Gaussian."""
+
+    def __init__(self, N=128, M=192, K=5, **kwargs):
+        super().__init__(entropy_bottleneck_channels=N, **kwargs)
+        self.gaussian1 = GaussianMixtureConditional(K=K)      # only its _quantize is used (:715)
+        self.gaussian2 = GaussianMixtureConditional(K=K)
+        self.N, self.M, self.K = int(N), int(M), int(K)
+        self.encoder1, self.encoder2 = Encoder1(N, M), Encoder2(N, M)
+        self.decoder1, self.decoder2 = Decoder1(N, M), Decoder2(N, M)
+
+        def h_a():
+            return nn.Sequential(conv(M, N, stride=1, kernel_size=3), nn.LeakyReLU(inplace=True),
+                                 conv(N, N, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 conv(N, N, stride=2, kernel_size=5))
+
+        def h_s():
+            return nn.Sequential(deconv(N, M, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 deconv(M, M * 3 // 2, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+
+        def ep(cin):
+            return nn.Sequential(HipConv2d(cin, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+                                 HipConv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+                                 HipConv2d(M * 8 // 3, M * 6 // 3, 1))
+
+        self.h_a1, self.h_s1 = h_a(), h_s()
+        self.entropy_parameters1 = ep(M * 12 // 3)
+        self.context_prediction1 = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.gaussian_conditional1 = GaussianConditional(None)
+        self.h_a2, self.h_s2 = h_a(), h_s()
+        self.entropy_parameters2 = ep(5 * M)
+        self.context_prediction2 = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.gaussian_conditional2 = GaussianConditional(None)
+
+    def forward(self, x1, x2, h_matrix, noise=None):
+        """noise keys (training): z1, y1, y1b, z2, y1w, y2, y2b (reference draw order)."""
+        tr = self.training
+        size = (x1.shape[-2], x1.shape[-1])
+        y1 = self.encoder1(x1)
+        z1 = _seq3(self.h_a1, y1)
+        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, _noise(noise, "z1", z1, tr))
+        params1 = _seq3(self.h_s1, z1_hat)
+        y1_hat = _quant(self.gaussian_conditional1, y1, noise, "y1", tr)
+        ctx1 = self.context_prediction1(y1_hat)
+        gp1 = _seq3(self.entropy_parameters1, torch.cat((params1, ctx1), 1))
+        sc1, mu1 = gp1.chunk(2, 1)
+        _, y1_lik = self.gaussian_conditional1(y1, sc1, means=mu1, noise=_noise(noise, "y1b", y1, tr))
+        x1_hat = self.decoder1(y1_hat)
+
+        x1_warp = warp_perspective(x1, h_matrix, size)
+        y2 = self.encoder2(x1_warp, x2)
+        z2 = _seq3(self.h_a2, y2)
+        z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, _noise(noise, "z2", z2, tr))
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        y1_hat_w = _quant(self.gaussian1, self.encoder1(x1_hat_warp), noise, "y1w", tr)
+        params2 = _seq3(self.h_s2, z2_hat)
+        y2_hat = _quant(self.gaussian_conditional2, y2, noise, "y2", tr)
+        ctx2 = self.context_prediction2(y2_hat)
+        gp2 = _seq3(self.entropy_parameters2, torch.cat((params2, ctx2, y1_hat_w), 1))
+        sc2, mu2 = gp2.chunk(2, 1)
+        # the reference evaluates view 2 with gaussian_conditional1 as well (:725); no learnable state, harmless
+        _, y2_lik = self.gaussian_conditional1(y2, sc2, means=mu2, noise=_noise(noise, "y2b", y2, tr))
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+                "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+# ------------------------------------------------------------------------------------------ metrics
+def rate_distortion(out, x1, x2):
+    """bits / squared error of one forward as fp64 device scalars (HIP reductions, no host sync):
+    returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""
+    res = {"bits_" + k: -Fn.sum_log2(v) for k, v in out["likelihoods"].items()}
+    res["sse1"] = Fn.sum_sq_diff(out["x1_hat"], x1)
+    res["sse2"] = Fn.sum_sq_diff(out["x2_hat"], x2)
+    res["num_pixels"] = x1.shape[0] * x1.shape[2] * x1.shape[3]
+    return res
+
+
+def metrics_from(rd, channels=3):
+    """Reference conventions (ywz/mywork/test3real.py:69-72,110-122; newtrain1.py:141-142)."""
+    n = rd["num_pixels"]
+    bits = {k[5:]: float(v) for k, v in rd.items() if k.startswith("bits_")}
+    mse1, mse2 = float(rd["sse1"]) / (n * channels), float(rd["sse2"]) / (n * channels)
+    p1, p2 = 10 * math.log10(1 / mse1), 10 * math.log10(1 / mse2)
+    bpp_loss = sum(bits.values()) / n
+    return {"bits": bits, "bpp_loss": bpp_loss, "bpp": bpp_loss / 2, "mse1": mse1, "mse2": mse2, "psnr1": p1,
+            "psnr2": p2, "psnr": (p1 + p2) / 2}

@@ -1,0 +1,150 @@
+"""Training harness of the path (the build's counterpart of ywz/mywork/newtrain1.py:74-111):
+R-D loss, the two-optimiser update order, and plain data parallelism -- one process per GPU, gradients
+summed with RCCL all-reduce over xGMI (``torch.distributed`` backend "nccl" on ROCm), bucketed and
+launched from autograd hooks so the collective overlaps the rest of the backward pass.
+
+The reference has no multi-device code at all; pairs are independent, the loss
+normalises by the LOCAL batch (newtrain1.py:45-47), so averaging rank gradients reproduces the
+single-process gradient of the concatenated batch exactly.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+
+
+class GradBucketReducer:
+    """Bucketed asynchronous gradient all-reduce (average).
+
+    Parameters are grouped into ~``bucket_mb`` buckets in reverse registration order (the order autograd
+    finishes them); a post-accumulate hook counts arrivals and, when a bucket is complete, packs it into one
+    flat buffer and starts ``all_reduce(async_op=True)``.  ``finish()`` waits and scatters the averages back.
+    With world_size == 1 (or no process group) everything is a no-op.
+    """
+
+    def __init__(self, params, bucket_mb: float = 25.0, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, self._of, self._pending, self._work = [], {}, [], []
+        if self.world == 1:
+            return
+        cap = int(bucket_mb * (1 << 20))
+        cur, size = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > cap:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._of[p] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+        self._pending = [len(b) for b in self.buckets]
+
+    def _hook(self, p):
+        bi = self._of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        ps = [p for p in self.buckets[bi] if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._work.append((work, flat, ps))
+
+    def finish(self):
+        """Wait for every bucket (launching the ones whose params got no gradient hook call) and write the
+        averaged gradients back.  Call once after each backward."""
+        if self.world == 1:
+            return
+        for bi, left in enumerate(self._pending):
+            if left > 0:          # parameters unused in this backward: reduce what exists so ranks stay in step
+                self._launch(bi)
+        for work, flat, ps in self._work:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._work.clear()
+        self._pending = [len(b) for b in self.buckets]
+
+
+class Trainer:
+    """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295)
+    and, when a process group is up, one reducer per optimiser group."""
+
+    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=None):
+        self.model, self.lmbda = model, float(lmbda)
+        main, aux = list(model.parameters()), list(model.aux_parameters())
+        on_gpu = main[0].is_cuda
+        kw = {"fused": True} if (fused if fused is not None else on_gpu) else {}
+        self.optimizer = torch.optim.Adam(main, lr=lr, **kw)
+        self.aux_optimizer = torch.optim.Adam(aux, lr=aux_lr, **kw)
+        # EB matrices/biases/factors get their gradient from the main backward but are stepped by the aux
+        # optimiser after the aux backward adds the quantile gradient: both groups are reduced,
+        # the aux group only after the aux backward.
+        self.main_reducer = GradBucketReducer(main, bucket_mb)
+        self.aux_params = aux
+        self.world = self.main_reducer.world
+
+    def _reduce_aux(self):
+        if self.world == 1:
+            return
+        gs = [p.grad for p in self.aux_params if p.grad is not None]
+        if not gs:
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in gs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world)
+        off = 0
+        for g in gs:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def step(self, x1, x2, h_matrix, noise=None):
+        """One iteration in the reference's order: zero both -> forward -> R-D loss backward -> optimizer.step
+        -> aux loss backward -> aux_optimizer.step.  Returns the loss dict (device scalars, no sync)."""
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.aux_optimizer.zero_grad(set_to_none=True)
+        out = self.model(x1, x2, h_matrix, noise=noise)
+        crit = Fn.rd_loss(out, x1, x2, self.lmbda)
+        crit["loss"].backward()
+        self.main_reducer.finish()
+        self.optimizer.step()
+        aux = self.model.aux_loss()
+        aux.backward()
+        self._reduce_aux()
+        self.aux_optimizer.step()
+        crit["aux_loss"] = aux.detach()
+        return crit
+
+
+def init_distributed(backend=None):
+    """Process-group bring-up from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, world_size, local_rank); a plain single-process run returns (0, 1, 0)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, 0
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local

@@ -183,6 +183,14 @@ int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream);
 int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
                       const int64_t b_strides[4], int B, int C, int H, int W, double* out, void* stream);
 
+/* Backward of the two reductions inside the R-D loss (newtrain1.py:44-56):
+ *   g_lik[i] = scale / lik[i]                      (d/dlik of scale * sum(ln lik))
+ *   g_a[i]   = scale * (a[i] - b[i])  (fp32, a's (B,C,H,W) index space, contiguous NCHW output)         */
+int hesic_log_backward(const float* lik, float scale, float* g_lik, int64_t n, void* stream);
+int hesic_sq_diff_backward(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
+                           const int64_t b_strides[4], int B, int C, int H, int W, float scale, float* g_a,
+                           void* stream);
+
 /* elementwise helpers used by the autograd wrappers */
 int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream);
 int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);

@@ -1,0 +1,141 @@
+"""Whole-model parity on the GPU: HESIC (HSIC) and HESIC+ (HSICJoint) forward against the golden vectors
+produced by the reference itself (tests/golden/{hsic,joint}_{64,256}.npz) and against the CPU oracle.
+
+fp32 storage: integer latents may flip only at rounding boundaries (<= 2e-4 of them), bits and MSE within
+1e-3 relative -- the BASELINE bar.  bf16 storage: stated tolerance 5e-2 on bits / MSE."""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, T, load_golden
+from hesic_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(kind, dtype=torch.float32):
+    import hesic_amd
+    from hesic_amd import models
+    hesic_amd.set_compute_dtype(dtype)
+    net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
+    synthetic.fill_state_dict_(net.state_dict())
+    return net.to(DEV).eval()
+
+
+@pytest.fixture(autouse=True)
+def _reset_dtype():
+    yield
+    import hesic_amd
+    hesic_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+@pytest.mark.parametrize("size,batch", [(64, 2), (256, 1)])
+def test_forward_fp32_matches_reference_golden(kind, size, batch):
+    from hesic_amd import models
+    g = load_golden(f"{kind}_{size}.npz")
+    net = build(kind)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, batch, size, size))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+        m = models.metrics_from(models.rate_distortion(out, x1, x2))
+    for k in ("y1_hat", "y2_hat"):
+        flips = (out[k].cpu().to(torch.int16) != T(g[k])).float().mean()
+        assert float(flips) < 2e-4, (k, float(flips))
+    for k in ("y1", "y2", "z1", "z2"):
+        assert m["bits"][k] == pytest.approx(float(g["bits_" + k]), rel=1e-3), k
+    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=1e-3)
+    assert m["mse2"] == pytest.approx(float(g["mse2"]), rel=1e-3)
+    n = batch * size * size
+    ref_bpp = sum(float(g["bits_" + k]) for k in ("y1", "y2", "z1", "z2")) / n / 2
+    ref_psnr = (10 * math.log10(1 / float(g["mse1"])) + 10 * math.log10(1 / float(g["mse2"]))) / 2
+    assert abs(m["bpp"] - ref_bpp) < 1e-3 * max(1.0, ref_bpp) and abs(m["psnr"] - ref_psnr) < 1e-3
+    if size == 64:
+        torch.testing.assert_close(out["x1_hat"].cpu(), T(g["x1_hat"]), rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(out["x2_hat"].cpu(), T(g["x2_hat"]), rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(out["likelihoods"]["z1"].cpu().contiguous(), T(g["lik_z1"]), rtol=2e-3, atol=1e-8)
+    else:
+        pool = torch.nn.functional.avg_pool2d(out["x2_hat"].cpu(), 8)
+        torch.testing.assert_close(pool, T(g["x2_hat_pool"]), rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_forward_bf16_within_stated_tolerance(kind):
+    from hesic_amd import models
+    g = load_golden(f"{kind}_256.npz")
+    net = build(kind, torch.bfloat16)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 1, 256, 256))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+        m = models.metrics_from(models.rate_distortion(out, x1, x2))
+    assert out["y1_hat"].dtype == torch.bfloat16
+    total = sum(float(g["bits_" + k]) for k in ("y1", "y2", "z1", "z2"))
+    assert sum(m["bits"].values()) == pytest.approx(total, rel=5e-2)
+    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=5e-2)
+    assert m["mse2"] == pytest.approx(float(g["mse2"]), rel=5e-2)
+    flips = (out["y1_hat"].float().cpu().to(torch.int16) != T(g["y1_hat"])).float().mean()
+    assert float(flips) < 0.05          # first-stage latents: bf16 rounding moves < 5% across a bin edge
+
+
+def test_forward_512_batch_properties():
+    """BASELINE size (512x512): size-independent properties -- pairs are independent (batch-of-2 equals two
+    batch-of-1 runs bit for bit), latents are integers, likelihoods are in [1e-9, 1]."""
+    net = build("hsic")
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(3, 2, 512, 512))
+    with torch.no_grad():
+        both = net(x1, x2, Hm)
+        one = net(x1[1:], x2[1:], Hm[1:])
+    assert torch.equal(both["y2_hat"][1:], one["y2_hat"]) and torch.equal(both["x2_hat"][1:], one["x2_hat"])
+    assert torch.equal(both["y1_hat"], both["y1_hat"].round())
+    for l in both["likelihoods"].values():
+        assert float(l.min()) >= 1e-9 and float(l.max()) <= 1.0 + 1e-6
+    assert both["x1_hat"].shape == (2, 3, 512, 512) and both["y1_hat"].shape == (2, 192, 32, 32)
+    assert both["likelihoods"]["z1"].shape == (2, 128, 8, 8)
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_train_trace_matches_reference(kind):
+    """Row T: two consecutive optimiser steps at 64x64 with injected noise reproduce the reference's
+    (loss, bpp, mse, aux) trace and its step-0 gradient norms."""
+    from hesic_amd import models
+    from hesic_amd.train import Trainer
+    g = load_golden(f"{kind}_train64.npz")
+    net = build(kind)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 2, 64, 64))
+    order = [str(s) for s in g["noise_order"]]
+    shapes = {"z1": (128, 1, 2), "z2": (128, 1, 2)}
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.0067)
+    trace = []
+    for step in range(2):
+        noise = {}
+        for k in order:
+            shp = shapes.get(k, (2, 192, 4, 4))
+            nz = synthetic._uniform(f"noise.{kind}.{step}.{k}", shp, -0.5, 0.5)
+            if k in ("z1", "z2"):      # reference layout (C, 1, B*H*W) with B fastest -> (B,C,1,1)
+                nz = nz.reshape(128, 1, 1, 2).permute(3, 0, 1, 2).contiguous()
+            noise[k] = nz.to(DEV)
+        if step == 0:
+            # gradient norms of the first backward, before any update
+            net.train()
+            out = net(x1, x2, Hm, noise=noise)
+            from hesic_amd import functional as Fn
+            Fn.rd_loss(out, x1, x2, 0.0067)["loss"].backward()
+            named = dict(net.named_parameters())
+            bad = []
+            for name, p in named.items():
+                ref = float(g["gn_" + name])
+                got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+                if abs(got - ref) > 2e-2 * max(ref, 1e-6) + 1e-7:
+                    bad.append((name, got, ref))
+            assert not bad, bad[:8]
+            torch.testing.assert_close(named["encoder1.g_a_conv4.bias"].grad.cpu(), T(g["g_encoder1.g_a_conv4.bias"]), rtol=2e-2, atol=1e-5)
+            torch.testing.assert_close(named["decoder2.after_conv.bias"].grad.cpu(), T(g["g_decoder2.after_conv.bias"]), rtol=2e-2, atol=1e-5)
+        crit = tr.step(x1, x2, Hm, noise=noise)
+        trace.append([float(crit["loss"]), float(crit["bpp_loss"]), float(crit["mse_loss"]), float(crit["aux_loss"])])
+    ref = g["trace"]
+    for s in range(2):
+        for j, nm in enumerate(("loss", "bpp", "mse", "aux")):
+            assert trace[s][j] == pytest.approx(float(ref[s][j]), rel=5e-3), (s, nm, trace, ref)
