@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo-pairs/sec of HESIC encode+decode at 512x512 on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic stereo pairs already resident in HBM:
+eval-mode ``HSIC.forward`` (3 analysis passes, hyper path, quantise + likelihood, 2 synthesis passes, 2 warps)
+plus the bpp / PSNR reductions -- SURVEY.md 8(d).  Workload at N=1: BASELINE config C2 (batch 8, bf16 storage,
+fp32 accumulation).  N>1: every rank runs its own batch of 8 (independent pairs, no collective on the path,
+weak scaling); only the final timing max / pair count are reduced.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel (implicit-GEMM conv, bf16 MFMA): achieved TFLOP/s = algorithmic conv FLOPs of its
+                launches / their summed HIP-event durations, measured live on the launch stream
+  cpu_baseline  the CPU oracle (a port of the reference's forward, oracle/hesic_oracle.py) timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N=1 only)
+  parity        |bpp - bpp_oracle|, |PSNR - PSNR_oracle| of the first pair: bf16 GPU path vs fp32 CPU oracle
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+HESIC_GFLOP_PER_PAIR_512 = 155.66
+
+
+def conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps=None):
+    """FLOP = 2 x MAC; Conv2d: out_numel*Cin*k^2, ConvTranspose2d: in_numel*Cout*k^2."""
+    taps = ntaps if ntaps is not None else k * k
+    if transposed:
+        return 2.0 * B * H * W * Cin * Cout * taps
+    return 2.0 * B * Ho * Wo * Cin * Cout * taps
+
+
+class KernelMeter:
+    """Wraps hesic_amd.functional._wide_conv: one HIP event pair per launch on the launch stream."""
+
+    def __init__(self, Fn):
+        self.Fn, self.orig, self.rec = Fn, Fn._wide_conv, []
+
+    def __enter__(self):
+        def timed(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, *a, **kw)
+            e1.record()
+            tap_mask = kw.get("tap_mask", a[2] if len(a) > 2 else 0)
+            ntaps = bin(tap_mask).count("1") if tap_mask else None
+            pad128, pad64 = -(-Cout // 128) * 128, -(-Cout // 64) * 64
+            self.rec.append((e0, e1, conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps), 64 if pad64 < pad128 else 128,
+                             x.dtype))
+            return y
+        self.Fn._wide_conv = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.Fn._wide_conv = self.orig
+
+    def summary(self, bn=128):
+        torch.cuda.synchronize()
+        sel = [(e0.elapsed_time(e1) * 1e-3, f) for e0, e1, f, b, _ in self.rec if b == bn]
+        if not sel:
+            return None
+        t, f = sum(s[0] for s in sel), sum(s[1] for s in sel)
+        return {"launches": len(sel), "avg_us": 1e6 * t / len(sel), "tflops": f / t / 1e12, "flops_per_launch": f / len(sel)}
+
+
+def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
+    from hesic_amd import synthetic
+    from oracle import hesic_oracle as O
+    fwd = O.hsic_forward if kind == "hsic" else O.hsic_joint_forward
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, size, size)
+    with torch.no_grad():
+        out = fwd(P_cpu, x1, x2, Hm)       # warm-up + the parity sample
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fwd(P_cpu, x1, x2, Hm)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 8:
+                break
+    m = O.metrics(out, x1, x2)
+    return {"value": n / el, "unit": "stereo-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x (1 pair {size}x{size}, fp32, torch CPU ops) after 1 warm-up, {el:.1f} s"}, m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--model", choices=["hsic", "joint"], default="hsic")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import hesic_amd
+    from hesic_amd import functional as Fn, models, synthetic
+    from hesic_amd.train import init_distributed
+    import torch.distributed as dist
+
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    hesic_amd.set_compute_dtype(cdt)
+
+    net = (models.HSIC if args.model == "hsic" else models.HSICJoint)()
+    synthetic.fill_state_dict_(net.state_dict())
+    P_cpu = {k: v.clone() for k, v in net.state_dict().items()} if rank == 0 else None
+    net = net.to(dev).eval()
+
+    # synthetic pairs: rank r gets pairs [r*B, (r+1)*B); one generated pair set is tiled if B is large
+    uniq = min(args.batch, 4)
+    x1, x2, Hm = synthetic.stereo_batch(rank * uniq, uniq, args.size, args.size)
+    reps = -(-args.batch // uniq)
+    x1, x2, Hm = (t.repeat(reps, *([1] * (t.dim() - 1)))[:args.batch].to(dev) for t in (x1, x2, Hm))
+
+    def step():
+        with torch.no_grad():
+            out = net(x1, x2, Hm)
+            return models.rate_distortion(out, x1, x2)
+
+    for _ in range(args.warmup):
+        rd = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rd = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    m_gpu = models.metrics_from(rd)
+
+    # roofline of the dominant kernel, measured live with HIP events on the launch stream
+    roof = None
+    with KernelMeter(Fn) as km:
+        for _ in range(3):
+            step()
+        s = km.summary(128)
+    if s:
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_igemm.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get(f"{args.model}_{args.dtype}_b{args.batch}_{args.size}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"kernel": f"igemm_conv_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},128>", "bound": "mfma",
+                "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
+                "traffic": traffic, "launches_per_step": s["launches"] // 3, "avg_launch_us": round(s["avg_us"], 2),
+                "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
+
+    if rank == 0:
+        pairs = world * args.batch * args.steps
+        res = {
+            "metric": "stereo-pairs/sec encode+decode @512x512; bpp & PSNR delta vs reference",
+            "value": round(pairs / elapsed, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{'HESIC' if args.model == 'hsic' else 'HESIC+'} eval forward (encode+decode) + bpp/PSNR, "
+                                   f"{args.size}x{args.size} stereo pairs, batch {args.batch}/GPU, random-init-shaped deterministic weights",
+                       "pairs_per_step": world * args.batch, "sharding": f"pairs over {world} GPU(s), no collective on the path"},
+            "model_tflops": round(pairs * HESIC_GFLOP_PER_PAIR_512 * (args.size / 512) ** 2 / elapsed / 1e3, 2) if args.model == "hsic" else None,
+            "roofline": roof,
+            "gpu_metrics_last_batch": {"bpp": round(m_gpu["bpp"], 5), "psnr": round(m_gpu["psnr"], 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, m_cpu = cpu_baseline(args.model, P_cpu, args.size)
+            res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
+            with torch.no_grad():
+                o1 = net(x1[:1], x2[:1], Hm[:1])
+                m1 = models.metrics_from(models.rate_distortion(o1, x1[:1], x2[:1]))
+            res["parity"] = {"abs_dbpp": round(abs(m1["bpp"] - m_cpu["bpp"]), 6), "abs_dpsnr_db": round(abs(m1["psnr"] - m_cpu["psnr"]), 6),
+                             "bpp_oracle": round(m_cpu["bpp"], 5), "psnr_oracle": round(m_cpu["psnr"], 4),
+                             "note": f"{args.dtype} GPU path vs fp32 CPU oracle, pair 0"}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

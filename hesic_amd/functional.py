@@ -43,23 +43,41 @@ def _is_narrow(c):
 
 
 # ------------------------------------------------------------------------------ packing cache
+_cache_epoch = 0
+
+
+def invalidate_weight_cache():
+    """Forget every packed inference weight (call after changing parameters through an API that does not bump
+    the tensor version counter, e.g. a fused optimiser step issued under ``torch.no_grad()`` outside training)."""
+    global _cache_epoch
+    _cache_epoch += 1
+
+
 class PackedWeight:
-    """Device copy of a conv weight in the kernels' [tap][Cout][Cin] layout, refreshed when the
-    parameter's version counter moves (optimizer steps are in-place)."""
+    """Device copy of a conv weight in the kernels' [tap][Cout][Cin] layout.
+
+    Inference (grad mode off): cached, refreshed when the parameter's version counter or storage moves.
+    Training (grad mode on): re-packed on every call and the inference cache is dropped -- fused optimisers
+    update parameters without touching the version counter, and a 35 M-parameter repack is ~50 us."""
 
     def __init__(self):
         self._cache = {}
 
     def get(self, weight, mask, cout, cin, kh, kw, transposed, flip, dtype):
+        caching = not torch.is_grad_enabled()
         key = (transposed, flip, dtype, cout, cin)
-        tag = (weight.data_ptr(), weight._version, None if mask is None else mask._version)
-        hit = self._cache.get(key)
-        if hit is not None and hit[0] == tag:
-            return hit[1]
+        tag = (weight.data_ptr(), weight._version, None if mask is None else mask._version, _cache_epoch)
+        if caching:
+            hit = self._cache.get(key)
+            if hit is not None and hit[0] == tag:
+                return hit[1]
+        elif self._cache:
+            self._cache.clear()
         wp = torch.empty(kh * kw * cout * cin, dtype=dtype, device=weight.device)
         L.call("hesic_pack_conv_weight", L.ptr(weight.detach()), L.ptr(mask), L.ptr(wp), cout, cin, kh, kw,
                int(transposed), int(flip), L.dt(dtype), L.stream())
-        self._cache[key] = (tag, wp)
+        if caching:
+            self._cache[key] = (tag, wp)
         return wp
 
 

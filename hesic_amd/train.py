@@ -86,11 +86,12 @@ class Trainer:
     """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295)
     and, when a process group is up, one reducer per optimiser group."""
 
-    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=None):
+    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=False):
         self.model, self.lmbda = model, float(lmbda)
         main, aux = list(model.parameters()), list(model.aux_parameters())
-        on_gpu = main[0].is_cuda
-        kw = {"fused": True} if (fused if fused is not None else on_gpu) else {}
+        # multi-tensor (foreach) Adam by default: on this ROCm build the fused Adam kernel takes visibly
+        # smaller first steps than the reference's plain Adam (measured: loss 220.4 -> 216.1 vs 220.3 -> 187.0)
+        kw = {"fused": True} if fused else {}
         self.optimizer = torch.optim.Adam(main, lr=lr, **kw)
         self.aux_optimizer = torch.optim.Adam(aux, lr=aux_lr, **kw)
         # EB matrices/biases/factors get their gradient from the main backward but are stepped by the aux

@@ -391,6 +391,9 @@ def fx_models(newnet1, newnet1_joint):
             if step == 0:
                 for n_, p_ in net.named_parameters():
                     T["gn_" + n_] = float(p_.grad.double().norm()) if p_.grad is not None else 0.0
+                for n_, m_ in net.named_modules():
+                    if hasattr(m_, "mask") and getattr(m_, "weight", None) is not None:
+                        T["gn_live_" + n_ + ".weight"] = float((m_.weight.grad * m_.mask).double().norm())
                 T["g_encoder1.g_a_conv4.bias"] = net.encoder1.g_a_conv4.bias.grad.clone()
                 T["g_decoder2.after_conv.bias"] = net.decoder2.after_conv.bias.grad.clone()
                 T["g_entropy_bottleneck1._biases.0"] = net.entropy_bottleneck1._biases[0].grad.clone()
