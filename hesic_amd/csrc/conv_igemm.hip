@@ -15,6 +15,8 @@
 //
 // Storage T is bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain,
 // used for the tight-parity mode); accumulation is fp32 in both.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -272,6 +274,180 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
     }
 }
 
+// ------------------------------------------------------------------------- bf16 fast path (LDS-DMA staging)
+// Same tiling and math as igemm_conv_kernel<bf16_t, BN>, but the tiles go global -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write), BK is 64 when Cin allows it, and the loads of
+// step s+1 are in flight while step s runs on the matrix cores.  The DMA writes LDS lane-linearly, so the
+// XOR swizzle is applied on the SOURCE side: lane j of a wave instruction fetches the 16-byte chunk that
+// belongs at LDS position j.  Padding taps / rows beyond the image or Cout read a zero page instead.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
+
+template <int BMP, int BN, int BK>
+__global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a) {
+    using T = bf16_t;
+    constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
+    constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row
+    constexpr int RPB = 256 / (BK * 2);       // rows per 256-byte bank row
+    constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
+    constexpr int XI = BM * CPR / 64 / 4;     // x-tile DMA instructions per wave per step
+    constexpr int WI = BN * CPR / 64 / 4;
+    static_assert(XI >= 1 && WI >= 1, "tile too small");
+    constexpr int WN = BM >= 64 ? 2 : 1, WM = 4 / WN;     // wave grid: WM cout slices x WN pixel slices
+    constexpr int OROW = BN * 2 + 16;
+    constexpr int EPI = BM * OROW;
+    constexpr int LDS_BYTES = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % a.n_tiles;
+    int rest = bid / a.n_tiles;
+    const int tx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int ty = rest % a.tiles_y;
+    rest /= a.tiles_y;
+    const int b = rest % a.B;
+    const int ph = rest / a.B;
+    const int n0 = nt * BN;
+    const int kchunks = a.Cin / BK;
+    const int nsteps = a.ntaps[ph] * kchunks;
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+    const T* zero = (const T*)g_zero_page;
+
+    const int prow = lane / CPR, pslot = lane % CPR;
+    const T* xrow[XI];
+    int iy0[XI], ix0[XI];
+    bool rowok[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
+        rowok[i] = qy < a.QH && qx < a.QW;
+        iy0[i] = qy * a.in_step;
+        ix0[i] = qx * a.in_step;
+        xrow[i] = xg + (((int64_t)b * a.H + iy0[i]) * a.W + ix0[i]) * a.x_ps + a.x_co + ls * 8;
+    }
+    const T* wrow[WI];
+    bool wok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave * WI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        wok[i] = (n0 + row) < a.Cout;
+        wrow[i] = wg + (int64_t)(n0 + row) * a.Cin + ls * 8;
+    }
+
+    auto issue = [&](int step, int buf) {
+        const int t = step / kchunks;
+        const int c0 = (step - t * kchunks) * BK;
+        const int dy = a.dy[ph][t], dx = a.dx[ph][t];
+        const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps + c0;
+        const int64_t wo = (int64_t)a.wt[ph][t] * a.Cout * a.Cin + c0;
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+            const T* src = ok ? xrow[i] + xo : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const T* src = wok[i] ? wrow[i] + wo : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    constexpr int MI = BN / WM / 32, NI = BM / WN / 32;
+    static_assert(MI >= 1 && NI >= 1, "wave tile too small");
+    const int wm = wave % WM, wn = wave / WM;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fh = lane >> 5;
+    auto off = [&](int row, int slot) { return (row * CPR + (slot ^ ((row / RPB) & (CPR - 1)))) * 16; };
+
+    issue(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const unsigned char* xs = smem + buf * STAGE;
+        const unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 wf[MI], xf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) wf[i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                xf[j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
+                if (a.in_abs) {
+                    u32x4 v = __builtin_bit_cast(u32x4, xf[j]);
+                    v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
+                    xf[j] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue (identical to the register-staged kernel)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
+                *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPO = BN * 2 / 16;
+        constexpr int TOT = BM * CPO;
+        T* __restrict__ yg = (T*)a.y;
+        const int oyo = a.oy_off[ph], oxo = a.ox_off[ph];
+#pragma unroll
+        for (int c = tid; c < TOT; c += NTHREADS) {
+            const int pr = c / CPO, cc = c % CPO;
+            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+            const int ch = n0 + cc * 8;
+            if (qy < a.QH && qx < a.QW && ch < a.Cout) {
+                const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
+                const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + ch;
+                *(u32x4*)(yg + o) = *(const u32x4*)(smem + pr * OROW + cc * 16);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------- weight packing
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ mask, T* __restrict__ wp,
@@ -393,23 +569,50 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         }
         (void)order; (void)cnt;  // phases are already heaviest-first for k=5,p=2,s=2 (9,6,6,4 taps)
     }
-    // 2-D pixel patch of 128: as square as the q-grid allows
-    int TW = 16;
-    while (TW > 1 && TW / 2 >= a.QW) TW /= 2;
-    if (a.QW >= 32 && a.QH < 8) TW = 32;
-    int TH = BM / TW;
-    a.TW = TW; a.TH = TH; a.tw_shift = ilog2(TW);
-    a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
-
     // cout tile: 128 unless 64 wastes less
     const int pad128 = ((d->Cout + 127) / 128) * 128, pad64 = ((d->Cout + 63) / 64) * 64;
     const int BN = (pad64 < pad128) ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
+    static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
+    const bool fast = d->dtype == HESIC_BF16 && !legacy;
+    // pixel tile: 128, shrunk to 64 / 32 (fast path only) until the grid has ~1.5 blocks per CU
+    int bm = 128;
+    auto count_blocks = [&](int m) {
+        int tw = 16;
+        while (tw > 1 && tw / 2 >= a.QW) tw /= 2;
+        if (tw > m) tw = m;
+        const int th = m / tw;
+        return (int64_t)a.n_tiles * ((a.QW + tw - 1) / tw) * ((a.QH + th - 1) / th) * a.B * a.nphase;
+    };
+    if (fast) {
+        if (count_blocks(128) < 384) bm = 64;
+        if (bm == 64 && count_blocks(64) < 384 && BN == 128 && d->Cin % 64 == 0) bm = 32;
+    }
+    // 2-D pixel patch: as square as the q-grid allows
+    int TW = 16;
+    while (TW > 1 && TW / 2 >= a.QW) TW /= 2;
+    if (bm == 128 && a.QW >= 32 && a.QH < 8) TW = 32;
+    if (TW > bm) TW = bm;
+    int TH = bm / TW;
+    a.TW = TW; a.TH = TH; a.tw_shift = ilog2(TW);
+    a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == HESIC_BF16) {
+#define LAUNCH_GLDS(M_, N_, K_) hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_>), grid, block, 0, st, a)
+    if (fast) {
+        const bool k64 = d->Cin % 64 == 0;
+        if (bm == 128) {
+            if (k64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64); else LAUNCH_GLDS(128, 64, 64); }
+            else { if (BN == 128) LAUNCH_GLDS(128, 128, 32); else LAUNCH_GLDS(128, 64, 32); }
+        } else if (bm == 64) {
+            if (k64) { if (BN == 128) LAUNCH_GLDS(64, 128, 64); else LAUNCH_GLDS(64, 64, 64); }
+            else { if (BN == 128) LAUNCH_GLDS(64, 128, 32); else LAUNCH_GLDS(64, 64, 32); }
+        } else {
+            LAUNCH_GLDS(32, 128, 64);
+        }
+    } else if (d->dtype == HESIC_BF16) {
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 128>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 64>), grid, block, 0, st, a);
     } else {

@@ -7,6 +7,8 @@
 //   narrow_to_wide : Conv2d,           Cin <= 8, Cout % 32 == 0, y channels contiguous (NHWC)
 //   wide_to_narrow : ConvTranspose2d,  5x5 s2,   Cout <= 4, Cin % 8 == 0, x channels contiguous (NHWC)
 //   generic        : anything else (also the fallback used by the odd-shape parity tests)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -222,12 +224,267 @@ __global__ __launch_bounds__(256) void sconv_wide_to_narrow_kernel(const SArgs a
             }
 }
 
+// ---------------------------------------------------------------- narrow -> wide on the matrix cores (bf16 output)
+// g_a_conv1 (3 -> 128, 5x5 s2): K = Cin*KH*KW = 75 is re-ordered as (ci, ky) rows of 8 (5 real taps + 3 zeros) so that one
+// lane-half of an MFMA B fragment is exactly one contiguous image row segment: K_pad = 16 rows * 8 = 128.
+// A = weights [cout][K_pad] (bf16, LDS, loaded once per block), B = im2col fragment gathered straight from the image
+// (any strides, fp32 or bf16), D -> bias/act -> bf16 -> LDS -> full NHWC rows.  HBM bound on the 128-channel output.
+constexpr int N2W_KPAD = 128;
+__global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
+    constexpr int OROW = 128 * 2 + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[128 * 256 + 128 * OROW];
+    unsigned char* wl = smem;                    // [128 cout][128 k] bf16, 16-byte slots XOR (row & 15)
+    unsigned char* os = smem + 128 * 256;        // output staging [128 px][OROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.Cin * a.KH;                  // <= 16 (checked by the launcher)
+    const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 7) / 8;
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
+    const int frow = lane & 31, fh = lane >> 5;
+
+    for (int n0 = 0; n0 < a.Cout; n0 += 128) {
+        __syncthreads();
+        for (int i = tid; i < 128 * 16; i += 256) {        // (cout row, 16-byte slot) = 8 k values = one (ci,ky) row
+            const int co = i >> 4, r = i & 15;
+            float v[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+                v[kx] = (r < R && kx < a.KW && n0 + co < a.Cout) ? w_at(a.w, n0 + co, r / a.KH, r % a.KH, kx, a.Cout, a.Cin, a.KH, a.KW, 0) : 0.f;
+            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        }
+        __syncthreads();
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+            // this wave: output rows 2*wave, 2*wave+1 of the 8x16 patch; lane pixel = (row, col)
+            const int pl = wave * 32 + frow;                 // pixel index in the patch
+            const int oy = ty * 8 + (pl >> 4), ox = tx * 16 + (pl & 15);
+            const bool pok = oy < a.Ho && ox < a.Wo;
+            f32x16 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < N2W_KPAD / 16; ++ks) {
+                const int r = 2 * ks + fh;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (r < R && pok) {
+                    const int ci = r / a.KH, ky = r - ci * a.KH;
+                    const int iy = oy * a.stride - a.pad + ky;
+                    if ((unsigned)iy < (unsigned)a.H) {
+                        const int64_t rb = b * a.xs_b + ci * a.xs_c + iy * a.xs_y;
+                        const int ix0 = ox * a.stride - a.pad;
+#pragma unroll
+                        for (int kx = 0; kx < 8; ++kx)
+                            if (kx < a.KW && (unsigned)(ix0 + kx) < (unsigned)a.W) v[kx] = ld_any(a.x, rb + (ix0 + kx) * a.xs_x, a.x_dtype);
+                    }
+                }
+                const u32x4 pk = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 32 + frow;
+                    const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                }
+            }
+            // D[i = cout][j = pixel]: lane holds pixel frow of this wave, couts i*32 + 8g + 4fh + {0..3}
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = i * 32 + 8 * g + 4 * fh;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = apply_act(acc[i][4 * g + e] + ((a.bias && n0 + cl + e < a.Cout) ? a.bias[n0 + cl + e] : 0.f), a.act);
+                    *(u32x2*)(os + pl * OROW + cl * 2) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                }
+            __syncthreads();
+            bf16_t* yg = (bf16_t*)a.y;
+            for (int c = tid; c < 128 * 16; c += 256) {
+                const int pr = c >> 4, cc = c & 15;
+                const int y2 = ty * 8 + (pr >> 4), x2 = tx * 16 + (pr & 15);
+                if (y2 < a.Ho && x2 < a.Wo && n0 + cc * 8 < a.Cout)
+                    *(u32x4*)(yg + b * a.ys_b + y2 * a.ys_y + x2 * a.ys_x + n0 + cc * 8) = *(const u32x4*)(os + pr * OROW + cc * 16);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- wide -> narrow on the matrix cores (bf16 input)
+// g_s_conv4 (ConvTranspose2d 128 -> 3, 5x5 s2 p2 op1).  With only 3 output channels the GEMM is turned round: every
+// INPUT pixel is multiplied by the whole [Cin x (25*Cout)] weight panel (N = 75 -> 96), giving its 5x5xCout "splat"
+// G[pixel][tap*Cout+co]; the output pixel then gathers the <= 9 splats that land on it (col2im) from LDS.
+// Block = a 14x14 input patch + 1-pixel halo (16x16 = 256 pixels = 8 MFMA pixel tiles) -> a 28x28 output patch.
+constexpr int W2N_T = 14;
+__global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, int NT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int NP = NT * 32;                                   // padded N
+    const int GROW = NP * 4 + 16;                             // G row stride (bytes)
+    unsigned char* wl = dsm;                                  // [NP][Cin] bf16, 16-byte slots XOR (row & 15)
+    float* G = (float*)(dsm + NP * a.Cin * 2);                // [256][GROW/4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int spr = a.Cin / 8;                                // 16-byte slots per weight row
+    const int N = 25 * a.Cout;
+    for (int i = tid; i < NP * spr; i += 256) {
+        const int n = i / spr, sl = i % spr;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = sl * 8 + e;
+            v[e] = n < N ? w_at(a.w, n % a.Cout, ci, (n / a.Cout) / 5, (n / a.Cout) % 5, a.Cout, a.Cin, 5, 5, 1) : 0.f;
+        }
+        *(u32x4*)(wl + (n * spr + (sl ^ (n & 15 & (spr - 1)))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+    __syncthreads();
+    const int tiles_x = (a.W + W2N_T - 1) / W2N_T, tiles_y = (a.H + W2N_T - 1) / W2N_T;
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
+    const bf16_t* xg = (const bf16_t*)a.x;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+        const int y0 = ty * W2N_T - 1, x0 = tx * W2N_T - 1;    // input coords of halo pixel (0,0)
+#pragma unroll 1
+        for (int pt = 0; pt < 2; ++pt) {
+            const int pl = (wave * 2 + pt) * 32 + frow;        // pixel in the 16x16 halo patch
+            const int iy = y0 + (pl >> 4), ix = x0 + (pl & 15);
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const bf16_t* xp = xg + b * a.xs_b + iy * a.xs_y + ix * a.xs_x + fh * 8;   // xs_c == 1
+            f32x16 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int ks = 0; ks < a.Cin / 16; ++ks) {
+                u32x4 raw = u32x4{0, 0, 0, 0};
+                if (ok) raw = *(const u32x4*)(xp + ks * 16);
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < NT) {
+                        const int row = i * 32 + frow;
+                        const bf16x8 wf = *(const bf16x8*)(wl + (row * spr + ((ks * 2 + fh) ^ (row & 15 & (spr - 1)))) * 16);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < NT)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(f32x4*)((unsigned char*)G + pl * GROW + (i * 32 + 8 * g + 4 * fh) * 4) =
+                            f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        }
+        __syncthreads();
+        // col2im: out(2*t0 + ol) = bias + sum_{k == ol parity} G[il = (ol + 2 - k)/2 + 1][k]
+        for (int o = tid; o < 4 * W2N_T * W2N_T; o += 256) {
+            const int oly = o / (2 * W2N_T), olx = o % (2 * W2N_T);
+            const int oy = 2 * ty * W2N_T + oly, ox = 2 * tx * W2N_T + olx;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ky = oly & 1; ky < 5; ky += 2) {
+                const int ily = (oly + 2 - ky) / 2 + 1;
+                for (int kx = olx & 1; kx < 5; kx += 2) {
+                    const int ilx = (olx + 2 - kx) / 2 + 1;
+                    const float* gp = (const float*)((const unsigned char*)G + (ily * 16 + ilx) * GROW) + (ky * 5 + kx) * a.Cout;
+                    for (int co = 0; co < a.Cout; ++co) r[co] += gp[co];
+                }
+            }
+            for (int co = 0; co < a.Cout; ++co)
+                st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype,
+                       apply_act(r[co] + (a.bias ? a.bias[co] : 0.f), a.act));
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- narrow -> narrow, stride 1 (pre_conv / after_conv)
+// Conv2d or (stride-1) ConvTranspose2d with Cin <= 8, Cout <= 4: y[co][o] = sum x[ci][o + k - p] w'[k][ci][co] where w' is
+// the kernel (mirrored for the transposed op).  One thread = 4 consecutive output pixels of one row; per (ci, ky) it
+// loads the KW+3 inputs once and feeds 4*KW*Cout FMAs.  Weights sit in LDS as [ky][kx][ci][4] and are read as
+// broadcast float4.
+constexpr int SS_PX = 4;
+__global__ __launch_bounds__(256) void sconv_small_s1_kernel(const SArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[7 * 7 * 8 * 4];
+    const int nW = a.KH * a.KW * a.Cin * 4;
+    for (int i = threadIdx.x; i < nW; i += 256) {
+        const int co = i & 3, ci = (i >> 2) % a.Cin, tap = (i >> 2) / a.Cin;
+        int ky = tap / a.KW, kx = tap % a.KW;
+        if (a.transposed) { ky = a.KH - 1 - ky; kx = a.KW - 1 - kx; }
+        wl[i] = co < a.Cout ? w_at(a.w, co, ci, ky, kx, a.Cout, a.Cin, a.KH, a.KW, a.transposed) : 0.f;
+    }
+    __syncthreads();
+    // for the transposed op the effective padding is K-1-p (= p for odd kernels with p = K/2)
+    const int pad_y = a.transposed ? a.KH - 1 - a.pad : a.pad, pad_x = a.transposed ? a.KW - 1 - a.pad : a.pad;
+    const int segs = (a.Wo + SS_PX - 1) / SS_PX;
+    const int64_t total = (int64_t)a.B * a.Ho * segs;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sg = i % segs, oy = (i / segs) % a.Ho, b = i / ((int64_t)segs * a.Ho);
+        const int ox0 = sg * SS_PX;
+        float acc[SS_PX][4];
+#pragma unroll
+        for (int p = 0; p < SS_PX; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            for (int ky = 0; ky < a.KH; ++ky) {
+                const int iy = oy - pad_y + ky;
+                if ((unsigned)iy >= (unsigned)a.H) continue;
+                const int64_t rb = b * a.xs_b + ci * a.xs_c + iy * a.xs_y;
+                float xin[SS_PX + 6];
+#pragma unroll
+                for (int j = 0; j < SS_PX + 6; ++j) {
+                    const int ix = ox0 - pad_x + j;
+                    xin[j] = (j < SS_PX + a.KW - 1 && (unsigned)ix < (unsigned)a.W) ? ld_any(a.x, rb + ix * a.xs_x, a.x_dtype) : 0.f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    if (kx < a.KW) {
+                        const f32x4 wv = *(const f32x4*)(wl + (((ky * a.KW + kx) * a.Cin) + ci) * 4);
+#pragma unroll
+                        for (int p = 0; p < SS_PX; ++p) {
+                            acc[p][0] += xin[p + kx] * wv.x; acc[p][1] += xin[p + kx] * wv.y;
+                            acc[p][2] += xin[p + kx] * wv.z; acc[p][3] += xin[p + kx] * wv.w;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < SS_PX; ++p) {
+            const int ox = ox0 + p;
+            if (ox < a.Wo)
+                for (int co = 0; co < a.Cout; ++co)
+                    st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype,
+                           apply_act(acc[p][co] + (a.bias ? a.bias[co] : 0.f), a.act));
+        }
+    }
+}
+
 int launch_forward(const SArgs& a, hipStream_t st) {
-    if (!a.transposed && a.Cin <= 8 && a.Cout % 32 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 &&
+    static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;   // A/B switch for profiling
+    if (!legacy && !a.transposed && a.y_dtype == HESIC_BF16 && a.Cin * a.KH <= 16 && a.KW <= 8 && a.Cout % 8 == 0 && a.ys_c == 1 &&
+        (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 && (a.ys_b % 8) == 0) {
+        const int64_t tiles = (int64_t)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * a.B;
+        hipLaunchKernelGGL(sconv_n2w_mfma_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, a);
+    } else if (!a.transposed && a.Cin <= 8 && a.Cout % 32 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 &&
         (a.ys_b % 8) == 0 && a.KH * a.KW * a.Cin * a.Cout * 4 <= 60 * 1024) {
         const int tiles = ((a.Wo + 7) / 8) * ((a.Ho + 7) / 8) * a.B;
         const size_t lds = (size_t)a.KH * a.KW * a.Cin * a.Cout * 4;
         hipLaunchKernelGGL(sconv_narrow_to_wide_kernel, dim3(tiles), dim3(256), lds, st, a);
+    } else if (!legacy && a.transposed && a.x_dtype == HESIC_BF16 && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 &&
+               a.Cout <= 4 && a.Cin % 16 == 0 && a.Cin >= 16 && a.Cin <= 128 && a.xs_c == 1 && (a.xs_x % 8) == 0 &&
+               (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Ho == 2 * a.H && a.Wo == 2 * a.W) {
+        const int NT = (25 * a.Cout + 31) / 32;
+        const size_t lds = (size_t)NT * 32 * a.Cin * 2 + (size_t)256 * (NT * 32 * 4 + 16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)sconv_w2n_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        const int64_t tiles = (int64_t)((a.W + W2N_T - 1) / W2N_T) * ((a.H + W2N_T - 1) / W2N_T) * a.B;
+        hipLaunchKernelGGL(sconv_w2n_mfma_kernel, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), lds, st, a, NT);
     } else if (a.transposed && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Cout <= 4 && a.Cin % 8 == 0 &&
                a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Cin <= 128) {
         const int64_t total = (int64_t)a.B * a.H * a.W;
@@ -236,6 +493,9 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+    } else if (a.stride == 1 && a.Cin <= 8 && a.Cout <= 4 && a.KH <= 7 && a.KW <= 7 && a.Ho == a.H && a.Wo == a.W) {
+        const int64_t total = (int64_t)a.B * a.Ho * ((a.Wo + SS_PX - 1) / SS_PX);
+        hipLaunchKernelGGL(sconv_small_s1_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, a);
     } else {
         const int64_t total = (int64_t)a.B * a.Ho * a.Wo * ((a.Cout + 3) / 4);
         hipLaunchKernelGGL(sconv_generic_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, a);

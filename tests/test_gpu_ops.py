@@ -151,14 +151,16 @@ def test_image_side_convs(dtype):
         b = rnd("ic_b", (128,), -0.1, 0.1)
         y = Fn.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=2, padding=2)
         assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
-        assert rel_err(y, O.conv(x, w, b, 2)) < tol
+        # bf16 storage: operands are rounded to bf16 before the MFMA -> compare with the oracle on rounded operands
+        r = bf if dtype == torch.bfloat16 else (lambda t: t)
+        assert rel_err(y, O.conv(r(x), r(w), b, 2)) < (1e-4 if dtype == torch.float32 else 6e-3)
         f = rnd("ic_f", (2, 128, 16, 24))
         wt = rnd("ic_wt", (128, 3, 5, 5)) * 0.05
         bt = rnd("ic_bt", (3,), -0.1, 0.1)
         fi = bf(f) if dtype == torch.bfloat16 else f
         yt = Fn.conv2d(fi.to(DEV, dtype), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
         assert yt.dtype == torch.float32 and yt.shape == (2, 3, 32, 48)
-        assert rel_err(yt, O.deconv(fi, wt, bt, 2)) < 1e-4
+        assert rel_err(yt, O.deconv(fi, r(wt), bt, 2)) < 1e-4
         x6 = rnd("ic_x6", (2, 6, 16, 16), 0, 1)
         w6 = rnd("ic_w6", (3, 6, 5, 5)) * 0.1
         assert rel_err(Fn.conv2d(x6.to(DEV), w6.to(DEV), None, kernel_size=5, stride=1, padding=2), O.conv(x6, w6, None, 1)) < 1e-4
