@@ -4,13 +4,31 @@ import torch
 
 
 def run(device):
-    from . import functional as Fn, synthetic
+    import hesic_amd
+    from hesic_amd import models, synthetic
     from oracle import hesic_oracle as O
-    x = synthetic._uniform("smoke.x", (1, 128, 16, 16), -1, 1)
-    w = synthetic._uniform("smoke.w", (128, 128, 5, 5), -0.03, 0.03)
-    b = synthetic._uniform("smoke.b", (128,), -0.1, 0.1)
-    y = Fn.conv2d(x.to(device), w.to(device), b.to(device), kernel_size=5, stride=2, padding=2)
-    ref = O.conv(x, w, b, 2)
-    err = float((y.cpu() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-4, f"smoke: conv mismatch {err}"
-    print(f"smoke ok: conv rel err {err:.2e}")
+    if device.type != "cuda":
+        raise RuntimeError("smoke(): needs a ROCm device, the HIP path has no CPU fallback")
+    hesic_amd.set_compute_dtype(torch.float32)
+    net = models.HSIC()
+    synthetic.fill_state_dict_(net.state_dict())
+    P = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(device).eval()
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 64, 64)
+    with torch.no_grad():
+        out = net(x1.to(device), x2.to(device), Hm.to(device))
+        m = models.metrics_from(models.rate_distortion(out, x1.to(device), x2.to(device)))
+        ref = O.hsic_forward(P, x1, x2, Hm)
+    mr = O.metrics(ref, x1, x2)
+    flips = float((out["y1_hat"].cpu() != ref["y1_hat"]).float().mean())
+    assert flips < 1e-3, f"smoke: {flips:.2e} of the y1 latents differ from the oracle"
+    assert abs(m["bpp"] - mr["bpp"]) < 1e-3 * max(1.0, mr["bpp"]), (m["bpp"], mr["bpp"])
+    assert abs(m["psnr"] - mr["psnr"]) < 1e-3, (m["psnr"], mr["psnr"])
+    # and one bf16 forward (the benchmark configuration) for shape / finiteness
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        ob = net(x1.to(device), x2.to(device), Hm.to(device))
+    hesic_amd.set_compute_dtype(torch.float32)
+    assert ob["x2_hat"].shape == (1, 3, 64, 64) and bool(torch.isfinite(ob["x2_hat"]).all())
+    print(f"smoke ok: HESIC 64x64 fp32 vs oracle  bpp {m['bpp']:.5f}/{mr['bpp']:.5f}  psnr {m['psnr']:.4f}/{mr['psnr']:.4f}  "
+          f"latent flips {flips:.1e}; bf16 forward finite")

@@ -512,6 +512,19 @@ extern "C" int hesic_unpack_conv_wgrad(const float* dwp, const float* mask, floa
     HESIC_LAUNCH_RETURN("unpack_conv_wgrad");
 }
 
+static thread_local int* g_plan_out = nullptr;   // when set, hesic_conv2d_forward only reports its tile choice
+
+extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                    void* y, void* stream);
+
+extern "C" int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds) {
+    HESIC_CHECK_ARG(d && bm_bn_bk_glds, "conv2d_variant: null pointer");
+    g_plan_out = bm_bn_bk_glds;
+    const int rc = hesic_conv2d_forward(d, (const void*)16, (const void*)16, nullptr, (void*)16, nullptr);
+    g_plan_out = nullptr;
+    return rc;
+}
+
 extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                     void* y, void* stream) {
     HESIC_CHECK_ARG(d && x && w_packed && y, "conv2d_forward: null pointer");
@@ -598,6 +611,10 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
+    if (g_plan_out) {
+        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (d->Cin % 64 == 0 ? 64 : 32) : BK; g_plan_out[3] = fast ? 1 : 0;
+        return 0;
+    }
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GLDS(M_, N_, K_) hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_>), grid, block, 0, st, a)

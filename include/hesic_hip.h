@@ -61,6 +61,10 @@ int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, in
 int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                          void* y, void* stream);
 
+/* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
+ * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
+int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);
+
 /* Weight gradient of the same op: dw_packed[KH*KW][Cout][Cin] (fp32, packed layout) = sum over pixels of
  * dy (x) x; dbias (Cout, fp32) may be NULL.  Pixels are split over blocks; the partial tiles live in `ws`
  * (hesic_conv2d_wgrad_ws_bytes(d) bytes) and are summed in a fixed order, so the result is deterministic.
