@@ -37,10 +37,37 @@ struct IgemmArgs {
     int Ho, Wo, Cout, y_ps, y_co;
     int act, in_abs;
     int n_tiles, nphase;
-    int ntaps[4];
-    int8_t oy_off[4], ox_off[4];
-    int8_t dy[4][MAX_TAPS], dx[4][MAX_TAPS], wt[4][MAX_TAPS];
+    int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
 };
+
+// Tap geometry of one launch phase, all wave-uniform scalars.
+//   conv:        taps = the first ntaps_live kernel positions in raster order (a MaskedConv2d mask is such a prefix),
+//                input offset d = k - pad, one phase.
+//   transposed:  output phase (ry, rx) = (ph / s, ph % s) uses k = k0 + s*j with k0 = (r + pad) % s and reads the
+//                input at q + (r + pad - k)/s;  output pixel = q*s + r.
+struct Taps {
+    int ry, rx, ky0, kx0, kst, nkx, ntaps;
+};
+__device__ __forceinline__ Taps make_taps(const IgemmArgs& a, int ph) {
+    Taps t;
+    if (a.transposed) {
+        t.ry = ph / a.stride; t.rx = ph - t.ry * a.stride;
+        t.ky0 = (t.ry + a.pad) % a.stride; t.kx0 = (t.rx + a.pad) % a.stride; t.kst = a.stride;
+        const int nky = (a.KH - t.ky0 + a.stride - 1) / a.stride;
+        t.nkx = (a.KW - t.kx0 + a.stride - 1) / a.stride;
+        t.ntaps = nky * t.nkx;
+    } else {
+        t.ry = t.rx = t.ky0 = t.kx0 = 0; t.kst = 1; t.nkx = a.KW; t.ntaps = a.ntaps_live;
+    }
+    return t;
+}
+__device__ __forceinline__ void tap_at(const IgemmArgs& a, const Taps& t, int i, int& dy, int& dx, int& wt) {
+    const int j = i / t.nkx, c = i - j * t.nkx;
+    const int ky = t.ky0 + j * t.kst, kx = t.kx0 + c * t.kst;
+    if (a.transposed) { dy = (t.ry + a.pad - ky) / a.stride; dx = (t.rx + a.pad - kx) / a.stride; }
+    else { dy = ky - a.pad; dx = kx - a.pad; }
+    wt = ky * a.KW + kx;
+}
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> {
@@ -102,9 +129,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
     const int b = rest % a.B;
     const int ph = rest / a.B;
     const int n0 = nt * BN;
-    const int ntaps = a.ntaps[ph];
+    const Taps taps = make_taps(a, ph);
     const int kchunks = a.Cin / BK;
-    const int nsteps = ntaps * kchunks;
+    const int nsteps = taps.ntaps * kchunks;
 
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ wg = (const T*)a.w;
@@ -137,9 +164,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
     auto load_step = [&](int step) {
         const int t = step / kchunks;
         const int c0 = (step - t * kchunks) * BK;
-        const int dy = a.dy[ph][t], dx = a.dx[ph][t];
+        int dy, dx, wt;
+        tap_at(a, taps, t, dy, dx, wt);
         const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps + c0;
-        const int64_t wo = (int64_t)a.wt[ph][t] * a.Cout * a.Cin + c0;
+        const int64_t wo = (int64_t)wt * a.Cout * a.Cin + c0;
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             const bool ok = rowok[j] && (unsigned)(iy0[j] + dy) < (unsigned)a.H && (unsigned)(ix0[j] + dx) < (unsigned)a.W;
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
         constexpr int CPO = BN * (int)sizeof(T) / 16;           // 16B chunks per output row
         constexpr int TOT = BM * CPO;
         T* __restrict__ yg = (T*)a.y;
-        const int oyo = a.oy_off[ph], oxo = a.ox_off[ph];
+        const int oyo = taps.ry, oxo = taps.rx;
 #pragma unroll
         for (int c = tid; c < TOT; c += NTHREADS) {
             const int prow = c / CPO, cc = c % CPO;
@@ -282,7 +310,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
 // belongs at LDS position j.  Padding taps / rows beyond the image or Cout read a zero page instead.
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
 
-template <int BMP, int BN, int BK>
+template <int LP>
+__device__ __forceinline__ void wait_dma_groups(int k) {
+    // leave the newest k stages (LP LDS-DMA instructions each, per wave) in flight, retire everything older
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LP) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LP) : "memory"); break;
+    }
+}
+
+template <int BMP, int BN, int BK, int NS>
 __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
@@ -295,7 +334,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     constexpr int WN = BM >= 64 ? 2 : 1, WM = 4 / WN;     // wave grid: WM cout slices x WN pixel slices
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
-    constexpr int LDS_BYTES = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
+    constexpr int LDS_BYTES = NS * STAGE > EPI ? NS * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -313,8 +353,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     const int b = rest % a.B;
     const int ph = rest / a.B;
     const int n0 = nt * BN;
+    const Taps taps = make_taps(a, ph);
     const int kchunks = a.Cin / BK;
-    const int nsteps = a.ntaps[ph] * kchunks;
+    const int nsteps = taps.ntaps * kchunks;
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ wg = (const T*)a.w;
     const T* zero = (const T*)g_zero_page;
@@ -346,9 +387,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     auto issue = [&](int step, int buf) {
         const int t = step / kchunks;
         const int c0 = (step - t * kchunks) * BK;
-        const int dy = a.dy[ph][t], dx = a.dx[ph][t];
+        int dy, dx, wt;
+        tap_at(a, taps, t, dy, dx, wt);
         const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps + c0;
-        const int64_t wo = (int64_t)a.wt[ph][t] * a.Cout * a.Cin + c0;
+        const int64_t wo = (int64_t)wt * a.Cout * a.Cin + c0;
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
 #pragma unroll
@@ -379,13 +421,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     const int frow = lane & 31, fh = lane >> 5;
     auto off = [&](int row, int slot) { return (row * CPR + (slot ^ ((row / RPB) & (CPR - 1)))) * 16; };
 
-    issue(0, 0);
-    __syncthreads();
+    // NS-deep ring: stage s+NS-1 is issued right after the barrier that proves stage s-1 has been read by
+    // every wave; a counted vmcnt keeps NS-2 younger stages in flight across the barrier (raw s_barrier: a
+    // __syncthreads() would drain the DMA queue).
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nsteps) issue(s, s);
+    int buf = 0, nxt = NS - 1;
     for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const int rem = nsteps - 1 - step;
+        wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+        __builtin_amdgcn_s_barrier();
+        if (step + NS - 1 < nsteps) issue(step + NS - 1, nxt);
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         const unsigned char* xs = smem + buf * STAGE;
         const unsigned char* ws = xs + XT;
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 wf[MI], xf[NI];
@@ -406,8 +457,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();     // every wave is done with the ring before the epilogue reuses it
 
     // epilogue (identical to the register-staged kernel)
 #pragma unroll
@@ -433,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
         constexpr int CPO = BN * 2 / 16;
         constexpr int TOT = BM * CPO;
         T* __restrict__ yg = (T*)a.y;
-        const int oyo = a.oy_off[ph], oxo = a.ox_off[ph];
+        const int oyo = taps.ry, oxo = taps.rx;
 #pragma unroll
         for (int c = tid; c < TOT; c += NTHREADS) {
             const int pr = c / CPO, cc = c % CPO;
@@ -546,41 +597,26 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
     a.act = d->act; a.in_abs = d->in_abs;
     const int s = d->stride, p = d->pad;
+    a.KH = d->KH; a.KW = d->KW; a.stride = s; a.pad = p; a.transposed = d->transposed;
     if (!d->transposed) {
         HESIC_CHECK_ARG(d->Ho == (d->H + 2 * p - d->KH) / s + 1 && d->Wo == (d->W + 2 * p - d->KW) / s + 1,
                         "conv2d_forward: output size does not match");
         a.QH = d->Ho; a.QW = d->Wo; a.in_step = s; a.out_step = 1; a.nphase = 1;
-        int n = 0;
-        for (int ky = 0; ky < d->KH; ++ky)
-            for (int kx = 0; kx < d->KW; ++kx) {
-                const int t = ky * d->KW + kx;
-                if (d->tap_mask_lo && !((d->tap_mask_lo >> t) & 1)) continue;
-                a.dy[0][n] = (int8_t)(ky - p); a.dx[0][n] = (int8_t)(kx - p); a.wt[0][n] = (int8_t)t; ++n;
-            }
-        a.ntaps[0] = n;
-        HESIC_CHECK_ARG(n > 0, "conv2d_forward: no live taps");
+        int live = d->KH * d->KW;
+        if (d->tap_mask_lo) {
+            // the kernels walk a raster-order PREFIX of the taps (what MaskedConv2d masks 'A'/'B' are)
+            live = 0;
+            while (live < d->KH * d->KW && ((d->tap_mask_lo >> live) & 1)) ++live;
+            HESIC_CHECK_ARG(live > 0 && (d->tap_mask_lo >> live) == 0, "conv2d_forward: tap mask must be a raster-order prefix");
+        }
+        a.ntaps_live = live;
     } else {
         HESIC_CHECK_ARG(d->Ho == d->H * s && d->Wo == d->W * s, "conv2d_forward: transposed output must be H*stride");
         HESIC_CHECK_ARG(!d->tap_mask_lo, "conv2d_forward: tap mask unsupported for transposed conv");
-        // output o = q*s + r gets input i = q + (r + p - k)/s for taps k == (r+p) mod s
+        HESIC_CHECK_ARG(d->KH >= s && d->KW >= s, "conv2d_forward: transposed kernel smaller than the stride");
+        // output o = q*s + r gets input i = q + (r + p - k)/s for taps k == (r+p) mod s  (see make_taps)
         a.QH = d->H; a.QW = d->W; a.in_step = 1; a.out_step = s; a.nphase = s * s;
-        int order[4] = {0, 1, 2, 3};
-        int cnt[4] = {0, 0, 0, 0};
-        for (int ph = 0; ph < s * s; ++ph) {
-            const int ry = ph / s, rx = ph % s;
-            int n = 0;
-            for (int ky = (ry + p) % s; ky < d->KH; ky += s)
-                for (int kx = (rx + p) % s; kx < d->KW; kx += s) {
-                    a.dy[ph][n] = (int8_t)((ry + p - ky) / s);
-                    a.dx[ph][n] = (int8_t)((rx + p - kx) / s);
-                    a.wt[ph][n] = (int8_t)(ky * d->KW + kx);
-                    ++n;
-                }
-            a.ntaps[ph] = n; cnt[ph] = n;
-            a.oy_off[ph] = (int8_t)ry; a.ox_off[ph] = (int8_t)rx;
-            HESIC_CHECK_ARG((ry + p - ((ry + p) % s)) % s == 0, "conv2d_forward: internal phase error");
-        }
-        (void)order; (void)cnt;  // phases are already heaviest-first for k=5,p=2,s=2 (9,6,6,4 taps)
+        a.ntaps_live = 0;
     }
     // cout tile: 128 unless 64 wastes less
     const int pad128 = ((d->Cout + 127) / 128) * 128, pad64 = ((d->Cout + 63) / 64) * 64;
@@ -617,17 +653,28 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     }
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_GLDS(M_, N_, K_) hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_>), grid, block, 0, st, a)
+#define LAUNCH_GLDS(M_, N_, K_, S_) hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_>), grid, block, 0, st, a)
+#define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
+    do {                                                             \
+        if (deep) LAUNCH_GLDS(M_, N_, K_, 4);                        \
+        else LAUNCH_GLDS(M_, N_, K_, 2);                             \
+    } while (0)
     if (fast) {
-        const bool k64 = d->Cin % 64 == 0;
+        // ring depth: a 2-deep ring relies on 2-3 co-resident blocks per CU to hide the L2 latency; layers whose grid
+        // is too small for that (low resolutions) get a 4-deep ring instead, as long as every block of the grid still
+        // fits in LDS at once (160 KB per CU)
+        const int bk = d->Cin % 64 == 0 ? 64 : 32;
+        const int stage = (bm + BN) * bk * 2;
+        const int64_t per_cu = (nblocks + 255) / 256;
+        const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
         if (bm == 128) {
-            if (k64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64); else LAUNCH_GLDS(128, 64, 64); }
-            else { if (BN == 128) LAUNCH_GLDS(128, 128, 32); else LAUNCH_GLDS(128, 64, 32); }
+            if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
+            else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }
         } else if (bm == 64) {
-            if (k64) { if (BN == 128) LAUNCH_GLDS(64, 128, 64); else LAUNCH_GLDS(64, 64, 64); }
-            else { if (BN == 128) LAUNCH_GLDS(64, 128, 32); else LAUNCH_GLDS(64, 64, 32); }
+            if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
+            else { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 32); else LAUNCH_GLDS_NS(64, 64, 32); }
         } else {
-            LAUNCH_GLDS(32, 128, 64);
+            LAUNCH_GLDS_NS(32, 128, 64);
         }
     } else if (d->dtype == HESIC_BF16) {
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 128>), grid, block, 0, st, a);
