@@ -40,38 +40,43 @@ def conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps=None):
 
 
 class KernelMeter:
-    """Wraps hesic_amd.functional._wide_conv: one HIP event pair per launch on the launch stream."""
+    """One HIP event pair around every implicit-GEMM launch (hesic_conv2d_forward / hesic_conv2d_gdn_forward),
+    recorded on the stream the kernel is launched on; the launch descriptor gives the algorithmic FLOPs and
+    hesic_conv2d_variant names the instantiation the library picked."""
+    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_gdn_forward")
 
-    def __init__(self, Fn):
-        self.Fn, self.orig, self.rec = Fn, Fn._wide_conv, []
+    def __init__(self, L):
+        self.L, self.orig, self.rec = L, L.call, []
 
     def __enter__(self):
-        def timed(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, *a, **kw):
+        def call(name, *args):
+            if name not in self.NAMES:
+                return self.orig(name, *args)
+            d = args[0]._obj
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = self.orig(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, *a, **kw)
+            rc = self.orig(name, *args)
             e1.record()
-            tap_mask = kw.get("tap_mask", a[2] if len(a) > 2 else 0)
-            ntaps = bin(tap_mask).count("1") if tap_mask else None
-            self.rec.append((e0, e1, conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps),
-                             self.variant(x, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, tap_mask)))
-            return y
-        self.Fn._wide_conv = timed
+            ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
+            fl = conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)
+            fused = name.endswith("gdn_forward")
+            if fused:
+                fl += 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cout          # the GDN 1x1 contraction (SURVEY 8d counts it)
+            self.rec.append((e0, e1, fl, self.variant(d, fused)))
+            return rc
+        self.L.call = call
         return self
 
     def __exit__(self, *exc):
-        self.Fn._wide_conv = self.orig
+        self.L.call = self.orig
 
-    @staticmethod
-    def variant(x, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, tap_mask):
-        """Name of the kernel instantiation the library picks for this launch (hesic_conv2d_variant)."""
+    def variant(self, d, fused):
         import ctypes as C
-        from hesic_amd import _lib as L
-        d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x.dtype), 0, 0, Cin, 0, Cout, 0, tap_mask)
         v = (C.c_int32 * 4)()
-        L.call("hesic_conv2d_variant", C.byref(d), v)
-        dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
-        return f"igemm_glds_kernel<{v[0]},{v[1]},{v[2]}>" if v[3] else f"igemm_conv_kernel<{dt},{v[1]}>"
+        self.orig("hesic_conv2d_variant", C.byref(d), v)
+        if v[3]:
+            return f"igemm_glds_kernel<{v[0]},{v[1]},{v[2]}{',gdn' if fused else ''}>"
+        return f"igemm_conv_kernel<{'bf16' if d.dtype == self.L.BF16 else 'f32'},{v[1]}>"
 
     def summary(self):
         """Per kernel instantiation: launches, summed event time, algorithmic FLOPs; returns the dominant one."""
@@ -188,7 +193,8 @@ def main():
 
     # roofline of the dominant kernel, measured live with HIP events on the launch stream
     roof = None
-    with KernelMeter(Fn) as km:
+    from hesic_amd import _lib as L_
+    with KernelMeter(L_) as km:
         for _ in range(3):
             step()
         s = km.summary()

@@ -24,6 +24,12 @@ class GDN(nn.Module):
     def forward(self, x):
         return Fn.gdn(x, self.beta, self.gamma, self.inverse, self.beta_min)
 
+    def packer(self):
+        """cache of the pre-transformed parameters used by the fused conv+GDN epilogue (inference)"""
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedGdn()
+        return self._packer
+
 
 class GDN1(GDN):
     r"""Simplified GDN, y_i = x_i / (beta_i + sum_j gamma_ij |x_j|) (reference gdn.py:73-97).

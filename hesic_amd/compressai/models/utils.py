@@ -30,6 +30,17 @@ class HipConv2d(nn.Conv2d):
                          padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                          mask=mask, tap_mask=tap_mask)
 
+    def run_gdn(self, x, gdn):
+        """gdn(self(x)); one fused kernel when eligible (inference, bf16 storage, 128 channels), else two ops."""
+        if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False):
+            self._check()
+            if not hasattr(self, "_packer"):
+                self._packer = Fn.PackedWeight()
+            return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
+                                 stride=self.stride[0], padding=self.padding[0], transposed=False, inverse=gdn.inverse,
+                                 beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
+        return gdn(self.run(x))
+
     def forward(self, x):
         return self.run(x)
 
@@ -49,6 +60,16 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
             self._packer = Fn.PackedWeight()
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=True, act=act, packer=self._packer)
+
+    def run_gdn(self, x, gdn):
+        if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), True):
+            self._check()
+            if not hasattr(self, "_packer"):
+                self._packer = Fn.PackedWeight()
+            return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
+                                 stride=self.stride[0], padding=self.padding[0], transposed=True, inverse=gdn.inverse,
+                                 beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
+        return gdn(self.run(x))
 
     def forward(self, x, output_size=None):
         if output_size is not None:

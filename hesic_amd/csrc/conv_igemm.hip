@@ -38,6 +38,8 @@ struct IgemmArgs {
     int act, in_abs;
     int n_tiles, nphase;
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
+    const void* gdn_gamma;     // fused GDN epilogue: gamma' bf16 [128][128] in the LDS image layout (hesic_gdn_pack_params)
+    const float* gdn_beta;     // beta' fp32 [128]
 };
 
 // Tap geometry of one launch phase, all wave-uniform scalars.
@@ -321,7 +323,10 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
     }
 }
 
-template <int BMP, int BN, int BK, int NS>
+// GDN = 0: plain conv epilogue; 1 / 2: y = conv * rsqrt / sqrt(beta' + gamma' @ conv^2) fused (BN == 128 == Cout): the
+// staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
+// activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
+template <int BMP, int BN, int BK, int NS, int GDN = 0>
 __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
@@ -335,7 +340,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
-    constexpr int LDS_BYTES = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static_assert(GDN == 0 || BN == 128, "fused GDN needs every channel of a pixel in the block");
+    constexpr int GOFF = (EPI + 1023) / 1024 * 1024;          // gamma' image behind the staged output tile
+    constexpr int EPI_ALL = GDN ? GOFF + 128 * 256 : EPI;
+    constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -474,10 +482,73 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
                 const int pr = wn * (BM / WN) + j * 32 + frow;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
+                    if (GDN) acc[i][j][4 * g + e] = v[e];          // keep the fp32 conv output for the final product
+                }
                 *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             }
         }
+    }
+    if constexpr (GDN != 0) {
+        // gamma' (already in LDS image order) -> LDS behind the tile, 8 DMA instructions per wave
+        const unsigned char* gsrc = (const unsigned char*)a.gdn_gamma;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (wave * 8 + i) * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + GOFF + (wave * 8 + i) * 1024), 16, 0, 0);
+        __syncthreads();                                       // drains the DMA; tile + gamma' visible to every wave
+        f32x16 nrm[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[i][j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            bf16x8 gf[MI], qf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (BN / WM) + i * 32 + frow;
+                gf[i] = *(const bf16x8*)(smem + GOFF + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const u32x4 raw = *(const u32x4*)(smem + (wn * (BM / WN) + j * 32 + frow) * OROW + (ks * 2 + fh) * 16);
+                const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
+                const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
+                const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
+                const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
+                const u32x4 sq = u32x4{pack_bf2(f0 * f0, f1 * f1), pack_bf2(f2 * f2, f3 * f3), pack_bf2(f4 * f4, f5 * f5), pack_bf2(f6 * f6, f7 * f7)};
+                qf[j] = __builtin_bit_cast(bf16x8, sq);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], qf[j], nrm[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                       // every wave has read the tile: safe to overwrite it
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                float be[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) be[e] = a.gdn_beta[cl + e];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int pr = wn * (BM / WN) + j * 32 + frow;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float n = nrm[i][j][4 * g + e] + be[e];
+                        v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? sqrtf(n) : rsqrtf(n));
+                    }
+                    *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                }
+            }
     }
     __syncthreads();
     {
@@ -537,6 +608,25 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* 
 
 int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
+// gamma' = max(gamma, 2^-18)^2 - 2^-36 as bf16 in the fused epilogue's LDS image order; beta' likewise (fp32)
+__global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
+                                bf16_t* __restrict__ gp, float* __restrict__ bp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte slot (8 values) per thread: 128 rows x 16 slots
+    if (i >= 128 * 16) return;
+    const int row = i >> 4, slot = i & 15;
+    const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
+    bf16_t* dst = gp + (row * 16 + (slot ^ (row & 15))) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = fmaxf(gamma[row * 128 + slot * 8 + e], gb);
+        dst[e] = f2bf(t * t - ped);
+    }
+    if (i < 128) {
+        const float t = fmaxf(beta[i], beta_bound);
+        bp[i] = t * t - ped;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- C ABI
@@ -563,7 +653,19 @@ extern "C" int hesic_unpack_conv_wgrad(const float* dwp, const float* mask, floa
     HESIC_LAUNCH_RETURN("unpack_conv_wgrad");
 }
 
-static thread_local int* g_plan_out = nullptr;   // when set, hesic_conv2d_forward only reports its tile choice
+static thread_local int* g_plan_out = nullptr;
+static thread_local const void* g_gdn_gamma = nullptr;   // set by hesic_conv2d_gdn_forward around its call to the launcher
+static thread_local const float* g_gdn_beta = nullptr;
+static thread_local int g_gdn_mode = 0;
+
+extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
+                                     int C, void* stream) {
+    HESIC_CHECK_ARG(beta && gamma && gamma_packed && beta_packed, "gdn_pack_params: null pointer");
+    HESIC_CHECK_ARG(C == 128, "gdn_pack_params: the fused conv+GDN epilogue is built for C == 128 (got %d)", C);
+    hipLaunchKernelGGL(gdn_pack_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, beta, gamma, sqrtf(beta_min + 1.0f / 68719476736.0f),
+                       (bf16_t*)gamma_packed, beta_packed);
+    HESIC_LAUNCH_RETURN("gdn_pack_params");
+}   // when set, hesic_conv2d_forward only reports its tile choice
 
 extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                     void* y, void* stream);
@@ -573,6 +675,17 @@ extern "C" int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds
     g_plan_out = bm_bn_bk_glds;
     const int rc = hesic_conv2d_forward(d, (const void*)16, (const void*)16, nullptr, (void*)16, nullptr);
     g_plan_out = nullptr;
+    return rc;
+}
+
+extern "C" int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                        const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream) {
+    HESIC_CHECK_ARG(d && gamma_packed && beta_packed, "conv2d_gdn_forward: null pointer");
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 && d->Cout == 128 && d->act == HESIC_ACT_NONE && d->Cin % 32 == 0,
+                    "conv2d_gdn_forward: needs bf16 storage, Cout == 128, Cin %% 32 == 0 and no activation");
+    g_gdn_gamma = gamma_packed; g_gdn_beta = beta_packed; g_gdn_mode = inverse ? 2 : 1;
+    const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
+    g_gdn_gamma = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     return rc;
 }
 
@@ -593,6 +706,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+    a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta;
+    const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
     a.act = d->act; a.in_abs = d->in_abs;
@@ -623,7 +738,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int BN = (pad64 < pad128) ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
     static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
-    const bool fast = d->dtype == HESIC_BF16 && !legacy;
+    const bool fast = d->dtype == HESIC_BF16 && (!legacy || gdn);
     // pixel tile: 128, shrunk to 64 / 32 (fast path only) until the grid has ~1.5 blocks per CU
     int bm = 128;
     auto count_blocks = [&](int m) {
@@ -653,7 +768,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     }
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_GLDS(M_, N_, K_, S_) hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_>), grid, block, 0, st, a)
+#define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \
+    do {                                                                                                    \
+        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);       \
+        else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
+    } while (0)
 #define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
     do {                                                             \
         if (deep) LAUNCH_GLDS(M_, N_, K_, 4);                        \

@@ -202,6 +202,49 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class PackedGdn:
+    """gamma' (bf16, LDS image order) / beta' (fp32) for the fused conv+GDN epilogue; inference-only cache."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, beta, gamma, beta_min):
+        tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
+        if self._hit is not None and self._hit[0] == tag:
+            return self._hit[1], self._hit[2]
+        gp = torch.empty(128 * 128, dtype=torch.bfloat16, device=gamma.device)
+        bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
+        L.call("hesic_gdn_pack_params", L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), float(beta_min), L.ptr(gp),
+               L.ptr(bp), 128, L.stream())
+        self._hit = (tag, gp, bp)
+        return gp, bp
+
+
+def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
+    """The fused epilogue exists for inference with bf16 storage, 128 output channels and a wide input."""
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    cin = weight.shape[0] if transposed else weight.shape[1]
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and cout == 128 and gdn_channels == 128
+            and cin % 32 == 0)
+
+
+def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, transposed, inverse, beta_min, packer, gdn_packer):
+    """(I)GDN(conv(x)) in ONE kernel (inference only; training keeps the two autograd ops)."""
+    L.require_cuda(x, weight)
+    k = kernel_size
+    Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    B, _, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    x = _nhwc(x)
+    wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
+    gp, bp = gdn_packer.get(beta, gamma, beta_min)
+    out = _empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+    d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, padding, int(transposed), L.dt(x), 0, 0, Cin, 0, Cout, 0, 0)
+    L.call("hesic_conv2d_gdn_forward", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse),
+           L.ptr(out), L.stream())
+    return out
+
+
 def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, in_abs=False,
            tap_mask=0, packer=None, mask=None):
     packer = packer if packer is not None else PackedWeight()

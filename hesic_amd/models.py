@@ -74,8 +74,8 @@ class Encoder1(nn.Module):
 
     def stack(self, x):
         x = self.g_a_gdn1(self.g_a_conv1(x))
-        x = self.g_a_gdn2(self.g_a_conv2(x))
-        x = self.g_a_gdn3(self.g_a_conv3(x))
+        x = self.g_a_conv2.run_gdn(x, self.g_a_gdn2)        # conv + GDN in one kernel at inference
+        x = self.g_a_conv3.run_gdn(x, self.g_a_gdn3)
         return self.g_a_conv4(x)
 
     def forward(self, x):
@@ -110,9 +110,9 @@ class Decoder1(nn.Module):
         self.g_s_conv4 = deconv(N, 3)
 
     def stack(self, y):
-        y = self.g_s_gdn1(self.g_s_conv1(y))
-        y = self.g_s_gdn2(self.g_s_conv2(y))
-        y = self.g_s_gdn3(self.g_s_conv3(y))
+        y = self.g_s_conv1.run_gdn(y, self.g_s_gdn1)        # deconv + IGDN in one kernel at inference
+        y = self.g_s_conv2.run_gdn(y, self.g_s_gdn2)
+        y = self.g_s_conv3.run_gdn(y, self.g_s_gdn3)
         return self.g_s_conv4(y)
 
     def forward(self, y_hat):

@@ -61,6 +61,15 @@ int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, in
 int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                          void* y, void* stream);
 
+/* Fused y = (I)GDN(conv(x)) (bf16 storage, Cout == 128, no activation): the conv output tile is normalised in the
+ * epilogue of the implicit-GEMM kernel, saving the activation's HBM round trip between conv()/deconv() and GDN.forward
+ * (newnet1.py:594-600, :617-623).  gamma_packed (128*128 bf16) / beta_packed (128 fp32) come from
+ * hesic_gdn_pack_params (NonNegativeParametrizer applied, LDS image order).                                             */
+int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
+                          int C, void* stream);
+int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                             const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
+
 /* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);

@@ -354,3 +354,26 @@ def test_reductions():
     ref = float(((a.double() - b.double()) ** 2).sum())
     got = float(Fn.sum_sq_diff(a.to(DEV), b.to(DEV).contiguous(memory_format=torch.channels_last)))
     assert abs(got - ref) < 1e-5 * ref
+
+
+@pytest.mark.parametrize("tr,inv", [(0, False), (1, True)], ids=["conv+gdn", "deconv+igdn"])
+def test_fused_conv_gdn_matches_the_two_ops(tr, inv):
+    """The inference-only fused epilogue equals conv() followed by GDN.forward (bf16 storage) and the fp32 oracle."""
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=9)
+    beta, gamma = sd["g.beta"], sd["g.gamma"]
+    Cin = 192 if tr else 128
+    w = rnd("fg_w", (Cin, 128, 5, 5) if tr else (128, Cin, 5, 5)) * (0.06 if tr else 0.03)
+    b = rnd("fg_b", (128,), -0.1, 0.1)
+    x = bf(rnd("fg_x", (2, Cin, 12, 20) if tr else (2, Cin, 40, 24), -2, 2))
+    ref = O.gdn((O.deconv if tr else O.conv)(x, bf(w), b, 2), beta, gamma, inv)
+    xd = x.to(DEV, torch.bfloat16)
+    args = dict(kernel_size=5, stride=2, padding=2, transposed=bool(tr))
+    with torch.no_grad():
+        two = Fn.gdn(Fn.conv2d(xd, w.to(DEV), b.to(DEV), **args), beta.to(DEV), gamma.to(DEV), inv)
+        one = Fn.conv2d_gdn(xd, w.to(DEV), b.to(DEV), beta.to(DEV), gamma.to(DEV), inverse=inv, beta_min=1e-6,
+                            packer=Fn.PackedWeight(), gdn_packer=Fn.PackedGdn(), **args)
+    assert one.shape == two.shape and one.dtype == torch.bfloat16
+    assert rel_err(one, ref) < 1.5e-2 and rel_err(two, ref) < 1.5e-2
+    assert rel_err(one, two) < 1.5e-2
