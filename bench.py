@@ -194,10 +194,12 @@ def main():
     # roofline of the dominant kernel, measured live with HIP events on the launch stream
     roof = None
     from hesic_amd import _lib as L_
+    overlap, models.OVERLAP_STREAMS = models.OVERLAP_STREAMS, False     # one stream: an event pair brackets ONE kernel
     with KernelMeter(L_) as km:
         for _ in range(3):
             step()
         s = km.summary()
+    models.OVERLAP_STREAMS = overlap
     if s:
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         traffic = None

@@ -22,6 +22,39 @@ from .geometry import warp_perspective
 
 RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
 
+# inference runs the two views' independent front ends on two HIP streams (set False for a single-stream schedule)
+OVERLAP_STREAMS = True
+_side_streams = {}
+
+
+def _side_stream(device, idx=0):
+    key = (device.type, device.index, idx)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def _branches(ref, *fns):
+    """Run independent branches; at inference each extra branch gets its own HIP stream (forked from / joined to the
+    current one) so their small kernels overlap.  Returns the branch results in order."""
+    if not (OVERLAP_STREAMS and ref.is_cuda and not torch.is_grad_enabled()):
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    outs = [None] * len(fns)
+    streams = [_side_stream(ref.device, 1 + i) for i in range(len(fns) - 1)]
+    for st in streams:
+        st.wait_stream(cur)
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            outs[i + 1] = fns[i + 1]()
+    outs[0] = fns[0]()
+    for i, st in enumerate(streams):
+        cur.wait_stream(st)
+        o = outs[i + 1]
+        for t in (o if isinstance(o, (tuple, list)) else (o,)):
+            t.record_stream(cur)
+    return outs
+
 
 class StereoCompressionModel(nn.Module):
     """Base with TWO entropy bottlenecks (reference newnet1.py:36-104): ``parameters()`` skips them,
@@ -179,10 +212,12 @@ class gmm_hyper_y1(nn.Module):
 
     def forward(self, z):
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
-        sigma = s[4].run(s[2].run(s[0].run(z, act=RELU), act=RELU), act=RELU)
-        means = m[4].run(m[2].run(m[0].run(z, act=LEAKY), act=LEAKY))
-        feat = w[2].run(w[0].run(z, act=LEAKY))
-        return sigma, means, _mixture_weights(w, feat, self.K, self.M)
+        sigma, means, weights = _branches(
+            z,
+            lambda: s[4].run(s[2].run(s[0].run(z, act=RELU), act=RELU), act=RELU),
+            lambda: m[4].run(m[2].run(m[0].run(z, act=LEAKY), act=LEAKY)),
+            lambda: _mixture_weights(w, w[2].run(w[0].run(z, act=LEAKY)), self.K, self.M))
+        return sigma, means, weights
 
 
 class gmm_hyper_y2(nn.Module):
@@ -204,10 +239,12 @@ class gmm_hyper_y2(nn.Module):
     def forward(self, z2, y1):
         c = Fn.upsample4_cat(z2, y1)
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
-        sigma = s[4].run(s[2].run(s[0].run(c, act=RELU), act=RELU), act=RELU)
-        means = m[4].run(m[2].run(m[0].run(c, act=LEAKY), act=LEAKY))
-        feat = w[2].run(w[0].run(c, act=LEAKY))
-        return sigma, means, _mixture_weights(w, feat, self.K, self.M)
+        sigma, means, weights = _branches(
+            c,
+            lambda: s[4].run(s[2].run(s[0].run(c, act=RELU), act=RELU), act=RELU),
+            lambda: m[4].run(m[2].run(m[0].run(c, act=LEAKY), act=LEAKY)),
+            lambda: _mixture_weights(w, w[2].run(w[0].run(c, act=LEAKY)), self.K, self.M))
+        return sigma, means, weights
 
 
 def _noise(nz, key, like, training):
@@ -242,6 +279,8 @@ class HSIC(StereoCompressionModel):
     def forward(self, x1, x2, h_matrix, noise=None):
         """``noise`` (training only, optional): dict z1,y1,y1w,z2,y2 of U(-1/2,1/2) draws, in the order the
         reference makes them; absent keys are drawn on the device."""
+        if OVERLAP_STREAMS and not self.training and not torch.is_grad_enabled() and x1.is_cuda:
+            return self._forward_two_streams(x1, x2, h_matrix)
         tr = self.training
         size = (x1.shape[-2], x1.shape[-1])
         y1 = self.encoder1(x1)
@@ -260,6 +299,38 @@ class HSIC(StereoCompressionModel):
         z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, _noise(noise, "z2", z2, tr))
         s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w)
         y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2, noise=_noise(noise, "y2", y2, tr))
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+                "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+    def _forward_two_streams(self, x1, x2, h_matrix):
+        """Inference schedule on two HIP streams.  View 2's analysis (warp -> encoder2 -> h_a2 -> bottleneck) depends
+        only on the inputs, so it runs on a side stream while the main stream walks view 1's chain
+        (encoder1 -> hyper path -> decoder1 -> warp -> encoder1); the many small hyper-path kernels of one stream fill
+        the CUs the other stream's tail blocks leave idle.  Results are identical to the single-stream order."""
+        size = (x1.shape[-2], x1.shape[-1])
+        main = torch.cuda.current_stream()
+        side = _side_stream(x1.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            x1_warp = warp_perspective(x1, h_matrix, size)
+            y2 = self.encoder2(x1_warp, x2)
+            z2 = self._h_a2(y2)
+            z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None)
+        y1 = self.encoder1(x1)
+        z1 = self._h_a1(y1)
+        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None)
+        s1, m1, w1 = self._h_s1(z1_hat)
+        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, w1)
+        x1_hat = self.decoder1(y1_hat)
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+        main.wait_stream(side)
+        for t in (y2, z2_hat, z2_lik):            # produced on the side stream, consumed / freed on the main one
+            t.record_stream(main)
+        s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w)
+        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2)
         x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
