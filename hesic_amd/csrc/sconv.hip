@@ -340,90 +340,94 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
 // g_s_conv4 (ConvTranspose2d 128 -> 3, 5x5 s2 p2 op1).  With only 3 output channels the GEMM is turned round: every
 // INPUT pixel is multiplied by the whole [Cin x (25*Cout)] weight panel (N = 75 -> 96), giving its 5x5xCout "splat"
 // G[pixel][tap*Cout+co]; the output pixel then gathers the <= 9 splats that land on it (col2im) from LDS.
-// Block = a 14x14 input patch + 1-pixel halo (16x16 = 256 pixels = 8 MFMA pixel tiles) -> a 28x28 output patch.
-constexpr int W2N_T = 14;
-__global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, int NT) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    const int NP = NT * 32;                                   // padded N
-    const int GROW = NP * 4 + 16;                             // G row stride (bytes)
-    unsigned char* wl = dsm;                                  // [NP][Cin] bf16, 16-byte slots XOR (row & 15)
-    float* G = (float*)(dsm + NP * a.Cin * 2);                // [256][GROW/4]
+// Block = a 6x14 input patch + 1-pixel halo (8x16 = 128 pixels = one 32-pixel MFMA tile per wave) -> a 12x28 output
+// patch; 75 KB of LDS -> two blocks per CU, and the next tile's pixel fragments are fetched while this tile's
+// col2im runs, so the HBM latency is hidden both by the co-resident block and by the prefetch.
+constexpr int W2N_TH = 6, W2N_TW = 14;
+template <int COUT>
+__global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
+    constexpr int N = 25 * COUT, NT = (N + 31) / 32, NP = NT * 32;
+    constexpr int GROW = NP * 4 + 16;                         // G row stride (bytes)
+    constexpr int CIN = 128, SPR = CIN / 8;
+    __shared__ __attribute__((aligned(16))) unsigned char dsm[NP * CIN * 2 + 128 * GROW];
+    unsigned char* wl = dsm;                                  // [NP][128] bf16, 16-byte slots XOR (row & 15)
+    unsigned char* G = dsm + NP * CIN * 2;                    // [128 px][GROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fh = lane >> 5;
-    const int spr = a.Cin / 8;                                // 16-byte slots per weight row
-    const int N = 25 * a.Cout;
-    for (int i = tid; i < NP * spr; i += 256) {
-        const int n = i / spr, sl = i % spr;
+    for (int i = tid; i < NP * SPR; i += 256) {
+        const int n = i / SPR, sl = i % SPR;
+        const int co = n % COUT, tap = n / COUT;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = sl * 8 + e;
-            v[e] = n < N ? w_at(a.w, n % a.Cout, ci, (n / a.Cout) / 5, (n / a.Cout) % 5, a.Cout, a.Cin, 5, 5, 1) : 0.f;
-        }
-        *(u32x4*)(wl + (n * spr + (sl ^ (n & 15 & (spr - 1)))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        for (int e = 0; e < 8; ++e) v[e] = n < N ? a.w[((int64_t)(sl * 8 + e) * COUT + co) * 25 + tap] : 0.f;   // w[ci][co][ky][kx]
+        *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
     }
-    __syncthreads();
-    const int tiles_x = (a.W + W2N_T - 1) / W2N_T, tiles_y = (a.H + W2N_T - 1) / W2N_T;
+    const int tiles_x = (a.W + W2N_TW - 1) / W2N_TW, tiles_y = (a.H + W2N_TH - 1) / W2N_TH;
     const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
     const bf16_t* xg = (const bf16_t*)a.x;
+    const int pl = wave * 32 + frow;                          // this lane's pixel in the 8x16 halo patch
+    u32x4 raws[8];
+    auto fetch = [&](int64_t tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+        const int iy = ty * W2N_TH - 1 + (pl >> 4), ix = tx * W2N_TW - 1 + (pl & 15);
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const bf16_t* xp = xg + b * a.xs_b + (int64_t)iy * a.xs_y + (int64_t)ix * a.xs_x + fh * 8;   // xs_c == 1
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) raws[ks] = ok ? *(const u32x4*)(xp + ks * 16) : u32x4{0, 0, 0, 0};
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    __syncthreads();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
-        const int y0 = ty * W2N_T - 1, x0 = tx * W2N_T - 1;    // input coords of halo pixel (0,0)
-#pragma unroll 1
-        for (int pt = 0; pt < 2; ++pt) {
-            const int pl = (wave * 2 + pt) * 32 + frow;        // pixel in the 16x16 halo patch
-            const int iy = y0 + (pl >> 4), ix = x0 + (pl & 15);
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const bf16_t* xp = xg + b * a.xs_b + iy * a.xs_y + ix * a.xs_x + fh * 8;   // xs_c == 1
-            f32x16 acc[4];
+        f32x16 acc[NT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            u32x4 raws[8];
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                raws[ks] = u32x4{0, 0, 0, 0};
-                if (ok && ks < a.Cin / 16) raws[ks] = *(const u32x4*)(xp + ks * 16);
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, raws[ks]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int row = i * 32 + frow;
+                const bf16x8 wf = *(const bf16x8*)(wl + (row * SPR + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
             }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks >= a.Cin / 16) break;
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, raws[ks]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < NT) {
-                        const int row = i * 32 + frow;
-                        const bf16x8 wf = *(const bf16x8*)(wl + (row * spr + ((ks * 2 + fh) ^ (row & 15 & (spr - 1)))) * 16);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < NT)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *(f32x4*)((unsigned char*)G + pl * GROW + (i * 32 + 8 * g + 4 * fh) * 4) =
-                            f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
         }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);          // in flight during the col2im below
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(G + pl * GROW + (i * 32 + 8 * g + 4 * fh) * 4) =
+                    f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
         __syncthreads();
         // col2im: out(2*t0 + ol) = bias + sum_{k == ol parity} G[il = (ol + 2 - k)/2 + 1][k]
-        for (int o = tid; o < 4 * W2N_T * W2N_T; o += 256) {
-            const int oly = o / (2 * W2N_T), olx = o % (2 * W2N_T);
-            const int oy = 2 * ty * W2N_T + oly, ox = 2 * tx * W2N_T + olx;
+        for (int o = tid; o < 4 * W2N_TH * W2N_TW; o += 256) {
+            const int oly = o / (2 * W2N_TW), olx = o % (2 * W2N_TW);
+            const int oy = 2 * ty * W2N_TH + oly, ox = 2 * tx * W2N_TW + olx;
             if (oy >= a.Ho || ox >= a.Wo) continue;
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int ky = oly & 1; ky < 5; ky += 2) {
+            float r[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) r[co] = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy) {
+                const int ky = (oly & 1) + 2 * jy;
+                if (ky > 4) continue;
                 const int ily = (oly + 2 - ky) / 2 + 1;
-                for (int kx = olx & 1; kx < 5; kx += 2) {
+#pragma unroll
+                for (int jx = 0; jx < 3; ++jx) {
+                    const int kx = (olx & 1) + 2 * jx;
+                    if (kx > 4) continue;
                     const int ilx = (olx + 2 - kx) / 2 + 1;
-                    const float* gp = (const float*)((const unsigned char*)G + (ily * 16 + ilx) * GROW) + (ky * 5 + kx) * a.Cout;
-                    for (int co = 0; co < a.Cout; ++co) r[co] += gp[co];
+                    const float* gp = (const float*)(G + (ily * 16 + ilx) * GROW) + (ky * 5 + kx) * COUT;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) r[co] += gp[co];
                 }
             }
-            for (int co = 0; co < a.Cout; ++co)
-                st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype,
-                       apply_act(r[co] + (a.bias ? a.bias[co] : 0.f), a.act));
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype, apply_act(r[co], a.act));
         }
         __syncthreads();
     }
@@ -504,17 +508,10 @@ int launch_forward(const SArgs& a, hipStream_t st) {
         const size_t lds = (size_t)a.KH * a.KW * a.Cin * a.Cout * 4;
         hipLaunchKernelGGL(sconv_narrow_to_wide_kernel, dim3(tiles), dim3(256), lds, st, a);
     } else if (!legacy && a.transposed && a.x_dtype == HESIC_BF16 && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 &&
-               a.Cout <= 4 && a.Cin % 16 == 0 && a.Cin >= 16 && a.Cin <= 128 && a.xs_c == 1 && (a.xs_x % 8) == 0 &&
-               (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Ho == 2 * a.H && a.Wo == 2 * a.W) {
-        const int NT = (25 * a.Cout + 31) / 32;
-        const size_t lds = (size_t)NT * 32 * a.Cin * 2 + (size_t)256 * (NT * 32 * 4 + 16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)sconv_w2n_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        const int64_t tiles = (int64_t)((a.W + W2N_T - 1) / W2N_T) * ((a.H + W2N_T - 1) / W2N_T) * a.B;
-        hipLaunchKernelGGL(sconv_w2n_mfma_kernel, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), lds, st, a, NT);
+               a.Cout == 3 && a.Cin == 128 && a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 &&
+               a.Ho == 2 * a.H && a.Wo == 2 * a.W) {
+        const int64_t tiles = (int64_t)((a.W + W2N_TW - 1) / W2N_TW) * ((a.H + W2N_TH - 1) / W2N_TH) * a.B;
+        hipLaunchKernelGGL((sconv_w2n_mfma_kernel<3>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, a);
     } else if (a.transposed && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Cout <= 4 && a.Cin % 8 == 0 &&
                a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Cin <= 128) {
         const int64_t total = (int64_t)a.B * a.H * a.W;
