@@ -117,6 +117,35 @@ __global__ __launch_bounds__(256) void spatial_max_kernel(const T* __restrict__ 
     }
 }
 
+// inference variant (no argmax): pixels are split over blockIdx.z as well, partial maxima merge through an
+// order-preserving integer atomic; LeakyReLU is monotone, so it is applied to the partials.
+__global__ void fill_neg_inf_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = -INFINITY;
+}
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+    if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+    else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_max_split_kernel(const T* __restrict__ x, float* __restrict__ out, int HW, int C,
+                                                                int leaky, int pix_per_block) {
+    __shared__ float sv[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const int p0 = blockIdx.z * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float best = -INFINITY;
+    if (c < C)
+        for (int p = p0 + pl; p < p1; p += 4) best = fmaxf(best, elem<T>::ld(x + ((int64_t)b * HW + p) * C + c));
+    sv[pl][cl] = best;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        best = fmaxf(fmaxf(sv[0][cl], sv[1][cl]), fmaxf(sv[2][cl], sv[3][cl]));
+        if (leaky) best = best > 0.f ? best : 0.01f * best;
+        atomic_max_float(out + (int64_t)b * C + c, best);
+    }
+}
+
 // logits[b,n] = sum_j w[n,j] * pooled[b,j] + bias[n]: one wave per output
 __global__ __launch_bounds__(256) void mix_logits_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ logits, int B, int N) {
@@ -258,6 +287,16 @@ extern "C" int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int
 
 extern "C" int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW, int C, int dtype, int leaky, void* stream) {
     HESIC_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "spatial_max: bad arguments");
+    if (!argmax && HW >= 256) {
+        const int ppb = 64, nz = (HW + ppb - 1) / ppb;
+        hipLaunchKernelGGL(fill_neg_inf_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, B * C);
+        const dim3 g3((C + 63) / 64, B, nz);
+        if (dtype == HESIC_BF16)
+            hipLaunchKernelGGL(spatial_max_split_kernel<bf16_t>, g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, HW, C, leaky, ppb);
+        else
+            hipLaunchKernelGGL(spatial_max_split_kernel<float>, g3, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, HW, C, leaky, ppb);
+        HESIC_LAUNCH_RETURN("spatial_max");
+    }
     const dim3 grid((C + 63) / 64, B);
     if (dtype == HESIC_BF16)
         hipLaunchKernelGGL(spatial_max_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, argmax, HW, C, leaky);

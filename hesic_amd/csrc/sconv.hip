@@ -437,6 +437,72 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
 // Conv2d or (stride-1) ConvTranspose2d with few channels on both sides: y[co][o] = sum x[ci][o + k - p] w'[k][ci][co] where
 // w' is the kernel (mirrored for the transposed op).  One thread = PX consecutive output pixels of one row; per (ci, ky)
 // it loads the K+PX-1 inputs once and feeds PX*K*COUT FMAs.  Weights sit in LDS as [ky][kx][ci][4] (broadcast float4).
+// LDS-tiled variant for the full-resolution 6 -> 3 stage (pre_conv / after_conv at 512x512): a block stages a
+// (16+K-1) x (64+K-1) x CIN input patch in LDS with row-contiguous loads (every input element leaves L2 once), then each
+// thread produces 4 consecutive pixels x COUT from two aligned ds_read_b128 per (ci, ky); weights are broadcast float4.
+template <int CIN, int COUT, int K>
+__global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) {
+    constexpr int TH = 16, TW = 64, PH = TH + K - 1, PW = TW + 8, PAD = K / 2;   // PW: halo rounded up to keep rows 16-B aligned
+    __shared__ __attribute__((aligned(16))) float xs[CIN * PH * PW];
+    __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * 4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * K * CIN * 4; i += 256) {
+        const int co = i & 3, ci = (i >> 2) % CIN, tap = (i >> 2) / CIN;
+        int ky = tap / K, kx = tap % K;
+        if (a.transposed) { ky = K - 1 - ky; kx = K - 1 - kx; }
+        wl[i] = co < COUT ? w_at(a.w, co, ci, ky, kx, COUT, CIN, K, K, a.transposed) : 0.f;
+    }
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = ty * TH - PAD, x0 = tx * TW - PAD;
+    for (int i = tid; i < CIN * PH * PW; i += 256) {
+        const int px = i % PW, py = (i / PW) % PH, ci = i / (PW * PH);
+        const int iy = y0 + py, ix = x0 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = ld_any(a.x, b * a.xs_b + ci * a.xs_c + (int64_t)iy * a.xs_y + (int64_t)ix * a.xs_x, a.x_dtype);
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = (tid & 15) * 4;
+    float acc[4][COUT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[p][c] = 0.f;
+#pragma unroll 1
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float* row = xs + (ci * PH + ly + ky) * PW + lx;
+            const f32x4 r0 = *(const f32x4*)row, r1 = *(const f32x4*)(row + 4);
+            const float xin[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 wv = *(const f32x4*)(wl + ((ky * K + kx) * CIN + ci) * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    acc[p][0] += xin[p + kx] * wv.x;
+                    if (COUT > 1) acc[p][1 % COUT] += xin[p + kx] * wv.y;
+                    if (COUT > 2) acc[p][2 % COUT] += xin[p + kx] * wv.z;
+                    if (COUT > 3) acc[p][3 % COUT] += xin[p + kx] * wv.w;
+                }
+            }
+        }
+    }
+    const int oy = ty * TH + ly;
+    if (oy < a.Ho)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int ox = tx * TW + lx + p;
+                if (ox < a.Wo) st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype, apply_act(acc[p][co] + bv, a.act));
+            }
+        }
+}
+
 constexpr int SS_PX = 4;
 __global__ __launch_bounds__(256) void sconv_small_s1_kernel(const SArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[7 * 7 * 8 * 4];
@@ -520,6 +586,10 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+    } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
+               a.Wo == a.W && a.Wo >= 64) {
+        const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
+        hipLaunchKernelGGL((sconv_small_s1_lds_kernel<6, 3, 5>), dim3(tiles), dim3(256), 0, st, a);
     } else if (a.stride == 1 && a.Cin <= 8 && a.Cout <= 4 && a.KH <= 7 && a.KW <= 7 && a.Ho == a.H && a.Wo == a.W) {
         const int64_t total = (int64_t)a.B * a.Ho * ((a.Wo + SS_PX - 1) / SS_PX);
         hipLaunchKernelGGL(sconv_small_s1_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, a);

@@ -536,7 +536,8 @@ class _SpatialMaxFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         x = _nhwc(x)
         out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
-        arg = torch.empty((B, Cc), dtype=torch.int32, device=x.device)
+        need_arg = ctx.needs_input_grad[0]                          # the arg-max is only needed by the backward
+        arg = torch.empty((B, Cc), dtype=torch.int32, device=x.device) if need_arg else None
         L.call("hesic_spatial_max", L.ptr(x), L.ptr(out), L.ptr(arg), B, H * W, Cc, L.dt(x), int(leaky), L.stream())
         ctx.save_for_backward(arg, out)
         ctx.meta = (x.shape, x.dtype, leaky)
