@@ -10,6 +10,8 @@
 // channel-major rows into LDS; from there the loop is the same MFMA tile loop as the forward kernel.
 // Pixels are split over blocks (split-K); partial tiles go to a workspace and are summed in a fixed
 // order by a second kernel, so the result is deterministic.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -20,7 +22,7 @@ constexpr int TC = 128;      // channel tile on both sides
 struct WgArgs {
     const void* x; const void* dy; float* out;     // out: workspace [split][tap][Cout][Cin] or dw itself
     int B, H, W, Cin, x_ps, x_co, Ho, Wo, Cout, y_ps, y_co;
-    int QH, QW, transposed, stride, pad, KW, in_abs;
+    int QH, QW, transposed, stride, pad, KW, in_abs, in_sq;
     int64_t Q, chunk;
     int co_tiles, ci_tiles, ntaps, nsplit;
     int8_t tap_id[25];
@@ -127,6 +129,17 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
             u32x4 t[PB];
             if constexpr (sizeof(T) == 2) {
                 transpose8(regs[nb], t);
+                if (a.in_sq && opnd[nb] == 1) {            // X operand squared on the fly (GDN: dgamma' = dn^T x^2)
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        uint32_t* w4 = (uint32_t*)&t[c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
+                            w4[q] = pack_bf2(lo * lo, hi * hi);
+                        }
+                    }
+                }
                 if (a.in_abs && opnd[nb] == 1) {
 #pragma unroll
                     for (int c = 0; c < PB; ++c) t[c] = u32x4{t[c].x & 0x7fff7fffu, t[c].y & 0x7fff7fffu, t[c].z & 0x7fff7fffu, t[c].w & 0x7fff7fffu};
@@ -277,6 +290,125 @@ __global__ __launch_bounds__(256) void sconv_wgrad_generic_kernel(const SWArgs a
     atomicAdd(a.dw + wi, acc);
 }
 
+// ---- narrow x wide weight gradient (g_a_conv1 3 -> 128 and g_s_conv4 128 -> 3, both 5x5 stride 2 pad 2).
+// Both are  dW[wc][nc][tap] = sum_q WIDE[q][wc] * NARROW[2q + k - 2][nc]  with q over the grid of the 128-channel
+// tensor (conv1: WIDE = dy, NARROW = x;  deconv4: WIDE = x, NARROW = dy) and the same weight index (wc*NC + nc)*25 + tap.
+// thread = one wide channel (x 2 pixel halves); the narrow patch of a 8x16 q-tile sits in LDS and is read as
+// wave-uniform (broadcast) rows; 75 accumulators live in registers across the block's tiles; one atomic per weight
+// and block at the end.
+template <int NC, typename WT>
+__global__ __launch_bounds__(256) void sconv_wgrad_nw_kernel(const WT* __restrict__ wide, int64_t ws_b, int64_t ws_y, int64_t ws_x,
+                                                             const void* __restrict__ narrow, int n_dtype, int64_t ns_b, int64_t ns_c,
+                                                             int64_t ns_y, int64_t ns_x, float* __restrict__ dw, int B, int QH, int QW,
+                                                             int NH, int NW) {
+    constexpr int TH = 8, TW = 16, PH = 2 * TH + 3, PW = 2 * TW + 4;       // PW padded to keep rows 8-byte aligned
+    __shared__ __attribute__((aligned(16))) float patch[NC * PH * PW];
+    __shared__ float red[128][NC * 25 + 1];
+    const int tid = threadIdx.x, wc = tid & 127, half = tid >> 7;
+    float acc[NC * 25];
+#pragma unroll
+    for (int i = 0; i < NC * 25; ++i) acc[i] = 0.f;
+    const int tiles_x = (QW + TW - 1) / TW, tiles_y = (QH + TH - 1) / TH;
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+        __syncthreads();
+        for (int i = tid; i < NC * PH * PW; i += 256) {
+            const int px = i % PW, py = (i / PW) % PH, nc = i / (PW * PH);
+            const int ny = 2 * ty * TH - 2 + py, nx = 2 * tx * TW - 2 + px;
+            float v = 0.f;
+            if ((unsigned)ny < (unsigned)NH && (unsigned)nx < (unsigned)NW)
+                v = ld_any(narrow, b * ns_b + nc * ns_c + (int64_t)ny * ns_y + (int64_t)nx * ns_x, n_dtype);
+            patch[i] = v;
+        }
+        __syncthreads();
+        for (int r = half * (TH / 2); r < (half + 1) * (TH / 2); ++r) {
+            const int qy = ty * TH + r;
+            if (qy >= QH) break;
+            for (int c = 0; c < TW; ++c) {
+                const int qx = tx * TW + c;
+                if (qx >= QW) break;
+                const float wv = elem<WT>::ld(wide + b * ws_b + (int64_t)qy * ws_y + (int64_t)qx * ws_x + wc);
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const float* pr = patch + (nc * PH + 2 * r + ky) * PW + 2 * c;     // 8-byte aligned, wave-uniform
+                        const float2 p01 = *(const float2*)pr, p23 = *(const float2*)(pr + 2);
+                        const float p4 = pr[4];
+                        float* ac = acc + (nc * 5 + ky) * 5;
+                        ac[0] += wv * p01.x; ac[1] += wv * p01.y; ac[2] += wv * p23.x; ac[3] += wv * p23.y; ac[4] += wv * p4;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (half == 1)
+#pragma unroll
+        for (int i = 0; i < NC * 25; ++i) red[wc][i] = acc[i];
+    __syncthreads();
+    if (half == 0)
+#pragma unroll
+        for (int i = 0; i < NC * 25; ++i) atomicAdd(dw + (int64_t)wc * NC * 25 + i, acc[i] + red[wc][i]);
+}
+
+// ---- narrow x narrow, stride 1 (pre_conv 6 -> 3, after_conv 6 -> 3 transposed), 5x5 pad 2.
+//   conv:        dW[co][ci][ky][kx] = sum_p dy[co][p] * x[ci][p + k - 2]
+//   transposed:  dW[ci][co][ky][kx] = sum_i x[ci][i]  * dy[co][i + k - 2]
+// i.e. in both cases  dW[a][s][k] = sum_p A[a][p] * S[s][p + k - 2]  with A the un-shifted tensor (dy | x), S the shifted one
+// (x | dy).  A block stages a 16x64 tile of A and the haloed tile of S in LDS; thread = (a, s, ky) keeps 5 kx
+// accumulators and slides along each row (one new S value + one A value per pixel).
+template <int NA, int NS_>
+__global__ __launch_bounds__(256) void sconv_wgrad_nn_kernel(const void* __restrict__ A, int a_dtype, int64_t as_b, int64_t as_c,
+                                                             int64_t as_y, int64_t as_x, const void* __restrict__ S, int s_dtype,
+                                                             int64_t ss_b, int64_t ss_c, int64_t ss_y, int64_t ss_x,
+                                                             float* __restrict__ dw, int a_major, int B, int H, int W) {
+    constexpr int TH = 16, TW = 64, PH = TH + 4, PW = TW + 4;
+    __shared__ float at[NA * TH * TW];
+    __shared__ float st[NS_ * PH * PW];
+    const int tid = threadIdx.x;
+    constexpr int NCOMBO = NA * NS_ * 5;
+    const int half = tid >> 7;
+    const bool live = (tid & 127) < NCOMBO;                      // 90 (a, s, ky) combos in lanes 0..89 of each 128-thread half
+    const int combo = live ? (tid & 127) : 0;
+    const int ia = combo / (NS_ * 5), is = (combo / 5) % NS_, ky = combo % 5;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+        __syncthreads();
+        for (int i = tid; i < NA * TH * TW; i += 256) {
+            const int px = i % TW, py = (i / TW) % TH, c = i / (TW * TH);
+            const int y = ty * TH + py, x = tx * TW + px;
+            at[i] = (y < H && x < W) ? ld_any(A, b * as_b + c * as_c + (int64_t)y * as_y + (int64_t)x * as_x, a_dtype) : 0.f;
+        }
+        for (int i = tid; i < NS_ * PH * PW; i += 256) {
+            const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+            const int y = ty * TH - 2 + py, x = tx * TW - 2 + px;
+            st[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ld_any(S, b * ss_b + c * ss_c + (int64_t)y * ss_y + (int64_t)x * ss_x, s_dtype) : 0.f;
+        }
+        __syncthreads();
+        if (live)
+            for (int r = half * (TH / 2); r < (half + 1) * (TH / 2); ++r) {
+                const float* ar = at + (ia * TH + r) * TW;
+                const float* sr = st + (is * PH + r + ky) * PW;
+                float w0 = sr[0], w1 = sr[1], w2 = sr[2], w3 = sr[3];
+                for (int c = 0; c < TW; ++c) {
+                    const float w4 = sr[c + 4], av = ar[c];
+                    acc[0] += av * w0; acc[1] += av * w1; acc[2] += av * w2; acc[3] += av * w3; acc[4] += av * w4;
+                    w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+                }
+            }
+    }
+    if (live) {
+        // weight layout: conv (a_major: a = co) -> [a][s][ky][kx]; transposed (a = ci... stored [s][a]) -> see launcher
+        const int64_t base = a_major ? ((int64_t)(ia * NS_ + is) * 5 + ky) * 5 : ((int64_t)(is * NA + ia) * 5 + ky) * 5;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) atomicAdd(dw + base + kx, acc[kx]);
+    }
+}
+
 __global__ __launch_bounds__(256) void sconv_dbias_kernel(const SWArgs a) {
     __shared__ float red[4];
     const int co = blockIdx.y;
@@ -368,6 +500,146 @@ __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float
     }
 }
 
+// ---- GDN backward, bf16 storage, C = 128: one pass over (x, gy) on the matrix cores.
+//   GEMM1  n = beta' + gamma' x^2          -> r = n^-1/2 | n^1/2,  t1 = g r,  dn = -1/2 g x r^3 | +1/2 g x / r
+//   GEMM2  s_j = sum_i gamma'[i,j] dn_i     -> dx = t1 + 2 x s
+// dn (bf16) also goes to a workspace; dgamma' = dn^T x^2 and dbeta' = colsum(dn) are then produced by the 1x1
+// weight-gradient MFMA kernel (x squared on load).  After the tile load every wave owns its 32 pixel rows of both
+// LDS tiles, so no block barrier is needed inside the tile loop.
+__device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (slot ^ (row & 15))) * 16; }   // 256-byte rows
+
+__global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy,
+                                                         const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out, int64_t P,
+                                                         int inverse, float beta_bound) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* gs = smem;                   // gamma'   [i][j]
+    unsigned char* gt = smem + 32768;           // gamma'^T [j][i]
+    unsigned char* xs = smem + 65536;           // x tile   [128 px][128 ch]  (becomes dx)
+    unsigned char* ds = smem + 98304;           // gy tile  (becomes dn)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int c = tid; c < 128 * 16; c += 256) {
+        const int row = c >> 4, slot = c & 15;
+        float v[8], vt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = reparam(gamma[row * 128 + slot * 8 + e], kGammaBound);
+            vt[e] = reparam(gamma[(slot * 8 + e) * 128 + row], kGammaBound);
+        }
+        *(u32x4*)(gs + gb_off(row, slot)) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(gt + gb_off(row, slot)) = u32x4{pack_bf2(vt[0], vt[1]), pack_bf2(vt[2], vt[3]), pack_bf2(vt[4], vt[5]), pack_bf2(vt[6], vt[7])};
+    }
+    float bv[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[i][g][e] = reparam(beta[i * 32 + 8 * g + 4 * fh + e], beta_bound);
+    __syncthreads();
+    const int64_t ntiles = (P + 127) / 128;
+    const int r0 = wave * 32;                   // this wave's rows in both tiles
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 128 + r0;
+        // wave-private load of 32 rows x 16 slots of x and gy
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
+            u32x4 vx = u32x4{0, 0, 0, 0}, vg = u32x4{0, 0, 0, 0};
+            if (p0 + row < P) {
+                vx = *(const u32x4*)(x + (p0 + row) * 128 + slot * 8);
+                vg = *(const u32x4*)(gy + (p0 + row) * 128 + slot * 8);
+            }
+            *(u32x4*)(xs + gb_off(r0 + row, slot)) = vx;
+            *(u32x4*)(ds + gb_off(r0 + row, slot)) = vg;
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 raw = *(const u32x4*)(xs + gb_off(r0 + frow, ks * 2 + fh));
+            const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
+            const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
+            const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
+            const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
+            const u32x4 sq = u32x4{pack_bf2(f0 * f0, f1 * f1), pack_bf2(f2 * f2, f3 * f3), pack_bf2(f4 * f4, f5 * f5), pack_bf2(f6 * f6, f7 * f7)};
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, sq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 gf = *(const bf16x8*)(gs + gb_off(i * 32 + frow, ks * 2 + fh));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[i], 0, 0, 0);
+            }
+        }
+        // lane: pixel r0+frow, channels i*32 + 8g + 4fh + e.  t1 stays in acc, dn replaces gy in LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * fh;
+                const int off = gb_off(r0 + frow, ch >> 3) + (ch & 7) * 2;
+                const u32x2 xr = *(const u32x2*)(xs + off), gr = *(const u32x2*)(ds + off);
+                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                const float gv[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xffff0000u), __uint_as_float(gr.y << 16), __uint_as_float(gr.y & 0xffff0000u)};
+                float dn[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = acc[i][4 * g + e] + bv[i][g][e];
+                    if (inverse) {
+                        const float sq = sqrtf(n);
+                        dn[e] = 0.5f * gv[e] * xv[e] / sq;
+                        acc[i][4 * g + e] = gv[e] * sq;
+                    } else {
+                        const float rs = rsqrtf(n);
+                        dn[e] = -0.5f * gv[e] * xv[e] * rs * rs * rs;
+                        acc[i][4 * g + e] = gv[e] * rs;
+                    }
+                }
+                *(u32x2*)(ds + off) = u32x2{pack_bf2(dn[0], dn[1]), pack_bf2(dn[2], dn[3])};
+            }
+        // GEMM2: s[j][p] = sum_i gamma'^T[j][i] dn[p][i]
+        f32x16 s2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 df = *(const bf16x8*)(ds + gb_off(r0 + frow, ks * 2 + fh));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 gf = *(const bf16x8*)(gt + gb_off(i * 32 + frow, ks * 2 + fh));
+                s2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, df, s2[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * fh;
+                const int off = gb_off(r0 + frow, ch >> 3) + (ch & 7) * 2;
+                const u32x2 xr = *(const u32x2*)(xs + off);
+                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[i][4 * g + e] + 2.f * xv[e] * s2[i][4 * g + e];
+                *(u32x2*)(xs + off) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            }
+        // wave-private copy-out of dx and dn (full 256-byte rows)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
+            if (p0 + row < P) {
+                *(u32x4*)(dx + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(xs + gb_off(r0 + row, slot));
+                *(u32x4*)(dn_out + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(ds + gb_off(r0 + row, slot));
+            }
+        }
+    }
+}
+
 int pick_splits(int64_t Q, int bk, int tiles) {
     // aim at ~1500 blocks, at least 4 K-steps per block
     int64_t s = (1536 + tiles - 1) / tiles;
@@ -451,33 +723,116 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nw = (int64_t)d->Cout * d->Cin * d->KH * d->KW;
-    const int64_t Q = (int64_t)d->B * (d->transposed ? d->H * d->W : d->Ho * d->Wo);
-    const int gx = (int)((nw + 255) / 256);
-    int gy = (int)(2048 / gx > 0 ? 2048 / gx : 1);
-    if (gy > Q) gy = (int)Q;
-    a.q_per_block = (Q + gy - 1) / gy;
-    gy = (int)((Q + a.q_per_block - 1) / a.q_per_block);
-    hipMemsetAsync(dw, 0, (size_t)nw * 4, st);
-    hipLaunchKernelGGL(sconv_wgrad_generic_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+    (void)hipMemsetAsync(dw, 0, (size_t)nw * 4, st);
+    static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;
+    const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2;
+    if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
+        d->H == 2 * d->Ho && d->W == 2 * d->Wo) {
+        // conv1: WIDE = dy (output grid), NARROW = x
+        const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 7) / 8) * d->B;
+        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, bf16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const bf16_t*)dy,
+                           d->ys_b, d->ys_y, d->ys_x, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, d->B, d->Ho, d->Wo, d->H, d->W);
+    } else if (!legacy && k5 && d->stride == 2 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_BF16 &&
+               d->Ho == 2 * d->H && d->Wo == 2 * d->W) {
+        // deconv4: WIDE = x (input grid), NARROW = dy
+        const int64_t tiles = (int64_t)((d->W + 15) / 16) * ((d->H + 7) / 8) * d->B;
+        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, bf16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const bf16_t*)x,
+                           d->xs_b, d->xs_y, d->xs_x, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, d->B, d->H, d->W, d->Ho, d->Wo);
+    } else if (!legacy && k5 && d->stride == 1 && d->Cin == 6 && d->Cout == 3 && d->Ho == d->H && d->Wo == d->W) {
+        const int64_t tiles = (int64_t)((d->W + 63) / 64) * ((d->H + 15) / 16) * d->B;
+        const unsigned g = (unsigned)(tiles < 1024 ? tiles : 1024);
+        if (!d->transposed)   // A = dy (co), S = x (ci); dW[co][ci][k]
+            hipLaunchKernelGGL((sconv_wgrad_nn_kernel<3, 6>), dim3(g), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, x,
+                               d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, 1, d->B, d->H, d->W);
+        else                  // A = x (ci), S = dy (co); dW[ci][co][k]
+            hipLaunchKernelGGL((sconv_wgrad_nn_kernel<6, 3>), dim3(g), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dy,
+                               d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, 1, d->B, d->H, d->W);
+    } else {
+        const int64_t Q = (int64_t)d->B * (d->transposed ? d->H * d->W : d->Ho * d->Wo);
+        const int gx = (int)((nw + 255) / 256);
+        int gy = (int)(2048 / gx > 0 ? 2048 / gx : 1);
+        if (gy > Q) gy = (int)Q;
+        a.q_per_block = (Q + gy - 1) / gy;
+        gy = (int)((Q + a.q_per_block - 1) / a.q_per_block);
+        hipLaunchKernelGGL(sconv_wgrad_generic_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+    }
     if (dbias) {
-        hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
+        (void)hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
         hipLaunchKernelGGL(sconv_dbias_kernel, dim3(64, d->Cout), dim3(256), 0, st, a);
     }
     HESIC_LAUNCH_RETURN("sconv2d_wgrad");
 }
 
-extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) { return (2 * P * C + (int64_t)C * C + C) * 4; }
+static int gdn_fast_desc(int64_t P, hesic_conv_desc& d) {
+    // the parameter gradients of the fast path are a 1x1 "conv" weight gradient over P pixels: dY = dn, X = x
+    memset(&d, 0, sizeof(d));
+    d.B = 1; d.H = 1; d.W = (int32_t)P; d.Cin = 128; d.Ho = 1; d.Wo = (int32_t)P; d.Cout = 128; d.KH = d.KW = 1; d.stride = 1;
+    d.dtype = HESIC_BF16; d.x_pix_stride = 128; d.y_pix_stride = 128;
+    return 0;
+}
+
+extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) {
+    int64_t generic = (2 * P * C + (int64_t)C * C + C) * 4;
+    if (C == 128 && P < (1ll << 31)) {
+        hesic_conv_desc d;
+        gdn_fast_desc(P, d);
+        WgArgs a;
+        fill_args(&d, a);
+        const int64_t fast = P * 128 * 2 + 256 + (int64_t)a.nsplit * 128 * 128 * 4 + (128 * 128 + 128) * 4;
+        if (fast > generic) generic = fast;
+    }
+    return generic;
+}
+
+extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
+                                  void* ws, int64_t ws_bytes, void* stream);
 
 extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
                                   float* dgamma, void* ws, int64_t P, int C, int inverse, float beta_min, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && dy && beta && gamma && dx && dbeta && dgamma && ws && P > 0 && C > 0, "gdn_backward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
+    static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr;
+    if (!legacy && C == 128 && dtype == HESIC_BF16 && P < (1ll << 31)) {
+        hesic_conv_desc d;
+        gdn_fast_desc(P, d);
+        WgArgs a;
+        fill_args(&d, a);
+        unsigned char* base = (unsigned char*)ws;
+        bf16_t* dn = (bf16_t*)base;
+        int64_t off = (P * 128 * 2 + 255) / 256 * 256;
+        void* wws = base + off;
+        const int64_t wws_bytes = (int64_t)a.nsplit * 128 * 128 * 4;
+        off += wws_bytes;
+        float* dgp = (float*)(base + off);
+        float* dbp = dgp + 128 * 128;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+        const int64_t tiles = (P + 127) / 128;
+        hipLaunchKernelGGL(gdn128_bwd_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), 131072, st, (const bf16_t*)x,
+                           (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, P, inverse, bound);
+        {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        // dgamma'[i][j] = sum_p dn[p][i] x[p][j]^2 ; dbeta'[i] = sum_p dn[p][i]
+        // (same kernels as hesic_conv2d_wgrad, with the X operand squared on load)
+        a.x = x; a.dy = dn; a.out = (float*)wws; a.in_sq = 1;
+        const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(128 * 128, 256)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
+                           (int64_t)128 * 128, a);
+        (void)hipMemsetAsync(dbp, 0, 128 * 4, st);
+        const int64_t rpb = P / 1024 > 0 ? (P + 1023) / 1024 : 1;
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(256), 0, st, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
+        hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
+        HESIC_LAUNCH_RETURN("gdn_backward");
+    }
     float* dn = (float*)ws;
     float* dx0 = dn + P * C;
     float* dgp = dx0 + P * C;
     float* dbp = dgp + (int64_t)C * C;
-    hipMemsetAsync(dgp, 0, ((size_t)C * C + C) * 4, st);
+    (void)hipMemsetAsync(dgp, 0, ((size_t)C * C + C) * 4, st);
     hipLaunchKernelGGL(gdn_bwd_dn_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, dy, beta, gamma, dn, dx0, P, C, inverse, bound, dtype);
     hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, gamma, dn, dx0, dx, P, C, dtype);
     const int gx = (C * C + 255) / 256;

@@ -377,3 +377,65 @@ def test_fused_conv_gdn_matches_the_two_ops(tr, inv):
     assert one.shape == two.shape and one.dtype == torch.bfloat16
     assert rel_err(one, ref) < 1.5e-2 and rel_err(two, ref) < 1.5e-2
     assert rel_err(one, two) < 1.5e-2
+
+
+def test_image_side_conv_gradients_bf16():
+    """Backward of the 3-channel-side convs in bf16 storage (MFMA dgrad kernels + the narrow weight-gradient kernels)."""
+    Fn, O = _imp()
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        # g_a_conv1: 3 -> 128, 5x5 s2
+        x = rnd("ig_x", (2, 3, 64, 96), 0, 1)
+        w = rnd("ig_w", (128, 3, 5, 5)) * 0.2
+        b = rnd("ig_b", (128,), -0.1, 0.1)
+        xo, wo, bo = x.clone().requires_grad_(), bf(w).requires_grad_(), b.clone().requires_grad_()
+        yo = O.conv(bf(xo), wo, bo, 2)
+        gy = bf(rnd("ig_g", yo.shape))
+        yo.backward(gy)
+        xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        y = Fn.conv2d(xd, wd, bd, kernel_size=5, stride=2, padding=2)
+        y.backward(gy.to(DEV, torch.bfloat16))
+        assert rel_err(xd.grad, xo.grad) < 2e-2 and rel_err(wd.grad, wo.grad) < 2e-2 and rel_err(bd.grad, bo.grad) < 2e-2
+        # g_s_conv4: 128 -> 3 transposed
+        f = bf(rnd("ig_f", (2, 128, 24, 40)))
+        wt = rnd("ig_wt", (128, 3, 5, 5)) * 0.05
+        fo, wto = f.clone().requires_grad_(), bf(wt).requires_grad_()
+        yo = O.deconv(fo, wto, None, 2)
+        g2 = rnd("ig_g2", yo.shape)
+        yo.backward(g2)
+        fd, wtd = f.to(DEV, torch.bfloat16).requires_grad_(), wt.to(DEV).requires_grad_()
+        yt = Fn.conv2d(fd, wtd, None, kernel_size=5, stride=2, padding=2, transposed=True)
+        yt.backward(g2.to(DEV))
+        assert rel_err(fd.grad, fo.grad) < 2e-2 and rel_err(wtd.grad, wto.grad) < 2e-2
+        # pre_conv / after_conv: 6 -> 3 stride 1 (fp32 on both sides)
+        for tr in (False, True):
+            x6 = rnd("ig_x6", (2, 6, 40, 72), 0, 1)
+            w6 = rnd("ig_w6" + str(tr), (6, 3, 5, 5) if tr else (3, 6, 5, 5)) * 0.1
+            b6 = rnd("ig_b6", (3,), -0.1, 0.1)
+            xo, wo, bo = x6.clone().requires_grad_(), w6.clone().requires_grad_(), b6.clone().requires_grad_()
+            yo = (O.deconv if tr else O.conv)(xo, wo, bo, 1)
+            g6 = rnd("ig_g6", yo.shape)
+            yo.backward(g6)
+            xd, wd, bd = x6.to(DEV).requires_grad_(), w6.to(DEV).requires_grad_(), b6.to(DEV).requires_grad_()
+            Fn.conv2d(xd, wd, bd, kernel_size=5, stride=1, padding=2, transposed=tr).backward(g6.to(DEV))
+            assert rel_err(xd.grad, xo.grad) < 2e-4 and rel_err(wd.grad, wo.grad) < 2e-4 and rel_err(bd.grad, bo.grad) < 2e-4, tr
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("inv", [False, True])
+def test_gdn128_backward_bf16(inv):
+    """The one-pass MFMA GDN backward (bf16 storage) against the oracle's autograd."""
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=4)
+    x = bf(rnd("gb_x", (2, 128, 20, 24), -3, 3))
+    g = bf(rnd("gb_g", x.shape))
+    xo, bo, go = x.clone().requires_grad_(), sd["g.beta"].clone().requires_grad_(), sd["g.gamma"].clone().requires_grad_()
+    O.gdn(xo, bo, go, inv).backward(g)
+    xd = x.to(DEV, torch.bfloat16).requires_grad_()
+    bd, gd = sd["g.beta"].to(DEV).requires_grad_(), sd["g.gamma"].to(DEV).requires_grad_()
+    Fn.gdn(xd, bd, gd, inv).backward(g.to(DEV, torch.bfloat16))
+    assert rel_err(xd.grad, xo.grad) < 2e-2
+    assert rel_err(bd.grad, bo.grad) < 2e-2
+    assert rel_err(gd.grad, go.grad) < 3e-2
