@@ -443,11 +443,13 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
 template <int CIN, int COUT, int K>
 __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) {
     constexpr int TH = 16, TW = 64, PH = TH + K - 1, PW = TW + 8, PAD = K / 2;   // PW: halo rounded up to keep rows 16-B aligned
+    constexpr int CP = COUT <= 4 ? 4 : 8;                                         // padded cout count of the weight rows
+    static_assert(COUT <= 8, "at most 8 output channels");
     __shared__ __attribute__((aligned(16))) float xs[CIN * PH * PW];
-    __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * 4];
+    __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * CP];
     const int tid = threadIdx.x;
-    for (int i = tid; i < K * K * CIN * 4; i += 256) {
-        const int co = i & 3, ci = (i >> 2) % CIN, tap = (i >> 2) / CIN;
+    for (int i = tid; i < K * K * CIN * CP; i += 256) {
+        const int co = i % CP, ci = (i / CP) % CIN, tap = (i / CP) / CIN;
         int ky = tap / K, kx = tap % K;
         if (a.transposed) { ky = K - 1 - ky; kx = K - 1 - kx; }
         wl[i] = co < COUT ? w_at(a.w, co, ci, ky, kx, COUT, CIN, K, K, a.transposed) : 0.f;
@@ -479,14 +481,14 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
             const float xin[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const f32x4 wv = *(const f32x4*)(wl + ((ky * K + kx) * CIN + ci) * 4);
+                const float* wp = wl + ((ky * K + kx) * CIN + ci) * CP;
+                float wv[CP];
+                *(f32x4*)wv = *(const f32x4*)wp;
+                if (CP == 8) *(f32x4*)(wv + 4) = *(const f32x4*)(wp + 4);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    acc[p][0] += xin[p + kx] * wv.x;
-                    if (COUT > 1) acc[p][1 % COUT] += xin[p + kx] * wv.y;
-                    if (COUT > 2) acc[p][2 % COUT] += xin[p + kx] * wv.z;
-                    if (COUT > 3) acc[p][3 % COUT] += xin[p + kx] * wv.w;
-                }
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[p][co] += xin[p + kx] * wv[co];
             }
         }
     }
@@ -586,10 +588,11 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
-    } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
-               a.Wo == a.W && a.Wo >= 64) {
+    } else if (!legacy && a.stride == 1 && ((a.Cin == 6 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 6)) && a.KH == 5 && a.KW == 5 &&
+               a.pad == 2 && a.Ho == a.H && a.Wo == a.W && a.Wo >= 64) {
         const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
-        hipLaunchKernelGGL((sconv_small_s1_lds_kernel<6, 3, 5>), dim3(tiles), dim3(256), 0, st, a);
+        if (a.Cin == 6) hipLaunchKernelGGL((sconv_small_s1_lds_kernel<6, 3, 5>), dim3(tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sconv_small_s1_lds_kernel<3, 6, 5>), dim3(tiles), dim3(256), 0, st, a);      // their data gradients
     } else if (a.stride == 1 && a.Cin <= 8 && a.Cout <= 4 && a.KH <= 7 && a.KW <= 7 && a.Ho == a.H && a.Wo == a.W) {
         const int64_t total = (int64_t)a.B * a.Ho * ((a.Wo + SS_PX - 1) / SS_PX);
         hipLaunchKernelGGL(sconv_small_s1_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, a);

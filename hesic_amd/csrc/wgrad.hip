@@ -325,10 +325,16 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nw_kernel(const WT* __restric
         for (int r = half * (TH / 2); r < (half + 1) * (TH / 2); ++r) {
             const int qy = ty * TH + r;
             if (qy >= QH) break;
+            // the row's 16 wide values first (independent loads in flight together), then 16 x 75 FMAs
+            float wrow[TW];
+#pragma unroll
             for (int c = 0; c < TW; ++c) {
                 const int qx = tx * TW + c;
-                if (qx >= QW) break;
-                const float wv = elem<WT>::ld(wide + b * ws_b + (int64_t)qy * ws_y + (int64_t)qx * ws_x + wc);
+                wrow[c] = qx < QW ? elem<WT>::ld(wide + b * ws_b + (int64_t)qy * ws_y + (int64_t)qx * ws_x + wc) : 0.f;
+            }
+#pragma unroll 4
+            for (int c = 0; c < TW; ++c) {
+                const float wv = wrow[c];
 #pragma unroll
                 for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
@@ -758,7 +764,16 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     }
     if (dbias) {
         (void)hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
-        hipLaunchKernelGGL(sconv_dbias_kernel, dim3(64, d->Cout), dim3(256), 0, st, a);
+        const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
+        if (d->ys_c == 1 && d->Cout >= 32 && d->ys_x == d->Cout && d->ys_y == (int64_t)d->Wo * d->Cout &&
+            d->ys_b == (int64_t)d->Ho * d->Wo * d->Cout) {       // dense NHWC: coalesced column sums
+            const int64_t rpb = P / 1024 > 0 ? (P + 1023) / 1024 : 1;
+            const unsigned g = (unsigned)((P + rpb - 1) / rpb);
+            if (d->y_dtype == HESIC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
+            else hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
+        } else {
+            hipLaunchKernelGGL(sconv_dbias_kernel, dim3(256, d->Cout), dim3(256), 0, st, a);
+        }
     }
     HESIC_LAUNCH_RETURN("sconv2d_wgrad");
 }
