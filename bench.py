@@ -202,11 +202,12 @@ def main():
     models.OVERLAP_STREAMS = overlap
     if s:
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        traffic = None
+        traffic = None            # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/make_pmc_json.py)
         pj = os.path.join(ROOT, "profiles", "pmc_igemm.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get(f"{args.model}_{args.dtype}_b{args.batch}_{args.size}", {}).get("hbm_bytes_per_launch")
+                key = f"{args.model}_{args.dtype}_b{args.batch}_{args.size}"
+                traffic = json.load(open(pj)).get(key, {}).get("per_kernel", {}).get(s["kernel"], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"kernel": s["kernel"], "bound": "mfma",

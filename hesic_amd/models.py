@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from compressai.entropy_models import EntropyBottleneck, GaussianConditional, GaussianMixtureConditional
-from compressai.layers import GDN, MaskedConv2d
+from compressai.layers import GDN, MaskedConv2d, ResidualBlock, conv3x3
 from compressai.models.utils import HipConv2d, conv, deconv
 
 from . import _lib as L
@@ -410,6 +410,62 @@ class HSICJoint(StereoCompressionModel):
         x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
+
+# -------------------------------------------------------------------- enhancement
+class Enhancement_Block(nn.Module):
+    """Three residual blocks with an outer skip (newnet1.py:272-286)."""
+
+    def __init__(self):
+        super().__init__()
+        self.RB1, self.RB2, self.RB3 = ResidualBlock(32, 32), ResidualBlock(32, 32), ResidualBlock(32, 32)
+
+    def forward(self, x):
+        return self.RB3(self.RB2(self.RB1(x))) + x
+
+
+class Enhancement(nn.Module):
+    """conv3x3(6->32) -> 3 Enhancement_Blocks -> conv3x3(32->3) -> + x (newnet1.py:288-311)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = conv3x3(6, 32)
+        self.EB1, self.EB2, self.EB3 = Enhancement_Block(), Enhancement_Block(), Enhancement_Block()
+        self.conv2 = conv3x3(32, 3)
+
+    def forward(self, x, x_another_warp):
+        t = self.conv1(torch.cat((x.float(), x_another_warp.float()), 1))
+        t = self.EB3(self.EB2(self.EB1(t)))
+        return self.conv2(t) + x
+
+
+class Independent_EN(nn.Module):
+    """Stage-2 cross-view enhancement (newnet1.py:1278-1300): view 1 is refined with view 2 warped by H^-1,
+    view 2 with view 1 warped by H.  The 3x3 inverse is plumbing (torch.inverse, 9 numbers per pair)."""
+
+    def __init__(self):
+        super().__init__()
+        self.EH1, self.EH2 = Enhancement(), Enhancement()
+
+    def forward(self, x1_hat, x2_hat, h_matrix):
+        size = (x1_hat.shape[-2], x1_hat.shape[-1])
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        x2_hat_warp = warp_perspective(x2_hat, torch.inverse(h_matrix), size)     # fp32 inverse, as the reference (:1290)
+        return {"x1_hat": self.EH1(x1_hat, x2_hat_warp), "x2_hat": self.EH2(x2_hat, x1_hat_warp)}
+
+
+class GMM_together(nn.Module):
+    """HESIC followed by the enhancement stage (newnet1.py:1304-1321) -- what the README's test script evaluates."""
+
+    def __init__(self, N=128, M=192, K=5, **kwargs):
+        super().__init__()
+        self.m1 = HSIC(N, M, K)
+        self.m2 = Independent_EN()
+
+    def forward(self, x1, x2, h):
+        out1 = self.m1(x1, x2, h)
+        out2 = self.m2(out1["x1_hat"], out1["x2_hat"], h)
+        return {"x1_hat": out2["x1_hat"], "x2_hat": out2["x2_hat"], "likelihoods": out1["likelihoods"]}
 
 
 # ------------------------------------------------------------------------------------------ metrics

@@ -394,6 +394,34 @@ def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=
             "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
 
+# ------------------------------------------------------ enhancement
+def _residual_block(P, pre, x):
+    """ResidualBlock (compressai/layers/layers.py:125-147): conv3x3 -> LeakyReLU -> conv3x3 -> LeakyReLU, + x."""
+    t = F.leaky_relu(F.conv2d(x, P[pre + "conv1.weight"], P[pre + "conv1.bias"], padding=1), 0.01)
+    t = F.leaky_relu(F.conv2d(t, P[pre + "conv2.weight"], P[pre + "conv2.bias"], padding=1), 0.01)
+    return t + x
+
+
+def enhancement(P, pre, x, x_other_warp):
+    """Enhancement.forward (ywz/mywork/newnet1.py:288-311): conv3x3(6->32), 3 blocks of 3 residual blocks (each block
+    with its own skip, :272-286), conv3x3(32->3), + x."""
+    t = F.conv2d(torch.cat((x, x_other_warp), 1), P[pre + "conv1.weight"], P[pre + "conv1.bias"], padding=1)
+    for eb in ("EB1.", "EB2.", "EB3."):
+        u = t
+        for rb in ("RB1.", "RB2.", "RB3."):
+            u = _residual_block(P, pre + eb + rb, u)
+        t = u + t
+    return F.conv2d(t, P[pre + "conv2.weight"], P[pre + "conv2.bias"], padding=1) + x
+
+
+def independent_en(P, x1_hat, x2_hat, Hm, align_corners=True):
+    """Independent_EN.forward (newnet1.py:1278-1300): each view is enhanced with the other view warped onto it."""
+    size = x1_hat.shape[-2:]
+    x1w = warp_perspective(x1_hat, Hm, size, align_corners)
+    x2w = warp_perspective(x2_hat, torch.inverse(Hm), size, align_corners)      # fp32 inverse, as the reference (:1290)
+    return {"x1_hat": enhancement(P, "EH1.", x1_hat, x2w), "x2_hat": enhancement(P, "EH2.", x2_hat, x1w)}
+
+
 # --------------------------------------------------------------- loss and metrics
 def rd_loss(out, x1, x2, lmbda):
     """RateDistortionLoss (ywz/mywork/newtrain1.py:37-56)."""

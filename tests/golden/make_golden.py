@@ -416,6 +416,23 @@ def fx_models(newnet1, newnet1_joint):
                     f.write(f"{k} {' '.join(map(str, shapes[k]))}\n")
 
 
+def fx_enhance(newnet1):
+    """Independent_EN (cross-view enhancement, newnet1.py:272-311,1278-1300)."""
+    net = newnet1.Independent_EN().eval()
+    sd = net.state_dict()
+    for name, t in sd.items():          # name-keyed deterministic fill (fan-in scaled), small so the residual stays tame
+        fan = t.shape[1] * 9 if t.dim() == 4 else 1
+        a = (3.0 / fan) ** 0.5 if t.dim() == 4 else 0.05
+        t.copy_(synthetic._uniform("en." + name, t.shape, -a, a))
+    x1, x2, Hm = synthetic.stereo_batch(5, 2, 64, 64)
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+    with open(os.path.join(HERE, "en_state_keys.txt"), "w") as f:
+        for k, v in sd.items():
+            f.write(f"{k} {' '.join(map(str, v.shape))}\n")
+    npz("en_64.npz", x1_hat=out["x1_hat"], x2_hat=out["x2_hat"])
+
+
 def fx_codec():
     """G11: pmf_to_quantized_cdf cases and rANS byte strings from the reference's C++ extensions."""
     from compressai._CXX import pmf_to_quantized_cdf
@@ -449,13 +466,15 @@ def fx_codec():
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "codec"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "codec", "enhance"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
         fx_warp()
     if "codec" in which:
         fx_codec()
+    if "enhance" in which:
+        fx_enhance(newnet1)
     if "models" in which:
         fx_models(newnet1, newnet1_joint)
 

@@ -143,3 +143,23 @@ def test_train_trace_matches_reference(kind):
     for s in range(2):
         for j, nm in enumerate(("loss", "bpp", "mse", "aux")):
             assert trace[s][j] == pytest.approx(float(ref[s][j]), rel=5e-3), (s, nm, trace, ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)], ids=["f32", "bf16"])
+def test_independent_en_matches_reference(dtype, tol):
+    """Independent_EN (9 residual blocks of 3x3 C=32 convs per view + 2 warps) on the HIP path."""
+    import hesic_amd
+    from hesic_amd import models
+    from test_oracle_golden import _en_params
+    g = load_golden("en_64.npz")
+    hesic_amd.set_compute_dtype(dtype)
+    net = models.Independent_EN()
+    net.load_state_dict(_en_params(), strict=True)
+    net = net.to(DEV).eval()
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(5, 2, 64, 64))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+    for k in ("x1_hat", "x2_hat"):
+        ref = T(g[k])
+        err = float((out[k].float().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < tol, (k, err)

@@ -34,6 +34,14 @@ def test_state_dict_keys_and_shapes_match_reference(kind):
     assert n_aux == 15616 and n_main == (35065128 if kind == "hsic" else 19886056)
 
 
+def test_enhancement_stage_state_dict_matches_reference():
+    from hesic_amd import models
+    ours = {k: tuple(v.shape) for k, v in models.Independent_EN().state_dict().items()}
+    assert ours == _keys("en")
+    both = models.GMM_together().state_dict()
+    assert "m1.encoder1.g_a_conv1.weight" in both and "m2.EH2.EB3.RB3.conv2.bias" in both
+
+
 def test_public_names_of_the_reference_import_block():
     from compressai.ans import BufferedRansEncoder, RansDecoder, RansEncoder  # noqa: F401
     from compressai._CXX import pmf_to_quantized_cdf  # noqa: F401

@@ -201,3 +201,27 @@ def test_whole_model_forward(kind, size, batch):
         close(out["x1_hat"], g["x1_hat"], 1e-3, 1e-4)
         close(out["x2_hat"], g["x2_hat"], 1e-3, 1e-4)
         close(out["likelihoods"]["z1"], g["lik_z1"], 1e-3, 1e-8)
+
+
+def _en_params():
+    import os
+    from conftest import GOLDEN
+    P = {}
+    with open(os.path.join(GOLDEN, "en_state_keys.txt")) as f:
+        for line in f:
+            parts = line.split()
+            shape = tuple(int(v) for v in parts[1:])
+            fan = shape[1] * 9 if len(shape) == 4 else 1
+            a = (3.0 / fan) ** 0.5 if len(shape) == 4 else 0.05
+            P[parts[0]] = synthetic._uniform("en." + parts[0], shape, -a, a)
+    return P
+
+
+def test_independent_en():
+    """the enhancement stage against the reference-generated golden."""
+    g = load_golden("en_64.npz")
+    x1, x2, Hm = synthetic.stereo_batch(5, 2, 64, 64)
+    with torch.no_grad():
+        out = O.independent_en(_en_params(), x1, x2, Hm)
+    close(out["x1_hat"], g["x1_hat"], 1e-4, 1e-5)
+    close(out["x2_hat"], g["x2_hat"], 1e-4, 1e-5)
