@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--height", type=int, default=None, help="non-square workloads (e.g. 860x1080, zero-padded to x64)")
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--model", choices=["hsic", "joint"], default="hsic")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,13 +166,15 @@ def main():
 
     # synthetic pairs: rank r gets pairs [r*B, (r+1)*B); one generated pair set is tiled if B is large
     uniq = min(args.batch, 4)
-    x1, x2, Hm = synthetic.stereo_batch(rank * uniq, uniq, args.size, args.size)
+    H_img, W_img = args.height or args.size, args.width or args.size
+    x1, x2, Hm = synthetic.stereo_batch(rank * uniq, uniq, H_img, W_img)
     reps = -(-args.batch // uniq)
     x1, x2, Hm = (t.repeat(reps, *([1] * (t.dim() - 1)))[:args.batch].to(dev) for t in (x1, x2, Hm))
+    x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)      # no-op at 512x512
 
     def step():
         with torch.no_grad():
-            out = net(x1, x2, Hm)
+            out = net(x1p, x2p, Hm)
             return models.rate_distortion(out, x1, x2)
 
     for _ in range(args.warmup):
@@ -223,18 +227,19 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{'HESIC' if args.model == 'hsic' else 'HESIC+'} eval forward (encode+decode) + bpp/PSNR, "
-                                   f"{args.size}x{args.size} stereo pairs, batch {args.batch}/GPU, random-init-shaped deterministic weights",
+                                   f"{H_img}x{W_img} stereo pairs, batch {args.batch}/GPU, random-init-shaped deterministic weights",
                        "pairs_per_step": world * args.batch, "sharding": f"pairs over {world} GPU(s), no collective on the path"},
-            "model_tflops": round(pairs * HESIC_GFLOP_PER_PAIR_512 * (args.size / 512) ** 2 / elapsed / 1e3, 2) if args.model == "hsic" else None,
+            "model_tflops": round(pairs * HESIC_GFLOP_PER_PAIR_512 * (x1p.shape[-2] * x1p.shape[-1] / 512 ** 2) / elapsed / 1e3, 2) if args.model == "hsic" else None,
             "roofline": roof,
             "gpu_metrics_last_batch": {"bpp": round(m_gpu["bpp"], 5), "psnr": round(m_gpu["psnr"], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, m_cpu = cpu_baseline(args.model, P_cpu, args.size)
+            base, m_cpu = cpu_baseline(args.model, P_cpu, args.size if not (args.height or args.width) else 512)
             res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
             with torch.no_grad():
-                o1 = net(x1[:1], x2[:1], Hm[:1])
-                m1 = models.metrics_from(models.rate_distortion(o1, x1[:1], x2[:1]))
+                xa, xb, hh = (t.to(dev) for t in synthetic.stereo_batch(0, 1, 512, 512)) if (args.height or args.width) else (x1[:1], x2[:1], Hm[:1])
+                o1 = net(xa, xb, hh)
+                m1 = models.metrics_from(models.rate_distortion(o1, xa, xb))
             res["parity"] = {"abs_dbpp": round(abs(m1["bpp"] - m_cpu["bpp"]), 6), "abs_dpsnr_db": round(abs(m1["psnr"] - m_cpu["psnr"]), 6),
                              "bpp_oracle": round(m_cpu["bpp"], 5), "psnr_oracle": round(m_cpu["psnr"], 4),
                              "note": f"{args.dtype} GPU path vs fp32 CPU oracle, pair 0"}

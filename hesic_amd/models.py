@@ -469,13 +469,22 @@ class GMM_together(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ metrics
+def pad_to_multiple(x, multiple=64):
+    """Zero-pad H, W (bottom / right) up to a multiple of 64: the hyper path needs it (the reference raises on e.g.
+    860x1080); pixel coordinates -- hence the homography -- are unchanged."""
+    h, w = x.shape[-2:]
+    ph, pw = (-h) % multiple, (-w) % multiple
+    return x if ph == 0 and pw == 0 else torch.nn.functional.pad(x, (0, pw, 0, ph))
+
+
 def rate_distortion(out, x1, x2):
     """bits / squared error of one forward as fp64 device scalars (HIP reductions, no host sync):
     returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""
     res = {"bits_" + k: -Fn.sum_log2(v) for k, v in out["likelihoods"].items()}
-    res["sse1"] = Fn.sum_sq_diff(out["x1_hat"], x1)
-    res["sse2"] = Fn.sum_sq_diff(out["x2_hat"], x2)
-    res["num_pixels"] = x1.shape[0] * x1.shape[2] * x1.shape[3]
+    h, w = x1.shape[-2:]                      # x1/x2 are the ORIGINAL images: padded reconstructions are cropped (views)
+    res["sse1"] = Fn.sum_sq_diff(out["x1_hat"][..., :h, :w], x1)
+    res["sse2"] = Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2)
+    res["num_pixels"] = x1.shape[0] * h * w    # bpp over the original pixel count
     return res
 
 
