@@ -733,9 +733,9 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         a.QH = d->H; a.QW = d->W; a.in_step = 1; a.out_step = s; a.nphase = s * s;
         a.ntaps_live = 0;
     }
-    // cout tile: 128 unless 64 wastes less
+    // cout tile: 128 (twice the FLOP per staged pixel byte) unless it would waste more than 1/8 of the MFMA work
     const int pad128 = ((d->Cout + 127) / 128) * 128, pad64 = ((d->Cout + 63) / 64) * 64;
-    const int BN = (pad64 < pad128) ? 64 : 128;
+    const int BN = (pad128 - pad64) * 8 > pad128 ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
     static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
     const bool fast = d->dtype == HESIC_BF16 && (!legacy || gdn);
