@@ -32,7 +32,7 @@ class HipConv2d(nn.Conv2d):
 
     def run_gdn(self, x, gdn):
         """gdn(self(x)); one fused kernel when eligible (inference, bf16 storage, 128 channels), else two ops."""
-        if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False):
+        if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False) and (self.weight.shape[1] != 3 or self.stride[0] == 2):
             self._check()
             if not hasattr(self, "_packer"):
                 self._packer = Fn.PackedWeight()

@@ -336,6 +336,136 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- conv1 + GDN1 in one kernel (inference, bf16 output)
+// g_a_gdn1(g_a_conv1(image)) (newnet1.py:594-595): the 3 -> 128 conv above followed, per pixel, by the 128x128 GDN
+// contraction -- both on the matrix cores, the 128-channel activation never visits HBM in between.  512 threads = 8 waves,
+// each wave owns a 32-pixel tile end to end (gather -> conv MFMAs -> bf16 rows in its private LDS slice -> squared rows
+// back as the B operand of the GDN MFMAs -> normalise -> rows out), so the tile loop needs no block barrier at all.
+template <int CIN, int KS, int ST, typename XT>
+__global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const bf16_t* __restrict__ gamma_packed,
+                                                            const float* __restrict__ beta_packed, int inverse) {
+    constexpr int OROW = 128 * 2 + 16, R = CIN * KS, PAD = KS / 2, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                          // conv weights [128][128] bf16, slot ^ (row & 15)
+    unsigned char* gl = smem + 32768;                  // gamma' image, same layout
+    float* bl = (float*)(smem + 65536);                // conv bias[128], beta'[128]
+    unsigned char* osb = smem + 65536 + 1024;          // per-wave 32 x OROW slices
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fh = lane >> 5;
+    unsigned char* os = osb + wave * 32 * OROW;
+    const XT* xg = (const XT*)a.x;
+    {
+        const int r = tid & 15, ci = r / KS, ky = r % KS;
+        for (int co = tid >> 4; co < 128; co += 32) {
+            float v[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+                v[kx] = (r < R && kx < KS && co < a.Cout) ? a.w[(((int64_t)co * CIN + ci) * KS + ky) * KS + kx] : 0.f;
+            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        }
+        for (int i = tid; i < 2048; i += 512) *(u32x4*)(gl + i * 16) = *(const u32x4*)((const unsigned char*)gamma_packed + i * 16);
+        if (tid < 128) { bl[tid] = a.bias ? a.bias[tid] : 0.f; bl[128 + tid] = beta_packed[tid]; }
+    }
+    __syncthreads();
+    const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 1) / 2;       // wave tile = 2 output rows x 16 columns
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+        const int oy = ty * 2 + (frow >> 4), ox = tx * 16 + (frow & 15);
+        const bool pok = oy < a.Ho && ox < a.Wo;
+        const int ix0 = ox * ST - PAD;
+        const XT* xb = xg + b * a.xs_b;
+        u32x4 frag[(R + 1) / 2];
+#pragma unroll
+        for (int ks = 0; ks < (R + 1) / 2; ++ks) {
+            const int r = 2 * ks + fh;
+            const int ci = fh ? (2 * ks + 1) / KS : (2 * ks) / KS, ky = fh ? (2 * ks + 1) % KS : (2 * ks) % KS;
+            const int iy = oy * ST - PAD + ky;
+            const bool rok = r < R && pok && (unsigned)iy < (unsigned)a.H;
+            const XT* rp = xb + ci * a.xs_c + (int64_t)iy * a.xs_y;
+            float v[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) {
+                v[kx] = 0.f;
+                if (kx < KS) {
+                    const bool ok = rok && (unsigned)(ix0 + kx) < (unsigned)a.W;
+                    if (ok) v[kx] = elem<XT>::ld(rp + (int64_t)(ix0 + kx) * a.xs_x);
+                }
+            }
+            frag[ks] = u32x4{pack_bf2_fast(v[0], v[1]), pack_bf2_fast(v[2], v[3]), pack_bf2_fast(v[4], v[5]), pack_bf2_fast(v[6], v[7])};
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < (R + 1) / 2; ++ks) {
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + frow;
+                const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+            }
+        }
+        // conv output (+bias) -> own LDS rows as bf16; the fp32 values stay in acc for the final product
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = i * 32 + 8 * g + 4 * fh;
+                const f32x4 bv = *(const f32x4*)(bl + cl);
+                acc[i][4 * g] += bv.x; acc[i][4 * g + 1] += bv.y; acc[i][4 * g + 2] += bv.z; acc[i][4 * g + 3] += bv.w;
+                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2_fast(acc[i][4 * g + 2], acc[i][4 * g + 3])};
+            }
+        f32x16 nrm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 raw = *(const u32x4*)(os + frow * OROW + (ks * 2 + fh) * 16);
+            const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
+            const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
+            const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
+            const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
+            const u32x4 sq = u32x4{pack_bf2_fast(f0 * f0, f1 * f1), pack_bf2_fast(f2 * f2, f3 * f3), pack_bf2_fast(f4 * f4, f5 * f5), pack_bf2_fast(f6 * f6, f7 * f7)};
+            const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + frow;
+                const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = i * 32 + 8 * g + 4 * fh;
+                const f32x4 be = *(const f32x4*)(bl + 128 + cl);
+                float o[4];
+                const float bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = nrm[i][4 * g + e] + bb[e];
+                    o[e] = acc[i][4 * g + e] * (inverse ? sqrtf(n) : rsqrtf(n));
+                }
+                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
+            }
+        bf16_t* yg = (bf16_t*)a.y;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 64 + lane, pr = c >> 4, cc = c & 15;
+            const int y2 = ty * 2 + (pr >> 4), x2 = tx * 16 + (pr & 15);
+            if (y2 < a.Ho && x2 < a.Wo)
+                *(u32x4*)(yg + b * a.ys_b + y2 * a.ys_y + x2 * a.ys_x + cc * 8) = *(const u32x4*)(os + pr * OROW + cc * 16);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- wide -> narrow on the matrix cores (bf16 input)
 // g_s_conv4 (ConvTranspose2d 128 -> 3, 5x5 s2 p2 op1).  With only 3 output channels the GEMM is turned round: every
 // INPUT pixel is multiplied by the whole [Cin x (25*Cout)] weight panel (N = 75 -> 96), giving its 5x5xCout "splat"
@@ -637,6 +767,33 @@ extern "C" int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, c
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     launch_forward(a, (hipStream_t)stream);
     HESIC_LAUNCH_RETURN("sconv2d_forward");
+}
+
+// conv (3 -> 128, 5x5 s2) + GDN fused; gamma_packed / beta_packed from hesic_gdn_pack_params.
+extern "C" int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
+                                         const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream) {
+    if (int e = check_desc(d, "sconv2d_gdn_forward")) return e;
+    HESIC_CHECK_ARG(x && w && y && gamma_packed && beta_packed, "sconv2d_gdn_forward: null pointer");
+    HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
+                        d->y_dtype == HESIC_BF16 && d->ys_c == 1 && d->act == HESIC_ACT_NONE && (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 &&
+                        (d->ys_b % 8) == 0,
+                    "sconv2d_gdn_forward: built for the 3 -> 128 5x5 stride-2 stage with bf16 NHWC output");
+    SArgs a = make_args(d);
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    const size_t lds = 65536 + 1024 + 8 * 32 * (128 * 2 + 16);
+    const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 1) / 2) * d->B;
+    const unsigned grid = (unsigned)((tiles + 7) / 8 < 256 ? (tiles + 7) / 8 : 256);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (d->x_dtype == HESIC_BF16)
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse);
+    else
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse);
+    HESIC_LAUNCH_RETURN("sconv2d_gdn_forward");
 }
 
 // dx of y = op(x): the opposite op (conv <-> transposed conv) applied to dy with the same weight tensor:

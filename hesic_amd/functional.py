@@ -224,8 +224,11 @@ def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
     """The fused epilogue exists for inference with bf16 storage, 128 output channels and a wide input."""
     cout = weight.shape[1] if transposed else weight.shape[0]
     cin = weight.shape[0] if transposed else weight.shape[1]
-    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and cout == 128 and gdn_channels == 128
-            and cin % 32 == 0)
+    if torch.is_grad_enabled() or not x.is_cuda or cout != 128 or gdn_channels != 128:
+        return False
+    if cin == 3:      # g_a_conv1 + g_a_gdn1: image in (any float dtype), bf16 storage out
+        return (not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5 and x.dtype in (torch.float32, torch.bfloat16))
+    return x.dtype == torch.bfloat16 and cin % 32 == 0
 
 
 def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, transposed, inverse, beta_min, packer, gdn_packer):
@@ -235,6 +238,13 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
     Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
     B, _, H, W = x.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    if Cin == 3:      # image-side stage: strided fp32/bf16 image in, bf16 NHWC out
+        gp, bp = gdn_packer.get(beta, gamma, beta_min)
+        out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
+        d = _sdesc(x, out, Cin, Cout, k, stride, padding, False)
+        L.call("hesic_sconv2d_gdn_forward", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
+               L.ptr(bp), int(inverse), L.ptr(out), L.stream())
+        return out
     x = _nhwc(x)
     wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
     gp, bp = gdn_packer.get(beta, gamma, beta_min)

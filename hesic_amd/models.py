@@ -106,8 +106,8 @@ class Encoder1(nn.Module):
         self.g_a_conv4 = conv(N, M)
 
     def stack(self, x):
-        x = self.g_a_gdn1(self.g_a_conv1(x))
-        x = self.g_a_conv2.run_gdn(x, self.g_a_gdn2)        # conv + GDN in one kernel at inference
+        x = self.g_a_conv1.run_gdn(x, self.g_a_gdn1)        # conv + GDN in one kernel at inference
+        x = self.g_a_conv2.run_gdn(x, self.g_a_gdn2)
         x = self.g_a_conv3.run_gdn(x, self.g_a_gdn3)
         return self.g_a_conv4(x)
 

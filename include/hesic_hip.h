@@ -96,6 +96,10 @@ typedef struct {
 /* w is the raw fp32 PyTorch weight ((Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW)). */
 int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
                           void* stream);
+/* g_a_gdn1(g_a_conv1(image)) in one kernel (inference; 3 -> 128, 5x5 stride 2, bf16 NHWC output): newnet1.py:594-595.
+ * gamma_packed / beta_packed from hesic_gdn_pack_params.                                                              */
+int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
+                              const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
 /* dx of the same op (dy has y's strides, dx has x's strides). */
 int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream);
 /* dw (raw PyTorch layout, fp32) and dbias (may be NULL). */

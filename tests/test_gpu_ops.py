@@ -439,3 +439,23 @@ def test_gdn128_backward_bf16(inv):
     assert rel_err(xd.grad, xo.grad) < 2e-2
     assert rel_err(bd.grad, bo.grad) < 2e-2
     assert rel_err(gd.grad, go.grad) < 3e-2
+
+
+def test_fused_image_conv_gdn():
+    """g_a_gdn1(g_a_conv1(image)) in one kernel (bf16 storage) vs the oracle on bf16-rounded operands."""
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=11)
+    x = rnd("fi_x", (2, 3, 72, 104), 0, 1)                 # not a multiple of the 2x16 wave tile
+    w = rnd("fi_w", (128, 3, 5, 5)) * 0.25
+    b = rnd("fi_b", (128,), -0.1, 0.1)
+    ref = O.gdn(O.conv(bf(x), bf(w), b, 2), sd["g.beta"], sd["g.gamma"], False)
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            y = Fn.conv2d_gdn(x.to(DEV), w.to(DEV), b.to(DEV), sd["g.beta"].to(DEV), sd["g.gamma"].to(DEV), kernel_size=5, stride=2,
+                              padding=2, transposed=False, inverse=False, beta_min=1e-6, packer=None, gdn_packer=Fn.PackedGdn())
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert rel_err(y, ref) < 1.5e-2
