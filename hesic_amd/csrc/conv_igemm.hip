@@ -392,27 +392,48 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
         wrow[i] = wg + (int64_t)(n0 + row) * a.Cin + ls * 8;
     }
 
-    auto issue = [&](int step, int buf) {
-        const int t = step / kchunks;
-        const int c0 = (step - t * kchunks) * BK;
-        int dy, dx, wt;
-        tap_at(a, taps, t, dy, dx, wt);
-        const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps + c0;
-        const int64_t wo = (int64_t)wt * a.Cout * a.Cin + c0;
+    // Stages are issued strictly in K order, so the (tap, channel-chunk) cursor advances incrementally: per-row source
+    // pointers and padding predicates are recomputed only when the tap changes (every Cin/BK stages), a stage itself
+    // costs one 64-bit add per DMA instruction -- no divisions or table look-ups in the K loop.
+    int cur_j = 0, cur_c = 0, cur_chunk = 0;          // tap row / column index inside this phase's tap grid, channel chunk
+    const T* xcur[XI];
+    const T* wcur[WI];
+    auto set_tap = [&]() {
+        const int ky = taps.ky0 + cur_j * taps.kst, kx = taps.kx0 + cur_c * taps.kst;
+        int dy, dx;
+        if (a.transposed) { dy = (taps.ry + a.pad - ky) / a.stride; dx = (taps.rx + a.pad - kx) / a.stride; }
+        else { dy = ky - a.pad; dx = kx - a.pad; }
+        const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps;
+        const int64_t wo = (int64_t)(ky * a.KW + kx) * a.Cout * a.Cin;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+            xcur[i] = ok ? xrow[i] + xo : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wcur[i] = wok[i] ? wrow[i] + wo : nullptr;
+    };
+    set_tap();
+    auto issue = [&](int /*step*/, int buf) {
+        const int c0 = cur_chunk * BK;
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-            const T* src = ok ? xrow[i] + xo : zero;
+            const T* src = xcur[i] ? xcur[i] + c0 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const T* src = wok[i] ? wrow[i] + wo : zero;
+            const T* src = wcur[i] ? wcur[i] + c0 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
+        }
+        if (++cur_chunk == kchunks) {
+            cur_chunk = 0;
+            if (++cur_c == taps.nkx) { cur_c = 0; ++cur_j; }
+            set_tap();
         }
     };
 
@@ -783,7 +804,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // ring depth: a 2-deep ring relies on 2-3 co-resident blocks per CU to hide the L2 latency; layers whose grid
         // is too small for that (low resolutions) get a 4-deep ring instead, as long as every block of the grid still
         // fits in LDS at once (160 KB per CU)
-        const int bk = d->Cin % 64 == 0 ? 64 : 32;
+        static const bool force_bk32 = getenv("HESIC_IGEMM_BK32") != nullptr;    // A/B switch for profiling
+        const int bk = (d->Cin % 64 == 0 && !force_bk32) ? 64 : 32;
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);

@@ -202,6 +202,10 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+import os as _os
+FUSE_CONV_GDN = _os.environ.get("HESIC_NO_FUSE") is None      # A/B switch for profiling
+
+
 class PackedGdn:
     """gamma' (bf16, LDS image order) / beta' (fp32) for the fused conv+GDN epilogue; inference-only cache."""
 
@@ -224,7 +228,7 @@ def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
     """The fused epilogue exists for inference with bf16 storage, 128 output channels and a wide input."""
     cout = weight.shape[1] if transposed else weight.shape[0]
     cin = weight.shape[0] if transposed else weight.shape[1]
-    if torch.is_grad_enabled() or not x.is_cuda or cout != 128 or gdn_channels != 128:
+    if torch.is_grad_enabled() or not x.is_cuda or cout != 128 or gdn_channels != 128 or not FUSE_CONV_GDN:
         return False
     if cin == 3:      # g_a_conv1 + g_a_gdn1: image in (any float dtype), bf16 storage out
         return (not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5 and x.dtype in (torch.float32, torch.bfloat16))

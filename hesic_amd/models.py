@@ -23,7 +23,8 @@ from .geometry import warp_perspective
 RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
 
 # inference runs the two views' independent front ends on two HIP streams (set False for a single-stream schedule)
-OVERLAP_STREAMS = True
+import os as _os
+OVERLAP_STREAMS = _os.environ.get("HESIC_NO_OVERLAP") is None
 _side_streams = {}
 
 
