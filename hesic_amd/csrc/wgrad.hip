@@ -224,6 +224,153 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
         }
 }
 
+// ---------------------------------------------------------------- bf16 fast path: LDS-DMA staging + transpose reads
+// Same contraction as wgrad_kernel, but the [pixel][channel] tiles of dY and X go global -> LDS in their natural NHWC
+// layout with global_load_lds_dwordx4 (no register staging, no in-register transposes) and the MFMA operands, which
+// need 8 consecutive PIXELS of one channel per lane, come out of LDS through ds_read_b64_tr_b16: a 16-lane group reads
+// a [4 pixels][16 channels] block and every lane receives one channel's 4 pixels.  The 16-byte slots of a 256-byte
+// pixel row are XOR-ed with ((pixel & 3) << 1) on the DMA source side so the 4 rows of a block hit distinct banks.
+__device__ __attribute__((aligned(16))) uint32_t g_wg_zero_page[16];
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct FastDiv { uint32_t magic, shift; };
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (uint32_t)(((uint64_t)__umulhi(n, d.magic) + n) >> d.shift); }
+
+struct WgTrArgs {
+    WgArgs w;
+    FastDiv dqw, dqh;
+};
+
+__global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
+    const WgArgs& a = A.w;
+    constexpr int BK = 64, TILE = BK * 256, STAGE = 2 * TILE;       // 64 pixels x 128 channels x 2 B per operand
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int split = bid % a.nsplit; bid /= a.nsplit;
+    const int cit = bid % a.ci_tiles; bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles; bid /= a.co_tiles;
+    const int tapi = bid;
+    const int tap = a.tap_id[0] + tapi;          // live taps are a raster-order prefix (checked by the launcher)
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int sh_y = ky - a.pad, sh_x = kx - a.pad;
+    const int co0 = cot * TC, ci0 = cit * TC;
+    const int64_t q_begin = split * a.chunk;
+    const int64_t q_end = (q_begin + a.chunk < a.Q) ? q_begin + a.chunk : a.Q;
+    const bf16_t* xg = (const bf16_t*)a.x;
+    const bf16_t* dg = (const bf16_t*)a.dy;
+    const bf16_t* zero = (const bf16_t*)g_wg_zero_page;
+
+    // DMA roles: instruction ii = wave*4 + i of an operand covers tile rows 4*ii .. 4*ii+3; lane -> (row, phys slot)
+    const int lrow = lane >> 4, pslot = lane & 15;
+    auto issue = [&](int64_t q0, int buf) {
+        unsigned char* dt = smem + buf * STAGE;
+        unsigned char* xt = dt + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 4 + lrow;
+            const int ls = pslot ^ ((row & 3) << 1);
+            const int64_t q = q0 + row;
+            const bf16_t* sd = zero;
+            const bf16_t* sx = zero;
+            if (q < q_end) {
+                const uint32_t qq = (uint32_t)q;
+                const uint32_t r1 = fdiv(qq, A.dqw);
+                const int qx = (int)(qq - r1 * (uint32_t)a.QW);
+                const uint32_t b = fdiv(r1, A.dqh);
+                const int qy = (int)(r1 - b * (uint32_t)a.QH);
+                // which operand carries the tap shift: conv -> X, transposed -> dY
+                int dpy = qy, dpx = qx, xpy = qy, xpx = qx;
+                bool dok = true, xok = true;
+                if (a.transposed) { dpy = qy * a.stride + sh_y; dpx = qx * a.stride + sh_x; dok = (unsigned)dpy < (unsigned)a.Ho && (unsigned)dpx < (unsigned)a.Wo; }
+                else { xpy = qy * a.stride + sh_y; xpx = qx * a.stride + sh_x; xok = (unsigned)xpy < (unsigned)a.H && (unsigned)xpx < (unsigned)a.W; }
+                if (dok && co0 + ls * 8 < a.Cout) sd = dg + (((int64_t)b * a.Ho + dpy) * a.Wo + dpx) * a.y_ps + a.y_co + co0 + ls * 8;
+                if (xok && ci0 + ls * 8 < a.Cin) sx = xg + (((int64_t)b * a.H + xpy) * a.W + xpx) * a.x_ps + a.x_co + ci0 + ls * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                             (__attribute__((address_space(3))) void*)(dt + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                             (__attribute__((address_space(3))) void*)(xt + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int g = lane >> 4, t = lane & 15;
+    // byte offset of this lane's 8-byte chunk inside a tile for channel-tile base cb, pixel base pb (multiples of 32 / 16)
+    auto tr_off = [&](int cb, int pix) {
+        const int ch = cb + (g & 1) * 16 + 4 * (t & 3);
+        return pix * 256 + (((ch >> 3) ^ ((pix & 3) << 1)) << 4) + (ch & 7) * 2;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int64_t nsteps = (q_end - q_begin + BK - 1) / BK;
+    if (nsteps > 0) issue(q_begin, 0);
+    for (int64_t step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (step + 1 < nsteps) issue(q_begin + (step + 1) * BK, buf ^ 1);
+        const unsigned char* dt = smem + buf * STAGE;
+        const unsigned char* xt = dt + TILE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int pix = ks * 16 + (g >> 1) * 8 + (t >> 2);
+            bf16x8 df[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix + 4)));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                df[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix + 4)));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (a.in_abs) v = v & (short)0x7fff;
+                if (a.in_sq) {
+                    u32x4 u = __builtin_bit_cast(u32x4, v);
+                    uint32_t* w4 = (uint32_t*)&u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
+                        w4[q] = pack_bf2(l2 * l2, h2 * h2);
+                    }
+                    v = __builtin_bit_cast(s16x8, u);
+                }
+                xf[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // dw[tap_id[t]][..] = sum_s ws[s][t][..]; dead taps (masked conv) are zero-filled by the host memset
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps, int64_t per_tap,
                                     const WgArgs a) {
@@ -646,6 +793,23 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
     }
 }
 
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    f.shift = sh;
+    f.magic = (uint32_t)((((1ull << sh) - d) << 32) / d + 1);
+    return f;
+}
+
+void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
+    WgTrArgs A;
+    A.w = a;
+    A.dqw = make_fastdiv((uint32_t)a.QW);
+    A.dqh = make_fastdiv((uint32_t)a.QH);
+    hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, A);
+}
+
 int pick_splits(int64_t Q, int bk, int tiles) {
     // aim at ~1500 blocks, at least 4 K-steps per block
     int64_t s = (1536 + tiles - 1) / tiles;
@@ -699,7 +863,11 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     hipStream_t st = (hipStream_t)stream;
     a.x = x; a.dy = dy; a.out = (float*)ws;
     const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-    if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+    static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
+    bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
+    for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
+    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31)) launch_wgrad_tr(a, blocks, st);
+    else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
     if (a.ntaps < d->KH * d->KW) hipMemsetAsync(dw_packed, 0, (size_t)d->KH * d->KW * per_tap * 4, st);
@@ -834,7 +1002,9 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         // (same kernels as hesic_conv2d_wgrad, with the X operand squared on load)
         a.x = x; a.dy = dn; a.out = (float*)wws; a.in_sq = 1;
         const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+        static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
+        if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+        else launch_wgrad_tr(a, blocks, st);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(128 * 128, 256)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
                            (int64_t)128 * 128, a);
         (void)hipMemsetAsync(dbp, 0, 128 * 4, st);
