@@ -386,13 +386,47 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C, int ps, int co,
                                                      int64_t rows_per_block) {
-    // threads over channels (coalesced), block over a row range; one atomic per (block, channel)
+    // thread = one 16-byte chunk (8 bf16 / 4 fp32 channels) of a row; 256 / (C/CE) rows in flight per block iteration;
+    // partial sums meet in LDS, one atomic per (block, channel)
+    constexpr int CE = 16 / (int)sizeof(T);
+    __shared__ float red[256 * CE];
+    const int cpr = (C + CE - 1) / CE;                       // chunks per row
+    const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;           // rows per iteration
+    const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
     const int64_t r0 = blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
-        for (int64_t r = r0; r < r1; ++r) acc += elem<T>::ld(dy + r * ps + co + c);
-        atomicAdd(db + c, acc);
+    float acc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+    const bool vec = (C % CE) == 0 && (ps % CE) == 0 && (co % CE) == 0;
+    if (rsub < rpi) {
+        for (int64_t r = r0 + rsub; r < r1; r += rpi) {
+            const T* p = dy + r * ps + co + chunk * CE;
+            if (vec) {
+                const u32x4 raw = *(const u32x4*)p;
+                if constexpr (sizeof(T) == 2) {
+                    acc[0] += __uint_as_float(raw.x << 16); acc[1] += __uint_as_float(raw.x & 0xffff0000u);
+                    acc[2] += __uint_as_float(raw.y << 16); acc[3] += __uint_as_float(raw.y & 0xffff0000u);
+                    acc[4] += __uint_as_float(raw.z << 16); acc[5] += __uint_as_float(raw.z & 0xffff0000u);
+                    acc[6] += __uint_as_float(raw.w << 16); acc[7] += __uint_as_float(raw.w & 0xffff0000u);
+                } else {
+                    acc[0] += __uint_as_float(raw.x); acc[1] += __uint_as_float(raw.y); acc[2] += __uint_as_float(raw.z); acc[3] += __uint_as_float(raw.w);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e)
+                    if (chunk * CE + e < C) acc[e] += elem<T>::ld(p + e);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) red[threadIdx.x * CE + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sum = 0.f;
+        const int ch = c / CE, e = c % CE;
+        for (int rs = 0; rs < rpi; ++rs) sum += red[(rs * cpr + ch) * CE + e];
+        atomicAdd(db + c, sum);
     }
 }
 
@@ -503,6 +537,40 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nw_kernel(const WT* __restric
     if (half == 0)
 #pragma unroll
         for (int i = 0; i < NC * 25; ++i) atomicAdd(dw + (int64_t)wc * NC * 25 + i, acc[i] + red[wc][i]);
+}
+
+// MFMA route for the same gradient: materialise the narrow side's im2col matrix P[q][nc*25 + tap] (bf16, 96 columns, the
+// last 21 zero) and feed it with WIDE to the 1x1 weight-gradient kernel above: dW[wc][n] = sum_q WIDE[q][wc] P[q][n].
+__global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtype, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
+                                     bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
+    const int64_t total = (int64_t)B * QH * QW * 12;          // 12 chunks of 8 columns per pixel
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ck = i % 12;
+        const int64_t q = i / 12;
+        const int qx = q % QW, qy = (q / QW) % QH, b = q / ((int64_t)QW * QH);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = ck * 8 + e;
+            v[e] = 0.f;
+            if (n < NC * 25) {
+                const int nc = n / 25, tap = n % 25, ky = tap / 5, kx = tap % 5;
+                const int ny = 2 * qy - 2 + ky, nx = 2 * qx - 2 + kx;
+                if ((unsigned)ny < (unsigned)NH && (unsigned)nx < (unsigned)NW)
+                    v[e] = ld_any(narrow, b * ns_b + nc * ns_c + (int64_t)ny * ns_y + (int64_t)nx * ns_x, n_dtype);
+            }
+        }
+        *(u32x4*)(P + q * 96 + ck * 8) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+}
+// dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
+__global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * NCT) return;
+    const int wc = i / NCT, n = i % NCT;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[((int64_t)k * 128 + wc) * 96 + n];
+    dw[i] = s;
 }
 
 // ---- narrow x narrow, stride 1 (pre_conv 6 -> 3, after_conv 6 -> 3 transposed), 5x5 pad 2.
@@ -886,7 +954,35 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     HESIC_LAUNCH_RETURN("conv2d_wgrad");
 }
 
-extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream) {
+static bool nw_fast_case(const hesic_sconv_desc* d, bool& conv1) {
+    const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 2;
+    conv1 = k5 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 && d->H == 2 * d->Ho &&
+            d->W == 2 * d->Wo && d->ys_x == 128 && d->ys_y == (int64_t)d->Wo * 128 && d->ys_b == (int64_t)d->Ho * d->Wo * 128;
+    const bool dec4 = k5 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_BF16 && d->Ho == 2 * d->H &&
+                      d->Wo == 2 * d->W && d->xs_x == 128 && d->xs_y == (int64_t)d->W * 128 && d->xs_b == (int64_t)d->H * d->W * 128;
+    return conv1 || dec4;
+}
+
+static void nw_gemm_desc(int64_t Q, hesic_conv_desc& g) {
+    memset(&g, 0, sizeof(g));
+    g.B = 1; g.H = 1; g.W = (int32_t)Q; g.Cin = 96; g.Ho = 1; g.Wo = (int32_t)Q; g.Cout = 128; g.KH = g.KW = 1; g.stride = 1;
+    g.dtype = HESIC_BF16; g.x_pix_stride = 96; g.y_pix_stride = 128;
+}
+
+extern "C" int64_t hesic_sconv2d_wgrad_ws_bytes(const hesic_sconv_desc* d) {
+    bool conv1;
+    if (!d || !nw_fast_case(d, conv1)) return 0;
+    const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
+    if (Q >= (1ll << 31)) return 0;
+    hesic_conv_desc g;
+    nw_gemm_desc(Q, g);
+    WgArgs a;
+    fill_args(&g, a);
+    return (Q * 96 * 2 + 255) / 256 * 256 + (int64_t)a.nsplit * 128 * 96 * 4;
+}
+
+extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                                   int64_t ws_bytes, void* stream) {
     HESIC_CHECK_ARG(d && x && dy && dw, "sconv2d_wgrad: null pointer");
     SWArgs a;
     memset(&a, 0, sizeof(a));
@@ -900,7 +996,28 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     (void)hipMemsetAsync(dw, 0, (size_t)nw * 4, st);
     static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2;
-    if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
+    bool conv1 = false;
+    const int64_t need = hesic_sconv2d_wgrad_ws_bytes(d);
+    if (!legacy && need > 0 && ws && ws_bytes >= need && nw_fast_case(d, conv1)) {
+        // MFMA route: im2col of the 3-channel side, then the 1x1 weight-gradient kernel with WIDE as "dY"
+        const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
+        const int QH = conv1 ? d->Ho : d->H, QW = conv1 ? d->Wo : d->W, NH = conv1 ? d->H : d->Ho, NW = conv1 ? d->W : d->Wo;
+        bf16_t* P = (bf16_t*)ws;
+        float* part = (float*)((unsigned char*)ws + (Q * 96 * 2 + 255) / 256 * 256);
+        if (conv1)
+            hipLaunchKernelGGL(im2col_narrow_kernel, dim3(grid_for(Q * 12, 256)), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y,
+                               d->xs_x, P, d->B, QH, QW, NH, NW, 3);
+        else
+            hipLaunchKernelGGL(im2col_narrow_kernel, dim3(grid_for(Q * 12, 256)), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y,
+                               d->ys_x, P, d->B, QH, QW, NH, NW, 3);
+        hesic_conv_desc g;
+        nw_gemm_desc(Q, g);
+        WgArgs a2;
+        fill_args(&g, a2);
+        a2.x = P; a2.dy = conv1 ? dy : x; a2.out = part;
+        launch_wgrad_tr(a2, (int64_t)a2.ntaps * a2.co_tiles * a2.ci_tiles * a2.nsplit, st);
+        hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 255) / 256), dim3(256), 0, st, (const float*)part, dw, a2.nsplit, 75);
+    } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
         d->H == 2 * d->Ho && d->W == 2 * d->Wo) {
         // conv1: WIDE = dy (output grid), NARROW = x
         const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 7) / 8) * d->B;

@@ -169,7 +169,9 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight, dtype=torch.float32)
                 db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.stream())
+                nws = L.lib().hesic_sconv2d_wgrad_ws_bytes(C.byref(d))
+                ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+                L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.ptr(ws), nws, L.stream())
                 if mask is not None:
                     dw = dw * mask
         else:

@@ -102,9 +102,11 @@ int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const fl
                               const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
 /* dx of the same op (dy has y's strides, dx has x's strides). */
 int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream);
-/* dw (raw PyTorch layout, fp32) and dbias (may be NULL). */
-int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
-                        void* stream);
+/* dw (raw PyTorch layout, fp32) and dbias (may be NULL).  ws (hesic_sconv2d_wgrad_ws_bytes(d) bytes, may be NULL/0) enables the
+ * matrix-core route for the 3 <-> 128 stages (im2col of the image side + the 1x1 weight-gradient kernel).                     */
+int64_t hesic_sconv2d_wgrad_ws_bytes(const hesic_sconv_desc* d);
+int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                        int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------ GDN / IGDN (row A3)
  * Replaces GDN.forward (compressai/layers/gdn.py:55-70).  beta/gamma are the RAW parameters (reparam
