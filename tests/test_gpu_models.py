@@ -163,3 +163,31 @@ def test_independent_en_matches_reference(dtype, tol):
         ref = T(g[k])
         err = float((out[k].float().cpu() - ref).abs().max() / ref.abs().max())
         assert err < tol, (k, err)
+
+
+def test_stream_overlap_and_fusion_do_not_change_results():
+    """The multi-stream inference schedule is bit-identical to the single-stream order; the fused conv+GDN epilogue
+    agrees with the two-kernel path to bf16 rounding."""
+    from hesic_amd import functional as Fn, models
+    net = build("hsic", torch.bfloat16)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(1, 2, 256, 256))
+    keep = (models.OVERLAP_STREAMS, Fn.FUSE_CONV_GDN)
+    try:
+        outs = {}
+        for ov in (True, False):
+            models.OVERLAP_STREAMS = ov
+            with torch.no_grad():
+                outs[ov] = net(x1, x2, Hm)
+            torch.cuda.synchronize()
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(outs[True][k], outs[False][k]), k
+        for k, v in outs[True]["likelihoods"].items():
+            assert torch.equal(v, outs[False]["likelihoods"][k]), k
+        Fn.FUSE_CONV_GDN = False
+        with torch.no_grad():
+            ref = net(x1, x2, Hm)
+        m_f = models.metrics_from(models.rate_distortion(outs[False], x1, x2))
+        m_u = models.metrics_from(models.rate_distortion(ref, x1, x2))
+        assert abs(m_f["bpp"] - m_u["bpp"]) < 2e-2 * m_u["bpp"] and abs(m_f["psnr"] - m_u["psnr"]) < 5e-2
+    finally:
+        models.OVERLAP_STREAMS, Fn.FUSE_CONV_GDN = keep
