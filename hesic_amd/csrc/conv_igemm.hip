@@ -17,6 +17,8 @@
 // used for the tight-parity mode); accumulation is fp32 in both.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -326,7 +328,7 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // GDN = 0: plain conv epilogue; 1 / 2: y = conv * rsqrt / sqrt(beta' + gamma' @ conv^2) fused (BN == 128 == Cout): the
 // staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
 // activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
-template <int BMP, int BN, int BK, int NS, int GDN = 0>
+template <int BMP, int BN, int BK, int NS, int GDN = 0, bool V2 = true>
 __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA bases go to M0
     int bid;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -368,75 +370,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     const T* __restrict__ wg = (const T*)a.w;
     const T* zero = (const T*)g_zero_page;
 
-    const int prow = lane / CPR, pslot = lane % CPR;
-    const T* xrow[XI];
-    int iy0[XI], ix0[XI];
-    bool rowok[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int row = (wave * XI + i) * (64 / CPR) + prow;
-        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-        const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
-        rowok[i] = qy < a.QH && qx < a.QW;
-        iy0[i] = qy * a.in_step;
-        ix0[i] = qx * a.in_step;
-        xrow[i] = xg + (((int64_t)b * a.H + iy0[i]) * a.W + ix0[i]) * a.x_ps + a.x_co + ls * 8;
-    }
-    const T* wrow[WI];
-    bool wok[WI];
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int row = (wave * WI + i) * (64 / CPR) + prow;
-        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-        wok[i] = (n0 + row) < a.Cout;
-        wrow[i] = wg + (int64_t)(n0 + row) * a.Cin + ls * 8;
-    }
-
-    // Stages are issued strictly in K order, so the (tap, channel-chunk) cursor advances incrementally: per-row source
-    // pointers and padding predicates are recomputed only when the tap changes (every Cin/BK stages), a stage itself
-    // costs one 64-bit add per DMA instruction -- no divisions or table look-ups in the K loop.
-    int cur_j = 0, cur_c = 0, cur_chunk = 0;          // tap row / column index inside this phase's tap grid, channel chunk
-    const T* xcur[XI];
-    const T* wcur[WI];
-    auto set_tap = [&]() {
-        const int ky = taps.ky0 + cur_j * taps.kst, kx = taps.kx0 + cur_c * taps.kst;
-        int dy, dx;
-        if (a.transposed) { dy = (taps.ry + a.pad - ky) / a.stride; dx = (taps.rx + a.pad - kx) / a.stride; }
-        else { dy = ky - a.pad; dx = kx - a.pad; }
-        const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps;
-        const int64_t wo = (int64_t)(ky * a.KW + kx) * a.Cout * a.Cin;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-            xcur[i] = ok ? xrow[i] + xo : nullptr;
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wcur[i] = wok[i] ? wrow[i] + wo : nullptr;
-    };
-    set_tap();
-    auto issue = [&](int /*step*/, int buf) {
-        const int c0 = cur_chunk * BK;
-        unsigned char* xs = smem + buf * STAGE;
-        unsigned char* ws = xs + XT;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const T* src = xcur[i] ? xcur[i] + c0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const T* src = wcur[i] ? wcur[i] + c0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
-        }
-        if (++cur_chunk == kchunks) {
-            cur_chunk = 0;
-            if (++cur_c == taps.nkx) { cur_c = 0; ++cur_j; }
-            set_tap();
-        }
-    };
-
     constexpr int MI = BN / WM / 32, NI = BM / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile too small");
     const int wm = wave % WM, wn = wave / WM;
@@ -450,42 +383,235 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     const int frow = lane & 31, fh = lane >> 5;
     auto off = [&](int row, int slot) { return (row * CPR + (slot ^ ((row / RPB) & (CPR - 1)))) * 16; };
 
-    // NS-deep ring: stage s+NS-1 is issued right after the barrier that proves stage s-1 has been read by
-    // every wave; a counted vmcnt keeps NS-2 younger stages in flight across the barrier (raw s_barrier: a
-    // __syncthreads() would drain the DMA queue).
+    if constexpr (!V2) {
+        const int prow = lane / CPR, pslot = lane % CPR;
+        const T* xrow[XI];
+        int iy0[XI], ix0[XI];
+        bool rowok[XI];
+    #pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * (64 / CPR) + prow;
+            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+            const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
+            rowok[i] = qy < a.QH && qx < a.QW;
+            iy0[i] = qy * a.in_step;
+            ix0[i] = qx * a.in_step;
+            xrow[i] = xg + (((int64_t)b * a.H + iy0[i]) * a.W + ix0[i]) * a.x_ps + a.x_co + ls * 8;
+        }
+        const T* wrow[WI];
+        bool wok[WI];
+    #pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wave * WI + i) * (64 / CPR) + prow;
+            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+            wok[i] = (n0 + row) < a.Cout;
+            wrow[i] = wg + (int64_t)(n0 + row) * a.Cin + ls * 8;
+        }
+
+        // Stages are issued strictly in K order, so the (tap, channel-chunk) cursor advances incrementally: per-row source
+        // pointers and padding predicates are recomputed only when the tap changes (every Cin/BK stages), a stage itself
+        // costs one 64-bit add per DMA instruction -- no divisions or table look-ups in the K loop.
+        int cur_j = 0, cur_c = 0, cur_chunk = 0;          // tap row / column index inside this phase's tap grid, channel chunk
+        const T* xcur[XI];
+        const T* wcur[WI];
+        auto set_tap = [&]() {
+            const int ky = taps.ky0 + cur_j * taps.kst, kx = taps.kx0 + cur_c * taps.kst;
+            int dy, dx;
+            if (a.transposed) { dy = (taps.ry + a.pad - ky) / a.stride; dx = (taps.rx + a.pad - kx) / a.stride; }
+            else { dy = ky - a.pad; dx = kx - a.pad; }
+            const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps;
+            const int64_t wo = (int64_t)(ky * a.KW + kx) * a.Cout * a.Cin;
+    #pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                xcur[i] = ok ? xrow[i] + xo : nullptr;
+            }
+    #pragma unroll
+            for (int i = 0; i < WI; ++i) wcur[i] = wok[i] ? wrow[i] + wo : nullptr;
+        };
+        set_tap();
+        auto issue = [&](int /*step*/, int buf) {
+            const int c0 = cur_chunk * BK;
+            unsigned char* xs = smem + buf * STAGE;
+            unsigned char* ws = xs + XT;
+    #pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const T* src = xcur[i] ? xcur[i] + c0 : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
+            }
+    #pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                const T* src = wcur[i] ? wcur[i] + c0 : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
+            }
+            if (++cur_chunk == kchunks) {
+                cur_chunk = 0;
+                if (++cur_c == taps.nkx) { cur_c = 0; ++cur_j; }
+                set_tap();
+            }
+        };
+
+        // NS-deep ring: stage s+NS-1 is issued right after the barrier that proves stage s-1 has been read by
+        // every wave; a counted vmcnt keeps NS-2 younger stages in flight across the barrier (raw s_barrier: a
+        // __syncthreads() would drain the DMA queue).
+    #pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nsteps) issue(s, s);
+        int buf = 0, nxt = NS - 1;
+        for (int step = 0; step < nsteps; ++step) {
+            const int rem = nsteps - 1 - step;
+            wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+            __builtin_amdgcn_s_barrier();
+            if (step + NS - 1 < nsteps) issue(step + NS - 1, nxt);
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            const unsigned char* xs = smem + buf * STAGE;
+            const unsigned char* ws = xs + XT;
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+    #pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 wf[MI], xf[NI];
+    #pragma unroll
+                for (int i = 0; i < MI; ++i) wf[i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+    #pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    xf[j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
+                    if (a.in_abs) {
+                        u32x4 v = __builtin_bit_cast(u32x4, xf[j]);
+                        v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
+                        xf[j] = __builtin_bit_cast(bf16x8, v);
+                    }
+                }
+    #pragma unroll
+                for (int i = 0; i < MI; ++i)
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+        // ---- buffer-addressed LDS-DMA: one resource per operand, a loop-invariant 32-bit VGPR offset per DMA row and a
+        // wave-uniform SGPR offset for (tap, channel chunk).  Rows that fall into the padding (or beyond the q-grid /
+        // Cout) carry an out-of-range offset: the buffer unit then writes zeros into LDS, so a stage costs no per-lane
+        // address arithmetic at all; the per-row offsets are re-selected only when the tap changes.
+        constexpr uint32_t OOB = 0x80000000u;
+        // the buffer-load-to-LDS builtin is not modelled as a store to smem: let the ring escape through an empty asm so
+        // that the "memory"-clobbering waits below count as writers of it
+        asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+        const int neg = (a.KH * a.W + a.KW) * a.x_ps;                  // elements; keeps every tap offset non-negative
+        const int row0 = ty * a.TH * a.in_step;                        // offsets are relative to the tile's first input row
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)OOB, 0x00020000);
+        const int prow = lane / CPR, pslot = lane % CPR;
+        uint32_t xoff[XI], xv[XI], wv[WI];
+        int iy0[XI], ix0[XI];
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nsteps) issue(s, s);
-    int buf = 0, nxt = NS - 1;
-    for (int step = 0; step < nsteps; ++step) {
-        const int rem = nsteps - 1 - step;
-        wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
-        __builtin_amdgcn_s_barrier();
-        if (step + NS - 1 < nsteps) issue(step + NS - 1, nxt);
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-        const unsigned char* xs = smem + buf * STAGE;
-        const unsigned char* ws = xs + XT;
-        buf = (buf + 1 == NS) ? 0 : buf + 1;
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * (64 / CPR) + prow;
+            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+            const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
+            const bool ok = qy < a.QH && qx < a.QW;
+            iy0[i] = ok ? qy * a.in_step : (int)0xc0000000;            // far outside: every tap of a dead row reads zeros
+            ix0[i] = qx * a.in_step;
+            xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + ls * 8) * 2);
+        }
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 wf[MI], xf[NI];
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wave * WI + i) * (64 / CPR) + prow;
+            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+            wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2) : OOB;
+        }
+        // tap cursor (all SGPR): input displacement moves by +1 (conv) / -1 (transposed phase) per tap index
+        const int dstep = a.transposed ? -1 : 1;
+        const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) / a.stride : -a.pad;
+        const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) / a.stride : -a.pad;
+        const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
+        int cur_j = 0, cur_c = 0, cur_chunk = 0, dy = dy_base, dx = dx_base;
+        uint32_t s_x = 0, s_w = 0;
+        auto set_tap = [&]() {
+            s_x = (uint32_t)(((dy * a.W + dx) * a.x_ps + neg) * 2);
+            s_w = (uint32_t)((taps.ky0 + cur_j * taps.kst) * a.KW + taps.kx0 + cur_c * taps.kst) * wtap;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) wf[i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+            for (int i = 0; i < XI; ++i) {
+                const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                xv[i] = ok ? xoff[i] : OOB;
+            }
+        };
+        set_tap();
+        auto issue = [&](int buf) {
+            const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+            unsigned char* xs = smem + buf * STAGE;
+            unsigned char* ws = xs + XT;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                xf[j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
-                if (a.in_abs) {
-                    u32x4 v = __builtin_bit_cast(u32x4, xf[j]);
-                    v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
-                    xf[j] = __builtin_bit_cast(bf16x8, v);
+            for (int i = 0; i < XI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024),
+                                                         16, (int)xv[i], (int)sx, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024),
+                                                         16, (int)wv[i], (int)sw, 0, 0);
+            if (++cur_chunk == kchunks) {
+                cur_chunk = 0;
+                dx += dstep;
+                if (++cur_c == taps.nkx) { cur_c = 0; dx = dx_base; ++cur_j; dy += dstep; }
+                set_tap();
+            }
+        };
+
+        // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
+        // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
+        // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
+        auto main_loop = [&](auto abs_tag) {
+            constexpr bool ABS = decltype(abs_tag)::value;
+            constexpr int KS = BK / 16;
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nsteps) issue(s);
+            int buf = 0, nxt = NS - 1;
+            for (int step = 0; step < nsteps; ++step) {
+                const int rem = nsteps - 1 - step;
+                if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
+                else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+                __builtin_amdgcn_s_barrier();
+                const unsigned char* xs = smem + buf * STAGE;
+                const unsigned char* ws = xs + XT;
+                buf = (buf + 1 == NS) ? 0 : buf + 1;
+                bf16x8 wf[2][MI], xf[2][NI];
+                auto ldf = [&](int set, int ks) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
+                };
+                ldf(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + NS - 1 < nsteps) issue(nxt);
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ABS) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            u32x4 v = __builtin_bit_cast(u32x4, xf[ks & 1][j]);
+                            v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
+                            xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
+        };
+        if (a.in_abs) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
     }
     __syncthreads();     // every wave is done with the ring before the epilogue reuses it
 
@@ -789,11 +915,16 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     }
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \
+#define LAUNCH_GLDS_V(M_, N_, K_, S_, V_)                                                                   \
     do {                                                                                                    \
-        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);       \
-        else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
+        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1, V_>), grid, block, 0, st, a);       \
+        else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2, V_>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, V_>), grid, block, 0, st, a);                              \
+    } while (0)
+#define LAUNCH_GLDS(M_, N_, K_, S_)                                  \
+    do {                                                             \
+        if (v1) LAUNCH_GLDS_V(M_, N_, K_, S_, false);                \
+        else LAUNCH_GLDS_V(M_, N_, K_, S_, true);                    \
     } while (0)
 #define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
     do {                                                             \
@@ -805,6 +936,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // is too small for that (low resolutions) get a 4-deep ring instead, as long as every block of the grid still
         // fits in LDS at once (160 KB per CU)
         static const bool force_bk32 = getenv("HESIC_IGEMM_BK32") != nullptr;    // A/B switch for profiling
+        static const bool v1 = getenv("HESIC_IGEMM_V1") != nullptr;              // A/B switch for profiling
+        // the buffer-addressed DMA keeps 32-bit offsets relative to the tile's first input row and the packed weights
+        HESIC_CHECK_ARG(((int64_t)(TH * a.in_step + 2 * d->KH) * a.W + 2 * d->KW) * a.x_ps * 2 < (1ll << 31) &&
+                            (int64_t)d->KH * d->KW * d->Cout * d->Cin * 2 < (1ll << 31),
+                        "conv2d_forward: image rows / weights too large for 32-bit tile offsets");
         const int bk = (d->Cin % 64 == 0 && !force_bk32) ? 64 : 32;
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
