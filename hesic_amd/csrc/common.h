@@ -35,13 +35,13 @@ void hesic_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> f32 (round to nearest even, NaN kept quiet)
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __bf16 hw_bf2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_bf2_t));
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct elem;
 template <> struct elem<float> {

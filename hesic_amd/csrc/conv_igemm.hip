@@ -40,7 +40,7 @@ struct IgemmArgs {
     int act, in_abs;
     int n_tiles, nphase;
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
-    const void* gdn_gamma;     // fused GDN epilogue: gamma' bf16 [128][128] in the LDS image layout (hesic_gdn_pack_params)
+    const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
 };
 
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
     static_assert(GDN == 0 || BN == 128, "fused GDN needs every channel of a pixel in the block");
-    constexpr int GOFF = (EPI + 1023) / 1024 * 1024;          // gamma' image behind the staged output tile
-    constexpr int EPI_ALL = GDN ? GOFF + 128 * 256 : EPI;
+    constexpr int YOFF = BM * 256;                            // fused GDN: squared tile at 0, output tile behind it
+    constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
     constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -613,92 +613,27 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
         if (a.in_abs) main_loop(std::true_type{});
         else main_loop(std::false_type{});
     }
-    __syncthreads();     // every wave is done with the ring before the epilogue reuses it
-
-    // epilogue (identical to the register-staged kernel)
+    if constexpr (GDN == 0) {
+        __syncthreads();     // every wave is done with the ring before the epilogue reuses it
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
-            float bv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int pr = wn * (BM / WN) + j * 32 + frow;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
-                    if (GDN) acc[i][j][4 * g + e] = v[e];          // keep the fp32 conv output for the final product
-                }
-                *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            }
-        }
-    }
-    if constexpr (GDN != 0) {
-        // gamma' (already in LDS image order) -> LDS behind the tile, 8 DMA instructions per wave
-        const unsigned char* gsrc = (const unsigned char*)a.gdn_gamma;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (wave * 8 + i) * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(smem + GOFF + (wave * 8 + i) * 1024), 16, 0, 0);
-        __syncthreads();                                       // drains the DMA; tile + gamma' visible to every wave
-        f32x16 nrm[MI][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) nrm[i][j][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            bf16x8 gf[MI], qf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = wm * (BN / WM) + i * 32 + frow;
-                gf[i] = *(const bf16x8*)(smem + GOFF + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const u32x4 raw = *(const u32x4*)(smem + (wn * (BM / WN) + j * 32 + frow) * OROW + (ks * 2 + fh) * 16);
-                const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
-                const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
-                const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
-                const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
-                const u32x4 sq = u32x4{pack_bf2(f0 * f0, f1 * f1), pack_bf2(f2 * f2, f3 * f3), pack_bf2(f4 * f4, f5 * f5), pack_bf2(f6 * f6, f7 * f7)};
-                qf[j] = __builtin_bit_cast(bf16x8, sq);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], qf[j], nrm[i][j], 0, 0, 0);
-        }
-        __syncthreads();                                       // every wave has read the tile: safe to overwrite it
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
-                float be[4];
+                float bv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) be[e] = a.gdn_beta[cl + e];
+                for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float n = nrm[i][j][4 * g + e] + be[e];
-                        v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? sqrtf(n) : rsqrtf(n));
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
                     *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
                 }
             }
-    }
-    __syncthreads();
-    {
+        }
+        __syncthreads();
         constexpr int CPO = BN * 2 / 16;
         constexpr int TOT = BM * CPO;
         T* __restrict__ yg = (T*)a.y;
@@ -712,6 +647,115 @@ __global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a)
                 const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
                 const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + ch;
                 *(u32x4*)(yg + o) = *(const u32x4*)(smem + pr * OROW + cc * 16);
+            }
+        }
+    } else {
+        // ---- fused (I)GDN epilogue.  Every lane already owns 4 consecutive channels of its pixels, so
+        //   1. bias, beta' and the gamma' MFMA fragments (fragment order in global memory: one coalesced 16-byte load per
+        //      lane and fragment, no LDS copy) are requested first and stay in flight across the barriers below;
+        //   2. v = conv + bias is squared in fp32 registers and only the bf16 squares go to LDS (XOR-swizzled 256-byte pixel
+        //      rows: the ring is reused, exactly BM*256 bytes) -- the one cross-wave exchange the channel contraction needs;
+        //   3. nrm = beta' + gamma' @ v^2 runs on the matrix cores with the accumulators preloaded with beta';
+        //   4. y = v * rsqrt(nrm) (GDN) or v * sqrt(nrm) (IGDN) is staged behind the squared tile, so writing it needs no
+        //      barrier against lanes still reading squares.
+        // Barriers are raw s_barrier + lgkmcnt waits: a __syncthreads() would drain the gamma' loads.
+        float bv[MI][4][4];
+        f32x16 nrm[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                const f32x4 t = a.bias ? *(const f32x4*)(a.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 be = *(const f32x4*)(a.gdn_beta + cl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bv[i][g][e] = t[e];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) nrm[i][j][4 * g + e] = be[e];
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 gq[MI][8];
+        {
+            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;       // second half of the packed buffer: fragment order
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x2 sq[MI][NI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][4 * g + e] + bv[i][g][e];
+                        acc[i][j][4 * g + e] = v[e];                   // keep the fp32 conv output for the final product
+                    }
+                    sq[i][j][g] = u32x2{pack_bf2(v[0] * v[0], v[1] * v[1]), pack_bf2(v[2] * v[2], v[3] * v[3])};
+                }
+        asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int pr = wn * (BM / WN) + j * 32 + frow;
+                    *(u32x2*)(smem + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) = sq[i][j][g];
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // squares visible to every wave
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            bf16x8 qf[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                qf[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qf[j], nrm[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int pr = wn * (BM / WN) + j * 32 + frow;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float n = nrm[i][j][4 * g + e];
+                        v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? sqrtf(n) : rsqrtf(n));
+                    }
+                    *(u32x2*)(smem + YOFF + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
+                        u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        constexpr int TOT = BM * 16;
+        T* __restrict__ yg = (T*)a.y;
+        const int oyo = taps.ry, oxo = taps.rx;
+#pragma unroll
+        for (int c = tid; c < TOT; c += NTHREADS) {
+            const int pr = c >> 4, cc = c & 15;
+            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+            if (qy < a.QH && qx < a.QW) {
+                const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
+                const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + cc * 8;
+                *(u32x4*)(yg + o) = *(const u32x4*)(smem + YOFF + pr * 256 + ((cc ^ (pr & 15)) << 4));
             }
         }
     }
@@ -755,7 +799,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* 
 
 int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
-// gamma' = max(gamma, 2^-18)^2 - 2^-36 as bf16 in the fused epilogue's LDS image order; beta' likewise (fp32)
+// gamma' = max(gamma, 2^-18)^2 - 2^-36 as bf16, twice: [0, 128*128) in the LDS image order of the image-side fused kernel
+// (sconv_n2w_gdn_kernel), [128*128, 2*128*128) in MFMA A-fragment order for igemm_glds_kernel -- fragment (rb, ks) holds,
+// for lane l, gamma'[rb*32 + (l & 31)][ks*16 + (l >> 5)*8 + 0..7].  beta' likewise (fp32).
 __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
                                 bf16_t* __restrict__ gp, float* __restrict__ bp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte slot (8 values) per thread: 128 rows x 16 slots
@@ -763,10 +809,11 @@ __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __r
     const int row = i >> 4, slot = i & 15;
     const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
     bf16_t* dst = gp + (row * 16 + (slot ^ (row & 15))) * 8;
+    bf16_t* frag = gp + 128 * 128 + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float t = fmaxf(gamma[row * 128 + slot * 8 + e], gb);
-        dst[e] = f2bf(t * t - ped);
+        dst[e] = frag[e] = f2bf(t * t - ped);
     }
     if (i < 128) {
         const float t = fmaxf(beta[i], beta_bound);

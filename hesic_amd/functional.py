@@ -209,7 +209,7 @@ FUSE_CONV_GDN = _os.environ.get("HESIC_NO_FUSE") is None      # A/B switch for p
 
 
 class PackedGdn:
-    """gamma' (bf16, LDS image order) / beta' (fp32) for the fused conv+GDN epilogue; inference-only cache."""
+    """gamma' (bf16, LDS-image + MFMA-fragment copies) / beta' (fp32) for the fused conv+GDN epilogue; inference-only cache."""
 
     def __init__(self):
         self._hit = None
@@ -218,7 +218,7 @@ class PackedGdn:
         tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
         if self._hit is not None and self._hit[0] == tag:
             return self._hit[1], self._hit[2]
-        gp = torch.empty(128 * 128, dtype=torch.bfloat16, device=gamma.device)
+        gp = torch.empty(2 * 128 * 128, dtype=torch.bfloat16, device=gamma.device)
         bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
         L.call("hesic_gdn_pack_params", L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), float(beta_min), L.ptr(gp),
                L.ptr(bp), 128, L.stream())

@@ -63,8 +63,9 @@ int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_
 
 /* Fused y = (I)GDN(conv(x)) (bf16 storage, Cout == 128, no activation): the conv output tile is normalised in the
  * epilogue of the implicit-GEMM kernel, saving the activation's HBM round trip between conv()/deconv() and GDN.forward
- * (newnet1.py:594-600, :617-623).  gamma_packed (128*128 bf16) / beta_packed (128 fp32) come from
- * hesic_gdn_pack_params (NonNegativeParametrizer applied, LDS image order).                                             */
+ * (newnet1.py:594-600, :617-623).  gamma_packed (2*128*128 bf16: an LDS-image copy for the image-side kernel, then an
+ * MFMA-fragment-order copy for the implicit-GEMM kernel) / beta_packed (128 fp32) come from hesic_gdn_pack_params
+ * (NonNegativeParametrizer applied).                                                                                   */
 int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                           int C, void* stream);
 int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
