@@ -334,7 +334,7 @@ class _GaussianBase(EntropyModel):
         return indexes
 
     def _bound(self):
-        return float(self.lower_bound_scale.bound)
+        return self.lower_bound_scale.value()
 
 
 class GaussianConditional(_GaussianBase):

@@ -28,6 +28,17 @@ class LowerBound(nn.Module):
     def __init__(self, bound):
         super().__init__()
         self.register_buffer("bound", torch.tensor([float(bound)], dtype=torch.float32))
+        self._host = None
+
+    def value(self):
+        """The bound as a Python float for kernel descriptors.  Read back from the buffer once per (storage, version) --
+        not per forward: a device->host read in the hot path would serialise the host with the GPU (and cannot be
+        captured in a HIP graph)."""
+        b = self.bound
+        tag = (b.data_ptr(), b._version, b.device)
+        if self._host is None or self._host[0] != tag:
+            self._host = (tag, float(b))
+        return self._host[1]
 
     def forward(self, x):
         if torch.jit.is_scripting():

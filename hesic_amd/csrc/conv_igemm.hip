@@ -329,7 +329,7 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
 // activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
 template <int BMP, int BN, int BK, int NS, int GDN = 0, bool V2 = true>
-__global__ __launch_bounds__(NTHREADS) void igemm_glds_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
     constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row

@@ -195,19 +195,30 @@ struct SqArgs {
     const void* a; const void* b; int a_dt, b_dt; int64_t as[4], bs[4]; int B, C, H, W; double* out;
 };
 __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
+    // one pixel per thread and iteration (all C channels of it): the index split is 32-bit and done once per pixel, and
+    // both an NCHW and an NHWC operand are read with at most a C-element stride between neighbouring lanes
     __shared__ double red[4];
-    const int64_t n = (int64_t)q.B * q.C * q.H * q.W;
+    const int64_t npix = (int64_t)q.B * q.H * q.W;
     double acc = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int x = r % q.W; r /= q.W;
-        const int y = r % q.H; r /= q.H;
-        const int c = r % q.C;
-        const int b = r / q.C;
-        const float va = ld_any(q.a, b * q.as[0] + c * q.as[1] + y * q.as[2] + x * q.as[3], q.a_dt);
-        const float vb = ld_any(q.b, b * q.bs[0] + c * q.bs[1] + y * q.bs[2] + x * q.bs[3], q.b_dt);
-        const float df = va - vb;
-        acc += (double)(df * df);
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        int x, y, b;
+        if (npix < (1ll << 31)) {
+            unsigned r = (unsigned)p;
+            x = r % (unsigned)q.W; r /= (unsigned)q.W;
+            y = r % (unsigned)q.H; b = r / (unsigned)q.H;
+        } else {
+            int64_t r = p;
+            x = r % q.W; r /= q.W;
+            y = r % q.H; b = (int)(r / q.H);
+        }
+        const int64_t oa = b * q.as[0] + y * q.as[2] + x * q.as[3], ob = b * q.bs[0] + y * q.bs[2] + x * q.bs[3];
+        float part = 0.f;
+        for (int c = 0; c < q.C; ++c) {
+            const float df = ld_any(q.a, oa + c * q.as[1], q.a_dt) - ld_any(q.b, ob + c * q.bs[1], q.b_dt);
+            part = fmaf(df, df, part);
+            if ((c & 7) == 7) { acc += (double)part; part = 0.f; }
+        }
+        acc += (double)part;
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -339,7 +350,7 @@ extern "C" int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_str
     SqArgs q;
     q.a = a; q.b = b; q.a_dt = a_dtype; q.b_dt = b_dtype; q.B = B; q.C = C; q.H = H; q.W = W; q.out = out;
     for (int i = 0; i < 4; ++i) { q.as[i] = a_strides[i]; q.bs[i] = b_strides[i]; }
-    hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * C * H * W, 256, 512)), dim3(256), 0, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * H * W, 256, 2048)), dim3(256), 0, (hipStream_t)stream, q);
     HESIC_LAUNCH_RETURN("sum_sq_diff");
 }
 
