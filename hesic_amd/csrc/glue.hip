@@ -350,7 +350,8 @@ extern "C" int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_str
     SqArgs q;
     q.a = a; q.b = b; q.a_dt = a_dtype; q.b_dt = b_dtype; q.B = B; q.C = C; q.H = H; q.W = W; q.out = out;
     for (int i = 0; i < 4; ++i) { q.as[i] = a_strides[i]; q.bs[i] = b_strides[i]; }
-    hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * H * W, 256, 2048)), dim3(256), 0, (hipStream_t)stream, q);
+    // few blocks: every block ends in one fp64 atomic on the same address, and those serialise in L2
+    hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * H * W, 256 * 4, 512)), dim3(256), 0, (hipStream_t)stream, q);
     HESIC_LAUNCH_RETURN("sum_sq_diff");
 }
 
