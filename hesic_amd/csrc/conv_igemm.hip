@@ -42,6 +42,8 @@ struct IgemmArgs {
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
     const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
+    int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
+    float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
 };
 
 // Tap geometry of one launch phase, all wave-uniform scalars.
@@ -311,8 +313,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
 // global_load_lds_dwordx4 (no VGPR round trip, no ds_write), BK is 64 when Cin allows it, and the loads of
 // step s+1 are in flight while step s runs on the matrix cores.  The DMA writes LDS lane-linearly, so the
 // XOR swizzle is applied on the SOURCE side: lane j of a wave instruction fetches the 16-byte chunk that
-// belongs at LDS position j.  Padding taps / rows beyond the image or Cout read a zero page instead.
-__device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
+// belongs at LDS position j.  Padding taps / rows beyond the image or Cout are out-of-range buffer offsets (zero fill).
 
 template <int LP>
 __device__ __forceinline__ void wait_dma_groups(int k) {
@@ -328,7 +329,7 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // GDN = 0: plain conv epilogue; 1 / 2: y = conv * rsqrt / sqrt(beta' + gamma' @ conv^2) fused (BN == 128 == Cout): the
 // staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
 // activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
-template <int BMP, int BN, int BK, int NS, int GDN = 0, bool V2 = true>
+template <int BMP, int BN, int BK, int NS, int GDN = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
@@ -361,14 +362,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs
     const int ty = rest % a.tiles_y;
     rest /= a.tiles_y;
     const int b = rest % a.B;
-    const int ph = rest / a.B;
+    rest /= a.B;
+    const int ph = rest % a.nphase;
+    const int kslice = rest / a.nphase;
     const int n0 = nt * BN;
     const Taps taps = make_taps(a, ph);
     const int kchunks = a.Cin / BK;
-    const int nsteps = taps.ntaps * kchunks;
+    const int step_lo = kslice * taps.ntaps * kchunks / a.ksplit, step_hi = (kslice + 1) * taps.ntaps * kchunks / a.ksplit;
+    const int nsteps = step_hi - step_lo;
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ wg = (const T*)a.w;
-    const T* zero = (const T*)g_zero_page;
 
     constexpr int MI = BN / WM / 32, NI = BM / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile too small");
@@ -383,237 +386,152 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs
     const int frow = lane & 31, fh = lane >> 5;
     auto off = [&](int row, int slot) { return (row * CPR + (slot ^ ((row / RPB) & (CPR - 1)))) * 16; };
 
-    if constexpr (!V2) {
-        const int prow = lane / CPR, pslot = lane % CPR;
-        const T* xrow[XI];
-        int iy0[XI], ix0[XI];
-        bool rowok[XI];
-    #pragma unroll
+    // ---- buffer-addressed LDS-DMA: one resource per operand, a loop-invariant 32-bit VGPR offset per DMA row and a
+    // wave-uniform SGPR offset for (tap, channel chunk).  Rows that fall into the padding (or beyond the q-grid /
+    // Cout) carry an out-of-range offset: the buffer unit then writes zeros into LDS, so a stage costs no per-lane
+    // address arithmetic at all; the per-row offsets are re-selected only when the tap changes.
+    constexpr uint32_t OOB = 0x80000000u;
+    // the buffer-load-to-LDS builtin is not modelled as a store to smem: let the ring escape through an empty asm so
+    // that the "memory"-clobbering waits below count as writers of it
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+    const int neg = (a.KH * a.W + a.KW) * a.x_ps;                  // elements; keeps every tap offset non-negative
+    const int row0 = ty * a.TH * a.in_step;                        // offsets are relative to the tile's first input row
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)OOB, 0x00020000);
+    const int prow = lane / CPR, pslot = lane % CPR;
+    uint32_t xoff[XI], xv[XI], wv[WI];
+    int iy0[XI], ix0[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
+        const bool ok = qy < a.QH && qx < a.QW;
+        iy0[i] = ok ? qy * a.in_step : (int)0xc0000000;            // far outside: every tap of a dead row reads zeros
+        ix0[i] = qx * a.in_step;
+        xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + ls * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave * WI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2) : OOB;
+    }
+    // tap cursor (all SGPR): input displacement moves by +1 (conv) / -1 (transposed phase) per tap index
+    const int dstep = a.transposed ? -1 : 1;
+    const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) / a.stride : -a.pad;
+    const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) / a.stride : -a.pad;
+    const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
+    const int tap_lo = step_lo / kchunks;
+    int cur_j = tap_lo / taps.nkx, cur_c = tap_lo % taps.nkx, cur_chunk = step_lo % kchunks;
+    int dy = dy_base + dstep * cur_j, dx = dx_base + dstep * cur_c;
+    uint32_t s_x = 0, s_w = 0;
+    auto set_tap = [&]() {
+        s_x = (uint32_t)(((dy * a.W + dx) * a.x_ps + neg) * 2);
+        s_w = (uint32_t)((taps.ky0 + cur_j * taps.kst) * a.KW + taps.kx0 + cur_c * taps.kst) * wtap;
+#pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const int row = (wave * XI + i) * (64 / CPR) + prow;
-            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-            const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
-            rowok[i] = qy < a.QH && qx < a.QW;
-            iy0[i] = qy * a.in_step;
-            ix0[i] = qx * a.in_step;
-            xrow[i] = xg + (((int64_t)b * a.H + iy0[i]) * a.W + ix0[i]) * a.x_ps + a.x_co + ls * 8;
+            const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+            xv[i] = ok ? xoff[i] : OOB;
         }
-        const T* wrow[WI];
-        bool wok[WI];
-    #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = (wave * WI + i) * (64 / CPR) + prow;
-            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-            wok[i] = (n0 + row) < a.Cout;
-            wrow[i] = wg + (int64_t)(n0 + row) * a.Cin + ls * 8;
+    };
+    set_tap();
+    auto issue = [&](int buf) {
+        const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024),
+                                                     16, (int)xv[i], (int)sx, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024),
+                                                     16, (int)wv[i], (int)sw, 0, 0);
+        if (++cur_chunk == kchunks) {
+            cur_chunk = 0;
+            dx += dstep;
+            if (++cur_c == taps.nkx) { cur_c = 0; dx = dx_base; ++cur_j; dy += dstep; }
+            set_tap();
         }
+    };
 
-        // Stages are issued strictly in K order, so the (tap, channel-chunk) cursor advances incrementally: per-row source
-        // pointers and padding predicates are recomputed only when the tap changes (every Cin/BK stages), a stage itself
-        // costs one 64-bit add per DMA instruction -- no divisions or table look-ups in the K loop.
-        int cur_j = 0, cur_c = 0, cur_chunk = 0;          // tap row / column index inside this phase's tap grid, channel chunk
-        const T* xcur[XI];
-        const T* wcur[WI];
-        auto set_tap = [&]() {
-            const int ky = taps.ky0 + cur_j * taps.kst, kx = taps.kx0 + cur_c * taps.kst;
-            int dy, dx;
-            if (a.transposed) { dy = (taps.ry + a.pad - ky) / a.stride; dx = (taps.rx + a.pad - kx) / a.stride; }
-            else { dy = ky - a.pad; dx = kx - a.pad; }
-            const int64_t xo = ((int64_t)dy * a.W + dx) * a.x_ps;
-            const int64_t wo = (int64_t)(ky * a.KW + kx) * a.Cout * a.Cin;
-    #pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bool ok = rowok[i] && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-                xcur[i] = ok ? xrow[i] + xo : nullptr;
-            }
-    #pragma unroll
-            for (int i = 0; i < WI; ++i) wcur[i] = wok[i] ? wrow[i] + wo : nullptr;
-        };
-        set_tap();
-        auto issue = [&](int /*step*/, int buf) {
-            const int c0 = cur_chunk * BK;
-            unsigned char* xs = smem + buf * STAGE;
-            unsigned char* ws = xs + XT;
-    #pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const T* src = xcur[i] ? xcur[i] + c0 : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
-            }
-    #pragma unroll
-            for (int i = 0; i < WI; ++i) {
-                const T* src = wcur[i] ? wcur[i] + c0 : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
-            }
-            if (++cur_chunk == kchunks) {
-                cur_chunk = 0;
-                if (++cur_c == taps.nkx) { cur_c = 0; ++cur_j; }
-                set_tap();
-            }
-        };
-
-        // NS-deep ring: stage s+NS-1 is issued right after the barrier that proves stage s-1 has been read by
-        // every wave; a counted vmcnt keeps NS-2 younger stages in flight across the barrier (raw s_barrier: a
-        // __syncthreads() would drain the DMA queue).
-    #pragma unroll
+    // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
+    // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
+    // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
+    auto main_loop = [&](auto abs_tag) {
+        constexpr bool ABS = decltype(abs_tag)::value;
+        constexpr int KS = BK / 16;
+#pragma unroll
         for (int s = 0; s < NS - 1; ++s)
-            if (s < nsteps) issue(s, s);
+            if (s < nsteps) issue(s);
         int buf = 0, nxt = NS - 1;
         for (int step = 0; step < nsteps; ++step) {
             const int rem = nsteps - 1 - step;
-            wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+            if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
+            else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
             __builtin_amdgcn_s_barrier();
-            if (step + NS - 1 < nsteps) issue(step + NS - 1, nxt);
-            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XT;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
-    #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 wf[MI], xf[NI];
-    #pragma unroll
-                for (int i = 0; i < MI; ++i) wf[i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
-    #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    xf[j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
-                    if (a.in_abs) {
-                        u32x4 v = __builtin_bit_cast(u32x4, xf[j]);
+            bf16x8 wf[2][MI], xf[2][NI];
+            auto ldf = [&](int set, int ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
+            };
+            ldf(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + NS - 1 < nsteps) issue(nxt);
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABS) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        u32x4 v = __builtin_bit_cast(u32x4, xf[ks & 1][j]);
                         v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
-                        xf[j] = __builtin_bit_cast(bf16x8, v);
+                        xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
                     }
                 }
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < MI; ++i)
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    } else {
-        // ---- buffer-addressed LDS-DMA: one resource per operand, a loop-invariant 32-bit VGPR offset per DMA row and a
-        // wave-uniform SGPR offset for (tap, channel chunk).  Rows that fall into the padding (or beyond the q-grid /
-        // Cout) carry an out-of-range offset: the buffer unit then writes zeros into LDS, so a stage costs no per-lane
-        // address arithmetic at all; the per-row offsets are re-selected only when the tap changes.
-        constexpr uint32_t OOB = 0x80000000u;
-        // the buffer-load-to-LDS builtin is not modelled as a store to smem: let the ring escape through an empty asm so
-        // that the "memory"-clobbering waits below count as writers of it
-        asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
-        const int neg = (a.KH * a.W + a.KW) * a.x_ps;                  // elements; keeps every tap offset non-negative
-        const int row0 = ty * a.TH * a.in_step;                        // offsets are relative to the tile's first input row
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)OOB, 0x00020000);
-        const int prow = lane / CPR, pslot = lane % CPR;
-        uint32_t xoff[XI], xv[XI], wv[WI];
-        int iy0[XI], ix0[XI];
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int row = (wave * XI + i) * (64 / CPR) + prow;
-            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-            const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
-            const bool ok = qy < a.QH && qx < a.QW;
-            iy0[i] = ok ? qy * a.in_step : (int)0xc0000000;            // far outside: every tap of a dead row reads zeros
-            ix0[i] = qx * a.in_step;
-            xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + ls * 8) * 2);
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = (wave * WI + i) * (64 / CPR) + prow;
-            const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-            wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2) : OOB;
-        }
-        // tap cursor (all SGPR): input displacement moves by +1 (conv) / -1 (transposed phase) per tap index
-        const int dstep = a.transposed ? -1 : 1;
-        const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) / a.stride : -a.pad;
-        const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) / a.stride : -a.pad;
-        const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
-        int cur_j = 0, cur_c = 0, cur_chunk = 0, dy = dy_base, dx = dx_base;
-        uint32_t s_x = 0, s_w = 0;
-        auto set_tap = [&]() {
-            s_x = (uint32_t)(((dy * a.W + dx) * a.x_ps + neg) * 2);
-            s_w = (uint32_t)((taps.ky0 + cur_j * taps.kst) * a.KW + taps.kx0 + cur_c * taps.kst) * wtap;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-                xv[i] = ok ? xoff[i] : OOB;
-            }
-        };
-        set_tap();
-        auto issue = [&](int buf) {
-            const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
-            unsigned char* xs = smem + buf * STAGE;
-            unsigned char* ws = xs + XT;
-#pragma unroll
-            for (int i = 0; i < XI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024),
-                                                         16, (int)xv[i], (int)sx, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024),
-                                                         16, (int)wv[i], (int)sw, 0, 0);
-            if (++cur_chunk == kchunks) {
-                cur_chunk = 0;
-                dx += dstep;
-                if (++cur_c == taps.nkx) { cur_c = 0; dx = dx_base; ++cur_j; dy += dstep; }
-                set_tap();
-            }
-        };
-
-        // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
-        // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
-        // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
-        auto main_loop = [&](auto abs_tag) {
-            constexpr bool ABS = decltype(abs_tag)::value;
-            constexpr int KS = BK / 16;
-#pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
-                if (s < nsteps) issue(s);
-            int buf = 0, nxt = NS - 1;
-            for (int step = 0; step < nsteps; ++step) {
-                const int rem = nsteps - 1 - step;
-                if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
-                else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
-                __builtin_amdgcn_s_barrier();
-                const unsigned char* xs = smem + buf * STAGE;
-                const unsigned char* ws = xs + XT;
-                buf = (buf + 1 == NS) ? 0 : buf + 1;
-                bf16x8 wf[2][MI], xf[2][NI];
-                auto ldf = [&](int set, int ks) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
-                };
-                ldf(0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (step + NS - 1 < nsteps) issue(nxt);
-                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            }
+        }
+    };
+    if (a.in_abs) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    if constexpr (GDN == 0) {
+        if (a.ksplit > 1) {
+            // K slice: raw fp32 partial sums straight from the accumulators (16 bytes per lane and channel quad)
+            float* __restrict__ wsp = a.ws + (int64_t)kslice * a.B * a.Ho * a.Wo * a.Cout;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (ABS) {
-#pragma unroll
-                        for (int j = 0; j < NI; ++j) {
-                            u32x4 v = __builtin_bit_cast(u32x4, xf[ks & 1][j]);
-                            v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
-                            xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
-                        }
-                    }
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+                if (qy < a.QH && qx < a.QW) {
+                    const int oy = qy * a.out_step + taps.ry, ox = qx * a.out_step + taps.rx;
+                    float* dst = wsp + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + n0;
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                            if (n0 + cl < a.Cout)
+                                *(f32x4*)(dst + cl) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        }
                 }
             }
-        };
-        if (a.in_abs) main_loop(std::true_type{});
-        else main_loop(std::false_type{});
-    }
-    if constexpr (GDN == 0) {
+            return;
+        }
         __syncthreads();     // every wave is done with the ring before the epilogue reuses it
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -761,6 +679,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs
     }
 }
 
+// y = act(sum of the K-slice partials + bias) as bf16: one thread per pixel and 8 channels
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int64_t npix, int Cout,
+                                                            const float* __restrict__ bias, int act, bf16_t* __restrict__ y,
+                                                            int y_ps, int y_co) {
+    const int cg = Cout >> 3;
+    const int64_t total = npix * cg, slice = npix * Cout;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / cg;
+        const int c = (int)(i - p * cg) * 8;
+        f32x4 lo = bias ? *(const f32x4*)(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 hi = bias ? *(const f32x4*)(bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* src = ws + p * Cout + c;
+        for (int s = 0; s < nslice; ++s) {
+            lo += *(const f32x4*)(src + s * slice);
+            hi += *(const f32x4*)(src + s * slice + 4);
+        }
+        *(u32x4*)(y + p * y_ps + y_co + c) =
+            u32x4{pack_bf2(apply_act(lo[0], act), apply_act(lo[1], act)), pack_bf2(apply_act(lo[2], act), apply_act(lo[3], act)),
+                  pack_bf2(apply_act(hi[0], act), apply_act(hi[1], act)), pack_bf2(apply_act(hi[2], act), apply_act(hi[3], act))};
+    }
+}
+
 // ------------------------------------------------------------------------- weight packing
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ mask, T* __restrict__ wp,
@@ -851,6 +791,9 @@ static thread_local int* g_plan_out = nullptr;
 static thread_local const void* g_gdn_gamma = nullptr;   // set by hesic_conv2d_gdn_forward around its call to the launcher
 static thread_local const float* g_gdn_beta = nullptr;
 static thread_local int g_gdn_mode = 0;
+static thread_local float* g_ws = nullptr;               // set by hesic_conv2d_forward_ws: split-K workspace
+static thread_local size_t g_ws_bytes = 0;
+static thread_local size_t* g_ws_need = nullptr;         // set by hesic_conv2d_ws_bytes: only report the workspace size
 
 extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                                      int C, void* stream) {
@@ -946,6 +889,33 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         if (count_blocks(128) < 384) bm = 64;
         if (bm == 64 && count_blocks(64) < 384 && BN == 128 && d->Cin % 64 == 0) bm = 32;
     }
+    // Split-K for the low-resolution layers (hyper path: 8x8 .. 32x32 maps): with so few pixels a full-K block per tile
+    // leaves most CUs idle and makes every block stream the whole weight tensor.  Given a workspace, the K loop is cut
+    // into up to 8 slices (>= 4 stages each) on the largest pixel tile the map fills, partial tiles go to the workspace
+    // in fp32 and splitk_reduce_kernel applies bias / activation / bf16 rounding.
+    int ksplit = 1;
+    static const bool nosplit = getenv("HESIC_IGEMM_NOSPLIT") != nullptr;    // A/B switch for profiling
+    if (fast && !gdn && !nosplit && (g_ws || g_ws_need)) {
+        const int qpix = a.QH * a.QW;
+        int bm_s = qpix >= 128 ? 128 : (qpix >= 64 ? 64 : 32);
+        if (bm_s == 32 && !(BN == 128 && d->Cin % 64 == 0)) bm_s = 64;
+        const int64_t nb = count_blocks(bm_s);
+        const int bk_ = d->Cin % 64 == 0 ? 64 : 32;
+        const int min_taps = d->transposed ? (d->KH / s) * (d->KW / s) : a.ntaps_live;
+        const int min_steps = min_taps * (d->Cin / bk_);
+        int S = (int)((256 + nb - 1) / nb);
+        if (S > 8) S = 8;
+        if (S > min_steps / 4) S = min_steps / 4;
+        // measured on MI355X (B=8): it pays when even 32-pixel tiles leave half the CUs idle, or when K is very long;
+        // the short K loops of transposed phases and mid-sized maps lose more to the reduce pass than they gain
+        const bool starved = !d->transposed && count_blocks(32) < 128;
+        const bool long_k = !d->transposed && min_steps >= 100;
+        if (nb < 256 && S >= 2 && (starved || long_k)) { ksplit = S; bm = bm_s; }
+    }
+    const size_t ws_need = ksplit > 1 ? (size_t)ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
+    if (g_ws_need) { *g_ws_need = ws_need; return 0; }
+    HESIC_CHECK_ARG(ws_need <= g_ws_bytes, "conv2d_forward_ws: workspace too small (%zu < %zu bytes)", g_ws_bytes, ws_need);
+    a.ksplit = ksplit; a.ws = g_ws;
     // 2-D pixel patch: as square as the q-grid allows
     int TW = 16;
     while (TW > 1 && TW / 2 >= a.QW) TW /= 2;
@@ -954,7 +924,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     int TH = bm / TW;
     a.TW = TW; a.TH = TH; a.tw_shift = ilog2(TW);
     a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
-    const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase;
+    const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase * ksplit;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
     if (g_plan_out) {
         g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (d->Cin % 64 == 0 ? 64 : 32) : BK; g_plan_out[3] = fast ? 1 : 0;
@@ -962,16 +932,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     }
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_GLDS_V(M_, N_, K_, S_, V_)                                                                   \
+#define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \
     do {                                                                                                    \
-        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1, V_>), grid, block, 0, st, a);       \
-        else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2, V_>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, V_>), grid, block, 0, st, a);                              \
-    } while (0)
-#define LAUNCH_GLDS(M_, N_, K_, S_)                                  \
-    do {                                                             \
-        if (v1) LAUNCH_GLDS_V(M_, N_, K_, S_, false);                \
-        else LAUNCH_GLDS_V(M_, N_, K_, S_, true);                    \
+        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);       \
+        else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
     } while (0)
 #define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
     do {                                                             \
@@ -983,7 +948,6 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // is too small for that (low resolutions) get a 4-deep ring instead, as long as every block of the grid still
         // fits in LDS at once (160 KB per CU)
         static const bool force_bk32 = getenv("HESIC_IGEMM_BK32") != nullptr;    // A/B switch for profiling
-        static const bool v1 = getenv("HESIC_IGEMM_V1") != nullptr;              // A/B switch for profiling
         // the buffer-addressed DMA keeps 32-bit offsets relative to the tile's first input row and the packed weights
         HESIC_CHECK_ARG(((int64_t)(TH * a.in_step + 2 * d->KH) * a.W + 2 * d->KW) * a.x_ps * 2 < (1ll << 31) &&
                             (int64_t)d->KH * d->KW * d->Cout * d->Cin * 2 < (1ll << 31),
@@ -1008,5 +972,27 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<float, 128>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((igemm_conv_kernel<float, 64>), grid, block, 0, st, a);
     }
+    if (ksplit > 1) {
+        const int64_t npix = (int64_t)d->B * d->Ho * d->Wo;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(npix * (d->Cout / 8), 256)), dim3(256), 0, st, (const float*)g_ws, ksplit,
+                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off);
+    }
     HESIC_LAUNCH_RETURN("conv2d_forward");
+}
+
+extern "C" size_t hesic_conv2d_ws_bytes(const hesic_conv_desc* d) {
+    size_t need = 0;
+    if (!d) return 0;
+    g_ws_need = &need;
+    const int rc = hesic_conv2d_forward(d, (const void*)16, (const void*)16, nullptr, (void*)16, nullptr);
+    g_ws_need = nullptr;
+    return rc == 0 ? need : 0;
+}
+
+extern "C" int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                       void* y, void* ws, size_t ws_bytes, void* stream) {
+    g_ws = (float*)ws; g_ws_bytes = ws ? ws_bytes : 0;
+    const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
+    g_ws = nullptr; g_ws_bytes = 0;
+    return rc;
 }

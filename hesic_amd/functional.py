@@ -89,8 +89,19 @@ def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transpos
         out = _empty_nhwc(B, Cout, Ho, Wo, dtype, x.device)
     d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(dtype), act, in_abs,
                    x.shape[1], x_c_off, out.shape[1], out_c_off, tap_mask)
-    L.call("hesic_conv2d_forward", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.stream())
+    key = (B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, int(transposed), L.dt(dtype), tap_mask)
+    need = _ws_bytes.get(key)
+    if need is None:
+        need = _ws_bytes[key] = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    if need:      # low-resolution layer: split-K launch, fp32 partial tiles in a scratch buffer
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.ptr(ws), need, L.stream())
+    else:
+        L.call("hesic_conv2d_forward", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.stream())
     return out
+
+
+_ws_bytes = {}
 
 
 def _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act=0):

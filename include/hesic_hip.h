@@ -71,6 +71,15 @@ int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min,
 int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
 
+/* Same op with a caller-provided scratch buffer.  Low-resolution layers (the hyper path's 8x8 .. 32x32 maps,
+ * newnet1.py:420-577) have too few pixels to fill the GPU with one block per output tile; given `ws` of at least
+ * hesic_conv2d_ws_bytes(d) bytes the launcher cuts their K loop (taps x channels) into slices that run as separate
+ * blocks, keeps the fp32 partial tiles in `ws` and finishes with a reduce + bias + activation pass.  ws_bytes(d) == 0
+ * means the plain launch is used (ws may be NULL).  Results are deterministic (fixed slice order).                   */
+size_t hesic_conv2d_ws_bytes(const hesic_conv_desc* d);
+int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                            void* y, void* ws, size_t ws_bytes, void* stream);
+
 /* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);
