@@ -102,6 +102,40 @@ def test_wide_conv_fused_abs_act_and_concat_write():
     assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 192:].abs().max()) == 0
 
 
+def test_wide_conv_split_k_matches_plain_launch():
+    """Low-resolution layers take the split-K launch (hesic_conv2d_forward_ws); it must agree with the one-block-per-tile
+    launch of the same op (fp32 partial sums in a different order, same bf16 rounding) and honour act / channel offsets."""
+    Fn, O = _imp()
+    from hesic_amd import _lib as L
+    import ctypes as C
+    B, Cin, Cout, H = 2, 128, 128, 32
+    x = bf(rnd("sk_x", (B, Cin, H, H), -2, 2))
+    w = bf(rnd("sk_w", (Cout, Cin, 5, 5)) * 0.03)
+    b = rnd("sk_b", (Cout,), -0.1, 0.1)
+    ref = torch.nn.functional.leaky_relu(O.conv(x, w, b, 2), 0.01)
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wp = Fn.PackedWeight().get(w.to(DEV), None, Cout, Cin, 5, 5, False, False, torch.bfloat16)
+    d = L.ConvDesc(B, H, H, Cin, 16, 16, Cout, 5, 5, 2, 2, 0, L.dt(torch.bfloat16), L.ACT_LEAKY, 0, Cin, 0, 192, 32, 0)
+    need = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    assert need >= 2 * B * 16 * 16 * Cout * 4                   # at least two K slices of fp32 partial tiles
+    big = L.ConvDesc(8, 256, 256, Cin, 128, 128, Cout, 5, 5, 2, 2, 0, L.dt(torch.bfloat16), 0, 0, Cin, 0, Cout, 0, 0)
+    assert int(L.lib().hesic_conv2d_ws_bytes(C.byref(big))) == 0   # full-size layers keep the plain launch
+    outs = []
+    for split in (True, False):
+        buf = torch.zeros((B, 192, 16, 16), device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if split:
+            ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+            L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(buf), L.ptr(ws), need, L.stream())
+        else:
+            L.call("hesic_conv2d_forward", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(buf), L.stream())
+        assert float(buf[:, :32].float().abs().max()) == 0 and float(buf[:, 160:].float().abs().max()) == 0
+        outs.append(buf[:, 32:160].float())
+        assert rel_err(outs[-1], ref) < 2e-2
+    assert rel_err(outs[0], outs[1]) < 4e-3                      # one bf16 ulp of the output scale
+    with pytest.raises(RuntimeError):                            # too small a workspace is an error, not a silent fallback
+        L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(buf), L.ptr(ws), 16, L.stream())
+
+
 def test_masked_conv_matches_golden(ops_golden):
     Fn, O = _imp()
     g = ops_golden
