@@ -329,8 +329,11 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // GDN = 0: plain conv epilogue; 1 / 2: y = conv * rsqrt / sqrt(beta' + gamma' @ conv^2) fused (BN == 128 == Cout): the
 // staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
 // activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
+// two blocks per CU (2 waves per SIMD, <= 256 VGPRs) whenever the ring leaves LDS for two
+constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns) { return ns * (bm + bn) * bk * 2 > 80 * 1024 ? 1 : 2; }
+
 template <int BMP, int BN, int BK, int NS, int GDN = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void igemm_glds_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void igemm_glds_kernel(const IgemmArgs a) {
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
     constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row

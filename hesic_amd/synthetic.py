@@ -201,3 +201,30 @@ def stereo_batch(first_seed: int, batch: int, height: int, width: int):
     xs1, xs2, hs = zip(*(stereo_pair(first_seed + i, height, width) for i in range(batch)))
     return (torch.from_numpy(np.stack(xs1)), torch.from_numpy(np.stack(xs2)),
             torch.from_numpy(np.stack(hs)))
+
+
+# ------------------------------------------------------------------ HomographyNet
+def fill_homography_state_dict_(sd: dict, salt: int = 0) -> dict:
+    """Name-keyed fill of a HomographyNet state-dict (reference ``model.Net`` keys: cnn.N.layers.{0,2}.*, fc.{2,5}.*):
+    He-style fan-in scaled uniform weights so activations survive the 8 ReLU layers, small biases, and a last layer
+    scaled so the corner deltas come out at a few pixels."""
+    for name, t in sd.items():
+        if not t.dtype.is_floating_point or t.numel() == 0:
+            continue
+        if name.endswith(".weight"):
+            fan = t[0].numel()
+            a = (6.0 / fan) ** 0.5 * (4.0 if name.startswith("fc.5") else 1.0)
+            t.copy_(_uniform("homo." + name, t.shape, -a, a, salt))
+        else:
+            t.copy_(_uniform("homo." + name, t.shape, -0.05, 0.05, salt))
+    return sd
+
+
+def homography_batch(seed: int, batch: int, patch: int = 128, rho: float = 32.0):
+    """Grey patch pairs (B,1,patch,patch) in [0,1) and the 4 patch corners (B,4,2) in the pic-frame, the inputs
+    ``Net.forward`` / the h_matrix derivation take (compressai/datasets/utils.py:161-186 produces them from images)."""
+    a = _uniform(f"homo.a{seed}", (batch, 1, patch, patch), 0.0, 1.0)
+    b = (0.7 * a.roll(3, -1) + 0.3 * _uniform(f"homo.b{seed}", (batch, 1, patch, patch), 0.0, 1.0))
+    tl = _uniform(f"homo.tl{seed}", (batch, 1, 2), rho, 2 * rho).round()
+    box = torch.tensor([[0.0, 0.0], [patch, 0.0], [patch, patch], [0.0, patch]])
+    return a, b, tl + box

@@ -224,6 +224,21 @@ int hesic_sq_diff_backward(const void* a, int a_dtype, const int64_t a_strides[4
 int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream);
 int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
 
+/* ------------------------------------------------- in front of the path: HomographyNet -> h_matrix
+ * The convolutions / linear layers of `Net` (ywz/mywork/model.py:73-96) go through hesic_(s)conv2d_forward (a Linear
+ * is a 1x1 conv over the NHWC-flattened map); these are the remaining pieces.
+ * MaxPool2d(2,2) of Block (model.py:62-63): NHWC (B,H,W,C) -> (B,H/2,W/2,C); C % 8 == 0 (bf16) / % 4 (fp32).        */
+int hesic_maxpool2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* kornia.get_perspective_transform(src, dst) (model.py:26,108): H (B,3,3) fp32 with dst ~ H src, src/dst (B,4,2) fp32.
+ * 4-point DLT with h33 = 1, solved per pair in fp64 (partial pivoting); NaNs for a singular configuration.          */
+int hesic_perspective_transform(const float* src, const float* dst, float* H, int B, void* stream);
+/* corner deltas -> the h_matrix HSIC.forward takes (newtrain1_real.py:113-123): corners0 = corners - corners[:,0]
+ * (subtract_origin != 0); h = get_perspective_transform(corners0, corners0 + delta); h_matrix = h_adjust(inverse(h))
+ * with the reference's scaling (:47-57: row 0 *= a, col 0 /= a, row 1 *= b, col 1 /= b; a = H_img/pic, b = W_img/pic).
+ * subtract_origin = 0 and a = b = 1 is Net.get_h (model.py:99-111).                                                  */
+int hesic_h_from_delta(const float* corners, const float* delta, float ratio_a, float ratio_b, int subtract_origin,
+                       float* H, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

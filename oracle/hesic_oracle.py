@@ -423,6 +423,63 @@ def independent_en(P, x1_hat, x2_hat, Hm, align_corners=True):
 
 
 # --------------------------------------------------------------- loss and metrics
+# --------------------------------------------------------------------------- in front of the path: HomographyNet -> h_matrix
+def homography_net(P, a, b, return_features=False):
+    """``Net.forward`` in eval mode (ywz/mywork/model.py:73-101): cat -> 4 Blocks (conv3x3+ReLU twice, MaxPool2d(2,2)
+    after the first three, :50-71) -> flatten (NCHW order) -> Linear+ReLU -> Linear -> (B,4,2) corner deltas.
+    Dropout (:80,84) is the identity in eval mode.  ``P`` holds the reference's state-dict keys."""
+    x = torch.cat((a, b), 1)
+    for blk in range(4):
+        pre = f"cnn.{blk}.layers."
+        x = F.relu(F.conv2d(x, P[pre + "0.weight"], P[pre + "0.bias"], padding=1))
+        x = F.relu(F.conv2d(x, P[pre + "2.weight"], P[pre + "2.bias"], padding=1))
+        if blk < 3:
+            x = F.max_pool2d(x, 2, 2)
+    feat = x
+    x = F.relu(F.linear(x.flatten(1), P["fc.2.weight"], P["fc.2.bias"]))
+    x = F.linear(x, P["fc.5.weight"], P["fc.5.bias"])
+    delta = x.view(-1, 4, 2)
+    return (delta, feat) if return_features else delta
+
+
+def get_perspective_transform(src, dst):
+    """kornia.get_perspective_transform(src, dst) (call sites model.py:26,108; newtrain1_real.py:116): the (B,3,3) H
+    with dst ~ H src from 4 point pairs -- third-party and unpinned like warp_perspective, restated from its published
+    definition: the 8x8 DLT system with h33 = 1 (rows [x y 1 0 0 0 -xu -yu | u], [0 0 0 x y 1 -xv -yv | v])."""
+    src, dst = src.double(), dst.double()
+    B = src.shape[0]
+    A = torch.zeros(B, 8, 8, dtype=torch.float64)
+    rhs = torch.zeros(B, 8, dtype=torch.float64)
+    for i in range(4):
+        x, y, u, v = src[:, i, 0], src[:, i, 1], dst[:, i, 0], dst[:, i, 1]
+        A[:, 2 * i, 0], A[:, 2 * i, 1], A[:, 2 * i, 2] = x, y, 1.0
+        A[:, 2 * i, 6], A[:, 2 * i, 7] = -x * u, -y * u
+        A[:, 2 * i + 1, 3], A[:, 2 * i + 1, 4], A[:, 2 * i + 1, 5] = x, y, 1.0
+        A[:, 2 * i + 1, 6], A[:, 2 * i + 1, 7] = -x * v, -y * v
+        rhs[:, 2 * i], rhs[:, 2 * i + 1] = u, v
+    h = torch.linalg.solve(A, rhs)
+    return torch.cat((h, torch.ones(B, 1, dtype=torch.float64)), 1).view(B, 3, 3).float()
+
+
+def h_adjust(orishapea, orishapeb, resizeshapea, resizeshapeb, h):
+    """newtrain1_real.py:47-57 (in-place there): rescale an H estimated in the pic_size frame to the image frame --
+    including the reference's quirk of scaling the x row by the HEIGHT ratio."""
+    a, b = orishapea / resizeshapea, orishapeb / resizeshapeb
+    h = h.clone()
+    h[:, 0, :] = a * h[:, 0, :]
+    h[:, :, 0] = (1. / a) * h[:, :, 0]
+    h[:, 1, :] = b * h[:, 1, :]
+    h[:, :, 1] = (1. / b) * h[:, :, 1]
+    return h
+
+
+def h_matrix_from_delta(corners, delta, img_h, img_w, pic_size):
+    """newtrain1_real.py:113-123: the h_matrix handed to HSIC.forward, from HomographyNet's corner deltas."""
+    c0 = corners - corners[:, 0].view(-1, 1, 2)
+    h = get_perspective_transform(c0, c0 + delta)
+    return h_adjust(img_h, img_w, pic_size, pic_size, torch.inverse(h))
+
+
 def rd_loss(out, x1, x2, lmbda):
     """RateDistortionLoss (ywz/mywork/newtrain1.py:37-56)."""
     n, _, h, w = x1.shape

@@ -433,6 +433,24 @@ def fx_enhance(newnet1):
     npz("en_64.npz", x1_hat=out["x1_hat"], x2_hat=out["x2_hat"])
 
 
+def fx_homo():
+    """HomographyNet forward (ywz/mywork/model.py:73-101) from the reference's own module.  Weights
+    and patches are the name-keyed synthetic ones (regenerated by the tests), so only outputs are stored."""
+    import model as ref_model                                   # ywz/mywork/model.py
+    net = ref_model.Net().eval()
+    sd = net.state_dict()
+    synthetic.fill_homography_state_dict_(sd)
+    a, b, corners = synthetic.homography_batch(0, 2)
+    feats = {}
+    net.cnn.register_forward_hook(lambda m, i, o: feats.__setitem__("cnn", o))
+    with torch.no_grad():
+        delta = net(a, b)
+    with open(os.path.join(HERE, "homo_state_keys.txt"), "w") as f:
+        for k, v in sd.items():
+            f.write(f"{k} {' '.join(map(str, v.shape))}\n")
+    npz("homo.npz", delta=delta, cnn_sub=feats["cnn"][:, ::8, ::2, ::2], cnn_absmean=feats["cnn"].abs().mean())
+
+
 def fx_codec():
     """G11: pmf_to_quantized_cdf cases and rANS byte strings from the reference's C++ extensions."""
     from compressai._CXX import pmf_to_quantized_cdf
@@ -466,7 +484,7 @@ def fx_codec():
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "codec", "enhance"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "codec", "enhance", "homo"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
@@ -475,6 +493,8 @@ def main():
         fx_codec()
     if "enhance" in which:
         fx_enhance(newnet1)
+    if "homo" in which:
+        fx_homo()
     if "models" in which:
         fx_models(newnet1, newnet1_joint)
 
