@@ -105,9 +105,10 @@ class Net(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
             x = Fn.conv2d(x, self._fc1_weight(), self.fc[2].bias, kernel_size=1, stride=1, padding=0, act=L.ACT_RELU,
                           packer=self._fc_pack[0])
-            w2 = self.fc[5].weight
-            x = Fn.conv2d(x, w2.view(w2.shape[0], w2.shape[1], 1, 1), self.fc[5].bias, kernel_size=1, stride=1, padding=0,
-                          packer=self._fc_pack[1])
+            w2 = self.fc[5].weight                   # 8 outputs: still the implicit-GEMM kernel (one padded cout tile)
+            wp = self._fc_pack[1].get(w2.view(w2.shape[0], w2.shape[1], 1, 1), None, w2.shape[0], w2.shape[1], 1, 1, False,
+                                      False, x.dtype)
+            x = Fn._wide_conv(x, wp, self.fc[5].bias, B, 1, 1, w2.shape[1], 1, 1, w2.shape[0], 1, 1, 0, False)
         finally:
             Fn.set_compute_dtype(prev)
         return x.reshape(-1, 4, 2).float()
