@@ -374,12 +374,12 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
 // dw[tap_id[t]][..] = sum_s ws[s][t][..]; dead taps (masked conv) are zero-filled by the host memset
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps, int64_t per_tap,
                                     const WgArgs a) {
-    const int64_t n = (int64_t)ntaps * per_tap;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[k * n + i];
+    const int64_t n = (int64_t)ntaps * per_tap;          // per_tap = Cout*Cin is a multiple of 4: 16-byte lanes
+    for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        f32x4 s = *(const f32x4*)(ws + i);
+        for (int k = 1; k < nsplit; ++k) s += *(const f32x4*)(ws + k * n + i);
         const int t = i / per_tap;
-        dw[(int64_t)a.tap_id[t] * per_tap + (i - t * per_tap)] = s;
+        *(f32x4*)(dw + (int64_t)a.tap_id[t] * per_tap + (i - t * per_tap)) = s;
     }
 }
 
@@ -400,19 +400,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
     for (int e = 0; e < CE; ++e) acc[e] = 0.f;
     const bool vec = (C % CE) == 0 && (ps % CE) == 0 && (co % CE) == 0;
     if (rsub < rpi) {
-        for (int64_t r = r0 + rsub; r < r1; r += rpi) {
-            const T* p = dy + r * ps + co + chunk * CE;
-            if (vec) {
-                const u32x4 raw = *(const u32x4*)p;
-                if constexpr (sizeof(T) == 2) {
-                    acc[0] += __uint_as_float(raw.x << 16); acc[1] += __uint_as_float(raw.x & 0xffff0000u);
-                    acc[2] += __uint_as_float(raw.y << 16); acc[3] += __uint_as_float(raw.y & 0xffff0000u);
-                    acc[4] += __uint_as_float(raw.z << 16); acc[5] += __uint_as_float(raw.z & 0xffff0000u);
-                    acc[6] += __uint_as_float(raw.w << 16); acc[7] += __uint_as_float(raw.w & 0xffff0000u);
-                } else {
-                    acc[0] += __uint_as_float(raw.x); acc[1] += __uint_as_float(raw.y); acc[2] += __uint_as_float(raw.z); acc[3] += __uint_as_float(raw.w);
-                }
+        auto add = [&](const u32x4 raw) {
+            if constexpr (sizeof(T) == 2) {
+                acc[0] += __uint_as_float(raw.x << 16); acc[1] += __uint_as_float(raw.x & 0xffff0000u);
+                acc[2] += __uint_as_float(raw.y << 16); acc[3] += __uint_as_float(raw.y & 0xffff0000u);
+                acc[4] += __uint_as_float(raw.z << 16); acc[5] += __uint_as_float(raw.z & 0xffff0000u);
+                acc[6] += __uint_as_float(raw.w << 16); acc[7] += __uint_as_float(raw.w & 0xffff0000u);
             } else {
+                acc[0] += __uint_as_float(raw.x); acc[1] += __uint_as_float(raw.y); acc[2] += __uint_as_float(raw.z); acc[3] += __uint_as_float(raw.w);
+            }
+        };
+        int64_t r = r0 + rsub;
+        if (vec) {
+            const T* base = dy + co + chunk * CE;
+            for (; r + 3 * rpi < r1; r += 4 * rpi) {           // four independent 16-byte loads in flight per lane
+                const u32x4 v0 = *(const u32x4*)(base + r * ps), v1 = *(const u32x4*)(base + (r + rpi) * ps);
+                const u32x4 v2 = *(const u32x4*)(base + (r + 2 * rpi) * ps), v3 = *(const u32x4*)(base + (r + 3 * rpi) * ps);
+                add(v0); add(v1); add(v2); add(v3);
+            }
+            for (; r < r1; r += rpi) add(*(const u32x4*)(base + r * ps));
+        } else {
+            for (; r < r1; r += rpi) {
+                const T* p = dy + r * ps + co + chunk * CE;
 #pragma unroll
                 for (int e = 0; e < CE; ++e)
                     if (chunk * CE + e < C) acc[e] += elem<T>::ld(p + e);
@@ -880,7 +889,8 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
 
 int pick_splits(int64_t Q, int bk, int tiles) {
     // aim at ~1500 blocks, at least 4 K-steps per block
-    int64_t s = (1536 + tiles - 1) / tiles;
+    static const int target = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 1536;   // A/B switch
+    int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -939,12 +949,12 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
     if (a.ntaps < d->KH * d->KW) hipMemsetAsync(dw_packed, 0, (size_t)d->KH * d->KW * per_tap * 4, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap / 4, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
                        a.nsplit, a.ntaps, per_tap, a);
     if (dbias) {
         hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
-        const int64_t rpb = P / 1024 > 0 ? (P + 1023) / 1024 : 1;
+        const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
         const unsigned g = (unsigned)((P + rpb - 1) / rpb);
         if (d->dtype == HESIC_BF16)
             hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dy, dbias, P, d->Cout, d->y_pix_stride, d->y_c_off, rpb);
@@ -1052,7 +1062,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         if (d->ys_c == 1 && d->Cout >= 32 && d->ys_x == d->Cout && d->ys_y == (int64_t)d->Wo * d->Cout &&
             d->ys_b == (int64_t)d->Ho * d->Wo * d->Cout) {       // dense NHWC: coalesced column sums
-            const int64_t rpb = P / 1024 > 0 ? (P + 1023) / 1024 : 1;
+            const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
             const unsigned g = (unsigned)((P + rpb - 1) / rpb);
             if (d->y_dtype == HESIC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
             else hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
@@ -1122,10 +1132,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
         if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
         else launch_wgrad_tr(a, blocks, st);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(128 * 128, 256)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(128 * 128 / 4, 256)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
                            (int64_t)128 * 128, a);
         (void)hipMemsetAsync(dbp, 0, 128 * 4, st);
-        const int64_t rpb = P / 1024 > 0 ? (P + 1023) / 1024 : 1;
+        const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(256), 0, st, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
         hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
         HESIC_LAUNCH_RETURN("gdn_backward");
