@@ -65,6 +65,7 @@ _SIGS = {
     "hesic_conv2d_wgrad": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i32),
     "hesic_unpack_conv_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_sconv2d_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_forward_cat": ([_P(SConvDesc), _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, _vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
     "hesic_sconv2d_dgrad": ([_P(SConvDesc), _vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_wgrad_ws_bytes": ([_P(SConvDesc)], _i64),

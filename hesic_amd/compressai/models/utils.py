@@ -41,6 +41,12 @@ class HipConv2d(nn.Conv2d):
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
         return gdn(self.run(x))
 
+    def run_cat(self, xa, xb):
+        """self(torch.cat((xa, xb), 1)) without materialising the cat where the kernels allow it (inference)."""
+        self._check()
+        return Fn.conv2d_cat(xa, xb, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                             padding=self.padding[0], transposed=False)
+
     def forward(self, x):
         return self.run(x)
 
@@ -70,6 +76,11 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
                                  stride=self.stride[0], padding=self.padding[0], transposed=True, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
         return gdn(self.run(x))
+
+    def run_cat(self, xa, xb):
+        self._check()
+        return Fn.conv2d_cat(xa, xb, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                             padding=self.padding[0], transposed=True)
 
     def forward(self, x, output_size=None):
         if output_size is not None:

@@ -17,6 +17,9 @@ struct SArgs {
     const void* x; const float* w; const float* bias; void* y;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed, x_dtype, y_dtype, act;
     int64_t xs_b, xs_c, xs_y, xs_x, ys_b, ys_c, ys_y, ys_x;
+    // optional second input (hesic_sconv2d_forward_cat): channels [c_split, Cin) come from x2 -- the torch.cat in front of
+    // pre_conv / after_conv (newnet1.py:643,686) never materialises
+    const void* x2; int64_t x2s_b, x2s_c, x2s_y, x2s_x; int x2_dtype, c_split;
 };
 
 // weight element for (co, ci, ky, kx) in either PyTorch layout
@@ -635,6 +638,104 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
         }
 }
 
+// ---------------------------------------------------------------- 6 -> 3, 5x5, stride 1 (pre_conv / after_conv)
+// 16 x 128 output tile per block, all 6 input planes of the tile (+halo) in LDS as fp32, 8 consecutive pixels x 3 couts
+// per thread: per (ci, ky) three ds_read_b128 of pixels and five broadcast weight reads feed 120 FMAs.  The 132-float
+// row pitch keeps the 16-lane groups of those reads on disjoint banks.  The two 3-channel halves of the input may come
+// from different tensors (any strides / fp32 or bf16): planar fp32 rows are fetched as 8-byte pairs.
+template <int K>
+__global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
+    constexpr int CIN = 6, COUT = 3, TH = 16, TW = 128, PAD = K / 2, PH = TH + K - 1, PW = TW + 4, NP = PW / 2;
+    __shared__ __attribute__((aligned(16))) float xs[CIN * PH * PW];
+    __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * 4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * K * CIN * 4; i += 256) {
+        const int co = i & 3, ci = (i >> 2) % CIN, tap = (i >> 2) / CIN;
+        int ky = tap / K, kx = tap % K;
+        if (a.transposed) { ky = K - 1 - ky; kx = K - 1 - kx; }
+        wl[i] = co < COUT ? w_at(a.w, co, ci, ky, kx, COUT, CIN, K, K, a.transposed) : 0.f;
+    }
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = ty * TH - PAD, x0 = tx * TW - PAD;
+    for (int half = 0; half < 2; ++half) {
+        const int c_lo = half ? a.c_split : 0, c_hi = half ? CIN : a.c_split;
+        if (c_hi <= c_lo) continue;
+        const void* src = half ? a.x2 : a.x;
+        const int64_t sb = half ? a.x2s_b : a.xs_b, sc = half ? a.x2s_c : a.xs_c, sy = half ? a.x2s_y : a.xs_y, sx = half ? a.x2s_x : a.xs_x;
+        const int dt = half ? a.x2_dtype : a.x_dtype;
+        const int rows = (c_hi - c_lo) * PH;
+        const bool pairs = dt == HESIC_F32 && sx == 1 && !(a.W & 1) && !((sb | sc | sy) & 1) && !((uintptr_t)src & 7);
+        if (pairs) {
+            const float* base = (const float*)src + b * sb;
+            for (int i = tid; i < rows * NP; i += 256) {
+                const int r = i / NP, j = i - r * NP;
+                const int ci = r / PH, py = r - ci * PH;
+                const int iy = y0 + py, ix = x0 + 2 * j;
+                f32x2 v = {0.f, 0.f};
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = *(const f32x2*)(base + ci * sc + (int64_t)iy * sy + ix);
+                *(f32x2*)(xs + ((c_lo + ci) * PH + py) * PW + 2 * j) = v;
+            }
+        } else {
+            for (int i = tid; i < rows * PW; i += 256) {
+                const int r = i / PW, px = i - r * PW;
+                const int ci = r / PH, py = r - ci * PH;
+                const int iy = y0 + py, ix = x0 + px;
+                float v = 0.f;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = ld_any(src, b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx, dt);
+                xs[((c_lo + ci) * PH + py) * PW + px] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = (tid & 15) * 8;
+    float acc[8][COUT];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[p][c] = 0.f;
+#pragma unroll 1
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float* row = xs + (ci * PH + ly + ky) * PW + lx;
+            const f32x4 r0 = *(const f32x4*)row, r1 = *(const f32x4*)(row + 4), r2 = *(const f32x4*)(row + 8);
+            const float xin[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 wv = *(const f32x4*)(wl + ((ky * K + kx) * CIN + ci) * 4);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    acc[p][0] = fmaf(xin[p + kx], wv.x, acc[p][0]);
+                    acc[p][1] = fmaf(xin[p + kx], wv.y, acc[p][1]);
+                    acc[p][2] = fmaf(xin[p + kx], wv.z, acc[p][2]);
+                }
+            }
+        }
+    }
+    const int oy = ty * TH + ly, ox0 = tx * TW + lx;
+    if (oy >= a.Ho) return;
+    const bool vec = a.y_dtype == HESIC_F32 && a.ys_x == 1 && !(a.Wo & 3) && !((a.ys_b | a.ys_c | a.ys_y) & 3) && !((uintptr_t)a.y & 15);
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        float o[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) o[p] = apply_act(acc[p][co] + bv, a.act);
+        const int64_t base = b * a.ys_b + co * a.ys_c + oy * a.ys_y;
+        if (vec && ox0 + 8 <= a.Wo) {
+            float* yp = (float*)a.y + base + ox0;
+            *(f32x4*)yp = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4*)(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (ox0 + p < a.Wo) st_any(a.y, base + (ox0 + p) * a.ys_x, a.y_dtype, o[p]);
+        }
+    }
+}
+
 constexpr int SS_PX = 4;
 __global__ __launch_bounds__(256) void sconv_small_s1_kernel(const SArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[7 * 7 * 8 * 4];
@@ -718,6 +819,10 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+    } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
+               a.Wo == a.W && a.Wo >= 128) {
+        const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+        hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, st, a);
     } else if (!legacy && a.stride == 1 && ((a.Cin == 6 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 6)) && a.KH == 5 && a.KW == 5 &&
                a.pad == 2 && a.Ho == a.H && a.Wo == a.W && a.Wo >= 64) {
         const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
@@ -754,10 +859,28 @@ SArgs make_args(const hesic_sconv_desc* d) {
     a.x_dtype = d->x_dtype; a.y_dtype = d->y_dtype; a.act = d->act;
     a.xs_b = d->xs_b; a.xs_c = d->xs_c; a.xs_y = d->xs_y; a.xs_x = d->xs_x;
     a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
+    a.c_split = d->Cin;          // single input tensor
     return a;
 }
 
 }  // namespace
+
+extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
+                                         int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream) {
+    if (int e = check_desc(d, "sconv2d_forward_cat")) return e;
+    HESIC_CHECK_ARG(xa && xb && xb_strides && w && y, "sconv2d_forward_cat: null pointer");
+    HESIC_CHECK_ARG(d->Cin == 6 && d->Cout == 3 && d->KH == 5 && d->KW == 5 && d->stride == 1 && d->pad == 2 && d->Wo >= 128 &&
+                        ca > 0 && ca < d->Cin,
+                    "sconv2d_forward_cat: built for the 6 -> 3 5x5 stride-1 stages (pre_conv / after_conv) at width >= 128");
+    HESIC_CHECK_ARG(xb_dtype == HESIC_F32 || xb_dtype == HESIC_BF16, "sconv2d_forward_cat: bad dtype");
+    SArgs a = make_args(d);
+    a.x = xa; a.w = w; a.bias = bias; a.y = y;
+    a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
+    a.x2_dtype = xb_dtype; a.c_split = ca;
+    const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+    hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("sconv2d_forward_cat");
+}
 
 extern "C" int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
                                      void* stream) {

@@ -279,6 +279,27 @@ def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, a
 
 
 # ------------------------------------------------------------------------------------ GDN
+def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed=False, packer=None):
+    """conv(torch.cat((xa, xb), 1)) (newnet1.py:643,686).  At inference the 6 -> 3 image-side stages read their two
+    3-channel halves straight from the two tensors (``hesic_sconv2d_forward_cat``: no concatenated copy); otherwise the
+    ordinary cat + conv2d (autograd) path runs."""
+    cin = weight.shape[0] if transposed else weight.shape[1]
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    ok = (not torch.is_grad_enabled() and xa.is_cuda and xb.is_cuda and cin == 6 and cout == 3 and kernel_size == 5 and stride == 1
+          and padding == 2 and xa.shape[1] + xb.shape[1] == 6 and xa.shape[-1] >= 128 and xa.shape[0] == xb.shape[0]
+          and xa.shape[2:] == xb.shape[2:] and xa.dtype in (torch.float32, torch.bfloat16) and xb.dtype in (torch.float32, torch.bfloat16))
+    if not ok:
+        return conv2d(torch.cat((xa.float(), xb.float()), 1), weight, bias, kernel_size=kernel_size, stride=stride,
+                      padding=padding, transposed=transposed, packer=packer)
+    B, _, H, W = xa.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=xa.device)
+    d = _sdesc(xa, y, cin, cout, kernel_size, stride, padding, transposed)
+    xbs = (C.c_int64 * 4)(*xb.stride())
+    L.call("hesic_sconv2d_forward_cat", C.byref(d), L.ptr(xa), L.ptr(xb), xbs, L.dt(xb), int(xa.shape[1]),
+           L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(y), L.stream())
+    return y
+
+
 class _GdnFn(torch.autograd.Function):
     """GDN.forward (compressai/layers/gdn.py:55-70), reparametrisation included."""
 

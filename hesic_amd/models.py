@@ -129,7 +129,7 @@ class Encoder2(Encoder1):
         self.g_a_conv4 = conv(N, M)
 
     def forward(self, x1_warp, x2):
-        t = self.pre_gdn(self.pre_conv(torch.cat((x1_warp.float(), x2.float()), 1)))
+        t = self.pre_gdn(self.pre_conv.run_cat(x1_warp, x2))
         return self.stack(t)
 
 
@@ -163,7 +163,7 @@ class Decoder2(Decoder1):
 
     def forward(self, y_hat, x1_hat_warp):
         t = self.after_gdn(self.stack(y_hat))
-        return self.after_conv(torch.cat((t, x1_hat_warp.float()), 1))
+        return self.after_conv.run_cat(t, x1_hat_warp)
 
 
 # ----------------------------------------------------------------------------------- hyper networks

@@ -106,6 +106,11 @@ typedef struct {
 /* w is the raw fp32 PyTorch weight ((Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW)). */
 int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
                           void* stream);
+/* conv(torch.cat((xa, xb), 1)) without the cat: channels [0, ca) come from xa (d's x strides / dtype), [ca, Cin) from xb
+ * (xb_strides in elements, b/c/y/x).  The 6 -> 3 5x5 stride-1 stages only: pre_conv on cat(x1_warp, x2) and after_conv on
+ * cat(IGDN(.), x1_hat_warp) (newnet1.py:643,686).                                                                      */
+int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
+                              int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream);
 /* g_a_gdn1(g_a_conv1(image)) in one kernel (inference; 3 -> 128, 5x5 stride 2, bf16 NHWC output): newnet1.py:594-595.
  * gamma_packed / beta_packed from hesic_gdn_pack_params.                                                              */
 int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,

@@ -136,6 +136,32 @@ def test_wide_conv_split_k_matches_plain_launch():
         L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(buf), L.ptr(ws), 16, L.stream())
 
 
+@pytest.mark.parametrize("tr", [0, 1], ids=["pre_conv", "after_conv"])
+def test_cat_free_6to3_conv(tr):
+    """pre_conv(cat(x1_warp, x2)) / after_conv(cat(t, x1_hat_warp)) read their halves from two tensors of different
+    layout / dtype (hesic_sconv2d_forward_cat); sizes that end in partial tiles."""
+    Fn, O = _imp()
+    B, H, W = 2, 37, 200
+    xa = rnd("cat_a", (B, 3, H, W))
+    xb = bf(rnd("cat_b", (B, 3, H, W)))
+    w = rnd("cat_w", (6, 3, 5, 5) if tr else (3, 6, 5, 5)) * 0.1
+    b = rnd("cat_bias", (3,), -0.1, 0.1)
+    ref = (O.deconv if tr else O.conv)(torch.cat((xa, xb), 1), w, b, 1)
+    xad = xa.to(DEV).contiguous(memory_format=torch.channels_last)            # NHWC fp32 (what GDN(3) hands over)
+    xbd = xb.to(DEV, torch.bfloat16)                                          # planar bf16
+    with torch.no_grad():
+        y = Fn.conv2d_cat(xad, xbd, w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=bool(tr))
+        y2 = Fn.conv2d_cat(xa.to(DEV), xb.to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=bool(tr))
+        y3 = Fn.conv2d(torch.cat((xa, xb), 1).to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=bool(tr))
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    assert rel_err(y, ref) < 1e-5 and rel_err(y2, ref) < 1e-5 and rel_err(y3, ref) < 1e-5
+    # with autograd on, the same call is the ordinary cat + conv
+    xg = xa.to(DEV).requires_grad_()
+    yg = Fn.conv2d_cat(xg, xb.to(DEV), w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=bool(tr))
+    yg.sum().backward()
+    assert rel_err(yg, ref) < 1e-5 and xg.grad is not None
+
+
 def test_masked_conv_matches_golden(ops_golden):
     Fn, O = _imp()
     g = ops_golden
