@@ -234,12 +234,7 @@ __global__ __launch_bounds__(256) void sconv_wide_to_narrow_kernel(const SArgs a
 // (any strides, fp32 or bf16), D -> bias/act -> bf16 -> LDS -> full NHWC rows.  HBM bound on the 128-channel output.
 // Geometry is a template parameter so every loop unrolls and the index arithmetic folds (the first, fully run-time
 // version spent 2250 VALU + 1570 SALU instructions per 32-pixel tile next to 32 MFMAs).
-__device__ __forceinline__ uint32_t pack_bf2_fast(float lo, float hi) {   // finite inputs only (activations)
-    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ uint32_t pack_bf2_fast(float lo, float hi) { return pack_bf2(lo, hi); }   // v_cvt_pk_bf16_f32
 
 constexpr int N2W_KPAD = 128;
 template <int CIN, int KS, int ST, typename XT>
@@ -366,7 +361,17 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                 v[kx] = (r < R && kx < KS && co < a.Cout) ? a.w[(((int64_t)co * CIN + ci) * KS + ky) * KS + kx] : 0.f;
             *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
         }
-        for (int i = tid; i < 2048; i += 512) *(u32x4*)(gl + i * 16) = *(const u32x4*)((const unsigned char*)gamma_packed + i * 16);
+        // gamma' image for the GDN contraction.  Its K (input-channel) order is permuted so that the squares a lane needs as
+        // MFMA B operand are the accumulator registers it already holds: slab ks = (i, gp) covers channels 32i+16gp+[0,16),
+        // and 16-byte chunk 2ks+h of a row carries channels {32i+16gp+4h+[0,4)} ++ {32i+16gp+8+4h+[0,4)} -- exactly
+        // acc[i][8gp .. 8gp+7] of lane-half h.  Source: the LDS-image half of hesic_gdn_pack_params (slot ^ (row & 15)).
+        for (int idx = tid; idx < 2048; idx += 512) {
+            const int row = idx >> 4, q = idx & 15, ks = q >> 1, h = q & 1;
+            const unsigned char* srow = (const unsigned char*)gamma_packed + row * 256;
+            const u32x2 lo = *(const u32x2*)(srow + (((2 * ks) ^ (row & 15)) << 4) + 8 * h);
+            const u32x2 hi = *(const u32x2*)(srow + (((2 * ks + 1) ^ (row & 15)) << 4) + 8 * h);
+            *(u32x4*)(gl + row * 256 + ((q ^ (row & 15)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
         if (tid < 128) { bl[tid] = a.bias ? a.bias[tid] : 0.f; bl[128 + tid] = beta_packed[tid]; }
     }
     __syncthreads();
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
             }
         }
-        // conv output (+bias) -> own LDS rows as bf16; the fp32 values stay in acc for the final product
+        // bias in registers; the squares of lane-half h's own accumulators are the B operand of the GDN contraction (see
+        // the permuted gamma' image above): no LDS exchange between the two GEMMs
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -420,7 +426,6 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                 const int cl = i * 32 + 8 * g + 4 * fh;
                 const f32x4 bv = *(const f32x4*)(bl + cl);
                 acc[i][4 * g] += bv.x; acc[i][4 * g + 1] += bv.y; acc[i][4 * g + 2] += bv.z; acc[i][4 * g + 3] += bv.w;
-                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2_fast(acc[i][4 * g + 2], acc[i][4 * g + 3])};
             }
         f32x16 nrm[4];
 #pragma unroll
@@ -429,12 +434,11 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
             for (int r = 0; r < 16; ++r) nrm[i][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const u32x4 raw = *(const u32x4*)(os + frow * OROW + (ks * 2 + fh) * 16);
-            const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
-            const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
-            const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
-            const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
-            const u32x4 sq = u32x4{pack_bf2_fast(f0 * f0, f1 * f1), pack_bf2_fast(f2 * f2, f3 * f3), pack_bf2_fast(f4 * f4, f5 * f5), pack_bf2_fast(f6 * f6, f7 * f7)};
+            const int si = ks >> 1, so = (ks & 1) * 8;
+            const u32x4 sq = u32x4{pack_bf2_fast(acc[si][so] * acc[si][so], acc[si][so + 1] * acc[si][so + 1]),
+                                   pack_bf2_fast(acc[si][so + 2] * acc[si][so + 2], acc[si][so + 3] * acc[si][so + 3]),
+                                   pack_bf2_fast(acc[si][so + 4] * acc[si][so + 4], acc[si][so + 5] * acc[si][so + 5]),
+                                   pack_bf2_fast(acc[si][so + 6] * acc[si][so + 6], acc[si][so + 7] * acc[si][so + 7])};
             const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
