@@ -215,6 +215,70 @@ __global__ void gmm_fwd_kernel(const hesic_gmm_desc d, const T* __restrict__ y, 
     }
 }
 
+// ---------------------------------------------------------------- per-element CDF tables of HSIC.compress / decompress
+// (ywz/mywork/newnet1.py:925-978, :1137-1175): for a listed channel m and every pixel, over the alphabet s = 0 .. 2*minmax,
+//   pmf[s]  = sum_k w[k*M+m] * (Phi((.5 - |s - (mu_k + minmax)|)/sigma'_k) - Phi((-.5 - |..|)/sigma'_k))     (fp32, k ascending)
+//   q[s]    = round_half_even(clip(pmf[s], 2^-16, 1) / sum(clip) * 65536)   with numpy's float32 pairwise summation order
+//   cdf     = [0, cumsum(q)]                                                (exact integers in fp32, as np.add.accumulate)
+// The reference does this with a Python loop per channel and pixel and a host round trip per channel; here it is one
+// launch.  One thread per (channel, pixel); the row is first filled with the clipped pmf (as float bits), then rewritten.
+__device__ float np_pairwise_sum(const float* a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+template <typename T>
+__global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
+                               const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
+                               uint32_t* __restrict__ cdf) {
+    const int A = 2 * minmax + 1;
+    const int64_t total = (int64_t)n_ch * d.HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int hw = i % d.HW, j = i / d.HW;
+        const int m = channels[j];
+        const int64_t sm = ((int64_t)b * d.HW + hw) * d.sm_pix_stride + m;
+        float mu[GMM_MAXK], sg[GMM_MAXK], wk[GMM_MAXK];
+        for (int k = 0; k < d.K; ++k) {
+            mu[k] = elem<T>::ld(means + sm + d.m_c_off + k * d.M) + (float)minmax;
+            sg[k] = fmaxf(elem<T>::ld(scales + sm + d.s_c_off + k * d.M), d.scale_bound);
+            wk[k] = weights ? weights[(int64_t)b * d.K * d.M + k * d.M + m] : 1.f;
+        }
+        uint32_t* row = cdf + i * (A + 1);
+        float* frow = (float*)(row + 1);
+        for (int s = 0; s < A; ++s) {
+            float pm = 0.f;
+            for (int k = 0; k < d.K; ++k) {
+                const float a = fabsf((float)s - mu[k]);
+                pm += (phi_cdf((0.5f - a) / sg[k]) - phi_cdf((-0.5f - a) / sg[k])) * wk[k];
+            }
+            frow[s] = fminf(fmaxf(pm, 1.0f / 65536.0f), 1.0f);
+        }
+        const float tot = np_pairwise_sum(frow, A);
+        float run = 0.f;
+        row[0] = 0u;
+        for (int s = 0; s < A; ++s) {
+            run += rintf(frow[s] / tot * 65536.0f);
+            row[s + 1] = (uint32_t)run;
+        }
+    }
+}
+
 // block = 64 channels x 4 pixel lanes; grid = (M/64, pixel chunks, B): dweights reduced in-block first
 template <typename T>
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, const T* __restrict__ y,
@@ -343,6 +407,23 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
         hipLaunchKernelGGL(gmm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
                            (const float*)scales, (const float*)means, weights, (const float*)noise, (float*)y_hat, lik, symbols);
     HESIC_LAUNCH_RETURN("gmm_forward");
+}
+
+extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                             const int32_t* channels, int n_channels, int minmax, uint32_t* cdf, void* stream) {
+    if (int e = check_gmm(d, "gmm_cdf")) return e;
+    HESIC_CHECK_ARG(scales && means && channels && cdf && n_channels > 0 && minmax >= 1 && minmax < 32768 && b >= 0 && b < d->B,
+                    "gmm_cdf: bad arguments");
+    HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf: weights required for K > 1");
+    const int64_t total = (int64_t)n_channels * d->HW;
+    const dim3 grid(grid_for(total, 128));
+    if (d->dtype == HESIC_BF16)
+        hipLaunchKernelGGL(gmm_cdf_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const bf16_t*)scales,
+                           (const bf16_t*)means, weights, channels, n_channels, minmax, cdf);
+    else
+        hipLaunchKernelGGL(gmm_cdf_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const float*)scales,
+                           (const float*)means, weights, channels, n_channels, minmax, cdf);
+    HESIC_LAUNCH_RETURN("gmm_cdf");
 }
 
 extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,

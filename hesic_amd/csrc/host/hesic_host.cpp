@@ -159,3 +159,91 @@ extern "C" int hesic_rans_decoder_decode(hesic_rans_decoder* d, const int32_t* i
     }
     return 0;
 }
+
+
+// ------------------------------------------------------------------ adaptive range coder (HSIC.compress .bin payload)
+// Carry-less range coder: low is 64 bits wide, a byte is emitted while the top bytes of low and low+range agree, and an
+// underflowing range is clamped to the distance to the next 2^48 boundary (the classic TOP/BOTTOM scheme).
+namespace {
+constexpr uint64_t RC_TOP = 1ull << 56, RC_BOT = 1ull << 48;
+}
+struct hesic_rc_encoder {
+    uint64_t low = 0, range = ~0ull;
+    std::vector<uint8_t> out;
+    bool finished = false;
+};
+struct hesic_rc_decoder {
+    uint64_t low = 0, range = ~0ull, code = 0;
+    std::vector<uint8_t> in;
+    size_t pos = 0;
+    uint8_t next() { return pos < in.size() ? in[pos++] : 0; }
+};
+
+extern "C" hesic_rc_encoder* hesic_rc_encoder_new(void) { return new hesic_rc_encoder(); }
+extern "C" void hesic_rc_encoder_free(hesic_rc_encoder* e) { delete e; }
+
+extern "C" int hesic_rc_encoder_encode(hesic_rc_encoder* e, const int32_t* symbols, const uint32_t* cdf, int64_t n, int32_t stride) {
+    if (!e || e->finished || !symbols || !cdf || n < 0 || stride < 2) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* c = cdf + i * stride;
+        const int32_t s = symbols[i];
+        const uint64_t tot = c[stride - 1];
+        if (s < 0 || s >= stride - 1 || c[s + 1] <= c[s] || tot == 0 || tot >= RC_BOT) return -2;
+        e->range /= tot;
+        e->low += (uint64_t)c[s] * e->range;
+        e->range *= (uint64_t)(c[s + 1] - c[s]);
+        while ((e->low ^ (e->low + e->range)) < RC_TOP || (e->range < RC_BOT && ((e->range = (0 - e->low) & (RC_BOT - 1)), true))) {
+            e->out.push_back((uint8_t)(e->low >> 56));
+            e->low <<= 8;
+            e->range <<= 8;
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t hesic_rc_encoder_finish(hesic_rc_encoder* e, uint8_t* out, int64_t cap) {
+    if (!e) return -1;
+    if (!e->finished) {
+        for (int i = 0; i < 8; ++i) { e->out.push_back((uint8_t)(e->low >> 56)); e->low <<= 8; }
+        e->finished = true;
+    }
+    const int64_t nb = (int64_t)e->out.size();
+    if (out && cap >= nb) memcpy(out, e->out.data(), (size_t)nb);
+    return nb;
+}
+
+extern "C" hesic_rc_decoder* hesic_rc_decoder_new(const uint8_t* bytes, int64_t nbytes) {
+    if (!bytes || nbytes < 0) return nullptr;
+    hesic_rc_decoder* d = new hesic_rc_decoder();
+    d->in.assign(bytes, bytes + nbytes);
+    for (int i = 0; i < 8; ++i) d->code = (d->code << 8) | d->next();
+    return d;
+}
+extern "C" void hesic_rc_decoder_free(hesic_rc_decoder* d) { delete d; }
+
+extern "C" int hesic_rc_decoder_decode(hesic_rc_decoder* d, const uint32_t* cdf, int64_t n, int32_t stride, int32_t* symbols_out) {
+    if (!d || !cdf || !symbols_out || n < 0 || stride < 2) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* c = cdf + i * stride;
+        const uint64_t tot = c[stride - 1];
+        if (tot == 0 || tot >= RC_BOT) return -2;
+        d->range /= tot;
+        uint64_t v = (d->code - d->low) / d->range;
+        if (v >= tot) v = tot - 1;
+        // last table entry <= v (zero-frequency entries are skipped by taking the LAST one)
+        int lo = 0, hi = stride - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] <= v) lo = mid; else hi = mid;
+        }
+        symbols_out[i] = lo;
+        d->low += (uint64_t)c[lo] * d->range;
+        d->range *= (uint64_t)(c[lo + 1] - c[lo]);
+        while ((d->low ^ (d->low + d->range)) < RC_TOP || (d->range < RC_BOT && ((d->range = (0 - d->low) & (RC_BOT - 1)), true))) {
+            d->code = (d->code << 8) | d->next();
+            d->low <<= 8;
+            d->range <<= 8;
+        }
+    }
+    return 0;
+}

@@ -34,6 +34,25 @@ int hesic_rans_decoder_set_stream(hesic_rans_decoder*, const uint8_t* bytes, int
 int hesic_rans_decoder_decode(hesic_rans_decoder*, const int32_t* indexes, int64_t n, const int32_t* cdfs, int ncdf,
                               int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols_out);
 
+/* ---- adaptive range coder of HSIC.compress / decompress (ywz/mywork/newnet1.py:905-1040, :1137-1240): every symbol
+ * comes with its own cumulative-frequency table (cdf[0] = 0 ... cdf[A] = total, total need not be a power of two), the
+ * two views share one stream and the decoder is fed view 2's tables only after view 1 has been decoded.  The reference
+ * delegates this to the third-party `range_coder` package (PyPI, unpinned, absent from the reference tree): this is the
+ * carry-less range coder of that family (64-bit low, 2^56 top / 2^48 bottom, byte-wise renormalisation), restated from
+ * the published algorithm -- round trips are exact, byte-compatibility with `range_coder` is NOT pinned.
+ * cdf: [n][stride] uint32 row-major, row i = table of symbol i (stride = alphabet + 1).                               */
+typedef struct hesic_rc_encoder hesic_rc_encoder;
+typedef struct hesic_rc_decoder hesic_rc_decoder;
+hesic_rc_encoder* hesic_rc_encoder_new(void);
+void hesic_rc_encoder_free(hesic_rc_encoder*);
+/* -1: bad argument, -2: a symbol with zero frequency / outside its table */
+int hesic_rc_encoder_encode(hesic_rc_encoder*, const int32_t* symbols, const uint32_t* cdf, int64_t n, int32_t stride);
+/* finishes the stream (idempotent); returns its size and copies it to out when cap suffices (out=NULL: size only) */
+int64_t hesic_rc_encoder_finish(hesic_rc_encoder*, uint8_t* out, int64_t cap);
+hesic_rc_decoder* hesic_rc_decoder_new(const uint8_t* bytes, int64_t nbytes);     /* copies the stream */
+void hesic_rc_decoder_free(hesic_rc_decoder*);
+int hesic_rc_decoder_decode(hesic_rc_decoder*, const uint32_t* cdf, int64_t n, int32_t stride, int32_t* symbols_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -502,6 +502,24 @@ def gaussian_conditional(y, scales, means=None, noise=None, scale_bound=0.11, li
     return _GmmFn.apply(y, scales, means, None, noise, 1, means is not None, scale_bound, lik_bound)
 
 
+def gmm_cdf_tables(scales, means, weights, channels, minmax, K, b=0, scale_bound=0.11):
+    """Per-element cumulative-frequency tables of the real bit-stream (HSIC.compress / decompress,
+    ywz/mywork/newnet1.py:925-978): returns an int32 tensor (len(channels), H, W, 2*minmax+2) on the device whose rows
+    are the uint32 tables [0, cumsum(round(clip(pmf)/sum*65536))] of image ``b``."""
+    L.require_cuda(scales, means)
+    B, KM, H, W = scales.shape
+    M = KM // K
+    dt = scales.dtype
+    scales, means = _nhwc(scales), _nhwc(means.to(dt))
+    wts = None if weights is None else weights.detach().reshape(B, K * M).to(torch.float32).contiguous()
+    ch = torch.as_tensor(channels, dtype=torch.int32, device=scales.device).contiguous()
+    out = torch.empty((ch.numel(), H, W, 2 * int(minmax) + 2), dtype=torch.int32, device=scales.device)
+    d = L.GmmDesc(B, H * W, M, K, L.dt(scales), 0, K * M, 0, 0, float(scale_bound), 0.0)
+    L.call("hesic_gmm_cdf", C.byref(d), int(b), L.ptr(scales), L.ptr(means), L.ptr(wts), L.ptr(ch), ch.numel(), int(minmax),
+           L.ptr(out), L.stream())
+    return out
+
+
 def quantize_symbols(y, means=None):
     """EntropyModel._quantize(x, 'symbols', means) (entropy_models.py:98-125): int32 indices."""
     L.require_cuda(y)

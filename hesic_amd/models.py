@@ -305,6 +305,138 @@ class HSIC(StereoCompressionModel):
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
 
+    # ---------------------------------------------------------------------------------------- real bit-stream
+    # HSIC.compress / decompress of the reference (ywz/mywork/newnet1.py:823-1073, :1076-1273).  Same
+    # flow and the same header file; the per-pixel Python loops of the reference are one HIP launch per view for the
+    # cumulative-frequency tables (hesic_gmm_cdf) + one pass of the host range coder.  The .bin payload is coded by
+    # libhesic_host's own carry-less range coder: the reference's `range_coder` package is third party, absent and
+    # unpinned, so byte-compatibility of that file is not claimed (round trips are exact).  Batch size 1, like the reference.
+    _CDF_CHUNK_BYTES = 256 << 20
+
+    def _cdf_chunks(self, gmm, channels, minmax, scale_bound, y_hat=None):
+        """(channels, symbols | None, cdf) numpy chunks in the reference's coding order: channel-major, rows, columns."""
+        import numpy as np
+        scales, means, weights = gmm
+        H, W = scales.shape[-2:]
+        per_ch = H * W * (2 * minmax + 2) * 4
+        step = max(1, self._CDF_CHUNK_BYTES // per_ch)
+        for i in range(0, len(channels), step):
+            ch = channels[i:i + step]
+            cdf = Fn.gmm_cdf_tables(scales, means, weights, ch, minmax, self.K, scale_bound=scale_bound)
+            cdf = cdf.cpu().numpy().view(np.uint32).reshape(-1, 2 * minmax + 2)
+            sym = None
+            if y_hat is not None:
+                sym = (y_hat[0, ch].float().cpu().numpy().astype(np.int64) + minmax).reshape(-1).astype(np.int32)
+            yield ch, sym, cdf
+
+    def _analysis(self, x1, x2, h_matrix):
+        size = (x1.shape[-2], x1.shape[-1])
+        y1 = self.encoder1(x1)
+        z1 = self._h_a1(y1)
+        z1_strings = self.entropy_bottleneck1.compress(z1)
+        z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(z1.dtype)
+        gmm1 = self._h_s1(z1_hat)
+        y1_hat = self.gaussian1._quantize(y1, "dequantize")
+        x1_hat = self.decoder1(y1_hat)
+        x1_warp = warp_perspective(x1, h_matrix, size)
+        y2 = self.encoder2(x1_warp, x2)
+        z2 = self._h_a2(y2)
+        z2_strings = self.entropy_bottleneck2.compress(z2)
+        z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(z2.dtype)
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+        gmm2 = self._h_s2(z2_hat, y1_hat_w)
+        y2_hat = self.gaussian2._quantize(y2, "dequantize")
+        return (y1_hat, z1_hat, z1_strings, gmm1), (y2_hat, z2_hat, z2_strings, gmm2)
+
+    def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
+        import os
+        import time
+        import numpy as np
+        from ._host import RangeEncoder
+        if x1.shape[0] != 1:
+            raise ValueError("HSIC.compress codes one stereo pair per call (batch size 1, as the reference)")
+        if self.entropy_bottleneck1._offset.numel() == 0:
+            self.update()
+        with torch.no_grad():
+            v1, v2 = self._analysis(x1, x2, h_matrix)
+        out1 = os.path.join(output_path, str(output_name) + ".npz")      # the reference's name for its raw header file
+        out2 = os.path.join(output_path, str(output_name) + ".bin")
+        head = bytearray(np.array(x1.shape[2:], dtype=np.uint16).tobytes())
+        enc = RangeEncoder()
+        start = time.time()
+        for (y_hat, _z_hat, z_strings, gmm), gauss in ((v1, self.gaussian1), (v2, self.gaussian2)):
+            yi = y_hat[0].float()
+            flag = (yi.abs().sum(dim=(1, 2)) > 0).cpu().numpy().astype(np.uint8)
+            minmax = int(max(float(yi.abs().max()), 1.0))
+            if len(z_strings[0]) > 65535 or minmax > 65535:
+                raise ValueError("HSIC.compress: header fields are uint16 (z string too long or latent range too wide)")
+            head += np.array([len(z_strings[0]), minmax], dtype=np.uint16).tobytes()
+            head += np.packbits(flag).tobytes()
+            head += z_strings[0]
+            channels = [int(c) for c in np.nonzero(flag)[0]]
+            for _ch, sym, cdf in self._cdf_chunks(gmm, channels, minmax, gauss._bound(), y_hat):
+                enc.encode(sym, cdf)
+        payload = enc.finish()
+        with open(out1, "wb") as f:
+            f.write(bytes(head))
+        with open(out2, "wb") as f:
+            f.write(payload)
+        num_pixels = x1.shape[2] * x1.shape[3] * 2
+        return {"bpp_real": (len(head) + len(payload)) * 8 / num_pixels, "bpp_side": len(head) * 8 / num_pixels,
+                "enctime": time.time() - start, "y1_hat": v1[0], "y2_hat": v2[0], "z1_hat": v1[1], "z2_hat": v2[1]}
+
+    def decompress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
+        """x1 / x2 are unused (the reference only reads their size, which the header carries); kept for its signature."""
+        import os
+        import time
+        import numpy as np
+        from ._host import RangeDecoder
+        if self.entropy_bottleneck1._offset.numel() == 0:
+            self.update()
+        dev = h_matrix.device
+        with open(os.path.join(output_path, str(output_name) + ".npz"), "rb") as f:
+            blob = f.read()
+        pos = 4
+        x_shape = np.frombuffer(blob[:4], dtype=np.uint16).astype(int)
+        views = []
+        for _ in range(2):
+            length, minmax = (int(v) for v in np.frombuffer(blob[pos:pos + 4], dtype=np.uint16))
+            pos += 4
+            flag = np.unpackbits(np.frombuffer(blob[pos:pos + self.M // 8], dtype=np.uint8))
+            pos += self.M // 8
+            views.append((minmax, [int(c) for c in np.nonzero(flag)[0]], blob[pos:pos + length]))
+            pos += length
+        y_shape = x_shape // 16
+        z_shape = y_shape // 4
+        with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
+            dec = RangeDecoder(f.read())
+        start = time.time()
+        cdt = Fn.compute_dtype()
+        size = (int(x_shape[0]), int(x_shape[1]))
+
+        def decode_view(gmm, minmax, channels, gauss):
+            y_hat = torch.zeros((1, self.M, int(y_shape[0]), int(y_shape[1])), dtype=torch.float32)
+            for ch, _sym, cdf in self._cdf_chunks(gmm, channels, minmax, gauss._bound()):
+                sym = dec.decode(cdf).reshape(len(ch), int(y_shape[0]), int(y_shape[1]))
+                y_hat[0, ch] = torch.from_numpy(sym.astype(np.float32) - minmax)
+            return y_hat.to(dev, cdt).contiguous(memory_format=torch.channels_last)
+
+        with torch.no_grad():
+            zs = (int(z_shape[0]), int(z_shape[1]))
+            z1_hat = self.entropy_bottleneck1.decompress([views[0][2]], zs).to(dev, cdt)
+            z2_hat = self.entropy_bottleneck2.decompress([views[1][2]], zs).to(dev, cdt)
+            gmm1 = self._h_s1(z1_hat)
+            y1_hat = decode_view(gmm1, views[0][0], views[0][1], self.gaussian1)
+            x1_hat = self.decoder1(y1_hat)
+            x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+            gmm2 = self._h_s2(z2_hat, y1_hat_w)
+            y2_hat = decode_view(gmm2, views[1][0], views[1][1], self.gaussian2)
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,
+                "dectime": time.time() - start}
+
     def _forward_two_streams(self, x1, x2, h_matrix):
         """Inference schedule on two HIP streams.  View 2's analysis (warp -> encoder2 -> h_a2 -> bottleneck) depends
         only on the inputs, so it runs on a side stream while the main stream walks view 1's chain

@@ -180,6 +180,12 @@ typedef struct {
 int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
                       const float* weights, const void* noise, void* y_hat, float* lik, int32_t* symbols,
                       void* stream);
+/* Per-element cumulative-frequency tables for the real bit-stream of HSIC.compress / decompress (newnet1.py:925-978,
+ * :1137-1175): for image b, every listed channel and pixel, cdf[(j*HW + hw)*(A+1) + 0..A], A = 2*minmax+1,
+ * = [0, cumsum(round(clip(pmf, 2^-16, 1) / sum * 65536))] over the shifted alphabet 0..2*minmax with the mixture pmf of
+ * GaussianMixtureConditional._likelihood -- the reference's Python double loop as one launch.  channels: device int32.  */
+int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                  const int32_t* channels, int n_channels, int minmax, uint32_t* cdf, void* stream);
 /* Gradients: dy (y dtype; only meaningful in noise mode), dscales/dmeans (scales dtype, same layout),
  * dweights (B,K*M) fp32 zero-filled by caller (atomic accumulate).                                   */
 int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,

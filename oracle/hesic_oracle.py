@@ -423,6 +423,34 @@ def independent_en(P, x1_hat, x2_hat, Hm, align_corners=True):
 
 
 # --------------------------------------------------------------- loss and metrics
+# --------------------------------------------------------------------------- real bit-stream (HSIC.compress / decompress)
+def compress_cdf_tables(scales, means, weights, channels, minmax, K, M):
+    """The per-pixel cumulative-frequency tables ``HSIC.compress`` feeds its range coder (newnet1.py:925-978; the
+    decoder repeats it, :1137-1175), for image 0: (len(channels), H, W, 2*minmax+2) uint32.  Same operations in the same
+    order as the reference: torch fp32 pmf of the K-mixture over the shifted alphabet, then numpy float32 clip / sum /
+    round / add.accumulate."""
+    import numpy as np
+    H, W = scales.shape[-2:]
+    samples = torch.arange(0, minmax * 2 + 1, dtype=torch.float32).reshape(-1, 1, 1).expand(-1, H, W)
+    out = np.zeros((len(channels), H, W, 2 * minmax + 2), dtype=np.uint32)
+    for j, ch in enumerate(channels):
+        idx = [int(ch) + k * M for k in range(K)]
+        sig, mu, w = scales[0, idx], means[0, idx] + minmax, weights.reshape(weights.shape[0], -1)[0, idx]
+        pmf = None
+        for k in range(K):
+            v = (samples - mu[k]).abs()
+            s_ = lower_bound(sig[k], SCALE_BOUND)
+            t = (std_cumulative((0.5 - v) / s_) - std_cumulative((-0.5 - v) / s_)) * w[k]
+            pmf = t if pmf is None else pmf + t
+        pmf = pmf.numpy()
+        for h in range(H):
+            for x in range(W):
+                pc = np.clip(pmf[:, h, x], 1.0 / 65536, 1.0)
+                pc = np.round(pc / np.sum(pc) * 65536)
+                out[j, h, x, 1:] = np.add.accumulate(pc).astype(np.uint32)
+    return out
+
+
 # --------------------------------------------------------------------------- in front of the path: HomographyNet -> h_matrix
 def homography_net(P, a, b, return_features=False):
     """``Net.forward`` in eval mode (ywz/mywork/model.py:73-101): cat -> 4 Blocks (conv3x3+ReLU twice, MaxPool2d(2,2)
