@@ -258,7 +258,10 @@ class EntropyBottleneck(EntropyModel):
 
     def forward_with_noise(self, x, noise):
         """noise=None: eval (round(x-med)+med); else x+noise (parity tests inject the draw)."""
-        return Fn.entropy_bottleneck(x, list(self._matrices), list(self._biases), list(self._factors), self.quantiles, noise)
+        if not hasattr(self, "_eb_packer"):
+            self._eb_packer = Fn.PackedEb()
+        return Fn.entropy_bottleneck(x, list(self._matrices), list(self._biases), list(self._factors), self.quantiles, noise,
+                                     packer=self._eb_packer)
 
     @staticmethod
     def _build_indexes(size):

@@ -34,6 +34,34 @@ __global__ void gdn_generic_kernel(const void* __restrict__ x, const float* __re
     }
 }
 
+// planar (NCHW) images with a handful of channels -- pre_gdn / after_gdn, C = 3 (newnet1.py:630,669): one thread per pixel,
+// every plane read and written coalesced, no layout copy on either side
+template <int C>
+__global__ void gdn_planar_kernel(const void* __restrict__ x, const float* __restrict__ beta, const float* __restrict__ gamma,
+                                  void* __restrict__ y, int B, int64_t HW, int inverse, float beta_bound, int dtype) {
+    float g[C][C], bt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        bt[c] = reparam(beta[c], beta_bound);
+#pragma unroll
+        for (int j = 0; j < C; ++j) g[c][j] = reparam(gamma[c * C + j], kGammaBound);
+    }
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, p = i - b * HW, base = b * C * HW + p;
+        float xv[C], sq[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { xv[c] = ld_any(x, base + c * HW, dtype); sq[c] = xv[c] * xv[c]; }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float norm = bt[c];
+#pragma unroll
+            for (int j = 0; j < C; ++j) norm += g[c][j] * sq[j];
+            st_any(y, base + c * HW, dtype, xv[c] * (inverse ? sqrtf(norm) : rsqrtf(norm)));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ C = 128 on the matrix cores
 template <typename T> struct G;
 template <> struct G<bf16_t> { static constexpr int BP = 128, CE = 8; };   // pixels per tile, elems / 16 B
@@ -160,6 +188,17 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
 }
 
 }  // namespace
+
+extern "C" int hesic_gdn_forward_planar(const void* x, const float* beta, const float* gamma, void* y, int B, int C, int64_t HW,
+                                        int inverse, float beta_min, int dtype, void* stream) {
+    HESIC_CHECK_ARG(x && beta && gamma && y && B > 0 && HW > 0, "gdn_forward_planar: bad arguments");
+    HESIC_CHECK_ARG(C == 3, "gdn_forward_planar: built for the 3-channel image-side GDNs (got C=%d)", C);
+    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "gdn_forward_planar: bad dtype");
+    const float bound = sqrtf(beta_min + 1.0f / 68719476736.0f);
+    hipLaunchKernelGGL(gdn_planar_kernel<3>, dim3(grid_for((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, beta, gamma, y,
+                       B, HW, inverse, bound, dtype);
+    HESIC_LAUNCH_RETURN("gdn_forward_planar");
+}
 
 extern "C" int hesic_gdn_forward(const void* x, const float* beta, const float* gamma, void* y, int64_t P, int C,
                                  int inverse, float beta_min, int dtype, void* stream) {

@@ -332,6 +332,13 @@ class _GdnFn(torch.autograd.Function):
 
 
 def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+    if x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16):
+        # image-side GDN on a planar tensor at inference: no NHWC round trip
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(y), B, Cc, H * W,
+               int(inverse), float(beta_min), L.dt(x), L.stream())
+        return y
     return _GdnFn.apply(x, beta, gamma, inverse, beta_min)
 
 
@@ -431,7 +438,32 @@ class _EbFn(torch.autograd.Function):
         return (dz, None, dq, None, *grads)
 
 
-def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None):
+class PackedEb:
+    """The [C][64] parameter table of an EntropyBottleneck; inference-only cache (same policy as PackedWeight)."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, matrices, biases, factors, quantiles):
+        ps = (*matrices, *biases, *factors, quantiles)
+        tag = tuple((p.data_ptr(), p._version) for p in ps) + (_cache_epoch,)
+        if self._hit is None or self._hit[0] != tag:
+            self._hit = (tag, eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
+                                             [f.detach() for f in factors], quantiles.detach()))
+        return self._hit[1]
+
+
+def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, packer=None):
+    if packer is not None and noise is None and not torch.is_grad_enabled():
+        # inference: cached parameter table, no autograd bookkeeping -- one launch
+        L.require_cuda(z)
+        B, Cc, H, W = z.shape
+        z = _nhwc(z)
+        table = packer.get(matrices, biases, factors, quantiles)
+        zh = torch.empty_like(z, memory_format=_CL)
+        lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
+        L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), None, L.ptr(zh), L.ptr(lik), None, B * H * W, Cc, L.dt(z), L.stream())
+        return zh, lik
     return _EbFn.apply(z, noise, quantiles, len(matrices), *matrices, *biases, *factors)
 
 

@@ -613,10 +613,17 @@ def pad_to_multiple(x, multiple=64):
 def rate_distortion(out, x1, x2):
     """bits / squared error of one forward as fp64 device scalars (HIP reductions, no host sync):
     returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""
-    res = {"bits_" + k: -Fn.sum_log2(v) for k, v in out["likelihoods"].items()}
+    keys = list(out["likelihoods"].keys())
+    acc = torch.zeros(len(keys) + 2, dtype=torch.float64, device=x1.device)      # one zero-fill for all six accumulators
+    for i, k in enumerate(keys):
+        Fn.sum_log2(out["likelihoods"][k], out=acc[i:i + 1])
     h, w = x1.shape[-2:]                      # x1/x2 are the ORIGINAL images: padded reconstructions are cropped (views)
-    res["sse1"] = Fn.sum_sq_diff(out["x1_hat"][..., :h, :w], x1)
-    res["sse2"] = Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2)
+    n = len(keys)
+    Fn.sum_sq_diff(out["x1_hat"][..., :h, :w], x1, out=acc[n:n + 1])
+    Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2, out=acc[n + 1:n + 2])
+    bits = -acc[:n]
+    res = {"bits_" + k: bits[i:i + 1] for i, k in enumerate(keys)}
+    res["sse1"], res["sse2"] = acc[n:n + 1], acc[n + 1:n + 2]
     res["num_pixels"] = x1.shape[0] * h * w    # bpp over the original pixel count
     return res
 

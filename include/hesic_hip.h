@@ -129,6 +129,9 @@ int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy
  * x, y: NHWC with C channels, P = B*H*W pixels.                                                       */
 int hesic_gdn_forward(const void* x, const float* beta, const float* gamma, void* y, int64_t P, int C,
                       int inverse, float beta_min, int dtype, void* stream);
+/* Same op on a planar (B,C,H,W) image, C = 3: pre_gdn / after_gdn (newnet1.py:630,669) without a layout copy.          */
+int hesic_gdn_forward_planar(const void* x, const float* beta, const float* gamma, void* y, int B, int C, int64_t HW,
+                             int inverse, float beta_min, int dtype, void* stream);
 /* dx (same dtype as x), dbeta (C) and dgamma (C*C) fp32, gradients w.r.t. the RAW parameters
  * (LowerBound rule of compressai/ops/bound_ops.py:28-31 included).  ws: fp32 workspace of
  * hesic_gdn_backward_ws_bytes(P,C) bytes.                                                             */
