@@ -12,6 +12,8 @@
 // order by a second kernel, so the result is deterministic.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -230,7 +232,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
 // need 8 consecutive PIXELS of one channel per lane, come out of LDS through ds_read_b64_tr_b16: a 16-lane group reads
 // a [4 pixels][16 channels] block and every lane receives one channel's 4 pixels.  The 16-byte slots of a 256-byte
 // pixel row are XOR-ed with ((pixel & 3) << 1) on the DMA source side so the 4 rows of a block hit distinct banks.
-__device__ __attribute__((aligned(16))) uint32_t g_wg_zero_page[16];
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const WgArgs& a = A.w;
     constexpr int BK = 64, TILE = BK * 256, STAGE = 2 * TILE;       // 64 pixels x 128 channels x 2 B per operand
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int split = bid % a.nsplit; bid /= a.nsplit;
     const int cit = bid % a.ci_tiles; bid /= a.ci_tiles;
@@ -258,40 +259,61 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const int co0 = cot * TC, ci0 = cit * TC;
     const int64_t q_begin = split * a.chunk;
     const int64_t q_end = (q_begin + a.chunk < a.Q) ? q_begin + a.chunk : a.Q;
-    const bf16_t* xg = (const bf16_t*)a.x;
-    const bf16_t* dg = (const bf16_t*)a.dy;
-    const bf16_t* zero = (const bf16_t*)g_wg_zero_page;
 
-    // DMA roles: instruction ii = wave*4 + i of an operand covers tile rows 4*ii .. 4*ii+3; lane -> (row, phys slot)
+    // Buffer-addressed LDS-DMA (as in conv_igemm.hip): out-of-range offsets make the buffer unit write zeros, so padding
+    // pixels, pixels beyond this block's slice and channels beyond the tensor need no zero page and no 64-bit pointers.
+    // One operand is walked linearly (its pixel index IS q: dY for a conv, X for a transposed conv), the other carries the
+    // tap shift and needs (b, qy, qx); those advance incrementally by 64 pixels per step -- a division only on a row wrap.
+    constexpr uint32_t OOB = 0x80000000u;
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)OOB, 0x00020000);
     const int lrow = lane >> 4, pslot = lane & 15;
-    auto issue = [&](int64_t q0, int buf) {
+    const int ls = pslot ^ ((lrow & 3) << 1);                     // row & 3 == lrow & 3 for all four DMA rows of a lane
+    const bool d_ch = co0 + ls * 8 < a.Cout, x_ch = ci0 + ls * 8 < a.Cin;
+    const uint32_t d_cb = (uint32_t)((a.y_co + co0 + ls * 8) * 2), x_cb = (uint32_t)((a.x_co + ci0 + ls * 8) * 2);
+    const int SH = a.transposed ? a.Ho : a.H, SW = a.transposed ? a.Wo : a.W;        // extent of the shifted operand
+    const uint32_t lin_ps = (uint32_t)((a.transposed ? a.x_ps : a.y_ps) * 2), sh_ps = (uint32_t)((a.transposed ? a.y_ps : a.x_ps) * 2);
+    uint32_t qi[4], lin_off[4];
+    int qx[4], qy[4], qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t q = (uint32_t)q_begin + (uint32_t)((wave * 4 + i) * 4 + lrow);
+        qi[i] = q;
+        const uint32_t r1 = fdiv(q, A.dqw);
+        qx[i] = (int)(q - r1 * (uint32_t)a.QW);
+        const uint32_t b = fdiv(r1, A.dqh);
+        qy[i] = (int)(r1 - b * (uint32_t)a.QH);
+        qb[i] = (int)b;
+        lin_off[i] = q * lin_ps;
+    }
+    auto issue = [&](int buf) {
         unsigned char* dt = smem + buf * STAGE;
         unsigned char* xt = dt + TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (wave * 4 + i) * 4 + lrow;
-            const int ls = pslot ^ ((row & 3) << 1);
-            const int64_t q = q0 + row;
-            const bf16_t* sd = zero;
-            const bf16_t* sx = zero;
-            if (q < q_end) {
-                const uint32_t qq = (uint32_t)q;
-                const uint32_t r1 = fdiv(qq, A.dqw);
-                const int qx = (int)(qq - r1 * (uint32_t)a.QW);
-                const uint32_t b = fdiv(r1, A.dqh);
-                const int qy = (int)(r1 - b * (uint32_t)a.QH);
-                // which operand carries the tap shift: conv -> X, transposed -> dY
-                int dpy = qy, dpx = qx, xpy = qy, xpx = qx;
-                bool dok = true, xok = true;
-                if (a.transposed) { dpy = qy * a.stride + sh_y; dpx = qx * a.stride + sh_x; dok = (unsigned)dpy < (unsigned)a.Ho && (unsigned)dpx < (unsigned)a.Wo; }
-                else { xpy = qy * a.stride + sh_y; xpx = qx * a.stride + sh_x; xok = (unsigned)xpy < (unsigned)a.H && (unsigned)xpx < (unsigned)a.W; }
-                if (dok && co0 + ls * 8 < a.Cout) sd = dg + (((int64_t)b * a.Ho + dpy) * a.Wo + dpx) * a.y_ps + a.y_co + co0 + ls * 8;
-                if (xok && ci0 + ls * 8 < a.Cin) sx = xg + (((int64_t)b * a.H + xpy) * a.W + xpx) * a.x_ps + a.x_co + ci0 + ls * 8;
+            const bool inq = qi[i] < (uint32_t)q_end;
+            const int sy = qy[i] * a.stride + sh_y, sx = qx[i] * a.stride + sh_x;
+            const bool sok = inq && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW;
+            const uint32_t s_off = (uint32_t)((qb[i] * SH + sy) * SW + sx) * sh_ps;
+            uint32_t vd, vx;
+            if (a.transposed) { vd = (sok && d_ch) ? s_off + d_cb : OOB; vx = (inq && x_ch) ? lin_off[i] + x_cb : OOB; }
+            else { vd = (inq && d_ch) ? lin_off[i] + d_cb : OOB; vx = (sok && x_ch) ? s_off + x_cb : OOB; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(dt + (wave * 4 + i) * 1024), 16, (int)vd, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xt + (wave * 4 + i) * 1024), 16, (int)vx, 0, 0, 0);
+            qi[i] += BK;
+            lin_off[i] += BK * lin_ps;
+            qx[i] += BK;
+            if (qx[i] >= a.QW) {
+                const uint32_t t = fdiv((uint32_t)qx[i], A.dqw);
+                qx[i] -= (int)t * a.QW;
+                qy[i] += (int)t;
+                if (qy[i] >= a.QH) {
+                    const uint32_t u = fdiv((uint32_t)qy[i], A.dqh);
+                    qy[i] -= (int)u * a.QH;
+                    qb[i] += (int)u;
+                }
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
-                                             (__attribute__((address_space(3))) void*)(dt + (wave * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
-                                             (__attribute__((address_space(3))) void*)(xt + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
 
@@ -311,52 +333,74 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int64_t nsteps = (q_end - q_begin + BK - 1) / BK;
-    if (nsteps > 0) issue(q_begin, 0);
-    for (int64_t step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (step + 1 < nsteps) issue(q_begin + (step + 1) * BK, buf ^ 1);
-        const unsigned char* dt = smem + buf * STAGE;
-        const unsigned char* xt = dt + TILE;
+    // the transform of the X operand (|x| for the abs-conv of encode_hyper, x^2 for the GDN gamma gradient) is a
+    // compile-time variant of the loop: no branches between the transpose reads and the MFMAs
+    auto main_loop = [&](auto abs_tag, auto sq_tag) {
+        constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value;
+        if (nsteps > 0) issue(0);
+        for (int64_t step = 0; step < nsteps; ++step) {
+            const int buf = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* dt = smem + buf * STAGE;
+            const unsigned char* xt = dt + TILE;
+            s16x4 dlo[2][2], dhi[2][2], xlo[2][2], xhi[2][2];
+            auto ldf = [&](int set, int ks) {
+                const int pix = ks * 16 + (g >> 1) * 8 + (t >> 2);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int pix = ks * 16 + (g >> 1) * 8 + (t >> 2);
-            bf16x8 df[2], xf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix + 4)));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                df[i] = __builtin_bit_cast(bf16x8, v);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix + 4)));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                if (a.in_abs) v = v & (short)0x7fff;
-                if (a.in_sq) {
-                    u32x4 u = __builtin_bit_cast(u32x4, v);
-                    uint32_t* w4 = (uint32_t*)&u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
-                        w4[q] = pack_bf2(l2 * l2, h2 * h2);
-                    }
-                    v = __builtin_bit_cast(s16x8, u);
+                for (int i = 0; i < 2; ++i) {
+                    dlo[set][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix)));
+                    dhi[set][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dt + tr_off(wm * 64 + i * 32, pix + 4)));
                 }
-                xf[j] = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    xlo[set][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix)));
+                    xhi[set][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix + 4)));
+                }
+            };
+            ldf(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < nsteps) issue(buf ^ 1);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) ldf((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 df[2], xf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x8 v = __builtin_shufflevector(dlo[ks & 1][i], dhi[ks & 1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                    df[i] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    s16x8 v = __builtin_shufflevector(xlo[ks & 1][j], xhi[ks & 1][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (ABS) v = v & (short)0x7fff;
+                    if (SQ) {
+                        u32x4 u = __builtin_bit_cast(u32x4, v);
+                        uint32_t* w4 = (uint32_t*)&u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
+                            w4[q] = pack_bf2(l2 * l2, h2 * h2);
+                        }
+                        v = __builtin_bit_cast(s16x8, u);
+                    }
+                    xf[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
         }
-    }
+    };
+    if (a.in_sq) main_loop(std::false_type{}, std::true_type{});
+    else if (a.in_abs) main_loop(std::true_type{}, std::false_type{});
+    else main_loop(std::false_type{}, std::false_type{});
+
     float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -888,8 +932,9 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
 }
 
 int pick_splits(int64_t Q, int bk, int tiles) {
-    // aim at ~1500 blocks, at least 4 K-steps per block
-    static const int target = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 1536;   // A/B switch
+    // aim at ~384 blocks (measured best on MI355X for the step as a whole: every extra slice is another fp32 partial tile
+    // to write and reduce), at least 4 K-steps per block
+    static const int target = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
     if (s > maxs) s = maxs;
@@ -944,7 +989,8 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
     bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
     for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
-    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31)) launch_wgrad_tr(a, blocks, st);
+    const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
+    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31) && off32) launch_wgrad_tr(a, blocks, st);
     else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
@@ -983,7 +1029,7 @@ extern "C" int64_t hesic_sconv2d_wgrad_ws_bytes(const hesic_sconv_desc* d) {
     bool conv1;
     if (!d || !nw_fast_case(d, conv1)) return 0;
     const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
-    if (Q >= (1ll << 31)) return 0;
+    if (Q >= (1ll << 22)) return 0;
     hesic_conv_desc g;
     nw_gemm_desc(Q, g);
     WgArgs a;
@@ -1083,7 +1129,7 @@ static int gdn_fast_desc(int64_t P, hesic_conv_desc& d) {
 
 extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) {
     int64_t generic = (2 * P * C + (int64_t)C * C + C) * 4;
-    if (C == 128 && P < (1ll << 31)) {
+    if (C == 128 && P < (1ll << 22)) {
         hesic_conv_desc d;
         gdn_fast_desc(P, d);
         WgArgs a;
@@ -1103,7 +1149,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
     static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr;
-    if (!legacy && C == 128 && dtype == HESIC_BF16 && P < (1ll << 31)) {
+    if (!legacy && C == 128 && dtype == HESIC_BF16 && P < (1ll << 22)) {
         hesic_conv_desc d;
         gdn_fast_desc(P, d);
         WgArgs a;
