@@ -136,7 +136,7 @@ __device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* r
 }
 
 template <typename T>
-__global__ void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+__global__ __launch_bounds__(64) void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
                               const float* __restrict__ glik, const T* __restrict__ gzhat, T* __restrict__ dz,
                               float* __restrict__ dparams, int64_t P, int C) {
     const int c = blockIdx.y * blockDim.x + threadIdx.x;

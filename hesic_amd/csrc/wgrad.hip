@@ -760,6 +760,45 @@ __global__ __launch_bounds__(256) void gdn_bwd_param_kernel(const void* __restri
     atomicAdd(dgp + e, acc);
     if (j == 0) atomicAdd(dbp + i, accb);
 }
+// few channels (the 3-channel image-side GDNs): thread = pixel, all C*C + C sums in registers, wave reduction, then one atomic
+// per wave and value -- the (i, j)-per-thread kernel above would run 9 lanes per block
+template <int C>
+__global__ __launch_bounds__(256) void gdn_bwd_param_small_kernel(const void* __restrict__ x, const float* __restrict__ dn,
+                                                                  float* __restrict__ dgp, float* __restrict__ dbp, int64_t P, int dtype) {
+    float g[C][C], bsum[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) g[i][j] = 0.f;
+    }
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        float d[C], sq[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            d[c] = dn[p * C + c];
+            const float xv = ld_any(x, p * C + c, dtype);
+            sq[c] = xv * xv;
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            bsum[i] += d[i];
+#pragma unroll
+            for (int j = 0; j < C; ++j) g[i][j] = fmaf(d[i], sq[j], g[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float b = wave_sum(bsum[i]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dbp + i, b);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float v = wave_sum(g[i][j]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(dgp + i * C + j, v);
+        }
+    }
+}
+
 __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, const float* __restrict__ dgp,
                                      const float* __restrict__ dbp, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                      float beta_bound) {
@@ -1198,7 +1237,8 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     if (gy > P) gy = (int)P;
     const int64_t rpb = (P + gy - 1) / gy;
     gy = (int)((P + rpb - 1) / rpb);
-    hipLaunchKernelGGL(gdn_bwd_param_kernel, dim3(gx, gy), dim3(256), 0, st, x, dn, dgp, dbp, P, C, dtype, rpb);
+    if (C == 3) hipLaunchKernelGGL(gdn_bwd_param_small_kernel<3>, dim3(grid_for(P, 256 * 8, 128)), dim3(256), 0, st, x, dn, dgp, dbp, P, dtype);
+    else hipLaunchKernelGGL(gdn_bwd_param_kernel, dim3(gx, gy), dim3(256), 0, st, x, dn, dgp, dbp, P, C, dtype, rpb);
     hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(gx), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
     HESIC_LAUNCH_RETURN("gdn_backward");
 }
