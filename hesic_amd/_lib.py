@@ -54,6 +54,7 @@ _SIGS = {
     "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv2d_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_gdn_forward_planar": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp], _i32),
+    "hesic_eb_prepare_params": ([_vp, _vp, _i32, _vp], _i32),
     "hesic_gmm_cdf": ([_P(GmmDesc), _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp], _i32),
     "hesic_maxpool2_forward": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_perspective_transform": ([_vp, _vp, _vp, _i32, _vp], _i32),

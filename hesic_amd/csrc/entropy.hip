@@ -26,7 +26,20 @@ struct EBParams {
     float tf[12];    // tanh(factors)
 };
 
+// slot 59 of a parameter row marks a table whose softplus / tanh have already been applied (hesic_eb_prepare_params:
+// the inference cache does the 45 transcendentals per channel once instead of once per thread and launch)
+constexpr int EB_READY = 59;
+
 __device__ __forceinline__ void eb_load(const float* p, EBParams& q) {
+    if (p[EB_READY] != 0.f) {
+#pragma unroll
+        for (int i = 0; i < 33; ++i) q.sp[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) q.b[i] = p[EB_B0 + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) q.tf[i] = p[EB_F0 + i];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 33; ++i) q.sp[i] = softplusf(p[i]);
 #pragma unroll
@@ -85,6 +98,19 @@ __global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__
         elem<T>::st(zhat + i, v);
         lik[i] = fmaxf(l, 1e-9f);
     }
+}
+
+__global__ void eb_prepare_kernel(const float* __restrict__ raw, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = raw + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    float* o = out + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    for (int i = 0; i < 33; ++i) o[i] = softplusf(p[i]);
+    for (int i = 0; i < 13; ++i) o[EB_B0 + i] = p[EB_B0 + i];
+    for (int i = 0; i < 12; ++i) o[EB_F0 + i] = tanhf(p[EB_F0 + i]);
+    o[EB_MED] = p[EB_MED];
+    o[EB_READY] = 1.f;
+    for (int i = EB_READY + 1; i < HESIC_EB_PARAM_STRIDE; ++i) o[i] = 0.f;
 }
 
 // backward through one logits evaluation: accumulates d(params) into gp[58] and returns d/dv
@@ -376,6 +402,12 @@ extern "C" int hesic_eb_forward(const void* z, const float* params, const void* 
         hipLaunchKernelGGL(eb_fwd_kernel<float>, grid, dim3(bx), 0, (hipStream_t)stream, (const float*)z, params,
                            (const float*)noise, (float*)z_hat, lik, symbols, P, C);
     HESIC_LAUNCH_RETURN("eb_forward");
+}
+
+extern "C" int hesic_eb_prepare_params(const float* params, float* prepared, int C, void* stream) {
+    HESIC_CHECK_ARG(params && prepared && C > 0, "eb_prepare_params: bad arguments");
+    hipLaunchKernelGGL(eb_prepare_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, prepared, C);
+    HESIC_LAUNCH_RETURN("eb_prepare_params");
 }
 
 extern "C" int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
     __shared__ double red[4];
     const int64_t npix = (int64_t)q.B * q.H * q.W;
     double acc = 0.0;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    auto offsets = [&](int64_t p, int64_t& oa, int64_t& ob) {
         int x, y, b;
         if (npix < (1ll << 31)) {
             unsigned r = (unsigned)p;
@@ -211,7 +211,34 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
             x = r % q.W; r /= q.W;
             y = r % q.H; b = (int)(r / q.H);
         }
-        const int64_t oa = b * q.as[0] + y * q.as[2] + x * q.as[3], ob = b * q.bs[0] + y * q.bs[2] + x * q.bs[3];
+        oa = b * q.as[0] + y * q.as[2] + x * q.as[3];
+        ob = b * q.bs[0] + y * q.bs[2] + x * q.bs[3];
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q.C == 3) {
+        // the image case: 4 pixels x 3 channels x 2 operands = 24 independent loads in flight per lane
+        for (; p + 3 * stride < npix; p += 4 * stride) {
+            float va[4][3], vb[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t oa, ob;
+                offsets(p + u * stride, oa, ob);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { va[u][c] = ld_any(q.a, oa + c * q.as[1], q.a_dt); vb[u][c] = ld_any(q.b, ob + c * q.bs[1], q.b_dt); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float part = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const float df = va[u][c] - vb[u][c]; part = fmaf(df, df, part); }
+                acc += (double)part;
+            }
+        }
+    }
+    for (; p < npix; p += stride) {
+        int64_t oa, ob;
+        offsets(p, oa, ob);
         float part = 0.f;
         for (int c = 0; c < q.C; ++c) {
             const float df = ld_any(q.a, oa + c * q.as[1], q.a_dt) - ld_any(q.b, ob + c * q.bs[1], q.b_dt);

@@ -1,7 +1,7 @@
 // warp_perspective: projective bilinear resample with zero padding, the build's replacement for
 // kornia.warp_perspective(src, M, dsize) (third party; call sites ywz/mywork/newnet1.py:746,753,767).
 //
-// One thread per destination pixel: invert M (3x3, fp64 -- it is 40 flops), map (x',y') back to the
+// One thread per destination pixel (grid.y = image): M is inverted once per block (3x3, fp64), (x',y') mapped back to the
 // source, gather the 4 neighbours of every channel.  Neighbouring lanes hit neighbouring source pixels,
 // so the gather is wavefront-coalesced; the kernel moves 2*C*H*W elements and is HBM / latency bound.
 #include "common.h"
@@ -13,18 +13,22 @@ struct WArgs {
     const void* src; const float* M; void* dst; float* dsrc;
 };
 
-__device__ __forceinline__ bool src_coords(const hesic_warp_desc& d, const float* M, int b, int ox, int oy, float& sx, float& sy) {
+// inverse of image b's 3x3 (fp64, adjugate / det) -- once per block, shared through LDS
+__device__ __forceinline__ void invert_h(const float* M, int b, double inv9[9]) {
     const float* m = M + b * 9;
     const double a = m[0], bb = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double A = e * i - f * h, B = -(dd * i - f * g), Cc = dd * h - e * g;
     const double det = a * A + bb * B + c * Cc;
     const double inv = 1.0 / det;
-    // adjugate / det
-    const double i00 = A * inv, i01 = -(bb * i - c * h) * inv, i02 = (bb * f - c * e) * inv;
-    const double i10 = B * inv, i11 = (a * i - c * g) * inv, i12 = -(a * f - c * dd) * inv;
-    const double i20 = Cc * inv, i21 = -(a * h - bb * g) * inv, i22 = (a * e - bb * dd) * inv;
-    const double X = i00 * ox + i01 * oy + i02, Y = i10 * ox + i11 * oy + i12, Z = i20 * ox + i21 * oy + i22;
-    double x = X / Z, y = Y / Z;
+    inv9[0] = A * inv; inv9[1] = -(bb * i - c * h) * inv; inv9[2] = (bb * f - c * e) * inv;
+    inv9[3] = B * inv; inv9[4] = (a * i - c * g) * inv; inv9[5] = -(a * f - c * dd) * inv;
+    inv9[6] = Cc * inv; inv9[7] = -(a * h - bb * g) * inv; inv9[8] = (a * e - bb * dd) * inv;
+}
+
+__device__ __forceinline__ bool src_coords(const hesic_warp_desc& d, const double* iv, int ox, int oy, float& sx, float& sy) {
+    const double X = iv[0] * ox + iv[1] * oy + iv[2], Y = iv[3] * ox + iv[4] * oy + iv[5], Z = iv[6] * ox + iv[7] * oy + iv[8];
+    const double rz = 1.0 / Z;                 // one fp64 division per pixel
+    double x = X * rz, y = Y * rz;
     if (!d.align_corners) {   // kornia <= 0.4: normalised with (W-1), sampled with align_corners=False
         x = x * d.W / (double)(d.W - 1) - 0.5;
         y = y * d.H / (double)(d.H - 1) - 0.5;
@@ -35,11 +39,15 @@ __device__ __forceinline__ bool src_coords(const hesic_warp_desc& d, const float
 
 __global__ void warp_fwd_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
-    const int64_t total = (int64_t)d.B * d.Ho * d.Wo;
+    __shared__ double iv[9];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) invert_h(a.M, b, iv);
+    __syncthreads();
+    const int64_t total = (int64_t)d.Ho * d.Wo;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = i % d.Wo, oy = (i / d.Wo) % d.Ho, b = i / ((int64_t)d.Wo * d.Ho);
+        const int ox = i % d.Wo, oy = i / d.Wo;
         float sx, sy;
-        const bool fin = src_coords(d, a.M, b, ox, oy, sx, sy);
+        const bool fin = src_coords(d, iv, ox, oy, sx, sy);
         const float fx0 = floorf(sx), fy0 = floorf(sy);
         const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
@@ -63,11 +71,15 @@ __global__ void warp_fwd_kernel(const WArgs a) {
 // transpose of the gather: scatter-add of the same four weights into d_src (fp32)
 __global__ void warp_bwd_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
-    const int64_t total = (int64_t)d.B * d.Ho * d.Wo;
+    __shared__ double iv[9];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) invert_h(a.M, b, iv);
+    __syncthreads();
+    const int64_t total = (int64_t)d.Ho * d.Wo;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = i % d.Wo, oy = (i / d.Wo) % d.Ho, b = i / ((int64_t)d.Wo * d.Ho);
+        const int ox = i % d.Wo, oy = i / d.Wo;
         float sx, sy;
-        const bool fin = src_coords(d, a.M, b, ox, oy, sx, sy);
+        const bool fin = src_coords(d, iv, ox, oy, sx, sy);
         const float fx0 = floorf(sx), fy0 = floorf(sy);
         const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
@@ -99,7 +111,7 @@ extern "C" int hesic_warp_perspective_forward(const hesic_warp_desc* d, const vo
     if (int e = check(d, "warp_perspective_forward")) return e;
     HESIC_CHECK_ARG(src && M && dst, "warp_perspective_forward: null pointer");
     WArgs a; a.d = *d; a.src = src; a.M = M; a.dst = dst; a.dsrc = nullptr;
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)d->B * d->Ho * d->Wo, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)d->Ho * d->Wo, 256), d->B), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("warp_perspective_forward");
 }
 
@@ -108,6 +120,6 @@ extern "C" int hesic_warp_perspective_backward(const hesic_warp_desc* d, const v
     if (int e = check(d, "warp_perspective_backward")) return e;
     HESIC_CHECK_ARG(d_dst && M && d_src, "warp_perspective_backward: null pointer");
     WArgs a; a.d = *d; a.src = nullptr; a.M = M; a.dst = (void*)d_dst; a.dsrc = d_src;
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3(grid_for((int64_t)d->B * d->Ho * d->Wo, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(grid_for((int64_t)d->Ho * d->Wo, 256), d->B), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("warp_perspective_backward");
 }

@@ -448,8 +448,11 @@ class PackedEb:
         ps = (*matrices, *biases, *factors, quantiles)
         tag = tuple((p.data_ptr(), p._version) for p in ps) + (_cache_epoch,)
         if self._hit is None or self._hit[0] != tag:
-            self._hit = (tag, eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
-                                             [f.detach() for f in factors], quantiles.detach()))
+            raw = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
+                                 [f.detach() for f in factors], quantiles.detach())
+            ready = torch.empty_like(raw)           # softplus / tanh applied once here, not per thread and launch
+            L.call("hesic_eb_prepare_params", L.ptr(raw), L.ptr(ready), raw.shape[0], L.stream())
+            self._hit = (tag, ready)
         return self._hit[1]
 
 

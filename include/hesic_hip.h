@@ -164,6 +164,9 @@ int hesic_warp_perspective_backward(const hesic_warp_desc* d, const void* d_dst,
 #define HESIC_EB_PARAM_STRIDE 64
 int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,
                      int64_t P, int C, int dtype, void* stream);
+/* Inference cache: apply softplus / tanh to a packed table once ([C][64] -> [C][64], slot 59 marks it); hesic_eb_forward
+ * accepts either form, hesic_eb_backward needs the raw one.                                            */
+int hesic_eb_prepare_params(const float* params, float* prepared, int C, void* stream);
 /* dz (z dtype) and dparams [C][64] fp32 (zero-filled by caller; atomically accumulated).
  * g_lik: fp32 gradient of lik, g_zhat: gradient of z_hat (may be NULL).                              */
 int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
