@@ -93,7 +93,7 @@ def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transpos
     need = _ws_bytes.get(key)
     if need is None:
         need = _ws_bytes[key] = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
-    if need:      # low-resolution layer: split-K launch, fp32 partial tiles in a scratch buffer
+    if need and SPLIT_K:      # low-resolution layer: split-K launch, fp32 partial tiles in a scratch buffer
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.ptr(ws), need, L.stream())
     else:
@@ -102,6 +102,22 @@ def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transpos
 
 
 _ws_bytes = {}
+SPLIT_K = True
+
+
+class no_split_k:
+    """Context manager: run the convs inside with one block per output tile (no split-K).  A split-K launch sums its K
+    slices in a different order than the plain launch, so results depend (in the last bit) on which launch a SHAPE gets;
+    the bit-stream codec, whose decoder re-evaluates the encoder's full-map convolutions one pixel at a time, needs
+    shape-independent numbers."""
+
+    def __enter__(self):
+        global SPLIT_K
+        self._prev, SPLIT_K = SPLIT_K, False
+
+    def __exit__(self, *exc):
+        global SPLIT_K
+        SPLIT_K = self._prev
 
 
 def _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act=0):

@@ -545,6 +545,161 @@ class HSICJoint(StereoCompressionModel):
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
 
+    # ---------------------------------------------------------------------------------------- real bit-stream
+    # compress / decompress of the reference's HESIC+ (ywz/mywork/newnet1_joint.py:793-1079, :1081-1321): same header
+    # file as HESIC, y coded pixel by pixel in raster order (all non-zero channels of a pixel together) under a single
+    # Gaussian whose (scale, mean) come from the hyper-decoder and the masked-conv context of the ALREADY CODED latents.
+    # The encoder knows every latent, so it evaluates the context model for the whole map in one pass; the decoder walks
+    # the map like the reference does (5x5 crop -> masked conv -> 1x1 entropy-parameter net -> tables -> decode -> write
+    # back).  Both run their convs without split-K: the kernels then accumulate every output element in the same order
+    # whatever the map size, which makes the decoder's per-pixel numbers bit-identical to the encoder's (tested).
+    def _params_view(self, which, z_hat):
+        h_s = self.h_s1 if which == 1 else self.h_s2
+        return _seq3(h_s, z_hat)
+
+    def _gauss_full(self, which, params, y_hat, extra=None):
+        ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
+        ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
+        ctx = ctx_m(y_hat)
+        cat = (params, ctx) if extra is None else (params, ctx, extra)
+        return _seq3(ep, torch.cat(cat, 1)).chunk(2, 1)
+
+    def _gauss_pixel(self, which, params, y_pad, h, w, extra=None):
+        """(scales, means) of pixel (h, w) from the 5x5 crop of the padded, partially decoded map (:903-911)."""
+        ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
+        ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
+        crop = y_pad[:, :, h:h + 5, w:w + 5].contiguous(memory_format=torch.channels_last)
+        if not hasattr(ctx_m, "_packer"):
+            ctx_m._packer = Fn.PackedWeight()
+        ctx = Fn.conv2d(crop, ctx_m.weight, ctx_m.bias, kernel_size=5, stride=1, padding=0, mask=ctx_m.mask,
+                        tap_mask=ctx_m._tap_mask, packer=ctx_m._packer)                       # (1, 2M, 1, 1)
+        parts = [params[:, :, h:h + 1, w:w + 1], ctx]
+        if extra is not None:
+            parts.append(extra[:, :, h:h + 1, w:w + 1])
+        return _seq3(ep, torch.cat(parts, 1).contiguous(memory_format=torch.channels_last)).chunk(2, 1)
+
+    @staticmethod
+    def _header_view(y_hat, z_strings):
+        import numpy as np
+        yi = y_hat[0].float()
+        flag = (yi.abs().sum(dim=(1, 2)) > 0).cpu().numpy().astype(np.uint8)
+        minmax = int(max(float(yi.abs().max()), 1.0))
+        if len(z_strings[0]) > 65535 or minmax > 65535:
+            raise ValueError("compress: header fields are uint16 (z string too long or latent range too wide)")
+        head = np.array([len(z_strings[0]), minmax], dtype=np.uint16).tobytes() + np.packbits(flag).tobytes() + z_strings[0]
+        return head, minmax, [int(c) for c in np.nonzero(flag)[0]]
+
+    def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
+        import os
+        import time
+        import numpy as np
+        from ._host import RangeEncoder
+        if x1.shape[0] != 1:
+            raise ValueError("compress codes one stereo pair per call (batch size 1, as the reference)")
+        if self.entropy_bottleneck1._offset.numel() == 0:
+            self.update()
+        size = (x1.shape[-2], x1.shape[-1])
+        start = time.time()
+        with torch.no_grad(), Fn.no_split_k():
+            self.context_prediction1.weight.data *= self.context_prediction1.mask
+            self.context_prediction2.weight.data *= self.context_prediction2.mask
+            y1 = self.encoder1(x1)
+            z1 = _seq3(self.h_a1, y1)
+            z1_strings = self.entropy_bottleneck1.compress(z1)
+            z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(z1.dtype)
+            y1_hat = self.gaussian_conditional1._quantize(y1, "dequantize")
+            sc1, mu1 = self._gauss_full(1, self._params_view(1, z1_hat), y1_hat)
+            x1_hat = self.decoder1(y1_hat)
+            x1_warp = warp_perspective(x1, h_matrix, size)
+            y2 = self.encoder2(x1_warp, x2)
+            z2 = _seq3(self.h_a2, y2)
+            z2_strings = self.entropy_bottleneck2.compress(z2)
+            z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(z2.dtype)
+            x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+            y2_hat = self.gaussian_conditional2._quantize(y2, "dequantize")
+            sc2, mu2 = self._gauss_full(2, self._params_view(2, z2_hat), y2_hat, y1_hat_w)
+            head = bytearray(np.array(x1.shape[2:], dtype=np.uint16).tobytes())
+            enc = RangeEncoder()
+            bound = self.gaussian_conditional1._bound()
+            for y_hat, z_strings, sc, mu in ((y1_hat, z1_strings, sc1, mu1), (y2_hat, z2_strings, sc2, mu2)):
+                hv, minmax, channels = self._header_view(y_hat, z_strings)
+                head += hv
+                if not channels:
+                    continue
+                H, W = y_hat.shape[-2:]
+                rows = max(1, (256 << 20) // (len(channels) * W * (2 * minmax + 2) * 4))
+                for r0 in range(0, H, rows):                     # raster order: row blocks keep the table buffer bounded
+                    r1 = min(H, r0 + rows)
+                    cdf = Fn.gmm_cdf_tables(sc[:, :, r0:r1], mu[:, :, r0:r1], None, channels, minmax, 1, scale_bound=bound)
+                    cdf = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(-1, 2 * minmax + 2)
+                    sym = y_hat[0, channels, r0:r1].float().cpu().numpy().astype(np.int64) + minmax
+                    enc.encode(sym.transpose(1, 2, 0).reshape(-1).astype(np.int32), np.ascontiguousarray(cdf))
+        payload = enc.finish()
+        with open(os.path.join(output_path, str(output_name) + ".npz"), "wb") as f:
+            f.write(bytes(head))
+        with open(os.path.join(output_path, str(output_name) + ".bin"), "wb") as f:
+            f.write(payload)
+        num_pixels = x1.shape[2] * x1.shape[3] * 2
+        return {"bpp_real": (len(head) + len(payload)) * 8 / num_pixels, "bpp_side": len(head) * 8 / num_pixels,
+                "enctime": time.time() - start, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat}
+
+    def decompress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
+        """x1 / x2 are unused (the header carries the size); kept for the reference's signature."""
+        import os
+        import time
+        import numpy as np
+        from ._host import RangeDecoder
+        if self.entropy_bottleneck1._offset.numel() == 0:
+            self.update()
+        dev = h_matrix.device
+        with open(os.path.join(output_path, str(output_name) + ".npz"), "rb") as f:
+            blob = f.read()
+        x_shape = np.frombuffer(blob[:4], dtype=np.uint16).astype(int)
+        pos, views = 4, []
+        for _ in range(2):
+            length, minmax = (int(v) for v in np.frombuffer(blob[pos:pos + 4], dtype=np.uint16))
+            pos += 4
+            flag = np.unpackbits(np.frombuffer(blob[pos:pos + self.M // 8], dtype=np.uint8))
+            pos += self.M // 8
+            views.append((minmax, [int(c) for c in np.nonzero(flag)[0]], blob[pos:pos + length]))
+            pos += length
+        yh, yw = int(x_shape[0]) // 16, int(x_shape[1]) // 16
+        size = (int(x_shape[0]), int(x_shape[1]))
+        with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
+            dec = RangeDecoder(f.read())
+        cdt = Fn.compute_dtype()
+        bound = self.gaussian_conditional1._bound()
+        start = time.time()
+
+        def decode_view(which, params, minmax, channels, extra=None):
+            y_pad = torch.zeros((1, self.M, yh + 4, yw + 4), dtype=cdt, device=dev).contiguous(memory_format=torch.channels_last)
+            if channels:
+                ch_t = torch.as_tensor(channels, device=dev)
+                for h in range(yh):
+                    for w in range(yw):
+                        sc, mu = self._gauss_pixel(which, params, y_pad, h, w, extra)
+                        cdf = Fn.gmm_cdf_tables(sc, mu, None, channels, minmax, 1, scale_bound=bound)
+                        sym = dec.decode(cdf.cpu().numpy().view(np.uint32).reshape(len(channels), -1))
+                        y_pad[0, ch_t, h + 2, w + 2] = torch.from_numpy(sym.astype(np.float32) - minmax).to(dev, cdt)
+            return y_pad[:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
+
+        with torch.no_grad(), Fn.no_split_k():
+            self.context_prediction1.weight.data *= self.context_prediction1.mask
+            self.context_prediction2.weight.data *= self.context_prediction2.mask
+            zs = (yh // 4, yw // 4)
+            z1_hat = self.entropy_bottleneck1.decompress([views[0][2]], zs).to(dev, cdt)
+            z2_hat = self.entropy_bottleneck2.decompress([views[1][2]], zs).to(dev, cdt)
+            y1_hat = decode_view(1, self._params_view(1, z1_hat), views[0][0], views[0][1])
+            x1_hat = self.decoder1(y1_hat)
+            x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+            y2_hat = decode_view(2, self._params_view(2, z2_hat), views[1][0], views[1][1], y1_hat_w)
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,
+                "dectime": time.time() - start}
+
+
 # -------------------------------------------------------------------- enhancement (SURVEY 8f rank 1)
 class Enhancement_Block(nn.Module):
     """Three residual blocks with an outer skip (newnet1.py:272-286)."""

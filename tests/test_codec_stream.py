@@ -152,3 +152,41 @@ def test_gpu_compress_decompress_round_trip(tmp_path, dtype):
         assert len(payload) > 0
     finally:
         hesic_amd.set_compute_dtype(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gpu_joint_compress_decompress_round_trip(tmp_path, dtype):
+    """HESIC+ (newnet1_joint.py:793-1321): the decoder re-derives every pixel's (scale, mean) from the latents decoded so
+    far (5x5 crop -> masked conv -> 1x1 net), the encoder evaluates the same model on the whole map at once -- the
+    stream only decodes if the two agree bit for bit."""
+    import hesic_amd
+    from hesic_amd import models
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(dtype)
+    try:
+        net = models.HSICJoint()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.cuda().eval()
+        net.update(force=True)
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(4, 1, 128, 192))
+        enc = net.compress(x1, x2, Hm, "pair", str(tmp_path))
+        head = (tmp_path / "pair.npz").read_bytes()
+        assert np.frombuffer(head[:4], np.uint16).tolist() == [128, 192]
+        dec = net.decompress(None, None, Hm, "pair", str(tmp_path))
+        assert torch.equal(dec["y1_hat"].float().cpu(), enc["y1_hat"].float().cpu())
+        assert torch.equal(dec["y2_hat"].float().cpu(), enc["y2_hat"].float().cpu())
+        with torch.no_grad(), hesic_amd.functional.no_split_k():
+            fwd = net(x1, x2, Hm)
+        assert torch.equal(fwd["y1_hat"].float().cpu(), enc["y1_hat"].float().cpu())
+        assert torch.equal(dec["x1_hat"].float().cpu(), fwd["x1_hat"].float().cpu())
+        assert torch.equal(dec["x2_hat"].float().cpu(), fwd["x2_hat"].float().cpu())
+        L = fwd["likelihoods"]
+        est = sum(float(-torch.log2(L[k].float().clamp_min(2.0 ** -16)).sum()) for k in ("y1", "y2"))
+        est += sum(float(-torch.log2(L[k].float()).sum()) for k in ("z1", "z2"))
+        est /= 2 * 128 * 192
+        # loose: the forward's likelihood is evaluated at round(y - mu) + mu (GaussianConditional quantises around the mean,
+        # newnet1_joint.py:689-691) while the stream, like the reference's, codes round(y) under the same Gaussian
+        assert abs(enc["bpp_real"] - est) < 0.15 * est + 0.05, (enc["bpp_real"], est)
+    finally:
+        hesic_amd.set_compute_dtype(prev)
