@@ -659,7 +659,7 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float n = nrm[i][j][4 * g + e];
-                        v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? sqrtf(n) : rsqrtf(n));
+                        v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? __builtin_amdgcn_sqrtf(n) : rsqrtf(n));   // n >= beta' > 0: raw v_sqrt_f32 (1 ulp; the output is bf16)
                     }
                     *(u32x2*)(smem + YOFF + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
                         u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};

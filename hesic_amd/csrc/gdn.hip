@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float n = acc[i][4 * g + e] + bv[i][g][e];
-                    o[e] = xv[e] * (inverse ? sqrtf(n) : rsqrtf(n));
+                    o[e] = xv[e] * (inverse ? (sizeof(T) == 2 ? __builtin_amdgcn_sqrtf(n) : sqrtf(n)) : rsqrtf(n));   // bf16 storage: raw v_sqrt_f32
                 }
                 if (p < P) {
                     if constexpr (sizeof(T) == 2) *(u32x2*)(y + p * C + ch) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};

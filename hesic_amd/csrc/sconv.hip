@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float n = nrm[i][4 * g + e] + bb[e];
-                    o[e] = acc[i][4 * g + e] * (inverse ? sqrtf(n) : rsqrtf(n));
+                    o[e] = acc[i][4 * g + e] * (inverse ? __builtin_amdgcn_sqrtf(n) : rsqrtf(n));
                 }
                 *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
             }
