@@ -69,6 +69,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// division of a 31-bit unsigned by a launch-time constant without the ~20-instruction rcp sequence: q = (mulhi(n, magic) + n) >> shift
+struct FastDiv { uint32_t magic, shift; };
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (uint32_t)(((uint64_t)__umulhi(n, d.magic) + n) >> d.shift); }
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    f.shift = sh;
+    f.magic = (uint32_t)((((1ull << sh) - d) << 32) / d + 1);
+    return f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -42,6 +42,7 @@ struct IgemmArgs {
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
     const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
+    FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
 };
@@ -57,10 +58,11 @@ struct Taps {
 __device__ __forceinline__ Taps make_taps(const IgemmArgs& a, int ph) {
     Taps t;
     if (a.transposed) {
-        t.ry = ph / a.stride; t.rx = ph - t.ry * a.stride;
-        t.ky0 = (t.ry + a.pad) % a.stride; t.kx0 = (t.rx + a.pad) % a.stride; t.kst = a.stride;
-        const int nky = (a.KH - t.ky0 + a.stride - 1) / a.stride;
-        t.nkx = (a.KW - t.kx0 + a.stride - 1) / a.stride;
+        const int sh = a.stride >> 1, sm = a.stride - 1;         // stride is 1 or 2 (checked by the launcher): shifts, no division
+        t.ry = ph >> sh; t.rx = ph & sm;
+        t.ky0 = (t.ry + a.pad) & sm; t.kx0 = (t.rx + a.pad) & sm; t.kst = a.stride;
+        const int nky = (a.KH - t.ky0 + sm) >> sh;
+        t.nkx = (a.KW - t.kx0 + sm) >> sh;
         t.ntaps = nky * t.nkx;
     } else {
         t.ry = t.rx = t.ky0 = t.kx0 = 0; t.kst = 1; t.nkx = a.KW; t.ntaps = a.ntaps_live;
@@ -358,20 +360,22 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int nt = bid % a.n_tiles;
-    int rest = bid / a.n_tiles;
-    const int tx = rest % a.tiles_x;
-    rest /= a.tiles_x;
-    const int ty = rest % a.tiles_y;
-    rest /= a.tiles_y;
-    const int b = rest % a.B;
-    rest /= a.B;
-    const int ph = rest % a.nphase;
-    const int kslice = rest / a.nphase;
+    uint32_t rest = fdiv((uint32_t)bid, a.fd_nt);
+    const int nt = bid - (int)rest * a.n_tiles;
+    uint32_t q_ = fdiv(rest, a.fd_tx);
+    const int tx = (int)(rest - q_ * (uint32_t)a.tiles_x);
+    rest = q_; q_ = fdiv(rest, a.fd_ty);
+    const int ty = (int)(rest - q_ * (uint32_t)a.tiles_y);
+    rest = q_; q_ = fdiv(rest, a.fd_b);
+    const int b = (int)(rest - q_ * (uint32_t)a.B);
+    rest = q_; q_ = fdiv(rest, a.fd_ph);
+    const int ph = (int)(rest - q_ * (uint32_t)a.nphase);
+    const int kslice = (int)q_;
     const int n0 = nt * BN;
     const Taps taps = make_taps(a, ph);
     const int kchunks = a.Cin / BK;
-    const int step_lo = kslice * taps.ntaps * kchunks / a.ksplit, step_hi = (kslice + 1) * taps.ntaps * kchunks / a.ksplit;
+    int step_lo = 0, step_hi = taps.ntaps * kchunks;
+    if (a.ksplit > 1) { step_lo = kslice * step_hi / a.ksplit; step_hi = (kslice + 1) * step_hi / a.ksplit; }
     const int nsteps = step_hi - step_lo;
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ wg = (const T*)a.w;
@@ -423,11 +427,11 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
     }
     // tap cursor (all SGPR): input displacement moves by +1 (conv) / -1 (transposed phase) per tap index
     const int dstep = a.transposed ? -1 : 1;
-    const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) / a.stride : -a.pad;
-    const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) / a.stride : -a.pad;
+    const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) >> (a.stride >> 1) : -a.pad;      // exact: multiple of the stride
+    const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) >> (a.stride >> 1) : -a.pad;
     const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
-    const int tap_lo = step_lo / kchunks;
-    int cur_j = tap_lo / taps.nkx, cur_c = tap_lo % taps.nkx, cur_chunk = step_lo % kchunks;
+    int cur_j = 0, cur_c = 0, cur_chunk = 0;
+    if (step_lo) { const int tap_lo = step_lo / kchunks; cur_j = tap_lo / taps.nkx; cur_c = tap_lo % taps.nkx; cur_chunk = step_lo % kchunks; }
     int dy = dy_base + dstep * cur_j, dx = dx_base + dstep * cur_c;
     uint32_t s_x = 0, s_w = 0;
     auto set_tap = [&]() {
@@ -933,6 +937,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (d->Cin % 64 == 0 ? 64 : 32) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
+    a.fd_nt = make_fastdiv((uint32_t)a.n_tiles); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
+    a.fd_b = make_fastdiv((uint32_t)a.B); a.fd_ph = make_fastdiv((uint32_t)a.nphase);
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \

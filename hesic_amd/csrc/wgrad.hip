@@ -235,9 +235,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-struct FastDiv { uint32_t magic, shift; };
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (uint32_t)(((uint64_t)__umulhi(n, d.magic) + n) >> d.shift); }
-
 struct WgTrArgs {
     WgArgs w;
     FastDiv dqw, dqh;
@@ -951,15 +948,6 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             }
         }
     }
-}
-
-FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    uint32_t sh = 0;
-    while ((1ull << sh) < d) ++sh;
-    f.shift = sh;
-    f.magic = (uint32_t)((((1ull << sh) - d) << 32) / d + 1);
-    return f;
 }
 
 void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
