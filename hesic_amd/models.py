@@ -765,6 +765,43 @@ def pad_to_multiple(x, multiple=64):
     return x if ph == 0 and pw == 0 else torch.nn.functional.pad(x, (0, pw, 0, ph))
 
 
+class GraphedForward:
+    """The eval forward (+ the bits / squared-error reductions) captured once into a HIP graph and replayed.
+
+    The whole path is capturable: every launch goes to the current stream, the side streams of the multi-stream schedule
+    fork from / join to the capture stream, nothing reads back to the host (the scale bound is cached on the host side) and
+    all scratch comes from the caching allocator.  Replay removes the per-launch host work (~95 launches per forward); on
+    a host that already keeps the GPU fed it changes nothing (2.57 vs 2.58 ms at B=8, 512x512), on a slower or busier
+    host it is the difference between a launch-bound and a GPU-bound step.  Inputs are copied into static buffers; the
+    returned tensors are the graph's static outputs (overwritten by the next call)."""
+
+    def __init__(self, net, x1, x2, h_matrix, with_metrics=True, warmup=3):
+        if net.training:
+            raise RuntimeError("GraphedForward captures the inference schedule: call net.eval() first")
+        self.net, self.with_metrics = net, with_metrics
+        self.x1, self.x2, self.h = x1.clone(), x2.clone(), h_matrix.clone()
+        side = torch.cuda.Stream(device=x1.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):      # warm-up off the default stream: packs weights, fills caches
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = self._run()
+
+    def _run(self):
+        out = self.net(self.x1, self.x2, self.h)
+        return (out, rate_distortion(out, self.x1, self.x2)) if self.with_metrics else (out, None)
+
+    def __call__(self, x1=None, x2=None, h_matrix=None):
+        for dst, src in ((self.x1, x1), (self.x2, x2), (self.h, h_matrix)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        return self.out
+
+
 def rate_distortion(out, x1, x2):
     """bits / squared error of one forward as fp64 device scalars (HIP reductions, no host sync):
     returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""

@@ -191,3 +191,31 @@ def test_stream_overlap_and_fusion_do_not_change_results():
         assert abs(m_f["bpp"] - m_u["bpp"]) < 2e-2 * m_u["bpp"] and abs(m_f["psnr"] - m_u["psnr"]) < 5e-2
     finally:
         models.OVERLAP_STREAMS, Fn.FUSE_CONV_GDN = keep
+
+
+def test_graphed_forward_replays_the_eager_result():
+    """HIP-graph capture of the whole eval forward (side streams included) + reductions: replay == eager, bit for bit, also
+    for new inputs copied into the static buffers."""
+    import hesic_amd
+    from hesic_amd import models
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        net = models.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.cuda().eval()
+        a = [t.cuda() for t in synthetic.stereo_batch(0, 2, 128, 128)]
+        b = [t.cuda() for t in synthetic.stereo_batch(7, 2, 128, 128)]
+        g = models.GraphedForward(net, *a)
+        for inp in (a, b, a):
+            with torch.no_grad():
+                want = net(*inp)
+                want_rd = models.rate_distortion(want, inp[0], inp[1])
+            got, got_rd = g(*inp)
+            for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+                assert torch.equal(got[k], want[k]), k
+            for k in want["likelihoods"]:
+                assert torch.equal(got["likelihoods"][k], want["likelihoods"][k]), k
+            assert abs(models.metrics_from(got_rd)["bpp"] - models.metrics_from(want_rd)["bpp"]) < 1e-9     # fp64 atomics: order-free to ~1e-16
+    finally:
+        hesic_amd.set_compute_dtype(prev)
