@@ -338,8 +338,8 @@ class _GdnFn(torch.autograd.Function):
         P = B * H * W
         gy = _nhwc(gy.to(x.dtype))
         dx = torch.empty_like(x, memory_format=_CL)
-        dbeta = torch.zeros_like(beta, dtype=torch.float32)
-        dgamma = torch.zeros_like(gamma, dtype=torch.float32)
+        dbeta = torch.empty_like(beta, dtype=torch.float32)          # fully written by the kernel's chain-rule pass
+        dgamma = torch.empty_like(gamma, dtype=torch.float32)
         ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=x.device)
         L.call("hesic_gdn_backward", L.ptr(x), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
                L.ptr(dx), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cc, int(ctx.inverse), float(ctx.beta_min),
