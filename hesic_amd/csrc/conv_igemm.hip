@@ -43,6 +43,7 @@ struct IgemmArgs {
     const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
     FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
+    int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
 };
@@ -332,19 +333,22 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // staged output tile is squared and sent through a second 128x128 MFMA contraction before it is written, so the
 // activation never makes the HBM round trip between conv and (I)GDN (compressai/layers/gdn.py:55-70).
 // two blocks per CU (2 waves per SIMD, <= 256 VGPRs) whenever the ring leaves LDS for two
-constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns) { return ns * (bm + bn) * bk * 2 > 80 * 1024 ? 1 : 2; }
+constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { return (ns * (bm + bn) * bk * 2 > 80 * 1024 ? 1 : 2) * nw / 4; }
 
-template <int BMP, int BN, int BK, int NS, int GDN = 0>
-__global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void igemm_glds_kernel(const IgemmArgs a) {
+// NW = waves per block: 4 (2x2 wave grid, 64x64 wave tiles) or 8 (4x2, 32 couts x 64 pixels: twice the waves per SIMD to
+// cover barrier / DMA waits, 1.5 instead of 1 fragment read per MFMA)
+template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
+    constexpr int NTHREADS = NW * 64;
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
     constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row
     constexpr int RPB = 256 / (BK * 2);       // rows per 256-byte bank row
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
-    constexpr int XI = BM * CPR / 64 / 4;     // x-tile DMA instructions per wave per step
-    constexpr int WI = BN * CPR / 64 / 4;
+    constexpr int XI = BM * CPR / 64 / NW;    // x-tile DMA instructions per wave per step
+    constexpr int WI = BN * CPR / 64 / NW;
     static_assert(XI >= 1 && WI >= 1, "tile too small");
-    constexpr int WN = BM >= 64 ? 2 : 1, WM = 4 / WN;     // wave grid: WM cout slices x WN pixel slices
+    constexpr int WN = BM >= 64 ? 2 : 1, WM = NW / WN;    // wave grid: WM cout slices x WN pixel slices
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
@@ -360,16 +364,18 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // order: cout tile, output phase, tile x, tile y, image, K slice -- the phases of a transposed conv read the same input
+    // tile, so they are neighbours in the launch order (same XCD, same time) and the tile leaves HBM once, not once per phase
     uint32_t rest = fdiv((uint32_t)bid, a.fd_nt);
     const int nt = bid - (int)rest * a.n_tiles;
-    uint32_t q_ = fdiv(rest, a.fd_tx);
+    uint32_t q_ = fdiv(rest, a.fd_ph);
+    const int ph = (int)(rest - q_ * (uint32_t)a.nphase);
+    rest = q_; q_ = fdiv(rest, a.fd_tx);
     const int tx = (int)(rest - q_ * (uint32_t)a.tiles_x);
     rest = q_; q_ = fdiv(rest, a.fd_ty);
     const int ty = (int)(rest - q_ * (uint32_t)a.tiles_y);
     rest = q_; q_ = fdiv(rest, a.fd_b);
     const int b = (int)(rest - q_ * (uint32_t)a.B);
-    rest = q_; q_ = fdiv(rest, a.fd_ph);
-    const int ph = (int)(rest - q_ * (uint32_t)a.nphase);
     const int kslice = (int)q_;
     const int n0 = nt * BN;
     const Taps taps = make_taps(a, ph);
@@ -430,13 +436,22 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
     const int dy_base = a.transposed ? (taps.ry + a.pad - taps.ky0) >> (a.stride >> 1) : -a.pad;      // exact: multiple of the stride
     const int dx_base = a.transposed ? (taps.rx + a.pad - taps.kx0) >> (a.stride >> 1) : -a.pad;
     const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
+    // Tap order.  A stride-2 conv reads input pixel (2q + k): taps of equal (ky & 1, kx & 1) touch the SAME quarter of the
+    // input pixels (shifted by whole output pixels), the other three parities touch disjoint quarters.  Walking the taps
+    // in raster order therefore cycles the whole input footprint of the co-resident blocks (~9 MB per XCD on the big
+    // layers) through the 4 MB L2 several times (measured: 511 MB fetched for 134 MB of input); walking them parity class
+    // by parity class -- (0,0): 9 taps, (0,1): 6, (1,0): 6, (1,1): 4 -- keeps one 2 MB quarter resident at a time.
+    const bool par = a.tap_parity != 0;
+    int kst_e = par ? 2 : taps.kst, ky0_e = taps.ky0, kx0_e = taps.kx0, cls = 0;
+    int nkx_e = par ? (a.KW + 1) >> 1 : taps.nkx, nky_e = par ? (a.KH + 1) >> 1 : 0x7fffffff;
     int cur_j = 0, cur_c = 0, cur_chunk = 0;
     if (step_lo) { const int tap_lo = step_lo / kchunks; cur_j = tap_lo / taps.nkx; cur_c = tap_lo % taps.nkx; cur_chunk = step_lo % kchunks; }
     int dy = dy_base + dstep * cur_j, dx = dx_base + dstep * cur_c;
+    int dx_row = dx_base;                                 // dx at the start of a tap row of the current class
     uint32_t s_x = 0, s_w = 0;
     auto set_tap = [&]() {
         s_x = (uint32_t)(((dy * a.W + dx) * a.x_ps + neg) * 2);
-        s_w = (uint32_t)((taps.ky0 + cur_j * taps.kst) * a.KW + taps.kx0 + cur_c * taps.kst) * wtap;
+        s_w = (uint32_t)((ky0_e + cur_j * kst_e) * a.KW + kx0_e + cur_c * kst_e) * wtap;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
@@ -444,6 +459,19 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
         }
     };
     set_tap();
+    auto next_tap = [&]() {
+        dx += dstep * (par ? 2 : 1);
+        if (++cur_c == nkx_e) {
+            cur_c = 0; dx = dx_row; ++cur_j; dy += dstep * (par ? 2 : 1);
+            if (cur_j == nky_e) {                         // parity walk only: next class
+                ++cls;
+                ky0_e = cls >> 1; kx0_e = cls & 1;
+                nkx_e = (a.KW - kx0_e + 1) >> 1; nky_e = (a.KH - ky0_e + 1) >> 1;
+                cur_j = 0; dy = ky0_e - a.pad; dx_row = kx0_e - a.pad; dx = dx_row;
+            }
+        }
+        set_tap();
+    };
     auto issue = [&](int buf) {
         const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
         unsigned char* xs = smem + buf * STAGE;
@@ -458,9 +486,7 @@ __global__ __launch_bounds__(NTHREADS, igemm_waves_per_eu(BMP, BN, BK, NS)) void
                                                      16, (int)wv[i], (int)sw, 0, 0);
         if (++cur_chunk == kchunks) {
             cur_chunk = 0;
-            dx += dstep;
-            if (++cur_c == taps.nkx) { cur_c = 0; dx = dx_base; ++cur_j; dy += dstep; }
-            set_tap();
+            next_tap();
         }
     };
 
@@ -937,6 +963,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (d->Cin % 64 == 0 ? 64 : 32) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
+    a.tap_parity = (!d->transposed && s == 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
     a.fd_nt = make_fastdiv((uint32_t)a.n_tiles); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     a.fd_b = make_fastdiv((uint32_t)a.B); a.fd_ph = make_fastdiv((uint32_t)a.nphase);
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
@@ -946,6 +973,13 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);       \
         else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
+    } while (0)
+#define LAUNCH_GLDS8(M_, N_, K_, S_)                                                                         \
+    do {                                                                                                    \
+        const dim3 block8(512);                                                                             \
+        if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1, 8>), grid, block8, 0, st, a);       \
+        else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2, 8>), grid, block8, 0, st, a);  \
+        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 8>), grid, block8, 0, st, a);                  \
     } while (0)
 #define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
     do {                                                             \
@@ -966,7 +1000,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
         if (bm == 128) {
-            if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
+            static const bool w8 = getenv("HESIC_IGEMM_W8") != nullptr;      // experiment: 8-wave blocks
+            if (bk == 64) { if (BN == 128) { if (w8) LAUNCH_GLDS8(128, 128, 64, 2); else LAUNCH_GLDS(128, 128, 64, 2); } else LAUNCH_GLDS_NS(128, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }
         } else if (bm == 64) {
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
