@@ -335,8 +335,9 @@ __device__ __forceinline__ void wait_dma_groups(int k) {
 // two blocks per CU (2 waves per SIMD, <= 256 VGPRs) whenever the ring leaves LDS for two
 constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { return (ns * (bm + bn) * bk * 2 > 80 * 1024 ? 1 : 2) * nw / 4; }
 
-// NW = waves per block: 4 (2x2 wave grid, 64x64 wave tiles) or 8 (4x2, 32 couts x 64 pixels: twice the waves per SIMD to
-// cover barrier / DMA waits, 1.5 instead of 1 fragment read per MFMA)
+// NW = waves per block: 4 (2x2 wave grid, 64x64 wave tiles).  NW = 8 (4x2 grid, 32 couts x 64 pixels per wave: twice the
+// waves per SIMD, 1.5 fragment reads per MFMA) compiles and is correct but measured EQUAL on every layer (the loop is not
+// limited by per-wave latency), so only NW = 4 is instantiated.
 template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
     constexpr int NTHREADS = NW * 64;
@@ -974,13 +975,6 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
     } while (0)
-#define LAUNCH_GLDS8(M_, N_, K_, S_)                                                                         \
-    do {                                                                                                    \
-        const dim3 block8(512);                                                                             \
-        if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1, 8>), grid, block8, 0, st, a);       \
-        else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2, 8>), grid, block8, 0, st, a);  \
-        else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 8>), grid, block8, 0, st, a);                  \
-    } while (0)
 #define LAUNCH_GLDS_NS(M_, N_, K_)                                   \
     do {                                                             \
         if (deep) LAUNCH_GLDS(M_, N_, K_, 4);                        \
@@ -1000,8 +994,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
         if (bm == 128) {
-            static const bool w8 = getenv("HESIC_IGEMM_W8") != nullptr;      // experiment: 8-wave blocks
-            if (bk == 64) { if (BN == 128) { if (w8) LAUNCH_GLDS8(128, 128, 64, 2); else LAUNCH_GLDS(128, 128, 64, 2); } else LAUNCH_GLDS_NS(128, 64, 64); }
+            if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }
         } else if (bm == 64) {
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
