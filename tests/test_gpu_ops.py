@@ -44,6 +44,8 @@ CONV_CASES = [
     ("c3s1_288_384", 288, 384, 3, 1, 0, (1, 8, 8)),
     ("c1_768_640", 768, 640, 1, 1, 0, (2, 4, 4)),
     ("c5s2_tiny", 128, 128, 5, 2, 0, (2, 2, 2)),
+    ("c5s2_parity_walk", 128, 128, 5, 2, 0, (4, 64, 48)),      # big enough for the plain launch: taps walked by parity class
+    ("c3s2_parity_walk", 64, 128, 3, 2, 0, (4, 64, 64)),
     ("c5s2_64_72", 64, 72, 5, 2, 0, (1, 10, 6)),
     ("d5s2_128", 128, 128, 5, 2, 1, (2, 16, 16)),
     ("d5s2_192_128", 192, 128, 5, 2, 1, (1, 4, 4)),
