@@ -81,6 +81,14 @@ static inline FastDiv make_fastdiv(uint32_t d) {
     return f;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (hardware block id & 7 = XCD), each with its own L2.  This maps the
+// hardware id to a logical id such that every XCD owns one CONTIGUOUS range of logical ids: neighbouring tiles (shared
+// halos, shared weights) then meet in the same L2 instead of being fetched once per XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
     __syncthreads();
     const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 1) / 2;       // wave tile = 2 output rows x 16 columns
     const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
-    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);                    // neighbouring tiles (shared input rows) on one XCD
+    for (int64_t tile = (int64_t)lb * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
         const int oy = ty * 2 + (frow >> 4), ox = tx * 16 + (frow & 15);
         const bool pok = oy < a.Ho && ox < a.Wo;
@@ -512,9 +513,10 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) raws[ks] = ok ? *(const u32x4*)(xp + ks * 16) : u32x4{0, 0, 0, 0};
     };
-    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);                    // neighbouring patches share their 1-pixel halo in one L2
+    if (lb < ntiles) fetch(lb);
     __syncthreads();
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = lb; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
         f32x16 acc[NT];
 #pragma unroll
@@ -592,7 +594,8 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
         wl[i] = co < COUT ? w_at(a.w, co, ci, ky, kx, COUT, CIN, K, K, a.transposed) : 0.f;
     }
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = lb % tiles_x, ty = (lb / tiles_x) % tiles_y, b = lb / (tiles_x * tiles_y);
     const int y0 = ty * TH - PAD, x0 = tx * TW - PAD;
     for (int i = tid; i < CIN * PH * PW; i += 256) {
         const int px = i % PW, py = (i / PW) % PH, ci = i / (PW * PH);
@@ -660,7 +663,8 @@ __global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
         wl[i] = co < COUT ? w_at(a.w, co, ci, ky, kx, COUT, CIN, K, K, a.transposed) : 0.f;
     }
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = lb % tiles_x, ty = (lb / tiles_x) % tiles_y, b = lb / (tiles_x * tiles_y);
     const int y0 = ty * TH - PAD, x0 = tx * TW - PAD;
     for (int half = 0; half < 2; ++half) {
         const int c_lo = half ? a.c_split : 0, c_hi = half ? CIN : a.c_split;

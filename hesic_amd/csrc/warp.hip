@@ -44,7 +44,7 @@ __global__ void warp_fwd_kernel(const WArgs a) {
     if (threadIdx.x == 0) invert_h(a.M, b, iv);
     __syncthreads();
     const int64_t total = (int64_t)d.Ho * d.Wo;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = xcd_remap(blockIdx.x, gridDim.x) * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ox = i % d.Wo, oy = i / d.Wo;
         float sx, sy;
         const bool fin = src_coords(d, iv, ox, oy, sx, sy);
@@ -76,7 +76,7 @@ __global__ void warp_bwd_kernel(const WArgs a) {
     if (threadIdx.x == 0) invert_h(a.M, b, iv);
     __syncthreads();
     const int64_t total = (int64_t)d.Ho * d.Wo;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = xcd_remap(blockIdx.x, gridDim.x) * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ox = i % d.Wo, oy = i / d.Wo;
         float sx, sy;
         const bool fin = src_coords(d, iv, ox, oy, sx, sy);
