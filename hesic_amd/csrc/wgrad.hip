@@ -245,11 +245,13 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     constexpr int BK = 64, TILE = BK * 256, STAGE = 2 * TILE;       // 64 pixels x 128 channels x 2 B per operand
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    const int split = bid % a.nsplit; bid /= a.nsplit;
+    // logical block order: tap fastest, then channel tiles, K slice (pixel range) slowest, on XCD-contiguous ids -- the
+    // 25 tap blocks of a pixel range read the same dY rows and overlapping X rows, so they should meet in one L2
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tapi = bid % a.ntaps; bid /= a.ntaps;
     const int cit = bid % a.ci_tiles; bid /= a.ci_tiles;
     const int cot = bid % a.co_tiles; bid /= a.co_tiles;
-    const int tapi = bid;
+    const int split = bid;
     const int tap = a.tap_id[0] + tapi;          // live taps are a raster-order prefix (checked by the launcher)
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
     const int sh_y = ky - a.pad, sh_x = kx - a.pad;
