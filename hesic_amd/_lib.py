@@ -63,6 +63,7 @@ _SIGS = {
     "hesic_conv2d_forward_ws": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp], _i32),
     "hesic_gdn_pack_params": ([_vp, _vp, _f32, _vp, _vp, _i32, _vp], _i32),
     "hesic_conv2d_gdn_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
+    "hesic_conv2d_gdn_forward_train": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
     "hesic_conv2d_variant": ([_P(ConvDesc), _P(_i32)], _i32),
     "hesic_conv2d_wgrad_ws_bytes": ([_P(ConvDesc)], _i64),
     "hesic_conv2d_wgrad": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i32),

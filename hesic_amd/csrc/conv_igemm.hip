@@ -42,6 +42,7 @@ struct IgemmArgs {
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
     const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
+    void* y_pre;               // fused GDN, training: also store the conv output v = conv + bias (bf16, y's geometry) for GDN's backward
     FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
@@ -698,17 +699,38 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
             }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         constexpr int TOT = BM * 16;
-        T* __restrict__ yg = (T*)a.y;
         const int oyo = taps.ry, oxo = taps.rx;
+        auto store_tile = [&](T* __restrict__ dstp, int lds_off) {
 #pragma unroll
-        for (int c = tid; c < TOT; c += NTHREADS) {
-            const int pr = c >> 4, cc = c & 15;
-            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
-            if (qy < a.QH && qx < a.QW) {
-                const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
-                const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + cc * 8;
-                *(u32x4*)(yg + o) = *(const u32x4*)(smem + YOFF + pr * 256 + ((cc ^ (pr & 15)) << 4));
+            for (int c = tid; c < TOT; c += NTHREADS) {
+                const int pr = c >> 4, cc = c & 15;
+                const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+                if (qy < a.QH && qx < a.QW) {
+                    const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
+                    const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + cc * 8;
+                    *(u32x4*)(dstp + o) = *(const u32x4*)(smem + lds_off + pr * 256 + ((cc ^ (pr & 15)) << 4));
+                }
             }
+        };
+        if (a.y_pre) {
+            // training: the squared tile is dead (every wave is past its GDN MFMAs), so v goes out through its place
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int pr = wn * (BM / WN) + j * 32 + frow;
+                        *(u32x2*)(smem + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
+                            u32x2{pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                    }
+                }
+        }
+        store_tile((T*)a.y, YOFF);
+        if (a.y_pre) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            store_tile((T*)a.y_pre, 0);
         }
     }
 }
@@ -825,6 +847,7 @@ static thread_local int* g_plan_out = nullptr;
 static thread_local const void* g_gdn_gamma = nullptr;   // set by hesic_conv2d_gdn_forward around its call to the launcher
 static thread_local const float* g_gdn_beta = nullptr;
 static thread_local int g_gdn_mode = 0;
+static thread_local void* g_y_pre = nullptr;              // set by hesic_conv2d_gdn_forward_train
 static thread_local float* g_ws = nullptr;               // set by hesic_conv2d_forward_ws: split-K workspace
 static thread_local size_t g_ws_bytes = 0;
 static thread_local size_t* g_ws_need = nullptr;         // set by hesic_conv2d_ws_bytes: only report the workspace size
@@ -860,6 +883,16 @@ extern "C" int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x,
     return rc;
 }
 
+extern "C" int hesic_conv2d_gdn_forward_train(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                              const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                              void* stream) {
+    HESIC_CHECK_ARG(y_pre, "conv2d_gdn_forward_train: null pointer");
+    g_y_pre = y_pre;
+    const int rc = hesic_conv2d_gdn_forward(d, x, w_packed, bias, gamma_packed, beta_packed, inverse, y, stream);
+    g_y_pre = nullptr;
+    return rc;
+}
+
 extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                     void* y, void* stream) {
     HESIC_CHECK_ARG(d && x && w_packed && y, "conv2d_forward: null pointer");
@@ -877,7 +910,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
-    a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta;
+    a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;

@@ -136,6 +136,38 @@ def _out_hw(H, W, k, stride, pad, transposed):
     return f(H), f(W)
 
 
+def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
+    """dx / dw / dbias of a wide conv (implicit-GEMM kernels): shared by _ConvFn and _ConvGdnFn."""
+    k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
+    B, H, W, Cin, Ho, Wo, Cout = dims
+    dx = dw = db = None
+    gy = _nhwc(gy.to(x.dtype))
+    if need_dx:
+        # data gradient = the opposite op with the same weight tensor read in the other layout
+        if Cout % 32 == 0 and Cin % 8 == 0:
+            wp = packer.get(weight, mask, Cin, Cout, k, k, not transposed, False, x.dtype)
+            dx = _wide_conv(gy, wp, None, B, Ho, Wo, Cout, H, W, Cin, k, stride, pad, not transposed)
+        else:   # odd channel counts (parity tests only): strided VALU kernel
+            w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
+            dx = torch.empty_like(x, memory_format=_CL)
+            d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
+            L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
+        if in_abs:
+            dx = dx * torch.sign(x)
+    if need_dw:
+        dwp = torch.empty(k * k * Cout * Cin, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+        d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, in_abs,
+                       x.shape[1], 0, gy.shape[1], 0, tap_mask)
+        nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+        L.call("hesic_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dwp), L.ptr(db), L.ptr(ws), nws, L.stream())
+        dw = torch.empty_like(weight, dtype=torch.float32)
+        L.call("hesic_unpack_conv_wgrad", L.ptr(dwp), L.ptr(mask), L.ptr(dw), Cout, Cin, k, k, int(transposed),
+               L.stream())
+    return dx, dw, db
+
+
 class _ConvFn(torch.autograd.Function):
     """conv()/deconv() of compressai/models/utils.py:104-118 (+ MaskedConv2d, layers.py:21-45)."""
 
@@ -202,30 +234,7 @@ class _ConvFn(torch.autograd.Function):
                 if mask is not None:
                     dw = dw * mask
         else:
-            gy = _nhwc(gy.to(x.dtype))
-            if ctx.needs_input_grad[0]:
-                # data gradient = the opposite op with the same weight tensor read in the other layout
-                if Cout % 32 == 0 and Cin % 8 == 0:
-                    wp = packer.get(weight, mask, Cin, Cout, k, k, not transposed, False, x.dtype)
-                    dx = _wide_conv(gy, wp, None, B, Ho, Wo, Cout, H, W, Cin, k, stride, pad, not transposed)
-                else:   # odd channel counts (parity tests only): strided VALU kernel
-                    w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
-                    dx = torch.empty_like(x, memory_format=_CL)
-                    d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
-                    L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
-                if in_abs:
-                    dx = dx * torch.sign(x)
-            if ctx.needs_input_grad[1]:
-                dwp = torch.empty(k * k * Cout * Cin, dtype=torch.float32, device=x.device)
-                db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, in_abs,
-                               x.shape[1], 0, gy.shape[1], 0, tap_mask)
-                nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
-                ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
-                L.call("hesic_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dwp), L.ptr(db), L.ptr(ws), nws, L.stream())
-                dw = torch.empty_like(weight, dtype=torch.float32)
-                L.call("hesic_unpack_conv_wgrad", L.ptr(dwp), L.ptr(mask), L.ptr(dw), Cout, Cin, k, k, int(transposed),
-                       L.stream())
+            dx, dw, db = _wide_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if not ctx.has_bias:
             db = None
         return dx, dw, db, None
@@ -243,7 +252,7 @@ class PackedGdn:
 
     def get(self, beta, gamma, beta_min):
         tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
-        if self._hit is not None and self._hit[0] == tag:
+        if self._hit is not None and self._hit[0] == tag and not torch.is_grad_enabled():
             return self._hit[1], self._hit[2]
         gp = torch.empty(2 * 128 * 128, dtype=torch.bfloat16, device=gamma.device)
         bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
@@ -253,15 +262,63 @@ class PackedGdn:
         return gp, bp
 
 
+FUSE_CONV_GDN_TRAIN = _os.environ.get("HESIC_NO_FUSE_TRAIN") is None      # A/B switch for profiling
+
+
 def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
-    """The fused epilogue exists for inference with bf16 storage, 128 output channels and a wide input."""
+    """The fused epilogue exists for bf16 storage, 128 output channels and a wide input; with autograd on, the wide
+    stages keep the fusion through ``_ConvGdnFn`` (the kernel then also stores the conv output for GDN's backward), the
+    image-side 3 -> 128 stage is fused at inference only."""
     cout = weight.shape[1] if transposed else weight.shape[0]
     cin = weight.shape[0] if transposed else weight.shape[1]
-    if torch.is_grad_enabled() or not x.is_cuda or cout != 128 or gdn_channels != 128 or not FUSE_CONV_GDN:
+    if not x.is_cuda or cout != 128 or gdn_channels != 128 or not FUSE_CONV_GDN:
         return False
     if cin == 3:      # g_a_conv1 + g_a_gdn1: image in (any float dtype), bf16 storage out
-        return (not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5 and x.dtype in (torch.float32, torch.bfloat16))
+        return (not torch.is_grad_enabled() and not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5
+                and x.dtype in (torch.float32, torch.bfloat16))
+    if torch.is_grad_enabled() and not FUSE_CONV_GDN_TRAIN:
+        return False
     return x.dtype == torch.bfloat16 and cin % 32 == 0
+
+
+class _ConvGdnFn(torch.autograd.Function):
+    """(I)GDN(conv(x)) with the fused forward kernel kept under autograd: the kernel stores the conv output v next to y,
+    the backward is GDN's backward on (v, gy) followed by the conv's data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, beta, gamma, cfg):
+        k, stride, pad, transposed, inverse, beta_min, packer, gdn_packer = cfg
+        Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+        B, _, H, W = x.shape
+        Ho, Wo = _out_hw(H, W, k, stride, pad, transposed)
+        x = _nhwc(x)
+        wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
+        gp, bp = gdn_packer.get(beta, gamma, beta_min)
+        y = _empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+        v = _empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+        d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, 0, Cin, 0, Cout, 0, 0)
+        L.call("hesic_conv2d_gdn_forward_train", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse),
+               L.ptr(y), L.ptr(v), L.stream())
+        ctx.save_for_backward(x, weight, v, beta, gamma)
+        ctx.cfg, ctx.dims, ctx.has_bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, v, beta, gamma = ctx.saved_tensors
+        k, stride, pad, transposed, inverse, beta_min, packer, _ = ctx.cfg
+        B, H, W, Cin, Ho, Wo, Cout = ctx.dims
+        P = B * Ho * Wo
+        gy = _nhwc(gy.to(v.dtype))
+        gv = torch.empty_like(v, memory_format=_CL)
+        dbeta = torch.empty_like(beta, dtype=torch.float32)
+        dgamma = torch.empty_like(gamma, dtype=torch.float32)
+        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cout)), dtype=torch.uint8, device=x.device)
+        L.call("hesic_gdn_backward", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
+               L.ptr(gv), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cout, int(inverse), float(beta_min), L.dt(v), L.stream())
+        ccfg = (k, stride, pad, transposed, 0, 0, 0, packer, None)
+        dx, dw, db = _wide_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, (db if ctx.has_bias else None), dbeta, dgamma, None
 
 
 def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, transposed, inverse, beta_min, packer, gdn_packer):
@@ -278,6 +335,8 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
         L.call("hesic_sconv2d_gdn_forward", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
                L.ptr(bp), int(inverse), L.ptr(out), L.stream())
         return out
+    if torch.is_grad_enabled():
+        return _ConvGdnFn.apply(x, weight, bias, beta, gamma, (k, stride, padding, transposed, inverse, beta_min, packer, gdn_packer))
     x = _nhwc(x)
     wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
     gp, bp = gdn_packer.get(beta, gamma, beta_min)

@@ -70,6 +70,11 @@ int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min,
                           int C, void* stream);
 int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
+/* Training form: additionally stores the conv output (conv + bias, bf16, same geometry as y) that GDN's backward needs
+ * (hesic_gdn_backward takes it as x), so the forward of a training step keeps the fusion too.                          */
+int hesic_conv2d_gdn_forward_train(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                   const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                   void* stream);
 
 /* Same op with a caller-provided scratch buffer.  Low-resolution layers (the hyper path's 8x8 .. 32x32 maps,
  * newnet1.py:420-577) have too few pixels to fill the GPU with one block per output tile; given `ws` of at least

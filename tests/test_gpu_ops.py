@@ -441,6 +441,48 @@ def test_fused_conv_gdn_matches_the_two_ops(tr, inv):
     assert rel_err(one, two) < 1.5e-2
 
 
+@pytest.mark.parametrize("tr,inv", [(0, False), (1, True)], ids=["conv+gdn", "deconv+igdn"])
+def test_fused_conv_gdn_under_autograd_matches_the_two_ops(tr, inv):
+    """With autograd on the fused kernel also stores the conv output; its backward (GDN backward on that tensor, then the
+    conv gradients) must agree with differentiating the two separate ops, and with the fp32 oracle."""
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=9)
+    Cin = 192 if tr else 128
+    w = bf(rnd("fa_w", (Cin, 128, 5, 5) if tr else (128, Cin, 5, 5)) * (0.06 if tr else 0.03))
+    b = rnd("fa_bb", (128,), -0.1, 0.1)
+    x = bf(rnd("fa_xx", (2, Cin, 12, 20) if tr else (2, Cin, 40, 24), -2, 2))
+    args = dict(kernel_size=5, stride=2, padding=2, transposed=bool(tr))
+
+    def leaves(dev, dt=None):
+        ts = [x.clone(), w.clone(), b.clone(), sd["g.beta"].clone(), sd["g.gamma"].clone()]
+        ts = [t.to(dev) for t in ts]
+        if dt is not None:
+            ts[0] = ts[0].to(dt).contiguous(memory_format=torch.channels_last)
+        return [t.requires_grad_() for t in ts]
+
+    ro = leaves("cpu")
+    yo = O.gdn((O.deconv if tr else O.conv)(ro[0], ro[1], ro[2], 2), ro[3], ro[4], inv)
+    gy = bf(rnd("fa_gy", yo.shape))
+    yo.backward(gy)
+    outs = []
+    for fused in (True, False):
+        t = leaves(DEV, torch.bfloat16)
+        if fused:
+            y = Fn.conv2d_gdn(t[0], t[1], t[2], t[3], t[4], inverse=inv, beta_min=1e-6, packer=Fn.PackedWeight(),
+                              gdn_packer=Fn.PackedGdn(), **args)
+        else:
+            y = Fn.gdn(Fn.conv2d(t[0], t[1], t[2], **args), t[3], t[4], inv)
+        assert y.requires_grad and y.dtype == torch.bfloat16
+        y.backward(gy.to(DEV, torch.bfloat16))
+        outs.append((y, [p.grad for p in t]))
+        assert rel_err(y, yo) < 1.5e-2
+        for g, r in zip(outs[-1][1], ro):
+            assert g is not None and rel_err(g, r.grad) < 4e-2
+    for g1, g2 in zip(outs[0][1], outs[1][1]):
+        assert rel_err(g1, g2) < 3e-2
+
+
 def test_image_side_conv_gradients_bf16():
     """Backward of the 3-channel-side convs in bf16 storage (MFMA dgrad kernels + the narrow weight-gradient kernels)."""
     Fn, O = _imp()
