@@ -414,7 +414,9 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
                                  void* dz, float* dparams, int64_t P, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(z && params && g_lik && dz && dparams && P > 0 && C > 0, "eb_backward: bad arguments");
     const int bx = 64;
-    const dim3 grid((unsigned)(P < 256 ? P : 256), (C + bx - 1) / bx);
+    // every thread ends in 59 atomics on its channel's gradient row; they serialise per address, so keep the number of
+    // pixel slices (= contenders per address) at 64
+    const dim3 grid((unsigned)(P < 64 ? P : 64), (C + bx - 1) / bx);
     if (dtype == HESIC_BF16)
         hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const bf16_t*)z, params,
                            (const bf16_t*)noise, g_lik, (const bf16_t*)g_zhat, (bf16_t*)dz, dparams, P, C);

@@ -96,24 +96,46 @@ __global__ void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y,
 template <typename T>
 __global__ __launch_bounds__(256) void spatial_max_kernel(const T* __restrict__ x, float* __restrict__ out, int32_t* __restrict__ arg,
                                                           int HW, int C, int leaky) {
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    float best = -INFINITY;
-    int bi = 0;
-    if (c < C)
-        for (int p = pl; p < HW; p += 4) {
-            const float v = elem<T>::ld(x + ((int64_t)b * HW + p) * C + c);
-            if (v > best) { best = v; bi = p; }
+    // block = 64 channels of one image: 8 groups of 8 channels (one 16-byte load per lane for bf16) x 32 pixel lanes;
+    // ties go to the lowest pixel index, like the serial scan of the reference's loop (newnet1.py:441-453)
+    constexpr int V = 8, G = 64 / V, PL = 256 / G;
+    __shared__ float sv[PL][64];
+    __shared__ int si[PL][64];
+    const int gl = threadIdx.x % G, pl = threadIdx.x / G;
+    const int c0 = blockIdx.x * 64 + gl * V, b = blockIdx.y;
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    const bool vec = sizeof(T) == 2 && (C % V) == 0 && c0 + V <= C;
+    for (int p = pl; p < HW; p += PL) {
+        const T* px = x + ((int64_t)b * HW + p) * C + c0;
+        float v[V];
+        if (vec) {
+            const u32x4 raw = *(const u32x4*)px;
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = c0 + e < C ? elem<T>::ld(px + e) : -INFINITY;
         }
-    sv[pl][cl] = best; si[pl][cl] = bi;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            if (v[e] > best[e]) { best[e] = v[e]; bi[e] = p; }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sv[pl][gl * V + e] = best[e]; si[pl][gl * V + e] = bi[e]; }
     __syncthreads();
-    if (pl == 0 && c < C) {
-        for (int k = 1; k < 4; ++k)
-            if (sv[k][cl] > best || (sv[k][cl] == best && si[k][cl] < bi)) { best = sv[k][cl]; bi = si[k][cl]; }
-        out[(int64_t)b * C + c] = leaky ? (best > 0.f ? best : 0.01f * best) : best;
-        if (arg) arg[(int64_t)b * C + c] = bi;
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        const int cl = threadIdx.x;
+        float bv = sv[0][cl];
+        int bp = si[0][cl];
+        for (int k = 1; k < PL; ++k)
+            if (sv[k][cl] > bv || (sv[k][cl] == bv && si[k][cl] < bp)) { bv = sv[k][cl]; bp = si[k][cl]; }
+        const int c = blockIdx.x * 64 + cl;
+        out[(int64_t)b * C + c] = leaky ? (bv > 0.f ? bv : 0.01f * bv) : bv;
+        if (arg) arg[(int64_t)b * C + c] = bp;
     }
 }
 

@@ -631,24 +631,32 @@ __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restri
 // i.e. in both cases  dW[a][s][k] = sum_p A[a][p] * S[s][p + k - 2]  with A the un-shifted tensor (dy | x), S the shifted one
 // (x | dy).  A block stages a 16x64 tile of A and the haloed tile of S in LDS; thread = (a, s, ky) keeps 5 kx
 // accumulators and slides along each row (one new S value + one A value per pixel).
+// dw[a][s][ky][kx] = sum_p A[a][p] * S[s][p + (ky-2, kx-2)] for the 6 <-> 3 channel 5x5 stride-1 stages (A = dY, S = X for the
+// conv; A = X, S = dY for the transposed op).  Lanes are PIXELS (64 columns of a tile row), the 450 sums live in registers:
+// the NS*5 (s, ky) pairs are dealt to the 4 waves, a wave keeps NA*5 accumulators per pair (<= 120 per lane) and walks all
+// 16 rows of the 16x64 LDS tile: per row and pair 5 shifted reads of S feed NA*5 FMAs.  Persistent blocks: the cross-lane
+// reduction and the atomics happen once per block.
 template <int NA, int NS_>
 __global__ __launch_bounds__(256) void sconv_wgrad_nn_kernel(const void* __restrict__ A, int a_dtype, int64_t as_b, int64_t as_c,
                                                              int64_t as_y, int64_t as_x, const void* __restrict__ S, int s_dtype,
                                                              int64_t ss_b, int64_t ss_c, int64_t ss_y, int64_t ss_x,
-                                                             float* __restrict__ dw, int a_major, int B, int H, int W) {
+                                                             float* __restrict__ dw, float* __restrict__ part, int a_major, int B, int H,
+                                                             int W) {
     constexpr int TH = 16, TW = 64, PH = TH + 4, PW = TW + 4;
+    constexpr int NP = NS_ * 5, NPW = (NP + 3) / 4;              // (s, ky) pairs, pairs per wave
     __shared__ float at[NA * TH * TW];
     __shared__ float st[NS_ * PH * PW];
-    const int tid = threadIdx.x;
-    constexpr int NCOMBO = NA * NS_ * 5;
-    const int half = tid >> 7;
-    const bool live = (tid & 127) < NCOMBO;                      // 90 (a, s, ky) combos in lanes 0..89 of each 128-thread half
-    const int combo = live ? (tid & 127) : 0;
-    const int ia = combo / (NS_ * 5), is = (combo / 5) % NS_, ky = combo % 5;
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float acc[NPW][NA][5];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[i][a][k] = 0.f;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
         __syncthreads();
         for (int i = tid; i < NA * TH * TW; i += 256) {
@@ -662,24 +670,57 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nn_kernel(const void* __restr
             st[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ld_any(S, b * ss_b + c * ss_c + (int64_t)y * ss_y + (int64_t)x * ss_x, s_dtype) : 0.f;
         }
         __syncthreads();
-        if (live)
-            for (int r = half * (TH / 2); r < (half + 1) * (TH / 2); ++r) {
-                const float* ar = at + (ia * TH + r) * TW;
-                const float* sr = st + (is * PH + r + ky) * PW;
-                float w0 = sr[0], w1 = sr[1], w2 = sr[2], w3 = sr[3];
-                for (int c = 0; c < TW; ++c) {
-                    const float w4 = sr[c + 4], av = ar[c];
-                    acc[0] += av * w0; acc[1] += av * w1; acc[2] += av * w2; acc[3] += av * w3; acc[4] += av * w4;
-                    w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+#pragma unroll 2
+        for (int r = 0; r < TH; ++r) {
+            float av[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) av[a] = at[(a * TH + r) * TW + lane];
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const int p = wave + 4 * i;                       // wave-uniform
+                if (p < NP) {
+                    const int is = p / 5, ky = p - is * 5;
+                    const float* sr = st + (is * PH + r + ky) * PW + lane;
+                    float sv[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) sv[k] = sr[k];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) acc[i][a][k] = fmaf(av[a], sv[k], acc[i][a][k]);
                 }
             }
+        }
     }
-    if (live) {
-        // weight layout: conv (a_major: a = co) -> [a][s][ky][kx]; transposed (a = ci... stored [s][a]) -> see launcher
-        const int64_t base = a_major ? ((int64_t)(ia * NS_ + is) * 5 + ky) * 5 : ((int64_t)(is * NA + ia) * 5 + ky) * 5;
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) atomicAdd(dw + base + kx, acc[kx]);
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 4 * i;
+        if (p < NP) {
+            const int is = p / 5, ky = p - is * 5;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                // weight layout: [a][s][ky][kx] (a_major) or [s][a][ky][kx]
+                const int64_t base = a_major ? ((int64_t)(a * NS_ + is) * 5 + ky) * 5 : ((int64_t)(is * NA + a) * 5 + ky) * 5;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float v = wave_sum(acc[i][a][k]);
+                    // 512 blocks x 450 same-address atomics cost more than the whole contraction (measured 0.27 of 0.55 ms):
+                    // with a workspace every block leaves its partial row there and nn_partial_reduce_kernel adds them up
+                    if (lane == 0) { if (part) part[(int64_t)blockIdx.x * (NA * NS_ * 25) + base + k] = v; else atomicAdd(dw + base + k, v); }
+                }
+            }
+        }
     }
+}
+
+__global__ void nn_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks, int n) {
+    // one wave per output value: its lanes stride over the per-block partial rows
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = lane; b < nblocks; b += 64) s += part[(int64_t)b * n + i];
+    s = wave_sum(s);
+    if (lane == 0) dw[i] = s;
 }
 
 __global__ __launch_bounds__(256) void sconv_dbias_kernel(const SWArgs a) {
@@ -786,15 +827,24 @@ __global__ __launch_bounds__(256) void gdn_bwd_param_small_kernel(const void* __
             for (int j = 0; j < C; ++j) g[i][j] = fmaf(d[i], sq[j], g[i][j]);
         }
     }
+    // wave sums -> LDS -> one atomic per block and value (same-address atomics serialise in L2: keep them few)
+    __shared__ float red[4][C * C + C];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const float b = wave_sum(bsum[i]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(dbp + i, b);
+        if ((threadIdx.x & 63) == 0) red[wv][C * C + i] = b;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const float v = wave_sum(g[i][j]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(dgp + i * C + j, v);
+            if ((threadIdx.x & 63) == 0) red[wv][i * C + j] = v;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < C * C + C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < C * C) atomicAdd(dgp + threadIdx.x, v);
+        else atomicAdd(dbp + (threadIdx.x - C * C), v);
     }
 }
 
@@ -1054,8 +1104,14 @@ static void nw_gemm_desc(int64_t Q, hesic_conv_desc& g) {
     g.dtype = HESIC_BF16; g.x_pix_stride = 96; g.y_pix_stride = 128;
 }
 
+static bool nn_case(const hesic_sconv_desc* d) {
+    return d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 && d->Cin == 6 && d->Cout == 3 && d->Ho == d->H && d->Wo == d->W;
+}
+constexpr int NN_BLOCKS = 512;
+
 extern "C" int64_t hesic_sconv2d_wgrad_ws_bytes(const hesic_sconv_desc* d) {
     bool conv1;
+    if (d && nn_case(d)) return (int64_t)NN_BLOCKS * 450 * 4;          // per-block partial rows of the 6 <-> 3 stages
     if (!d || !nw_fast_case(d, conv1)) return 0;
     const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
     if (Q >= (1ll << 22)) return 0;
@@ -1116,13 +1172,15 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
                            d->xs_b, d->xs_y, d->xs_x, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, d->B, d->H, d->W, d->Ho, d->Wo);
     } else if (!legacy && k5 && d->stride == 1 && d->Cin == 6 && d->Cout == 3 && d->Ho == d->H && d->Wo == d->W) {
         const int64_t tiles = (int64_t)((d->W + 63) / 64) * ((d->H + 15) / 16) * d->B;
-        const unsigned g = (unsigned)(tiles < 1024 ? tiles : 1024);
+        const unsigned g = (unsigned)(tiles < NN_BLOCKS ? tiles : NN_BLOCKS);       // persistent blocks
+        float* part = (ws && ws_bytes >= (int64_t)NN_BLOCKS * 450 * 4) ? (float*)ws : nullptr;
         if (!d->transposed)   // A = dy (co), S = x (ci); dW[co][ci][k]
             hipLaunchKernelGGL((sconv_wgrad_nn_kernel<3, 6>), dim3(g), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, x,
-                               d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, 1, d->B, d->H, d->W);
+                               d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, part, 1, d->B, d->H, d->W);
         else                  // A = x (ci), S = dy (co); dW[ci][co][k]
             hipLaunchKernelGGL((sconv_wgrad_nn_kernel<6, 3>), dim3(g), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dy,
-                               d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, 1, d->B, d->H, d->W);
+                               d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, part, 1, d->B, d->H, d->W);
+        if (part) hipLaunchKernelGGL(nn_partial_reduce_kernel, dim3((450 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, (int)g, 450);
     } else {
         const int64_t Q = (int64_t)d->B * (d->transposed ? d->H * d->W : d->Ho * d->Wo);
         const int gx = (int)((nw + 255) / 256);
