@@ -617,12 +617,14 @@ __global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtyp
 }
 // dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
 __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per output value (the K split of this route is up to 256 deep: a serial sum per thread was 74 us)
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 128 * NCT) return;
     const int wc = i / NCT, n = i % NCT;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[((int64_t)k * 128 + wc) * 96 + n];
-    dw[i] = s;
+    for (int k = lane; k < nsplit; k += 64) s += part[((int64_t)k * 128 + wc) * 96 + n];
+    s = wave_sum(s);
+    if (lane == 0) dw[i] = s;
 }
 
 // ---- narrow x narrow, stride 1 (pre_conv 6 -> 3, after_conv 6 -> 3 transposed), 5x5 pad 2.
@@ -1157,7 +1159,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         fill_args(&g, a2);
         a2.x = P; a2.dy = conv1 ? dy : x; a2.out = part;
         launch_wgrad_tr(a2, (int64_t)a2.ntaps * a2.co_tiles * a2.ci_tiles * a2.nsplit, st);
-        hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 255) / 256), dim3(256), 0, st, (const float*)part, dw, a2.nsplit, 75);
+        hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, a2.nsplit, 75);
     } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
         d->H == 2 * d->Ho && d->W == 2 * d->Wo) {
         // conv1: WIDE = dy (output grid), NARROW = x
