@@ -904,20 +904,32 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
     __syncthreads();
     const int64_t ntiles = (P + 127) / 128;
     const int r0 = wave * 32;                   // this wave's rows in both tiles
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t p0 = tile * 128 + r0;
-        // wave-private load of 32 rows x 16 slots of x and gy
+    // 128 KB of LDS = one block (one wave per SIMD) per CU: nothing else hides the HBM latency, so the rows of tile t+1
+    // are requested into registers before tile t is computed (64 VGPRs; the budget of a lone wave is 512)
+    u32x4 px[8], pg[8];
+    auto fetch = [&](int64_t t) {
+        const int64_t q0 = t * 128 + r0;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
-            u32x4 vx = u32x4{0, 0, 0, 0}, vg = u32x4{0, 0, 0, 0};
-            if (p0 + row < P) {
-                vx = *(const u32x4*)(x + (p0 + row) * 128 + slot * 8);
-                vg = *(const u32x4*)(gy + (p0 + row) * 128 + slot * 8);
+            px[it] = u32x4{0, 0, 0, 0}; pg[it] = u32x4{0, 0, 0, 0};
+            if (q0 + row < P) {
+                px[it] = *(const u32x4*)(x + (q0 + row) * 128 + slot * 8);
+                pg[it] = *(const u32x4*)(gy + (q0 + row) * 128 + slot * 8);
             }
-            *(u32x4*)(xs + gb_off(r0 + row, slot)) = vx;
-            *(u32x4*)(ds + gb_off(r0 + row, slot)) = vg;
         }
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 128 + r0;
+        // wave-private 32 rows x 16 slots of x and gy: registers -> LDS, then the next tile's loads go out
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
+            *(u32x4*)(xs + gb_off(r0 + row, slot)) = px[it];
+            *(u32x4*)(ds + gb_off(r0 + row, slot)) = pg[it];
+        }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -953,9 +965,9 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 for (int e = 0; e < 4; ++e) {
                     const float n = acc[i][4 * g + e] + bv[i][g][e];
                     if (inverse) {
-                        const float sq = sqrtf(n);
-                        dn[e] = 0.5f * gv[e] * xv[e] / sq;
-                        acc[i][4 * g + e] = gv[e] * sq;
+                        const float rs = rsqrtf(n);                   // one v_rsq instead of sqrt + division (outputs are bf16)
+                        dn[e] = 0.5f * gv[e] * xv[e] * rs;
+                        acc[i][4 * g + e] = gv[e] * (n * rs);
                     } else {
                         const float rs = rsqrtf(n);
                         dn[e] = -0.5f * gv[e] * xv[e] * rs * rs * rs;
