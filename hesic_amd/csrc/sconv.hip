@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
 // back as the B operand of the GDN MFMAs -> normalise -> rows out), so the tile loop needs no block barrier at all.
 template <int CIN, int KS, int ST, typename XT>
 __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const bf16_t* __restrict__ gamma_packed,
-                                                            const float* __restrict__ beta_packed, int inverse) {
+                                                            const float* __restrict__ beta_packed, int inverse,
+                                                            bf16_t* __restrict__ y_pre) {
     constexpr int OROW = 128 * 2 + 16, R = CIN * KS, PAD = KS / 2, NW = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;                          // conv weights [128][128] bf16, slot ^ (row & 15)
@@ -463,13 +464,26 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                 }
                 *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
             }
-        bf16_t* yg = (bf16_t*)a.y;
+        auto store_rows = [&](bf16_t* dstp) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int c = it * 64 + lane, pr = c >> 4, cc = c & 15;
-            const int y2 = ty * 2 + (pr >> 4), x2 = tx * 16 + (pr & 15);
-            if (y2 < a.Ho && x2 < a.Wo)
-                *(u32x4*)(yg + b * a.ys_b + y2 * a.ys_y + x2 * a.ys_x + cc * 8) = *(const u32x4*)(os + pr * OROW + cc * 16);
+            for (int it = 0; it < 8; ++it) {
+                const int c = it * 64 + lane, pr = c >> 4, cc = c & 15;
+                const int y2 = ty * 2 + (pr >> 4), x2 = tx * 16 + (pr & 15);
+                if (y2 < a.Ho && x2 < a.Wo)
+                    *(u32x4*)(dstp + b * a.ys_b + y2 * a.ys_y + x2 * a.ys_x + cc * 8) = *(const u32x4*)(os + pr * OROW + cc * 16);
+            }
+        };
+        store_rows((bf16_t*)a.y);
+        if (y_pre) {
+            // training form: the conv output v (still in acc) goes out through the same wave-private rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = i * 32 + 8 * g + 4 * fh;
+                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
+                }
+            store_rows(y_pre);
         }
     }
 }
@@ -901,8 +915,8 @@ extern "C" int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, c
 }
 
 // conv (3 -> 128, 5x5 s2) + GDN fused; gamma_packed / beta_packed from hesic_gdn_pack_params.
-extern "C" int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
-                                         const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream) {
+static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, const void* gamma_packed,
+                            const float* beta_packed, int inverse, void* y, void* y_pre, void* stream) {
     if (int e = check_desc(d, "sconv2d_gdn_forward")) return e;
     HESIC_CHECK_ARG(x && w && y && gamma_packed && beta_packed, "sconv2d_gdn_forward: null pointer");
     HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
@@ -921,10 +935,22 @@ extern "C" int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* 
         attr = true;
     }
     if (d->x_dtype == HESIC_BF16)
-        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse);
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
     else
-        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse);
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
     HESIC_LAUNCH_RETURN("sconv2d_gdn_forward");
+}
+
+extern "C" int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
+                                         const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream) {
+    return sconv_gdn_launch(d, x, w, bias, gamma_packed, beta_packed, inverse, y, nullptr, stream);
+}
+
+extern "C" int hesic_sconv2d_gdn_forward_train(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
+                                               const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                               void* stream) {
+    HESIC_CHECK_ARG(y_pre, "sconv2d_gdn_forward_train: null pointer");
+    return sconv_gdn_launch(d, x, w, bias, gamma_packed, beta_packed, inverse, y, y_pre, stream);
 }
 
 // dx of y = op(x): the opposite op (conv <-> transposed conv) applied to dy with the same weight tensor:

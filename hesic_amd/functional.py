@@ -136,6 +136,32 @@ def _out_hw(H, W, k, stride, pad, transposed):
     return f(H), f(W)
 
 
+def _narrow_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
+    """dx / dw / dbias of an image-side conv (few channels on one side: strided kernels)."""
+    k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
+    B, H, W, Cin, Ho, Wo, Cout = dims
+    dx = dw = db = None
+    ydt = torch.float32 if _is_narrow(Cout) else (_compute_dtype if _is_narrow(Cin) else x.dtype)
+    gy = gy.to(ydt)
+    gy = gy.contiguous() if _is_narrow(Cout) else _nhwc(gy)
+    w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
+    d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
+    if need_dx:
+        dx = torch.empty_like(x)
+        L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
+        if in_abs:
+            dx = dx * torch.sign(x)
+    if need_dw:
+        dw = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+        nws = L.lib().hesic_sconv2d_wgrad_ws_bytes(C.byref(d))
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.ptr(ws), nws, L.stream())
+        if mask is not None:
+            dw = dw * mask
+    return dx, dw, db
+
+
 def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
     """dx / dw / dbias of a wide conv (implicit-GEMM kernels): shared by _ConvFn and _ConvGdnFn."""
     k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
@@ -215,24 +241,7 @@ class _ConvFn(torch.autograd.Function):
             gy = g2
         dx = dw = db = None
         if ctx.narrow:
-            ydt = torch.float32 if _is_narrow(Cout) else (_compute_dtype if _is_narrow(Cin) else x.dtype)
-            gy = gy.to(ydt)
-            gy = gy.contiguous() if _is_narrow(Cout) else _nhwc(gy)
-            w = (weight.detach() if mask is None else weight.detach() * mask).contiguous()
-            d = _sdesc(x, gy, Cin, Cout, k, stride, pad, transposed)
-            if ctx.needs_input_grad[0]:
-                dx = torch.empty_like(x)
-                L.call("hesic_sconv2d_dgrad", C.byref(d), L.ptr(gy), L.ptr(w), L.ptr(dx), L.stream())
-                if in_abs:
-                    dx = dx * torch.sign(x)
-            if ctx.needs_input_grad[1]:
-                dw = torch.empty_like(weight, dtype=torch.float32)
-                db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                nws = L.lib().hesic_sconv2d_wgrad_ws_bytes(C.byref(d))
-                ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-                L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.ptr(ws), nws, L.stream())
-                if mask is not None:
-                    dw = dw * mask
+            dx, dw, db = _narrow_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         else:
             dx, dw, db = _wide_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if not ctx.has_bias:
@@ -268,17 +277,56 @@ FUSE_CONV_GDN_TRAIN = _os.environ.get("HESIC_NO_FUSE_TRAIN") is None      # A/B 
 def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
     """The fused epilogue exists for bf16 storage, 128 output channels and a wide input; with autograd on, the wide
     stages keep the fusion through ``_ConvGdnFn`` (the kernel then also stores the conv output for GDN's backward), the
-    image-side 3 -> 128 stage is fused at inference only."""
+    same goes for the image-side 3 -> 128 stage (``_SConvGdnFn``)."""
     cout = weight.shape[1] if transposed else weight.shape[0]
     cin = weight.shape[0] if transposed else weight.shape[1]
     if not x.is_cuda or cout != 128 or gdn_channels != 128 or not FUSE_CONV_GDN:
         return False
     if cin == 3:      # g_a_conv1 + g_a_gdn1: image in (any float dtype), bf16 storage out
-        return (not torch.is_grad_enabled() and not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5
+        if torch.is_grad_enabled() and not FUSE_CONV_GDN_TRAIN:
+            return False
+        return (not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5
                 and x.dtype in (torch.float32, torch.bfloat16))
     if torch.is_grad_enabled() and not FUSE_CONV_GDN_TRAIN:
         return False
     return x.dtype == torch.bfloat16 and cin % 32 == 0
+
+
+class _SConvGdnFn(torch.autograd.Function):
+    """g_a_gdn1(g_a_conv1(image)) fused under autograd (the 3 -> 128 stage): v = conv output is stored next to y."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, beta, gamma, cfg):
+        k, stride, pad, inverse, beta_min, gdn_packer = cfg
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = _out_hw(H, W, k, stride, pad, False)
+        gp, bp = gdn_packer.get(beta, gamma, beta_min)
+        y = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
+        v = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
+        d = _sdesc(x, y, Cin, Cout, k, stride, pad, False)
+        L.call("hesic_sconv2d_gdn_forward_train", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
+               L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
+        ctx.save_for_backward(x, weight, v, beta, gamma)
+        ctx.cfg, ctx.dims, ctx.has_bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, v, beta, gamma = ctx.saved_tensors
+        k, stride, pad, inverse, beta_min, _ = ctx.cfg
+        B, H, W, Cin, Ho, Wo, Cout = ctx.dims
+        P = B * Ho * Wo
+        gy = _nhwc(gy.to(v.dtype))
+        gv = torch.empty_like(v, memory_format=_CL)
+        dbeta = torch.empty_like(beta, dtype=torch.float32)
+        dgamma = torch.empty_like(gamma, dtype=torch.float32)
+        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cout)), dtype=torch.uint8, device=x.device)
+        L.call("hesic_gdn_backward", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
+               L.ptr(gv), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cout, int(inverse), float(beta_min), L.dt(v), L.stream())
+        ccfg = (k, stride, pad, False, 0, 0, 0, None, None)
+        dx, dw, db = _narrow_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, (db if ctx.has_bias else None), dbeta, dgamma, None
 
 
 class _ConvGdnFn(torch.autograd.Function):
@@ -328,6 +376,8 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
     Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
     B, _, H, W = x.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    if Cin == 3 and torch.is_grad_enabled():
+        return _SConvGdnFn.apply(x, weight, bias, beta, gamma, (k, stride, padding, inverse, beta_min, gdn_packer))
     if Cin == 3:      # image-side stage: strided fp32/bf16 image in, bf16 NHWC out
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
         out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)

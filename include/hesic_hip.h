@@ -120,6 +120,10 @@ int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const v
  * gamma_packed / beta_packed from hesic_gdn_pack_params.                                                              */
 int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
                               const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
+/* training form: also stores the conv output (bf16 NHWC, y's geometry) for GDN's backward */
+int hesic_sconv2d_gdn_forward_train(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
+                                    const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                    void* stream);
 /* dx of the same op (dy has y's strides, dx has x's strides). */
 int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream);
 /* dw (raw PyTorch layout, fp32) and dbias (may be NULL).  ws (hesic_sconv2d_wgrad_ws_bytes(d) bytes, may be NULL/0) enables the
