@@ -205,12 +205,17 @@ __global__ void softmax_k_bwd_kernel(const float* __restrict__ w, const float* _
 __global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__ lik, int64_t n, double* __restrict__ out) {
     __shared__ double red[4];
     double acc = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        acc += (double)log2f(lik[i]);
+    const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = (((uintptr_t)lik & 15) == 0) ? (n >> 2) : 0;           // 16-byte lanes when the tensor allows it
+    for (int64_t i = gt; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)lik)[i];
+        acc += (double)log2f(v.x) + (double)log2f(v.y) + (double)log2f(v.z) + (double)log2f(v.w);
+    }
+    for (int64_t i = n4 * 4 + gt; i < n; i += stride) acc += (double)log2f(lik[i]);
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);      // <= 128 blocks: same-address atomics serialise
 }
 
 struct SqArgs {
@@ -389,7 +394,7 @@ extern "C" int hesic_softmax_k_backward(const float* weights, const float* g, fl
 
 extern "C" int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream) {
     HESIC_CHECK_ARG(lik && out && n > 0, "sum_log2: bad arguments");
-    hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
+    hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n / 4 + 1, 256, 128)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
     HESIC_LAUNCH_RETURN("sum_log2");
 }
 
