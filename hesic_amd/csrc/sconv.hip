@@ -488,6 +488,185 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
     }
 }
 
+// Fast form of the kernel above for the layout the hot path actually feeds it: fp32 planes with unit pixel stride and an
+// even width.  The generic gather costs ~1500 VALU instructions per 32-pixel tile (64-bit addressing and a predicate per
+// element, both transcendentals of the GDN/IGDN select evaluated, 64-bit tile decode) against 64 MFMAs -- the kernel was
+// VALU-bound at 2.6x its HBM time.  Here
+//   * the 5 taps of an input row are three 8-byte buffer loads (ix0 = 2 ox - 2 is even); out-of-image rows / pairs are a
+//     poisoned offset (>= 2^31: the buffer unit returns zeros), one add + three selects per row;
+//   * per-lane row constants (plane/row byte offset, ky) are computed once, the tile decode is scalar (fast division);
+//   * the next tile's rows are requested as soon as this tile's conv MFMAs have consumed the fragments, so the HBM
+//     latency hides behind the GDN contraction, the epilogue and the stores;
+//   * accumulators start from bias / beta' (no separate adds), INV is a template parameter, rows leave through buffer
+//     stores with scalar tile offsets.
+template <int INV>
+__global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, const bf16_t* __restrict__ gamma_packed,
+                                                                 const float* __restrict__ beta_packed, bf16_t* __restrict__ y_pre,
+                                                                 FastDiv fd_tx, FastDiv fd_ty) {
+    constexpr int OROW = 128 * 2 + 16, CIN = 3, KS = 5, R = CIN * KS, NW = 8;
+    constexpr uint32_t POISON = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                          // conv weights [128][128] bf16, slot ^ (row & 15)
+    unsigned char* gl = smem + 32768;                  // gamma' image (K order permuted, see the kernel above)
+    float* bl = (float*)(smem + 65536);                // conv bias[128], beta'[128]
+    unsigned char* osb = smem + 65536 + 1024;          // per-wave 32 x OROW slices
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    unsigned char* os = osb + wave * 32 * OROW;
+
+    const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 1) / 2;       // wave tile = 2 output rows x 16 columns
+    const int ntiles = tiles_x * tiles_y * a.B;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tstride = (int)gridDim.x * NW;
+    u32x2 raw[8][3];
+    int tb = 0, tty = 0, ttx = 0;
+    auto decode = [&](int tile) {
+        const uint32_t q = fdiv((uint32_t)tile, fd_tx);
+        ttx = tile - (int)q * tiles_x;
+        tb = (int)fdiv(q, fd_ty);
+        tty = (int)q - tb * tiles_y;
+    };
+    auto request = [&](int tile) {                    // issue the 24 row-pair loads of a tile
+        decode(tile);
+        // the resource starts 8 bytes in front of the image so that every in-image pair has a non-negative lane offset
+        // (row 0, ox = 0: the second pair sits at byte 0, its lane offset without the shift would be -8 = out of range)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)a.x + (int64_t)tb * a.xs_b - 2), 0, (int)POISON, 0x00020000);
+        const int oy = tty * 2 + (frow >> 4), ox = ttx * 16 + (frow & 15);
+        const bool pok = oy < a.Ho && ox < a.Wo;
+        const int iy0 = oy * 2 - 2, ix0 = ox * 2 - 2;
+        const uint32_t base = (uint32_t)((iy0 * (int)a.xs_y + ix0) * 4 + 8);
+        const bool ok0 = pok && ox > 0, ok2 = pok && ix0 + 4 < a.W;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            // k-step ks of lane-half fh carries input row r = 2 ks + fh = (plane ci, tap row ky); row 15 does not exist
+            const int ra = 2 * ks, rb = 2 * ks + 1;
+            const int kya = ra % KS, kyb = rb < R ? rb % KS : 0x40000000, cia = ra / KS, cib = rb / KS;
+            const uint32_t offa = (uint32_t)((cia * (int)a.xs_c + kya * (int)a.xs_y) * 4), offb = (uint32_t)((cib * (int)a.xs_c + (rb % KS) * (int)a.xs_y) * 4);
+            const bool okr = (unsigned)(iy0 + (fh ? kyb : kya)) < (unsigned)a.H;
+            const uint32_t v = base + (fh ? offb : offa);
+            const uint32_t v0 = (okr && ok0) ? v : POISON, v1 = (okr && pok) ? v : POISON, v2 = (okr && ok2) ? v : POISON;
+            raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v0, 0, 0);
+            raw[ks][1] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, 8, 0);
+            raw[ks][2] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v2, 16, 0);
+        }
+    };
+    int tile = lb * NW + wave;
+    if (tile < ntiles) request(tile);                 // in flight while the block packs its weights
+
+    {
+        const int r = tid & 15, ci = r / KS, ky = r % KS;
+        for (int co = tid >> 4; co < 128; co += 32) {
+            float v[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+                v[kx] = (r < R && kx < KS && co < a.Cout) ? a.w[(((int64_t)co * CIN + ci) * KS + ky) * KS + kx] : 0.f;
+            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        }
+        for (int idx = tid; idx < 2048; idx += 512) {
+            const int row = idx >> 4, q = idx & 15, ks = q >> 1, h = q & 1;
+            const unsigned char* srow = (const unsigned char*)gamma_packed + row * 256;
+            const u32x2 lo = *(const u32x2*)(srow + (((2 * ks) ^ (row & 15)) << 4) + 8 * h);
+            const u32x2 hi = *(const u32x2*)(srow + (((2 * ks + 1) ^ (row & 15)) << 4) + 8 * h);
+            *(u32x4*)(gl + row * 256 + ((q ^ (row & 15)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+        if (tid < 128) { bl[tid] = a.bias ? a.bias[tid] : 0.f; bl[128 + tid] = beta_packed[tid]; }
+    }
+    __syncthreads();
+
+    // lane part of the output row addresses: store instruction `it` writes pixel it*4 + (lane >> 4), 16-byte chunk lane & 15
+    const uint32_t st_lane = (uint32_t)(((lane >> 4) * (int)a.ys_x + (lane & 15) * 8) * 2);
+    for (; tile < ntiles; tile += tstride) {
+        const int b = tb, ty = tty, tx = ttx;        // of the tile whose rows are in `raw`
+        u32x4 frag[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x2 p0 = __builtin_bit_cast(f32x2, raw[ks][0]), p1 = __builtin_bit_cast(f32x2, raw[ks][1]), p2 = __builtin_bit_cast(f32x2, raw[ks][2]);
+            frag[ks] = u32x4{pack_bf2_fast(p0.x, p0.y), pack_bf2_fast(p1.x, p1.y), pack_bf2_fast(p2.x, 0.f), 0u};
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(bl + i * 32 + 8 * g + 4 * fh);
+                acc[i][4 * g] = bv.x; acc[i][4 * g + 1] = bv.y; acc[i][4 * g + 2] = bv.z; acc[i][4 * g + 3] = bv.w;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + frow;
+                const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+            }
+        }
+        f32x16 nrm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 be = *(const f32x4*)(bl + 128 + i * 32 + 8 * g + 4 * fh);
+                nrm[i][4 * g] = be.x; nrm[i][4 * g + 1] = be.y; nrm[i][4 * g + 2] = be.z; nrm[i][4 * g + 3] = be.w;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int si = ks >> 1, so = (ks & 1) * 8;
+            const u32x4 sq = u32x4{pack_bf2_fast(acc[si][so] * acc[si][so], acc[si][so + 1] * acc[si][so + 1]),
+                                   pack_bf2_fast(acc[si][so + 2] * acc[si][so + 2], acc[si][so + 3] * acc[si][so + 3]),
+                                   pack_bf2_fast(acc[si][so + 4] * acc[si][so + 4], acc[si][so + 5] * acc[si][so + 5]),
+                                   pack_bf2_fast(acc[si][so + 6] * acc[si][so + 6], acc[si][so + 7] * acc[si][so + 7])};
+            const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + frow;
+                const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + tstride < ntiles) request(tile + tstride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = i * 32 + 8 * g + 4 * fh;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = nrm[i][4 * g + e];
+                    o[e] = acc[i][4 * g + e] * (INV ? __builtin_amdgcn_sqrtf(n) : __builtin_amdgcn_rsqf(n));
+                }
+                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
+            }
+        const bool full = ty * 2 + 2 <= a.Ho && tx * 16 + 16 <= a.Wo;     // wave-uniform
+        auto store_rows = [&](bf16_t* dstp) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(dstp + (int64_t)b * a.ys_b), 0, (int)POISON, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int y2 = ty * 2 + (it >> 2), x2 = tx * 16 + (it & 3) * 4;
+                const int so = (y2 * (int)a.ys_y + x2 * (int)a.ys_x) * 2;                       // scalar
+                const bool ok = full || (y2 < a.Ho && x2 + (lane >> 4) < a.Wo);
+                const u32x4 v = *(const u32x4*)(os + (it * 4 + (lane >> 4)) * OROW + (lane & 15) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)(ok ? st_lane : POISON), so, 0);
+            }
+        };
+        store_rows((bf16_t*)a.y);
+        if (y_pre) {
+            // training form: the conv output v (still in acc) goes out through the same wave-private rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = i * 32 + 8 * g + 4 * fh;
+                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
+                }
+            store_rows(y_pre);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- wide -> narrow on the matrix cores (bf16 input)
 // g_s_conv4 (ConvTranspose2d 128 -> 3, 5x5 s2 p2 op1).  With only 3 output channels the GEMM is turned round: every
 // INPUT pixel is multiplied by the whole [Cin x (25*Cout)] weight panel (N = 75 -> 96), giving its 5x5xCout "splat"
@@ -934,7 +1113,24 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
         (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (d->x_dtype == HESIC_BF16)
+    // fp32 planes, unit pixel stride, even width, everything addressable with 32-bit byte offsets inside one image
+    static const bool no_fast = getenv("HESIC_N2W_GENERIC") != nullptr;              // A/B switch for profiling
+    const bool fastx = !no_fast && d->x_dtype == HESIC_F32 && d->xs_x == 1 && d->W % 2 == 0 && tiles < (1ll << 30) &&
+                       (2 * d->xs_c + (int64_t)(d->H + 4) * d->xs_y + d->W) * 4 < (1ll << 31) &&
+                       ((int64_t)d->Ho * d->ys_y + (int64_t)d->Wo * d->ys_x) * 2 < (1ll << 31) && d->xs_c >= 0 && d->xs_y >= 0;
+    if (fastx) {
+        static bool attr_f = false;
+        if (!attr_f) {
+            (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_fast_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_fast_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_f = true;
+        }
+        const FastDiv fd_tx = make_fastdiv((uint32_t)((d->Wo + 15) / 16)), fd_ty = make_fastdiv((uint32_t)((d->Ho + 1) / 2));
+        if (inverse)
+            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<1>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, (bf16_t*)y_pre, fd_tx, fd_ty);
+        else
+            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<0>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, (bf16_t*)y_pre, fd_tx, fd_ty);
+    } else if (d->x_dtype == HESIC_BF16)
         hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
     else
         hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
