@@ -844,8 +844,10 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
 // row pitch keeps the 16-lane groups of those reads on disjoint banks.  The two 3-channel halves of the input may come
 // from different tensors (any strides / fp32 or bf16): planar fp32 rows are fetched as 8-byte pairs.
 template <int K>
-__global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
-    constexpr int CIN = 6, COUT = 3, TH = 16, TW = 128, PAD = K / 2, PH = TH + K - 1, PW = TW + 4, NP = PW / 2;
+__global__ __launch_bounds__(256, 4) void sconv_6to3_s1_kernel(const SArgs a) {
+    // 16 x 64 pixel tile, 4 pixels per thread: 35 KB of LDS and < 128 VGPRs -> four blocks (16 waves) per CU, so the staging
+    // of one block overlaps the FMA phase of the others
+    constexpr int CIN = 6, COUT = 3, TH = 16, PX = 4, TW = 16 * PX, PAD = K / 2, PH = TH + K - 1, PW = TW + 4, NP = PW / 2;
     __shared__ __attribute__((aligned(16))) float xs[CIN * PH * PW];
     __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * 4];
     const int tid = threadIdx.x;
@@ -867,15 +869,29 @@ __global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
         const int dt = half ? a.x2_dtype : a.x_dtype;
         const int rows = (c_hi - c_lo) * PH;
         const bool pairs = dt == HESIC_F32 && sx == 1 && !(a.W & 1) && !((sb | sc | sy) & 1) && !((uintptr_t)src & 7);
-        if (pairs) {
-            const float* base = (const float*)src + b * sb;
-            for (int i = tid; i < rows * NP; i += 256) {
-                const int r = i / NP, j = i - r * NP;
-                const int ci = r / PH, py = r - ci * PH;
-                const int iy = y0 + py, ix = x0 + 2 * j;
-                f32x2 v = {0.f, 0.f};
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = *(const f32x2*)(base + ci * sc + (int64_t)iy * sy + ix);
-                *(f32x2*)(xs + ((c_lo + ci) * PH + py) * PW + 2 * j) = v;
+        if (pairs && ((int64_t)CIN * sc + (int64_t)a.H * sy) * 4 < (1ll << 31)) {
+            // 8-byte buffer loads, eight in flight per thread before the first LDS write (the one-load-per-iteration form
+            // serialised ~31 HBM round trips per block and set the kernel's time); out-of-image pairs read zeros through a
+            // poisoned offset, so the loop body has no branch
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)src + b * sb), 0, (int)0x80000000u, 0x00020000);
+            const int total = rows * NP;
+            for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+                u32x2 v[8];
+                int dst[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256;
+                    const int r = i / NP, j = i - r * NP;
+                    const int ci = r / PH, py = r - ci * PH;
+                    const int iy = y0 + py, ix = x0 + 2 * j;
+                    const bool ok = i < total && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    const uint32_t off = ok ? (uint32_t)((ci * (int)sc + iy * (int)sy + ix) * 4) : 0x80000000u;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)off, 0, 0);
+                    dst[u] = i < total ? ((c_lo + ci) * PH + py) * PW + 2 * j : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (dst[u] >= 0) *(u32x2*)(xs + dst[u]) = v[u];
             }
         } else {
             for (int i = tid; i < rows * PW; i += 256) {
@@ -890,24 +906,24 @@ __global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
         }
     }
     __syncthreads();
-    const int ly = tid >> 4, lx = (tid & 15) * 8;
-    float acc[8][COUT];
+    const int ly = tid >> 4, lx = (tid & 15) * PX;
+    float acc[PX][COUT];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < PX; ++p)
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[p][c] = 0.f;
 #pragma unroll 1
     for (int ci = 0; ci < CIN; ++ci) {
-#pragma unroll
+#pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
             const float* row = xs + (ci * PH + ly + ky) * PW + lx;
-            const f32x4 r0 = *(const f32x4*)row, r1 = *(const f32x4*)(row + 4), r2 = *(const f32x4*)(row + 8);
-            const float xin[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const f32x4 r0 = *(const f32x4*)row, r1 = *(const f32x4*)(row + 4);
+            const float xin[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const f32x4 wv = *(const f32x4*)(wl + ((ky * K + kx) * CIN + ci) * 4);
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
+                for (int p = 0; p < PX; ++p) {
                     acc[p][0] = fmaf(xin[p + kx], wv.x, acc[p][0]);
                     acc[p][1] = fmaf(xin[p + kx], wv.y, acc[p][1]);
                     acc[p][2] = fmaf(xin[p + kx], wv.z, acc[p][2]);
@@ -921,17 +937,16 @@ __global__ __launch_bounds__(256) void sconv_6to3_s1_kernel(const SArgs a) {
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
         const float bv = a.bias ? a.bias[co] : 0.f;
-        float o[8];
+        float o[PX];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) o[p] = apply_act(acc[p][co] + bv, a.act);
+        for (int p = 0; p < PX; ++p) o[p] = apply_act(acc[p][co] + bv, a.act);
         const int64_t base = b * a.ys_b + co * a.ys_c + oy * a.ys_y;
-        if (vec && ox0 + 8 <= a.Wo) {
+        if (vec && ox0 + PX <= a.Wo) {
             float* yp = (float*)a.y + base + ox0;
             *(f32x4*)yp = f32x4{o[0], o[1], o[2], o[3]};
-            *(f32x4*)(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
         } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
+            for (int p = 0; p < PX; ++p)
                 if (ox0 + p < a.Wo) st_any(a.y, base + (ox0 + p) * a.ys_x, a.y_dtype, o[p]);
         }
     }
@@ -1022,7 +1037,7 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
     } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
                a.Wo == a.W && a.Wo >= 128) {
-        const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+        const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
         hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, st, a);
     } else if (!legacy && a.stride == 1 && ((a.Cin == 6 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 6)) && a.KH == 5 && a.KW == 5 &&
                a.pad == 2 && a.Ho == a.H && a.Wo == a.W && a.Wo >= 64) {
@@ -1078,7 +1093,7 @@ extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* 
     a.x = xa; a.w = w; a.bias = bias; a.y = y;
     a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
     a.x2_dtype = xb_dtype; a.c_split = ca;
-    const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+    const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
     hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("sconv2d_forward_cat");
 }
