@@ -676,15 +676,42 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
 // col2im runs, so the HBM latency is hidden both by the co-resident block and by the prefetch.
 constexpr int W2N_TH = 6, W2N_TW = 14;
 template <int COUT>
-__global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
+__global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, FastDiv fd_tx, FastDiv fd_ty) {
     constexpr int N = 25 * COUT, NT = (N + 31) / 32, NP = NT * 32;
     constexpr int GROW = NP * 4 + 16;                         // G row stride (bytes)
     constexpr int CIN = 128, SPR = CIN / 8;
+    constexpr uint32_t POISON = 0x80000000u;
     __shared__ __attribute__((aligned(16))) unsigned char dsm[NP * CIN * 2 + 128 * GROW];
     unsigned char* wl = dsm;                                  // [NP][128] bf16, 16-byte slots XOR (row & 15)
     unsigned char* G = dsm + NP * CIN * 2;                    // [128 px][GROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fh = lane >> 5;
+    const int tiles_x = (a.W + W2N_TW - 1) / W2N_TW, tiles_y = (a.H + W2N_TH - 1) / W2N_TH;
+    const int ntiles = tiles_x * tiles_y * a.B;               // < 2^31 (launcher)
+    const int pl = wave * 32 + frow;                          // this lane's pixel in the 8x16 halo patch
+    // two tiles of pixel fragments in flight (A / B): a fetch is issued as soon as the MFMAs have consumed its registers and
+    // is not needed before the block has worked through the other tile, so the HBM latency never sits in front of a barrier
+    struct Slot { u32x4 raws[8]; int tb, tty, ttx; };
+    Slot sa, sb;
+    auto fetch = [&](Slot& sl, int tile) {
+        u32x4 (&raws)[8] = sl.raws;
+        const uint32_t q = fdiv((uint32_t)tile, fd_tx);
+        const int ttx = tile - (int)q * tiles_x;
+        const int tb = (int)fdiv(q, fd_ty);
+        const int tty = (int)q - tb * tiles_y;
+        sl.tb = tb; sl.tty = tty; sl.ttx = ttx;
+        // one buffer resource per image: a halo pixel outside the image is a poisoned offset and reads zeros
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)a.x + (int64_t)tb * a.xs_b), 0, (int)POISON, 0x00020000);
+        const int iy = tty * W2N_TH - 1 + (pl >> 4), ix = ttx * W2N_TW - 1 + (pl & 15);
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const uint32_t off = ok ? (uint32_t)((iy * (int)a.xs_y + ix * (int)a.xs_x + fh * 8) * 2) : POISON;    // xs_c == 1
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) raws[ks] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, ks * 32, 0);
+    };
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);                    // neighbouring patches share their 1-pixel halo in one L2
+    const int gstep = (int)gridDim.x;
+    if (lb < ntiles) fetch(sa, lb);                           // in flight while the weight panel is packed
+    if (lb + gstep < ntiles) fetch(sb, lb + gstep);
     for (int i = tid; i < NP * SPR; i += 256) {
         const int n = i / SPR, sl = i % SPR;
         const int co = n % COUT, tap = n / COUT;
@@ -693,24 +720,18 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
         for (int e = 0; e < 8; ++e) v[e] = n < N ? a.w[((int64_t)(sl * 8 + e) * COUT + co) * 25 + tap] : 0.f;   // w[ci][co][ky][kx]
         *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
     }
-    const int tiles_x = (a.W + W2N_TW - 1) / W2N_TW, tiles_y = (a.H + W2N_TH - 1) / W2N_TH;
-    const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B;
-    const bf16_t* xg = (const bf16_t*)a.x;
-    const int pl = wave * 32 + frow;                          // this lane's pixel in the 8x16 halo patch
-    u32x4 raws[8];
-    auto fetch = [&](int64_t tile) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
-        const int iy = ty * W2N_TH - 1 + (pl >> 4), ix = tx * W2N_TW - 1 + (pl & 15);
-        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const bf16_t* xp = xg + b * a.xs_b + (int64_t)iy * a.xs_y + (int64_t)ix * a.xs_x + fh * 8;   // xs_c == 1
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) raws[ks] = ok ? *(const u32x4*)(xp + ks * 16) : u32x4{0, 0, 0, 0};
-    };
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);                    // neighbouring patches share their 1-pixel halo in one L2
-    if (lb < ntiles) fetch(lb);
+    // col2im role of this thread: output channel cq of the 2x2 output quad around input pixel (qy, qx) of the 6x14 patch --
+    // 252 of the 256 threads busy, every lane the same 25 taps (no divergence between output parities)
+    const int qi = tid / COUT, cq = tid - qi * COUT;
+    const int qy = qi / W2N_TW, qx = qi - qy * W2N_TW;
+    const bool qlive = qi < W2N_TH * W2N_TW;
+    const float bq = (a.bias && qlive) ? a.bias[cq] : 0.f;
+    const unsigned char* gq = G + ((qy + 2) * 16 + qx + 2) * GROW + cq * 4;
+    const bool pair_st = a.y_dtype == HESIC_F32 && a.ys_x == 1 && !((a.ys_b | a.ys_c | a.ys_y) & 1) && !((uintptr_t)a.y & 7);
     __syncthreads();
-    for (int64_t tile = lb; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
+    auto process = [&](Slot& sl, int next_tile) {
+        u32x4 (&raws)[8] = sl.raws;
+        const int tx = sl.ttx, ty = sl.tty, b = sl.tb;        // of the tile whose pixels are in `raws`
         f32x16 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -726,7 +747,7 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
             }
         }
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);          // in flight during the col2im below
+        if (next_tile < ntiles) fetch(sl, next_tile);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -734,34 +755,39 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a) {
                 *(f32x4*)(G + pl * GROW + (i * 32 + 8 * g + 4 * fh) * 4) =
                     f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
         __syncthreads();
-        // col2im: out(2*t0 + ol) = bias + sum_{k == ol parity} G[il = (ol + 2 - k)/2 + 1][k]
-        for (int o = tid; o < 4 * W2N_TH * W2N_TW; o += 256) {
-            const int oly = o / (2 * W2N_TW), olx = o % (2 * W2N_TW);
-            const int oy = 2 * ty * W2N_TH + oly, ox = 2 * tx * W2N_TW + olx;
-            if (oy >= a.Ho || ox >= a.Wo) continue;
-            float r[COUT];
+        // col2im: out(2 q + p) = bias + sum over taps k = p + 2 j (<= 4) of G[q + 1 - j (+1 halo)][k]
+        const int gy = ty * W2N_TH + qy, gx = tx * W2N_TW + qx;
+        if (qlive && gy < a.H && gx < a.W) {
+            float o[2][2] = {{bq, bq}, {bq, bq}};
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) r[co] = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-            for (int jy = 0; jy < 3; ++jy) {
-                const int ky = (oly & 1) + 2 * jy;
-                if (ky > 4) continue;
-                const int ily = (oly + 2 - ky) / 2 + 1;
+            for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
                 for (int jx = 0; jx < 3; ++jx) {
-                    const int kx = (olx & 1) + 2 * jx;
-                    if (kx > 4) continue;
-                    const int ilx = (olx + 2 - kx) / 2 + 1;
-                    const float* gp = (const float*)(G + (ily * 16 + ilx) * GROW) + (ky * 5 + kx) * COUT;
+                    const unsigned char* gp = gq - (jy * 16 + jx) * GROW;
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co) r[co] += gp[co];
+                    for (int py = 0; py < 2; ++py)
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const int ky = py + 2 * jy, kx = px + 2 * jx;
+                            if (ky < 5 && kx < 5) o[py][px] += *(const float*)(gp + (ky * 5 + kx) * COUT * 4);
+                        }
+                }
+            const int64_t ob = b * a.ys_b + cq * a.ys_c + (int64_t)(2 * gy) * a.ys_y + (int64_t)(2 * gx) * a.ys_x;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const float o0 = apply_act(o[py][0], a.act), o1 = apply_act(o[py][1], a.act);
+                if (pair_st) *(f32x2*)((float*)a.y + ob + py * a.ys_y) = f32x2{o0, o1};
+                else {
+                    st_any(a.y, ob + py * a.ys_y, a.y_dtype, o0);
+                    st_any(a.y, ob + py * a.ys_y + a.ys_x, a.y_dtype, o1);
                 }
             }
-#pragma unroll
-            for (int co = 0; co < COUT; ++co)
-                st_any(a.y, b * a.ys_b + co * a.ys_c + oy * a.ys_y + ox * a.ys_x, a.y_dtype, apply_act(r[co], a.act));
         }
         __syncthreads();
+    };
+    for (int tile = lb; tile < ntiles; tile += 2 * gstep) {
+        process(sa, tile + 2 * gstep);
+        if (tile + gstep < ntiles) process(sb, tile + 3 * gstep);
     }
 }
 
@@ -1024,9 +1050,10 @@ int launch_forward(const SArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(sconv_narrow_to_wide_kernel, dim3(tiles), dim3(256), lds, st, a);
     } else if (!legacy && a.transposed && a.x_dtype == HESIC_BF16 && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 &&
                a.Cout == 3 && a.Cin == 128 && a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 &&
-               a.Ho == 2 * a.H && a.Wo == 2 * a.W) {
+               a.Ho == 2 * a.H && a.Wo == 2 * a.W && (int64_t)a.H * a.xs_y * 2 < (1ll << 31) && (int64_t)a.B * a.H * a.W < (1ll << 31)) {
         const int64_t tiles = (int64_t)((a.W + W2N_TW - 1) / W2N_TW) * ((a.H + W2N_TH - 1) / W2N_TH) * a.B;
-        hipLaunchKernelGGL((sconv_w2n_mfma_kernel<3>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((sconv_w2n_mfma_kernel<3>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, a,
+                           make_fastdiv((uint32_t)((a.W + W2N_TW - 1) / W2N_TW)), make_fastdiv((uint32_t)((a.H + W2N_TH - 1) / W2N_TH)));
     } else if (a.transposed && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Cout <= 4 && a.Cin % 8 == 0 &&
                a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Cin <= 128) {
         const int64_t total = (int64_t)a.B * a.H * a.W;
