@@ -238,6 +238,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct WgTrArgs {
     WgArgs w;
     FastDiv dqw, dqh;
+    int fastq;          // QW % 16 == 0 (and chunk % 64 == 0): the 16 pixels a wave stages per step share one image row
 };
 
 __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         qb[i] = (int)b;
         lin_off[i] = q * lin_ps;
     }
-    auto issue = [&](int buf) {
+    auto issue_slow = [&](int buf) {
         unsigned char* dt = smem + buf * STAGE;
         unsigned char* xt = dt + TILE;
 #pragma unroll
@@ -316,6 +317,62 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         }
     };
 
+    // Fast bookkeeping (QW % 16 == 0, every training layer above the 8x8 hyper maps): the 16 pixels of a wave's four DMA
+    // instructions lie in one image row, so (b, qy, qx of the first pixel), the row validity and the row's byte offset
+    // are wave-uniform SCALARS that go into the instruction's soffset; per lane only the x-range check of the shifted
+    // operand is left (3 VALU per instruction).  The per-lane form above costs ~140 VALU per step -- more issue time than
+    // the step's 16 MFMAs.
+    const uint32_t lin_cb = a.transposed ? x_cb : d_cb, sft_cb = a.transposed ? d_cb : x_cb;
+    const bool lin_ch = a.transposed ? x_ch : d_ch, sft_ch = a.transposed ? d_ch : x_ch;
+    const uint32_t v_lin = lin_ch ? (uint32_t)lrow * lin_ps + lin_cb : OOB;
+    const uint32_t v_sft = sft_ch ? (uint32_t)(lrow * a.stride) * sh_ps + sft_cb : OOB;
+    const int lx = lrow * a.stride;
+    const uint32_t neg_b = (uint32_t)a.pad * sh_ps;             // the shifted operand's resource starts pad pixels early: soffset >= 0
+    const __amdgpu_buffer_rsrc_t lr = a.transposed ? xr : dr;
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)(a.transposed ? a.dy : a.x) - neg_b), 0, (int)OOB, 0x00020000);
+    uint32_t sq_w = (uint32_t)q_begin + (uint32_t)(wave * 16);
+    int sqx, sqy, sqb;
+    {
+        const uint32_t r1 = fdiv(sq_w, A.dqw);
+        sqx = (int)(sq_w - r1 * (uint32_t)a.QW);
+        const uint32_t b = fdiv(r1, A.dqh);
+        sqy = (int)(r1 - b * (uint32_t)a.QH);
+        sqb = (int)b;
+    }
+    auto issue_fast = [&](int buf) {
+        unsigned char* dt = smem + buf * STAGE;
+        unsigned char* xt = dt + TILE;
+        unsigned char* lt = a.transposed ? xt : dt;
+        unsigned char* stt = a.transposed ? dt : xt;
+        const bool inq = sq_w < (uint32_t)q_end;
+        const int sy = sqy * a.stride + sh_y, sxw = sqx * a.stride + sh_x;
+        const bool rowok = inq && (unsigned)sy < (unsigned)SH;
+        const uint32_t so_l = sq_w * lin_ps;
+        const uint32_t so_s = (uint32_t)(((sqb * SH + sy) * SW + sxw) * (int)sh_ps) + neg_b;
+        const uint32_t vl = inq ? v_lin : OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool okx = rowok && (unsigned)(sxw + 4 * i * a.stride + lx) < (unsigned)SW;
+            const uint32_t vs = okx ? v_sft : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (__attribute__((address_space(3))) void*)(lt + (wave * 4 + i) * 1024), 16, (int)vl,
+                                                     (int)(so_l + (uint32_t)(4 * i) * lin_ps), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(stt + (wave * 4 + i) * 1024), 16, (int)vs,
+                                                     (int)(so_s + (uint32_t)(4 * i * a.stride) * sh_ps), 0, 0);
+        }
+        sq_w += BK;
+        sqx += BK;
+        if (sqx >= a.QW) {
+            const uint32_t t = fdiv((uint32_t)sqx, A.dqw);
+            sqx -= (int)t * a.QW;
+            sqy += (int)t;
+            if (sqy >= a.QH) {
+                const uint32_t u = fdiv((uint32_t)sqy, A.dqh);
+                sqy -= (int)u * a.QH;
+                sqb += (int)u;
+            }
+        }
+    };
+
     const int wm = wave & 1, wn = wave >> 1;
     const int frow = lane & 31, fh = lane >> 5;
     const int g = lane >> 4, t = lane & 15;
@@ -336,8 +393,12 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const int64_t nsteps = (q_end - q_begin + BK - 1) / BK;
     // the transform of the X operand (|x| for the abs-conv of encode_hyper, x^2 for the GDN gamma gradient) is a
     // compile-time variant of the loop: no branches between the transpose reads and the MFMAs
-    auto main_loop = [&](auto abs_tag, auto sq_tag) {
-        constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value;
+    auto main_loop = [&](auto abs_tag, auto sq_tag, auto fast_tag) {
+        constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value, FASTQ = decltype(fast_tag)::value;
+        auto issue = [&](int buf) {
+            if constexpr (FASTQ) issue_fast(buf);
+            else issue_slow(buf);
+        };
         if (nsteps > 0) issue(0);
         for (int64_t step = 0; step < nsteps; ++step) {
             const int buf = step & 1;
@@ -396,9 +457,15 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
             }
         }
     };
-    if (a.in_sq) main_loop(std::false_type{}, std::true_type{});
-    else if (a.in_abs) main_loop(std::true_type{}, std::false_type{});
-    else main_loop(std::false_type{}, std::false_type{});
+    if (A.fastq) {
+        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::true_type{});
+        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::true_type{});
+        else main_loop(std::false_type{}, std::false_type{}, std::true_type{});
+    } else {
+        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::false_type{});
+        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::false_type{});
+        else main_loop(std::false_type{}, std::false_type{}, std::false_type{});
+    }
 
     float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
 #pragma unroll
@@ -1021,6 +1088,8 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
     A.w = a;
     A.dqw = make_fastdiv((uint32_t)a.QW);
     A.dqh = make_fastdiv((uint32_t)a.QH);
+    static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
+    A.fastq = (!slow && a.QW % 16 == 0 && a.chunk % 64 == 0) ? 1 : 0;
     hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, A);
 }
 

@@ -86,12 +86,14 @@ class Trainer:
     """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295)
     and, when a process group is up, one reducer per optimiser group."""
 
-    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=False):
+    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=False, capturable=False):
         self.model, self.lmbda = model, float(lmbda)
         main, aux = list(model.parameters()), list(model.aux_parameters())
         # multi-tensor (foreach) Adam by default: on this ROCm build the fused Adam kernel takes visibly
         # smaller first steps than the reference's plain Adam (measured: loss 220.4 -> 216.1 vs 220.3 -> 187.0)
         kw = {"fused": True} if fused else {}
+        if capturable:            # step counters live on the device: the update can be recorded into a HIP graph
+            kw["capturable"] = True
         self.optimizer = torch.optim.Adam(main, lr=lr, **kw)
         self.aux_optimizer = torch.optim.Adam(aux, lr=aux_lr, **kw)
         # EB matrices/biases/factors get their gradient from the main backward but are stepped by the aux
@@ -130,8 +132,63 @@ class Trainer:
         aux.backward()
         self._reduce_aux()
         self.aux_optimizer.step()
+        # detached scalars only: a returned loss that still requires grad would keep this step's autograd graph (and its
+        # AccumulateGrad nodes, bound to this step's stream) alive into the next one
+        crit = {k: v.detach() for k, v in crit.items()}
         crit["aux_loss"] = aux.detach()
         return crit
+
+
+class GraphedTrainer(Trainer):
+    """``Trainer.step`` recorded once into a HIP graph and replayed (single process; with a process group the eager
+    ``Trainer`` and its overlapped all-reduce is the path).
+
+    One training step is ~600 launches, most of them a few microseconds long: eagerly the Python/ctypes launch work
+    (~12 ms at B=8, 256x256) exceeds the GPU time (~9.6 ms), so the step is host-bound.  The first ``warmup`` calls run
+    eagerly on a side stream (they are real steps: they pack weights, size workspaces and let autograd allocate), the next
+    call captures zero_grad -> forward -> R-D backward -> Adam -> aux backward -> aux Adam and every later call is a copy
+    of the inputs into the static buffers plus one graph launch.  The quantisation noise is drawn inside the graph by
+    the graph-safe Philox generator unless a ``noise`` dict is given at capture time (then it is a static input too).
+    The returned dict holds the graph's static loss tensors (overwritten by the next call)."""
+
+    def __init__(self, model, *args, warmup=3, **kw):
+        kw["capturable"] = True
+        super().__init__(model, *args, **kw)
+        if self.world != 1:
+            raise RuntimeError("GraphedTrainer is single-process: use Trainer under torch.distributed")
+        self.warmup, self.calls, self.graph = int(warmup), 0, None
+        self._in = self._noise = self._out = None
+
+    def _stage(self, x1, x2, h_matrix, noise):
+        if self._in is None:
+            self._in = (x1.clone(), x2.clone(), h_matrix.clone())
+            self._noise = None if noise is None else {k: v.clone() for k, v in noise.items()}
+        else:
+            for dst, src in zip(self._in, (x1, x2, h_matrix)):
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src)
+            if self._noise is not None:
+                if noise is None:
+                    raise RuntimeError("GraphedTrainer: the step was captured with explicit noise tensors")
+                for k, dst in self._noise.items():
+                    dst.copy_(noise[k])
+
+    def step(self, x1, x2, h_matrix, noise=None):
+        self._stage(x1, x2, h_matrix, noise)
+        self.calls += 1
+        if self.graph is None and self.calls <= self.warmup:
+            side = torch.cuda.Stream(device=x1.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = super().step(*self._in, noise=self._noise)
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        if self.graph is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._out = super().step(*self._in, noise=self._noise)
+        self.graph.replay()
+        return self._out
 
 
 def init_distributed(backend=None):

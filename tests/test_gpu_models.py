@@ -219,3 +219,39 @@ def test_graphed_forward_replays_the_eager_result():
             assert abs(models.metrics_from(got_rd)["bpp"] - models.metrics_from(want_rd)["bpp"]) < 1e-9     # fp64 atomics: order-free to ~1e-16
     finally:
         hesic_amd.set_compute_dtype(prev)
+
+
+def test_graphed_trainer_follows_the_eager_trace():
+    """Whole training step (zero_grad -> forward -> R-D backward -> Adam -> aux backward -> aux Adam) captured into a HIP
+    graph: with the same injected noise the replayed steps give the eager Trainer's loss trace and parameters."""
+    import hesic_amd
+    from hesic_amd import models
+    from hesic_amd.train import Trainer, GraphedTrainer
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 2, 128, 128))
+        def noise_for(step):
+            shp = {"z1": (2, 128, 2, 2), "z2": (2, 128, 2, 2)}
+            return {k: synthetic._uniform(f"gt.noise.{step}.{k}", shp.get(k, (2, 192, 8, 8)), -0.5, 0.5).cuda()
+                    for k in ("z1", "y1", "y1w", "z2", "y2")}
+        traces, finals = [], []
+        for cls, kw in ((Trainer, {}), (GraphedTrainer, {"warmup": 2})):
+            net = models.HSIC()
+            synthetic.fill_state_dict_(net.state_dict())
+            net = net.cuda()
+            tr = cls(net, lr=1e-4, aux_lr=1e-3, lmbda=0.0067, **kw)
+            trace = []
+            for step in range(5):
+                c = tr.step(x1, x2, Hm, noise=noise_for(step))
+                trace.append([float(c["loss"]), float(c["bpp_loss"]), float(c["mse_loss"]), float(c["aux_loss"])])
+            traces.append(trace)
+            finals.append({k: v.detach().float().clone() for k, v in net.named_parameters()})
+        assert tr.graph is not None                       # steps 3 and 4 were graph replays
+        for a, b in zip(*traces):
+            for u, v in zip(a, b):
+                assert u == pytest.approx(v, rel=2e-3), traces
+        for k in ("encoder1.g_a_conv2.weight", "decoder2.after_conv.bias", "entropy_bottleneck1._biases.0", "entropy_bottleneck1.quantiles"):
+            torch.testing.assert_close(finals[1][k], finals[0][k], rtol=1e-2, atol=2e-4)
+    finally:
+        hesic_amd.set_compute_dtype(prev)
