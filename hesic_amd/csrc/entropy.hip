@@ -426,6 +426,93 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
     HESIC_LAUNCH_RETURN("eb_backward");
 }
 
+// Branch-free erfc for the bf16 path: erfc(a) = exp(-a^2) * P((a-2)/(a+2)) / (1 + 2a) for a >= 0 (P: degree-10 least-squares
+// fit of erfcx(a)(1+2a) on a in [0, 10.2], max relative error 1.8e-7 in fp32 Horner form), erfc(-a) = 2 - erfc(a); a^2 is
+// split into its rounded value and the fma remainder so exp keeps ~2e-6 relative accuracy out to the 1e-9 likelihood
+// floor.  ocml's erfcf is range-split (divergent lanes run several ranges) and cost ~45 VALU instructions per call, ten
+// calls per latent: the kernel was VALU-bound at 2.7 TB/s.
+__device__ __forceinline__ float erfc_fast(float z) {
+    const float a = fabsf(z);
+    const float p = (a - 2.f) * __builtin_amdgcn_rcpf(a + 2.f);
+    float q = 5.535401624402612e-05f;
+    q = fmaf(q, p, -0.0003277268339344692f);
+    q = fmaf(q, p, -0.0012812873942078364f);
+    q = fmaf(q, p, 0.001231548543911547f);
+    q = fmaf(q, p, 0.008647743766865298f);
+    q = fmaf(q, p, -0.008028522672854756f);
+    q = fmaf(q, p, -0.054206538593428145f);
+    q = fmaf(q, p, 0.16405084760016128f);
+    q = fmaf(q, p, -0.1660312591225932f);
+    q = fmaf(q, p, -0.0927638072951173f);
+    q = fmaf(q, p, 1.2769783903081213f);
+    const float s2 = a * a, el = fmaf(a, a, -s2);
+    float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * s2);
+    ex = fmaf(-el, ex, ex);
+    const float ec = q * __builtin_amdgcn_rcpf(fmaf(2.f, a, 1.f)) * ex;
+    return z >= 0.f ? ec : 2.f - ec;
+}
+__device__ __forceinline__ float phi_cdf_fast(float x) { return 0.5f * erfc_fast(-0.70710678118654752440f * x); }
+
+// bf16 fast form of gmm_fwd_kernel: one thread = two neighbouring channels of a pixel (4-byte loads), K a template
+// parameter so the 2K parameter loads of a thread are all in flight before the first erfc (the generic kernel's run-time
+// K loop made them K serial HBM round trips: 44 % of its wave cycles were parked at s_waitcnt), 32-bit indexing.
+template <int K>
+__global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc d, const bf16_t* __restrict__ y, const bf16_t* __restrict__ scales,
+                                                           const bf16_t* __restrict__ means, const float* __restrict__ weights,
+                                                           const bf16_t* __restrict__ noise, bf16_t* __restrict__ yhat, float* __restrict__ lik,
+                                                           int32_t* __restrict__ sym, FastDiv fd_m2) {
+    const int M2 = d.M >> 1;
+    const uint32_t total = (uint32_t)d.B * (uint32_t)d.HW * (uint32_t)M2;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const uint32_t p = fdiv(j, fd_m2);
+        const int m = (int)(j - p * (uint32_t)M2) * 2;
+        const int b = (int)(p / (uint32_t)d.HW);
+        const int64_t i = (int64_t)p * d.M + m;
+        const int64_t sm = (int64_t)p * d.sm_pix_stride + m;
+        const uint32_t yr = *(const uint32_t*)(y + i);
+        uint32_t mr[K], sr[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            mr[k] = *(const uint32_t*)(means + sm + d.m_c_off + k * d.M);
+            sr[k] = *(const uint32_t*)(scales + sm + d.s_c_off + k * d.M);
+        }
+        f32x2 wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k] = weights ? *(const f32x2*)(weights + (int64_t)b * d.K * d.M + k * d.M + m) : f32x2{1.f, 1.f};
+        const uint32_t nr = noise ? *(const uint32_t*)(noise + i) : 0u;
+        float out_v[2], out_l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float yv = __uint_as_float(e ? (yr & 0xffff0000u) : (yr << 16));
+            float v;
+            if (noise) {
+                v = yv + __uint_as_float(e ? (nr & 0xffff0000u) : (nr << 16));
+            } else if (d.use_means_in_quant) {
+                const float mu = __uint_as_float(e ? (mr[0] & 0xffff0000u) : (mr[0] << 16));
+                const float r = rintf(yv - mu);
+                if (sym) sym[i + e] = (int32_t)r;
+                v = r + mu;
+            } else {
+                v = rintf(yv);
+                if (sym) sym[i + e] = (int32_t)v;
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float mu = __uint_as_float(e ? (mr[k] & 0xffff0000u) : (mr[k] << 16));
+                const float sc = fmaxf(__uint_as_float(e ? (sr[k] & 0xffff0000u) : (sr[k] << 16)), d.scale_bound);
+                const float a = fabsf(v - mu), inv = __builtin_amdgcn_rcpf(sc);
+                const float pk = phi_cdf_fast((0.5f - a) * inv) - phi_cdf_fast((-0.5f - a) * inv);
+                acc += weights ? pk * (e ? wk[k].y : wk[k].x) : pk;
+            }
+            out_v[e] = v;
+            out_l[e] = fmaxf(acc, d.lik_bound);
+        }
+        *(uint32_t*)(yhat + i) = (uint32_t)f2bf(out_v[0]) | ((uint32_t)f2bf(out_v[1]) << 16);
+        *(f32x2*)(lik + i) = f32x2{out_l[0], out_l[1]};
+    }
+}
+
 extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
                                  const float* weights, const void* noise, void* y_hat, float* lik, int32_t* symbols,
                                  void* stream) {
@@ -434,7 +521,22 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_forward: weights required for K > 1");
     const int64_t total = (int64_t)d->B * d->HW * d->M;
     const dim3 grid(grid_for(total, 256));
-    if (d->dtype == HESIC_BF16)
+    // pair form: even channel geometry (4-byte bf16 pairs, 8-byte fp32 pairs), 32-bit pair index
+    static const bool no_pair = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
+    const bool pair = !no_pair && d->dtype == HESIC_BF16 && (d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 &&
+                      d->s_c_off % 2 == 0 && d->m_c_off % 2 == 0 && total / 2 < (1ll << 31) && !((uintptr_t)y & 3) &&
+                      !((uintptr_t)scales & 3) && !((uintptr_t)means & 3) && !((uintptr_t)noise & 3) && !((uintptr_t)y_hat & 3) &&
+                      !((uintptr_t)lik & 7) && !((uintptr_t)weights & 7);
+    if (pair) {
+        const dim3 g2(grid_for(total / 2, 256));
+        const FastDiv fd = make_fastdiv((uint32_t)(d->M / 2));
+        if (d->K == 5)
+            hipLaunchKernelGGL(gmm_fwd_pair_kernel<5>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y, (const bf16_t*)scales,
+                               (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols, fd);
+        else
+            hipLaunchKernelGGL(gmm_fwd_pair_kernel<1>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y, (const bf16_t*)scales,
+                               (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols, fd);
+    } else if (d->dtype == HESIC_BF16)
         hipLaunchKernelGGL(gmm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
                            (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols);
     else

@@ -252,6 +252,8 @@ def test_graphed_trainer_follows_the_eager_trace():
             for u, v in zip(a, b):
                 assert u == pytest.approx(v, rel=2e-3), traces
         for k in ("encoder1.g_a_conv2.weight", "decoder2.after_conv.bias", "entropy_bottleneck1._biases.0", "entropy_bottleneck1.quantiles"):
-            torch.testing.assert_close(finals[1][k], finals[0][k], rtol=1e-2, atol=2e-4)
+            # Adam moves an element by <= lr per step whatever the gradient's size: where a ~0 gradient flips sign between two
+            # runs (bf16 + atomics are not run-to-run bit-stable) the two trajectories drift by up to 2 * lr per step
+            torch.testing.assert_close(finals[1][k], finals[0][k], rtol=1e-2, atol=2 * 5 * 1e-3 if "entropy_bottleneck" in k else 2 * 5 * 1e-4 + 1e-4)
     finally:
         hesic_amd.set_compute_dtype(prev)
