@@ -203,6 +203,33 @@ __global__ __launch_bounds__(64) void eb_bwd_kernel(const T* __restrict__ z, con
 __device__ __forceinline__ float phi_cdf(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
 __device__ __forceinline__ float phi_pdf(float x) { return 0.39894228040143267794f * expf(-0.5f * x * x); }
 
+// Branch-free erfc for the bf16 path: erfc(a) = exp(-a^2) * P((a-2)/(a+2)) / (1 + 2a) for a >= 0 (P: degree-10 least-squares
+// fit of erfcx(a)(1+2a) on a in [0, 10.2], max relative error 1.8e-7 in fp32 Horner form), erfc(-a) = 2 - erfc(a); a^2 is
+// split into its rounded value and the fma remainder so exp keeps ~2e-6 relative accuracy out to the 1e-9 likelihood
+// floor.  ocml's erfcf is range-split (divergent lanes run several ranges) and cost ~45 VALU instructions per call, ten
+// calls per latent: the kernel was VALU-bound at 2.7 TB/s.
+__device__ __forceinline__ float erfc_fast(float z) {
+    const float a = fabsf(z);
+    const float p = (a - 2.f) * __builtin_amdgcn_rcpf(a + 2.f);
+    float q = 5.535401624402612e-05f;
+    q = fmaf(q, p, -0.0003277268339344692f);
+    q = fmaf(q, p, -0.0012812873942078364f);
+    q = fmaf(q, p, 0.001231548543911547f);
+    q = fmaf(q, p, 0.008647743766865298f);
+    q = fmaf(q, p, -0.008028522672854756f);
+    q = fmaf(q, p, -0.054206538593428145f);
+    q = fmaf(q, p, 0.16405084760016128f);
+    q = fmaf(q, p, -0.1660312591225932f);
+    q = fmaf(q, p, -0.0927638072951173f);
+    q = fmaf(q, p, 1.2769783903081213f);
+    const float s2 = a * a, el = fmaf(a, a, -s2);
+    float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * s2);
+    ex = fmaf(-el, ex, ex);
+    const float ec = q * __builtin_amdgcn_rcpf(fmaf(2.f, a, 1.f)) * ex;
+    return z >= 0.f ? ec : 2.f - ec;
+}
+__device__ __forceinline__ float phi_cdf_fast(float x) { return 0.5f * erfc_fast(-0.70710678118654752440f * x); }
+
 constexpr int GMM_MAXK = 8;
 
 template <typename T>
@@ -306,7 +333,9 @@ __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restric
 }
 
 // block = 64 channels x 4 pixel lanes; grid = (M/64, pixel chunks, B): dweights reduced in-block first
-template <typename T>
+// KT > 0: mixture count known at compile time (all 3K parameter loads of a pixel in flight at once, arrays in registers)
+// and, for the bf16 path it is used on, the branch-free erfc / hardware reciprocal and exp2; KT == 0: run-time K, ocml math.
+template <typename T, int KT>
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, const T* __restrict__ y,
                                                       const T* __restrict__ scales, const T* __restrict__ means,
                                                       const float* __restrict__ weights, const T* __restrict__ noise,
@@ -318,9 +347,11 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, co
     const int m = blockIdx.x * 64 + ml;
     const int b = blockIdx.z;
     const int hw0 = blockIdx.y * pix_per_block;
-    float dw[GMM_MAXK];
+    const int KK = KT > 0 ? KT : d.K;
+    constexpr int KA = KT > 0 ? KT : GMM_MAXK;
+    float dw[KA];
 #pragma unroll
-    for (int k = 0; k < GMM_MAXK; ++k) dw[k] = 0.f;
+    for (int k = 0; k < KA; ++k) dw[k] = 0.f;
     if (m < d.M) {
         for (int hw = hw0 + pl; hw < hw0 + pix_per_block && hw < d.HW; hw += 4) {
             const int64_t p = (int64_t)b * d.HW + hw;
@@ -331,28 +362,50 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, co
             if (noise) v = yv + elem<T>::ld(noise + i);
             else if (d.use_means_in_quant) { const float mu = elem<T>::ld(means + sm + d.m_c_off); v = rintf(yv - mu) + mu; }
             else v = rintf(yv);
-            float pk[GMM_MAXK], mu[GMM_MAXK], s[GMM_MAXK], sraw[GMM_MAXK], wk[GMM_MAXK];
+            float pk[KA], mu[KA], s[KA], sraw[KA], wk[KA], is[KA];
             float L = 0.f;
-            for (int k = 0; k < d.K; ++k) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                if (k >= KK) break;
                 mu[k] = elem<T>::ld(means + sm + d.m_c_off + k * d.M);
                 sraw[k] = elem<T>::ld(scales + sm + d.s_c_off + k * d.M);
-                s[k] = fmaxf(sraw[k], d.scale_bound);
                 wk[k] = weights ? weights[(int64_t)b * d.K * d.M + k * d.M + m] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                if (k >= KK) break;
+                s[k] = fmaxf(sraw[k], d.scale_bound);
                 const float a = fabsf(v - mu[k]);
-                pk[k] = phi_cdf((0.5f - a) / s[k]) - phi_cdf((-0.5f - a) / s[k]);
+                if constexpr (KT > 0) {
+                    is[k] = __builtin_amdgcn_rcpf(s[k]);
+                    pk[k] = phi_cdf_fast((0.5f - a) * is[k]) - phi_cdf_fast((-0.5f - a) * is[k]);
+                } else {
+                    is[k] = 1.f / s[k];
+                    pk[k] = phi_cdf((0.5f - a) / s[k]) - phi_cdf((-0.5f - a) / s[k]);
+                }
                 L += wk[k] * pk[k];
             }
             float g = glik[i];
             if (!(L >= d.lik_bound || g < 0.f)) g = 0.f;
             float dv_sum = 0.f;
-            for (int k = 0; k < d.K; ++k) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                if (k >= KK) break;
                 dw[k] += g * pk[k];
                 const float df = v - mu[k];
                 const float a = fabsf(df), sg = signf(df);
-                const float u = (0.5f - a) / s[k], l = (-0.5f - a) / s[k];
-                const float ak = g * wk[k] * phi_pdf(u), ck = -g * wk[k] * phi_pdf(l);
-                const float dvk = -(ak + ck) / s[k];                      // d/d|v-mu|
-                float dsk = -(ak * u + ck * l) / s[k];
+                float u, l, pu, pl_, dvk, dsk;
+                if constexpr (KT > 0) {
+                    u = (0.5f - a) * is[k]; l = (-0.5f - a) * is[k];
+                    pu = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170f * u * u);
+                    pl_ = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170f * l * l);
+                } else {
+                    u = (0.5f - a) / s[k]; l = (-0.5f - a) / s[k];
+                    pu = phi_pdf(u); pl_ = phi_pdf(l);
+                }
+                const float ak = g * wk[k] * pu, ck = -g * wk[k] * pl_;
+                if constexpr (KT > 0) { dvk = -(ak + ck) * is[k]; dsk = -(ak * u + ck * l) * is[k]; }
+                else { dvk = -(ak + ck) / s[k]; dsk = -(ak * u + ck * l) / s[k]; }
                 if (!(sraw[k] >= d.scale_bound || dsk < 0.f)) dsk = 0.f;  // LowerBound on the scale
                 float dmu = -dvk * sg;
                 dv_sum += dvk * sg;
@@ -373,10 +426,10 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, co
     }
     if (dweights) {
 #pragma unroll
-        for (int k = 0; k < GMM_MAXK; ++k) red[pl][ml][k] = dw[k];
+        for (int k = 0; k < KA; ++k) red[pl][ml][k] = dw[k];
         __syncthreads();
         if (pl == 0 && m < d.M)
-            for (int k = 0; k < d.K; ++k)
+            for (int k = 0; k < KK; ++k)
                 atomicAdd(dweights + (int64_t)b * d.K * d.M + k * d.M + m, red[0][ml][k] + red[1][ml][k] + red[2][ml][k] + red[3][ml][k]);
     }
 }
@@ -425,33 +478,6 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
                            (const float*)noise, g_lik, (const float*)g_zhat, (float*)dz, dparams, P, C);
     HESIC_LAUNCH_RETURN("eb_backward");
 }
-
-// Branch-free erfc for the bf16 path: erfc(a) = exp(-a^2) * P((a-2)/(a+2)) / (1 + 2a) for a >= 0 (P: degree-10 least-squares
-// fit of erfcx(a)(1+2a) on a in [0, 10.2], max relative error 1.8e-7 in fp32 Horner form), erfc(-a) = 2 - erfc(a); a^2 is
-// split into its rounded value and the fma remainder so exp keeps ~2e-6 relative accuracy out to the 1e-9 likelihood
-// floor.  ocml's erfcf is range-split (divergent lanes run several ranges) and cost ~45 VALU instructions per call, ten
-// calls per latent: the kernel was VALU-bound at 2.7 TB/s.
-__device__ __forceinline__ float erfc_fast(float z) {
-    const float a = fabsf(z);
-    const float p = (a - 2.f) * __builtin_amdgcn_rcpf(a + 2.f);
-    float q = 5.535401624402612e-05f;
-    q = fmaf(q, p, -0.0003277268339344692f);
-    q = fmaf(q, p, -0.0012812873942078364f);
-    q = fmaf(q, p, 0.001231548543911547f);
-    q = fmaf(q, p, 0.008647743766865298f);
-    q = fmaf(q, p, -0.008028522672854756f);
-    q = fmaf(q, p, -0.054206538593428145f);
-    q = fmaf(q, p, 0.16405084760016128f);
-    q = fmaf(q, p, -0.1660312591225932f);
-    q = fmaf(q, p, -0.0927638072951173f);
-    q = fmaf(q, p, 1.2769783903081213f);
-    const float s2 = a * a, el = fmaf(a, a, -s2);
-    float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * s2);
-    ex = fmaf(-el, ex, ex);
-    const float ec = q * __builtin_amdgcn_rcpf(fmaf(2.f, a, 1.f)) * ex;
-    return z >= 0.f ? ec : 2.f - ec;
-}
-__device__ __forceinline__ float phi_cdf_fast(float x) { return 0.5f * erfc_fast(-0.70710678118654752440f * x); }
 
 // bf16 fast form of gmm_fwd_kernel: one thread = two neighbouring channels of a pixel (4-byte loads), K a template
 // parameter so the 2K parameter loads of a thread are all in flight before the first erfc (the generic kernel's run-time
@@ -568,14 +594,31 @@ extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const 
     if (int e = check_gmm(d, "gmm_backward")) return e;
     HESIC_CHECK_ARG(y && scales && means && g_lik && dy && dscales && dmeans, "gmm_backward: null pointer");
     HESIC_CHECK_ARG((weights && dweights) || d->K == 1, "gmm_backward: weights/dweights required for K > 1");
-    const int ppb = 64;
+    // pixels per block: 64 on big maps, fewer (>= 4, one per pixel lane group) when that is what it takes to put ~1000 blocks
+    // on the chip -- a 16x16 latent map at 64 pixels per block was 96 blocks of 16 serial iterations each
+    const int other = ((d->M + 63) / 64) * d->B;
+    const int want = (1024 + other - 1) / other;
+    int ppb = (d->HW + want - 1) / want;
+    ppb = (ppb + 3) / 4 * 4;
+    if (ppb < 4) ppb = 4;
+    if (ppb > 64) ppb = 64;
     const dim3 grid((d->M + 63) / 64, (d->HW + ppb - 1) / ppb, d->B);
-    if (d->dtype == HESIC_BF16)
-        hipLaunchKernelGGL(gmm_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
+    static const bool slow_bwd = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
+    if (d->dtype == HESIC_BF16 && !slow_bwd && (d->K == 5 || d->K == 1)) {
+        if (d->K == 5)
+            hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 5>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
+                               (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
+                               (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
+        else
+            hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
+                               (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
+                               (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
+    } else if (d->dtype == HESIC_BF16)
+        hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
                            (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
                            (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
     else
-        hipLaunchKernelGGL(gmm_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
+        hipLaunchKernelGGL((gmm_bwd_kernel<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
                            (const float*)scales, (const float*)means, weights, (const float*)noise, g_lik,
                            (const float*)g_yhat, (float*)dy, (float*)dscales, (float*)dmeans, dweights, ppb);
     HESIC_LAUNCH_RETURN("gmm_backward");
