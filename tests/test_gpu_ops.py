@@ -563,3 +563,82 @@ def test_fused_image_conv_gdn():
         Fn.set_compute_dtype(torch.float32)
     assert y.shape == ref.shape and y.dtype == torch.bfloat16
     assert rel_err(y, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("hw", [(50, 70), (51, 71), (2, 2), (130, 34)], ids=["even_w", "odd_w_generic", "tiny", "tall"])
+@pytest.mark.parametrize("inv", [False, True], ids=["gdn", "igdn"])
+def test_fused_image_conv_gdn_shapes(hw, inv):
+    """conv1 + GDN in one kernel on sizes that end in partial wave tiles: even widths take the 8-byte buffer-load form
+    (poisoned offsets for the padding), odd widths the generic gather -- both against the oracle on bf16-rounded operands."""
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=13)
+    x = rnd(f"fis_x{hw}", (3, 3) + hw, 0, 1)
+    w = rnd("fis_w", (128, 3, 5, 5)) * 0.25
+    b = rnd("fis_b", (128,), -0.1, 0.1)
+    ref = O.gdn(O.conv(bf(x), bf(w), b, 2), sd["g.beta"], sd["g.gamma"], inv)
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            y = Fn.conv2d_gdn(x.to(DEV), w.to(DEV), b.to(DEV), sd["g.beta"].to(DEV), sd["g.gamma"].to(DEV), kernel_size=5, stride=2,
+                              padding=2, transposed=False, inverse=inv, beta_min=1e-6, packer=None, gdn_packer=Fn.PackedGdn())
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("hw", [(23, 37), (6, 14), (7, 15), (1, 1), (64, 5)])
+def test_wide_to_narrow_deconv_shapes(hw):
+    """g_s_conv4 (128 -> 3 transposed, splat GEMM + col2im): input maps that end in partial 6x14 patches."""
+    Fn, O = _imp()
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        f = bf(rnd(f"w2n_f{hw}", (2, 128) + hw))
+        wt = rnd("w2n_w", (128, 3, 5, 5)) * 0.05
+        bt = rnd("w2n_b", (3,), -0.1, 0.1)
+        with torch.no_grad():
+            y = Fn.conv2d(f.to(DEV, torch.bfloat16), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        ref = O.deconv(f, bf(wt), bt, 2)
+        assert y.shape == ref.shape and y.dtype == torch.float32
+        # the MFMA kernel multiplies bf16-rounded weights exactly like the oracle call; a 1x1 map (ambiguous NHWC strides) takes
+        # the scalar kernel, which keeps the fp32 weights: bf16 bar
+        assert rel_err(y, ref) < (6e-3 if hw == (1, 1) else 1e-4)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+
+
+def test_gmm_bf16_fast_path_matches_fp32_path():
+    """bf16 storage takes the pair-per-thread forward and the compile-time-K backward with the branch-free erfc: the
+    likelihoods stay within 2e-5 of the fp32 (ocml erfc) kernels run on the same bf16-rounded operands, rounded latents
+    are identical, gradients agree to bf16 resolution."""
+    Fn, _ = _imp()
+    B, M, H, W, K = 2, 192, 6, 10, 5
+    y = bf(rnd("gb_y", (B, M, H, W), -6, 6))
+    sc = bf(rnd("gb_s", (B, K * M, H, W), 0.02, 3))
+    mu = bf(rnd("gb_m", (B, K * M, H, W), -2, 2))
+    wt = torch.softmax(rnd("gb_w", (B, K, M), -1, 1), 1).reshape(B, K * M, 1, 1)
+    gl = rnd("gb_gl", (B, M, H, W), -1, 1)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        Fn.set_compute_dtype(dt)
+        try:
+            ins = [t.to(DEV, dt).contiguous(memory_format=torch.channels_last).requires_grad_() for t in (y, sc, mu)]
+            wd = wt.to(DEV).requires_grad_()
+            yh, lik = Fn.gaussian_mixture(ins[0], ins[1], ins[2], wd, K=K)
+            (lik * gl.to(DEV)).sum().backward()
+            res[dt] = (yh.detach().float().cpu(), lik.detach().cpu(), [t.grad.float().cpu() for t in ins[1:]], wd.grad.cpu())
+            # K == 1 with the mean in the quantiser (GaussianConditional)
+            i1 = [t.to(DEV, dt).contiguous(memory_format=torch.channels_last) for t in (y, sc[:, :M], mu[:, :M])]
+            yh1, lik1 = Fn.gaussian_conditional(i1[0], i1[1], means=i1[2])
+            res[dt] += (yh1.float().cpu(), lik1.cpu())
+        finally:
+            Fn.set_compute_dtype(torch.float32)
+    f, h = res[torch.float32], res[torch.bfloat16]
+    assert torch.equal(f[0], h[0])
+    torch.testing.assert_close(h[1], f[1], rtol=2e-5, atol=1e-9)
+    for a, b_ in zip(h[2], f[2]):
+        assert rel_err(a, b_) < 1e-2
+    assert rel_err(h[3], f[3]) < 1e-3
+    assert torch.equal(bf(f[4]), h[4])          # round(y - mu) + mu, stored in bf16
+    torch.testing.assert_close(h[5], f[5], rtol=2e-5, atol=1e-9)
