@@ -89,6 +89,8 @@ _SIGS = {
     "hesic_copy_channels": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_spatial_max": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_mix_weights_forward": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_pooled_linear_forward": ([_vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
+    "hesic_pooled_linear_backward": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_softmax_k_forward": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_softmax_k_backward": ([_vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_sum_log2": ([_vp, _i64, _vp, _vp], _i32),

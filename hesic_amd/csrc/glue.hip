@@ -180,6 +180,38 @@ __global__ __launch_bounds__(256) void mix_logits_kernel(const float* __restrict
     if (lane == 0) logits[(int64_t)b * N + n] = acc + (bias ? bias[n] : 0.f);
 }
 
+// Backward of logits = W pooled + bias on the pooled (B, N) vector (training form of the head; the conv kernels would run
+// a 128x128 tile pipeline for 8 "pixels"): dpooled[b, j] = sum_n g[b, n] W[n, j] -- one thread per (b, j), rows of W read
+// coalesced; dW[n, j] = sum_b g[b, n] pooled[b, j], dbias[n] = sum_b g[b, n] -- one thread per element, fixed b order.
+__global__ __launch_bounds__(256) void pooled_linear_dx_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                               float* __restrict__ dpooled, int B, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= N) return;
+    const float* gb = g + (int64_t)b * N;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(gb[n + u], w[(int64_t)(n + u) * N + j], acc[u]);
+    }
+    for (; n < N; ++n) acc[0] = fmaf(gb[n], w[(int64_t)n * N + j], acc[0]);
+    dpooled[(int64_t)b * N + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(256) void pooled_linear_dw_kernel(const float* __restrict__ pooled, const float* __restrict__ g,
+                                                               float* __restrict__ dw, float* __restrict__ dbias, int B, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (j >= N) return;
+    float acc = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float gv = g[(int64_t)b * N + n];
+        acc = fmaf(gv, pooled[(int64_t)b * N + j], acc);
+        sb += gv;
+    }
+    dw[(int64_t)n * N + j] = acc;
+    if (dbias && j == 0) dbias[n] = sb;
+}
+
 __global__ void softmax_k_kernel(const float* __restrict__ logits, float* __restrict__ weights, int B, int K, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * M) return;
@@ -378,6 +410,24 @@ extern "C" int hesic_mix_weights_forward(const float* pooled, const float* w, co
     hipLaunchKernelGGL(mix_logits_kernel, dim3((unsigned)cdiv64(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, pooled, w, bias, logits, B, N);
     hipLaunchKernelGGL(softmax_k_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, weights, B, K, M);
     HESIC_LAUNCH_RETURN("mix_weights_forward");
+}
+
+extern "C" int hesic_pooled_linear_forward(const float* pooled, const float* w, const float* bias, float* logits, int B, int N,
+                                           void* stream) {
+    HESIC_CHECK_ARG(pooled && w && logits && B > 0 && N > 0, "pooled_linear_forward: bad arguments");
+    hipLaunchKernelGGL(mix_logits_kernel, dim3((unsigned)cdiv64((int64_t)B * N * 64, 256)), dim3(256), 0, (hipStream_t)stream, pooled, w, bias,
+                       logits, B, N);
+    HESIC_LAUNCH_RETURN("pooled_linear_forward");
+}
+
+extern "C" int hesic_pooled_linear_backward(const float* pooled, const float* w, const float* g, float* dpooled, float* dw, float* dbias,
+                                            int B, int N, void* stream) {
+    HESIC_CHECK_ARG(pooled && w && g && B > 0 && N > 0 && N <= 65535 && B <= 65535, "pooled_linear_backward: bad arguments");
+    if (dpooled)
+        hipLaunchKernelGGL(pooled_linear_dx_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, w, g, dpooled, B, N);
+    if (dw)
+        hipLaunchKernelGGL(pooled_linear_dw_kernel, dim3((N + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, pooled, g, dw, dbias, B, N);
+    HESIC_LAUNCH_RETURN("pooled_linear_backward");
 }
 
 extern "C" int hesic_softmax_k_forward(const float* logits, float* weights, int B, int K, int M, void* stream) {

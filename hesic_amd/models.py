@@ -194,6 +194,8 @@ def _mixture_weights(head, feat, K, M):
     pooled = Fn.spatial_max(feat, leaky=True)
     c1 = head[5]
     if torch.is_grad_enabled() and (pooled.requires_grad or c1.weight.requires_grad):
+        if pooled.is_cuda and c1.weight.shape[-1] == 1 and c1.weight.shape[0] == c1.weight.shape[1] == pooled.shape[1]:
+            return Fn.softmax_k(Fn.pooled_linear(pooled, c1.weight, c1.bias), K, M)
         return Fn.softmax_k(c1.run(pooled), K, M)
     return Fn.mix_weights(pooled, c1.weight, c1.bias, K, M)
 

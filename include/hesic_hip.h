@@ -226,6 +226,13 @@ int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW,
 int hesic_mix_weights_forward(const float* pooled, const float* w, const float* bias, float* logits, float* weights,
                               int B, int K, int M, void* stream);
 
+/* The same 1x1 conv on the pooled vector as a differentiable pair (training form of newnet1.py:500; N = K*M):
+ * logits (B,N) = pooled (B,N) @ W^T (N,N) + bias; backward: dpooled = g @ W, dw = g^T @ pooled, dbias = sum_b g.
+ * All fp32, W in the Conv2d layout (N, N, 1, 1).  dpooled / dw / dbias may be NULL (not needed).       */
+int hesic_pooled_linear_forward(const float* pooled, const float* w, const float* bias, float* logits, int B, int N, void* stream);
+int hesic_pooled_linear_backward(const float* pooled, const float* w, const float* g, float* dpooled, float* dw, float* dbias,
+                                 int B, int N, void* stream);
+
 /* softmax over K of logits laid out (B, K*M) with channel k*M+m, and its backward
  * dlogits = w * (g - sum_k g*w).                                                                       */
 int hesic_softmax_k_forward(const float* logits, float* weights, int B, int K, int M, void* stream);

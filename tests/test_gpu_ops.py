@@ -642,3 +642,23 @@ def test_gmm_bf16_fast_path_matches_fp32_path():
     assert rel_err(h[3], f[3]) < 1e-3
     assert torch.equal(bf(f[4]), h[4])          # round(y - mu) + mu, stored in bf16
     torch.testing.assert_close(h[5], f[5], rtol=2e-5, atol=1e-9)
+
+
+def test_pooled_linear_head_forward_backward():
+    """The 1x1 conv on the pooled (B, K*M, 1, 1) vector under autograd (newnet1.py:500): value and the three gradients
+    against torch's fp32 linear on the CPU."""
+    Fn, _ = _imp()
+    B, N = 3, 960
+    p = rnd("pl_p", (B, N, 1, 1), -2, 2)
+    w = rnd("pl_w", (N, N, 1, 1)) * 0.05
+    b = rnd("pl_b", (N,), -0.1, 0.1)
+    g = rnd("pl_g", (B, N, 1, 1))
+    pr, wr, br = (t.clone().double().requires_grad_() for t in (p, w, b))
+    ref = torch.nn.functional.conv2d(pr, wr, br)
+    (ref * g.double()).sum().backward()
+    pd, wd, bd = (t.to(DEV).requires_grad_() for t in (p, w, b))
+    y = Fn.pooled_linear(pd, wd, bd)
+    (y * g.to(DEV)).sum().backward()
+    assert y.shape == (B, N, 1, 1)
+    assert rel_err(y, ref) < 1e-5
+    assert rel_err(pd.grad, pr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
