@@ -42,6 +42,15 @@ class WarpDesc(C.Structure):
                [(n, _i64) for n in ("ss_b", "ss_c", "ss_y", "ss_x", "ds_b", "ds_c", "ds_y", "ds_x")]
 
 
+ADAM_MAX_TENSORS = 24
+
+
+class AdamChunk(C.Structure):
+    _fields_ = [("p", _vp * ADAM_MAX_TENSORS), ("g", _vp * ADAM_MAX_TENSORS), ("m", _vp * ADAM_MAX_TENSORS),
+                ("v", _vp * ADAM_MAX_TENSORS), ("step", _vp * ADAM_MAX_TENSORS), ("numel", _i64 * ADAM_MAX_TENSORS),
+                ("block0", _i32 * (ADAM_MAX_TENSORS + 1)), ("n", _i32), ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32)]
+
+
 class GmmDesc(C.Structure):
     _fields_ = [(n, _i32) for n in ("B", "HW", "M", "K", "dtype", "use_means_in_quant", "sm_pix_stride",
                                     "s_c_off", "m_c_off")] + [("scale_bound", _f32), ("lik_bound", _f32)]
@@ -52,6 +61,7 @@ _SIGS = {
     "hesic_abi_version": ([], _i32),
     "hesic_last_error": ([], C.c_char_p),
     "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_pack_conv_weights_batched": ([_vp, _i32, _i32, _vp], _i32),
     "hesic_conv2d_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_gdn_forward_planar": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp], _i32),
     "hesic_eb_prepare_params": ([_vp, _vp, _i32, _vp], _i32),
@@ -89,6 +99,7 @@ _SIGS = {
     "hesic_copy_channels": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_spatial_max": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_mix_weights_forward": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_adam_step": ([_vp, _vp], _i32),
     "hesic_pooled_linear_forward": ([_vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_pooled_linear_backward": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_softmax_k_forward": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),

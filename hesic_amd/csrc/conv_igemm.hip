@@ -777,6 +777,37 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// All weight repacks of a training step in ONE launch (an eager step issued 68 of them, ~7 us each): block -> job by a
+// search over the jobs' first-block table, then the same element mapping as pack_weight_kernel on a 1024-element chunk.
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const hesic_pack_job* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {                       // last job whose first block is <= bid (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const hesic_pack_job j = jobs[lo];
+    const int n = j.KH * j.KW * j.Cout * j.Cin;
+    const int base = (bid - j.block0) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + (int)threadIdx.x;
+        if (i >= n) break;
+        const int ci = i % j.Cin;
+        const int r = i / j.Cin;
+        const int co = r % j.Cout;
+        const int tap = r / j.Cout;
+        int ky = tap / j.KW, kx = tap % j.KW;
+        if (j.flip) { ky = j.KH - 1 - ky; kx = j.KW - 1 - kx; }
+        const int64_t src = j.transposed ? (((int64_t)ci * j.Cout + co) * j.KH + ky) * j.KW + kx
+                                         : (((int64_t)co * j.Cin + ci) * j.KH + ky) * j.KW + kx;
+        float v = j.w[src];
+        if (j.mask) v *= j.mask[src];
+        if (j.dtype == HESIC_BF16) ((bf16_t*)j.w_packed)[i] = f2bf(v);
+        else ((float*)j.w_packed)[i] = v;
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ mask, float* __restrict__ dw,
                                     int Cout, int Cin, int KH, int KW, int transposed) {
     const int64_t n = (int64_t)KH * KW * Cout * Cin;
@@ -832,6 +863,12 @@ extern "C" int hesic_pack_conv_weight(const float* w, const float* mask, void* w
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (float*)wp,
                            Cout, Cin, KH, KW, transposed, flip);
     HESIC_LAUNCH_RETURN("pack_conv_weight");
+}
+
+extern "C" int hesic_pack_conv_weights_batched(const hesic_pack_job* jobs_device, int n_jobs, int total_blocks, void* stream) {
+    HESIC_CHECK_ARG(jobs_device && n_jobs > 0 && total_blocks > 0, "pack_conv_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs);
+    HESIC_LAUNCH_RETURN("pack_conv_weights_batched");
 }
 
 extern "C" int hesic_unpack_conv_wgrad(const float* dwp, const float* mask, float* dw, int Cout, int Cin, int KH, int KW,

@@ -185,17 +185,44 @@ __global__ __launch_bounds__(256) void mix_logits_kernel(const float* __restrict
 // coalesced; dW[n, j] = sum_b g[b, n] pooled[b, j], dbias[n] = sum_b g[b, n] -- one thread per element, fixed b order.
 __global__ __launch_bounds__(256) void pooled_linear_dx_kernel(const float* __restrict__ w, const float* __restrict__ g,
                                                                float* __restrict__ dpooled, int B, int N) {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j >= N) return;
-    const float* gb = g + (int64_t)b * N;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int n = 0;
-    for (; n + 4 <= N; n += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = fmaf(gb[n + u], w[(int64_t)(n + u) * N + j], acc[u]);
+    // block = 32 columns j x 8 slices of the n range, up to 8 samples per thread so every W element is loaded once per
+    // block; the samples' g rows sit in LDS (broadcast reads), the W loads of 8 consecutive n are issued together, the
+    // slices meet in LDS in a fixed order.  (One thread per (b, j) walking all n was a 960-step serial chain of loads.)
+    extern __shared__ float gsm[];                       // [8][N] g rows, then [8][8][32] partial sums
+    float* red = gsm + 8 * N;
+    const int jl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jl, b0 = blockIdx.y * 8;
+    const int nb = B - b0 < 8 ? B - b0 : 8;
+    for (int i = threadIdx.x; i < 8 * N; i += 256) {
+        const int bb = i / N;
+        gsm[i] = bb < nb ? g[(int64_t)(b0 + bb) * N + (i - bb * N)] : 0.f;
     }
-    for (; n < N; ++n) acc[0] = fmaf(gb[n], w[(int64_t)n * N + j], acc[0]);
-    dpooled[(int64_t)b * N + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    const int per = (N + 7) / 8, n0 = sl * per, n1 = n0 + per < N ? n0 + per : N;
+    float acc[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) acc[bb] = 0.f;
+    const int jc = j < N ? j : N - 1;                    // clamped column: loads stay in range, result discarded
+    for (int n = n0; n < n1; n += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = n + u < n1 ? w[(int64_t)(n + u) * N + jc] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nn = n + u < n1 ? n + u : n0;
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) acc[bb] = fmaf(gsm[bb * N + nn], wv[u], acc[bb]);
+        }
+    }
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) red[(sl * 8 + bb) * 32 + jl] = acc[bb];
+    __syncthreads();
+    if (j < N && sl < nb) {                              // thread (jl, sl) finishes sample b0 + sl
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += red[(q * 8 + sl) * 32 + jl];
+        dpooled[(int64_t)(b0 + sl) * N + j] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void pooled_linear_dw_kernel(const float* __restrict__ pooled, const float* __restrict__ g,
@@ -412,6 +439,64 @@ extern "C" int hesic_mix_weights_forward(const float* pooled, const float* w, co
     HESIC_LAUNCH_RETURN("mix_weights_forward");
 }
 
+// ---------------------------------------------------------------- Adam over many tensors in one launch
+// torch.optim.Adam (newtrain1.py:294-295) in its default (no amsgrad / weight decay) form.  The descriptor travels BY VALUE
+// in the kernel arguments (no device table: nothing to keep alive, capturable in a HIP graph); every tensor has its own
+// fp32 step counter like torch's capturable state, bumped by a first tiny launch so all blocks of a tensor see the same
+// count.  Math as the reference's single-tensor path: m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), bias corrections in double.
+__global__ void adam_bump_steps_kernel(const hesic_adam_chunk c) {
+    const int i = threadIdx.x;
+    if (i < c.n) *c.step[i] += 1.f;
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(const hesic_adam_chunk c) {
+    const int bid = blockIdx.x;
+    int t = 0;
+    while (t + 1 < c.n && c.block0[t + 1] <= bid) ++t;            // uniform: scalar loop over <= 24 entries
+    __shared__ float sc[2];
+    if (threadIdx.x == 0) {
+        const double st = (double)*c.step[t];
+        const double bc1 = 1.0 - pow((double)c.beta1, st), bc2 = 1.0 - pow((double)c.beta2, st);
+        sc[0] = (float)((double)c.lr / bc1);
+        sc[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sc[0], bc2s = sc[1];
+    float* __restrict__ p = c.p[t];
+    const float* __restrict__ g = c.g[t];
+    float* __restrict__ m = c.m[t];
+    float* __restrict__ v = c.v[t];
+    const int64_t n = c.numel[t];
+    const int64_t base = (int64_t)(bid - c.block0[t]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const float gv = g[i];
+            const float mv = m[i] + (1.f - c.beta1) * (gv - m[i]);
+            const float vv = v[i] * c.beta2 + (1.f - c.beta2) * gv * gv;
+            m[i] = mv; v[i] = vv;
+            p[i] -= step_size * (mv / (sqrtf(vv) / bc2s + c.eps));
+        }
+    }
+}
+
+extern "C" int hesic_adam_step(const hesic_adam_chunk* chunk_host, void* stream) {
+    HESIC_CHECK_ARG(chunk_host && chunk_host->n > 0 && chunk_host->n <= HESIC_ADAM_MAX_TENSORS, "adam_step: bad chunk");
+    hesic_adam_chunk c = *chunk_host;
+    int blk = 0;
+    for (int i = 0; i < c.n; ++i) {
+        HESIC_CHECK_ARG(c.p[i] && c.g[i] && c.m[i] && c.v[i] && c.step[i] && c.numel[i] > 0, "adam_step: null tensor");
+        c.block0[i] = blk;
+        blk += (int)((c.numel[i] + 1023) / 1024);
+    }
+    c.block0[c.n] = blk;
+    hipLaunchKernelGGL(adam_bump_steps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c);
+    hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, c);
+    HESIC_LAUNCH_RETURN("adam_step");
+}
+
 extern "C" int hesic_pooled_linear_forward(const float* pooled, const float* w, const float* bias, float* logits, int B, int N,
                                            void* stream) {
     HESIC_CHECK_ARG(pooled && w && logits && B > 0 && N > 0, "pooled_linear_forward: bad arguments");
@@ -422,9 +507,10 @@ extern "C" int hesic_pooled_linear_forward(const float* pooled, const float* w, 
 
 extern "C" int hesic_pooled_linear_backward(const float* pooled, const float* w, const float* g, float* dpooled, float* dw, float* dbias,
                                             int B, int N, void* stream) {
-    HESIC_CHECK_ARG(pooled && w && g && B > 0 && N > 0 && N <= 65535 && B <= 65535, "pooled_linear_backward: bad arguments");
+    HESIC_CHECK_ARG(pooled && w && g && B > 0 && N > 0 && N <= 4096 && B <= 65535, "pooled_linear_backward: bad arguments (N <= 4096)");
     if (dpooled)
-        hipLaunchKernelGGL(pooled_linear_dx_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, w, g, dpooled, B, N);
+        hipLaunchKernelGGL(pooled_linear_dx_kernel, dim3((N + 31) / 32, (B + 7) / 8), dim3(256), (size_t)(8 * N + 8 * 8 * 32) * sizeof(float), (hipStream_t)stream, w, g,
+                           dpooled, B, N);
     if (dw)
         hipLaunchKernelGGL(pooled_linear_dw_kernel, dim3((N + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, pooled, g, dw, dbias, B, N);
     HESIC_LAUNCH_RETURN("pooled_linear_backward");

@@ -57,6 +57,15 @@ typedef struct {
 int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, int Cout, int Cin, int KH, int KW,
                            int transposed, int flip, int dtype, void* stream);
 
+/* Many repacks in one launch (a training step repacks every conv weight after the optimiser update): `jobs_device` is a
+ * DEVICE array of n_jobs descriptors, job i owns blocks [block0_i, block0_{i+1}) of 1024 elements each
+ * (block0 ascending, block0_0 = 0, total_blocks = sum of ceil(KH*KW*Cout*Cin / 1024)); fields as hesic_pack_conv_weight. */
+typedef struct {
+    const float* w; const float* mask; void* w_packed;
+    int32_t Cout, Cin, KH, KW, transposed, flip, dtype, block0;
+} hesic_pack_job;
+int hesic_pack_conv_weights_batched(const hesic_pack_job* jobs_device, int n_jobs, int total_blocks, void* stream);
+
 /* y = act(conv(x, w) + bias).  bias may be NULL.  w_packed from hesic_pack_conv_weight. */
 int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                          void* y, void* stream);
@@ -232,6 +241,21 @@ int hesic_mix_weights_forward(const float* pooled, const float* w, const float* 
 int hesic_pooled_linear_forward(const float* pooled, const float* w, const float* bias, float* logits, int B, int N, void* stream);
 int hesic_pooled_linear_backward(const float* pooled, const float* w, const float* g, float* dpooled, float* dw, float* dbias,
                                  int B, int N, void* stream);
+
+/* torch.optim.Adam(params, lr) update (ywz/mywork/newtrain1.py:294-295; no amsgrad, no weight decay) for up to
+ * HESIC_ADAM_MAX_TENSORS fp32 tensors per call: p, g, m (exp_avg), v (exp_avg_sq) dense arrays of numel elements in the
+ * same element order, step = the tensor's own fp32 step counter (device scalar, incremented by the call).  The struct is
+ * read on the HOST (pointers inside are device pointers) and travels in the kernel arguments; block0 is filled in.   */
+#define HESIC_ADAM_MAX_TENSORS 24
+typedef struct {
+    float* p[HESIC_ADAM_MAX_TENSORS]; const float* g[HESIC_ADAM_MAX_TENSORS]; float* m[HESIC_ADAM_MAX_TENSORS];
+    float* v[HESIC_ADAM_MAX_TENSORS]; float* step[HESIC_ADAM_MAX_TENSORS];
+    int64_t numel[HESIC_ADAM_MAX_TENSORS];
+    int32_t block0[HESIC_ADAM_MAX_TENSORS + 1];
+    int32_t n;
+    float lr, beta1, beta2, eps;
+} hesic_adam_chunk;
+int hesic_adam_step(const hesic_adam_chunk* chunk_host, void* stream);
 
 /* softmax over K of logits laid out (B, K*M) with channel k*M+m, and its backward
  * dlogits = w * (g - sum_k g*w).                                                                       */
