@@ -494,16 +494,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C, int ps, int co,
-                                                     int64_t rows_per_block) {
+__device__ __forceinline__ void colsum_body(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C, int ps, int co,
+                                            int64_t rows_per_block, int bid, float* red) {
     // thread = one 16-byte chunk (8 bf16 / 4 fp32 channels) of a row; 256 / (C/CE) rows in flight per block iteration;
     // partial sums meet in LDS, one atomic per (block, channel)
     constexpr int CE = 16 / (int)sizeof(T);
-    __shared__ float red[256 * CE];
     const int cpr = (C + CE - 1) / CE;                       // chunks per row
     const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;           // rows per iteration
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
-    const int64_t r0 = blockIdx.x * rows_per_block;
+    const int64_t r0 = bid * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
     float acc[CE];
 #pragma unroll
@@ -546,6 +545,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
         const int ch = c / CE, e = c % CE;
         for (int rs = 0; rs < rpi; ++rs) sum += red[(rs * cpr + ch) * CE + e];
         atomicAdd(db + c, sum);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C, int ps, int co,
+                                                     int64_t rows_per_block) {
+    __shared__ float red[256 * (16 / (int)sizeof(T))];
+    colsum_body<T>(dy, db, P, C, ps, co, rows_per_block, (int)blockIdx.x, red);
+}
+
+// wgrad_reduce_kernel and colsum_kernel as one launch: blocks [0, n_red) sum the K slices, blocks [n_red, ...) the columns
+// of dY (bias gradient).  The two are independent and each too small to fill the chip; a training step issues ~55 pairs.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_reduce_colsum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps,
+                                                                  int64_t per_tap, const WgArgs a, int n_red, const T* __restrict__ dy,
+                                                                  float* __restrict__ db, int64_t P, int64_t rows_per_block) {
+    __shared__ float red[256 * (16 / (int)sizeof(T))];
+    if ((int)blockIdx.x >= n_red) {
+        colsum_body<T>(dy, db, P, a.Cout, a.y_ps, a.y_co, rows_per_block, (int)blockIdx.x - n_red, red);
+        return;
+    }
+    const int64_t n = (int64_t)ntaps * per_tap;
+    for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)n_red * blockDim.x * 4) {
+        f32x4 s = *(const f32x4*)(ws + i);
+        for (int k = 1; k < nsplit; ++k) s += *(const f32x4*)(ws + k * n + i);
+        const int t = i / per_tap;
+        *(f32x4*)(dw + (int64_t)a.tap_id[t] * per_tap + (i - t * per_tap)) = s;
     }
 }
 
@@ -1157,6 +1183,20 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
     if (a.ntaps < d->KH * d->KW) hipMemsetAsync(dw_packed, 0, (size_t)d->KH * d->KW * per_tap * 4, st);
+    static const bool split_launch = getenv("HESIC_WGRAD_SPLIT_FINISH") != nullptr;     // A/B switch for profiling
+    if (dbias && !split_launch) {
+        hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
+        const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
+        const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: each ends in C atomics
+        const int n_col = (int)((P + rpb - 1) / rpb), n_red = grid_for(a.ntaps * per_tap / 4, 256);
+        if (d->dtype == HESIC_BF16)
+            hipLaunchKernelGGL(wgrad_reduce_colsum_kernel<bf16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)ws, dw_packed,
+                               a.nsplit, a.ntaps, per_tap, a, n_red, (const bf16_t*)dy, dbias, P, rpb);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_colsum_kernel<float>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)ws, dw_packed,
+                               a.nsplit, a.ntaps, per_tap, a, n_red, (const float*)dy, dbias, P, rpb);
+        HESIC_LAUNCH_RETURN("conv2d_wgrad");
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap / 4, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
                        a.nsplit, a.ntaps, per_tap, a);
     if (dbias) {
