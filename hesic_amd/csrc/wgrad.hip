@@ -493,6 +493,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// Many K slices, few outputs (the 1x1 "convs" behind the GDN parameter gradients: up to 256 slices of one 128x128 tile):
+// 16 float4 lanes x 16 slice groups per block, the groups meet in LDS in a fixed order -- 16x the parallelism of the
+// one-thread-per-output loop above (which walked 256 slices serially in 16 blocks: 35 us for 16 MB).
+__device__ __forceinline__ void reduce_wide_body(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps, int64_t per_tap,
+                                                 const WgArgs& a, int bid, f32x4 (*red)[16]) {
+    const int64_t n = (int64_t)ntaps * per_tap;
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)bid * 16 + el) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (i < n) {
+        int k = grp;
+        for (; k + 16 < nsplit; k += 32) {
+            s0 += *(const f32x4*)(ws + k * n + i);
+            s1 += *(const f32x4*)(ws + (k + 16) * n + i);
+        }
+        if (k < nsplit) s0 += *(const f32x4*)(ws + k * n + i);
+    }
+    red[grp][el] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        f32x4 s = red[0][el];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) s += red[g][el];
+        const int t = i / per_tap;
+        *(f32x4*)(dw + (int64_t)a.tap_id[t] * per_tap + (i - t * per_tap)) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps,
+                                                                int64_t per_tap, const WgArgs a) {
+    __shared__ f32x4 red[16][16];
+    reduce_wide_body(ws, dw, nsplit, ntaps, per_tap, a, (int)blockIdx.x, red);
+}
+
 template <typename T>
 __device__ __forceinline__ void colsum_body(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C, int ps, int co,
                                             int64_t rows_per_block, int bid, float* red) {
@@ -573,6 +607,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_colsum_kernel(const float* _
         const int t = i / per_tap;
         *(f32x4*)(dw + (int64_t)a.tap_id[t] * per_tap + (i - t * per_tap)) = s;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_colsum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ntaps,
+                                                                       int64_t per_tap, const WgArgs a, int n_red, const T* __restrict__ dy,
+                                                                       float* __restrict__ db, int64_t P, int C, int ps, int co, int64_t rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float scratch[256 * (16 / (int)sizeof(T)) > 1024 ? 256 * (16 / (int)sizeof(T)) : 1024];
+    if ((int)blockIdx.x >= n_red) {
+        colsum_body<T>(dy, db, P, C, ps, co, rows_per_block, (int)blockIdx.x - n_red, scratch);
+        return;
+    }
+    reduce_wide_body(ws, dw, nsplit, ntaps, per_tap, a, (int)blockIdx.x, (f32x4(*)[16])scratch);
 }
 
 // ------------------------------------------------------------------ narrow-channel weight gradient
@@ -1197,8 +1243,12 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
                                a.nsplit, a.ntaps, per_tap, a, n_red, (const float*)dy, dbias, P, rpb);
         HESIC_LAUNCH_RETURN("conv2d_wgrad");
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap / 4, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
-                       a.nsplit, a.ntaps, per_tap, a);
+    if (a.nsplit >= 32 && a.ntaps * per_tap / 64 < 4096)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((a.ntaps * per_tap / 4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_packed,
+                           a.nsplit, a.ntaps, per_tap, a);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap / 4, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
+                           a.nsplit, a.ntaps, per_tap, a);
     if (dbias) {
         hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
@@ -1388,11 +1438,12 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
         if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
         else launch_wgrad_tr(a, blocks, st);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(128 * 128 / 4, 256)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
-                           (int64_t)128 * 128, a);
         (void)hipMemsetAsync(dbp, 0, 128 * 4, st);
-        const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(256), 0, st, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
+        const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: every block ends in C atomics
+        // K-slice reduce (slice-parallel form: this 1-tap problem is cut into up to 256 slices) + column sums of dn, one launch
+        const int n_red = 128 * 128 / 64, n_col = (int)((P + rpb - 1) / rpb);
+        hipLaunchKernelGGL(wgrad_reduce_wide_colsum_kernel<bf16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
+                           (int64_t)128 * 128, a, n_red, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
         hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
         HESIC_LAUNCH_RETURN("gdn_backward");
     }
