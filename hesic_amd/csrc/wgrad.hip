@@ -21,6 +21,18 @@ namespace {
 constexpr int NT = 256;
 constexpr int TC = 128;      // channel tile on both sides
 
+// hipMemsetAsync is NOT used in this library: recorded into a HIP graph (torch.cuda.graph) its memset node did not
+// reliably precede the kernels that accumulate into the buffer on replays >= 1 (measured on ROCm 7.2 / MI355X: bias
+// gradients summed on top of the previous replay's values).  A plain kernel keeps the stream order in every mode.
+__global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline void zero_async(float* p, int64_t n, hipStream_t st) {
+    if (n <= 0) return;
+    const int64_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, p, n);
+}
+
 struct WgArgs {
     const void* x; const void* dy; float* out;     // out: workspace [split][tap][Cout][Cin] or dw itself
     int B, H, W, Cin, x_ps, x_co, Ho, Wo, Cout, y_ps, y_co;
@@ -237,6 +249,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct WgTrArgs {
     WgArgs w;
+    float* zero_me; int zero_n;      // optional: block 0 clears this array (the bias gradient the next launch accumulates into)
     FastDiv dqw, dqh;
     int fastq;          // QW % 16 == 0 (and chunk % 64 == 0): the 16 pixels a wave stages per step share one image row
 };
@@ -246,6 +259,8 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     constexpr int BK = 64, TILE = BK * 256, STAGE = 2 * TILE;       // 64 pixels x 128 channels x 2 B per operand
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (A.zero_me && blockIdx.x == 0)
+        for (int i = tid; i < A.zero_n; i += NT) A.zero_me[i] = 0.f;       // the bias gradient's zero-fill rides on this launch (stream order: done before the next one)
     // logical block order: tap fastest, then channel tiles, K slice (pixel range) slowest, on XCD-contiguous ids -- the
     // 25 tap blocks of a pixel range read the same dY rows and overlapping X rows, so they should meet in one L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1155,9 +1170,10 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
     }
 }
 
-void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st) {
+void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zero_me = nullptr, int zero_n = 0) {
     WgTrArgs A;
     A.w = a;
+    A.zero_me = zero_me; A.zero_n = zero_n;
     A.dqw = make_fastdiv((uint32_t)a.QW);
     A.dqh = make_fastdiv((uint32_t)a.QH);
     static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
@@ -1224,14 +1240,18 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
     for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
     const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
-    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31) && off32) launch_wgrad_tr(a, blocks, st);
+    bool db_zeroed = false;
+    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31) && off32) {
+        launch_wgrad_tr(a, blocks, st, dbias, dbias ? d->Cout : 0);
+        db_zeroed = dbias != nullptr;
+    }
     else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
-    if (a.ntaps < d->KH * d->KW) hipMemsetAsync(dw_packed, 0, (size_t)d->KH * d->KW * per_tap * 4, st);
+    if (a.ntaps < d->KH * d->KW) zero_async(dw_packed, (int64_t)d->KH * d->KW * per_tap, st);
     static const bool split_launch = getenv("HESIC_WGRAD_SPLIT_FINISH") != nullptr;     // A/B switch for profiling
     if (dbias && !split_launch) {
-        hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
+        if (!db_zeroed) zero_async(dbias, d->Cout, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: each ends in C atomics
         const int n_col = (int)((P + rpb - 1) / rpb), n_red = grid_for(a.ntaps * per_tap / 4, 256);
@@ -1250,7 +1270,7 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(a.ntaps * per_tap / 4, 256)), dim3(256), 0, st, (const float*)ws, dw_packed,
                            a.nsplit, a.ntaps, per_tap, a);
     if (dbias) {
-        hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
+        zero_async(dbias, d->Cout, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
         const unsigned g = (unsigned)((P + rpb - 1) / rpb);
@@ -1307,7 +1327,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nw = (int64_t)d->Cout * d->Cin * d->KH * d->KW;
-    (void)hipMemsetAsync(dw, 0, (size_t)nw * 4, st);
+    zero_async(dw, nw, st);
     static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2;
     bool conv1 = false;
@@ -1364,7 +1384,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         hipLaunchKernelGGL(sconv_wgrad_generic_kernel, dim3(gx, gy), dim3(256), 0, st, a);
     }
     if (dbias) {
-        (void)hipMemsetAsync(dbias, 0, (size_t)d->Cout * 4, st);
+        zero_async(dbias, d->Cout, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         if (d->ys_c == 1 && d->Cout >= 32 && d->ys_x == d->Cout && d->ys_y == (int64_t)d->Wo * d->Cout &&
             d->ys_b == (int64_t)d->Ho * d->Wo * d->Cout) {       // dense NHWC: coalesced column sums
@@ -1437,8 +1457,8 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
         static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
         if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
-        else launch_wgrad_tr(a, blocks, st);
-        (void)hipMemsetAsync(dbp, 0, 128 * 4, st);
+        else launch_wgrad_tr(a, blocks, st, dbp, 128);
+        if (wg_legacy) zero_async(dbp, 128, st);
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: every block ends in C atomics
         // K-slice reduce (slice-parallel form: this 1-tap problem is cut into up to 256 slices) + column sums of dn, one launch
         const int n_red = 128 * 128 / 64, n_col = (int)((P + rpb - 1) / rpb);
@@ -1451,7 +1471,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     float* dx0 = dn + P * C;
     float* dgp = dx0 + P * C;
     float* dbp = dgp + (int64_t)C * C;
-    (void)hipMemsetAsync(dgp, 0, ((size_t)C * C + C) * 4, st);
+    zero_async(dgp, (int64_t)C * C + C, st);
     hipLaunchKernelGGL(gdn_bwd_dn_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, dy, beta, gamma, dn, dx0, P, C, inverse, bound, dtype);
     hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, gamma, dn, dx0, dx, P, C, dtype);
     const int gx = (C * C + 255) / 256;

@@ -42,6 +42,13 @@ def _is_narrow(c):
     return c <= 8
 
 
+def _zeros(shape, dtype, device):
+    """Zero-filled scratch for kernels that ACCUMULATE into it.  ``torch.zeros`` is a hipMemsetAsync on ROCm, and a memset
+    node recorded into a HIP graph did not reliably run before the accumulating kernel on replays (see csrc/wgrad.hip:
+    zero_async); ``fill_`` is an ordinary kernel and keeps its place in the stream in eager and graph mode alike."""
+    return torch.empty(shape, dtype=dtype, device=device).fill_(0)
+
+
 # ------------------------------------------------------------------------------ packing cache
 _cache_epoch = 0
 
@@ -571,7 +578,7 @@ class _WarpFn(torch.autograd.Function):
         shape, sdt, Ho, Wo, ac = ctx.meta
         B, Cc, H, W = shape
         g = g.contiguous()
-        dsrc = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        dsrc = _zeros(shape, torch.float32, g.device)
         ss, ds = dsrc.stride(), g.stride()
         d = L.WarpDesc(B, Cc, H, W, Ho, Wo, ac, L.F32, L.dt(g), 0, ss[0], ss[1], ss[2], ss[3], ds[0], ds[1], ds[2], ds[3])
         L.call("hesic_warp_perspective_backward", C.byref(d), L.ptr(g), L.ptr(Mf), L.ptr(dsrc), L.stream())
@@ -600,7 +607,7 @@ def eb_unpack_grads(dparams, matrices, biases, factors, quantiles):
             n = p[0].numel()
             out.append(dparams[:, o:o + n].reshape(p.shape).to(p.dtype))
             o += n
-    dq = torch.zeros_like(quantiles)
+    dq = _zeros(quantiles.shape, quantiles.dtype, quantiles.device)
     dq[:, 0, 1] = dparams[:, 58]
     return out, dq
 
@@ -631,7 +638,7 @@ class _EbFn(torch.autograd.Function):
         n_mat = ctx.n_mat
         B, Cc, H, W = z.shape
         dz = torch.empty_like(z, memory_format=_CL)
-        dpar = torch.zeros_like(table)
+        dpar = _zeros(table.shape, table.dtype, table.device)
         g_lik = _nhwc(g_lik.to(torch.float32))
         g_zh = None if g_zh is None else _nhwc(g_zh.to(z.dtype))
         L.call("hesic_eb_backward", L.ptr(z), L.ptr(table), L.ptr(nz), L.ptr(g_lik), L.ptr(g_zh), L.ptr(dz), L.ptr(dpar),
@@ -683,7 +690,7 @@ class _GmmFn(torch.autograd.Function):
         B, M, H, W = y.shape
         y = _nhwc(y)
         if means is None:
-            means = torch.zeros_like(scales)
+            means = _zeros(scales.shape, scales.dtype, scales.device).contiguous(memory_format=_CL) if scales.dim() == 4 else _zeros(scales.shape, scales.dtype, scales.device)
         # scales / means may be the two halves of one tensor (chunk(2,1)): keep them in place
         same = (scales.dim() == 4 and means.dim() == 4 and scales._base is not None and scales._base is means._base
                 and scales._base.is_contiguous(memory_format=_CL) and scales._base.dtype == y.dtype)
@@ -720,7 +727,7 @@ class _GmmFn(torch.autograd.Function):
         dy = torch.empty_like(y, memory_format=_CL)
         dsc = torch.empty_like(scales, memory_format=_CL)
         dmu = torch.empty_like(means, memory_format=_CL)
-        dw = torch.zeros((B, K * M), dtype=torch.float32, device=y.device) if has_w else None
+        dw = _zeros((B, K * M), torch.float32, y.device) if has_w else None
         g_lik = _nhwc(g_lik.to(torch.float32))
         g_yh = None if g_yh is None else _nhwc(g_yh.to(y.dtype))
         d = L.GmmDesc(B, H * W, M, K, L.dt(y), umq, K * M, 0, 0, sb, lb)
@@ -763,7 +770,7 @@ def quantize_symbols(y, means=None):
     B, M, H, W = y.shape
     y = _nhwc(y)
     sc = torch.ones_like(y, memory_format=_CL)
-    mu = torch.zeros_like(y, memory_format=_CL) if means is None else _nhwc(means.to(y.dtype).expand_as(y))
+    mu = torch.empty_like(y, memory_format=_CL).fill_(0) if means is None else _nhwc(means.to(y.dtype).expand_as(y))
     yh = torch.empty_like(y, memory_format=_CL)
     lik = _empty_nhwc(B, M, H, W, torch.float32, y.device)
     sym = torch.empty((B, M, H, W), dtype=torch.int32, device=y.device).contiguous(memory_format=_CL)
@@ -854,7 +861,7 @@ class _SpatialMaxFn(torch.autograd.Function):
         g = g.reshape(B, Cc).to(torch.float32)
         if leaky:
             g = torch.where(out > 0, g, 0.01 * g)
-        dx = torch.zeros((B, H * W, Cc), dtype=dtype, device=g.device)
+        dx = _zeros((B, H * W, Cc), dtype, g.device)
         dx.scatter_(1, arg.long().unsqueeze(1), g.to(dtype).unsqueeze(1))
         return dx.reshape(B, H, W, Cc).permute(0, 3, 1, 2), None
 
@@ -949,7 +956,7 @@ def sum_log2(lik, out=None):
     L.require_cuda(lik)
     lik = lik.contiguous() if not lik.is_contiguous(memory_format=_CL) else lik
     if out is None:
-        out = torch.zeros(1, dtype=torch.float64, device=lik.device)
+        out = _zeros(1, torch.float64, lik.device)
     L.call("hesic_sum_log2", L.ptr(lik), lik.numel(), L.ptr(out), L.stream())
     return out
 
@@ -958,7 +965,7 @@ def sum_sq_diff(a, b, out=None):
     L.require_cuda(a, b)
     B, Cc, H, W = a.shape
     if out is None:
-        out = torch.zeros(1, dtype=torch.float64, device=a.device)
+        out = _zeros(1, torch.float64, a.device)
     sa = (C.c_int64 * 4)(*a.stride())
     sb = (C.c_int64 * 4)(*b.stride())
     L.call("hesic_sum_sq_diff", L.ptr(a), L.dt(a), sa, L.ptr(b), L.dt(b), sb, B, Cc, H, W, L.ptr(out), L.stream())
@@ -974,7 +981,7 @@ class _RdLossFn(torch.autograd.Function):
         import math
         B, Cc, H, W = x1.shape
         npix = B * H * W
-        acc = torch.zeros(3, dtype=torch.float64, device=x1.device)
+        acc = _zeros(3, torch.float64, x1.device)
         liks = tuple(l if (l.is_contiguous() or l.is_contiguous(memory_format=_CL)) else l.contiguous() for l in liks)
         for l in liks:
             sum_log2(l, acc[0:1])

@@ -808,7 +808,7 @@ def rate_distortion(out, x1, x2):
     """bits / squared error of one forward as fp64 device scalars (HIP reductions, no host sync):
     returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""
     keys = list(out["likelihoods"].keys())
-    acc = torch.zeros(len(keys) + 2, dtype=torch.float64, device=x1.device)      # one zero-fill for all six accumulators
+    acc = Fn._zeros(len(keys) + 2, torch.float64, x1.device)      # one zero-fill (a kernel, not a memset: graph-safe) for all six accumulators
     for i, k in enumerate(keys):
         Fn.sum_log2(out["likelihoods"][k], out=acc[i:i + 1])
     h, w = x1.shape[-2:]                      # x1/x2 are the ORIGINAL images: padded reconstructions are cropped (views)

@@ -279,3 +279,56 @@ def test_multi_tensor_adam_matches_torch_adam():
     c = torch.optim.Adam([p.detach().clone().requires_grad_() for p in ps_a], lr=1e-3, capturable=True)
     c.load_state_dict(sd)                                  # a torch Adam resumes from the HIP optimiser's checkpoint
     torch.testing.assert_close(c.state_dict()["state"][3]["exp_avg_sq"], sd["state"][3]["exp_avg_sq"])
+
+
+def test_bias_gradient_survives_graph_replay():
+    """Regression: buffers that kernels accumulate into are zeroed by kernels, never by hipMemsetAsync -- recorded into a HIP
+    graph, the memset node did not reliably precede the accumulating kernel from the second replay on (bias gradients were
+    summed on top of the previous replay's values).  Wide conv (bias zero-fill rides on the wgrad launch) and the image-side
+    3 -> 128 conv (zero kernel), poisoned output buffers, five replays each against the eager result."""
+    import ctypes as C
+    from hesic_amd import functional as Fn, _lib as L
+    torch.manual_seed(0)
+    bf16, cl = torch.bfloat16, torch.channels_last
+    x = torch.randn(4, 128, 32, 32, device="cuda").to(bf16).contiguous(memory_format=cl)
+    gy = torch.randn(4, 128, 16, 16, device="cuda").to(bf16).contiguous(memory_format=cl)
+    d = L.ConvDesc(4, 32, 32, 128, 16, 16, 128, 5, 5, 2, 2, 0, L.dt(x), 0, 0, 128, 0, 128, 0, 0)
+    nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
+
+    def wide(poison):
+        dwp = torch.empty(25 * 128 * 128, dtype=torch.float32, device="cuda")
+        db = torch.empty(128, dtype=torch.float32, device="cuda").fill_(poison)
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device="cuda")
+        L.call("hesic_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dwp), L.ptr(db), L.ptr(ws), nws, L.stream())
+        return db
+
+    img = torch.rand(4, 3, 64, 64, device="cuda")
+    w1 = (torch.randn(128, 3, 5, 5, device="cuda") * 0.1).requires_grad_()
+    b1 = torch.zeros(128, device="cuda").requires_grad_()
+    g1 = torch.randn(4, 128, 32, 32, device="cuda").to(bf16).contiguous(memory_format=cl)
+    prev = Fn.compute_dtype()
+    Fn.set_compute_dtype(bf16)
+    try:
+        def narrow(_poison):
+            w1.grad = b1.grad = None
+            y = Fn.conv2d(img, w1, b1, kernel_size=5, stride=2, padding=2)
+            y.backward(g1)
+            return torch.cat((b1.grad.reshape(-1), w1.grad.reshape(-1)[:256]))
+
+        for fn in (wide, narrow):
+            ref = fn(0.0).clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn(float("nan"))
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn(float("nan"))
+            for _ in range(5):
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.isfinite(out).all()
+                assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-5
+    finally:
+        Fn.set_compute_dtype(prev)
