@@ -450,6 +450,7 @@ __global__ void adam_bump_steps_kernel(const hesic_adam_chunk c) {
     if (i < c.n) *c.step[i] += 1.f;
 }
 
+constexpr int ADAM_EPB = 4096;                   // elements per block: the two double-precision pow() of a block's bias corrections amortise
 __global__ __launch_bounds__(256) void adam_update_kernel(const hesic_adam_chunk c) {
     const int bid = blockIdx.x;
     int t = 0;
@@ -459,25 +460,39 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const hesic_adam_chunk
         const double st = (double)*c.step[t];
         const double bc1 = 1.0 - pow((double)c.beta1, st), bc2 = 1.0 - pow((double)c.beta2, st);
         sc[0] = (float)((double)c.lr / bc1);
-        sc[1] = (float)sqrt(bc2);
+        sc[1] = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
-    const float step_size = sc[0], bc2s = sc[1];
+    const float step_size = sc[0], rbc2s = sc[1];
     float* __restrict__ p = c.p[t];
     const float* __restrict__ g = c.g[t];
     float* __restrict__ m = c.m[t];
     float* __restrict__ v = c.v[t];
     const int64_t n = c.numel[t];
-    const int64_t base = (int64_t)(bid - c.block0[t]) * 1024;
+    const int64_t base = (int64_t)(bid - c.block0[t]) * ADAM_EPB;
+    const float omb1 = 1.f - c.beta1, omb2 = 1.f - c.beta2;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && base + ADAM_EPB <= n;
+    if (vec) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = base + u * 256 + threadIdx.x;
-        if (i < n) {
+        for (int u = 0; u < ADAM_EPB / 1024; ++u) {
+            const int64_t i = base + u * 1024 + threadIdx.x * 4;
+            const f32x4 gv = *(const f32x4*)(g + i);
+            f32x4 mv = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i), pv = *(const f32x4*)(p + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mv[e] = mv[e] + omb1 * (gv[e] - mv[e]);
+                vv[e] = vv[e] * c.beta2 + omb2 * gv[e] * gv[e];
+                pv[e] -= step_size * (mv[e] / (sqrtf(vv[e]) * rbc2s + c.eps));
+            }
+            *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv; *(f32x4*)(p + i) = pv;
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < base + ADAM_EPB && i < n; i += 256) {
             const float gv = g[i];
-            const float mv = m[i] + (1.f - c.beta1) * (gv - m[i]);
-            const float vv = v[i] * c.beta2 + (1.f - c.beta2) * gv * gv;
+            const float mv = m[i] + omb1 * (gv - m[i]);
+            const float vv = v[i] * c.beta2 + omb2 * gv * gv;
             m[i] = mv; v[i] = vv;
-            p[i] -= step_size * (mv / (sqrtf(vv) / bc2s + c.eps));
+            p[i] -= step_size * (mv / (sqrtf(vv) * rbc2s + c.eps));
         }
     }
 }
@@ -489,7 +504,7 @@ extern "C" int hesic_adam_step(const hesic_adam_chunk* chunk_host, void* stream)
     for (int i = 0; i < c.n; ++i) {
         HESIC_CHECK_ARG(c.p[i] && c.g[i] && c.m[i] && c.v[i] && c.step[i] && c.numel[i] > 0, "adam_step: null tensor");
         c.block0[i] = blk;
-        blk += (int)((c.numel[i] + 1023) / 1024);
+        blk += (int)((c.numel[i] + ADAM_EPB - 1) / ADAM_EPB);
     }
     c.block0[c.n] = blk;
     hipLaunchKernelGGL(adam_bump_steps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c);

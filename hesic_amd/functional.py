@@ -93,7 +93,7 @@ def repack_all():
             w = e["weight"]()
             jobs[i] = (w.data_ptr(), 0 if e["mask"] is None else e["mask"].data_ptr(), e["wp"].data_ptr(), e["cout"], e["cin"], e["kh"], e["kw"],
                        int(e["transposed"]), int(e["flip"]), L.dt(e["dtype"]), blk)
-            blk += (e["kh"] * e["kw"] * e["cout"] * e["cin"] + 1023) // 1024
+            blk += ((e["cout"] + 7) // 8) * ((e["cin"] + 31) // 32)          # one block per 8-cout x 32-cin tile
         dev = ents[0]["wp"].device
         table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
         _pack_table = (sig, table, len(ents), blk)

@@ -58,8 +58,9 @@ int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, in
                            int transposed, int flip, int dtype, void* stream);
 
 /* Many repacks in one launch (a training step repacks every conv weight after the optimiser update): `jobs_device` is a
- * DEVICE array of n_jobs descriptors, job i owns blocks [block0_i, block0_{i+1}) of 1024 elements each
- * (block0 ascending, block0_0 = 0, total_blocks = sum of ceil(KH*KW*Cout*Cin / 1024)); fields as hesic_pack_conv_weight. */
+ * DEVICE array of n_jobs descriptors, job i owns blocks [block0_i, block0_{i+1}), one per tile of 8 couts x 32 cins
+ * (block0 ascending, block0_0 = 0, total_blocks = sum of ceil(Cout/8) * ceil(Cin/32)); fields as hesic_pack_conv_weight,
+ * KH*KW <= 25.                                                                                           */
 typedef struct {
     const float* w; const float* mask; void* w_packed;
     int32_t Cout, Cin, KH, KW, transposed, flip, dtype, block0;
