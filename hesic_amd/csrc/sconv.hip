@@ -869,11 +869,12 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
 // per thread: per (ci, ky) three ds_read_b128 of pixels and five broadcast weight reads feed 120 FMAs.  The 132-float
 // row pitch keeps the 16-lane groups of those reads on disjoint banks.  The two 3-channel halves of the input may come
 // from different tensors (any strides / fp32 or bf16): planar fp32 rows are fetched as 8-byte pairs.
-template <int K>
-__global__ __launch_bounds__(256, 4) void sconv_6to3_s1_kernel(const SArgs a) {
+template <int K, int PX>
+__global__ __launch_bounds__(256, PX == 4 ? 4 : 2) void sconv_6to3_s1_kernel(const SArgs a) {
     // 16 x 64 pixel tile, 4 pixels per thread: 35 KB of LDS and < 128 VGPRs -> four blocks (16 waves) per CU, so the staging
     // of one block overlaps the FMA phase of the others
-    constexpr int CIN = 6, COUT = 3, TH = 16, PX = 4, TW = 16 * PX, PAD = K / 2, PH = TH + K - 1, PW = TW + 4, NP = PW / 2;
+    // (PX = 8: 16 x 128 tile, 66 KB of LDS, two blocks per CU, 1.5 instead of 2.1 VALU instructions per packed FMA)
+    constexpr int CIN = 6, COUT = 3, TH = 16, TW = 16 * PX, PAD = K / 2, PH = TH + K - 1, PW = TW + 4, NP = PW / 2;
     __shared__ __attribute__((aligned(16))) float xs[CIN * PH * PW];
     __shared__ __attribute__((aligned(16))) float wl[K * K * CIN * 4];
     const int tid = threadIdx.x;
@@ -943,8 +944,9 @@ __global__ __launch_bounds__(256, 4) void sconv_6to3_s1_kernel(const SArgs a) {
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
             const float* row = xs + (ci * PH + ly + ky) * PW + lx;
-            const f32x4 r0 = *(const f32x4*)row, r1 = *(const f32x4*)(row + 4);
-            const float xin[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            float xin[PX + 4];
+#pragma unroll
+            for (int q = 0; q < (PX + 4) / 4; ++q) *(f32x4*)(xin + 4 * q) = *(const f32x4*)(row + 4 * q);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const f32x4 wv = *(const f32x4*)(wl + ((ky * K + kx) * CIN + ci) * 4);
@@ -969,7 +971,8 @@ __global__ __launch_bounds__(256, 4) void sconv_6to3_s1_kernel(const SArgs a) {
         const int64_t base = b * a.ys_b + co * a.ys_c + oy * a.ys_y;
         if (vec && ox0 + PX <= a.Wo) {
             float* yp = (float*)a.y + base + ox0;
-            *(f32x4*)yp = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+            for (int q = 0; q < PX / 4; ++q) *(f32x4*)(yp + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
         } else {
 #pragma unroll
             for (int p = 0; p < PX; ++p)
@@ -1064,8 +1067,14 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
     } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
                a.Wo == a.W && a.Wo >= 128) {
-        const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
-        hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, st, a);
+        static const int px = getenv("HESIC_6TO3_PX") ? atoi(getenv("HESIC_6TO3_PX")) : 4;       // A/B switch
+        if (px == 8) {
+            const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+            hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 8>), dim3(tiles), dim3(256), 0, st, a);
+        } else {
+            const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
+            hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 4>), dim3(tiles), dim3(256), 0, st, a);
+        }
     } else if (!legacy && a.stride == 1 && ((a.Cin == 6 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 6)) && a.KH == 5 && a.KW == 5 &&
                a.pad == 2 && a.Ho == a.H && a.Wo == a.W && a.Wo >= 64) {
         const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
@@ -1120,8 +1129,14 @@ extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* 
     a.x = xa; a.w = w; a.bias = bias; a.y = y;
     a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
     a.x2_dtype = xb_dtype; a.c_split = ca;
-    const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
-    hipLaunchKernelGGL((sconv_6to3_s1_kernel<5>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    static const int px = getenv("HESIC_6TO3_PX") ? atoi(getenv("HESIC_6TO3_PX")) : 4;           // A/B switch
+    if (px == 8) {
+        const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
+        hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 8>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const int tiles = ((a.Wo + 63) / 64) * ((a.Ho + 15) / 16) * a.B;
+        hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 4>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HESIC_LAUNCH_RETURN("sconv2d_forward_cat");
 }
 
