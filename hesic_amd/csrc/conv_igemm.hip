@@ -1045,7 +1045,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase * ksplit;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
     if (g_plan_out) {
-        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (d->Cin % 64 == 0 ? 64 : 32) : BK; g_plan_out[3] = fast ? 1 : 0;
+        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (bm == 32 && d->Cin % 128 == 0 ? 128 : (d->Cin % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
     a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
@@ -1084,7 +1084,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 32); else LAUNCH_GLDS_NS(64, 64, 32); }
         } else {
-            LAUNCH_GLDS_NS(32, 128, 64);
+            // 32-pixel tiles are bound by per-stage bookkeeping and barrier waits (PMC: ~95 scalar/vector instructions per 4
+            // MFMAs): BK = 128 halves the stage count (8 MFMAs per wave and stage, 2-deep ring of 40 KB stages) --
+            // 128 -> 128 5x5 s1 @32x32 B=8: 23.4 -> 18.8 us; a 3-deep ring was slower (20.7).  HESIC_IGEMM_BK128=0 = A/B switch.
+            static const bool bk128 = !(getenv("HESIC_IGEMM_BK128") && atoi(getenv("HESIC_IGEMM_BK128")) == 0);
+            if (bk128 && d->Cin % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
+            else LAUNCH_GLDS_NS(32, 128, 64);
         }
     } else if (d->dtype == HESIC_BF16) {
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 128>), grid, block, 0, st, a);
