@@ -1045,7 +1045,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase * ksplit;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
     if (g_plan_out) {
-        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (bm == 32 && d->Cin % 128 == 0 ? 128 : (d->Cin % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
+        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (((bm == 32) || (bm == 64 && BN == 64)) && d->Cin % 128 == 0 ? 128 : (d->Cin % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
     a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
@@ -1081,7 +1081,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }
         } else if (bm == 64) {
-            if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
+            // same lever as for the 32-pixel tile: BK = 128 where two 2-stage blocks still fit a CU (64 x 64 tiles: 64 KB; 128 ->
+            // 192 5x5 s2 @64x64 B=8: 28.4 -> 22.3 us) or where the grid is one block per CU anyway (64 x 128 tiles, 96 KB)
+            static const int bk128m = getenv("HESIC_IGEMM_BK128M") ? atoi(getenv("HESIC_IGEMM_BK128M")) : 1;       // A/B switch: 0 off, 2 = also 64x128
+            if (bk == 64 && BN == 64 && bk128m && d->Cin % 128 == 0) LAUNCH_GLDS(64, 64, 128, 2);
+            else if (bk == 64 && BN == 128 && bk128m == 2 && d->Cin % 128 == 0 && nblocks <= 256) LAUNCH_GLDS(64, 128, 128, 2);
+            else if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 32); else LAUNCH_GLDS_NS(64, 64, 32); }
         } else {
             // 32-pixel tiles are bound by per-stage bookkeeping and barrier waits (PMC: ~95 scalar/vector instructions per 4
