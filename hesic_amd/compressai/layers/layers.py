@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from compressai.models.utils import HipConv2d
 from hesic_amd import _lib as L
+from hesic_amd import functional as Fn
 
 from .gdn import GDN
 
@@ -55,11 +56,17 @@ class ResidualBlock(nn.Module):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def forward(self, x):
+    def forward(self, x, outer_skip=None):
+        """``outer_skip``: an extra tensor added to the result (the Enhancement_Block's ``+ x``, newnet1.py:286), fused
+        into the last conv's epilogue on the 32-channel inference path."""
+        if self.skip is None and Fn.conv3x3_c32_ok(x, self.conv1.weight) and Fn.conv3x3_c32_ok(x, self.conv2.weight):
+            out = Fn.conv3x3_c32(x, self.conv1.weight, self.conv1.bias, act=L.ACT_LEAKY)
+            return Fn.conv3x3_c32(out, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY, res1=x, res2=outer_skip)
         out = self.conv1.run(x, act=L.ACT_LEAKY)
         out = self.conv2.run(out, act=L.ACT_LEAKY)
         identity = x if self.skip is None else self.skip(x)
-        return out + identity.to(out.dtype)
+        out = out + identity.to(out.dtype)
+        return out if outer_skip is None else out + outer_skip.to(out.dtype)
 
 
 class ResidualBlockWithStride(nn.Module):

@@ -488,6 +488,36 @@ def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, a
 
 
 # ------------------------------------------------------------------------------------ GDN
+def conv3x3_c32_ok(x, weight):
+    """Inference-only fast path of the enhancement net's 32-channel 3x3 convs (``hesic_conv3x3_c32_forward``)."""
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == torch.bfloat16
+            and weight.shape[1] == 32 and tuple(weight.shape[2:]) == (3, 3) and (weight.shape[0] == 32 or weight.shape[0] <= 4)
+            and weight.dtype == torch.float32 and _compute_dtype == torch.bfloat16)
+
+
+def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
+    """act(conv3x3(x) + bias) + res1 + res2 in one launch: x (B,32,H,W) bf16 (any layout, made NHWC); 32 couts -> bf16 NHWC
+    with bf16 residuals, <= 4 couts -> fp32 planar with one fp32 planar residual (the 32 -> 3 output conv + the image)."""
+    L.require_cuda(x, weight)
+    B, _, H, W = x.shape
+    cout = weight.shape[0]
+    x = _nhwc(x)
+    w = weight.detach().contiguous()
+    if cout == 32:
+        y = _empty_nhwc(B, 32, H, W, torch.bfloat16, x.device)
+        r1 = None if res1 is None else _nhwc(res1.to(torch.bfloat16))
+        r2 = None if res2 is None else _nhwc(res2.to(torch.bfloat16))
+    else:
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+        r1 = None if res1 is None else res1.to(torch.float32).contiguous()
+        r2 = None
+        if res2 is not None:
+            raise RuntimeError("conv3x3_c32: the planar form takes one residual")
+    L.call("hesic_conv3x3_c32_forward", L.ptr(x), L.ptr(w), L.ptr(None if bias is None else bias.detach().float()), cout, int(act),
+           L.ptr(r1), L.ptr(r2), L.ptr(y), B, H, W, L.stream())
+    return y
+
+
 def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed=False, packer=None):
     """conv(torch.cat((xa, xb), 1)) (newnet1.py:643,686).  At inference the 6 -> 3 image-side stages read their two
     3-channel halves straight from the two tensors (``hesic_sconv2d_forward_cat``: no concatenated copy); otherwise the

@@ -711,7 +711,7 @@ class Enhancement_Block(nn.Module):
         self.RB1, self.RB2, self.RB3 = ResidualBlock(32, 32), ResidualBlock(32, 32), ResidualBlock(32, 32)
 
     def forward(self, x):
-        return self.RB3(self.RB2(self.RB1(x))) + x
+        return self.RB3(self.RB2(self.RB1(x)), outer_skip=x)
 
 
 class Enhancement(nn.Module):
@@ -726,6 +726,8 @@ class Enhancement(nn.Module):
     def forward(self, x, x_another_warp):
         t = self.conv1(torch.cat((x.float(), x_another_warp.float()), 1))
         t = self.EB3(self.EB2(self.EB1(t)))
+        if Fn.conv3x3_c32_ok(t, self.conv2.weight):          # 32 -> 3 output conv + the image it refines, fp32 planar out
+            return Fn.conv3x3_c32(t, self.conv2.weight, self.conv2.bias, res1=x)
         return self.conv2(t) + x
 
 

@@ -243,6 +243,16 @@ int hesic_pooled_linear_forward(const float* pooled, const float* w, const float
 int hesic_pooled_linear_backward(const float* pooled, const float* w, const float* g, float* dpooled, float* dw, float* dbias,
                                  int B, int N, void* stream);
 
+/* 3x3 stride-1 pad-1 convolution over a 32-channel NHWC bf16 map at full resolution -- the layer shape of the stage-2
+ * enhancement net (ResidualBlock / Enhancement / Independent_EN: compressai/layers/layers.py:125-147,
+ * ywz/mywork/newnet1.py:272-311, 1278-1300), inference form:  y = act(conv(x, w) + bias) + res1 + res2.
+ *   Cout == 32: y, res1, res2 bf16 NHWC (B,H,W,32) (res may be NULL): conv2 of a ResidualBlock with its identity and, for the
+ *               last block of an Enhancement_Block, the block's outer skip, in one pass;
+ *   Cout <= 4 : y and res1 fp32 planar (B,Cout,H,W): the 32 -> 3 output conv plus the image it refines (res2 must be NULL).
+ * w: fp32 (Cout,32,3,3) as stored by nn.Conv2d (packed in registers by the kernel), act: HESIC_ACT_*.            */
+int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,
+                              const void* res2, void* y, int B, int H, int W, void* stream);
+
 /* torch.optim.Adam(params, lr) update (ywz/mywork/newtrain1.py:294-295; no amsgrad, no weight decay) for up to
  * HESIC_ADAM_MAX_TENSORS fp32 tensors per call: p, g, m (exp_avg), v (exp_avg_sq) dense arrays of numel elements in the
  * same element order, step = the tensor's own fp32 step counter (device scalar, incremented by the call).  The struct is
