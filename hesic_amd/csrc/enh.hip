@@ -22,23 +22,38 @@ struct C32Args {
 
 constexpr int TH = 16, TW = 32, HW_ = TW + 2, HH = TH + 2, HPIX = HH * HW_;     // halo: 18 x 34 pixels of 64 bytes
 
+constexpr int OPITCH = 36;       // floats per staged output pixel (32 + 4: bank spread)
+
 template <int MODE>      // 0: 32 couts, bf16 NHWC out (+ bf16 NHWC residuals); 1: <= 4 couts, fp32 planar out (+ fp32 planar residual)
 __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char halo[HPIX * 64];
+    __shared__ __attribute__((aligned(16))) float ostage[4][32 * OPITCH];        // per wave: 32 pixels x 32 couts fp32, padded rows
     constexpr uint32_t POISON = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
-    // weights -> 18 A fragments: lane (cout = p, half h) holds channels k*16 + h*8 + [0,8) of tap t
+    // weights -> 18 A fragments: lane (cout = p, half h) holds channels k*16 + h*8 + [0,8) of tap t.  The (Cout,32,3,3) fp32
+    // tensor comes in through LDS with coalesced loads (row pitch 289 floats: the per-lane gathers below hit 32 different
+    // banks); gathering it straight from global memory cost every block ~9000 scattered cache-line requests.
     bf16x8 wf[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p < a.Cout ? a.w[((int64_t)p * 32 + k * 16 + h * 8 + e) * 9 + t] : 0.f;
-            wf[t][k] = __builtin_bit_cast(bf16x8, u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+    {
+        float* wst = (float*)halo;                               // 32 x 289 floats = 37 KB <= the halo buffer
+        const int nw = a.Cout * 288;
+        for (int i = tid; i < 32 * 288; i += 256) {
+            const int co = i / 288, r = i - co * 288;
+            wst[co * 289 + r] = i < nw ? a.w[i] : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
+                wf[t][k] = __builtin_bit_cast(bf16x8, u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+            }
+        __syncthreads();
+    }
     float bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -48,16 +63,18 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             bv[j][e] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
         }
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // halo -> registers: 16-byte piece i = (pixel i >> 2, slot i & 3) holds channel chunk slot ^ ((pixel >> 2) & 3); pixels
+    // outside the image are poisoned offsets (zeros = the conv's zero padding).  The next tile's pieces are requested as soon
+    // as this tile's are in LDS, so their HBM latency runs under the MFMA phase.
+    u32x4 pc[10];
+    int cb = 0, cty = 0, ctx = 0;
+    auto request = [&](int tile) {
         const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
-        const int tx = tile - (int)q * a.tiles_x;
-        const int b = (int)fdiv(q, a.fd_ty);
-        const int ty = (int)q - b * a.tiles_y;
-        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
-        // halo -> LDS: 16-byte piece i = (pixel i >> 2, slot i & 3) holds channel chunk slot ^ ((pixel >> 2) & 3); pixels outside
-        // the image are poisoned offsets (zeros = the conv's zero padding)
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
-        u32x4 pc[10];
+        ctx = tile - (int)q * a.tiles_x;
+        cb = (int)fdiv(q, a.fd_ty);
+        cty = (int)q - cb * a.tiles_y;
+        const int y0 = cty * TH - 1, x0 = ctx * TW - 1;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)cb * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int i = tid + 256 * u;
@@ -68,63 +85,90 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             const int chunk = slot ^ ((hp >> 2) & 3);
             pc[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, 0, 0);
         }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) request(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = cb, ty = cty, tx = ctx;                     // of the tile whose halo is in `pc`
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int i = tid + 256 * u;
             if (i < HPIX * 4) *(u32x4*)(halo + i * 16) = pc[u];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) request(tile + (int)gridDim.x);
 #pragma unroll 1
         for (int rq = 0; rq < TH / 4; ++rq) {
             const int yl = wave + 4 * rq;
-            f32x16 acc;
+            const int y = ty * TH + yl, x = tx * TW + p;
+            const bool live = y < a.H && x < a.W;
+            // Row-major view of the wave's 32 output pixels: lane -> (pixel (lane >> 2) + 16 it, 16-byte chunk lane & 3), so loads
+            // and stores are full 64-byte pixel rows, 1 KB contiguous per instruction (the accumulator layout -- 8 bytes per lane,
+            // lanes 64 bytes apart -- cost 43 us of scattered stores and 30 us per residual).  Residuals are requested here, before
+            // the MFMAs, and added in fp32 after the tile has turned round in the wave's LDS slice.
+            const int rpx = lane >> 2, rch = lane & 3;
+            u32x4 r1v[2], r2v[2];
+            float rp[4];
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int it = 0; it < 2; ++it) {
+                    const int xx = tx * TW + rpx + 16 * it;
+                    const bool lv = y < a.H && xx < a.W;
+                    const int64_t o = (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8;
+                    r1v[it] = (a.res1 && lv) ? *(const u32x4*)((const bf16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r2v[it] = (a.res2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    rp[c] = (a.res1 && live && h == 0 && c < a.Cout) ? ((const float*)a.res1)[(((int64_t)b * a.Cout + c) * a.H + y) * a.W + x] : 0.f;
+            }
+            f32x16 acc, acc1;                                      // two chains: consecutive MFMAs never wait on each other
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int hp = (yl + t / 3) * HW_ + p + t % 3;
                 const unsigned char* row = halo + hp * 64;
                 const int sw = (hp >> 2) & 3;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bf16x8 xf = *(const bf16x8*)(row + (((k * 2 + h) ^ sw) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], xf, acc, 0, 0, 0);
-                }
+                const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
             // D[cout][pixel]: lane holds pixel p, couts 8 j + 4 h + e (j = r >> 2, e = r & 3)
-            const int y = ty * TH + yl, x = tx * TW + p;
-            if (y < a.H && x < a.W) {
-                if constexpr (MODE == 0) {
-                    const int64_t pix = (((int64_t)b * a.H + y) * a.W + x) * 32;
+            if constexpr (MODE == 0) {
+                float* os = ostage[wave];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c0 = 8 * j + 4 * h;
-                        float v[4];
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[4 * j + e] + bv[j][e], a.act);
-                        if (a.res1) {
-                            const u32x2 r = *(const u32x2*)((const bf16_t*)a.res1 + pix + c0);
-                            v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-                            v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-                        }
-                        if (a.res2) {
-                            const u32x2 r = *(const u32x2*)((const bf16_t*)a.res2 + pix + c0);
-                            v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-                            v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-                        }
-                        *(u32x2*)((bf16_t*)a.y + pix + c0) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[4 * j + e] + bv[j][e], a.act);
+                    *(f32x4*)(os + p * OPITCH + 8 * j + 4 * h) = v;
+                }
+                // (wave-private slice: the LDS pipe keeps a wave's own writes and reads in order, no barrier)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = rpx + 16 * it, xx = tx * TW + q;
+                    const f32x4 lo = *(const f32x4*)(os + q * OPITCH + rch * 8), hi = *(const f32x4*)(os + q * OPITCH + rch * 8 + 4);
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(ra[e] << 16) + __uint_as_float(rb[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(ra[e] & 0xffff0000u) + __uint_as_float(rb[e] & 0xffff0000u);
                     }
-                } else {
-                    if (h == 0) {
+                    if (y < a.H && xx < a.W)
+                        *(u32x4*)((bf16_t*)a.y + (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8) =
+                            u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                }
+            } else {
+                if (live && h == 0) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < a.Cout) {
-                                const int64_t o = (((int64_t)b * a.Cout + c) * a.H + y) * a.W + x;
-                                float v = apply_act(acc[c] + bv[0][c], a.act);
-                                if (a.res1) v += ((const float*)a.res1)[o];
-                                ((float*)a.y)[o] = v;
-                            }
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (c < a.Cout)
+                            ((float*)a.y)[(((int64_t)b * a.Cout + c) * a.H + y) * a.W + x] = apply_act(acc[c] + bv[0][c], a.act) + rp[c];
                 }
             }
         }
@@ -132,7 +176,31 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     }
 }
 
+// cat(xa, xb) (two fp32 planar 3-channel images, newnet1.py:300) as channels 0..5 of a zero-padded 32-channel NHWC bf16 map:
+// the input of the 6 -> 32 conv in the layout of the kernel above.  One thread per pixel: six coalesced plane reads, one
+// 64-byte row out.
+__global__ __launch_bounds__(256) void pack_images_c32_kernel(const float* __restrict__ xa, const float* __restrict__ xb, bf16_t* __restrict__ out,
+                                                              int B, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, q = i - b * HW;
+        const float* pa = xa + b * 3 * HW + q;
+        const float* pb = xb + b * 3 * HW + q;
+        const u32x4 v0 = {pack_bf2(pa[0], pa[HW]), pack_bf2(pa[2 * HW], pb[0]), pack_bf2(pb[HW], pb[2 * HW]), 0u};
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        u32x4* o = (u32x4*)(out + i * 32);
+        o[0] = v0; o[1] = z; o[2] = z; o[3] = z;
+    }
+}
+
 }  // namespace
+
+extern "C" int hesic_pack_images_c32(const float* xa, const float* xb, void* out, int B, int H, int W, void* stream) {
+    HESIC_CHECK_ARG(xa && xb && out && B > 0 && H > 0 && W > 0, "pack_images_c32: bad arguments");
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(pack_images_c32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, xa, xb, (bf16_t*)out, B, (int64_t)H * W);
+    HESIC_LAUNCH_RETURN("pack_images_c32");
+}
 
 extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,
                                          const void* res2, void* y, int B, int H, int W, void* stream) {

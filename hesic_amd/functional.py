@@ -495,6 +495,15 @@ def conv3x3_c32_ok(x, weight):
             and weight.dtype == torch.float32 and _compute_dtype == torch.bfloat16)
 
 
+def pack_images_c32(xa, xb):
+    """cat((xa, xb), 1) of two (B,3,H,W) images as channels 0..5 of a zero-padded (B,32,H,W) bf16 NHWC tensor."""
+    L.require_cuda(xa, xb)
+    B, _, H, W = xa.shape
+    out = _empty_nhwc(B, 32, H, W, torch.bfloat16, xa.device)
+    L.call("hesic_pack_images_c32", L.ptr(xa.float().contiguous()), L.ptr(xb.float().contiguous()), L.ptr(out), B, H, W, L.stream())
+    return out
+
+
 def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     """act(conv3x3(x) + bias) + res1 + res2 in one launch: x (B,32,H,W) bf16 (any layout, made NHWC); 32 couts -> bf16 NHWC
     with bf16 residuals, <= 4 couts -> fp32 planar with one fp32 planar residual (the 32 -> 3 output conv + the image)."""

@@ -724,7 +724,21 @@ class Enhancement(nn.Module):
         self.conv2 = conv3x3(32, 3)
 
     def forward(self, x, x_another_warp):
-        t = self.conv1(torch.cat((x.float(), x_another_warp.float()), 1))
+        if (Fn.conv3x3_c32_ok(x.new_empty((1, 32, 1, 1), dtype=torch.bfloat16), self.EB1.RB1.conv1.weight) and x.is_cuda
+                and tuple(self.conv1.weight.shape) == (32, 6, 3, 3)):
+            # inference: the 6 -> 32 input conv runs on the 32-channel kernel too -- the two images go into channels 0..5 of a
+            # zero-padded NHWC bf16 map, the weight is zero-padded along Cin (cached)
+            B, _, H, W = x.shape
+            xin = Fn.pack_images_c32(x, x_another_warp)
+            w6 = self.conv1.weight
+            tag = (w6.data_ptr(), w6._version)
+            if getattr(self, "_w32", None) is None or self._w32[0] != tag:
+                wp = torch.zeros((32, 32, 3, 3), dtype=torch.float32, device=w6.device)
+                wp[:, :6] = w6.detach()
+                self._w32 = (tag, wp)
+            t = Fn.conv3x3_c32(xin, self._w32[1], self.conv1.bias)
+        else:
+            t = self.conv1(torch.cat((x.float(), x_another_warp.float()), 1))
         t = self.EB3(self.EB2(self.EB1(t)))
         if Fn.conv3x3_c32_ok(t, self.conv2.weight):          # 32 -> 3 output conv + the image it refines, fp32 planar out
             return Fn.conv3x3_c32(t, self.conv2.weight, self.conv2.bias, res1=x)

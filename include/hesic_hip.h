@@ -253,6 +253,11 @@ int hesic_pooled_linear_backward(const float* pooled, const float* w, const floa
 int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,
                               const void* res2, void* y, int B, int H, int W, void* stream);
 
+/* torch.cat((xa, xb), 1) of two fp32 planar (B,3,H,W) images (Enhancement.forward, newnet1.py:300) written as channels 0..5
+ * of a zero-padded (B,H,W,32) bf16 NHWC map: the 6 -> 32 input conv then runs on hesic_conv3x3_c32_forward with its weight
+ * zero-padded along Cin.                                                                                  */
+int hesic_pack_images_c32(const float* xa, const float* xb, void* out_nhwc32_bf16, int B, int H, int W, void* stream);
+
 /* torch.optim.Adam(params, lr) update (ywz/mywork/newtrain1.py:294-295; no amsgrad, no weight decay) for up to
  * HESIC_ADAM_MAX_TENSORS fp32 tensors per call: p, g, m (exp_avg), v (exp_avg_sq) dense arrays of numel elements in the
  * same element order, step = the tensor's own fp32 step counter (device scalar, incremented by the call).  The struct is
