@@ -662,3 +662,42 @@ def test_pooled_linear_head_forward_backward():
     assert y.shape == (B, N, 1, 1)
     assert rel_err(y, ref) < 1e-5
     assert rel_err(pd.grad, pr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (37, 45), (16, 32), (5, 3), (50, 130)])
+def test_conv3x3_c32_enhancement_kernel(hw):
+    """hesic_conv3x3_c32_forward (32-channel 3x3 convs of the enhancement stage): plain, LeakyReLU + one / two residuals,
+    the 32 -> 3 planar output form, and the packed 6 -> 32 input conv, on sizes that end in partial 16x32 tiles; against the
+    oracle conv on bf16-rounded operands (fp32 accumulation on both sides, one final bf16 rounding on the device)."""
+    Fn, O = _imp()
+    H, W = hw
+    x = bf(rnd(f"c32_x{hw}", (2, 32, H, W), -2, 2))
+    r1, r2 = bf(rnd(f"c32_r1{hw}", (2, 32, H, W))), bf(rnd(f"c32_r2{hw}", (2, 32, H, W)))
+    w = rnd("c32_w", (32, 32, 3, 3)) * 0.1
+    b = rnd("c32_b", (32,), -0.2, 0.2)
+    w3, b3 = rnd("c32_w3", (3, 32, 3, 3)) * 0.1, rnd("c32_b3", (3,), -0.2, 0.2)
+    img = rnd(f"c32_img{hw}", (2, 3, H, W), 0, 1)
+    leaky = torch.nn.functional.leaky_relu
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        xd = x.to(DEV, torch.bfloat16)
+        with torch.no_grad():
+            assert Fn.conv3x3_c32_ok(xd, w.to(DEV))
+            y0 = Fn.conv3x3_c32(xd, w.to(DEV), b.to(DEV))
+            y1 = Fn.conv3x3_c32(xd, w.to(DEV), b.to(DEV), act=2, res1=r1.to(DEV, torch.bfloat16))
+            y2 = Fn.conv3x3_c32(xd, w.to(DEV), None, act=2, res1=r1.to(DEV, torch.bfloat16), res2=r2.to(DEV, torch.bfloat16))
+            y3 = Fn.conv3x3_c32(xd, w3.to(DEV), b3.to(DEV), res1=img.to(DEV))
+            a6, b6 = rnd(f"c32_a{hw}", (2, 3, H, W), 0, 1), rnd(f"c32_bb{hw}", (2, 3, H, W), 0, 1)
+            w6 = rnd("c32_w6", (32, 6, 3, 3)) * 0.2
+            wpad = torch.zeros(32, 32, 3, 3)
+            wpad[:, :6] = w6
+            y6 = Fn.conv3x3_c32(Fn.pack_images_c32(a6.to(DEV), b6.to(DEV)), wpad.to(DEV), b.to(DEV))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    c = O.conv(x, bf(w), b, 1)
+    assert y0.dtype == torch.bfloat16 and y0.shape == c.shape and rel_err(y0, c) < 1e-2
+    assert rel_err(y1, leaky(c, 0.01) + r1) < 1e-2
+    assert rel_err(y2, leaky(O.conv(x, bf(w), None, 1), 0.01) + r1 + r2) < 1e-2
+    assert y3.dtype == torch.float32 and y3.shape == (2, 3, H, W)
+    assert rel_err(y3, O.conv(x, bf(w3), b3, 1) + img) < 1e-4
+    assert rel_err(y6, O.conv(bf(torch.cat((a6, b6), 1)), bf(w6), b, 1)) < 1e-2
