@@ -86,6 +86,9 @@ def repack_all():
     import numpy as np
     sig = tuple((e["weight"]().data_ptr(), 0 if e["mask"] is None else e["mask"].data_ptr(), e["wp"].data_ptr()) for e in ents)
     if _pack_table is None or _pack_table[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            # the job table is uploaded from host memory: never from inside a graph capture (warm-up steps build it)
+            raise RuntimeError("repack_all: the set of packed weights changed during HIP-graph capture; run a warm-up step first")
         jobs = np.zeros(len(ents), dtype=np.dtype([("w", "<u8"), ("mask", "<u8"), ("wp", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("KH", "<i4"),
                                                       ("KW", "<i4"), ("transposed", "<i4"), ("flip", "<i4"), ("dtype", "<i4"), ("block0", "<i4")]))
         blk = 0
