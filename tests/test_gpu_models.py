@@ -221,7 +221,8 @@ def test_graphed_forward_replays_the_eager_result():
         hesic_amd.set_compute_dtype(prev)
 
 
-def test_graphed_trainer_follows_the_eager_trace():
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_graphed_trainer_follows_the_eager_trace(kind):
     """Whole training step (zero_grad -> forward -> R-D backward -> Adam -> aux backward -> aux Adam) captured into a HIP
     graph: with the same injected noise the replayed steps give the eager Trainer's loss trace and parameters."""
     import hesic_amd
@@ -234,10 +235,10 @@ def test_graphed_trainer_follows_the_eager_trace():
         def noise_for(step):
             shp = {"z1": (2, 128, 2, 2), "z2": (2, 128, 2, 2)}
             return {k: synthetic._uniform(f"gt.noise.{step}.{k}", shp.get(k, (2, 192, 8, 8)), -0.5, 0.5).cuda()
-                    for k in ("z1", "y1", "y1w", "z2", "y2")}
+                    for k in ("z1", "y1", "y1b", "y1w", "z2", "y2", "y2b")}
         traces, finals = [], []
         for cls, kw in ((Trainer, {}), (GraphedTrainer, {"warmup": 2})):
-            net = models.HSIC()
+            net = models.HSIC() if kind == "hsic" else models.HSICJoint()
             synthetic.fill_state_dict_(net.state_dict())
             net = net.cuda()
             tr = cls(net, lr=1e-4, aux_lr=1e-3, lmbda=0.0067, **kw)
@@ -250,7 +251,10 @@ def test_graphed_trainer_follows_the_eager_trace():
         assert tr.graph is not None                       # steps 3 and 4 were graph replays
         for a, b in zip(*traces):
             for u, v in zip(a, b):
-                assert u == pytest.approx(v, rel=2e-3), traces
+                # atomics settle in a different order under graph replay; Adam turns a flipped sign of a ~0 gradient into a 2*lr step,
+                # and the context model of HESIC+ amplifies that faster than HESIC does (eager reruns agree to 4-5 digits, eager vs
+                # graph to 3)
+                assert u == pytest.approx(v, rel=2e-3 if kind == "hsic" else 8e-3), traces
         for k in ("encoder1.g_a_conv2.weight", "decoder2.after_conv.bias", "entropy_bottleneck1._biases.0", "entropy_bottleneck1.quantiles"):
             # Adam moves an element by <= lr per step whatever the gradient's size: where a ~0 gradient flips sign between two
             # runs (bf16 + atomics are not run-to-run bit-stable) the two trajectories drift by up to 2 * lr per step
