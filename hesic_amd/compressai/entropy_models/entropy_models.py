@@ -86,6 +86,10 @@ class EntropyModel(nn.Module):
         if inputs.is_cuda and inputs.dim() == 4 and inputs.dtype in (torch.float32, torch.bfloat16):
             if mode == "symbols":
                 return Fn.quantize_symbols(inputs, means)
+            if means is None:
+                # round-half-even of the stored value: one elementwise kernel (the conditional kernel below would also evaluate a
+                # likelihood nobody reads, on a ones / zeros scale and mean map filled just for it)
+                return torch.round(inputs.detach())
             sc = torch.ones_like(inputs)
             out, _ = Fn.gaussian_conditional(inputs.detach(), sc, None if means is None else means.detach().expand_as(inputs))
             return out
