@@ -40,10 +40,10 @@ def conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps=None):
 
 
 class KernelMeter:
-    """One HIP event pair around every implicit-GEMM launch (hesic_conv2d_forward / hesic_conv2d_gdn_forward),
+    """One HIP event pair around every implicit-GEMM launch (hesic_conv2d_forward[_ws|_f32out] / hesic_conv2d_gdn_forward),
     recorded on the stream the kernel is launched on; the launch descriptor gives the algorithmic FLOPs and
     hesic_conv2d_variant names the instantiation the library picked."""
-    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_gdn_forward")
+    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward")
 
     def __init__(self, L):
         self.L, self.orig, self.rec = L, L.call, []
@@ -125,6 +125,7 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
             if el > budget_s or n >= 64:
                 break
     m = O.metrics(out, x1, x2)
+    m["y_hat"] = {k: out[k].to(torch.int16) for k in ("y1_hat", "y2_hat")}      # rounded latents of the sample: the bit-exactness check
     return {"value": n / el, "unit": "stereo-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} x (1 pair {size}x{size}, fp32, torch CPU ops) after 1 warm-up, {el:.1f} s; threads calibrated "
                       f"over 8/16/32/64 of {cores} host cores"}, m
@@ -249,8 +250,13 @@ def main():
                 xa, xb, hh = (t.to(dev) for t in synthetic.stereo_batch(0, 1, 512, 512)) if (args.height or args.width) else (x1[:1], x2[:1], Hm[:1])
                 o1 = net(xa, xb, hh)
                 m1 = models.metrics_from(models.rate_distortion(o1, xa, xb))
+            flips = {k: float((o1[k].float().cpu().to(torch.int16) != v).float().mean()) for k, v in m_cpu["y_hat"].items()}
             res["parity"] = {"abs_dbpp": round(abs(m1["bpp"] - m_cpu["bpp"]), 6), "abs_dpsnr_db": round(abs(m1["psnr"] - m_cpu["psnr"]), 6),
                              "bpp_oracle": round(m_cpu["bpp"], 5), "psnr_oracle": round(m_cpu["psnr"], 4),
+                             "latent_flips": {k: round(v, 6) for k, v in flips.items()},
+                             "target": "abs_dbpp < 1e-3*max(1,bpp) and abs_dpsnr_db < 1e-3 (north_star)",
+                             "met": bool(abs(m1["bpp"] - m_cpu["bpp"]) < 1e-3 * max(1.0, m_cpu["bpp"]) and abs(m1["psnr"] - m_cpu["psnr"]) < 1e-3),
+                             "latents": "fp32 (y, z, sigma, mu from the fp32 accumulators)" if (args.dtype == "f32" or Fn.FP32_LATENTS) else "bf16",
                              "note": f"{args.dtype} GPU path vs fp32 CPU oracle, pair 0"}
         else:
             res["cpu_baseline"] = None

@@ -16,6 +16,7 @@ def lib():
             raise ImportError(f"{LIB_PATH} is missing -- run `make -C hesic_amd/csrc` (or __graft_entry__.build())")
         l = C.CDLL(LIB_PATH)
         l.hesic_pmf_to_quantized_cdf.argtypes = [C.POINTER(C.c_float), _i32, _i32, C.POINTER(C.c_uint32)]
+        l.hesic_pmf_rows_to_quantized_cdfs.argtypes = [C.POINTER(C.c_float), _i32, _i32, _pi32, C.POINTER(C.c_float), _i32, _pi32, _i32]
         l.hesic_rans_encoder_new.restype = _vp
         l.hesic_rans_encoder_free.argtypes = [_vp]
         l.hesic_rans_encoder_push.argtypes = [_vp, _pi32, _pi32, _i64, _pi32, _i32, _i32, _pi32, _pi32]
@@ -50,6 +51,68 @@ def cdf_table(cdfs):
     for i, r in enumerate(cdfs):
         flat[i * stride:i * stride + len(r)] = list(r)
     return flat, len(cdfs), stride
+
+
+def _np_i32(a):
+    import numpy as np
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def quantized_cdf_rows(pmf, lengths, tail_mass, precision, cdf_stride):
+    """(rows, stride) float32 pmf matrix -> (rows, cdf_stride) int32 quantised CDFs in ONE native call (row r codes its first
+    ``lengths[r]`` bins plus the tail-mass escape bin)."""
+    import numpy as np
+    pmf = np.ascontiguousarray(pmf, dtype=np.float32)
+    lengths, tail = _np_i32(lengths).reshape(-1), np.ascontiguousarray(tail_mass, dtype=np.float32).reshape(-1)
+    if pmf.ndim != 2 or lengths.size != pmf.shape[0] or tail.size != pmf.shape[0]:
+        raise ValueError("quantized_cdf_rows: one length and one tail mass per pmf row")
+    out = np.zeros((pmf.shape[0], int(cdf_stride)), dtype=np.int32)
+    rc = lib().hesic_pmf_rows_to_quantized_cdfs(pmf.ctypes.data_as(C.POINTER(C.c_float)), pmf.shape[0], pmf.shape[1],
+                                                lengths.ctypes.data_as(_pi32), tail.ctypes.data_as(C.POINTER(C.c_float)), int(precision),
+                                                out.ctypes.data_as(_pi32), out.shape[1])
+    if rc:
+        raise ValueError("quantized_cdf_rows: invalid pmf / lengths / precision")
+    return out
+
+
+def rans_encode_arrays(symbols, indexes, cdf_table, cdf_sizes, offsets) -> bytes:
+    """One rANS stream from numpy buffers (no Python lists): symbols / indexes (n,), cdf_table (ncdf, stride) int32."""
+    symbols, indexes, table = _np_i32(symbols).reshape(-1), _np_i32(indexes).reshape(-1), _np_i32(cdf_table)
+    sizes, offsets = _np_i32(cdf_sizes).reshape(-1), _np_i32(offsets).reshape(-1)
+    if symbols.size != indexes.size or table.ndim != 2 or sizes.size != table.shape[0] or offsets.size != table.shape[0]:
+        raise ValueError("rans_encode_arrays: inconsistent shapes")
+    l = lib()
+    h = l.hesic_rans_encoder_new()
+    try:
+        p = lambda a: a.ctypes.data_as(_pi32)
+        if l.hesic_rans_encoder_push(h, p(symbols), p(indexes), symbols.size, p(table), table.shape[0], table.shape[1], p(sizes), p(offsets)):
+            raise ValueError("encode_with_indexes: invalid indexes / cdfs")
+        n = l.hesic_rans_encoder_flush(h, None, 0)
+        buf = C.create_string_buffer(int(n))
+        l.hesic_rans_encoder_flush(h, buf, n)
+        return buf.raw
+    finally:
+        l.hesic_rans_encoder_free(h)
+
+
+def rans_decode_arrays(stream, indexes, cdf_table, cdf_sizes, offsets):
+    """Inverse of ``rans_encode_arrays``: int32 numpy array of ``indexes.size`` symbols."""
+    import numpy as np
+    indexes, table = _np_i32(indexes).reshape(-1), _np_i32(cdf_table)
+    sizes, offsets = _np_i32(cdf_sizes).reshape(-1), _np_i32(offsets).reshape(-1)
+    out = np.empty(indexes.size, dtype=np.int32)
+    l = lib()
+    h = l.hesic_rans_decoder_new()
+    try:
+        p = lambda a: a.ctypes.data_as(_pi32)
+        stream = bytes(stream)
+        if l.hesic_rans_decoder_set_stream(h, stream, len(stream)):
+            raise ValueError("set_stream: invalid stream")
+        if l.hesic_rans_decoder_decode(h, p(indexes), indexes.size, p(table), table.shape[0], table.shape[1], p(sizes), p(offsets), p(out)):
+            raise ValueError("decode_stream: invalid indexes / cdfs / stream")
+        return out
+    finally:
+        l.hesic_rans_decoder_free(h)
 
 
 class RangeEncoder:

@@ -112,6 +112,10 @@ _SIGS = {
     "hesic_sq_diff_backward": ([_vp, _i32, _P(_i64), _vp, _i32, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_act_backward": ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     "hesic_cast": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
+    "hesic_round": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
+    "hesic_conv2d_forward_f32out": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_size_t, _vp], _i32),
+    "hesic_eb_forward_f32in": ([_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
+    "hesic_gmm_forward_f32in": ([_P(GmmDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
 }
 
 _lib = None

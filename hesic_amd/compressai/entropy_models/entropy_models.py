@@ -47,7 +47,8 @@ def default_entropy_coder():
 
 
 def pmf_to_quantized_cdf(pmf, precision=16):
-    return torch.IntTensor(_pmf_to_quantized_cdf(pmf.tolist(), precision))
+    """1-D pmf tensor -> int32 tensor of len(pmf) + 1 cumulative counts summing to 2**precision."""
+    return torch.tensor(_pmf_to_quantized_cdf(pmf.tolist(), precision), dtype=torch.int32)
 
 
 class EntropyModel(nn.Module):
@@ -106,82 +107,92 @@ class EntropyModel(nn.Module):
 
     @staticmethod
     def _dequantize(inputs, means=None):
-        if means is not None:
-            outputs = inputs.type_as(means)
-            outputs += means
-        else:
-            outputs = inputs.float()
-        return outputs
+        """int32 symbols -> values: + means in the means' dtype, else plain fp32 (reference :127-134)."""
+        return inputs.float() if means is None else inputs.to(means.dtype) + means
 
     def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
-        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
-        for i, p in enumerate(pmf):
-            prob = torch.cat((p[:pmf_length[i]], tail_mass[i]), dim=0)
-            _cdf = pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
-            cdf[i, :_cdf.size(0)] = _cdf
-        return cdf
+        """All rows' quantised CDFs from the pmf matrix in one native call (``hesic_pmf_rows_to_quantized_cdfs``): row i codes
+        its first ``pmf_length[i]`` bins + the tail-mass escape bin; (rows, max_length + 2) int32 (reference :136-142)."""
+        from hesic_amd import _host
+        table = _host.quantized_cdf_rows(pmf.detach().cpu().numpy(), pmf_length.detach().cpu().numpy(),
+                                         tail_mass.detach().cpu().numpy(), self.entropy_coder_precision, int(max_length) + 2)
+        return torch.from_numpy(table)
+
+    # (buffer, what it is called in the messages): filled by update(), checked before every coding call
+    _TABLES = (("_quantized_cdf", "CDFs", "CDF", 2), ("_cdf_length", "CDF lengths", "offsets", 1), ("_offset", "offsets", "offsets", 1))
+
+    def _require_tables(self, only=None):
+        for name, plural, noun, ndim in self._TABLES:
+            if only is not None and name != only:
+                continue
+            buf = getattr(self, name)
+            if buf.numel() == 0:
+                raise ValueError(f"Uninitialized {plural}. Run update() first")
+            if buf.dim() != ndim:
+                raise ValueError(f"Invalid {noun} size {buf.size()}")
 
     def _check_cdf_size(self):
-        if self._quantized_cdf.numel() == 0:
-            raise ValueError("Uninitialized CDFs. Run update() first")
-        if len(self._quantized_cdf.size()) != 2:
-            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
+        self._require_tables("_quantized_cdf")
 
     def _check_offsets_size(self):
-        if self._offset.numel() == 0:
-            raise ValueError("Uninitialized offsets. Run update() first")
-        if len(self._offset.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._offset.size()}")
+        self._require_tables("_offset")
 
     def _check_cdf_length(self):
-        if self._cdf_length.numel() == 0:
-            raise ValueError("Uninitialized CDF lengths. Run update() first")
-        if len(self._cdf_length.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._cdf_length.size()}")
+        self._require_tables("_cdf_length")
+
+    def _coding_tables(self):
+        """(cdf table, lengths, offsets) as int32 numpy arrays for the native coder."""
+        self._require_tables()
+        as_np = lambda t: t.detach().reshape(t.shape[0], -1).int().cpu().numpy()
+        return as_np(self._quantized_cdf), as_np(self._cdf_length).reshape(-1), as_np(self._offset).reshape(-1)
+
+    def _native_coder(self):
+        from compressai import ans
+        return isinstance(self.entropy_coder._encoder, ans.RansEncoder)
 
     def compress(self, inputs, indexes, means=None):
-        """Tensors -> list of byte strings (one per batch element), reference :165-196."""
+        """Tensors -> one byte string per batch element (reference :165-196).  Symbols, indexes and tables go to the
+        native rANS coder as int32 buffers."""
         symbols = self._quantize(inputs, "symbols", means)
-        if len(inputs.size()) != 4:
+        if inputs.dim() != 4:
             raise ValueError("Invalid `inputs` size. Expected a 4-D tensor.")
         if inputs.size() != indexes.size():
             raise ValueError("`inputs` and `indexes` should have the same size.")
-        self._check_cdf_size()
-        self._check_cdf_length()
-        self._check_offsets_size()
-        cdf = self._quantized_cdf.cpu().tolist()
-        lengths = self._cdf_length.reshape(-1).int().cpu().tolist()
-        offsets = self._offset.reshape(-1).int().cpu().tolist()
-        symbols, indexes = symbols.cpu(), indexes.cpu()
-        return [self.entropy_coder.encode_with_indexes(symbols[i].reshape(-1).int().tolist(),
-                                                       indexes[i].reshape(-1).int().tolist(), cdf, lengths, offsets)
-                for i in range(symbols.size(0))]
+        table, lengths, offsets = self._coding_tables()
+        sym = symbols.detach().int().cpu().numpy().reshape(symbols.shape[0], -1)
+        idx = indexes.detach().int().cpu().numpy().reshape(indexes.shape[0], -1)
+        if self._native_coder():
+            from hesic_amd import _host
+            return [_host.rans_encode_arrays(s_, i_, table, lengths, offsets) for s_, i_ in zip(sym, idx)]
+        rows = table.tolist()
+        return [self.entropy_coder.encode_with_indexes(s_.tolist(), i_.tolist(), rows, lengths.tolist(), offsets.tolist())
+                for s_, i_ in zip(sym, idx)]
 
     def decompress(self, strings, indexes, means=None):
-        """List of byte strings -> tensor, reference :199-239."""
+        """Byte strings -> tensor (reference :199-239)."""
         if not isinstance(strings, (tuple, list)):
             raise ValueError("Invalid `strings` parameter type.")
-        if not len(strings) == indexes.size(0):
+        if len(strings) != indexes.size(0):
             raise ValueError("Invalid strings or indexes parameters")
-        if len(indexes.size()) != 4:
+        if indexes.dim() != 4:
             raise ValueError("Invalid `indexes` size. Expected a 4-D tensor.")
-        self._check_cdf_size()
-        self._check_cdf_length()
-        self._check_offsets_size()
+        table, lengths, offsets = self._coding_tables()
         if means is not None:
             if means.size()[:-2] != indexes.size()[:-2]:
                 raise ValueError("Invalid means or indexes parameters")
             if means.size() != indexes.size() and (means.size(2) != 1 or means.size(3) != 1):
                 raise ValueError("Invalid means parameters")
-        cdf = self._quantized_cdf.cpu().tolist()
-        lengths = self._cdf_length.reshape(-1).int().cpu().tolist()
-        offsets = self._offset.reshape(-1).int().cpu().tolist()
-        outputs = torch.empty(indexes.size(), dtype=torch.int32)
-        for i, s in enumerate(strings):
-            values = self.entropy_coder.decode_with_indexes(s, indexes[i].reshape(-1).int().cpu().tolist(), cdf, lengths, offsets)
-            outputs[i] = torch.tensor(values, dtype=torch.int32).reshape(outputs[i].size())
+        idx = indexes.detach().int().cpu().numpy().reshape(indexes.shape[0], -1)
+        if self._native_coder():
+            from hesic_amd import _host
+            decoded = [_host.rans_decode_arrays(s_, i_, table, lengths, offsets) for s_, i_ in zip(strings, idx)]
+        else:
+            rows = table.tolist()
+            decoded = [np.asarray(self.entropy_coder.decode_with_indexes(s_, i_.tolist(), rows, lengths.tolist(), offsets.tolist()),
+                                  dtype=np.int32) for s_, i_ in zip(strings, idx)]
         dev = self._quantized_cdf.device
-        return self._dequantize(outputs.to(dev), None if means is None else means.to(dev))
+        symbols = torch.from_numpy(np.stack(decoded)).reshape(indexes.size()).to(dev)
+        return self._dequantize(symbols, None if means is None else means.to(dev))
 
 
 class EntropyBottleneck(EntropyModel):
@@ -234,25 +245,26 @@ class EntropyBottleneck(EntropyModel):
         return torch.abs(logits - self.target).sum()
 
     def update(self, force=False):
+        """Fill ``_offset`` / ``_quantized_cdf`` / ``_cdf_length`` from the learned quantiles (reference :302-343): per channel the
+        support is [median - ceil(median - q_lo), median + ceil(q_hi - median)], the pmf is the model's likelihood at those
+        integer offsets from the median and the mass outside is the escape bin."""
         if self._offset.numel() > 0 and not force:
             return
         with torch.no_grad():
-            medians = self.quantiles[:, 0, 1]
-            minima = torch.clamp(torch.ceil(medians - self.quantiles[:, 0, 0]).int(), min=0)
-            maxima = torch.clamp(torch.ceil(self.quantiles[:, 0, 2] - medians).int(), min=0)
-            self._offset = -minima
-            pmf_start = medians - minima
-            pmf_length = maxima + minima + 1
-            max_length = int(pmf_length.max())
-            samples = torch.arange(max_length, device=medians.device)[None, :] + pmf_start[:, None, None]
-            lower = self._logits_cumulative(samples - 0.5, stop_gradient=True)
-            upper = self._logits_cumulative(samples + 0.5, stop_gradient=True)
-            sign = -torch.sign(lower + upper)
-            pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
-            tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
-            quantized_cdf = self._pmf_to_cdf(pmf.cpu(), tail_mass.cpu(), pmf_length.cpu(), max_length)
-            self._quantized_cdf = quantized_cdf.to(medians.device)
-            self._cdf_length = (pmf_length + 2).int()
+            q_lo, med, q_hi = self.quantiles[:, 0, 0], self.quantiles[:, 0, 1], self.quantiles[:, 0, 2]
+            below = torch.ceil(med - q_lo).clamp_(min=0).int()
+            above = torch.ceil(q_hi - med).clamp_(min=0).int()
+            support = below + above + 1
+            width = int(support.max())
+            grid = (med - below)[:, None, None] + torch.arange(width, device=med.device)[None, None, :]    # (C, 1, width)
+            lo = self._logits_cumulative(grid - 0.5, stop_gradient=True)
+            hi = self._logits_cumulative(grid + 0.5, stop_gradient=True)
+            flip = -torch.sign(lo + hi)
+            pmf = (torch.sigmoid(flip * hi) - torch.sigmoid(flip * lo)).abs()[:, 0, :]
+            outside = torch.sigmoid(lo[:, 0, :1]) + torch.sigmoid(-hi[:, 0, -1:])
+            self._quantized_cdf = self._pmf_to_cdf(pmf, outside, support, width).to(med.device)
+            self._offset = -below
+            self._cdf_length = (support + 2).int()
 
     def forward(self, x):
         if len(self.filters) != 4 or any(f != 3 for f in self.filters):
@@ -260,12 +272,13 @@ class EntropyBottleneck(EntropyModel):
         noise = self._noise_like(x) if self.training else None
         return self.forward_with_noise(x, noise)
 
-    def forward_with_noise(self, x, noise):
-        """noise=None: eval (round(x-med)+med); else x+noise (parity tests inject the draw)."""
+    def forward_with_noise(self, x, noise, out_dtype=None):
+        """noise=None: eval (round(x-med)+med); else x+noise (parity tests inject the draw).  ``out_dtype``: storage of the
+        returned z_hat when x is an fp32 latent of the bf16 mode (inference)."""
         if not hasattr(self, "_eb_packer"):
             self._eb_packer = Fn.PackedEb()
         return Fn.entropy_bottleneck(x, list(self._matrices), list(self._biases), list(self._factors), self.quantiles, noise,
-                                     packer=self._eb_packer)
+                                     packer=self._eb_packer, out_dtype=out_dtype)
 
     @staticmethod
     def _build_indexes(size):
@@ -318,27 +331,25 @@ class _GaussianBase(EntropyModel):
         self.update()
 
     def update(self):
-        multiplier = -self._standardized_quantile(self.tail_mass / 2)
-        pmf_center = torch.ceil(self.scale_table * multiplier).int()
-        pmf_length = 2 * pmf_center + 1
-        max_length = torch.max(pmf_length).item()
-        samples = torch.abs(torch.arange(max_length, device=pmf_center.device).int() - pmf_center[:, None]).float()
-        samples_scale = self.scale_table.unsqueeze(1).float()
-        upper = self._standardized_cumulative((.5 - samples) / samples_scale)
-        lower = self._standardized_cumulative((-.5 - samples) / samples_scale)
-        pmf = upper - lower
-        tail_mass = 2 * lower[:, :1]
-        quantized_cdf = self._pmf_to_cdf(pmf.cpu(), tail_mass.cpu(), pmf_length.cpu(), max_length)
-        self._quantized_cdf = quantized_cdf.to(pmf_center.device)
-        self._offset = -pmf_center
-        self._cdf_length = pmf_length + 2
+        """Tables for the scale levels (reference :494-514): level s gets the zero-mean Gaussian pmf on
+        [-c, c], c = ceil(s * Phi^-1(1 - tail_mass / 2)), plus the two-sided tail as escape bin."""
+        reach = -self._standardized_quantile(self.tail_mass / 2)
+        table = self.scale_table.float()
+        half = torch.ceil(table * reach).int()
+        support = 2 * half + 1
+        width = int(support.max())
+        dist = (torch.arange(width, device=table.device).int()[None, :] - half[:, None]).abs().float()
+        sigma = table[:, None]
+        hi = self._standardized_cumulative((0.5 - dist) / sigma)
+        lo = self._standardized_cumulative((-0.5 - dist) / sigma)
+        self._quantized_cdf = self._pmf_to_cdf(hi - lo, 2 * lo[:, :1], support, width).to(table.device)
+        self._offset = -half
+        self._cdf_length = support + 2
 
     def build_indexes(self, scales):
-        scales = self.lower_bound_scale(scales)
-        indexes = scales.new_full(scales.size(), len(self.scale_table) - 1).int()
-        for s in self.scale_table[:-1]:
-            indexes -= (scales <= s).int()
-        return indexes
+        """Index of the first table level >= scale (the last level for anything larger), reference :516-521."""
+        levels = self.scale_table[:-1].to(scales.device, scales.dtype).contiguous()
+        return torch.bucketize(self.lower_bound_scale(scales).contiguous(), levels).int()
 
     def _bound(self):
         return self.lower_bound_scale.value()
@@ -362,12 +373,12 @@ class GaussianConditional(_GaussianBase):
         scales = self.lower_bound_scale(scales)
         return self._standardized_cumulative((.5 - values) / scales) - self._standardized_cumulative((-.5 - values) / scales)
 
-    def forward(self, inputs, scales, means=None, noise=None):
+    def forward(self, inputs, scales, means=None, noise=None, out_dtype=None):
         if self.training and noise is None:
             noise = self._noise_like(inputs)
         lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
         return Fn.gaussian_conditional(inputs, scales, means, noise=noise if self.training else None,
-                                       scale_bound=self._bound(), lik_bound=lb)
+                                       scale_bound=self._bound(), lik_bound=lb, out_dtype=out_dtype)
 
 
 class GaussianMixtureConditional(_GaussianBase):
@@ -392,9 +403,9 @@ class GaussianMixtureConditional(_GaussianBase):
             likelihood = term if likelihood is None else likelihood + term
         return likelihood
 
-    def forward(self, inputs, scales, means=None, weights=None, noise=None):
+    def forward(self, inputs, scales, means=None, weights=None, noise=None, out_dtype=None):
         if self.training and noise is None:
             noise = self._noise_like(inputs)
         lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
         return Fn.gaussian_mixture(inputs, scales, means, weights, self.K, noise=noise if self.training else None,
-                                   scale_bound=self._bound(), lik_bound=lb)
+                                   scale_bound=self._bound(), lik_bound=lb, out_dtype=out_dtype)

@@ -30,6 +30,16 @@ class HipConv2d(nn.Conv2d):
                          padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                          mask=mask, tap_mask=tap_mask)
 
+    def run_latent(self, x, act=L.ACT_NONE, in_abs=False, want_lo=True):
+        """(lo, hi) of a conv that feeds an entropy model: ``hi`` is fp32 from the accumulators at bf16 inference
+        (``Fn.conv2d_latent``), ``lo`` (optional) the storage-dtype copy for the next conv."""
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d_latent(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                                padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
+                                want_lo=want_lo)
+
     def run_gdn(self, x, gdn):
         """gdn(self(x)); one fused kernel when eligible (inference, bf16 storage, 128 channels), else two ops."""
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False) and (self.weight.shape[1] != 3 or self.stride[0] == 2):
@@ -66,6 +76,13 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
             self._packer = Fn.PackedWeight()
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=True, act=act, packer=self._packer)
+
+    def run_latent(self, x, act=L.ACT_NONE, want_lo=True):
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d_latent(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                                padding=self.padding[0], transposed=True, act=act, packer=self._packer, want_lo=want_lo)
 
     def run_gdn(self, x, gdn):
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), True):

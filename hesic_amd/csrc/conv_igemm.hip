@@ -47,6 +47,8 @@ struct IgemmArgs {
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
+    float* y32;                // bf16 fast path: also (or, with y == nullptr, only) store act(conv + bias) as fp32 straight from the
+    int y32_ps, y32_co;        //      accumulators -- what feeds round() and the likelihoods must not pass through bf16 storage
 };
 
 // Tap geometry of one launch phase, all wave-uniform scalars.
@@ -567,6 +569,31 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
             }
             return;
         }
+        if (a.y32) {
+            // fp32 copy of the output (latents y / z and the sigma, mu maps): 16 bytes per lane and channel quad, the two lane
+            // halves of a pixel side by side (32-byte runs; the whole 4*BN-byte row leaves the wave within 8 instructions)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+                if (qy < a.QH && qx < a.QW) {
+                    const int oy = qy * a.out_step + taps.ry, ox = qx * a.out_step + taps.rx;
+                    float* dst = a.y32 + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y32_ps + a.y32_co + n0;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                            if (n0 + cl < a.Cout) {
+                                const f32x4 bq = a.bias ? *(const f32x4*)(a.bias + n0 + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+                                *(f32x4*)(dst + cl) = f32x4{apply_act(acc[i][j][4 * g] + bq[0], a.act), apply_act(acc[i][j][4 * g + 1] + bq[1], a.act),
+                                                            apply_act(acc[i][j][4 * g + 2] + bq[2], a.act), apply_act(acc[i][j][4 * g + 3] + bq[3], a.act)};
+                            }
+                        }
+                }
+            }
+            if (!a.y) return;
+        }
         __syncthreads();     // every wave is done with the ring before the epilogue reuses it
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -735,10 +762,10 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     }
 }
 
-// y = act(sum of the K-slice partials + bias) as bf16: one thread per pixel and 8 channels
+// y = act(sum of the K-slice partials + bias) as bf16 (y) and / or fp32 (y32): one thread per pixel and 8 channels
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int64_t npix, int Cout,
                                                             const float* __restrict__ bias, int act, bf16_t* __restrict__ y,
-                                                            int y_ps, int y_co) {
+                                                            int y_ps, int y_co, float* __restrict__ y32, int y32_ps, int y32_co) {
     const int cg = Cout >> 3;
     const int64_t total = npix * cg, slice = npix * Cout;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -751,9 +778,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             lo += *(const f32x4*)(src + s * slice);
             hi += *(const f32x4*)(src + s * slice + 4);
         }
-        *(u32x4*)(y + p * y_ps + y_co + c) =
-            u32x4{pack_bf2(apply_act(lo[0], act), apply_act(lo[1], act)), pack_bf2(apply_act(lo[2], act), apply_act(lo[3], act)),
-                  pack_bf2(apply_act(hi[0], act), apply_act(hi[1], act)), pack_bf2(apply_act(hi[2], act), apply_act(hi[3], act))};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = apply_act(lo[e], act); hi[e] = apply_act(hi[e], act); }
+        if (y32) {
+            *(f32x4*)(y32 + p * y32_ps + y32_co + c) = lo;
+            *(f32x4*)(y32 + p * y32_ps + y32_co + c + 4) = hi;
+        }
+        if (y)
+            *(u32x4*)(y + p * y_ps + y_co + c) =
+                u32x4{pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
     }
 }
 
@@ -902,6 +935,8 @@ static thread_local void* g_y_pre = nullptr;              // set by hesic_conv2d
 static thread_local float* g_ws = nullptr;               // set by hesic_conv2d_forward_ws: split-K workspace
 static thread_local size_t g_ws_bytes = 0;
 static thread_local size_t* g_ws_need = nullptr;         // set by hesic_conv2d_ws_bytes: only report the workspace size
+static thread_local float* g_y32 = nullptr;              // set by hesic_conv2d_forward_f32out: fp32 copy of the output
+static thread_local int g_y32_ps = 0, g_y32_co = 0;
 
 extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                                      int C, void* stream) {
@@ -946,7 +981,7 @@ extern "C" int hesic_conv2d_gdn_forward_train(const hesic_conv_desc* d, const vo
 
 extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                     void* y, void* stream) {
-    HESIC_CHECK_ARG(d && x && w_packed && y, "conv2d_forward: null pointer");
+    HESIC_CHECK_ARG(d && x && w_packed && (y || g_y32), "conv2d_forward: null pointer");
     HESIC_CHECK_ARG(d->Cin % BK == 0, "conv2d_forward: Cin=%d must be a multiple of %d (use hesic_sconv2d_forward)", d->Cin, BK);
     const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
     HESIC_CHECK_ARG(d->Cout % ce == 0 && d->y_c_off % ce == 0 && d->y_pix_stride % ce == 0 && d->x_c_off % ce == 0 &&
@@ -962,6 +997,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre;
+    a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
@@ -993,7 +1029,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int BN = (pad128 - pad64) * 8 > pad128 ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
     static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
-    const bool fast = d->dtype == HESIC_BF16 && (!legacy || gdn);
+    const bool fast = d->dtype == HESIC_BF16 && (!legacy || gdn || g_y32);
+    HESIC_CHECK_ARG(!g_y32 || (fast && !gdn), "conv2d_forward_f32out: bf16 storage without the fused GDN epilogue only");
     // pixel tile: 128, shrunk to 64 / 32 (fast path only) until the grid has ~1.5 blocks per CU
     int bm = 128;
     auto count_blocks = [&](int m) {
@@ -1106,7 +1143,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (ksplit > 1) {
         const int64_t npix = (int64_t)d->B * d->Ho * d->Wo;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(npix * (d->Cout / 8), 256)), dim3(256), 0, st, (const float*)g_ws, ksplit,
-                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off);
+                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off, g_y32, g_y32_ps, g_y32_co);
     }
     HESIC_LAUNCH_RETURN("conv2d_forward");
 }
@@ -1125,5 +1162,20 @@ extern "C" int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, 
     g_ws = (float*)ws; g_ws_bytes = ws ? ws_bytes : 0;
     const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
     g_ws = nullptr; g_ws_bytes = 0;
+    return rc;
+}
+
+extern "C" int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                           void* y, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    HESIC_CHECK_ARG(d && y_f32, "conv2d_forward_f32out: null pointer");
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16, "conv2d_forward_f32out: the fp32 copy exists for bf16 storage (fp32 storage is fp32 already)");
+    HESIC_CHECK_ARG(y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride,
+                    "conv2d_forward_f32out: fp32 channel slice must be 16-byte aligned and in range");
+    g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
+    g_ws = (float*)ws; g_ws_bytes = ws ? ws_bytes : 0;
+    const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
+    g_ws = nullptr; g_ws_bytes = 0;
+    g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
     return rc;
 }

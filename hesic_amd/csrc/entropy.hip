@@ -73,9 +73,9 @@ __device__ __forceinline__ float eb_logits(const EBParams& q, float v, float (*p
     return q.sp[EB_M4] * h[0] + q.sp[EB_M4 + 1] * h[1] + q.sp[EB_M4 + 2] * h[2] + q.b[12];
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 __global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
-                              T* __restrict__ zhat, float* __restrict__ lik, int32_t* __restrict__ sym, int64_t P, int C) {
+                              TO* __restrict__ zhat, float* __restrict__ lik, int32_t* __restrict__ sym, int64_t P, int C) {
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= C) return;
     EBParams q;
@@ -95,7 +95,7 @@ __global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__
         const float lo = eb_logits(q, v - 0.5f, nullptr, nullptr), up = eb_logits(q, v + 0.5f, nullptr, nullptr);
         const float s = -signf(lo + up);
         const float l = fabsf(sigmoidf(s * up) - sigmoidf(s * lo));
-        elem<T>::st(zhat + i, v);
+        elem<TO>::st(zhat + i, v);
         lik[i] = fmaxf(l, 1e-9f);
     }
 }
@@ -482,10 +482,22 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
 // bf16 fast form of gmm_fwd_kernel: one thread = two neighbouring channels of a pixel (4-byte loads), K a template
 // parameter so the 2K parameter loads of a thread are all in flight before the first erfc (the generic kernel's run-time
 // K loop made them K serial HBM round trips: 44 % of its wave cycles were parked at s_waitcnt), 32-bit indexing.
-template <int K>
-__global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc d, const bf16_t* __restrict__ y, const bf16_t* __restrict__ scales,
-                                                           const bf16_t* __restrict__ means, const float* __restrict__ weights,
-                                                           const bf16_t* __restrict__ noise, bf16_t* __restrict__ yhat, float* __restrict__ lik,
+// One channel pair of an NHWC row as two floats: 4-byte bf16 pairs or 8-byte fp32 pairs.
+__device__ __forceinline__ f32x2 ld_pair(const bf16_t* p) {
+    const uint32_t r = *(const uint32_t*)p;
+    return f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x2 ld_pair(const float* p) { return *(const f32x2*)p; }
+__device__ __forceinline__ void st_pair(bf16_t* p, float a, float b) { *(uint32_t*)p = pack_bf2(a, b); }
+__device__ __forceinline__ void st_pair(float* p, float a, float b) { *(f32x2*)p = f32x2{a, b}; }
+
+// TI: storage of y / scales / means / noise, TO: storage of y_hat.  TI = float with TO = bf16 is the inference form of the
+// bf16 mode: the latents and the entropy parameters come straight from the convs' fp32 accumulators
+// (hesic_conv2d_forward_f32out), only the integer-valued y_hat that feeds the synthesis convs is bf16.
+template <int K, typename TI = bf16_t, typename TO = bf16_t>
+__global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc d, const TI* __restrict__ y, const TI* __restrict__ scales,
+                                                           const TI* __restrict__ means, const float* __restrict__ weights,
+                                                           const TI* __restrict__ noise, TO* __restrict__ yhat, float* __restrict__ lik,
                                                            int32_t* __restrict__ sym, FastDiv fd_m2) {
     const int M2 = d.M >> 1;
     const uint32_t total = (uint32_t)d.B * (uint32_t)d.HW * (uint32_t)M2;
@@ -495,26 +507,26 @@ __global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc 
         const int b = (int)(p / (uint32_t)d.HW);
         const int64_t i = (int64_t)p * d.M + m;
         const int64_t sm = (int64_t)p * d.sm_pix_stride + m;
-        const uint32_t yr = *(const uint32_t*)(y + i);
-        uint32_t mr[K], sr[K];
+        const f32x2 yr = ld_pair(y + i);
+        f32x2 mr[K], sr[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            mr[k] = *(const uint32_t*)(means + sm + d.m_c_off + k * d.M);
-            sr[k] = *(const uint32_t*)(scales + sm + d.s_c_off + k * d.M);
+            mr[k] = ld_pair(means + sm + d.m_c_off + k * d.M);
+            sr[k] = ld_pair(scales + sm + d.s_c_off + k * d.M);
         }
         f32x2 wk[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) wk[k] = weights ? *(const f32x2*)(weights + (int64_t)b * d.K * d.M + k * d.M + m) : f32x2{1.f, 1.f};
-        const uint32_t nr = noise ? *(const uint32_t*)(noise + i) : 0u;
+        const f32x2 nr = noise ? ld_pair(noise + i) : f32x2{0.f, 0.f};
         float out_v[2], out_l[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float yv = __uint_as_float(e ? (yr & 0xffff0000u) : (yr << 16));
+            const float yv = e ? yr.y : yr.x;
             float v;
             if (noise) {
-                v = yv + __uint_as_float(e ? (nr & 0xffff0000u) : (nr << 16));
+                v = yv + (e ? nr.y : nr.x);
             } else if (d.use_means_in_quant) {
-                const float mu = __uint_as_float(e ? (mr[0] & 0xffff0000u) : (mr[0] << 16));
+                const float mu = e ? mr[0].y : mr[0].x;
                 const float r = rintf(yv - mu);
                 if (sym) sym[i + e] = (int32_t)r;
                 v = r + mu;
@@ -525,8 +537,8 @@ __global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc 
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float mu = __uint_as_float(e ? (mr[k] & 0xffff0000u) : (mr[k] << 16));
-                const float sc = fmaxf(__uint_as_float(e ? (sr[k] & 0xffff0000u) : (sr[k] << 16)), d.scale_bound);
+                const float mu = e ? mr[k].y : mr[k].x;
+                const float sc = fmaxf(e ? sr[k].y : sr[k].x, d.scale_bound);
                 const float a = fabsf(v - mu), inv = __builtin_amdgcn_rcpf(sc);
                 const float pk = phi_cdf_fast((0.5f - a) * inv) - phi_cdf_fast((-0.5f - a) * inv);
                 acc += weights ? pk * (e ? wk[k].y : wk[k].x) : pk;
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc 
             out_v[e] = v;
             out_l[e] = fmaxf(acc, d.lik_bound);
         }
-        *(uint32_t*)(yhat + i) = (uint32_t)f2bf(out_v[0]) | ((uint32_t)f2bf(out_v[1]) << 16);
+        st_pair(yhat + i, out_v[0], out_v[1]);
         *(f32x2*)(lik + i) = f32x2{out_l[0], out_l[1]};
     }
 }
@@ -622,4 +634,45 @@ extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const 
                            (const float*)scales, (const float*)means, weights, (const float*)noise, g_lik,
                            (const float*)g_yhat, (float*)dy, (float*)dscales, (float*)dmeans, dweights, ppb);
     HESIC_LAUNCH_RETURN("gmm_backward");
+}
+
+// ------------------------------------------------------------------ inference forms with fp32 latents (bf16 mode)
+// In the bf16 mode the analysis convs hand y / z and the hyper-synthesis convs hand sigma / mu over as fp32 (straight from
+// their accumulators, hesic_conv2d_forward_f32out): round() and the likelihoods then see the same precision as in the
+// reference's fp32 pipeline, only the outputs that feed the next bf16 conv (z_hat, y_hat) are stored in `out_dtype`.
+extern "C" int hesic_eb_forward_f32in(const float* z, const float* params, void* z_hat, int out_dtype, float* lik, int32_t* symbols,
+                                      int64_t P, int C, void* stream) {
+    HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward_f32in: bad arguments");
+    HESIC_CHECK_ARG(out_dtype == HESIC_BF16 || out_dtype == HESIC_F32, "eb_forward_f32in: bad dtype");
+    const int bx = C >= 128 ? 128 : 64;
+    const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
+    if (out_dtype == HESIC_BF16)
+        hipLaunchKernelGGL((eb_fwd_kernel<float, bf16_t>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
+                           (bf16_t*)z_hat, lik, symbols, P, C);
+    else
+        hipLaunchKernelGGL((eb_fwd_kernel<float, float>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
+                           (float*)z_hat, lik, symbols, P, C);
+    HESIC_LAUNCH_RETURN("eb_forward_f32in");
+}
+
+extern "C" int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, const float* scales, const float* means,
+                                       const float* weights, void* y_hat, int out_dtype, float* lik, int32_t* symbols, void* stream) {
+    if (int e = check_gmm(d, "gmm_forward_f32in")) return e;
+    HESIC_CHECK_ARG(y && scales && means && y_hat && lik, "gmm_forward_f32in: null pointer");
+    HESIC_CHECK_ARG(weights || d->K == 1, "gmm_forward_f32in: weights required for K > 1");
+    HESIC_CHECK_ARG(out_dtype == HESIC_BF16 || out_dtype == HESIC_F32, "gmm_forward_f32in: bad dtype");
+    const int64_t total = (int64_t)d->B * d->HW * d->M;
+    HESIC_CHECK_ARG((d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 && d->s_c_off % 2 == 0 && d->m_c_off % 2 == 0 &&
+                        total / 2 < (1ll << 31) && !((uintptr_t)y & 7) && !((uintptr_t)scales & 7) && !((uintptr_t)means & 7) &&
+                        !((uintptr_t)y_hat & 7) && !((uintptr_t)lik & 7) && !((uintptr_t)weights & 7),
+                    "gmm_forward_f32in: K in {1, 5}, even channel geometry and 8-byte aligned buffers");
+    const dim3 g2(grid_for(total / 2, 256));
+    const FastDiv fd = make_fastdiv((uint32_t)(d->M / 2));
+    hipStream_t st = (hipStream_t)stream;
+#define GMM_F32IN(K_, TO_) hipLaunchKernelGGL((gmm_fwd_pair_kernel<K_, float, TO_>), g2, dim3(256), 0, st, *d, y, scales, means, weights, \
+                                              (const float*)nullptr, (TO_*)y_hat, lik, symbols, fd)
+    if (d->K == 5) { if (out_dtype == HESIC_BF16) GMM_F32IN(5, bf16_t); else GMM_F32IN(5, float); }
+    else { if (out_dtype == HESIC_BF16) GMM_F32IN(1, bf16_t); else GMM_F32IN(1, float); }
+#undef GMM_F32IN
+    HESIC_LAUNCH_RETURN("gmm_forward_f32in");
 }

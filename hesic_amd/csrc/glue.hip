@@ -372,7 +372,20 @@ __global__ void cast_kernel(const void* __restrict__ x, int xd, void* __restrict
         st_any(y, i, yd, ld_any(x, i, xd));
 }
 
+// round-half-even of x, stored as y's dtype: EntropyModel._quantize(x, "dequantize") without means (newnet1.py:755) on an
+// fp32 latent whose rounded value feeds a bf16 conv
+__global__ void round_cast_kernel(const void* __restrict__ x, int xd, void* __restrict__ y, int yd, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st_any(y, i, yd, rintf(ld_any(x, i, xd)));
+}
+
 }  // namespace
+
+extern "C" int hesic_round(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream) {
+    HESIC_CHECK_ARG(x && y && n > 0, "round: bad arguments");
+    hipLaunchKernelGGL(round_cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n);
+    HESIC_LAUNCH_RETURN("round");
+}
 
 extern "C" int hesic_upsample4_forward(const void* x, void* y, int B, int H, int W, int C, int yps, int yco, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && yco + C <= yps, "upsample4_forward: bad arguments");

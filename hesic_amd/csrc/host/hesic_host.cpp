@@ -57,6 +57,27 @@ extern "C" int hesic_pmf_to_quantized_cdf(const float* pmf, int n, int precision
     return 0;
 }
 
+// Every row of a pmf matrix at once (EntropyModel.update(): one row per channel / scale level): row r codes
+// pmf[r][0 .. lengths[r]) followed by its tail-mass escape bin; the quantised CDF (lengths[r] + 2 entries) lands in
+// cdf_out[r][...], the rest of the row is zero.
+extern "C" int hesic_pmf_rows_to_quantized_cdfs(const float* pmf, int rows, int pmf_stride, const int32_t* lengths, const float* tail_mass,
+                                                int precision, int32_t* cdf_out, int cdf_stride) {
+    if (!pmf || !lengths || !tail_mass || !cdf_out || rows < 1 || pmf_stride < 1) return -1;
+    std::vector<float> row;
+    std::vector<uint32_t> q;
+    for (int r = 0; r < rows; ++r) {
+        const int n = lengths[r];
+        if (n < 1 || n > pmf_stride || n + 2 > cdf_stride) return -1;
+        row.assign(pmf + (int64_t)r * pmf_stride, pmf + (int64_t)r * pmf_stride + n);
+        row.push_back(tail_mass[r]);
+        q.assign(n + 2, 0u);
+        if (hesic_pmf_to_quantized_cdf(row.data(), n + 1, precision, q.data()) != 0) return -1;
+        int32_t* dst = cdf_out + (int64_t)r * cdf_stride;
+        for (int i = 0; i < cdf_stride; ++i) dst[i] = i < n + 2 ? (int32_t)q[i] : 0;
+    }
+    return 0;
+}
+
 extern "C" hesic_rans_encoder* hesic_rans_encoder_new(void) { return new hesic_rans_encoder(); }
 extern "C" void hesic_rans_encoder_free(hesic_rans_encoder* e) { delete e; }
 

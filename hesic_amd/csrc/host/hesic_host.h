@@ -15,6 +15,12 @@ extern "C" {
 /* cdf_out has n+1 entries; cdf_out[0]=0, cdf_out[n]=1<<precision, strictly increasing. */
 int hesic_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf_out);
 
+/* The same for every row of a [rows][pmf_stride] matrix in one call (EntropyBottleneck.update / GaussianConditional.update,
+ * compressai/entropy_models/entropy_models.py:136-142): row r = pmf[r][0..lengths[r]) + its tail-mass escape bin;
+ * cdf_out [rows][cdf_stride] int32 gets lengths[r]+2 entries per row, zero padded.                       */
+int hesic_pmf_rows_to_quantized_cdfs(const float* pmf, int rows, int pmf_stride, const int32_t* lengths, const float* tail_mass,
+                                     int precision, int32_t* cdf_out, int cdf_stride);
+
 typedef struct hesic_rans_encoder hesic_rans_encoder;
 typedef struct hesic_rans_decoder hesic_rans_decoder;
 

@@ -169,19 +169,29 @@ class PackedWeight:
 
 
 def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, act=0, in_abs=0, tap_mask=0,
-               out=None, out_c_off=0, x_c_off=0):
-    """Launch the implicit-GEMM kernel. ``x`` NHWC (may be wider than Cin), returns / fills NHWC ``out``."""
+               out=None, out_c_off=0, x_c_off=0, f32_out=None):
+    """Launch the implicit-GEMM kernel. ``x`` NHWC (may be wider than Cin), returns / fills NHWC ``out``.
+    ``f32_out`` ("only" | "both", bf16 storage): also / only store the output as fp32 from the fp32 accumulators
+    (``hesic_conv2d_forward_f32out``); returns ``(out | None, out_f32)`` then."""
     dtype = x.dtype
-    if out is None:
+    if out is None and f32_out != "only":
         out = _empty_nhwc(B, Cout, Ho, Wo, dtype, x.device)
+    y_ps, y_co = (out.shape[1], out_c_off) if out is not None else (Cout, 0)
     d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(dtype), act, in_abs,
-                   x.shape[1], x_c_off, out.shape[1], out_c_off, tap_mask)
+                   x.shape[1], x_c_off, y_ps, y_co, tap_mask)
     key = (B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, int(transposed), L.dt(dtype), tap_mask)
     need = _ws_bytes.get(key)
     if need is None:
         need = _ws_bytes[key] = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    ws = None
     if need and SPLIT_K:      # low-resolution layer: split-K launch, fp32 partial tiles in a scratch buffer
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    if f32_out:
+        out32 = _empty_nhwc(B, Cout, Ho, Wo, torch.float32, x.device)
+        L.call("hesic_conv2d_forward_f32out", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.ptr(out32), Cout, 0,
+               L.ptr(ws), need if ws is not None else 0, L.stream())
+        return out, out32
+    if ws is not None:
         L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.ptr(ws), need, L.stream())
     else:
         L.call("hesic_conv2d_forward", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.stream())
@@ -490,6 +500,50 @@ def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, a
     return _ConvFn.apply(x, weight, bias, (kernel_size, stride, padding, transposed, act, int(in_abs), tap_mask, packer, mask))
 
 
+FP32_LATENTS = _os.environ.get("HESIC_BF16_LATENTS") is None      # A/B switch: set to store latents / sigma / mu as bf16 again
+
+
+def fp32_latents():
+    """True when the inference forward keeps what feeds round() and the likelihoods in fp32 although the feature maps are
+    bf16: the latents y, z and the sigma / mu maps are written from the convs' fp32 accumulators (round 1 stored them as
+    bf16: one ulp = 1/16 at |y| ~ 10, so latents near .5 flipped and bpp / PSNR sat just outside the 1e-3 target)."""
+    return FP32_LATENTS and _compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
+
+
+def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, in_abs=False,
+                  tap_mask=0, packer=None, mask=None, want_lo=True):
+    """A conv whose output feeds an entropy model: returns ``(lo, hi)`` -- ``lo`` in the storage dtype for the next conv
+    (None unless ``want_lo``), ``hi`` for round() / the likelihood.  bf16 inference: ``hi`` is fp32 straight from the
+    accumulators; otherwise both are the ordinary output."""
+    k = kernel_size
+    Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    ok = (fp32_latents() and x.is_cuda and x.dtype == torch.bfloat16 and not _is_narrow(Cin) and not _is_narrow(Cout)
+          and Cin % 32 == 0 and Cout % 8 == 0)
+    if not ok:
+        y = conv2d(x, weight, bias, kernel_size=k, stride=stride, padding=padding, transposed=transposed, act=act, in_abs=in_abs,
+                   tap_mask=tap_mask, packer=packer, mask=mask)
+        return (y if want_lo else None), y
+    L.require_cuda(x, weight)
+    packer = packer if packer is not None else PackedWeight()
+    B, _, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    x = _nhwc(x)
+    wp = packer.get(weight, mask, Cout, Cin, k, k, transposed, False, x.dtype)
+    return _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, padding, transposed, act, int(in_abs), tap_mask,
+                      f32_out="both" if want_lo else "only")
+
+
+def round_to(x, dtype):
+    """round-half-even(x) stored as ``dtype``: ``_quantize(x, "dequantize")`` without means on an fp32 latent."""
+    L.require_cuda(x)
+    x = x.detach()
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=_CL)):
+        x = x.contiguous(memory_format=_CL)
+    y = torch.empty_like(x, dtype=dtype)
+    L.call("hesic_round", L.ptr(x), L.dt(x), L.ptr(y), L.dt(dtype), x.numel(), L.stream())
+    return y
+
+
 # ------------------------------------------------------------------------------------ GDN
 def conv3x3_c32_ok(x, weight):
     """Inference-only fast path of the enhancement net's 32-channel 3x3 convs (``hesic_conv3x3_c32_forward``)."""
@@ -707,13 +761,19 @@ class PackedEb:
         return self._hit[1]
 
 
-def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, packer=None):
+def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, packer=None, out_dtype=None):
+    """``out_dtype`` (inference, fp32 ``z`` only): storage of z_hat when it differs from z's (bf16 mode with fp32 latents)."""
     if packer is not None and noise is None and not torch.is_grad_enabled():
         # inference: cached parameter table, no autograd bookkeeping -- one launch
         L.require_cuda(z)
         B, Cc, H, W = z.shape
         z = _nhwc(z)
         table = packer.get(matrices, biases, factors, quantiles)
+        if out_dtype is not None and out_dtype != z.dtype and z.dtype == torch.float32:
+            zh = _empty_nhwc(B, Cc, H, W, out_dtype, z.device)
+            lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
+            L.call("hesic_eb_forward_f32in", L.ptr(z), L.ptr(table), L.ptr(zh), L.dt(out_dtype), L.ptr(lik), None, B * H * W, Cc, L.stream())
+            return zh, lik
         zh = torch.empty_like(z, memory_format=_CL)
         lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
         L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), None, L.ptr(zh), L.ptr(lik), None, B * H * W, Cc, L.dt(z), L.stream())
@@ -780,11 +840,52 @@ class _GmmFn(torch.autograd.Function):
         return dy, dsc, dmu, dw, None, None, None, None, None
 
 
-def gaussian_mixture(y, scales, means, weights, K, noise=None, scale_bound=0.11, lik_bound=1e-9):
+def _sm_pointers(scales, means, y, B, K, M):
+    """(stride, scales ptr, means ptr, keep-alive) of the two parameter maps in ``y``'s dtype; the two halves of one
+    channels_last tensor (``chunk(2, 1)``) stay in place."""
+    same = (scales.dim() == 4 and means.dim() == 4 and scales._base is not None and scales._base is means._base
+            and scales._base.is_contiguous(memory_format=_CL) and scales._base.dtype == y.dtype)
+    if same:
+        base = scales._base
+        ps = base.shape[1]
+        s_off = scales.storage_offset() - base.storage_offset()
+        m_off = means.storage_offset() - base.storage_offset()
+        if 0 <= s_off < ps and 0 <= m_off < ps and base.shape[0] == B and base.shape[2:] == y.shape[2:]:
+            es = base.element_size()
+            return ps, C.c_void_p(base.data_ptr() + s_off * es), C.c_void_p(base.data_ptr() + m_off * es), (base,)
+    scales, means = _nhwc(scales.to(y.dtype)), _nhwc(means.to(y.dtype))
+    return K * M, L.ptr(scales), L.ptr(means), (scales, means)
+
+
+def _gmm_f32in(y, scales, means, weights, K, use_means_in_quant, scale_bound, lik_bound, out_dtype):
+    """Inference with fp32 latents / parameters and y_hat stored as ``out_dtype`` (``hesic_gmm_forward_f32in``)."""
+    L.require_cuda(y, scales, means)
+    B, M, H, W = y.shape
+    y = _nhwc(y.detach())
+    ps, sptr, mptr, keep = _sm_pointers(scales.detach(), means.detach(), y, B, K, M)
+    wts = None if weights is None else weights.detach().reshape(B, K * M).to(torch.float32).contiguous()
+    yh = _empty_nhwc(B, M, H, W, out_dtype, y.device)
+    lik = _empty_nhwc(B, M, H, W, torch.float32, y.device)
+    d = L.GmmDesc(B, H * W, M, K, L.F32, int(use_means_in_quant), ps, 0, 0, float(scale_bound), float(lik_bound))
+    L.call("hesic_gmm_forward_f32in", C.byref(d), L.ptr(y), sptr, mptr, L.ptr(wts), L.ptr(yh), L.dt(out_dtype), L.ptr(lik), None, L.stream())
+    del keep
+    return yh, lik
+
+
+def _use_f32in(y, noise, out_dtype, K, M):
+    return (out_dtype is not None and out_dtype != y.dtype and y.dtype == torch.float32 and noise is None and not torch.is_grad_enabled()
+            and K in (1, 5) and M % 2 == 0 and y.is_cuda)
+
+
+def gaussian_mixture(y, scales, means, weights, K, noise=None, scale_bound=0.11, lik_bound=1e-9, out_dtype=None):
+    if _use_f32in(y, noise, out_dtype, K, y.shape[1]):
+        return _gmm_f32in(y, scales, means, weights, K, False, scale_bound, lik_bound, out_dtype)
     return _GmmFn.apply(y, scales, means, weights, noise, K, False, scale_bound, lik_bound)
 
 
-def gaussian_conditional(y, scales, means=None, noise=None, scale_bound=0.11, lik_bound=1e-9):
+def gaussian_conditional(y, scales, means=None, noise=None, scale_bound=0.11, lik_bound=1e-9, out_dtype=None):
+    if means is not None and _use_f32in(y, noise, out_dtype, 1, y.shape[1]):
+        return _gmm_f32in(y, scales, means, None, 1, True, scale_bound, lik_bound, out_dtype)
     return _GmmFn.apply(y, scales, means, None, noise, 1, means is not None, scale_bound, lik_bound)
 
 

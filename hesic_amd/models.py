@@ -106,14 +106,21 @@ class Encoder1(nn.Module):
         self.g_a_conv3, self.g_a_gdn3 = conv(N, N), GDN(N)
         self.g_a_conv4 = conv(N, M)
 
-    def stack(self, x):
+    def trunk(self, x):
         x = self.g_a_conv1.run_gdn(x, self.g_a_gdn1)        # conv + GDN in one kernel at inference
         x = self.g_a_conv2.run_gdn(x, self.g_a_gdn2)
-        x = self.g_a_conv3.run_gdn(x, self.g_a_gdn3)
-        return self.g_a_conv4(x)
+        return self.g_a_conv3.run_gdn(x, self.g_a_gdn3)
+
+    def stack(self, x):
+        return self.g_a_conv4(self.trunk(x))
 
     def forward(self, x):
         return self.stack(x)
+
+    def latent(self, x, want_lo=True):
+        """(lo, hi): the latent in the storage dtype for the hyper-analysis convs (None unless ``want_lo``) and as it feeds
+        round() / the likelihood (fp32 from the accumulators at bf16 inference, see ``Fn.conv2d_latent``)."""
+        return self.g_a_conv4.run_latent(self.trunk(x), want_lo=want_lo)
 
 
 class Encoder2(Encoder1):
@@ -131,6 +138,10 @@ class Encoder2(Encoder1):
     def forward(self, x1_warp, x2):
         t = self.pre_gdn(self.pre_conv.run_cat(x1_warp, x2))
         return self.stack(t)
+
+    def latent(self, x1_warp, x2, want_lo=True):
+        t = self.pre_gdn(self.pre_conv.run_cat(x1_warp, x2))
+        return self.g_a_conv4.run_latent(self.trunk(t), want_lo=want_lo)
 
 
 class Decoder1(nn.Module):
@@ -181,6 +192,13 @@ class encode_hyper(nn.Module):
         t = s[2].run(t, act=RELU)
         return s[4].run(t)
 
+    def latent(self, y):
+        """z as it feeds the bottleneck (fp32 at bf16 inference)."""
+        s = self.encode_hyper
+        t = s[0].run(y, act=RELU, in_abs=True)
+        t = s[2].run(t, act=RELU)
+        return s[4].run_latent(t, want_lo=False)[1]
+
 
 class spatial_pool2d(nn.Module):
     """Global spatial max per (sample, channel) (newnet1.py:441-453) as one reduction kernel."""
@@ -213,12 +231,14 @@ class gmm_hyper_y1(nn.Module):
         self.gmm_weights = nn.Sequential(deconv(N, N, kernel_size=5), nn.LeakyReLU(), deconv(N, M * K, kernel_size=5),
                                          spatial_pool2d(), nn.LeakyReLU(), conv(M * K, M * K, kernel_size=1, stride=1))
 
-    def forward(self, z):
+    def forward(self, z, hi=False):
+        """``hi``: sigma / means as they feed the likelihood (fp32 from the accumulators at bf16 inference)."""
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        last = (lambda c, t, act=NONE: c.run_latent(t, act=act, want_lo=False)[1]) if hi else (lambda c, t, act=NONE: c.run(t, act=act))
         sigma, means, weights = _branches(
             z,
-            lambda: s[4].run(s[2].run(s[0].run(z, act=RELU), act=RELU), act=RELU),
-            lambda: m[4].run(m[2].run(m[0].run(z, act=LEAKY), act=LEAKY)),
+            lambda: last(s[4], s[2].run(s[0].run(z, act=RELU), act=RELU), RELU),
+            lambda: last(m[4], m[2].run(m[0].run(z, act=LEAKY), act=LEAKY)),
             lambda: _mixture_weights(w, w[2].run(w[0].run(z, act=LEAKY)), self.K, self.M))
         return sigma, means, weights
 
@@ -239,13 +259,14 @@ class gmm_hyper_y2(nn.Module):
                                          conv(N, M * K, kernel_size=5, stride=1), spatial_pool2d(), nn.LeakyReLU(),
                                          conv(M * K, M * K, kernel_size=1, stride=1))
 
-    def forward(self, z2, y1):
+    def forward(self, z2, y1, hi=False):
         c = Fn.upsample4_cat(z2, y1)
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        last = (lambda cv, t, act=NONE: cv.run_latent(t, act=act, want_lo=False)[1]) if hi else (lambda cv, t, act=NONE: cv.run(t, act=act))
         sigma, means, weights = _branches(
             c,
-            lambda: s[4].run(s[2].run(s[0].run(c, act=RELU), act=RELU), act=RELU),
-            lambda: m[4].run(m[2].run(m[0].run(c, act=LEAKY), act=LEAKY)),
+            lambda: last(s[4], s[2].run(s[0].run(c, act=RELU), act=RELU), RELU),
+            lambda: last(m[4], m[2].run(m[0].run(c, act=LEAKY), act=LEAKY)),
             lambda: _mixture_weights(w, w[2].run(w[0].run(c, act=LEAKY)), self.K, self.M))
         return sigma, means, weights
 
@@ -265,6 +286,15 @@ def _quant(model, y, nz, key, training):
     return model._quantize(y, "dequantize")
 
 
+def _round_latent(model, y_hi):
+    """``_quantize(y, "dequantize")`` without means at inference: an fp32 latent of the bf16 mode is rounded in fp32 and
+    stored in the storage dtype (integers: exact) for the convs that read it."""
+    cdt = Fn.compute_dtype()
+    if y_hi.is_cuda and y_hi.dtype == torch.float32 and cdt != torch.float32:
+        return Fn.round_to(y_hi, cdt)
+    return model._quantize(y_hi, "dequantize")
+
+
 # --------------------------------------------------------------------------------------------- HESIC
 class HSIC(StereoCompressionModel):
     """HESIC (reference ``HSIC``, ywz/mywork/newnet1.py:696-783)."""
@@ -282,8 +312,8 @@ class HSIC(StereoCompressionModel):
     def forward(self, x1, x2, h_matrix, noise=None):
         """``noise`` (training only, optional): dict z1,y1,y1w,z2,y2 of U(-1/2,1/2) draws, in the order the
         reference makes them; absent keys are drawn on the device."""
-        if OVERLAP_STREAMS and not self.training and not torch.is_grad_enabled() and x1.is_cuda:
-            return self._forward_two_streams(x1, x2, h_matrix)
+        if not self.training and not torch.is_grad_enabled() and x1.is_cuda:
+            return self._forward_eval(x1, x2, h_matrix, two_streams=OVERLAP_STREAMS)
         tr = self.training
         size = (x1.shape[-2], x1.shape[-1])
         y1 = self.encoder1(x1)
@@ -333,22 +363,23 @@ class HSIC(StereoCompressionModel):
 
     def _analysis(self, x1, x2, h_matrix):
         size = (x1.shape[-2], x1.shape[-1])
-        y1 = self.encoder1(x1)
-        z1 = self._h_a1(y1)
+        cdt = Fn.compute_dtype()
+        y1_lo, y1 = self.encoder1.latent(x1)
+        z1 = self._h_a1.latent(y1_lo)
         z1_strings = self.entropy_bottleneck1.compress(z1)
-        z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(z1.dtype)
-        gmm1 = self._h_s1(z1_hat)
-        y1_hat = self.gaussian1._quantize(y1, "dequantize")
+        z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(cdt)
+        gmm1 = self._h_s1(z1_hat, hi=True)
+        y1_hat = _round_latent(self.gaussian1, y1)
         x1_hat = self.decoder1(y1_hat)
         x1_warp = warp_perspective(x1, h_matrix, size)
-        y2 = self.encoder2(x1_warp, x2)
-        z2 = self._h_a2(y2)
+        y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+        z2 = self._h_a2.latent(y2_lo)
         z2_strings = self.entropy_bottleneck2.compress(z2)
-        z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(z2.dtype)
+        z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(cdt)
         x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-        y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
-        gmm2 = self._h_s2(z2_hat, y1_hat_w)
-        y2_hat = self.gaussian2._quantize(y2, "dequantize")
+        y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+        gmm2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
+        y2_hat = _round_latent(self.gaussian2, y2)
         return (y1_hat, z1_hat, z1_strings, gmm1), (y2_hat, z2_hat, z2_strings, gmm2)
 
     def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
@@ -428,44 +459,58 @@ class HSIC(StereoCompressionModel):
             zs = (int(z_shape[0]), int(z_shape[1]))
             z1_hat = self.entropy_bottleneck1.decompress([views[0][2]], zs).to(dev, cdt)
             z2_hat = self.entropy_bottleneck2.decompress([views[1][2]], zs).to(dev, cdt)
-            gmm1 = self._h_s1(z1_hat)
+            gmm1 = self._h_s1(z1_hat, hi=True)
             y1_hat = decode_view(gmm1, views[0][0], views[0][1], self.gaussian1)
             x1_hat = self.decoder1(y1_hat)
             x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
-            gmm2 = self._h_s2(z2_hat, y1_hat_w)
+            y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+            gmm2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
             y2_hat = decode_view(gmm2, views[1][0], views[1][1], self.gaussian2)
             x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,
                 "dectime": time.time() - start}
 
-    def _forward_two_streams(self, x1, x2, h_matrix):
-        """Inference schedule on two HIP streams.  View 2's analysis (warp -> encoder2 -> h_a2 -> bottleneck) depends
-        only on the inputs, so it runs on a side stream while the main stream walks view 1's chain
+    def _forward_eval(self, x1, x2, h_matrix, two_streams=True):
+        """Inference schedule.  View 2's analysis (warp -> encoder2 -> h_a2 -> bottleneck) depends only on the inputs, so
+        with ``two_streams`` it runs on a side HIP stream while the main stream walks view 1's chain
         (encoder1 -> hyper path -> decoder1 -> warp -> encoder1); the many small hyper-path kernels of one stream fill
-        the CUs the other stream's tail blocks leave idle.  Results are identical to the single-stream order."""
+        the CUs the other stream's tail blocks leave idle.  Results are identical to the single-stream order.
+
+        What feeds round() and the likelihoods -- y, z, sigma, mu -- is fp32 even in the bf16 mode (``Fn.fp32_latents``):
+        those convs also / only write their fp32 accumulators, the entropy kernels read fp32 and store the integer-valued
+        y_hat / z_hat in the storage dtype for the synthesis convs."""
         size = (x1.shape[-2], x1.shape[-1])
-        main = torch.cuda.current_stream()
-        side = _side_stream(x1.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        cdt = Fn.compute_dtype()
+
+        def view2_front():
             x1_warp = warp_perspective(x1, h_matrix, size)
-            y2 = self.encoder2(x1_warp, x2)
-            z2 = self._h_a2(y2)
-            z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None)
-        y1 = self.encoder1(x1)
-        z1 = self._h_a1(y1)
-        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None)
-        s1, m1, w1 = self._h_s1(z1_hat)
-        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, w1)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            z2 = self._h_a2.latent(y2_lo)
+            z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None, out_dtype=cdt)
+            return y2, z2_hat, z2_lik
+
+        if two_streams:
+            main = torch.cuda.current_stream()
+            side = _side_stream(x1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                y2, z2_hat, z2_lik = view2_front()
+        y1_lo, y1 = self.encoder1.latent(x1)
+        z1 = self._h_a1.latent(y1_lo)
+        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None, out_dtype=cdt)
+        s1, m1, w1 = self._h_s1(z1_hat, hi=True)
+        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, w1, out_dtype=cdt)
         x1_hat = self.decoder1(y1_hat)
-        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-        y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
-        main.wait_stream(side)
-        for t in (y2, z2_hat, z2_lik):            # produced on the side stream, consumed / freed on the main one
-            t.record_stream(main)
-        s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w)
-        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2)
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)          # :753 and :767 are the same tensor
+        y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+        if two_streams:
+            main.wait_stream(side)
+            for t in (y2, z2_hat, z2_lik):            # produced on the side stream, consumed / freed on the main one
+                t.record_stream(main)
+        else:
+            y2, z2_hat, z2_lik = view2_front()
+        s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
+        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2, out_dtype=cdt)
         x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
@@ -476,6 +521,11 @@ def _seq3(seq, x, last_act=NONE):
     """conv/deconv -> LeakyReLU -> conv/deconv -> LeakyReLU -> conv (the h_a / h_s / entropy_parameters
     Sequentials of newnet1_joint.py:611-665) with the activations fused."""
     return seq[4].run(seq[2].run(seq[0].run(x, act=LEAKY), act=LEAKY), act=last_act)
+
+
+def _seq3_hi(seq, x):
+    """``_seq3`` whose last conv feeds an entropy model: returns its ``hi`` output (``run_latent``)."""
+    return seq[4].run_latent(seq[2].run(seq[0].run(x, act=LEAKY), act=LEAKY), want_lo=False)[1]
 
 
 class HSICJoint(StereoCompressionModel):
@@ -516,6 +566,8 @@ class HSICJoint(StereoCompressionModel):
 
     def forward(self, x1, x2, h_matrix, noise=None):
         """noise keys (training): z1, y1, y1b, z2, y1w, y2, y2b (reference draw order)."""
+        if not self.training and not torch.is_grad_enabled() and x1.is_cuda:
+            return self._forward_eval(x1, x2, h_matrix)
         tr = self.training
         size = (x1.shape[-2], x1.shape[-1])
         y1 = self.encoder1(x1)
@@ -547,6 +599,34 @@ class HSICJoint(StereoCompressionModel):
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
 
+    def _forward_eval(self, x1, x2, h_matrix):
+        """Inference: y, z and the (scale, mean) maps are fp32 even in the bf16 mode (see ``HSIC._forward_eval``)."""
+        size = (x1.shape[-2], x1.shape[-1])
+        cdt = Fn.compute_dtype()
+        y1_lo, y1 = self.encoder1.latent(x1)
+        z1 = _seq3_hi(self.h_a1, y1_lo)
+        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None, out_dtype=cdt)
+        params1 = _seq3(self.h_s1, z1_hat)
+        y1_hat = _round_latent(self.gaussian_conditional1, y1)
+        sc1, mu1 = self._gauss_full(1, params1, y1_hat)
+        _, y1_lik = self.gaussian_conditional1(y1, sc1, means=mu1, out_dtype=cdt)
+        x1_hat = self.decoder1(y1_hat)
+
+        x1_warp = warp_perspective(x1, h_matrix, size)
+        y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+        z2 = _seq3_hi(self.h_a2, y2_lo)
+        z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None, out_dtype=cdt)
+        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+        params2 = _seq3(self.h_s2, z2_hat)
+        y2_hat = _round_latent(self.gaussian_conditional2, y2)
+        sc2, mu2 = self._gauss_full(2, params2, y2_hat, y1_hat_w)
+        # the reference evaluates view 2 with gaussian_conditional1 as well (:725); no learnable state, harmless
+        _, y2_lik = self.gaussian_conditional1(y2, sc2, means=mu2, out_dtype=cdt)
+        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+                "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+
     # ---------------------------------------------------------------------------------------- real bit-stream
     # compress / decompress of the reference's HESIC+ (ywz/mywork/newnet1_joint.py:793-1079, :1081-1321): same header
     # file as HESIC, y coded pixel by pixel in raster order (all non-zero channels of a pixel together) under a single
@@ -564,7 +644,7 @@ class HSICJoint(StereoCompressionModel):
         ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
         ctx = ctx_m(y_hat)
         cat = (params, ctx) if extra is None else (params, ctx, extra)
-        return _seq3(ep, torch.cat(cat, 1)).chunk(2, 1)
+        return _seq3_hi(ep, torch.cat(cat, 1)).chunk(2, 1)
 
     def _gauss_pixel(self, which, params, y_pad, h, w, extra=None):
         """(scales, means) of pixel (h, w) from the 5x5 crop of the padded, partially decoded map (:903-911)."""
@@ -578,7 +658,7 @@ class HSICJoint(StereoCompressionModel):
         parts = [params[:, :, h:h + 1, w:w + 1], ctx]
         if extra is not None:
             parts.append(extra[:, :, h:h + 1, w:w + 1])
-        return _seq3(ep, torch.cat(parts, 1).contiguous(memory_format=torch.channels_last)).chunk(2, 1)
+        return _seq3_hi(ep, torch.cat(parts, 1).contiguous(memory_format=torch.channels_last)).chunk(2, 1)
 
     @staticmethod
     def _header_view(y_hat, z_strings):
@@ -605,21 +685,22 @@ class HSICJoint(StereoCompressionModel):
         with torch.no_grad(), Fn.no_split_k():
             self.context_prediction1.weight.data *= self.context_prediction1.mask
             self.context_prediction2.weight.data *= self.context_prediction2.mask
-            y1 = self.encoder1(x1)
-            z1 = _seq3(self.h_a1, y1)
+            cdt = Fn.compute_dtype()
+            y1_lo, y1 = self.encoder1.latent(x1)
+            z1 = _seq3_hi(self.h_a1, y1_lo)
             z1_strings = self.entropy_bottleneck1.compress(z1)
-            z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(z1.dtype)
-            y1_hat = self.gaussian_conditional1._quantize(y1, "dequantize")
+            z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(cdt)
+            y1_hat = _round_latent(self.gaussian_conditional1, y1)
             sc1, mu1 = self._gauss_full(1, self._params_view(1, z1_hat), y1_hat)
             x1_hat = self.decoder1(y1_hat)
             x1_warp = warp_perspective(x1, h_matrix, size)
-            y2 = self.encoder2(x1_warp, x2)
-            z2 = _seq3(self.h_a2, y2)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            z2 = _seq3_hi(self.h_a2, y2_lo)
             z2_strings = self.entropy_bottleneck2.compress(z2)
-            z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(z2.dtype)
+            z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(cdt)
             x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
-            y2_hat = self.gaussian_conditional2._quantize(y2, "dequantize")
+            y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+            y2_hat = _round_latent(self.gaussian_conditional2, y2)
             sc2, mu2 = self._gauss_full(2, self._params_view(2, z2_hat), y2_hat, y1_hat_w)
             head = bytearray(np.array(x1.shape[2:], dtype=np.uint16).tobytes())
             enc = RangeEncoder()
@@ -695,7 +776,7 @@ class HSICJoint(StereoCompressionModel):
             y1_hat = decode_view(1, self._params_view(1, z1_hat), views[0][0], views[0][1])
             x1_hat = self.decoder1(y1_hat)
             x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-            y1_hat_w = self.gaussian1._quantize(self.encoder1(x1_hat_warp), "dequantize")
+            y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
             y2_hat = decode_view(2, self._params_view(2, z2_hat), views[1][0], views[1][1], y1_hat_w)
             x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat,

@@ -95,6 +95,16 @@ size_t hesic_conv2d_ws_bytes(const hesic_conv_desc* d);
 int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                             void* y, void* ws, size_t ws_bytes, void* stream);
 
+/* bf16 storage only: the same op that ALSO (y != NULL) or ONLY (y == NULL) stores act(conv + bias) as fp32, straight from
+ * the fp32 accumulators, into channels [y32_c_off, y32_c_off + Cout) of an NHWC fp32 buffer with y32_pix_stride channels.
+ * The reference computes the whole path in fp32 (newnet1.py:726-731): what feeds round() and the likelihoods -- the latents
+ * y = g_a_conv4(.), z = encode_hyper(.) and the sigma / mu maps of gmm_hyper_y1/y2 or entropy_parameters -- must not pass
+ * through 8-bit-mantissa storage (at |y| ~ 10 one bf16 ulp is 1/16: latents near .5 flip).  ws / ws_bytes as
+ * hesic_conv2d_forward_ws (may be NULL / 0).                                                                        */
+int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                void* y, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);
@@ -183,6 +193,10 @@ int hesic_warp_perspective_backward(const hesic_warp_desc* d, const void* d_dst,
 #define HESIC_EB_PARAM_STRIDE 64
 int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,
                      int64_t P, int C, int dtype, void* stream);
+/* Inference form for the bf16 mode: z is fp32 (hesic_conv2d_forward_f32out), z_hat is stored as out_dtype (it feeds the
+ * hyper-synthesis convs), eval quantisation only.                                                          */
+int hesic_eb_forward_f32in(const float* z, const float* params, void* z_hat, int out_dtype, float* lik, int32_t* symbols,
+                           int64_t P, int C, void* stream);
 /* Inference cache: apply softplus / tanh to a packed table once ([C][64] -> [C][64], slot 59 marks it); hesic_eb_forward
  * accepts either form, hesic_eb_backward needs the raw one.                                            */
 int hesic_eb_prepare_params(const float* params, float* prepared, int C, void* stream);
@@ -205,6 +219,10 @@ typedef struct {
 int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
                       const float* weights, const void* noise, void* y_hat, float* lik, int32_t* symbols,
                       void* stream);
+/* Inference form for the bf16 mode: y, scales, means fp32 (d->dtype is ignored), y_hat stored as out_dtype; K in {1, 5},
+ * eval quantisation only.  Same arithmetic as the bf16 kernel (branch-free erfc, 1.8e-7 relative).        */
+int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, const float* scales, const float* means,
+                            const float* weights, void* y_hat, int out_dtype, float* lik, int32_t* symbols, void* stream);
 /* Per-element cumulative-frequency tables for the real bit-stream of HSIC.compress / decompress (newnet1.py:925-978,
  * :1137-1175): for image b, every listed channel and pixel, cdf[(j*HW + hw)*(A+1) + 0..A], A = 2*minmax+1,
  * = [0, cumsum(round(clip(pmf, 2^-16, 1) / sum * 65536))] over the shifted alphabet 0..2*minmax with the mixture pmf of
@@ -296,6 +314,8 @@ int hesic_sq_diff_backward(const void* a, int a_dtype, const int64_t a_strides[4
 /* elementwise helpers used by the autograd wrappers */
 int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream);
 int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
+/* y = round_half_even(x): EntropyModel._quantize(x, "dequantize") without means (entropy_models.py:98-125; newnet1.py:755) */
+int hesic_round(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream);
 
 /* ------------------------------------------------- in front of the path: HomographyNet -> h_matrix
  * The convolutions / linear layers of `Net` (ywz/mywork/model.py:73-96) go through hesic_(s)conv2d_forward (a Linear

@@ -2,7 +2,8 @@
 produced by the reference itself (tests/golden/{hsic,joint}_{64,256}.npz) and against the CPU oracle.
 
 fp32 storage: integer latents may flip only at rounding boundaries (<= 2e-4 of them), bits and MSE within
-1e-3 relative -- the BASELINE bar.  bf16 storage: stated tolerance 5e-2 on bits / MSE."""
+1e-3 relative -- the BASELINE bar.  bf16 feature maps (fp32 latents): bits 4e-3, MSE 1e-3 relative, <= 2 % flipped latents
+(measured 1.6e-3 / 1.5e-4 / 1.0 %)."""
 import math
 import os
 
@@ -65,20 +66,52 @@ def test_forward_fp32_matches_reference_golden(kind, size, batch):
 
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
 def test_forward_bf16_within_stated_tolerance(kind):
-    from hesic_amd import models
+    """bf16 feature maps with fp32 latents (y, z, sigma, mu from the fp32 accumulators): measured on MI355X against the
+    reference golden at 256x256 -- 1.0 % of the rounded latents sit on the other side of a bin edge (bf16 operand rounding
+    inside the four analysis layers moves y by ~0.3 %, i.e. ~0.02 at |y| ~ 7), total bits off by 1.6e-3 (HESIC) / 7e-4
+    (HESIC+) relative, PSNR by 6e-4 dB.  Bars = measured value + margin."""
+    from hesic_amd import functional as Fn, models
     g = load_golden(f"{kind}_256.npz")
     net = build(kind, torch.bfloat16)
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 1, 256, 256))
     with torch.no_grad():
+        assert Fn.fp32_latents()
         out = net(x1, x2, Hm)
         m = models.metrics_from(models.rate_distortion(out, x1, x2))
-    assert out["y1_hat"].dtype == torch.bfloat16
+    assert out["y1_hat"].dtype == torch.bfloat16            # integer-valued: exact in the storage dtype of the synthesis convs
     total = sum(float(g["bits_" + k]) for k in ("y1", "y2", "z1", "z2"))
-    assert sum(m["bits"].values()) == pytest.approx(total, rel=5e-2)
-    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=5e-2)
-    assert m["mse2"] == pytest.approx(float(g["mse2"]), rel=5e-2)
-    flips = (out["y1_hat"].float().cpu().to(torch.int16) != T(g["y1_hat"])).float().mean()
-    assert float(flips) < 0.05          # first-stage latents: bf16 rounding moves < 5% across a bin edge
+    assert sum(m["bits"].values()) == pytest.approx(total, rel=4e-3)
+    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=1e-3)
+    assert m["mse2"] == pytest.approx(float(g["mse2"]), rel=1e-3)
+    ref_psnr = (10 * math.log10(1 / float(g["mse1"])) + 10 * math.log10(1 / float(g["mse2"]))) / 2
+    assert abs(m["psnr"] - ref_psnr) < 2e-3
+    for k in ("y1_hat", "y2_hat"):
+        flips = (out[k].float().cpu().to(torch.int16) != T(g[k])).float().mean()
+        assert float(flips) < 0.02, (k, float(flips))
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_fp32_latents_only_change_the_rounding_inputs(kind):
+    """HESIC_BF16_LATENTS A/B: with the latents stored as bf16 again (round-1 behaviour) the forward still runs and the two
+    modes agree to the bf16 noise level; the fp32-latent mode rounds y from the fp32 accumulator, so re-rounding ITS bf16
+    copy reproduces the bf16-latent mode's y_hat wherever the two differ only by storage."""
+    from hesic_amd import functional as Fn, models
+    net = build(kind, torch.bfloat16)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(2, 1, 128, 128))
+    keep = Fn.FP32_LATENTS
+    try:
+        outs = {}
+        for mode in (True, False):
+            Fn.FP32_LATENTS = mode
+            with torch.no_grad():
+                outs[mode] = net(x1, x2, Hm)
+        same = (outs[True]["y1_hat"] == outs[False]["y1_hat"]).float().mean()
+        assert float(same) > 0.98
+        b_hi = float(models.metrics_from(models.rate_distortion(outs[True], x1, x2))["bpp"])
+        b_lo = float(models.metrics_from(models.rate_distortion(outs[False], x1, x2))["bpp"])
+        assert abs(b_hi - b_lo) < 1e-2 * b_lo
+    finally:
+        Fn.FP32_LATENTS = keep
 
 
 def test_forward_512_batch_properties():

@@ -701,3 +701,87 @@ def test_conv3x3_c32_enhancement_kernel(hw):
     assert y3.dtype == torch.float32 and y3.shape == (2, 3, H, W)
     assert rel_err(y3, O.conv(x, bf(w3), b3, 1) + img) < 1e-4
     assert rel_err(y6, O.conv(bf(torch.cat((a6, b6), 1)), bf(w6), b, 1)) < 1e-2
+
+
+# ------------------------------------------------------------------ fp32 latents of the bf16 mode (round 2)
+@pytest.mark.parametrize("shape,split", [((2, 128, 192, 5, 2, 64), False), ((2, 128, 128, 5, 2, 16), True), ((1, 128, 960, 5, 1, 32), False)],
+                         ids=["conv4", "hyper_z_splitk", "sigma960"])
+def test_conv_f32out_is_the_unrounded_accumulator(shape, split):
+    """hesic_conv2d_forward_f32out: the fp32 copy equals the oracle on the bf16-rounded operands to fp32 accuracy (not bf16
+    accuracy), the bf16 copy is its rounding, `y == NULL` writes only the fp32 tensor; plain and split-K launches."""
+    Fn, O = _imp()
+    from hesic_amd import _lib as L
+    import ctypes as C
+    B, Cin, Cout, k, s, H = shape
+    x = bf(rnd("f32o_x", (B, Cin, H, H), -2, 2))
+    w = bf(rnd("f32o_w", (Cout, Cin, k, k)) * 0.03)
+    b = rnd("f32o_b", (Cout,), -0.1, 0.1)
+    ref = torch.relu(O.conv(x, w, b, s))
+    Ho = ref.shape[-1]
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wp = Fn.PackedWeight().get(w.to(DEV), None, Cout, Cin, k, k, False, False, torch.bfloat16)
+    d = L.ConvDesc(B, H, H, Cin, Ho, Ho, Cout, k, k, s, k // 2, 0, L.BF16, L.ACT_RELU, 0, Cin, 0, Cout, 0, 0)
+    need = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    assert (need > 0) == split
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+    lo = torch.zeros((B, Cout, Ho, Ho), device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    hi = torch.full((B, Cout + 8, Ho, Ho), 7.0, device=DEV).contiguous(memory_format=torch.channels_last)
+    L.call("hesic_conv2d_forward_f32out", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(lo), L.ptr(hi), Cout + 8, 4,
+           L.ptr(ws), need, L.stream())
+    assert rel_err(hi[:, 4:4 + Cout], ref) < 2e-5
+    assert torch.equal(hi[:, :4], torch.full_like(hi[:, :4], 7.0)) and torch.equal(hi[:, 4 + Cout:], torch.full_like(hi[:, 4 + Cout:], 7.0))
+    assert torch.equal(lo, hi[:, 4:4 + Cout].to(torch.bfloat16))
+    only = torch.zeros((B, Cout, Ho, Ho), device=DEV).contiguous(memory_format=torch.channels_last)
+    L.call("hesic_conv2d_forward_f32out", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), None, L.ptr(only), Cout, 0, L.ptr(ws), need, L.stream())
+    assert torch.equal(only, hi[:, 4:4 + Cout])
+    df = L.ConvDesc(B, H, H, Cin, Ho, Ho, Cout, k, k, s, k // 2, 0, L.F32, L.ACT_RELU, 0, Cin, 0, Cout, 0, 0)
+    with pytest.raises(RuntimeError):                            # fp32 storage has no separate fp32 copy
+        L.call("hesic_conv2d_forward_f32out", C.byref(df), L.ptr(xd), L.ptr(wp), None, None, L.ptr(only), Cout, 0, None, 0, L.stream())
+
+
+def test_entropy_kernels_f32in_match_the_oracle_bit_exact_indices():
+    """hesic_gmm_forward_f32in / hesic_eb_forward_f32in / hesic_round (bf16 mode with fp32 latents): rounded latents are
+    bit-exact against the oracle on the same fp32 inputs, likelihoods within 1e-5 (branch-free erfc), y_hat is stored bf16."""
+    Fn, O = _imp()
+    B, M, K, H = 2, 192, 5, 8
+    y = rnd("f32in_y", (B, M, H, H), -12, 12)
+    sc = rnd("f32in_s", (B, M * K, H, H), 0.05, 4.0)
+    mu = rnd("f32in_m", (B, M * K, H, H), -3, 3)
+    wt = torch.softmax(rnd("f32in_w", (B, K, M, 1, 1), -1, 1), 1).reshape(B, K * M, 1, 1)
+    yh_o, lik_o = O.gmm_forward(y, sc, mu, wt, K)
+    cl = torch.channels_last
+    yh, lik = Fn.gaussian_mixture(y.to(DEV).contiguous(memory_format=cl), sc.to(DEV).contiguous(memory_format=cl),
+                                  mu.to(DEV).contiguous(memory_format=cl), wt.to(DEV), K, out_dtype=torch.bfloat16)
+    assert yh.dtype == torch.bfloat16 and torch.equal(yh.float().cpu(), yh_o)
+    assert float((lik.cpu() - lik_o).abs().max()) < 1e-5
+    # single Gaussian with means in the quantiser, scale / mean = the two halves of one tensor (HESIC+)
+    gp = rnd("f32in_gp", (B, 2 * M, H, H), -2, 2)
+    gp[:, :M] = gp[:, :M].abs() + 0.05
+    yh_o, lik_o = O.gc_forward(y, gp[:, :M], gp[:, M:])
+    gpd = gp.to(DEV).contiguous(memory_format=cl)
+    s_, m_ = gpd.chunk(2, 1)
+    yh, lik = Fn.gaussian_conditional(y.to(DEV).contiguous(memory_format=cl), s_, m_, out_dtype=torch.float32)
+    assert torch.equal(yh.cpu(), yh_o) and float((lik.cpu() - lik_o).abs().max()) < 1e-5
+    # round-half-even into bf16
+    r = Fn.round_to(y.to(DEV), torch.bfloat16)
+    assert r.dtype == torch.bfloat16 and torch.equal(r.float().cpu(), torch.round(y))
+    half = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 3.4999998], device=DEV).reshape(1, 6, 1, 1)
+    assert Fn.round_to(half, torch.bfloat16).float().flatten().tolist() == [0.0, 2.0, 2.0, -0.0, -2.0, 3.0]
+
+
+def test_entropy_bottleneck_f32in():
+    Fn, O = _imp()
+    from compressai.entropy_models import EntropyBottleneck
+    torch.manual_seed(3)
+    eb = EntropyBottleneck(128)
+    with torch.no_grad():
+        eb.quantiles[:, 0, 1] = rnd("ebq", (128,), -0.4, 0.4)
+    z = rnd("eb32_z", (2, 128, 4, 4), -6, 6)
+    P = {k: v.detach() for k, v in eb.state_dict().items()}
+    zh_o, lik_o = O.eb_forward(P, "", z)
+    eb = eb.to(DEV).eval()
+    with torch.no_grad():
+        zh, lik = eb.forward_with_noise(z.to(DEV), None, out_dtype=torch.bfloat16)
+        zh32, lik32 = eb.forward_with_noise(z.to(DEV), None)
+    assert zh.dtype == torch.bfloat16 and torch.equal(zh, zh32.to(torch.bfloat16)) and torch.equal(lik, lik32)
+    assert torch.equal(zh32.cpu(), zh_o) and rel_err(lik, lik_o) < 2e-4
