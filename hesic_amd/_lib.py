@@ -37,8 +37,7 @@ class SConvDesc(C.Structure):
 
 
 class WarpDesc(C.Structure):
-    _fields_ = [(n, _i32) for n in ("B", "C", "H", "W", "Ho", "Wo", "align_corners", "src_dtype", "dst_dtype")] + \
-               [("_pad", _i32)] + \
+    _fields_ = [(n, _i32) for n in ("B", "C", "H", "W", "Ho", "Wo", "align_corners", "src_dtype", "dst_dtype", "m_is_dst_to_src")] + \
                [(n, _i64) for n in ("ss_b", "ss_c", "ss_y", "ss_x", "ds_b", "ds_c", "ds_y", "ds_x")]
 
 
@@ -169,7 +168,17 @@ def stream():
 
 
 def require_cuda(*tensors):
+    """Every kernel is launched on the CURRENT device's current stream: refuse CPU tensors (no fallback) and tensors of
+    another GPU (the launch would run on the wrong device against foreign pointers)."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("hesic_amd: the HIP path needs tensors on a ROCm device (no CPU fallback); "
                                f"got a tensor on {t.device}")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"hesic_amd: tensor on {t.device} but the current device is cuda:{cur} -- kernels launch on the current "
+                               "device's stream; wrap the call in `with torch.cuda.device(tensor.device):`")

@@ -278,7 +278,8 @@ class EntropyBottleneck(EntropyModel):
         if not hasattr(self, "_eb_packer"):
             self._eb_packer = Fn.PackedEb()
         return Fn.entropy_bottleneck(x, list(self._matrices), list(self._biases), list(self._factors), self.quantiles, noise,
-                                     packer=self._eb_packer, out_dtype=out_dtype)
+                                     packer=self._eb_packer, out_dtype=out_dtype,
+                                     lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
 
     @staticmethod
     def _build_indexes(size):

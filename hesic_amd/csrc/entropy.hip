@@ -29,6 +29,8 @@ struct EBParams {
 // slot 59 of a parameter row marks a table whose softplus / tanh have already been applied (hesic_eb_prepare_params:
 // the inference cache does the 45 transcendentals per channel once instead of once per thread and launch)
 constexpr int EB_READY = 59;
+// slot 60: the likelihood lower bound of the module (EntropyModel(likelihood_bound=...), entropy_models.py:60-66); 0 = no bound
+constexpr int EB_BOUND = 60;
 
 __device__ __forceinline__ void eb_load(const float* p, EBParams& q) {
     if (p[EB_READY] != 0.f) {
@@ -81,6 +83,7 @@ __global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__
     EBParams q;
     eb_load(params + (int64_t)c * HESIC_EB_PARAM_STRIDE, q);
     const float med = params[(int64_t)c * HESIC_EB_PARAM_STRIDE + EB_MED];
+    const float bound = params[(int64_t)c * HESIC_EB_PARAM_STRIDE + EB_BOUND];
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
         const int64_t i = p * C + c;
         const float zv = elem<T>::ld(z + i);
@@ -96,7 +99,7 @@ __global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__
         const float s = -signf(lo + up);
         const float l = fabsf(sigmoidf(s * up) - sigmoidf(s * lo));
         elem<TO>::st(zhat + i, v);
-        lik[i] = fmaxf(l, 1e-9f);
+        lik[i] = fmaxf(l, bound);
     }
 }
 
@@ -110,7 +113,8 @@ __global__ void eb_prepare_kernel(const float* __restrict__ raw, float* __restri
     for (int i = 0; i < 12; ++i) o[EB_F0 + i] = tanhf(p[EB_F0 + i]);
     o[EB_MED] = p[EB_MED];
     o[EB_READY] = 1.f;
-    for (int i = EB_READY + 1; i < HESIC_EB_PARAM_STRIDE; ++i) o[i] = 0.f;
+    o[EB_BOUND] = p[EB_BOUND];
+    for (int i = EB_BOUND + 1; i < HESIC_EB_PARAM_STRIDE; ++i) o[i] = 0.f;
 }
 
 // backward through one logits evaluation: accumulates d(params) into gp[58] and returns d/dv
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(64) void eb_bwd_kernel(const T* __restrict__ z, con
     const float* raw = params + (int64_t)c * HESIC_EB_PARAM_STRIDE;
     EBParams q;
     eb_load(raw, q);
-    const float med = raw[EB_MED];
+    const float med = raw[EB_MED], bound = raw[EB_BOUND];
     float gp[EB_NP + 1];
 #pragma unroll
     for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(64) void eb_bwd_kernel(const T* __restrict__ z, con
         const float s = -signf(lo + up);
         const float A = sigmoidf(s * up), Bv = sigmoidf(s * lo), dlt = A - Bv;
         float g = glik[i];
-        if (!(fabsf(dlt) >= 1e-9f || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
+        if (!(fabsf(dlt) >= bound || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
         const float sg = signf(dlt) * g;
         const float gU = sg * A * (1.f - A) * s, gL = -sg * Bv * (1.f - Bv) * s;
         float dv = eb_logits_bwd(q, raw, v + 0.5f, gU, gp) + eb_logits_bwd(q, raw, v - 0.5f, gL, gp);

@@ -649,7 +649,13 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
                 const int so = (y2 * (int)a.ys_y + x2 * (int)a.ys_x) * 2;                       // scalar
                 const bool ok = full || (y2 < a.Ho && x2 + (lane >> 4) < a.Wo);
                 const u32x4 v = *(const u32x4*)(os + (it * 4 + (lane >> 4)) * OROW + (lane & 15) * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)(ok ? st_lane : POISON), so, 0);
+                // The tile offset is ADDED INTO THE VGPR OFFSET, not passed as the SGPR soffset.  A buffer store of more than 8
+                // bytes must not be followed by a VALU write of its data VGPRs within one wait state; the compiler's hazard
+                // recognizer skips that rule when soffset is a register (the ISA manual exempts that form), and with the SGPR
+                // form it scheduled the next store's v_cndmask into data dword 0 right behind the store -- on gfx950 that is NOT
+                // safe: ~1 forward in 25 came back with the first two channels of a few 16-byte chunks replaced by offset bits
+                // (found in round 2 by a bit-identity stress test).  With an immediate soffset the compiler inserts the s_nop.
+                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)(ok ? st_lane + (uint32_t)so : POISON), 0, 0);
             }
         };
         store_rows((bf16_t*)a.y);

@@ -14,8 +14,13 @@ struct WArgs {
 };
 
 // inverse of image b's 3x3 (fp64, adjugate / det) -- once per block, shared through LDS
-__device__ __forceinline__ void invert_h(const float* M, int b, double inv9[9]) {
+__device__ __forceinline__ void invert_h(const float* M, int b, double inv9[9], int already_inverse = 0) {
     const float* m = M + b * 9;
+    if (already_inverse) {          // the caller's matrix maps destination -> source pixels (warp by H^-1 given H)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) inv9[j] = m[j];
+        return;
+    }
     const double a = m[0], bb = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double A = e * i - f * h, B = -(dd * i - f * g), Cc = dd * h - e * g;
     const double det = a * A + bb * B + c * Cc;
@@ -41,7 +46,7 @@ __global__ void warp_fwd_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
     __shared__ double iv[9];
     const int b = blockIdx.y;
-    if (threadIdx.x == 0) invert_h(a.M, b, iv);
+    if (threadIdx.x == 0) invert_h(a.M, b, iv, a.d.m_is_dst_to_src);
     __syncthreads();
     const int64_t total = (int64_t)d.Ho * d.Wo;
     for (int64_t i = xcd_remap(blockIdx.x, gridDim.x) * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void warp_fwd_f32c3_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
     __shared__ double iv[9];
     const int b = blockIdx.z;
-    if (threadIdx.x == 0) invert_h(a.M, b, iv);
+    if (threadIdx.x == 0) invert_h(a.M, b, iv, a.d.m_is_dst_to_src);
     __syncthreads();
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
     if (ox >= d.Wo) return;
@@ -117,7 +122,7 @@ __global__ void warp_bwd_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
     __shared__ double iv[9];
     const int b = blockIdx.y;
-    if (threadIdx.x == 0) invert_h(a.M, b, iv);
+    if (threadIdx.x == 0) invert_h(a.M, b, iv, a.d.m_is_dst_to_src);
     __syncthreads();
     const int64_t total = (int64_t)d.Ho * d.Wo;
     for (int64_t i = xcd_remap(blockIdx.x, gridDim.x) * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

@@ -652,7 +652,7 @@ class _WarpFn(torch.autograd.Function):
     """kornia.warp_perspective(src, M, dsize) (third party; call sites newnet1.py:746,753,767)."""
 
     @staticmethod
-    def forward(ctx, src, M, dsize, align_corners):
+    def forward(ctx, src, M, dsize, align_corners, inverse_map=False):
         L.require_cuda(src, M)
         B, Cc, H, W = src.shape
         Ho, Wo = int(dsize[0]), int(dsize[1])
@@ -661,39 +661,46 @@ class _WarpFn(torch.autograd.Function):
         Mf = M.detach().to(torch.float32).contiguous()
         dst = torch.empty((B, Cc, Ho, Wo), dtype=src.dtype, device=src.device)
         ss, ds = src.stride(), dst.stride()
-        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, int(align_corners), L.dt(src), L.dt(dst), 0, ss[0], ss[1], ss[2], ss[3],
+        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, int(align_corners), L.dt(src), L.dt(dst), int(inverse_map), ss[0], ss[1], ss[2], ss[3],
                        ds[0], ds[1], ds[2], ds[3])
         L.call("hesic_warp_perspective_forward", C.byref(d), L.ptr(src), L.ptr(Mf), L.ptr(dst), L.stream())
         ctx.save_for_backward(Mf)
-        ctx.meta = (src.shape, src.dtype, Ho, Wo, int(align_corners))
+        ctx.meta = (src.shape, src.dtype, Ho, Wo, int(align_corners), int(inverse_map))
         return dst
 
     @staticmethod
     def backward(ctx, g):
         (Mf,) = ctx.saved_tensors
-        shape, sdt, Ho, Wo, ac = ctx.meta
+        shape, sdt, Ho, Wo, ac, inv = ctx.meta
         B, Cc, H, W = shape
         g = g.contiguous()
         dsrc = _zeros(shape, torch.float32, g.device)
         ss, ds = dsrc.stride(), g.stride()
-        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, ac, L.F32, L.dt(g), 0, ss[0], ss[1], ss[2], ss[3], ds[0], ds[1], ds[2], ds[3])
+        d = L.WarpDesc(B, Cc, H, W, Ho, Wo, ac, L.F32, L.dt(g), inv, ss[0], ss[1], ss[2], ss[3], ds[0], ds[1], ds[2], ds[3])
         L.call("hesic_warp_perspective_backward", C.byref(d), L.ptr(g), L.ptr(Mf), L.ptr(dsrc), L.stream())
-        return dsrc.to(sdt), None, None, None
+        return dsrc.to(sdt), None, None, None, None
 
 
-def warp_perspective(src, M, dsize, align_corners=True):
-    return _WarpFn.apply(src, M, dsize, align_corners)
+def warp_perspective(src, M, dsize, align_corners=True, inverse_map=False):
+    """``inverse_map``: ``M`` already maps destination pixels to source pixels, i.e. this is the warp by ``M^-1``
+    (Independent_EN warps view 2 by ``torch.inverse(h_matrix)``, newnet1.py:1290-1291: no 3x3 inversion launches)."""
+    return _WarpFn.apply(src, M, dsize, align_corners, inverse_map)
 
 
 # ---------------------------------------------------------------------- entropy bottleneck
-def eb_pack_params(matrices, biases, factors, quantiles):
-    """[C][64] fp32 table read by hesic_eb_forward/backward (layout in csrc/entropy.hip)."""
+EB_BOUND_SLOT = 60
+
+
+def eb_pack_params(matrices, biases, factors, quantiles, lik_bound=1e-9):
+    """[C][64] fp32 table read by hesic_eb_forward/backward (layout in csrc/entropy.hip); slot 60 = likelihood lower bound."""
     Cc = quantiles.shape[0]
     cols = [m.reshape(Cc, -1) for m in matrices] + [b.reshape(Cc, -1) for b in biases] + \
            [f.reshape(Cc, -1) for f in factors] + [quantiles[:, 0, 1:2]]
     t = torch.cat(cols, 1).to(torch.float32)
     assert t.shape[1] == 59, "EntropyBottleneck kernels are specialised for filters=(3,3,3,3)"
-    return torch.nn.functional.pad(t, (0, L.EB_PARAM_STRIDE - 59)).contiguous()
+    t = torch.nn.functional.pad(t, (0, L.EB_PARAM_STRIDE - 59)).contiguous()
+    t[:, EB_BOUND_SLOT] = float(lik_bound)
+    return t
 
 
 def eb_unpack_grads(dparams, matrices, biases, factors, quantiles):
@@ -712,13 +719,13 @@ class _EbFn(torch.autograd.Function):
     """EntropyBottleneck.forward (entropy_models.py:384-411): returns (z_hat, likelihood)."""
 
     @staticmethod
-    def forward(ctx, z, noise, quantiles, n_mat, *params):
+    def forward(ctx, z, noise, quantiles, n_mat, lik_bound, *params):
         L.require_cuda(z)
         matrices, biases, factors = params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:]
         B, Cc, H, W = z.shape
         z = _nhwc(z)
         table = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
-                               [f.detach() for f in factors], quantiles.detach())
+                               [f.detach() for f in factors], quantiles.detach(), lik_bound)
         zh = torch.empty_like(z, memory_format=_CL)
         lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
         nz = None if noise is None else _nhwc(noise.to(z.dtype))
@@ -740,7 +747,7 @@ class _EbFn(torch.autograd.Function):
         L.call("hesic_eb_backward", L.ptr(z), L.ptr(table), L.ptr(nz), L.ptr(g_lik), L.ptr(g_zh), L.ptr(dz), L.ptr(dpar),
                B * H * W, Cc, L.dt(z), L.stream())
         grads, dq = eb_unpack_grads(dpar, params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:], quantiles)
-        return (dz, None, dq, None, *grads)
+        return (dz, None, dq, None, None, *grads)
 
 
 class PackedEb:
@@ -749,26 +756,26 @@ class PackedEb:
     def __init__(self):
         self._hit = None
 
-    def get(self, matrices, biases, factors, quantiles):
+    def get(self, matrices, biases, factors, quantiles, lik_bound=1e-9):
         ps = (*matrices, *biases, *factors, quantiles)
-        tag = tuple((p.data_ptr(), p._version) for p in ps) + (_cache_epoch,)
+        tag = tuple((p.data_ptr(), p._version) for p in ps) + (_cache_epoch, float(lik_bound))
         if self._hit is None or self._hit[0] != tag:
             raw = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
-                                 [f.detach() for f in factors], quantiles.detach())
+                                 [f.detach() for f in factors], quantiles.detach(), lik_bound)
             ready = torch.empty_like(raw)           # softplus / tanh applied once here, not per thread and launch
             L.call("hesic_eb_prepare_params", L.ptr(raw), L.ptr(ready), raw.shape[0], L.stream())
             self._hit = (tag, ready)
         return self._hit[1]
 
 
-def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, packer=None, out_dtype=None):
+def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, packer=None, out_dtype=None, lik_bound=1e-9):
     """``out_dtype`` (inference, fp32 ``z`` only): storage of z_hat when it differs from z's (bf16 mode with fp32 latents)."""
     if packer is not None and noise is None and not torch.is_grad_enabled():
         # inference: cached parameter table, no autograd bookkeeping -- one launch
         L.require_cuda(z)
         B, Cc, H, W = z.shape
         z = _nhwc(z)
-        table = packer.get(matrices, biases, factors, quantiles)
+        table = packer.get(matrices, biases, factors, quantiles, lik_bound)
         if out_dtype is not None and out_dtype != z.dtype and z.dtype == torch.float32:
             zh = _empty_nhwc(B, Cc, H, W, out_dtype, z.device)
             lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
@@ -778,7 +785,7 @@ def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, pack
         lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
         L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), None, L.ptr(zh), L.ptr(lik), None, B * H * W, Cc, L.dt(z), L.stream())
         return zh, lik
-    return _EbFn.apply(z, noise, quantiles, len(matrices), *matrices, *biases, *factors)
+    return _EbFn.apply(z, noise, quantiles, len(matrices), float(lik_bound), *matrices, *biases, *factors)
 
 
 # ------------------------------------------------------------ Gaussian (mixture) conditional
@@ -1135,13 +1142,18 @@ class _RdLossFn(torch.autograd.Function):
         loss = lmbda * 255.0 ** 2 * mse + bpp
         ctx.save_for_backward(x1, x2, x1_hat, x2_hat, *liks)
         ctx.meta = (float(lmbda), npix, B * Cc * H * W, -1.0 / (math.log(2.0) * npix))
-        return loss.float(), bpp.float(), mse.float()
+        bpp, mse = bpp.float(), mse.float()
+        ctx.mark_non_differentiable(bpp, mse)        # reported values (the reference logs them); only `loss` carries a gradient
+        return loss.float(), bpp, mse
 
     @staticmethod
     def backward(ctx, g_loss, g_bpp, g_mse):
         x1, x2, x1_hat, x2_hat, *liks = ctx.saved_tensors
         lmbda, npix, numel, lik_scale = ctx.meta
-        g = 1.0   # the loss is the root of the graph (loss.backward()); reading g_loss would force a host sync
+        # g_loss stays on the device (reading it would be a host sync): the kernels compute the gradient of the unscaled loss
+        # and, unless SCALED_LOSS is off, one multiply per gradient applies g_loss (loss / accum_steps, loss scaling, ...).
+        # Trainer.step calls loss.backward() on the unscaled root and switches the multiplies off.
+        g = 1.0
         B, Cc, H, W = x1.shape
         grads = []
         for xh, x in ((x1_hat, x1), (x2_hat, x2)):
@@ -1155,7 +1167,13 @@ class _RdLossFn(torch.autograd.Function):
             o = torch.empty_like(l)
             L.call("hesic_log_backward", L.ptr(l), g * lik_scale, L.ptr(o), l.numel(), L.stream())
             gl.append(o)
+        if SCALED_LOSS:
+            grads = [t.mul_(g_loss) for t in grads]
+            gl = [t.mul_(g_loss) for t in gl]
         return (None, None, None, grads[0], grads[1], *gl)
+
+
+SCALED_LOSS = True      # False (Trainer.step): loss.backward() is called on the unscaled loss, skip the six g_loss multiplies
 
 
 def rd_loss(out, x1, x2, lmbda):

@@ -11,10 +11,14 @@ import torch
 
 from . import functional as Fn
 
-DEFAULT_ALIGN_CORNERS = True
+# Checkpoints trained with the reference's pinned environment (torch 1.6.0 / unpinned kornia of that era, Readme.md:11,16:
+# kornia 0.4.x, whose warp_perspective defaulted to align_corners=False) expect the legacy sampling: set this to False (or
+# HESIC_WARP_ALIGN_CORNERS=0) for them.  True = kornia >= 0.5 = cv2.warpPerspective.
+import os as _os
+DEFAULT_ALIGN_CORNERS = _os.environ.get("HESIC_WARP_ALIGN_CORNERS", "1") not in ("0", "false", "False")
 
 
-def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_corners=None):
+def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_corners=None, inverse_map=False):
     """dst(x', y') = bilinear(src, M^-1 (x', y', 1)), zeros outside.  src (B,C,H,W), M (B,3,3) maps source
     pixels to destination pixels, dsize = (H_out, W_out).  HIP kernel: csrc/warp.hip."""
     if flags != "bilinear":
@@ -26,7 +30,7 @@ def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_co
     ac = DEFAULT_ALIGN_CORNERS if align_corners is None else bool(align_corners)
     if M.shape[0] != src.shape[0]:
         M = M.expand(src.shape[0], 3, 3)
-    return Fn.warp_perspective(src, M, dsize, ac)
+    return Fn.warp_perspective(src, M, dsize, ac, inverse_map)
 
 
 def get_perspective_transform(src, dst):

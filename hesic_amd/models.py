@@ -402,8 +402,8 @@ class HSIC(StereoCompressionModel):
             yi = y_hat[0].float()
             flag = (yi.abs().sum(dim=(1, 2)) > 0).cpu().numpy().astype(np.uint8)
             minmax = int(max(float(yi.abs().max()), 1.0))
-            if len(z_strings[0]) > 65535 or minmax > 65535:
-                raise ValueError("HSIC.compress: header fields are uint16 (z string too long or latent range too wide)")
+            if len(z_strings[0]) > 65535 or minmax > 32767:
+                raise ValueError("HSIC.compress: z string longer than the uint16 header field or latent range beyond the table kernel's 32767")
             head += np.array([len(z_strings[0]), minmax], dtype=np.uint16).tobytes()
             head += np.packbits(flag).tobytes()
             head += z_strings[0]
@@ -436,8 +436,8 @@ class HSIC(StereoCompressionModel):
         for _ in range(2):
             length, minmax = (int(v) for v in np.frombuffer(blob[pos:pos + 4], dtype=np.uint16))
             pos += 4
-            flag = np.unpackbits(np.frombuffer(blob[pos:pos + self.M // 8], dtype=np.uint8))
-            pos += self.M // 8
+            flag = np.unpackbits(np.frombuffer(blob[pos:pos + (self.M + 7) // 8], dtype=np.uint8))[:self.M]
+            pos += (self.M + 7) // 8
             views.append((minmax, [int(c) for c in np.nonzero(flag)[0]], blob[pos:pos + length]))
             pos += length
         y_shape = x_shape // 16
@@ -666,8 +666,8 @@ class HSICJoint(StereoCompressionModel):
         yi = y_hat[0].float()
         flag = (yi.abs().sum(dim=(1, 2)) > 0).cpu().numpy().astype(np.uint8)
         minmax = int(max(float(yi.abs().max()), 1.0))
-        if len(z_strings[0]) > 65535 or minmax > 65535:
-            raise ValueError("compress: header fields are uint16 (z string too long or latent range too wide)")
+        if len(z_strings[0]) > 65535 or minmax > 32767:
+            raise ValueError("compress: z string longer than the uint16 header field or latent range beyond the table kernel's 32767")
         head = np.array([len(z_strings[0]), minmax], dtype=np.uint16).tobytes() + np.packbits(flag).tobytes() + z_strings[0]
         return head, minmax, [int(c) for c in np.nonzero(flag)[0]]
 
@@ -743,8 +743,8 @@ class HSICJoint(StereoCompressionModel):
         for _ in range(2):
             length, minmax = (int(v) for v in np.frombuffer(blob[pos:pos + 4], dtype=np.uint16))
             pos += 4
-            flag = np.unpackbits(np.frombuffer(blob[pos:pos + self.M // 8], dtype=np.uint8))
-            pos += self.M // 8
+            flag = np.unpackbits(np.frombuffer(blob[pos:pos + (self.M + 7) // 8], dtype=np.uint8))[:self.M]
+            pos += (self.M + 7) // 8
             views.append((minmax, [int(c) for c in np.nonzero(flag)[0]], blob[pos:pos + length]))
             pos += length
         yh, yw = int(x_shape[0]) // 16, int(x_shape[1]) // 16
@@ -828,7 +828,8 @@ class Enhancement(nn.Module):
 
 class Independent_EN(nn.Module):
     """Stage-2 cross-view enhancement (newnet1.py:1278-1300): view 1 is refined with view 2 warped by H^-1,
-    view 2 with view 1 warped by H.  The 3x3 inverse is plumbing (torch.inverse, 9 numbers per pair)."""
+    view 2 with view 1 warped by H.  Warping by H^-1 needs no inversion at all: the warp kernel wants the destination ->
+    source map, which for H^-1 is H itself (the reference's torch.inverse + kornia's own inverse cancel)."""
 
     def __init__(self):
         super().__init__()
@@ -837,7 +838,7 @@ class Independent_EN(nn.Module):
     def forward(self, x1_hat, x2_hat, h_matrix):
         size = (x1_hat.shape[-2], x1_hat.shape[-1])
         x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-        x2_hat_warp = warp_perspective(x2_hat, torch.inverse(h_matrix), size)     # fp32 inverse, as the reference (:1290)
+        x2_hat_warp = warp_perspective(x2_hat, h_matrix, size, inverse_map=True)   # warp by inverse(H) (:1290): H is its inverse map
         return {"x1_hat": self.EH1(x1_hat, x2_hat_warp), "x2_hat": self.EH2(x2_hat, x1_hat_warp)}
 
 

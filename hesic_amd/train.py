@@ -59,6 +59,11 @@ class MultiTensorAdam(torch.optim.Adam):
                     c.step[j], c.numel[j] = st["step"].data_ptr(), p.numel()
                 c.n, c.lr, c.beta1, c.beta2, c.eps = len(part), float(group["lr"]), float(b1), float(b2), float(group["eps"])
                 L.call("hesic_adam_step", C.byref(c), L.stream())
+            # the kernel writes through raw pointers: tell PyTorch (version counters, like any in-place optimiser) and the
+            # packed-weight / GDN / bottleneck caches (keyed on those counters) that the parameters moved
+            if ps:
+                torch.autograd.graph.increment_version(ps)
+        Fn.invalidate_weight_cache()
         return loss
 
 
@@ -177,12 +182,14 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         self.aux_optimizer.zero_grad(set_to_none=True)
         prev = Fn.train_pack_cache(True)          # packed conv weights persist across the step, one batched repack below
+        scaled, Fn.SCALED_LOSS = Fn.SCALED_LOSS, False     # backward() starts at the unscaled loss: no g_loss multiplies
         try:
             out = self.model(x1, x2, h_matrix, noise=noise)
             crit = Fn.rd_loss(out, x1, x2, self.lmbda)
             crit["loss"].backward()
         finally:
             Fn.train_pack_cache(prev)
+            Fn.SCALED_LOSS = scaled
         self.main_reducer.finish()
         self.optimizer.step()
         Fn.invalidate_weight_cache()              # fused optimisers do not bump version counters: new epoch for every cache
@@ -216,6 +223,9 @@ class GraphedTrainer(Trainer):
         super().__init__(model, *args, **kw)
         if self.world != 1:
             raise RuntimeError("GraphedTrainer is single-process: use Trainer under torch.distributed")
+        if int(warmup) < 1:
+            raise ValueError("GraphedTrainer: warmup >= 1 (the optimiser state and the packed-weight registry are created by an eager step; "
+                             "captured, their zero-initialisation would replay on every step)")
         self.warmup, self.calls, self.graph = int(warmup), 0, None
         self._in = self._noise = self._out = None
 
@@ -248,6 +258,9 @@ class GraphedTrainer(Trainer):
             with torch.cuda.graph(self.graph):
                 self._out = super().step(*self._in, noise=self._noise)
         self.graph.replay()
+        # a replay runs no Python: the captured Adam kernels moved the parameters without touching their version counters, so
+        # every cache keyed on them (bottleneck tables, packed GDN parameters, inference weight packs) must start a new epoch
+        Fn.invalidate_weight_cache()
         return self._out
 
 

@@ -176,6 +176,8 @@ int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const f
  * align_corners=0: kornia <= 0.4 default (samples at xs*W/(W-1) - 1/2).                              */
 typedef struct {
     int32_t B, C, H, W, Ho, Wo, align_corners, src_dtype, dst_dtype;
+    int32_t m_is_dst_to_src;          /* 1: M maps destination -> source pixels already (no inversion): warping by H^-1
+                                         given H, Independent_EN.forward (newnet1.py:1290-1291)                      */
     int64_t ss_b, ss_c, ss_y, ss_x;   /* src element strides */
     int64_t ds_b, ds_c, ds_y, ds_x;   /* dst element strides */
 } hesic_warp_desc;
@@ -188,7 +190,8 @@ int hesic_warp_perspective_backward(const hesic_warp_desc* d, const void* d_dst,
 /* ------------------------------------------------------------ EntropyBottleneck (row A8)
  * Replaces EntropyBottleneck.forward (compressai/entropy_models/entropy_models.py:384-411) for the
  * default filters=(3,3,3,3).  params: fp32 [C][64] packed by hesic_eb_pack_params: 58 MLP values
- * (softplus / tanh NOT yet applied) + median.  z: NHWC (P pixels, C channels).  noise: NULL => eval
+ * (softplus / tanh NOT yet applied) + median (slot 58) + the likelihood lower bound (slot 60; 1e-9 in the reference,
+ * 0 = none: EntropyModel(likelihood_bound=...), entropy_models.py:60-66).  z: NHWC (P pixels, C channels).  noise: NULL => eval
  * (round(z-med)+med), else training (z+noise).  z_hat in z's dtype, lik fp32 NHWC.                   */
 #define HESIC_EB_PARAM_STRIDE 64
 int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,

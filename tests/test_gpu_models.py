@@ -369,3 +369,95 @@ def test_bias_gradient_survives_graph_replay():
                 assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-5
     finally:
         Fn.set_compute_dtype(prev)
+
+
+def _fresh_like(net, kind="hsic"):
+    from hesic_amd import models
+    twin = (models.HSIC if kind == "hsic" else models.HSICJoint)()
+    twin.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()}, strict=True)
+    return twin.cuda().eval()
+
+
+def test_eval_after_graph_replays_sees_the_updated_parameters():
+    """a graph replay runs no Python, and the captured Adam kernel writes parameters through raw pointers -- the
+    caches keyed on version counters (bottleneck table, packed GDN parameters, inference weight packs) must not serve the
+    pre-update values.  eval -> N replays -> eval must equal a fresh model loaded from the same state_dict, bit for bit."""
+    import hesic_amd
+    from hesic_amd import models
+    from hesic_amd.train import GraphedTrainer
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        net = models.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.cuda()
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 2, 128, 128))
+        tr = GraphedTrainer(net, lr=1e-3, aux_lr=1e-2, lmbda=0.0067, warmup=2)
+        net.eval()
+        with torch.no_grad():
+            before = net(x1, x2, Hm)                      # fills every inference cache
+        for _ in range(5):                               # 2 eager warm-ups, capture, 2 replays
+            tr.step(x1, x2, Hm)
+        assert tr.graph is not None
+        net.eval()
+        with torch.no_grad():
+            after = net(x1, x2, Hm)
+            want = _fresh_like(net)(x1, x2, Hm)
+        assert not torch.equal(after["likelihoods"]["z1"], before["likelihoods"]["z1"])      # the parameters did move
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(after[k], want[k]), k
+        for k in want["likelihoods"]:
+            assert torch.equal(after["likelihoods"][k], want["likelihoods"][k]), k
+    finally:
+        hesic_amd.set_compute_dtype(prev)
+
+
+def test_multi_tensor_adam_is_self_contained_in_a_user_loop():
+    """the reference's loop with the optimiser swapped (loss.backward(); MultiTensorAdam.step(), no Trainer) must
+    run the next forward on the updated weights: version counters are bumped and the pack caches invalidated by step()."""
+    from hesic_amd import functional as Fn, models
+    from hesic_amd.train import MultiTensorAdam
+    net = build("hsic")
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(4, 1, 64, 64))
+    opt = MultiTensorAdam(list(net.parameters()), lr=1e-3)
+    aux = MultiTensorAdam(list(net.aux_parameters()), lr=1e-2)
+    noise = {k: synthetic._uniform(f"ul.{k}", (1, 128, 1, 1) if k[0] == "z" else (1, 192, 4, 4), -0.5, 0.5).to(DEV) for k in ("z1", "y1", "y1w", "z2", "y2")}
+    for _ in range(2):
+        net.train()
+        v0 = net.encoder1.g_a_conv2.weight._version
+        out = net(x1, x2, Hm, noise=noise)
+        loss = Fn.rd_loss(out, x1, x2, 0.0067)["loss"]
+        opt.zero_grad(); aux.zero_grad()
+        loss.backward()
+        opt.step()
+        net.aux_loss().backward()
+        aux.step()
+        assert net.encoder1.g_a_conv2.weight._version > v0
+        net.eval()
+        with torch.no_grad():
+            got = net(x1, x2, Hm)
+            want = _fresh_like(net)(x1, x2, Hm)
+        for k in ("x1_hat", "x2_hat", "y1_hat"):
+            assert torch.equal(got[k], want[k]), k
+        assert torch.equal(got["likelihoods"]["z2"], want["likelihoods"]["z2"])
+
+
+def test_rd_loss_gradient_follows_a_scaled_loss():
+    """(loss / accum).backward() must give gradients scaled by 1 / accum (they used to ignore g_loss)."""
+    from hesic_amd import functional as Fn
+    net = build("hsic")
+    net.train()
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(4, 1, 64, 64))
+    noise = {k: synthetic._uniform(f"sl.{k}", (1, 128, 1, 1) if k[0] == "z" else (1, 192, 4, 4), -0.5, 0.5).to(DEV) for k in ("z1", "y1", "y1w", "z2", "y2")}
+    grads = []
+    for scale in (1.0, 0.25):
+        net.zero_grad(set_to_none=True)
+        for p in net.aux_parameters():        # parameters() skips the bottlenecks (newnet1.py:74-80): zero_grad() does not reach them
+            p.grad = None
+        c = Fn.rd_loss(net(x1, x2, Hm, noise=noise), x1, x2, 0.0067)
+        assert not c["bpp_loss"].requires_grad and not c["mse_loss"].requires_grad
+        (c["loss"] * scale).backward()
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    for n in ("encoder1.g_a_conv1.weight", "decoder2.after_conv.bias", "_h_s2.gmm_means.4.weight", "entropy_bottleneck1._matrices.2"):
+        ref = 0.25 * grads[0][n]          # two backward passes: atomics settle in a different order, elements near zero move by ~1e-7 of the scale
+        torch.testing.assert_close(grads[1][n], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))

@@ -750,6 +750,7 @@ def test_entropy_kernels_f32in_match_the_oracle_bit_exact_indices():
     wt = torch.softmax(rnd("f32in_w", (B, K, M, 1, 1), -1, 1), 1).reshape(B, K * M, 1, 1)
     yh_o, lik_o = O.gmm_forward(y, sc, mu, wt, K)
     cl = torch.channels_last
+    torch.set_grad_enabled(False)            # the f32in kernels are the inference forms
     yh, lik = Fn.gaussian_mixture(y.to(DEV).contiguous(memory_format=cl), sc.to(DEV).contiguous(memory_format=cl),
                                   mu.to(DEV).contiguous(memory_format=cl), wt.to(DEV), K, out_dtype=torch.bfloat16)
     assert yh.dtype == torch.bfloat16 and torch.equal(yh.float().cpu(), yh_o)
@@ -767,6 +768,7 @@ def test_entropy_kernels_f32in_match_the_oracle_bit_exact_indices():
     assert r.dtype == torch.bfloat16 and torch.equal(r.float().cpu(), torch.round(y))
     half = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 3.4999998], device=DEV).reshape(1, 6, 1, 1)
     assert Fn.round_to(half, torch.bfloat16).float().flatten().tolist() == [0.0, 2.0, 2.0, -0.0, -2.0, 3.0]
+    torch.set_grad_enabled(True)
 
 
 def test_entropy_bottleneck_f32in():
@@ -785,3 +787,58 @@ def test_entropy_bottleneck_f32in():
         zh32, lik32 = eb.forward_with_noise(z.to(DEV), None)
     assert zh.dtype == torch.bfloat16 and torch.equal(zh, zh32.to(torch.bfloat16)) and torch.equal(lik, lik32)
     assert torch.equal(zh32.cpu(), zh_o) and rel_err(lik, lik_o) < 2e-4
+
+
+def test_entropy_bottleneck_honours_its_likelihood_bound():
+    """EntropyModel(likelihood_bound=...) reaches the kernel (slot 60 of the parameter table), forward and backward."""
+    from compressai.entropy_models import EntropyBottleneck
+    z = rnd("lb_z", (2, 128, 4, 4), -3000, 3000)                  # far tails: raw likelihoods underflow to 0
+    for bound in (1e-3, 0.0):
+        eb = EntropyBottleneck(128, likelihood_bound=bound).to(DEV).eval()
+        zd = z.to(DEV).requires_grad_()
+        _, lik = eb(zd)
+        if bound:
+            assert float(lik.min()) == pytest.approx(bound, rel=1e-6)
+        else:
+            assert float(lik.min()) < 1e-9
+        with torch.no_grad():
+            _, lik2 = eb(z.to(DEV))                               # cached-table inference path
+        assert torch.equal(lik2, lik.detach())
+
+
+def test_warp_inverse_map_is_the_warp_by_the_inverse():
+    """warp(x, inverse(H)) == warp(x, H, inverse_map=True): Independent_EN (newnet1.py:1290-1291) without 3x3 inversion launches."""
+    Fn, O = _imp()
+    x1, _, Hm = synthetic.stereo_batch(3, 2, 96, 128)
+    a = Fn.warp_perspective(x1.to(DEV), torch.inverse(Hm).to(DEV), (96, 128))
+    b = Fn.warp_perspective(x1.to(DEV), Hm.to(DEV), (96, 128), inverse_map=True)
+    ref = O.warp_perspective(x1, torch.inverse(Hm), (96, 128))
+    # torch.inverse is fp32: its rounding moves the sample positions by ~1e-4 px against the exact inverse map
+    assert float((a - b).abs().max()) < 2e-4 and float((b.cpu() - ref).abs().max()) < 2e-4
+
+
+def test_image_side_conv_gdn_is_bit_stable_across_launches():
+    """Regression (round 2): the fused 3 -> 128 conv + GDN kernel stored its rows with `buffer_store_dwordx4 ... soffset=SGPR`;
+    the compiler skips the "no VALU write of the store data within one wait state" rule for that form and had scheduled the next
+    store's address select into data dword 0 right behind the store.  On gfx950 that corrupted two channels of a few 16-byte
+    chunks in roughly one forward out of 25.  600 launches interleaved with allocator churn must all be bit-identical."""
+    Fn, O = _imp()
+    from compressai.layers import GDN
+    from compressai.models.utils import conv
+    prev = Fn.compute_dtype()
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(5)
+        c1, g1 = conv(3, 128).to(DEV), GDN(128).to(DEV)
+        x = synthetic.stereo_batch(2, 2, 256, 256)[0].to(DEV)
+        with torch.no_grad():
+            ref = c1.run_gdn(x, g1).clone()
+            bad = 0
+            for it in range(600):
+                if it % 7 == 0:
+                    junk = torch.full((1 << (10 + it % 13),), 1e30, device=DEV)
+                    del junk
+                bad += int(not torch.equal(c1.run_gdn(x, g1), ref))
+        assert bad == 0, bad
+    finally:
+        Fn.set_compute_dtype(prev)
