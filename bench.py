@@ -7,6 +7,11 @@ plus the bpp / PSNR reductions -- SURVEY.md 8(d).  Workload at N=1: BASELINE con
 fp32 accumulation).  N>1: every rank runs its own batch of 8 (independent pairs, no collective on the path,
 weak scaling); only the final timing max / pair count are reduced.
 
+``--mode train`` (BASELINE config C3): a step is one training iteration on the rank's batch of 8 pairs -- zero_grad,
+forward with quantisation noise, R-D loss, backward, in-place RCCL all-reduce of the flat gradient buffer (N > 1; bucketed,
+overlapped with the backward pass), Adam, aux-loss backward, aux all-reduce, aux Adam (ywz/mywork/newtrain1.py:74-111) --
+replayed from one HIP graph per rank (``--eager`` issues it from Python).  Weak scaling: global batch = 8 N.
+
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      dominant kernel (implicit-GEMM conv, bf16 MFMA): achieved TFLOP/s = algorithmic conv FLOPs of its
                 launches / their summed HIP-event durations, measured live on the launch stream
@@ -95,6 +100,82 @@ class KernelMeter:
                         for k, v in agg.items()}}
 
 
+class WgradMeter:
+    """Training mode: one HIP event pair around the split-K MFMA launch of every wide weight gradient.  The training path
+    issues ``hesic_conv2d_wgrad_direct`` (MFMA launch + finishing launch); during the metering pass each such call is
+    preceded by ``hesic_conv2d_wgrad_partial`` -- the MFMA launch alone, same arguments, bracketed by the events."""
+
+    def __init__(self, L):
+        self.L, self.orig, self.rec = L, L.call, []
+
+    def __enter__(self):
+        def call(name, *args):
+            if name == "hesic_conv2d_wgrad_direct":
+                d = args[0]._obj
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.orig("hesic_conv2d_wgrad_partial", args[0], args[1], args[2], args[6], args[7], args[8])
+                e1.record()
+                ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
+                self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)))
+            return self.orig(name, *args)
+        self.L.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        n = len(self.rec)
+        if not n:
+            return None
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec) * 1e-3
+        f = sum(r[2] for r in self.rec)
+        return {"launches": n, "avg_us": 1e6 * t / n, "tflops": f / t / 1e12, "flops_per_launch": f / n}
+
+
+def cpu_train_baseline(kind, P_cpu, param_names, size, lmbda, budget_s=15.0):
+    """One reference-order training step of the CPU oracle (forward with noise, R-D loss, backward, Adam, aux backward,
+    aux Adam) on a bounded sample: 1 pair per step."""
+    from hesic_amd import synthetic
+    from oracle import hesic_oracle as O
+    fwd = O.hsic_forward if kind == "hsic" else O.hsic_joint_forward
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(16, cores))
+    P = {k: v.clone() for k, v in P_cpu.items()}
+    aux_keys = [k for k in param_names if k.startswith("entropy_bottleneck")]
+    main_keys = [k for k in param_names if not k.startswith("entropy_bottleneck")]
+    for k in param_names:
+        P[k].requires_grad_()
+    opt = torch.optim.Adam([P[k] for k in main_keys], lr=1e-4)
+    aux = torch.optim.Adam([P[k] for k in aux_keys], lr=1e-3)
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, size, size)
+
+    zs, ys = (1, 128, size // 64, size // 64), (1, 192, size // 16, size // 16)
+
+    def step():
+        opt.zero_grad(); aux.zero_grad()
+        noise = {k: torch.empty(zs if k[0] == "z" else ys).uniform_(-0.5, 0.5) for k in ("z1", "y1", "y1b", "y1w", "z2", "y2", "y2b")}
+        out = fwd(P, x1, x2, Hm, training=True, noise=noise)
+        O.rd_loss(out, x1, x2, lmbda)["loss"].backward()
+        opt.step()
+        O.aux_loss(P).backward()
+        aux.step()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 16:
+            break
+    return {"value": n / el, "unit": "stereo-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training steps x (1 pair {size}x{size}, fp32, torch CPU autograd + Adam x2) after 1 warm-up, {el:.1f} s, "
+                      f"{torch.get_num_threads()} of {cores} host cores"}
+
+
 def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
     from hesic_amd import synthetic
     from oracle import hesic_oracle as O
@@ -131,6 +212,90 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
                       f"over 8/16/32/64 of {cores} host cores"}, m
 
 
+def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
+    """--mode train: see the module docstring.  Timed region = ``steps`` calls of ``Trainer.step`` on resident inputs."""
+    import torch.distributed as dist
+    from hesic_amd import _lib as L_, functional as Fn
+    from hesic_amd.train import GraphedTrainer, Trainer
+    x1, x2, Hm = batch
+    net.train()
+    param_names = [n for n, _ in net.named_parameters()]
+    tr = (Trainer if args.eager else GraphedTrainer)(net, lr=1e-4, aux_lr=1e-3, lmbda=args.lmbda)
+    for _ in range(max(args.warmup, 0 if args.eager else tr.warmup + 1)):
+        crit = tr.step(x1, x2, Hm)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        crit = tr.step(x1, x2, Hm)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    losses = {k: float(v) for k, v in crit.items()}
+
+    # roofline of the weight-gradient MFMA kernel, measured live (eager steps, events on the launch stream); launch census
+    roof, census = None, {}
+    if rank == 0:
+        eager = Trainer.step          # the un-graphed step of the same trainer object
+        orig_call = L_.call
+
+        def counting(name, *a):
+            census[name] = census.get(name, 0) + 1
+            return orig_call(name, *a)
+        L_.call = counting
+        try:
+            eager(tr, x1, x2, Hm)
+        finally:
+            L_.call = orig_call
+        with WgradMeter(L_) as wm:
+            for _ in range(2):
+                eager(tr, x1, x2, Hm)
+            s = wm.summary()
+        if s:
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
+                    "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        pairs = world * args.batch * args.steps
+        gflop_pair = 3 * HESIC_GFLOP_PER_PAIR_512 * (x1.shape[-2] * x1.shape[-1] / 512 ** 2)      # fwd + dgrad + wgrad (SURVEY 8d)
+        res = {
+            "metric": "stereo-pairs/sec encode+decode @512x512; bpp & PSNR delta vs reference",
+            "value": round(pairs / elapsed, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{'HESIC' if args.model == 'hsic' else 'HESIC+'} TRAINING step (BASELINE config C3: R-D loss, Adam x2, "
+                                   f"gradient all-reduce), {H_img}x{W_img} stereo pairs, batch {args.batch}/GPU, lambda {args.lmbda}",
+                       "pairs_per_step": world * args.batch, "global_batch": world * args.batch,
+                       "sharding": f"data parallel over {world} GPU(s): one in-place bucketed RCCL all-reduce of the "
+                                   f"{tr.main_group.numel * 4 / 1e6:.1f} MB flat gradient per step" + ("" if world > 1 else " (single rank: no collective)"),
+                       "step": "eager" if args.eager else "HIP graph replay"},
+            "model_tflops": round(pairs * gflop_pair / elapsed / 1e3, 2) if args.model == "hsic" else None,
+            "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype == "bf16" else None,
+            "roofline": roof,
+            "launches_per_step": {"c_abi_calls": sum(census.values()), "note": "C-ABI calls of one eager step (each is 1-2 kernel launches); "
+                                  "ATen launches not included -- see profiles/ for the rocprofv3 count"},
+            "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_train_baseline(args.model, P_cpu, param_names, 512 if (args.height or args.width) else args.size, args.lmbda)
+            res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +307,9 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--model", choices=["hsic", "joint"], default="hsic")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer", help="train: BASELINE config C3 (R-D training step, DP gradient all-reduce)")
+    ap.add_argument("--eager", action="store_true", help="train mode: issue the step from Python instead of replaying the HIP graph")
+    ap.add_argument("--lmbda", type=float, default=0.0067)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (models.GraphedForward) instead of issuing it eagerly")
     args = ap.parse_args()
@@ -173,6 +341,9 @@ def main():
     reps = -(-args.batch // uniq)
     x1, x2, Hm = (t.repeat(reps, *([1] * (t.dim() - 1)))[:args.batch].to(dev) for t in (x1, x2, Hm))
     x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)      # no-op at 512x512
+
+    if args.mode == "train":
+        return train_main(args, net, P_cpu, (x1p, x2p, Hm), rank, world, dev, H_img, W_img)
 
     def step():
         with torch.no_grad():

@@ -50,6 +50,14 @@ class AdamChunk(C.Structure):
                 ("block0", _i32 * (ADAM_MAX_TENSORS + 1)), ("n", _i32), ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32)]
 
 
+EB_MAX_TENSORS = 16
+
+
+class EbLayout(C.Structure):
+    _fields_ = [("ptr", _vp * EB_MAX_TENSORS), ("width", _i32 * EB_MAX_TENSORS), ("stride", _i32 * EB_MAX_TENSORS),
+                ("first", _i32 * EB_MAX_TENSORS), ("col", _i32 * EB_MAX_TENSORS), ("n", _i32), ("lik_bound", _f32)]
+
+
 class GmmDesc(C.Structure):
     _fields_ = [(n, _i32) for n in ("B", "HW", "M", "K", "dtype", "use_means_in_quant", "sm_pix_stride",
                                     "s_c_off", "m_c_off")] + [("scale_bound", _f32), ("lik_bound", _f32)]
@@ -112,6 +120,12 @@ _SIGS = {
     "hesic_act_backward": ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     "hesic_cast": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
     "hesic_round": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
+    "hesic_conv2d_wgrad_direct": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp], _i32),
+    "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
+    "hesic_gdn_backward_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
+    "hesic_eb_pack_table": ([_P(EbLayout), _vp, _i32, _vp], _i32),
+    "hesic_eb_scatter_grads": ([_P(EbLayout), _vp, _i32, _i32, _vp], _i32),
+    "hesic_eb_aux_loss": ([_vp, _vp, _f32, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_conv2d_forward_f32out": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_size_t, _vp], _i32),
     "hesic_eb_forward_f32in": ([_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
     "hesic_gmm_forward_f32in": ([_P(GmmDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),

@@ -640,6 +640,59 @@ extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const 
     HESIC_LAUNCH_RETURN("gmm_backward");
 }
 
+// ------------------------------------------------------------------ training plumbing of the bottleneck parameters
+// The 13 MLP tensors + quantiles of an EntropyBottleneck (entropy_models.py:262-300) <-> the [C][64] table of the kernels
+// above, one launch each way (the torch route was cat + pad + fill on the way in and 14 slice copies on the way out, per
+// bottleneck and step).  Entry j is a (C, width_j) row-major tensor occupying table columns [col_j, col_j + width_j);
+// `stride` / `first` select a column subset of a wider tensor (the median = quantiles[:, 0, 1]: stride 3, first 1).
+__global__ void eb_pack_table_kernel(const hesic_eb_layout L, float* __restrict__ table, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float* row = table + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    for (int i = 0; i < HESIC_EB_PARAM_STRIDE; ++i) row[i] = 0.f;
+    for (int j = 0; j < L.n; ++j)
+        for (int k = 0; k < L.width[j]; ++k) row[L.col[j] + k] = L.ptr[j][(int64_t)c * L.stride[j] + L.first[j] + k];
+    row[EB_BOUND] = L.lik_bound;
+}
+
+__global__ void eb_scatter_grads_kernel(const hesic_eb_layout L, const float* __restrict__ dtable, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* row = dtable + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    for (int j = 0; j < L.n; ++j)
+        for (int k = 0; k < L.width[j]; ++k) {
+            float* dst = L.ptr[j] + (int64_t)c * L.stride[j] + L.first[j] + k;
+            *dst = accumulate ? *dst + row[L.col[j] + k] : row[L.col[j] + k];
+        }
+}
+
+// EntropyBottleneck.loss (entropy_models.py:345-348) forward + backward in one launch: loss += sum_c sum_q |c(quantiles[c,q]) -
+// target[q]| with the cumulative's parameters detached, so the only gradient is d/dquantiles = sign(.) * dc/dv.
+__global__ void eb_aux_loss_kernel(const float* __restrict__ params, const float* __restrict__ quantiles, float t_hi,
+                                   float* __restrict__ loss, float* __restrict__ dq, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float part = 0.f;
+    if (c < C) {
+        const float* raw = params + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+        EBParams q;
+        eb_load(raw, q);
+        float gp[EB_NP + 1];
+#pragma unroll
+        for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
+        for (int j = 0; j < 3; ++j) {
+            const float v = quantiles[c * 3 + j], tgt = j == 0 ? -t_hi : (j == 1 ? 0.f : t_hi);
+            const float diff = eb_logits(q, v, nullptr, nullptr) - tgt;
+            part += fabsf(diff);
+            if (dq) {
+                const float g = eb_logits_bwd(q, raw, v, signf(diff), gp);
+                dq[c * 3 + j] = accumulate ? dq[c * 3 + j] + g : g;
+            }
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(loss, part);
+}
+
 // ------------------------------------------------------------------ inference forms with fp32 latents (bf16 mode)
 // In the bf16 mode the analysis convs hand y / z and the hyper-synthesis convs hand sigma / mu over as fp32 (straight from
 // their accumulators, hesic_conv2d_forward_f32out): round() and the likelihoods then see the same precision as in the
@@ -679,4 +732,27 @@ extern "C" int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, 
     else { if (out_dtype == HESIC_BF16) GMM_F32IN(1, bf16_t); else GMM_F32IN(1, float); }
 #undef GMM_F32IN
     HESIC_LAUNCH_RETURN("gmm_forward_f32in");
+}
+
+extern "C" int hesic_eb_pack_table(const hesic_eb_layout* layout_host, float* table, int C, void* stream) {
+    HESIC_CHECK_ARG(layout_host && table && C > 0 && layout_host->n > 0 && layout_host->n <= HESIC_EB_MAX_TENSORS, "eb_pack_table: bad arguments");
+    for (int j = 0; j < layout_host->n; ++j)
+        HESIC_CHECK_ARG(layout_host->ptr[j] && layout_host->width[j] > 0 && layout_host->col[j] >= 0 &&
+                            layout_host->col[j] + layout_host->width[j] <= EB_READY, "eb_pack_table: entry %d out of range", j);
+    hipLaunchKernelGGL(eb_pack_table_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *layout_host, table, C);
+    HESIC_LAUNCH_RETURN("eb_pack_table");
+}
+
+extern "C" int hesic_eb_scatter_grads(const hesic_eb_layout* layout_host, const float* dtable, int C, int accumulate, void* stream) {
+    HESIC_CHECK_ARG(layout_host && dtable && C > 0 && layout_host->n > 0 && layout_host->n <= HESIC_EB_MAX_TENSORS, "eb_scatter_grads: bad arguments");
+    hipLaunchKernelGGL(eb_scatter_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *layout_host, dtable, C, accumulate);
+    HESIC_LAUNCH_RETURN("eb_scatter_grads");
+}
+
+extern "C" int hesic_eb_aux_loss(const float* params, const float* quantiles, float tail_mass, float* loss, float* dquantiles, int C,
+                                 int accumulate, void* stream) {
+    HESIC_CHECK_ARG(params && quantiles && loss && C > 0 && tail_mass > 0.f && tail_mass < 1.f, "eb_aux_loss: bad arguments");
+    const float t_hi = logf(2.f / tail_mass - 1.f);
+    hipLaunchKernelGGL(eb_aux_loss_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, quantiles, t_hi, loss, dquantiles, C, accumulate);
+    HESIC_LAUNCH_RETURN("eb_aux_loss");
 }

@@ -636,6 +636,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_colsum_kernel(const flo
     reduce_wide_body(ws, dw, nsplit, ntaps, per_tap, a, (int)blockIdx.x, (f32x4(*)[16])scratch);
 }
 
+// K-slice reduce straight into the PyTorch weight layout, optionally ACCUMULATING (dw += ...), + the bias column sums, one
+// launch.  A training step used to run reduce (packed layout) -> unpack (PyTorch layout) -> AccumulateGrad copy / add per
+// layer; with the gradients of all parameters living in one flat buffer (train.FlatGroup) this kernel adds the layer's
+// gradient in place.  Block = a tile of 8 couts x 32 cins x a group of live taps: the slices are summed with coalesced
+// 128-byte reads along cin, the tile turns round in LDS and leaves as runs along the destination's fastest index
+// (conv: (Cout, Cin, KH, KW) -> TG taps of 32 cins; transposed conv: (Cin, Cout, KH, KW) -> TG taps of 8 couts).
+struct FinishArgs {
+    const float* ws; float* dw; int nsplit, ntaps, T_all, Cout, Cin, transposed, accumulate;
+    int tiles_ci, tiles_co, tap_groups, taps_per_group, n_red;
+    int8_t tap_id[25];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinishArgs f, const T* __restrict__ dy, float* __restrict__ db, int64_t P,
+                                                           int y_ps, int y_co, int64_t rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float scratch[25 * 257 > 256 * (16 / (int)sizeof(T)) ? 25 * 257 : 256 * (16 / (int)sizeof(T))];
+    if ((int)blockIdx.x >= f.n_red) {
+        colsum_body<T>(dy, db, P, f.Cout, y_ps, y_co, rows_per_block, (int)blockIdx.x - f.n_red, scratch);
+        return;
+    }
+    int bid = blockIdx.x;
+    const int tci = bid % f.tiles_ci; bid /= f.tiles_ci;
+    const int tco = bid % f.tiles_co;
+    const int tg = bid / f.tiles_co;
+    const int t0 = tg * f.taps_per_group;
+    const int tn = (t0 + f.taps_per_group <= f.ntaps ? f.taps_per_group : f.ntaps - t0);
+    const int cl = threadIdx.x >> 5, il = threadIdx.x & 31;
+    const int co = tco * 8 + cl, ci = tci * 32 + il;
+    const int64_t per_tap = (int64_t)f.Cout * f.Cin, n = (int64_t)f.ntaps * per_tap;
+    const bool in = co < f.Cout && ci < f.Cin;
+    for (int tl = 0; tl < tn; ++tl) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (in) {
+            const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co * f.Cin + ci;
+            int k = 0;
+            for (; k + 3 < f.nsplit; k += 4) {           // fixed order (s0 + s1) + (s2 + s3): deterministic
+                s0 += src[(int64_t)k * n]; s1 += src[(int64_t)(k + 1) * n]; s2 += src[(int64_t)(k + 2) * n]; s3 += src[(int64_t)(k + 3) * n];
+            }
+            for (; k < f.nsplit; ++k) s0 += src[(int64_t)k * n];
+        }
+        scratch[tl * 257 + threadIdx.x] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    const int run = (f.transposed ? 8 : 32) * tn;          // values per outer index of the destination
+    for (int o = threadIdx.x; o < 256 * tn; o += 256) {
+        const int ol = o / run, rem = o - ol * run;
+        const int inner = rem / tn, tl = rem - inner * tn;
+        const int c_o = f.transposed ? tco * 8 + inner : tco * 8 + ol;
+        const int c_i = f.transposed ? tci * 32 + ol : tci * 32 + inner;
+        if (c_o >= f.Cout || c_i >= f.Cin) continue;
+        const float v = f.transposed ? scratch[tl * 257 + inner * 32 + ol] : scratch[tl * 257 + ol * 32 + inner];
+        const int t = f.tap_id[t0 + tl];
+        const int64_t dst = f.transposed ? ((int64_t)c_i * f.Cout + c_o) * f.T_all + t : ((int64_t)c_o * f.Cin + c_i) * f.T_all + t;
+        f.dw[dst] = f.accumulate ? f.dw[dst] + v : v;
+    }
+}
+
 // ------------------------------------------------------------------ narrow-channel weight gradient
 struct SWArgs {
     const void* x; const void* dy; float* dw; float* db;
@@ -1006,15 +1063,17 @@ __global__ __launch_bounds__(256) void gdn_bwd_param_small_kernel(const void* __
 
 __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, const float* __restrict__ dgp,
                                      const float* __restrict__ dbp, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                     float beta_bound) {
+                                     float beta_bound, int accumulate) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < C * C) {
         const float th = gamma[e], g = dgp[e] * 2.f * fmaxf(th, kGammaBound);
-        dgamma[e] = (th >= kGammaBound || g < 0.f) ? g : 0.f;
+        const float v = (th >= kGammaBound || g < 0.f) ? g : 0.f;
+        dgamma[e] = accumulate ? dgamma[e] + v : v;
     }
     if (e < C) {
         const float th = beta[e], g = dbp[e] * 2.f * fmaxf(th, beta_bound);
-        dbeta[e] = (th >= beta_bound || g < 0.f) ? g : 0.f;
+        const float v = (th >= beta_bound || g < 0.f) ? g : 0.f;
+        dbeta[e] = accumulate ? dbeta[e] + v : v;
     }
 }
 
@@ -1282,6 +1341,62 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     HESIC_LAUNCH_RETURN("conv2d_wgrad");
 }
 
+static thread_local int g_wgrad_partial_only = 0;      // set by hesic_conv2d_wgrad_partial: stop after the split-K MFMA launch
+
+extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                         int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    HESIC_CHECK_ARG(d && x && dy && (dw || g_wgrad_partial_only), "conv2d_wgrad_direct: null pointer");
+    const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
+    HESIC_CHECK_ARG(d->Cin % ce == 0 && d->Cout % ce == 0 && d->x_pix_stride % ce == 0 && d->y_pix_stride % ce == 0 &&
+                        d->x_c_off % ce == 0 && d->y_c_off % ce == 0,
+                    "conv2d_wgrad_direct: channels must be multiples of %d", ce);
+    HESIC_CHECK_ARG(d->KH * d->KW <= 25, "conv2d_wgrad_direct: at most 25 taps");
+    WgArgs a;
+    fill_args(d, a);
+    const int64_t need = (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4;
+    HESIC_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad_direct: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    a.x = x; a.dy = dy; a.out = (float*)ws;
+    const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
+    bool prefix = true;
+    for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
+    const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
+    float* zero_me = (dbias && !accumulate) ? dbias : nullptr;       // accumulate: the caller's buffer already holds a value
+    bool db_zeroed = false;
+    if (d->dtype == HESIC_BF16 && prefix && a.Q < (1ll << 31) && off32) {
+        launch_wgrad_tr(a, blocks, st, zero_me, zero_me ? d->Cout : 0);
+        db_zeroed = true;
+    } else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+    if (g_wgrad_partial_only) HESIC_LAUNCH_RETURN("conv2d_wgrad_partial");
+    if (zero_me && !db_zeroed) zero_async(dbias, d->Cout, st);
+    const int T_all = d->KH * d->KW;
+    if (a.ntaps < T_all && !accumulate) zero_async(dw, (int64_t)T_all * d->Cout * d->Cin, st);      // dead taps of a masked conv
+    FinishArgs f;
+    memset(&f, 0, sizeof(f));
+    f.ws = (const float*)ws; f.dw = dw; f.nsplit = a.nsplit; f.ntaps = a.ntaps; f.T_all = T_all; f.Cout = d->Cout; f.Cin = d->Cin;
+    f.transposed = d->transposed; f.accumulate = (accumulate || a.ntaps < T_all) ? 1 : 0;
+    memcpy(f.tap_id, a.tap_id, sizeof(f.tap_id));
+    f.tiles_ci = (d->Cin + 31) / 32; f.tiles_co = (d->Cout + 7) / 8;
+    const int tiles = f.tiles_ci * f.tiles_co;
+    int groups = (512 + tiles - 1) / tiles;                      // enough blocks to cover the chip twice
+    if (groups > a.ntaps) groups = a.ntaps;
+    if (groups < 1) groups = 1;
+    f.taps_per_group = (a.ntaps + groups - 1) / groups;
+    f.tap_groups = (a.ntaps + f.taps_per_group - 1) / f.taps_per_group;
+    f.n_red = tiles * f.tap_groups;
+    const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
+    const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;
+    const int n_col = dbias ? (int)((P + rpb - 1) / rpb) : 0;
+    if (d->dtype == HESIC_BF16)
+        hipLaunchKernelGGL(wgrad_finish_kernel<bf16_t>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const bf16_t*)dy, dbias, P,
+                           d->y_pix_stride, d->y_c_off, rpb);
+    else
+        hipLaunchKernelGGL(wgrad_finish_kernel<float>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const float*)dy, dbias, P,
+                           d->y_pix_stride, d->y_c_off, rpb);
+    HESIC_LAUNCH_RETURN("conv2d_wgrad_direct");
+}
+
 static bool nw_fast_case(const hesic_sconv_desc* d, bool& conv1) {
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 2;
     conv1 = k5 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 && d->H == 2 * d->Ho &&
@@ -1423,8 +1538,11 @@ extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) {
 extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
                                   void* ws, int64_t ws_bytes, void* stream);
 
+static thread_local int g_gdn_accumulate = 0;      // set by hesic_gdn_backward_acc around its call
+
 extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
                                   float* dgamma, void* ws, int64_t P, int C, int inverse, float beta_min, int dtype, void* stream) {
+    const int accumulate = g_gdn_accumulate;
     HESIC_CHECK_ARG(x && dy && beta && gamma && dx && dbeta && dgamma && ws && P > 0 && C > 0, "gdn_backward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
@@ -1464,7 +1582,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         const int n_red = 128 * 128 / 64, n_col = (int)((P + rpb - 1) / rpb);
         hipLaunchKernelGGL(wgrad_reduce_wide_colsum_kernel<bf16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
                            (int64_t)128 * 128, a, n_red, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
-        hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
+        hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate);
         HESIC_LAUNCH_RETURN("gdn_backward");
     }
     float* dn = (float*)ws;
@@ -1481,6 +1599,22 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     gy = (int)((P + rpb - 1) / rpb);
     if (C == 3) hipLaunchKernelGGL(gdn_bwd_param_small_kernel<3>, dim3(grid_for(P, 256 * 8, 128)), dim3(256), 0, st, x, dn, dgp, dbp, P, dtype);
     else hipLaunchKernelGGL(gdn_bwd_param_kernel, dim3(gx, gy), dim3(256), 0, st, x, dn, dgp, dbp, P, C, dtype, rpb);
-    hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(gx), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound);
+    hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(gx), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate);
     HESIC_LAUNCH_RETURN("gdn_backward");
+}
+
+extern "C" int hesic_gdn_backward_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
+                                      float* dgamma, int accumulate, void* ws, int64_t P, int C, int inverse, float beta_min, int dtype,
+                                      void* stream) {
+    g_gdn_accumulate = accumulate ? 1 : 0;
+    const int rc = hesic_gdn_backward(x, dy, beta, gamma, dx, dbeta, dgamma, ws, P, C, inverse, beta_min, dtype, stream);
+    g_gdn_accumulate = 0;
+    return rc;
+}
+
+extern "C" int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* x, const void* dy, void* ws, int64_t ws_bytes, void* stream) {
+    g_wgrad_partial_only = 1;
+    const int rc = hesic_conv2d_wgrad_direct(d, x, dy, nullptr, nullptr, 1, ws, ws_bytes, stream);
+    g_wgrad_partial_only = 0;
+    return rc;
 }

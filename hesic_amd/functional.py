@@ -49,6 +49,61 @@ def _zeros(shape, dtype, device):
     return torch.empty(shape, dtype=dtype, device=device).fill_(0)
 
 
+# ------------------------------------------------------------------------------ flat gradient slots
+# train.FlatGroup keeps the gradients of all parameters of an optimiser group in ONE flat fp32 buffer (cleared by one
+# launch per step, reduced over ranks in place, read by one Adam launch); every ``p.grad`` is a view into it.  The
+# backward passes below look the parameter up here (by storage address: saved tensors come back as fresh wrappers) and, if
+# it has a slot, ADD their gradient into it directly -- K-slice reduce, layout change and accumulation in the finishing
+# kernel -- and hand ``None`` to autograd: no unpack kernel, no AccumulateGrad copy / add per parameter.
+class GradSlot:
+    __slots__ = ("grad", "writes", "on_write", "name", "param")
+
+    def __init__(self, grad, name=""):
+        self.grad, self.writes, self.on_write, self.name, self.param = grad, 0, None, name, None
+
+
+_grad_slots = {}
+
+
+def register_grad_slots(slots):
+    """``slots``: iterable of (parameter, GradSlot).  Replaces any slot registered for the same storage address; returns the
+    registered addresses (for ``clear_grad_slots``)."""
+    import weakref
+    keys = []
+    for p, s in slots:
+        s.param = weakref.ref(p)
+        _grad_slots[p.data_ptr()] = s
+        keys.append(p.data_ptr())
+    return keys
+
+
+def clear_grad_slots(keys=None):
+    if keys is None:
+        _grad_slots.clear()
+    else:
+        for k in keys:
+            _grad_slots.pop(k, None)
+
+
+def _slot_for(t):
+    if t is None or not _grad_slots:
+        return None
+    s = _grad_slots.get(t.data_ptr())
+    if s is None:
+        return None
+    owner = s.param() if s.param is not None else None
+    if owner is None or owner.data_ptr() != t.data_ptr():       # the parameter is gone (its address may have been reused)
+        _grad_slots.pop(t.data_ptr(), None)
+        return None
+    return s if s.grad.shape == t.shape and s.grad.device == t.device else None
+
+
+def _slot_done(slot):
+    slot.writes += 1
+    if slot.on_write is not None:
+        slot.on_write(slot)
+
+
 # ------------------------------------------------------------------------------ packing cache
 _cache_epoch = 0
 
@@ -233,7 +288,7 @@ def _out_hw(H, W, k, stride, pad, transposed):
     return f(H), f(W)
 
 
-def _narrow_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
+def _narrow_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=None):
     """dx / dw / dbias of an image-side conv (few channels on one side: strided kernels)."""
     k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
     B, H, W, Cin, Ho, Wo, Cout = dims
@@ -249,18 +304,34 @@ def _narrow_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
         if in_abs:
             dx = dx * torch.sign(x)
     if need_dw:
-        dw = torch.empty_like(weight, dtype=torch.float32)
-        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+        # flat gradient slots: the kernel overwrites, so it may write the slot itself only while the (cleared) slot is untouched
+        ws_, bs_ = (_slot_for(weight) if mask is None else None), _slot_for(bias) if has_bias else None
+        w_direct = ws_ is not None and ws_.writes == 0 and weight.dtype == torch.float32
+        b_direct = bs_ is not None and bs_.writes == 0
+        dw = ws_.grad if w_direct else torch.empty_like(weight, dtype=torch.float32)
+        db = (bs_.grad if b_direct else torch.empty(Cout, dtype=torch.float32, device=x.device)) if has_bias else None
         nws = L.lib().hesic_sconv2d_wgrad_ws_bytes(C.byref(d))
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
         L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.ptr(ws), nws, L.stream())
         if mask is not None:
             dw = dw * mask
+        if ws_ is not None:
+            if not w_direct:
+                ws_.grad.add_(dw)
+            _slot_done(ws_)
+            dw = None
+        if bs_ is not None:
+            if not b_direct:
+                bs_.grad.add_(db)
+            _slot_done(bs_)
+            db = None
     return dx, dw, db
 
 
-def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
-    """dx / dw / dbias of a wide conv (implicit-GEMM kernels): shared by _ConvFn and _ConvGdnFn."""
+def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=None):
+    """dx / dw / dbias of a wide conv (implicit-GEMM kernels): shared by _ConvFn and _ConvGdnFn.  The weight gradient is one
+    split-K MFMA launch + one finishing launch that reduces the K slices, writes the PyTorch layout and sums dY's columns
+    for the bias (``hesic_conv2d_wgrad_direct``)."""
     k, stride, pad, transposed, act, in_abs, tap_mask, packer, mask = cfg
     B, H, W, Cin, Ho, Wo, Cout = dims
     dx = dw = db = None
@@ -278,16 +349,24 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw):
         if in_abs:
             dx = dx * torch.sign(x)
     if need_dw:
-        dwp = torch.empty(k * k * Cout * Cin, dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
         d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, in_abs,
                        x.shape[1], 0, gy.shape[1], 0, tap_mask)
         nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
         ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
-        L.call("hesic_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dwp), L.ptr(db), L.ptr(ws), nws, L.stream())
-        dw = torch.empty_like(weight, dtype=torch.float32)
-        L.call("hesic_unpack_conv_wgrad", L.ptr(dwp), L.ptr(mask), L.ptr(dw), Cout, Cin, k, k, int(transposed),
-               L.stream())
+        ws_, bs_ = _slot_for(weight), (_slot_for(bias) if has_bias else None)
+        if ws_ is not None and weight.dtype == torch.float32 and (not has_bias or bs_ is not None) and (mask is None or tap_mask):
+            # flat gradient buffer: the finishing kernel adds dW (PyTorch layout) and dbias into the slots
+            L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
+                   L.ptr(ws), nws, L.stream())
+            _slot_done(ws_)
+            if has_bias:
+                _slot_done(bs_)
+            return dx, None, None
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)      # dead taps of a masked conv are zero-filled by the call
+        L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), 0, L.ptr(ws), nws, L.stream())
+        if mask is not None and not tap_mask:
+            dw = dw * mask
     return dx, dw, db
 
 
@@ -322,7 +401,7 @@ class _ConvFn(torch.autograd.Function):
             wp = packer.get(weight, mask, Cout, Cin, k, k, transposed, False, x.dtype)
             y = _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, act, in_abs, tap_mask)
         ctx.save_for_backward(x, weight, y if act else None)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.bias = bias is not None, bias
         return y
 
     @staticmethod
@@ -338,9 +417,9 @@ class _ConvFn(torch.autograd.Function):
             gy = g2
         dx = dw = db = None
         if ctx.narrow:
-            dx, dw, db = _narrow_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            dx, dw, db = _narrow_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias)
         else:
-            dx, dw, db = _wide_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            dx, dw, db = _wide_conv_grads(x, weight, gy, ctx.cfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias)
         if not ctx.has_bias:
             db = None
         return dx, dw, db, None
@@ -389,6 +468,26 @@ def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
     return x.dtype == torch.bfloat16 and cin % 32 == 0
 
 
+def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
+    """GDN.backward on (input v, dy): returns (dv, dbeta, dgamma); with flat gradient slots the parameter gradients are
+    added in place and come back as None."""
+    B, Cc, H, W = v.shape
+    P = B * H * W
+    gv = torch.empty_like(v, memory_format=_CL)
+    sb, sg = _slot_for(beta), _slot_for(gamma)
+    direct = sb is not None and sg is not None
+    dbeta = sb.grad if direct else torch.empty_like(beta, dtype=torch.float32)
+    dgamma = sg.grad if direct else torch.empty_like(gamma, dtype=torch.float32)
+    ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=v.device)
+    L.call("hesic_gdn_backward_acc", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(gv), L.ptr(dbeta),
+           L.ptr(dgamma), int(direct), L.ptr(ws), P, Cc, int(inverse), float(beta_min), L.dt(v), L.stream())
+    if direct:
+        _slot_done(sb)
+        _slot_done(sg)
+        return gv, None, None
+    return gv, dbeta, dgamma
+
+
 class _SConvGdnFn(torch.autograd.Function):
     """g_a_gdn1(g_a_conv1(image)) fused under autograd (the 3 -> 128 stage): v = conv output is stored next to y."""
 
@@ -405,24 +504,16 @@ class _SConvGdnFn(torch.autograd.Function):
         L.call("hesic_sconv2d_gdn_forward_train", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
                L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
         ctx.save_for_backward(x, weight, v, beta, gamma)
-        ctx.cfg, ctx.dims, ctx.has_bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None
+        ctx.cfg, ctx.dims, ctx.has_bias, ctx.bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None, bias
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, v, beta, gamma = ctx.saved_tensors
         k, stride, pad, inverse, beta_min, _ = ctx.cfg
-        B, H, W, Cin, Ho, Wo, Cout = ctx.dims
-        P = B * Ho * Wo
-        gy = _nhwc(gy.to(v.dtype))
-        gv = torch.empty_like(v, memory_format=_CL)
-        dbeta = torch.empty_like(beta, dtype=torch.float32)
-        dgamma = torch.empty_like(gamma, dtype=torch.float32)
-        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cout)), dtype=torch.uint8, device=x.device)
-        L.call("hesic_gdn_backward", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
-               L.ptr(gv), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cout, int(inverse), float(beta_min), L.dt(v), L.stream())
+        gv, dbeta, dgamma = _gdn_backward(v, _nhwc(gy.to(v.dtype)), beta, gamma, inverse, beta_min)
         ccfg = (k, stride, pad, False, 0, 0, 0, None, None)
-        dx, dw, db = _narrow_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw, db = _narrow_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias)
         return dx, dw, (db if ctx.has_bias else None), dbeta, dgamma, None
 
 
@@ -445,24 +536,16 @@ class _ConvGdnFn(torch.autograd.Function):
         L.call("hesic_conv2d_gdn_forward_train", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse),
                L.ptr(y), L.ptr(v), L.stream())
         ctx.save_for_backward(x, weight, v, beta, gamma)
-        ctx.cfg, ctx.dims, ctx.has_bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None
+        ctx.cfg, ctx.dims, ctx.has_bias, ctx.bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None, bias
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, v, beta, gamma = ctx.saved_tensors
         k, stride, pad, transposed, inverse, beta_min, packer, _ = ctx.cfg
-        B, H, W, Cin, Ho, Wo, Cout = ctx.dims
-        P = B * Ho * Wo
-        gy = _nhwc(gy.to(v.dtype))
-        gv = torch.empty_like(v, memory_format=_CL)
-        dbeta = torch.empty_like(beta, dtype=torch.float32)
-        dgamma = torch.empty_like(gamma, dtype=torch.float32)
-        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cout)), dtype=torch.uint8, device=x.device)
-        L.call("hesic_gdn_backward", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
-               L.ptr(gv), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cout, int(inverse), float(beta_min), L.dt(v), L.stream())
+        gv, dbeta, dgamma = _gdn_backward(v, _nhwc(gy.to(v.dtype)), beta, gamma, inverse, beta_min)
         ccfg = (k, stride, pad, transposed, 0, 0, 0, packer, None)
-        dx, dw, db = _wide_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw, db = _wide_conv_grads(x, weight, gv, ccfg, ctx.dims, ctx.has_bias, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias)
         return dx, dw, (db if ctx.has_bias else None), dbeta, dgamma, None
 
 
@@ -623,16 +706,7 @@ class _GdnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, beta, gamma = ctx.saved_tensors
-        B, Cc, H, W = x.shape
-        P = B * H * W
-        gy = _nhwc(gy.to(x.dtype))
-        dx = torch.empty_like(x, memory_format=_CL)
-        dbeta = torch.empty_like(beta, dtype=torch.float32)          # fully written by the kernel's chain-rule pass
-        dgamma = torch.empty_like(gamma, dtype=torch.float32)
-        ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=x.device)
-        L.call("hesic_gdn_backward", L.ptr(x), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()),
-               L.ptr(dx), L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), P, Cc, int(ctx.inverse), float(ctx.beta_min),
-               L.dt(x), L.stream())
+        dx, dbeta, dgamma = _gdn_backward(x, _nhwc(gy.to(x.dtype)), beta, gamma, ctx.inverse, ctx.beta_min)
         return dx, dbeta, dgamma, None, None
 
 
@@ -715,6 +789,50 @@ def eb_unpack_grads(dparams, matrices, biases, factors, quantiles):
     return out, dq
 
 
+def _eb_layout(matrices, biases, factors, quantiles, lik_bound=0.0, grads=False):
+    """``EbLayout`` of a bottleneck's 14 parameter tensors (or, ``grads``: of their flat gradient slots; None if any has no
+    slot).  Table columns: matrices, then biases, then factors, each (C, rows, cols) flattened per channel; column 58 = the
+    median = quantiles[:, 0, 1]."""
+    lay = L.EbLayout()
+    col, j = 0, 0
+    for group in (matrices, biases, factors):
+        for p in group:
+            t = p
+            if grads:
+                sl = _slot_for(p)
+                if sl is None:
+                    return None
+                t = sl.grad
+            n = p[0].numel()
+            lay.ptr[j], lay.width[j], lay.stride[j], lay.first[j], lay.col[j] = t.data_ptr(), n, n, 0, col
+            col += n
+            j += 1
+    if col != 58:
+        raise NotImplementedError("EntropyBottleneck kernels are specialised for filters=(3,3,3,3)")
+    t = quantiles
+    if grads:
+        sl = _slot_for(quantiles)
+        if sl is None:
+            return None
+        t = sl.grad
+    lay.ptr[j], lay.width[j], lay.stride[j], lay.first[j], lay.col[j] = t.data_ptr(), 1, 3, 1, 58
+    lay.n, lay.lik_bound = j + 1, float(lik_bound)
+    return lay
+
+
+def _eb_table(matrices, biases, factors, quantiles, lik_bound):
+    """The raw [C][64] parameter table in one launch (``hesic_eb_pack_table``)."""
+    ps = (*matrices, *biases, *factors, quantiles)
+    if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+        return eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases], [f.detach() for f in factors],
+                              quantiles.detach(), lik_bound)
+    Cc = quantiles.shape[0]
+    table = torch.empty((Cc, L.EB_PARAM_STRIDE), dtype=torch.float32, device=quantiles.device)
+    lay = _eb_layout(matrices, biases, factors, quantiles, lik_bound)
+    L.call("hesic_eb_pack_table", C.byref(lay), L.ptr(table), Cc, L.stream())
+    return table
+
+
 class _EbFn(torch.autograd.Function):
     """EntropyBottleneck.forward (entropy_models.py:384-411): returns (z_hat, likelihood)."""
 
@@ -724,8 +842,7 @@ class _EbFn(torch.autograd.Function):
         matrices, biases, factors = params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:]
         B, Cc, H, W = z.shape
         z = _nhwc(z)
-        table = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
-                               [f.detach() for f in factors], quantiles.detach(), lik_bound)
+        table = _eb_table(matrices, biases, factors, quantiles, lik_bound)
         zh = torch.empty_like(z, memory_format=_CL)
         lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
         nz = None if noise is None else _nhwc(noise.to(z.dtype))
@@ -746,6 +863,12 @@ class _EbFn(torch.autograd.Function):
         g_zh = None if g_zh is None else _nhwc(g_zh.to(z.dtype))
         L.call("hesic_eb_backward", L.ptr(z), L.ptr(table), L.ptr(nz), L.ptr(g_lik), L.ptr(g_zh), L.ptr(dz), L.ptr(dpar),
                B * H * W, Cc, L.dt(z), L.stream())
+        glay = _eb_layout(params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:], quantiles, grads=True)
+        if glay is not None:          # flat gradient slots: one scatter-add launch instead of 14 slice copies + AccumulateGrad
+            L.call("hesic_eb_scatter_grads", C.byref(glay), L.ptr(dpar), Cc, 1, L.stream())
+            for p in (*params, quantiles):
+                _slot_done(_slot_for(p))
+            return (dz, None, None, None, None, *([None] * len(params)))
         grads, dq = eb_unpack_grads(dpar, params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:], quantiles)
         return (dz, None, dq, None, None, *grads)
 
@@ -760,8 +883,7 @@ class PackedEb:
         ps = (*matrices, *biases, *factors, quantiles)
         tag = tuple((p.data_ptr(), p._version) for p in ps) + (_cache_epoch, float(lik_bound))
         if self._hit is None or self._hit[0] != tag:
-            raw = eb_pack_params([m.detach() for m in matrices], [b.detach() for b in biases],
-                                 [f.detach() for f in factors], quantiles.detach(), lik_bound)
+            raw = _eb_table(matrices, biases, factors, quantiles, lik_bound)
             ready = torch.empty_like(raw)           # softplus / tanh applied once here, not per thread and launch
             L.call("hesic_eb_prepare_params", L.ptr(raw), L.ptr(ready), raw.shape[0], L.stream())
             self._hit = (tag, ready)
@@ -786,6 +908,33 @@ def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, pack
         L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), None, L.ptr(zh), L.ptr(lik), None, B * H * W, Cc, L.dt(z), L.stream())
         return zh, lik
     return _EbFn.apply(z, noise, quantiles, len(matrices), float(lik_bound), *matrices, *biases, *factors)
+
+
+class _EbAuxFn(torch.autograd.Function):
+    """EntropyBottleneck.loss (entropy_models.py:345-348): sum |c(quantiles) - target| with the cumulative's parameters
+    detached -- forward AND the quantile gradient in one launch (the tensor-op form is ~35 launches per bottleneck)."""
+
+    @staticmethod
+    def forward(ctx, quantiles, tail_mass, n_mat, *params):
+        L.require_cuda(quantiles)
+        matrices, biases, factors = params[:n_mat], params[n_mat:2 * n_mat], params[2 * n_mat:]
+        Cc = quantiles.shape[0]
+        table = _eb_table(matrices, biases, factors, quantiles, 0.0)
+        loss = _zeros(1, torch.float32, quantiles.device)
+        dq = torch.empty_like(quantiles, dtype=torch.float32)
+        L.call("hesic_eb_aux_loss", L.ptr(table), L.ptr(quantiles.detach().contiguous()), float(tail_mass), L.ptr(loss), L.ptr(dq), Cc, 0, L.stream())
+        ctx.save_for_backward(dq)
+        ctx.n_params = len(params)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dq,) = ctx.saved_tensors
+        return (dq * g, None, None, *([None] * ctx.n_params))
+
+
+def eb_aux_loss(matrices, biases, factors, quantiles, tail_mass=1e-9):
+    return _EbAuxFn.apply(quantiles, float(tail_mass), len(matrices), *matrices, *biases, *factors)
 
 
 # ------------------------------------------------------------ Gaussian (mixture) conditional
@@ -1063,6 +1212,7 @@ class _PooledLinearFn(torch.autograd.Function):
         L.call("hesic_pooled_linear_forward", L.ptr(p), L.ptr(w), L.ptr(None if bias is None else bias.detach().float()), L.ptr(out),
                B, N, L.stream())
         ctx.save_for_backward(p, w)
+        ctx.weight, ctx.bias = weight, bias
         ctx.meta = (pooled.dtype, weight.dtype, weight.shape, bias is not None, None if bias is None else bias.dtype)
         return out.reshape(B, N, 1, 1)
 
@@ -1074,9 +1224,20 @@ class _PooledLinearFn(torch.autograd.Function):
         g = g.reshape(B, N).to(torch.float32).contiguous()
         need_p, need_w, need_b = ctx.needs_input_grad
         dp = torch.empty_like(p) if need_p else None
-        dw = torch.empty((N, N), dtype=torch.float32, device=p.device) if (need_w or (need_b and has_b)) else None
-        db = torch.empty(N, dtype=torch.float32, device=p.device) if (need_b and has_b) else None
+        # flat gradient slots: the kernel overwrites, so it writes the (cleared, still untouched) slots themselves
+        ws_, bs_ = _slot_for(ctx.weight), (_slot_for(ctx.bias) if has_b else None)
+        direct = need_w and ws_ is not None and ws_.writes == 0 and (not has_b or (bs_ is not None and bs_.writes == 0))
+        if direct:
+            dw, db = ws_.grad, (bs_.grad if has_b else None)
+        else:
+            dw = torch.empty((N, N), dtype=torch.float32, device=p.device) if (need_w or (need_b and has_b)) else None
+            db = torch.empty(N, dtype=torch.float32, device=p.device) if (need_b and has_b) else None
         L.call("hesic_pooled_linear_backward", L.ptr(p), L.ptr(w), L.ptr(g), L.ptr(dp), L.ptr(dw), L.ptr(db), B, N, L.stream())
+        if direct:
+            _slot_done(ws_)
+            if has_b:
+                _slot_done(bs_)
+            return (None if dp is None else dp.reshape(B, N, 1, 1).to(pdt), None, None)
         return (None if dp is None else dp.reshape(B, N, 1, 1).to(pdt), dw.reshape(wshape).to(wdt) if need_w else None,
                 None if db is None else db.to(bdt))
 

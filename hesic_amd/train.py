@@ -1,13 +1,22 @@
-"""Training harness of the path (the build's counterpart of ywz/mywork/newtrain1.py:74-111):
-R-D loss, the two-optimiser update order, and plain data parallelism -- one process per GPU, gradients
-summed with RCCL all-reduce over xGMI (``torch.distributed`` backend "nccl" on ROCm), bucketed and
-launched from autograd hooks so the collective overlaps the rest of the backward pass.
+"""Training harness of the path (the build's counterpart of ywz/mywork/newtrain1.py:74-111): R-D loss, the
+two-optimiser update order, and plain data parallelism -- one process per GPU, gradients averaged with RCCL
+all-reduce over xGMI (``torch.distributed`` backend "nccl" on ROCm).
 
-The reference has no multi-device code at all; pairs are independent, the loss
-normalises by the LOCAL batch (newtrain1.py:45-47), so averaging rank gradients reproduces the
-single-process gradient of the concatenated batch exactly.
+The reference has no multi-device code at all; pairs are independent, the loss normalises by the
+LOCAL batch (newtrain1.py:45-47), so averaging rank gradients reproduces the single-process gradient of the
+concatenated batch exactly.
+
+Layout (round 2).  The parameters of an optimiser group live in ONE flat fp32 buffer and so do their gradients
+(``FlatGroup``): ``p.data`` / ``p.grad`` are views.  That makes the bookkeeping of a step a handful of launches: one fill
+clears all gradients, the weight-gradient kernels ADD into their slot in place (``functional.GradSlot``: no unpack, no
+AccumulateGrad copy/add), the all-reduce runs in place on contiguous slices of the flat gradient (no ``torch.cat`` /
+``copy_`` pack and unpack), one Adam launch updates everything.  The collective is issued per bucket as soon as the
+bucket's last gradient has been written, so it overlaps the rest of the backward pass, and every piece is capturable:
+``GraphedTrainer`` records the step -- collectives included -- into one HIP graph per rank.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -23,7 +32,8 @@ class MultiTensorAdam(torch.optim.Adam):
     device, ``exp_avg``, ``exp_avg_sq``), so checkpoints move between the two.  Why: the multi-tensor (foreach) torch
     step falls back to one elementwise launch per parameter for its 0-dim step counters -- ~290 launches, 1.2 ms of the
     9 ms graphed training step.  Anything this kernel does not cover (CPU tensors, non-fp32, non-contiguous, amsgrad,
-    weight decay, maximize) goes to the parent's step."""
+    weight decay, maximize) goes to the parent's step.  Self-contained: ``step()`` bumps the version counters of what it
+    updated and starts a new epoch for the packed-weight caches, like any in-place optimiser."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, capturable=True, foreach=True)
@@ -31,7 +41,6 @@ class MultiTensorAdam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         from . import _lib as L
-        import ctypes as C
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             ok = (not group.get("amsgrad") and not group.get("weight_decay") and not group.get("maximize")
@@ -67,137 +76,234 @@ class MultiTensorAdam(torch.optim.Adam):
         return loss
 
 
-class GradBucketReducer:
-    """Bucketed asynchronous gradient all-reduce (average).
+# ------------------------------------------------------------------------------------------------ flat buffers
+class FlatGroup:
+    """The parameters of one optimiser group as views into one flat fp32 buffer, their gradients as views into another.
 
-    Parameters are grouped into ~``bucket_mb`` buckets in reverse registration order (the order autograd
-    finishes them); a post-accumulate hook counts arrivals and, when a bucket is complete, packs it into one
-    flat buffer and starts ``all_reduce(async_op=True)``.  ``finish()`` waits and scatters the averages back.
-    With world_size == 1 (or no process group) everything is a no-op.
-    """
+    ``p.data`` and ``p.grad`` are re-pointed (values are kept); state-dict keys, shapes and ``nn.Module`` structure are
+    untouched.  Every tensor starts on a 256-byte boundary (the kernels read biases / GDN parameters with 16-byte loads).
+    Moving the module afterwards (``.to()``, ``.cuda()``) would break the aliasing: build the group last."""
 
-    def __init__(self, params, bucket_mb: float = 25.0, process_group=None):
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.params = [p for p in params if p.requires_grad]
-        self.buckets, self._of, self._pending, self._work = [], {}, [], []
-        if self.world == 1:
+    ALIGN = 64      # floats
+
+    def __init__(self, params):
+        seen, self.params = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        if not self.params:
+            raise ValueError("FlatGroup: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatGroup: fp32 parameters on one device")
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach())
+                p.data = view
+                g = self.flat_g[o:o + p.numel()].view(p.shape)
+                p.grad = g
+                self.grad_views.append(g)
+        self.slots = [Fn.GradSlot(g, name=str(i)) for i, g in enumerate(self.grad_views)]
+        if dev.type == "cuda":
+            import weakref
+            keys = Fn.register_grad_slots(zip(self.params, self.slots))
+            weakref.finalize(self, Fn.clear_grad_slots, keys)       # a dead group must not keep its gradient buffer registered
+
+    def zero_grad(self):
+        """One fill for every gradient of the group (a kernel, not a memset: graph-safe); re-attaches ``p.grad`` views that
+        user code dropped (``zero_grad(set_to_none=True)``)."""
+        self.flat_g.fill_(0)
+        for p, g, s in zip(self.params, self.grad_views, self.slots):
+            if p.grad is not g:
+                p.grad = g
+            s.writes = 0
+
+    def view_like_params(self, flat):
+        return [flat[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+
+
+class FlatAdam:
+    """``torch.optim.Adam(params, lr)`` (newtrain1.py:294-295; no amsgrad / weight decay) over a ``FlatGroup``: ONE update
+    launch for the whole group (``hesic_adam_step`` on the flat buffers; padding elements have zero gradient and stay
+    zero).  ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.Adam``'s per-parameter format."""
+
+    def __init__(self, group: FlatGroup, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.group, self.betas, self.eps = group, (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = torch.zeros_like(group.flat_p)
+        self.exp_avg_sq = torch.zeros_like(group.flat_p)
+        self.step_count = torch.zeros((), dtype=torch.float32, device=group.flat_p.device)
+        self.param_groups = [{"params": group.params, "lr": float(lr), "betas": self.betas, "eps": self.eps}]
+
+    def zero_grad(self, set_to_none=False):
+        self.group.zero_grad()
+
+    @torch.no_grad()
+    def step(self):
+        from . import _lib as L
+        g = self.group
+        c = L.AdamChunk()
+        c.p[0], c.g[0], c.m[0], c.v[0] = g.flat_p.data_ptr(), g.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        c.step[0], c.numel[0] = self.step_count.data_ptr(), g.numel
+        c.n, c.lr, c.beta1, c.beta2, c.eps = 1, float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps
+        L.call("hesic_adam_step", C.byref(c), L.stream())
+        torch.autograd.graph.increment_version(g.params)
+        Fn.invalidate_weight_cache()
+
+    def state_dict(self):
+        m, v = self.group.view_like_params(self.exp_avg), self.group.view_like_params(self.exp_avg_sq)
+        state = {i: {"step": self.step_count.clone(), "exp_avg": m[i].clone(), "exp_avg_sq": v[i].clone()} for i in range(len(m))}
+        pg = {"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+              "foreach": None, "capturable": True, "differentiable": False, "fused": None, "params": list(range(len(m)))}
+        return {"state": state, "param_groups": [pg]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        m, v = self.group.view_like_params(self.exp_avg), self.group.view_like_params(self.exp_avg_sq)
+        for i, st in sd["state"].items():
+            m[int(i)].copy_(st["exp_avg"])
+            v[int(i)].copy_(st["exp_avg_sq"])
+            self.step_count.fill_(float(st["step"]))
+        if sd.get("param_groups"):
+            self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.param_groups[0]["lr"])
+
+
+class FlatReducer:
+    """Gradient averaging over the ranks, in place on a ``FlatGroup``'s flat gradient buffer.
+
+    The buffer is cut into ~``bucket_mb`` buckets of whole parameters.  With ``overlap`` a bucket's all-reduce is issued
+    (``async_op``: on the backend's own stream, after an event on the compute stream) the moment its last gradient has been
+    written -- gradient kernels report through ``GradSlot.on_write``, parameters that go through autograd's AccumulateGrad
+    through a post-accumulate hook -- so the collective runs under the rest of the backward pass.  How many writes complete
+    a parameter (encoder1's weights receive two per step) is learned in the first step, which reduces everything at
+    ``finish()``.  ``finish()`` launches what is left (parameters without gradient on this rank still take part: ranks stay
+    in step), waits and -- for backends without an averaging reduction (gloo) -- divides.  world_size 1: all no-ops."""
+
+    def __init__(self, group: FlatGroup, bucket_mb: float = 25.0, process_group=None, overlap=True, force=False):
+        self.group, self.pg, self.overlap = group, process_group, overlap
+        up = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if up else 1
+        self.buckets, self._work, self._expected, self._events = [], [], None, [0] * len(group.params)
+        # ``force``: issue the collectives even in a 1-rank group (a 1-GPU box can then exercise RCCL bring-up and the capture
+        # of the all-reduces into the step's HIP graph)
+        self.active = self.world > 1 or (force and up)
+        if not self.active:
             return
-        cap = int(bucket_mb * (1 << 20))
-        cur, size = [], 0
-        for p in reversed(self.params):
-            nbytes = p.numel() * 4
-            if cur and size + nbytes > cap:
-                self.buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += nbytes
-        if cur:
-            self.buckets.append(cur)
+        self.avg_op = dist.get_backend(process_group) == "nccl"
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        lo, members = 0, []
+        for i in range(len(group.params)):
+            end = group.offsets[i + 1] if i + 1 < len(group.params) else group.numel
+            members.append(i)
+            if end - lo >= cap or i + 1 == len(group.params):
+                self.buckets.append({"lo": lo, "hi": end, "members": members, "pending": len(members), "launched": False})
+                lo, members = end, []
+        self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
-            for p in b:
-                self._of[p] = bi
-                p.register_post_accumulate_grad_hook(self._hook)
-        self._pending = [len(b) for b in self.buckets]
+            for i in b["members"]:
+                self._bucket_of[i] = bi
+        for i, (p, s) in enumerate(zip(group.params, group.slots)):
+            s.on_write = (lambda slot, i=i: self._event(i))
+            p.register_post_accumulate_grad_hook(lambda p_, i=i: self._event(i))
 
-    def _hook(self, p):
-        bi = self._of[p]
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
-
-    def _launch(self, bi):
-        ps = [p for p in self.buckets[bi] if p.grad is not None]
-        if not ps:
+    def begin(self):
+        """Call before the backward pass of every step."""
+        if not self.active:
             return
-        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._work.append((work, flat, ps))
+        self._events = [0] * len(self.group.params)
+        for b in self.buckets:
+            b["pending"], b["launched"] = len(b["members"]), False
+
+    def _event(self, i):
+        self._events[i] += 1
+        if self._expected is None or self._events[i] != self._expected[i]:
+            return
+        b = self.buckets[self._bucket_of[i]]
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.overlap and not b["launched"]:
+            self._launch(b)
+
+    def _launch(self, b):
+        b["launched"] = True
+        op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
+        self._work.append(dist.all_reduce(self.group.flat_g[b["lo"]:b["hi"]], op=op, group=self.pg, async_op=True))
 
     def finish(self):
-        """Wait for every bucket (launching the ones whose params got no gradient hook call) and write the
-        averaged gradients back.  Call once after each backward."""
-        if self.world == 1:
+        """Call once after the backward pass: launches the remaining buckets, waits, averages."""
+        if not self.active:
             return
-        for bi, left in enumerate(self._pending):
-            if left > 0:          # parameters unused in this backward: reduce what exists so ranks stay in step
-                self._launch(bi)
-        for work, flat, ps in self._work:
-            work.wait()
-            flat.div_(self.world)
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for w in self._work:
+            w.wait()
         self._work.clear()
-        self._pending = [len(b) for b in self.buckets]
+        if not self.avg_op and self.world > 1:
+            self.group.flat_g.div_(self.world)
+        if self._expected is None:
+            # a parameter that saw no gradient event this step completes its bucket at finish() in later steps too
+            self._expected = [e if e > 0 else -1 for e in self._events]
 
 
 class Trainer:
-    """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295)
-    and, when a process group is up, one reducer per optimiser group."""
+    """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295) over flat
+    parameter / gradient buffers and, when a process group is up, one in-place reducer per optimiser group."""
 
-    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, fused=False, capturable=False, multi_tensor=True):
+    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, overlap=True, force_collectives=False):
         self.model, self.lmbda = model, float(lmbda)
         main, aux = list(model.parameters()), list(model.aux_parameters())
-        # multi-tensor (foreach) Adam by default: on this ROCm build the fused Adam kernel takes visibly
-        # smaller first steps than the reference's plain Adam (measured: loss 220.4 -> 216.1 vs 220.3 -> 187.0)
-        kw = {"fused": True} if fused else {}
-        if capturable:            # step counters live on the device: the update can be recorded into a HIP graph
-            kw["capturable"] = True
-        on_gpu = all(p.is_cuda for p in main + aux) and len(main) > 0
-        if on_gpu and not fused and multi_tensor:
-            # same state layout as Adam(capturable=True); update of all tensors in ~6 launches per optimiser
-            self.optimizer = MultiTensorAdam(main, lr=lr)
-            self.aux_optimizer = MultiTensorAdam(aux, lr=aux_lr)
-        else:
-            self.optimizer = torch.optim.Adam(main, lr=lr, **kw)
-            self.aux_optimizer = torch.optim.Adam(aux, lr=aux_lr, **kw)
+        self.main_group, self.aux_group = FlatGroup(main), FlatGroup(aux)
+        self.on_gpu = self.main_group.flat_p.is_cuda
+        if self.on_gpu:
+            self.optimizer = FlatAdam(self.main_group, lr=lr)
+            self.aux_optimizer = FlatAdam(self.aux_group, lr=aux_lr)
+        else:       # host modules (the gloo tests): torch's Adam on the same views
+            self.optimizer = torch.optim.Adam(self.main_group.params, lr=lr)
+            self.aux_optimizer = torch.optim.Adam(self.aux_group.params, lr=aux_lr)
         # EB matrices/biases/factors get their gradient from the main backward but are stepped by the aux
         # optimiser after the aux backward adds the quantile gradient (SURVEY.md 3.1): both groups are reduced,
         # the aux group only after the aux backward.
-        self.main_reducer = GradBucketReducer(main, bucket_mb)
-        self.aux_params = aux
+        self.main_reducer = FlatReducer(self.main_group, bucket_mb, overlap=overlap, force=force_collectives)
+        self.aux_reducer = FlatReducer(self.aux_group, bucket_mb, overlap=False, force=force_collectives)
         self.world = self.main_reducer.world
 
-    def _reduce_aux(self):
-        if self.world == 1:
-            return
-        gs = [p.grad for p in self.aux_params if p.grad is not None]
-        if not gs:
-            return
-        flat = torch.cat([g.reshape(-1).float() for g in gs])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(self.world)
-        off = 0
-        for g in gs:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+    def _forward_loss(self, x1, x2, h_matrix, noise):
+        out = self.model(x1, x2, h_matrix, noise=noise)
+        return Fn.rd_loss(out, x1, x2, self.lmbda)
 
     def step(self, x1, x2, h_matrix, noise=None):
-        """One iteration in the reference's order: zero both -> forward -> R-D loss backward -> optimizer.step
-        -> aux loss backward -> aux_optimizer.step.  Returns the loss dict (device scalars, no sync)."""
+        """One iteration in the reference's order: zero both -> forward -> R-D loss backward -> (reduce) -> optimizer.step
+        -> aux loss backward -> (reduce) -> aux_optimizer.step.  Returns the loss dict (device scalars, no sync)."""
         self.model.train()
-        self.optimizer.zero_grad(set_to_none=True)
-        self.aux_optimizer.zero_grad(set_to_none=True)
+        self.main_group.zero_grad()
+        self.aux_group.zero_grad()
+        self.main_reducer.begin()
+        self.aux_reducer.begin()
         prev = Fn.train_pack_cache(True)          # packed conv weights persist across the step, one batched repack below
         scaled, Fn.SCALED_LOSS = Fn.SCALED_LOSS, False     # backward() starts at the unscaled loss: no g_loss multiplies
         try:
-            out = self.model(x1, x2, h_matrix, noise=noise)
-            crit = Fn.rd_loss(out, x1, x2, self.lmbda)
+            crit = self._forward_loss(x1, x2, h_matrix, noise)
             crit["loss"].backward()
         finally:
             Fn.train_pack_cache(prev)
             Fn.SCALED_LOSS = scaled
         self.main_reducer.finish()
         self.optimizer.step()
-        Fn.invalidate_weight_cache()              # fused optimisers do not bump version counters: new epoch for every cache
-        if x1.is_cuda:
+        Fn.invalidate_weight_cache()              # new epoch for every cache keyed on the parameters
+        if self.on_gpu:
             Fn.repack_all()
         aux = self.model.aux_loss()
         aux.backward()
-        self._reduce_aux()
+        self.aux_reducer.finish()
         self.aux_optimizer.step()
         # detached scalars only: a returned loss that still requires grad would keep this step's autograd graph (and its
         # AccumulateGrad nodes, bound to this step's stream) alive into the next one
@@ -207,25 +313,25 @@ class Trainer:
 
 
 class GraphedTrainer(Trainer):
-    """``Trainer.step`` recorded once into a HIP graph and replayed (single process; with a process group the eager
-    ``Trainer`` and its overlapped all-reduce is the path).
+    """``Trainer.step`` recorded once into a HIP graph and replayed -- with a process group up, one graph per rank with the
+    bucketed RCCL all-reduces inside it (collectives are stream work like any kernel; their forked comm-stream nodes keep the
+    overlap with the backward pass in the graph).
 
-    One training step is ~600 launches, most of them a few microseconds long: eagerly the Python/ctypes launch work
-    (~12 ms at B=8, 256x256) exceeds the GPU time (~9.6 ms), so the step is host-bound.  The first ``warmup`` calls run
-    eagerly on a side stream (they are real steps: they pack weights, size workspaces and let autograd allocate), the next
-    call captures zero_grad -> forward -> R-D backward -> Adam -> aux backward -> aux Adam and every later call is a copy
-    of the inputs into the static buffers plus one graph launch.  The quantisation noise is drawn inside the graph by
-    the graph-safe Philox generator unless a ``noise`` dict is given at capture time (then it is a static input too).
-    The returned dict holds the graph's static loss tensors (overwritten by the next call)."""
+    One training step is a few hundred launches, most of them a few microseconds long: eagerly the Python/ctypes launch work
+    exceeds the GPU time, so the step is host-bound.  The first ``warmup`` calls run eagerly on a side stream (they are real
+    steps: they pack weights, size workspaces, let autograd allocate and teach the reducer how many writes complete each
+    gradient), the next call captures zero_grad -> forward -> R-D backward -> reduce -> Adam -> aux backward -> reduce -> aux
+    Adam and every later call is a copy of the inputs into the static buffers plus one graph launch.  The quantisation noise
+    is drawn inside the graph by the graph-safe Philox generator unless a ``noise`` dict is given at capture time (then it is
+    a static input too).  The returned dict holds the graph's static loss tensors (overwritten by the next call)."""
 
     def __init__(self, model, *args, warmup=3, **kw):
-        kw["capturable"] = True
         super().__init__(model, *args, **kw)
-        if self.world != 1:
-            raise RuntimeError("GraphedTrainer is single-process: use Trainer under torch.distributed")
+        if not self.on_gpu:
+            raise RuntimeError("GraphedTrainer needs the model on a ROCm device")
         if int(warmup) < 1:
-            raise ValueError("GraphedTrainer: warmup >= 1 (the optimiser state and the packed-weight registry are created by an eager step; "
-                             "captured, their zero-initialisation would replay on every step)")
+            raise ValueError("GraphedTrainer: warmup >= 1 (the packed-weight registry and the reducer's write counts are created by an "
+                             "eager step)")
         self.warmup, self.calls, self.graph = int(warmup), 0, None
         self._in = self._noise = self._out = None
 

@@ -118,6 +118,15 @@ int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, 
                        void* ws, int64_t ws_bytes, void* stream);
 int hesic_unpack_conv_wgrad(const float* dw_packed, const float* mask, float* dw, int Cout, int Cin, int KH, int KW,
                             int transposed, void* stream);
+/* The same gradient written straight in the PyTorch layout ((Cout,Cin,KH,KW), transposed: (Cin,Cout,KH,KW)) with the
+ * K-slice reduce, the layout change and the bias column sums in ONE finishing launch; accumulate != 0: dw += ..., dbias += ...
+ * (the gradients of a training step live in one flat buffer that is cleared once per step; a weight used twice per step --
+ * encoder1, newnet1.py:726,754 -- simply adds twice).  Dead taps of a masked conv are left untouched when accumulating.  */
+int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                              void* ws, int64_t ws_bytes, void* stream);
+/* Only the first of its two launches -- the split-K MFMA kernel that leaves the fp32 partial tiles in ws -- for profiling
+ * (bench.py brackets it with HIP events to price the weight-gradient kernel against the MFMA roofline).               */
+int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* x, const void* dy, void* ws, int64_t ws_bytes, void* stream);
 
 /* 3-channel image convs with arbitrary element strides on the image side (conv1 3->N, pre_conv 6->3,
  * g_s_conv4 N->3, after_conv 6->3: newnet1.py:583,629,612,670).  `img_*` strides describe the tensor
@@ -168,6 +177,10 @@ int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C);
 int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const float* gamma, void* dx,
                        float* dbeta, float* dgamma, void* ws, int64_t P, int C, int inverse, float beta_min,
                        int dtype, void* stream);
+/* accumulate != 0: dbeta += ..., dgamma += ... (flat gradient buffer of a training step) */
+int hesic_gdn_backward_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx,
+                           float* dbeta, float* dgamma, int accumulate, void* ws, int64_t P, int C, int inverse,
+                           float beta_min, int dtype, void* stream);
 
 /* ------------------------------------------------------------------- warp_perspective (row A10)
  * Replaces kornia.warp_perspective(src, M, dsize) (third party; call sites newnet1.py:746,753,767).
@@ -207,6 +220,26 @@ int hesic_eb_prepare_params(const float* params, float* prepared, int C, void* s
  * g_lik: fp32 gradient of lik, g_zhat: gradient of z_hat (may be NULL).                              */
 int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
                       void* dz, float* dparams, int64_t P, int C, int dtype, void* stream);
+
+/* Training plumbing of the bottleneck parameters (EntropyBottleneck.__init__, entropy_models.py:262-300): the 13 MLP
+ * tensors + quantiles <-> the [C][64] table, one launch each way.  Entry j: a (C, ...) fp32 tensor with `stride[j]` floats
+ * per channel whose `width[j]` values starting at `first[j]` occupy table columns [col[j], col[j] + width[j]).  The struct
+ * is read on the HOST and travels in the kernel arguments; ptr[] are device pointers.                              */
+#define HESIC_EB_MAX_TENSORS 16
+typedef struct {
+    float* ptr[HESIC_EB_MAX_TENSORS];
+    int32_t width[HESIC_EB_MAX_TENSORS], stride[HESIC_EB_MAX_TENSORS], first[HESIC_EB_MAX_TENSORS], col[HESIC_EB_MAX_TENSORS];
+    int32_t n;
+    float lik_bound;                 /* written to slot 60 by hesic_eb_pack_table */
+} hesic_eb_layout;
+int hesic_eb_pack_table(const hesic_eb_layout* layout_host, float* table, int C, void* stream);
+/* d(tensor j)[c][first + k] (+)= dtable[c][col_j + k]: hesic_eb_backward's dparams back into the parameters' gradients */
+int hesic_eb_scatter_grads(const hesic_eb_layout* layout_host, const float* dtable, int C, int accumulate, void* stream);
+/* EntropyBottleneck.loss (entropy_models.py:345-348; newtrain1.py:94) forward + backward: loss[0] += sum |c(quantiles) -
+ * (-t, 0, t)|, t = ln(2 / tail_mass - 1), cumulative parameters detached; dquantiles (C,3) (+)= the gradient (may be NULL).
+ * params: the raw [C][64] table.                                                                                   */
+int hesic_eb_aux_loss(const float* params, const float* quantiles, float tail_mass, float* loss, float* dquantiles, int C,
+                      int accumulate, void* stream);
 
 /* ------------------------------------------------- GaussianMixtureConditional (row A9) / Gaussian (A11)
  * Replaces GaussianMixtureConditional.forward (entropy_models.py:661-702) and

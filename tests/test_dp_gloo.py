@@ -1,10 +1,11 @@
-"""Data-parallel plumbing on CPU: two gloo ranks, bucketed asynchronous gradient all-reduce
-(hesic_amd.train.GradBucketReducer) reproduces the single-process gradient of the concatenated batch,
-including parameters that receive no gradient on some rank and the "aux group after the aux backward" order."""
+"""Data-parallel plumbing on CPU, two gloo ranks: the in-place bucketed all-reduce over the flat gradient buffer
+(hesic_amd.train.FlatGroup / FlatReducer) and the Trainer's REAL two-optimiser order (zero -> forward -> main backward ->
+reduce main -> step -> aux backward -> reduce aux -> aux step, ywz/mywork/newtrain1.py:85-96) on a module that has an
+EntropyBottleneck-like aux group: tensors that get their gradient from the MAIN loss but are stepped by the aux optimiser
+after the aux loss added to them.  Both parameter groups must follow the single-process run on the concatenated batch."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -18,64 +19,126 @@ def _free_port():
     return p
 
 
-def _toy():
-    torch.manual_seed(0)
-    return torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
-                               torch.nn.Linear(32, 3))
+class _Bottleneck(torch.nn.Module):
+    """Stands in for EntropyBottleneck: `scale` takes part in the main loss only (like _matrices / _biases / _factors),
+    `quantiles` in the aux loss only; both belong to the aux optimiser."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.linspace(0.5, 1.5, 32))
+        self.quantiles = torch.nn.Parameter(torch.linspace(-1.0, 1.0, 32))
+
+    def forward(self, h):
+        return h * self.scale
+
+    def loss(self):
+        return (self.quantiles - 0.25).abs().sum()
 
 
-def _loss(net, x, y):
-    return ((net(x) - y) ** 2).mean()          # a MEAN over the local batch, like the R-D loss (newtrain1.py:45-52)
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.body = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh())
+        self.shared = torch.nn.Linear(32, 32)             # used twice per forward, like encoder1 (newnet1.py:726,754)
+        self.head = torch.nn.Linear(32, 3)
+        self.unused = torch.nn.Parameter(torch.ones(5))   # never touched by the loss
+        self.bottleneck = _Bottleneck()
+
+    def parameters(self, recurse=True):
+        for m in (self.body, self.shared, self.head):
+            yield from m.parameters()
+        yield self.unused
+
+    def aux_parameters(self):
+        yield from self.bottleneck.parameters()
+
+    def aux_loss(self):
+        return self.bottleneck.loss()
+
+    def forward(self, x):
+        h = self.bottleneck(self.body(x))
+        return self.head(self.shared(torch.tanh(self.shared(h))))
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+
+
+def _trainer(net, bucket_mb):
+    from hesic_amd.train import Trainer
+
+    class ToyTrainer(Trainer):
+        def _forward_loss(self, x, y, _h, noise):
+            return {"loss": ((self.model(x) - y) ** 2).mean()}        # a MEAN over the local batch, like the R-D loss (newtrain1.py:45-52)
+
+    return ToyTrainer(net, lr=1e-2, aux_lr=1e-1, bucket_mb=bucket_mb)
+
+
+def _run_steps(tr, X, Y, n=3):
+    trace = []
+    for _ in range(n):
+        c = tr.step(X, Y, None)
+        trace.append((float(c["loss"]), float(c["aux_loss"])))
+    return trace
 
 
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from hesic_amd.train import GradBucketReducer
-        net = _toy()
-        unused = torch.nn.Parameter(torch.ones(5))                 # never touched by the loss
-        params = list(net.parameters()) + [unused]
-        red = GradBucketReducer(params, bucket_mb=0.002)            # tiny buckets -> several collectives in flight
-        assert red.world == world and len(red.buckets) >= 3
-        g = torch.Generator().manual_seed(1)
-        X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
-        for it in range(2):                                         # two iterations: hook state must reset
-            for p in params:
-                p.grad = None
-            sl = slice(rank * 4, rank * 4 + 4)
-            _loss(net, X[sl], Y[sl]).backward()
-            red.finish()
-        ret[rank] = [p.grad.clone() if p.grad is not None else None for p in params]
+        net = _Toy()
+        tr = _trainer(net, bucket_mb=0.002)                           # tiny buckets -> several collectives in flight
+        assert tr.world == world and len(tr.main_reducer.buckets) >= 3 and len(tr.aux_reducer.buckets) >= 1
+        X, Y = _data()
+        sl = slice(rank * 4, rank * 4 + 4)
+        _run_steps(tr, X[sl], Y[sl])
+        # step 1 learned the write counts; steps 2, 3 launch buckets from the gradient hooks (overlap path)
+        assert tr.main_reducer._expected is not None and tr.main_reducer._expected[-1] == -1        # `unused` never gets a gradient
+        ret[rank] = {"main": [p.detach().clone() for p in net.parameters()], "aux": [p.detach().clone() for p in net.aux_parameters()],
+                     "flat_alias": all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(tr.main_group.params, tr.main_group.grad_views))}
     finally:
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_matches_single_process_gradient():
+def test_two_rank_trainer_matches_single_process_on_the_concatenated_batch():
     world, port = 2, _free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    net = _toy()
-    g = torch.Generator().manual_seed(1)
-    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
-    _loss(net, X, Y).backward()
-    ref = [p.grad for p in net.parameters()]
+    net = _Toy()
+    tr = _trainer(net, bucket_mb=25.0)
+    assert tr.world == 1
+    X, Y = _data()
+    _run_steps(tr, X, Y)
+    ref_main, ref_aux = [p.detach() for p in net.parameters()], [p.detach() for p in net.aux_parameters()]
     for rank in range(world):
         got = ret[rank]
-        assert got[-1] is None                                       # the unused parameter stays without gradient
-        for a, b in zip(got[:-1], ref):
-            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        assert got["flat_alias"]
+        for a, b in zip(got["main"], ref_main):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+        for a, b in zip(got["aux"], ref_aux):                           # scale: main-loss gradient, aux step; quantiles: aux gradient
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+    assert not torch.equal(ref_aux[0], torch.linspace(0.5, 1.5, 32)) and not torch.equal(ref_aux[1], torch.linspace(-1.0, 1.0, 32))
 
 
-def test_single_process_reducer_is_a_noop():
-    from hesic_amd.train import GradBucketReducer, init_distributed
-    net = _toy()
-    red = GradBucketReducer(net.parameters())
+def test_flat_group_keeps_values_and_aliases_gradients():
+    from hesic_amd.train import FlatGroup, FlatReducer, init_distributed
+    net = _Toy()
+    before = [p.detach().clone() for p in net.parameters()]
+    g = FlatGroup(net.parameters())
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, g.params))
+    assert all(o % FlatGroup.ALIGN == 0 for o in g.offsets) and g.flat_p.numel() == g.numel
+    X, Y = _data()
+    ((net(X) - Y) ** 2).mean().backward()
+    assert float(g.flat_g.abs().sum()) > 0 and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(g.params, g.grad_views))
+    for p in g.params:
+        p.grad = None                                                   # user code dropping the views ...
+    g.zero_grad()                                                       # ... is repaired by the next zero_grad
+    assert float(g.flat_g.abs().sum()) == 0 and all(p.grad is v for p, v in zip(g.params, g.grad_views))
+    red = FlatReducer(g)
     assert red.world == 1 and red.buckets == []
-    _loss(net, torch.randn(4, 6), torch.randn(4, 3)).backward()
-    before = [p.grad.clone() for p in net.parameters()]
-    red.finish()
-    assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
+    red.begin(); red.finish()                                           # single process: no-ops
     env = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK") if k in os.environ}
     try:
         assert init_distributed() == (0, 1, 0)

@@ -461,3 +461,102 @@ def test_rd_loss_gradient_follows_a_scaled_loss():
     for n in ("encoder1.g_a_conv1.weight", "decoder2.after_conv.bias", "_h_s2.gmm_means.4.weight", "entropy_bottleneck1._matrices.2"):
         ref = 0.25 * grads[0][n]          # two backward passes: atomics settle in a different order, elements near zero move by ~1e-7 of the scale
         torch.testing.assert_close(grads[1][n], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+def _noise_hsic(tag, B, size):
+    zs, ys = (B, 128, size // 64, size // 64), (B, 192, size // 16, size // 16)
+    return {k: synthetic._uniform(f"{tag}.{k}", zs if k[0] == "z" else ys, -0.5, 0.5).to(DEV) for k in ("z1", "y1", "y1w", "z2", "y2")}
+
+
+def test_trainer_step_equals_the_average_of_split_batch_gradients():
+    """SURVEY 8e on one GPU: the gradient of a batch of 4 equals the mean of the gradients of its two halves (what two DP
+    ranks would all-reduce), so one Trainer step on the batch equals an Adam step on the averaged half-batch gradients --
+    through the flat gradient buffer the reducer works on."""
+    from hesic_amd import functional as Fn
+    from hesic_amd.train import Trainer
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 4, 64, 64))
+    noise = _noise_hsic("sb", 4, 64)
+    full = Trainer(build("hsic"), lr=1e-3, aux_lr=1e-2, lmbda=0.0067)
+    full.step(x1, x2, Hm, noise=noise)
+
+    half = Trainer(build("hsic"), lr=1e-3, aux_lr=1e-2, lmbda=0.0067)
+    half.model.train()
+    acc_main, acc_aux = torch.zeros_like(half.main_group.flat_g), torch.zeros_like(half.aux_group.flat_g)
+    for sl in (slice(0, 2), slice(2, 4)):
+        half.main_group.zero_grad(); half.aux_group.zero_grad()
+        out = half.model(x1[sl], x2[sl], Hm[sl], noise={k: v[sl] for k, v in noise.items()})
+        Fn.rd_loss(out, x1[sl], x2[sl], 0.0067)["loss"].backward()
+        acc_main += half.main_group.flat_g
+        acc_aux += half.aux_group.flat_g
+    half.main_group.flat_g.copy_(acc_main / 2)
+    half.optimizer.step()
+    half.aux_group.flat_g.copy_(acc_aux / 2)       # the EB tensors' main-loss gradient, averaged like the reducer would
+    for p in half.aux_group.params:
+        assert p.grad.data_ptr() >= half.aux_group.flat_g.data_ptr()
+    half.model.aux_loss().backward()                # + the (rank-independent) quantile gradient
+    half.aux_optimizer.step()
+    a, b = dict(full.model.named_parameters()), dict(half.model.named_parameters())
+    worst = max(float((a[k] - b[k]).abs().max()) for k in a)
+    # Adam moves an element by <= lr whatever the gradient; fp32 atomics order differs between a batch of 4 and 2 x 2
+    assert worst < 2.5e-4, worst
+    for k in ("encoder1.g_a_conv2.weight", "decoder2.after_conv.weight", "_h_s2.gmm_sigma.4.bias", "entropy_bottleneck1.quantiles", "entropy_bottleneck2._matrices.1"):
+        torch.testing.assert_close(a[k], b[k], rtol=0, atol=2.5e-4)
+
+
+def test_flat_gradients_match_autograd_accumulation():
+    """The in-place gradient path (finishing kernel adds into the flat slot, None to autograd) against the plain autograd
+    path (fresh tensors, AccumulateGrad) on the same model and batch: every parameter, incl. encoder1's twice-used weights."""
+    from hesic_amd import functional as Fn
+    from hesic_amd.train import FlatGroup
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(1, 2, 64, 64))
+    noise = _noise_hsic("fg", 2, 64)
+    grads = []
+    for flat in (False, True):
+        net = build("hsic")
+        net.train()
+        groups = [FlatGroup(list(net.parameters())), FlatGroup(list(net.aux_parameters()))] if flat else []
+        for g in groups:
+            g.zero_grad()
+        Fn.rd_loss(net(x1, x2, Hm, noise=noise), x1, x2, 0.0067)["loss"].backward()
+        if flat:
+            assert all(s.writes > 0 for g in groups for s, p in zip(g.slots, g.params))          # every gradient took the in-place path
+            assert dict(net.named_parameters())["encoder1.g_a_conv2.weight"].grad.data_ptr() == groups[0].grad_views[
+                [id(p) for p in groups[0].params].index(id(net.encoder1.g_a_conv2.weight))].data_ptr()
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        del groups
+    for n in grads[0]:
+        ref = grads[0][n]
+        torch.testing.assert_close(grads[1][n], ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max()) + 1e-9, msg=n)
+
+
+def test_graphed_trainer_with_rccl_collectives_inside_the_graph():
+    """A 1-rank nccl (= RCCL) process group on this box: the bucketed in-place all-reduces of the flat gradient are issued
+    (force_collectives) and captured into the step's HIP graph; replays follow the plain eager trainer."""
+    import torch.distributed as dist
+    from hesic_amd.train import GraphedTrainer, Trainer
+    import hesic_amd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 2, 128, 128))
+        noise = _noise_hsic("rc", 2, 128)
+        traces = []
+        for cls, kw in ((Trainer, {}), (GraphedTrainer, {"warmup": 2, "force_collectives": True, "bucket_mb": 16.0})):
+            from hesic_amd import models
+            net = models.HSIC()
+            synthetic.fill_state_dict_(net.state_dict())
+            tr = cls(net.cuda(), lr=1e-4, aux_lr=1e-3, lmbda=0.0067, **kw)
+            traces.append([[float(v) for v in tr.step(x1, x2, Hm, noise=noise).values()] for _ in range(5)])
+        assert tr.graph is not None and tr.main_reducer.active and len(tr.main_reducer.buckets) >= 4
+        for a, b in zip(*traces):
+            for u, v in zip(a, b):
+                assert u == pytest.approx(v, rel=2e-3), traces
+    finally:
+        hesic_amd.set_compute_dtype(prev)
+        if created:
+            dist.destroy_process_group()
