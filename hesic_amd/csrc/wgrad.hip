@@ -671,7 +671,12 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinishArgs f, c
         if (in) {
             const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co * f.Cin + ci;
             int k = 0;
-            for (; k + 3 < f.nsplit; k += 4) {           // fixed order (s0 + s1) + (s2 + s3): deterministic
+            for (; k + 7 < f.nsplit; k += 8) {           // eight loads in flight per lane; fixed order: deterministic
+                const float a0 = src[(int64_t)k * n], a1 = src[(int64_t)(k + 1) * n], a2 = src[(int64_t)(k + 2) * n], a3 = src[(int64_t)(k + 3) * n];
+                const float a4 = src[(int64_t)(k + 4) * n], a5 = src[(int64_t)(k + 5) * n], a6 = src[(int64_t)(k + 6) * n], a7 = src[(int64_t)(k + 7) * n];
+                s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+            }
+            for (; k + 3 < f.nsplit; k += 4) {
                 s0 += src[(int64_t)k * n]; s1 += src[(int64_t)(k + 1) * n]; s2 += src[(int64_t)(k + 2) * n]; s3 += src[(int64_t)(k + 3) * n];
             }
             for (; k < f.nsplit; ++k) s0 += src[(int64_t)k * n];

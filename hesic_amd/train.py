@@ -72,7 +72,6 @@ class MultiTensorAdam(torch.optim.Adam):
             # packed-weight / GDN / bottleneck caches (keyed on those counters) that the parameters moved
             if ps:
                 torch.autograd.graph.increment_version(ps)
-        Fn.invalidate_weight_cache()
         return loss
 
 
@@ -156,8 +155,9 @@ class FlatAdam:
         c.step[0], c.numel[0] = self.step_count.data_ptr(), g.numel
         c.n, c.lr, c.beta1, c.beta2, c.eps = 1, float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps
         L.call("hesic_adam_step", C.byref(c), L.stream())
+        # the kernel writes through raw pointers: bump the version counters (like any in-place optimiser) -- every cache of
+        # packed weights / GDN parameters / bottleneck tables is keyed on them
         torch.autograd.graph.increment_version(g.params)
-        Fn.invalidate_weight_cache()
 
     def state_dict(self):
         m, v = self.group.view_like_params(self.exp_avg), self.group.view_like_params(self.exp_avg_sq)
@@ -298,9 +298,8 @@ class Trainer:
             Fn.SCALED_LOSS = scaled
         self.main_reducer.finish()
         self.optimizer.step()
-        Fn.invalidate_weight_cache()              # new epoch for every cache keyed on the parameters
         if self.on_gpu:
-            Fn.repack_all()
+            Fn.repack_all()                       # every packed conv weight of the step refreshed (and re-tagged) in ONE launch
         aux = self.model.aux_loss()
         aux.backward()
         self.aux_reducer.finish()
