@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0              # HBM3E spec (the guide's measured copy ceiling is 6.29 TB/s)
 HESIC_GFLOP_PER_PAIR_512 = 155.66
 
 
@@ -50,11 +51,33 @@ class KernelMeter:
     hesic_conv2d_variant names the instantiation the library picked."""
     NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward")
 
+    STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
+              "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)"}
+
     def __init__(self, L):
-        self.L, self.orig, self.rec = L, L.call, []
+        self.L, self.orig, self.rec, self.stream = L, L.call, [], {}
+
+    def _stream_bytes(self, name, d):
+        """ALGORITHMIC HBM bytes of one launch: every input element read once, every output element written once."""
+        size = lambda dt: 2 if dt == self.L.BF16 else 4
+        if name == "hesic_warp_perspective_forward":
+            return d.B * d.C * (d.H * d.W * size(d.src_dtype) + d.Ho * d.Wo * size(d.dst_dtype))
+        if name == "hesic_sconv2d_forward" and not (d.transposed and d.Cin >= 32):
+            return None                       # only the 128 -> 3 synthesis output stage is priced here
+        return d.B * (d.H * d.W * d.Cin * size(d.x_dtype) + d.Ho * d.Wo * d.Cout * size(d.y_dtype))
 
     def __enter__(self):
         def call(name, *args):
+            if name in self.STREAM:
+                nbytes = self._stream_bytes(name, args[0]._obj)
+                if nbytes is None:
+                    return self.orig(name, *args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = self.orig(name, *args)
+                e1.record()
+                self.stream.setdefault(self.STREAM[name], []).append((e0, e1, nbytes))
+                return rc
             if name not in self.NAMES:
                 return self.orig(name, *args)
             d = args[0]._obj
@@ -95,6 +118,13 @@ class KernelMeter:
         if not agg:
             return None
         name, (n, t, f) = max(agg.items(), key=lambda kv: kv[1][1])
+        streaming = {}
+        for k, recs in self.stream.items():
+            ts = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
+            by = sum(r[2] for r in recs)
+            streaming[k] = {"bound": "hbm", "achieved": round(by / ts / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / ts / 1e9 / HBM_PEAK_GBS, 4),
+                            "launches": len(recs), "avg_launch_us": round(1e6 * ts / len(recs), 2), "bytes_per_launch": int(by / len(recs))}
+        self.streaming = streaming
         return {"kernel": name, "launches": n, "avg_us": 1e6 * t / n, "tflops": f / t / 1e12, "flops_per_launch": f / n,
                 "all": {k: {"launches": v[0], "avg_us": round(1e6 * v[1] / v[0], 2), "tflops": round(v[2] / v[1] / 1e12, 1)}
                         for k, v in agg.items()}}
@@ -212,6 +242,77 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
                       f"over 8/16/32/64 of {cores} host cores"}, m
 
 
+SWEEP_LAMBDAS = (0.0018, 0.0035, 0.0067, 0.0130)       # SURVEY 8d config C5; lambda only names the (independently trained) model
+
+
+def sweep_main(args, batch, rank, world, dev, H_img, W_img):
+    """--sweep: BASELINE config C5.  Four lambda-models (four independent weight sets; there are no trained checkpoints
+    offline, so four deterministic synthetic fills), InStereo2K-size pairs zero-padded to x64, reconstructions cropped, bpp
+    over the original pixels.  Every rank evaluates one (model, batch) unit per step; the model index rotates over ranks
+    and steps, so all four are exercised on any N.  No collective on the path; per-lambda sums are reduced once at the end."""
+    import torch.distributed as dist
+    from hesic_amd import models, synthetic
+    x1, x2, x1p, x2p, Hm = batch
+    nets = []
+    for m in range(4):
+        net = (models.HSIC if args.model == "hsic" else models.HSICJoint)()
+        synthetic.fill_state_dict_(net.state_dict(), salt=m)
+        nets.append(net.to(dev).eval())
+    acc = torch.zeros((4, 4), dtype=torch.float64, device=dev)        # per model: bits, sse1, sse2, pairs
+
+    def step(k, record):
+        m = (rank + k) % 4
+        with torch.no_grad():
+            out = nets[m](x1p, x2p, Hm)
+            rd = models.rate_distortion(out, x1, x2)
+        if record:
+            bits = sum(v for kk, v in rd.items() if kk.startswith("bits_"))
+            acc[m, 0:1] += bits
+            acc[m, 1:2] += rd["sse1"]
+            acc[m, 2:3] += rd["sse2"]
+            acc[m, 3] += x1.shape[0]
+        return rd
+
+    for k in range(max(args.warmup, 4)):           # every model packs its weights before the timed region
+        step(k, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        dist.all_reduce(acc)
+    if rank == 0:
+        pairs = world * args.batch * args.steps
+        per = {}
+        for m, lam in enumerate(SWEEP_LAMBDAS):
+            bits, s1, s2, n = (float(v) for v in acc[m])
+            if n > 0:
+                npx = n * H_img * W_img
+                p1, p2 = 10 * math.log10(npx * 3 / s1), 10 * math.log10(npx * 3 / s2)
+                per[str(lam)] = {"pairs": int(n), "bpp": round(bits / npx / 2, 5), "psnr": round((p1 + p2) / 2, 4)}
+        print(json.dumps({
+            "metric": "stereo-pairs/sec encode+decode @512x512; bpp & PSNR delta vs reference",
+            "value": round(pairs / elapsed, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE config C5: {'HESIC' if args.model == 'hsic' else 'HESIC+'} rate-distortion sweep, 4 lambda-models x "
+                                   f"{H_img}x{W_img} pairs (zero-padded to {x1p.shape[-2]}x{x1p.shape[-1]}, bpp over the original pixels), batch {args.batch}/GPU",
+                       "pairs_per_step": world * args.batch, "sharding": f"one (lambda-model, batch) unit per rank and step over {world} GPU(s), no collective on the path",
+                       "lambdas": list(SWEEP_LAMBDAS)},
+            "per_lambda": per, "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
     """--mode train: see the module docstring.  Timed region = ``steps`` calls of ``Trainer.step`` on resident inputs."""
     import torch.distributed as dist
@@ -310,14 +411,22 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer", help="train: BASELINE config C3 (R-D training step, DP gradient all-reduce)")
     ap.add_argument("--eager", action="store_true", help="train mode: issue the step from Python instead of replaying the HIP graph")
     ap.add_argument("--lmbda", type=float, default=0.0067)
+    ap.add_argument("--sweep", action="store_true", help="BASELINE config C5: 4 lambda-models x pairs at --height/--width (default 860x1080), "
+                    "one (model, batch) unit per rank and step, models rotating over ranks and steps")
+    ap.add_argument("--warp-align-corners", type=int, choices=[0, 1], default=None,
+                    help="0: kornia <= 0.4 sampling (what torch-1.6-era checkpoints were trained with), 1: kornia >= 0.5 (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (models.GraphedForward) instead of issuing it eagerly")
     args = ap.parse_args()
 
     import hesic_amd
-    from hesic_amd import functional as Fn, models, synthetic
+    from hesic_amd import functional as Fn, geometry, models, synthetic
     from hesic_amd.train import init_distributed
     import torch.distributed as dist
+    if args.warp_align_corners is not None:
+        geometry.DEFAULT_ALIGN_CORNERS = bool(args.warp_align_corners)
+    if args.sweep and not (args.height or args.width):
+        args.height, args.width = 860, 1080
 
     rank, world, local = init_distributed()
     if world != args.gpus:
@@ -344,6 +453,8 @@ def main():
 
     if args.mode == "train":
         return train_main(args, net, P_cpu, (x1p, x2p, Hm), rank, world, dev, H_img, W_img)
+    if args.sweep:
+        return sweep_main(args, (x1, x2, x1p, x2p, Hm), rank, world, dev, H_img, W_img)
 
     def step():
         with torch.no_grad():
@@ -398,7 +509,9 @@ def main():
         roof = {"kernel": s["kernel"], "bound": "mfma",
                 "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
                 "traffic": traffic, "launches_per_step": s["launches"] // 3, "avg_launch_us": round(s["avg_us"], 2),
-                "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3), "other_conv_kernels": s["all"]}
+                "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3), "other_conv_kernels": s["all"],
+                # the HBM-bound kernels of the path against the 8 TB/s peak (north_star: "achieved HBM GB/s for the warp")
+                "streaming_kernels": km.streaming}
 
     if rank == 0:
         pairs = world * args.batch * args.steps

@@ -47,6 +47,7 @@ struct IgemmArgs {
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
+    int dbg;                   // profiling ablations (HESIC_IGEMM_DBG, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMAs
     float* y32;                // bf16 fast path: also (or, with y == nullptr, only) store act(conv + bias) as fp32 straight from the
     int y32_ps, y32_co;        //      accumulators -- what feeds round() and the likelihoods must not pass through bf16 storage
 };
@@ -341,9 +342,20 @@ constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { retur
 // NW = waves per block: 4 (2x2 wave grid, 64x64 wave tiles).  NW = 8 (4x2 grid, 32 couts x 64 pixels per wave: twice the
 // waves per SIMD, 1.5 fragment reads per MFMA) compiles and is correct but measured EQUAL on every layer (the loop is not
 // limited by per-wave latency), so only NW = 4 is instantiated.
-template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4>
-__global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
-    constexpr int NTHREADS = NW * 64;
+// WS = 1 ("wave-specialised", A/B switch HESIC_IGEMM_WS=1, NOT the default): the block carries NW extra LOADER waves (one per
+// SIMD, next to a compute wave).  The compute waves run nothing but fragment reads + MFMAs + one barrier per stage; all
+// LDS-DMA issue, its address bookkeeping and the vmcnt waits live in the loaders (one block per CU, NS = 3 stages of 32 KB).
+// This is the per-SIMD ping-pong pairing of MI355X_MICROARCH.md ("two waves per SIMD") in its cleanest form.  Measured
+// (round 2, conv 128 -> 128 5x5 s2 @256^2 B=8 + GDN, same box, back to back): 144.0 us against 143.8 us for the self-loading
+// form at two blocks per CU -- no gain, and the ablations (HESIC_IGEMM_DBG) say why: with the DMA removed the self-loading
+// form runs at 84 us, with the MFMAs removed at 86 us, with both removed at 33 us (loop + barriers + GDN epilogue): the
+// matrix phase (~58 us) and the LDS-fill phase (~60 us) ADD instead of overlapping, and the fill alone costs 39 us even from
+// an L1-resident source (DBG=14 vs 6: 53 us from L2) -- 1.64 GB through the ~64 B/clk/CU global->LDS path, which a 128 x 128
+// tile needs at 62.5 B/clk/CU to feed the matrix cores at peak.  The bound is the tile's arithmetic intensity against that
+// path (and against L2: 33 TB/s), not issue scheduling; only a larger (cout x pixel) tile moves it.
+template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS = 0>
+__global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
+    constexpr int NTHREADS = NW * 64;          // COMPUTE threads (the epilogue's copy loops stride by this)
     using T = bf16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
     constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
+    static_assert(!WS || (BMP == 128 && BN == 128 && NW == 4), "the wave-specialised form is built for the 128 x 128 tile");
     static_assert(GDN == 0 || BN == 128, "fused GDN needs every channel of a pixel in the block");
     constexpr int YOFF = BM * 256;                            // fused GDN: squared tile at 0, output tile behind it
     constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
@@ -363,6 +376,8 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA bases go to M0
+    const bool loader = WS && wave >= NW;      // wave-uniform
+    const int lw = WS ? (wave >= NW ? wave - NW : wave) : wave;     // index among the waves that issue the DMA
     int bid;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     int iy0[XI], ix0[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int row = (wave * XI + i) * (64 / CPR) + prow;
+        const int row = (lw * XI + i) * (64 / CPR) + prow;
         const int ls = pslot ^ ((row / RPB) & (CPR - 1));
         const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
         const bool ok = qy < a.QH && qx < a.QW;
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int row = (wave * WI + i) * (64 / CPR) + prow;
+        const int row = (lw * WI + i) * (64 / CPR) + prow;
         const int ls = pslot ^ ((row / RPB) & (CPR - 1));
         wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2) : OOB;
     }
@@ -477,16 +492,24 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
         set_tap();
     };
     auto issue = [&](int buf) {
-        const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+        if (a.dbg & 1) return;
+        uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+        if (a.dbg & 8) {          // every piece re-reads the first kilobytes of its tensor: L1-resident source, same LDS traffic
+            sx = (uint32_t)(neg * 2); sw = 0;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xv[i] = (xoff[i] & 0xff0u);
+#pragma unroll
+            for (int i = 0; i < WI; ++i) wv[i] &= 0xff0u;
+        }
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
 #pragma unroll
         for (int i = 0; i < XI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (lw * XI + i) * 1024),
                                                      16, (int)xv[i], (int)sx, 0, 0);
 #pragma unroll
         for (int i = 0; i < WI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (lw * WI + i) * 1024),
                                                      16, (int)wv[i], (int)sw, 0, 0);
         if (++cur_chunk == kchunks) {
             cur_chunk = 0;
@@ -497,23 +520,48 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
     // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
     // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
+    if constexpr (WS) {
+        if (loader) {
+            // ---- loader wave: stage s+NS-1 is requested right behind the barrier that opens stage s (every compute wave has then
+            // finished reading the buffer it goes to: stage s-1's fragments were consumed by MFMAs issued before that barrier); a
+            // stage is announced (barrier) only after this wave's pieces of it have landed (counted vmcnt, never a drain)
+            static_assert(!WS || NS >= 3, "the loaders need a stage in flight beside the one being computed");
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nsteps) issue(s);
+            int nxt = NS - 1;
+            for (int step = 0; step < nsteps; ++step) {
+                const int rem = nsteps - 1 - step;
+                wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+                __builtin_amdgcn_s_barrier();
+                if (step + NS - 1 < nsteps) issue(nxt);
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            }
+            return;           // the epilogue's barriers only count the waves that are still alive
+        }
+    }
     auto main_loop = [&](auto abs_tag) {
         constexpr bool ABS = decltype(abs_tag)::value;
         constexpr int KS = BK / 16;
+        if constexpr (!WS) {
 #pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (s < nsteps) issue(s);
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nsteps) issue(s);
+        }
         int buf = 0, nxt = NS - 1;
         for (int step = 0; step < nsteps; ++step) {
             const int rem = nsteps - 1 - step;
-            if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
-            else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+            if constexpr (!WS) {
+                if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
+                else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
+            }
             __builtin_amdgcn_s_barrier();
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XT;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             bf16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
+                if (a.dbg & 2) return;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
@@ -521,8 +569,10 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (step + NS - 1 < nsteps) issue(nxt);
-            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            if constexpr (!WS) {
+                if (step + NS - 1 < nsteps) issue(nxt);
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
@@ -535,11 +585,13 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
                         xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
                     }
                 }
+                if (!(a.dbg & 4)) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -998,6 +1050,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre;
     a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
+    static const int dbg = getenv("HESIC_IGEMM_DBG") ? atoi(getenv("HESIC_IGEMM_DBG")) : 0;
+    a.dbg = dbg;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
@@ -1114,7 +1168,13 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
-        if (bm == 128) {
+        static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
+        if (bm == 128 && bk == 64 && BN == 128 && ws_mode && ksplit == 1) {
+            const dim3 block_ws(2 * NTHREADS);
+            if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
+            else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
+            else hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 0, 4, 1>), grid, block_ws, 0, st, a);
+        } else if (bm == 128) {
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }
         } else if (bm == 64) {

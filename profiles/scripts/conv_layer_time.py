@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""One layer of the analysis / synthesis stacks on the implicit-GEMM kernel, timed with HIP events.
+
+    python profiles/scripts/conv_layer_time.py [--layer conv2|deconv3|conv3|plain] [--batch 8] [--size 256]
+Environment A/B switches of csrc/conv_igemm.hip apply (HESIC_IGEMM_WS, HESIC_IGEMM_DBG = ablations with garbage results)."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layer", default="conv2")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256, help="input height = width of the layer")
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+    import hesic_amd
+    from compressai.layers import GDN
+    from compressai.models.utils import conv, deconv
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    B, S = args.batch, args.size
+    x = (torch.randn(B, 128, S, S, device="cuda") * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if args.layer in ("conv2", "conv3", "plain"):
+        layer, g = conv(128, 128).cuda(), GDN(128).cuda()
+        flops = 2.0 * B * (S // 2) ** 2 * 128 * 128 * 25 + (0 if args.layer == "plain" else 2.0 * B * (S // 2) ** 2 * 128 * 128)
+    else:
+        layer, g = deconv(128, 128).cuda(), GDN(128, inverse=True).cuda()
+        flops = 2.0 * B * S * S * 128 * 128 * 25 + 2.0 * B * (2 * S) ** 2 * 128 * 128
+    f = (lambda: layer.run(x)) if args.layer == "plain" else (lambda: layer.run_gdn(x, g))
+    with torch.no_grad():
+        for _ in range(5):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / args.iters * 1e3
+    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   WS={os.environ.get('HESIC_IGEMM_WS', '0')} DBG={os.environ.get('HESIC_IGEMM_DBG', '0')}")
+
+
+if __name__ == "__main__":
+    main()

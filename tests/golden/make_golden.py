@@ -416,6 +416,60 @@ def fx_models(newnet1, newnet1_joint):
                     f.write(f"{k} {' '.join(map(str, shapes[k]))}\n")
 
 
+def fx_models_r2(newnet1, newnet1_joint):
+    """Round 2: (a) a NON-SQUARE eval forward (256 x 320, the class of BASELINE config C5's 896 x 1088) under BOTH warp
+    conventions -- align_corners=True (kornia >= 0.5) and the legacy align_corners=False sampling of the kornia 0.4.x era
+    the reference's pinned torch 1.6.0 implies (Readme.md:11,16); (b) the 2-step Adam trace of row T at 256 x 256."""
+    import math
+    from compressai.entropy_models import EntropyModel
+    nq = NoiseQueue()
+    EntropyModel._get_noise_cached = lambda self, x: nq(self, x)
+    for tag, mod in (("hsic", newnet1), ("joint", newnet1_joint)):
+        torch.manual_seed(0)
+        net = mod.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net.eval()
+        x1, x2, Hm = synthetic.stereo_batch(0, 1, 256, 320)
+        for ac in (True, False):
+            KORNIA_ALIGN["align_corners"] = ac
+            with torch.no_grad():
+                out = net(x1, x2, Hm)
+            bits = {k: float(torch.log(v.double()).sum() / -math.log(2)) for k, v in out["likelihoods"].items()}
+            mse1 = float(((out["x1_hat"].double() - x1.double()) ** 2).mean())
+            mse2 = float(((out["x2_hat"].double() - x2.double()) ** 2).mean())
+            npz(f"{tag}_256x320{'' if ac else '_ac0'}.npz", H=Hm, bits_y1=bits["y1"], bits_y2=bits["y2"], bits_z1=bits["z1"], bits_z2=bits["z2"],
+                mse1=mse1, mse2=mse2, y1_hat=out["y1_hat"].to(torch.int16), y2_hat=out["y2_hat"].to(torch.int16),
+                x2_hat_pool=F.avg_pool2d(out["x2_hat"], 8))
+            print(tag, "256x320 align_corners", ac, "bpp_loss", sum(bits.values()) / (256 * 320), "mse", mse1, mse2)
+        KORNIA_ALIGN["align_corners"] = True
+
+        net.train()
+        x1, x2, Hm = synthetic.stereo_batch(0, 1, 256, 256)
+        order = ["z1", "y1", "y1w", "z2", "y2"] if tag == "hsic" else ["z1", "y1", "y1b", "z2", "y1w", "y2", "y2b"]
+        shapes_n = {k: ((128, 1, 16) if k[0] == "z" else (1, 192, 16, 16)) for k in order}
+        lam = 0.0067
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        aux_opt = torch.optim.Adam(net.aux_parameters(), lr=1e-3)
+        trace = []
+        for step in range(2):
+            nq.items = [det_noise(f"{tag}.t256.{step}.{k}", shapes_n[k]) for k in order]
+            opt.zero_grad()
+            aux_opt.zero_grad()
+            out = net(x1, x2, Hm)
+            npix = 256 * 256
+            bpp = sum(torch.log(l).sum() / (-math.log(2) * npix) for l in out["likelihoods"].values())
+            mse = F.mse_loss(out["x1_hat"], x1) + F.mse_loss(out["x2_hat"], x2)
+            loss = lam * 255 ** 2 * mse + bpp
+            loss.backward()
+            opt.step()
+            aux = net.aux_loss()
+            aux.backward()
+            aux_opt.step()
+            trace.append([float(loss), float(bpp), float(mse), float(aux)])
+        npz(f"{tag}_train256.npz", trace=np.array(trace), noise_order=np.array(order))
+        print(tag, "train256 trace", trace)
+
+
 def fx_enhance(newnet1):
     """Independent_EN (cross-view enhancement, newnet1.py:272-311,1278-1300)."""
     net = newnet1.Independent_EN().eval()
@@ -484,7 +538,7 @@ def fx_codec():
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "codec", "enhance", "homo"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "enhance", "homo"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
@@ -497,6 +551,8 @@ def main():
         fx_homo()
     if "models" in which:
         fx_models(newnet1, newnet1_joint)
+    if "models2" in which:
+        fx_models_r2(newnet1, newnet1_joint)
 
 
 if __name__ == "__main__":

@@ -560,3 +560,79 @@ def test_graphed_trainer_with_rccl_collectives_inside_the_graph():
         hesic_amd.set_compute_dtype(prev)
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+@pytest.mark.parametrize("align", [True, False], ids=["ac1", "ac0"])
+def test_forward_non_square_both_warp_conventions(kind, align):
+    """256 x 320 against the reference golden generated with the matching kornia convention (geometry.DEFAULT_ALIGN_CORNERS:
+    True = kornia >= 0.5, False = the 0.4.x sampling torch-1.6-era checkpoints were trained with)."""
+    from hesic_amd import geometry, models
+    g = load_golden(f"{kind}_256x320{'' if align else '_ac0'}.npz")
+    net = build(kind)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 1, 256, 320))
+    keep = geometry.DEFAULT_ALIGN_CORNERS
+    geometry.DEFAULT_ALIGN_CORNERS = align
+    try:
+        with torch.no_grad():
+            out = net(x1, x2, Hm)
+            m = models.metrics_from(models.rate_distortion(out, x1, x2))
+    finally:
+        geometry.DEFAULT_ALIGN_CORNERS = keep
+    assert out["x1_hat"].shape == (1, 3, 256, 320) and out["y1_hat"].shape == (1, 192, 16, 20)
+    for k in ("y1_hat", "y2_hat"):
+        assert float((out[k].cpu().to(torch.int16) != T(g[k])).float().mean()) < 2e-4, k
+    for k in ("y1", "y2", "z1", "z2"):
+        assert m["bits"][k] == pytest.approx(float(g["bits_" + k]), rel=1e-3), k
+    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=1e-3) and m["mse2"] == pytest.approx(float(g["mse2"]), rel=1e-3)
+    torch.testing.assert_close(torch.nn.functional.avg_pool2d(out["x2_hat"].cpu(), 8), T(g["x2_hat_pool"]), rtol=2e-3, atol=3e-3)
+
+
+def test_c5_860x1080_padded_matches_the_oracle():
+    """BASELINE config C5: an InStereo2K-size 860 x 1080 pair.  The hyper path needs multiples of 64 (the reference raises on
+    860 x 1080): pad to 896 x 1088 (zeros, bottom / right; pixel coordinates -- hence the homography -- unchanged),
+    run, crop the reconstructions, bpp over the ORIGINAL pixel count.  Checked against the CPU oracle on the same padded input."""
+    from hesic_amd import models
+    from oracle import hesic_oracle as O
+    net = build("hsic")
+    P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 860, 1080)
+    x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)
+    assert x1p.shape[-2:] == (896, 1088) and torch.equal(x1p[..., :860, :1080], x1) and float(x1p[..., 860:, :].abs().max()) == 0
+    with torch.no_grad():
+        out = net(x1p.to(DEV), x2p.to(DEV), Hm.to(DEV))
+        m = models.metrics_from(models.rate_distortion(out, x1.to(DEV), x2.to(DEV)))       # crops to 860 x 1080, bpp over 860*1080
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        ref = O.hsic_forward(P, x1p, x2p, Hm)
+    for k in ("y1_hat", "y2_hat"):
+        assert float((out[k].cpu() != ref[k]).float().mean()) < 2e-4, k
+    ref_crop = {"x1_hat": ref["x1_hat"][..., :860, :1080], "x2_hat": ref["x2_hat"][..., :860, :1080], "likelihoods": ref["likelihoods"]}
+    mr = O.metrics(ref_crop, x1, x2)
+    assert out["y1_hat"].shape == (1, 192, 56, 68)
+    assert m["bpp"] == pytest.approx(mr["bpp"], rel=1e-3) and abs(m["psnr"] - mr["psnr"]) < 1e-3
+    assert m["bpp"] == pytest.approx(sum(mr["bits"].values()) / (860 * 1080) / 2, rel=1e-3)     # over the original pixels
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_train_trace_256_matches_reference(kind):
+    """Row T at 256 x 256 (SURVEY 8a asked for 64 AND 256): two optimiser steps with injected noise against the reference's
+    (loss, bpp, mse, aux) trace."""
+    from hesic_amd.train import Trainer
+    g = load_golden(f"{kind}_train256.npz")
+    net = build(kind)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 1, 256, 256))
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.0067)
+    trace = []
+    for step in range(2):
+        noise = {}
+        for k in (str(s) for s in g["noise_order"]):
+            if k[0] == "z":      # reference layout (C, 1, H*W*B), B fastest -> (B, C, H, W)
+                nz = synthetic._uniform(f"noise.{kind}.t256.{step}.{k}", (128, 1, 16), -0.5, 0.5).reshape(128, 4, 4, 1).permute(3, 0, 1, 2).contiguous()
+            else:
+                nz = synthetic._uniform(f"noise.{kind}.t256.{step}.{k}", (1, 192, 16, 16), -0.5, 0.5)
+            noise[k] = nz.to(DEV)
+        c = tr.step(x1, x2, Hm, noise=noise)
+        trace.append([float(c["loss"]), float(c["bpp_loss"]), float(c["mse_loss"]), float(c["aux_loss"])])
+    for s in range(2):
+        for j, nm in enumerate(("loss", "bpp", "mse", "aux")):
+            assert trace[s][j] == pytest.approx(float(g["trace"][s][j]), rel=5e-3), (s, nm, trace, g["trace"])

@@ -203,6 +203,28 @@ def test_whole_model_forward(kind, size, batch):
         close(out["likelihoods"]["z1"], g["lik_z1"], 1e-3, 1e-8)
 
 
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+@pytest.mark.parametrize("align", [True, False], ids=["ac1", "ac0"])
+def test_whole_model_forward_non_square_both_warp_conventions(kind, align):
+    """Round 2: 256 x 320 (the class of BASELINE config C5's padded 896 x 1088) under align_corners=True (kornia >= 0.5) and
+    the legacy align_corners=False sampling (kornia 0.4.x, what the reference's pinned torch 1.6.0 era implies): the oracle's
+    warp restatement inside the whole model against the reference run with the matching convention."""
+    g = load_golden(f"{kind}_256x320{'' if align else '_ac0'}.npz")
+    P = _model_params(kind)
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 256, 320)
+    with torch.no_grad():
+        out = (O.hsic_forward if kind == "hsic" else O.hsic_joint_forward)(P, x1, x2, Hm, align_corners=align)
+    m = O.metrics(out, x1, x2)
+    for k in ("y1_hat", "y2_hat"):
+        assert float((out[k].to(torch.int16) != T(g[k])).float().mean()) < 2e-4, k
+    for k in ("y1", "y2", "z1", "z2"):
+        assert m["bits"][k] == pytest.approx(float(g["bits_" + k]), rel=1e-3)
+    assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=1e-3) and m["mse2"] == pytest.approx(float(g["mse2"]), rel=1e-3)
+    if not align:       # the two conventions really differ on this input (view 2 sees the warped view 1)
+        g1 = load_golden(f"{kind}_256x320.npz")
+        assert abs(float(g1["bits_y2"]) - float(g["bits_y2"])) > 1e-4 * float(g["bits_y2"])
+
+
 def _en_params():
     import os
     from conftest import GOLDEN
