@@ -1,0 +1,79 @@
+"""The stereo ``ImageFolder`` (reference: compressai/datasets/utils.py:68-214) on a synthetic left/right folder:
+paired crops, the crop-frame homography from a full-frame sidecar, the HomographyNet windows, the item layouts."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from hesic_amd import synthetic
+
+
+def _write_pairs(root, n=3, H=192, W=256, with_h=True, split="train"):
+    from PIL import Image
+    x1, x2, Hm = synthetic.stereo_batch(0, n, H, W)
+    for side in ("left", "right"):
+        os.makedirs(os.path.join(root, split, side), exist_ok=True)
+    if with_h:
+        os.makedirs(os.path.join(root, split, "H"), exist_ok=True)
+    arrs = []
+    for i in range(n):
+        a = (x1[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+        b = (x2[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+        Image.fromarray(a).save(os.path.join(root, split, "left", f"{i:04d}.png"))
+        Image.fromarray(b).save(os.path.join(root, split, "right", f"{i:04d}.png"))
+        if with_h:
+            (np.save if i % 2 else np.savetxt)(os.path.join(root, split, "H", f"{i:04d}" + (".npy" if i % 2 else ".txt")), Hm[i].numpy())
+        arrs.append((a, b))
+    return arrs, Hm
+
+
+def test_paired_crops_crop_frame_homography_and_homonet_windows(tmp_path):
+    from compressai.datasets import ImageFolder, MEAN, STD, to_tensor
+    arrs, Hm = _write_pairs(str(tmp_path))
+    ds = ImageFolder(str(tmp_path), transform=to_tensor, patch_size=(128, 160), split="train")
+    assert len(ds) == 3
+    for i in range(3):
+        random.seed(100 + i)
+        x1, x2, H, h1, h2, corners = ds[i]
+        random.seed(100 + i)                                       # the draws the item made, in its order
+        y0, x0 = random.randint(0, 192 - 128 - 1), random.randint(0, 256 - 160 - 1)
+        wx, wy = random.randint(45, 256 - 45 - 128), random.randint(45, 256 - 45 - 128)
+        a, b = arrs[i]
+        assert x1.shape == (3, 128, 160) and x1.dtype == torch.float32 and float(x1.max()) <= 1.0
+        np.testing.assert_array_equal((x1 * 255).round().byte().permute(1, 2, 0).numpy(), a[y0:y0 + 128, x0:x0 + 160])
+        np.testing.assert_array_equal((x2 * 255).round().byte().permute(1, 2, 0).numpy(), b[y0:y0 + 128, x0:x0 + 160])   # SAME offset
+        # crop-frame homography: a crop pixel p of the left view lands at H_full (p + t) - t in the right crop
+        p = np.array([37.0, 51.0, 1.0])
+        q_full = Hm[i].double().numpy() @ (p + np.array([x0, y0, 0.0]))
+        want = q_full[:2] / q_full[2] - np.array([x0, y0])
+        q = H.double().numpy() @ p
+        np.testing.assert_allclose(q[:2] / q[2], want, rtol=0, atol=1e-3)
+        assert H.dtype == torch.float32 and H.shape == (3, 3) and abs(float(H[2, 2]) - 1) < 1e-6
+        # HomographyNet windows: 128 x 128 of the normalised grey 256 x 256 resize, corners clockwise from the top-left
+        assert h1.shape == h2.shape == (1, 128, 128) and corners.tolist() == [[wx, wy], [wx + 128, wy], [wx + 128, wy + 128], [wx, wy + 128]]
+        full = torch.nn.functional.interpolate(x1.unsqueeze(0) * 255, size=(256, 256), mode="bilinear", align_corners=False)[0].round() / 255
+        grey = ((full - MEAN.view(1, 1, 1)) / STD.view(1, 1, 1)).mean(0, keepdim=True)
+        torch.testing.assert_close(h1, grey[:, wy:wy + 128, wx:wx + 128], rtol=0, atol=1e-5)
+
+
+def test_item_layouts_and_error_paths(tmp_path):
+    from compressai.datasets import ImageFolder, to_tensor
+    _write_pairs(str(tmp_path / "a"), n=2, with_h=False)
+    with pytest.raises(RuntimeError):
+        ImageFolder(str(tmp_path / "missing"))
+    no_h = ImageFolder(str(tmp_path / "a"), transform=to_tensor, patch_size=(64, 64))
+    assert len(no_h[0]) == 2                                          # no homography source: images only (as when RANSAC fails)
+    eye = ImageFolder(str(tmp_path / "a"), transform=to_tensor, patch_size=(64, 64), need_file_name=True,
+                      homography=lambda a, b: np.eye(3))
+    item = eye[1]
+    assert len(item) == 7 and item[3] == "0001.png" and torch.equal(item[2], torch.eye(3)) and item[6].shape == (4, 2)
+    raw = ImageFolder(str(tmp_path / "a"), patch_size=(192, 256), homography=lambda a, b: np.eye(3))[0]       # full height: no offset
+    assert isinstance(raw[0], np.ndarray) and raw[0].shape == (192, 256, 3) and raw[0].dtype == np.uint8
+    batch = next(iter(torch.utils.data.DataLoader(ImageFolder(str(tmp_path / "a"), transform=to_tensor, patch_size=(64, 64),
+                                                              homography=lambda a, b: np.eye(3)), batch_size=2)))
+    assert batch[0].shape == (2, 3, 64, 64) and batch[2].shape == (2, 3, 3) and batch[5].shape == (2, 4, 2)
+    os.rename(tmp_path / "a" / "train" / "right" / "0001.png", tmp_path / "a" / "train" / "right" / "0009.png")
+    with pytest.raises(ValueError, match="cannot compare pictures"):
+        ImageFolder(str(tmp_path / "a"), transform=to_tensor, patch_size=(64, 64))[1]
