@@ -470,37 +470,44 @@ def _noise_hsic(tag, B, size):
 
 def test_trainer_step_equals_the_average_of_split_batch_gradients():
     """SURVEY 8e on one GPU: the gradient of a batch of 4 equals the mean of the gradients of its two halves (what two DP
-    ranks would all-reduce), so one Trainer step on the batch equals an Adam step on the averaged half-batch gradients --
-    through the flat gradient buffer the reducer works on."""
+    ranks would all-reduce) -- compared on the flat gradient buffers the reducer works on, both optimiser groups -- and an
+    Adam step on the averaged buffers lands where ``Trainer.step`` on the whole batch does."""
     from hesic_amd import functional as Fn
     from hesic_amd.train import Trainer
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 4, 64, 64))
     noise = _noise_hsic("sb", 4, 64)
-    full = Trainer(build("hsic"), lr=1e-3, aux_lr=1e-2, lmbda=0.0067)
-    full.step(x1, x2, Hm, noise=noise)
+
+    def grads(tr, sl):
+        tr.model.train()
+        tr.main_group.zero_grad(); tr.aux_group.zero_grad()
+        out = tr.model(x1[sl], x2[sl], Hm[sl], noise={k: v[sl] for k, v in noise.items()})
+        Fn.rd_loss(out, x1[sl], x2[sl], 0.0067)["loss"].backward()
+        return tr.main_group.flat_g.clone(), tr.aux_group.flat_g.clone()
 
     half = Trainer(build("hsic"), lr=1e-3, aux_lr=1e-2, lmbda=0.0067)
-    half.model.train()
-    acc_main, acc_aux = torch.zeros_like(half.main_group.flat_g), torch.zeros_like(half.aux_group.flat_g)
-    for sl in (slice(0, 2), slice(2, 4)):
-        half.main_group.zero_grad(); half.aux_group.zero_grad()
-        out = half.model(x1[sl], x2[sl], Hm[sl], noise={k: v[sl] for k, v in noise.items()})
-        Fn.rd_loss(out, x1[sl], x2[sl], 0.0067)["loss"].backward()
-        acc_main += half.main_group.flat_g
-        acc_aux += half.aux_group.flat_g
-    half.main_group.flat_g.copy_(acc_main / 2)
+    gm_full, ga_full = grads(half, slice(0, 4))
+    (gm1, ga1), (gm2, ga2) = grads(half, slice(0, 2)), grads(half, slice(2, 4))
+    gm_avg, ga_avg = (gm1 + gm2) / 2, (ga1 + ga2) / 2
+    for views_full, views_avg, group in ((half.main_group.view_like_params(gm_full), half.main_group.view_like_params(gm_avg), half.main_group),
+                                          (half.aux_group.view_like_params(ga_full), half.aux_group.view_like_params(ga_avg), half.aux_group)):
+        for a, b in zip(views_full, views_avg):
+            scale = float(a.abs().max())
+            assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-9, (tuple(a.shape), scale)       # fp32 atomics order differs: 4 vs 2 + 2
+    # the update itself: Adam on the averaged buffers vs Trainer.step on the batch (an element moves by <= lr per step; where a ~0
+    # gradient changes sign between the two summation orders the two results differ by up to 2 lr)
+    half.main_group.flat_g.copy_(gm_avg)
     half.optimizer.step()
-    half.aux_group.flat_g.copy_(acc_aux / 2)       # the EB tensors' main-loss gradient, averaged like the reducer would
-    for p in half.aux_group.params:
-        assert p.grad.data_ptr() >= half.aux_group.flat_g.data_ptr()
+    half.aux_group.flat_g.copy_(ga_avg)
     half.model.aux_loss().backward()                # + the (rank-independent) quantile gradient
     half.aux_optimizer.step()
+    full = Trainer(build("hsic"), lr=1e-3, aux_lr=1e-2, lmbda=0.0067)
+    full.step(x1, x2, Hm, noise=noise)
     a, b = dict(full.model.named_parameters()), dict(half.model.named_parameters())
-    worst = max(float((a[k] - b[k]).abs().max()) for k in a)
-    # Adam moves an element by <= lr whatever the gradient; fp32 atomics order differs between a batch of 4 and 2 x 2
-    assert worst < 2.5e-4, worst
-    for k in ("encoder1.g_a_conv2.weight", "decoder2.after_conv.weight", "_h_s2.gmm_sigma.4.bias", "entropy_bottleneck1.quantiles", "entropy_bottleneck2._matrices.1"):
-        torch.testing.assert_close(a[k], b[k], rtol=0, atol=2.5e-4)
+    for k in a:
+        lr = 1e-2 if k.startswith("entropy_bottleneck") else 1e-3
+        diff = (a[k].detach() - b[k].detach()).abs()
+        assert float(diff.max()) <= 2.1 * lr, k
+        assert float((diff > 0.2 * lr).float().mean()) < 0.02, k          # ... and that is rare
 
 
 def test_flat_gradients_match_autograd_accumulation():
