@@ -49,7 +49,7 @@ class KernelMeter:
     """One HIP event pair around every implicit-GEMM launch (hesic_conv2d_forward[_ws|_f32out] / hesic_conv2d_gdn_forward),
     recorded on the stream the kernel is launched on; the launch descriptor gives the algorithmic FLOPs and
     hesic_conv2d_variant names the instantiation the library picked."""
-    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward")
+    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward", "hesic_conv2d_forward_grouped")
 
     STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
               "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)"}
@@ -90,7 +90,7 @@ class KernelMeter:
             fused = name.endswith("gdn_forward")
             if fused:
                 fl += 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cout          # the GDN 1x1 contraction (SURVEY 8d counts it)
-            self.rec.append((e0, e1, fl, self.variant(d, fused)))
+            self.rec.append((e0, e1, fl, self.variant(d, fused) + (" grouped" if name.endswith("grouped") else "")))
             return rc
         self.L.call = call
         return self

@@ -121,6 +121,8 @@ _SIGS = {
     "hesic_cast": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
     "hesic_round": ([_vp, _i32, _vp, _i32, _i64, _vp], _i32),
     "hesic_conv2d_wgrad_direct": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp], _i32),
+    "hesic_conv2d_forward_grouped": ([_P(ConvDesc), _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
+    "hesic_pack_conv_weight_slice": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
     "hesic_gdn_backward_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
     "hesic_eb_pack_table": ([_P(EbLayout), _vp, _i32, _vp], _i32),

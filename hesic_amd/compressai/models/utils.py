@@ -30,6 +30,14 @@ class HipConv2d(nn.Conv2d):
                          padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                          mask=mask, tap_mask=tap_mask)
 
+    def run_slice(self, x, c_off, act=L.ACT_NONE):
+        """self(x[:, c_off:c_off + in_channels]) at inference, reading the channel slice in place."""
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d_slice(x, c_off, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                               padding=self.padding[0], transposed=False, act=act, packer=self._packer)
+
     def run_latent(self, x, act=L.ACT_NONE, in_abs=False, want_lo=True):
         """(lo, hi) of a conv that feeds an entropy model: ``hi`` is fp32 from the accumulators at bf16 inference
         (``Fn.conv2d_latent``), ``lo`` (optional) the storage-dtype copy for the next conv."""
@@ -76,6 +84,13 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
             self._packer = Fn.PackedWeight()
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=True, act=act, packer=self._packer)
+
+    def run_slice(self, x, c_off, act=L.ACT_NONE):
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d_slice(x, c_off, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                               padding=self.padding[0], transposed=True, act=act, packer=self._packer)
 
     def run_latent(self, x, act=L.ACT_NONE, want_lo=True):
         self._check()

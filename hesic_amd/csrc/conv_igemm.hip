@@ -47,6 +47,8 @@ struct IgemmArgs {
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
+    int x_group_step, tiles_per_group;   // grouped launch: cout tile nt reads input channels [x_co + (nt / tiles_per_group) * x_group_step, + Cin)
+    int act2, act_split;       // couts >= act_split (a multiple of the cout tile) take activation act2 instead of act
     int dbg;                   // profiling ablations (HESIC_IGEMM_DBG, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMAs
     float* y32;                // bf16 fast path: also (or, with y == nullptr, only) store act(conv + bias) as fp32 straight from the
     int y32_ps, y32_co;        //      accumulators -- what feeds round() and the likelihoods must not pass through bf16 storage
@@ -364,7 +366,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     constexpr int XI = BM * CPR / 64 / NW;    // x-tile DMA instructions per wave per step
     constexpr int WI = BN * CPR / 64 / NW;
     static_assert(XI >= 1 && WI >= 1, "tile too small");
-    constexpr int WN = BM >= 64 ? 2 : 1, WM = NW / WN;    // wave grid: WM cout slices x WN pixel slices
+    constexpr int WN = BM >= 256 ? NW / 2 : (BM >= 64 ? 2 : 1), WM = NW / WN;    // wave grid: WM cout slices x WN pixel slices
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
@@ -432,6 +434,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)OOB, 0x00020000);
     const int prow = lane / CPR, pslot = lane % CPR;
+    const int gco = a.x_group_step ? (nt / a.tiles_per_group) * a.x_group_step : 0;      // grouped launch: this cout tile's input slice
+    const int act_eff = (a.act_split && n0 >= a.act_split) ? a.act2 : a.act;
     uint32_t xoff[XI], xv[XI], wv[WI];
     int iy0[XI], ix0[XI];
 #pragma unroll
@@ -442,7 +446,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         const bool ok = qy < a.QH && qx < a.QW;
         iy0[i] = ok ? qy * a.in_step : (int)0xc0000000;            // far outside: every tap of a dead row reads zeros
         ix0[i] = qx * a.in_step;
-        xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + ls * 8) * 2);
+        xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + gco + ls * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
@@ -638,8 +642,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                             const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
                             if (n0 + cl < a.Cout) {
                                 const f32x4 bq = a.bias ? *(const f32x4*)(a.bias + n0 + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
-                                *(f32x4*)(dst + cl) = f32x4{apply_act(acc[i][j][4 * g] + bq[0], a.act), apply_act(acc[i][j][4 * g + 1] + bq[1], a.act),
-                                                            apply_act(acc[i][j][4 * g + 2] + bq[2], a.act), apply_act(acc[i][j][4 * g + 3] + bq[3], a.act)};
+                                *(f32x4*)(dst + cl) = f32x4{apply_act(acc[i][j][4 * g] + bq[0], act_eff), apply_act(acc[i][j][4 * g + 1] + bq[1], act_eff),
+                                                            apply_act(acc[i][j][4 * g + 2] + bq[2], act_eff), apply_act(acc[i][j][4 * g + 3] + bq[3], act_eff)};
                             }
                         }
                 }
@@ -660,7 +664,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], act_eff);
                     *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
                 }
             }
@@ -987,6 +991,7 @@ static thread_local void* g_y_pre = nullptr;              // set by hesic_conv2d
 static thread_local float* g_ws = nullptr;               // set by hesic_conv2d_forward_ws: split-K workspace
 static thread_local size_t g_ws_bytes = 0;
 static thread_local size_t* g_ws_need = nullptr;         // set by hesic_conv2d_ws_bytes: only report the workspace size
+static thread_local int g_groups = 1, g_x_group_step = 0, g_act2 = 0, g_act_split = 0;   // set by hesic_conv2d_forward_grouped
 static thread_local float* g_y32 = nullptr;              // set by hesic_conv2d_forward_f32out: fp32 copy of the output
 static thread_local int g_y32_ps = 0, g_y32_co = 0;
 
@@ -1121,6 +1126,23 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const bool long_k = !d->transposed && min_steps >= 100;
         if (nb < 256 && S >= 2 && (starved || long_k)) { ksplit = S; bm = bm_s; }
     }
+    // 256-pixel tile, 8 waves of 64 x 64 (2 cout x 4 pixel slices), one block per CU: the weight tile is shared by twice the
+    // pixels, i.e. 25 % fewer bytes through the global -> LDS path per MFMA (that path bounds the kernel)
+    // Measured (round 2, same box, back to back): conv 128->128 s2 @256^2 146 vs 153 us, the transposed layer 223 vs 216 us, the
+    // step's 7 fused launches 132 vs 124 us -- no gain (one 8-wave block per CU marches through its barriers in lockstep and loses
+    // the overlap two independent 4-wave blocks give), so it stays an A/B switch, off by default.
+    static const int big = getenv("HESIC_IGEMM_BM256") ? atoi(getenv("HESIC_IGEMM_BM256")) : 0;      // A/B switch
+    if (fast && big && bm == 128 && BN == 128 && d->Cin % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
+    if (g_groups > 1 || g_act_split) {
+        HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
+        HESIC_CHECK_ARG(d->Cout % g_groups == 0 && (d->Cout / g_groups) % BN == 0 && g_act_split % BN == 0,
+                        "conv2d_forward_grouped: couts per group and the activation split must be multiples of the cout tile (%d)", BN);
+        HESIC_CHECK_ARG(d->x_c_off + (g_groups - 1) * g_x_group_step + d->Cin <= d->x_pix_stride, "conv2d_forward_grouped: input slice out of range");
+        ksplit = 1; bm = (bm == 256) ? 128 : bm;          // one block per output tile: the K-slice reduce knows neither groups nor two activations
+        a.x_group_step = g_groups > 1 ? g_x_group_step : 0;
+        a.tiles_per_group = (d->Cout / g_groups) / BN;
+        a.act2 = g_act2; a.act_split = g_act_split;
+    }
     const size_t ws_need = ksplit > 1 ? (size_t)ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
     if (g_ws_need) { *g_ws_need = ws_need; return 0; }
     HESIC_CHECK_ARG(ws_need <= g_ws_bytes, "conv2d_forward_ws: workspace too small (%zu < %zu bytes)", g_ws_bytes, ws_need);
@@ -1169,7 +1191,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
         static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
-        if (bm == 128 && bk == 64 && BN == 128 && ws_mode && ksplit == 1) {
+        if (bm == 256) {
+            const dim3 block2(512);
+            if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 1, 8>), grid, block2, 0, st, a);
+            else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 2, 8>), grid, block2, 0, st, a);
+            else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 0, 8>), grid, block2, 0, st, a);
+        } else if (bm == 128 && bk == 64 && BN == 128 && ws_mode && ksplit == 1) {
             const dim3 block_ws(2 * NTHREADS);
             if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
@@ -1238,4 +1265,44 @@ extern "C" int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void*
     g_ws = nullptr; g_ws_bytes = 0;
     g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
     return rc;
+}
+
+extern "C" int hesic_conv2d_forward_grouped(const hesic_conv_desc* d, int groups, int x_group_step, int act2, int act_split, const void* x,
+                                            const void* w_packed, const float* bias, void* y, float* y_f32, int y32_pix_stride,
+                                            int y32_c_off, void* stream) {
+    HESIC_CHECK_ARG(d && groups >= 1 && x_group_step >= 0 && act_split >= 0 && act_split <= d->Cout, "conv2d_forward_grouped: bad arguments");
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16, "conv2d_forward_grouped: bf16 storage");
+    HESIC_CHECK_ARG(!y_f32 || (y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride),
+                    "conv2d_forward_grouped: fp32 channel slice must be 16-byte aligned and in range");
+    g_groups = groups; g_x_group_step = x_group_step; g_act2 = act2; g_act_split = act_split;
+    g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
+    const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
+    g_groups = 1; g_x_group_step = g_act2 = g_act_split = 0;
+    g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
+    return rc;
+}
+
+// One weight of a grouped launch into its cout slice [co_off, co_off + Cout) of a packed buffer [KH*KW][Cout_total][Cin].
+namespace {
+__global__ void pack_weight_slice_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KH, int KW, int transposed,
+                                         int Cout_total, int co_off) {
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = i % Cin;
+        int64_t r = i / Cin;
+        const int co = r % Cout, tap = r / Cout;
+        const int ky = tap / KW, kx = tap % KW;
+        const int64_t src = transposed ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
+        wp[((int64_t)tap * Cout_total + co_off + co) * Cin + ci] = f2bf(w[src]);
+    }
+}
+}  // namespace
+
+extern "C" int hesic_pack_conv_weight_slice(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int transposed, int Cout_total,
+                                            int co_off, void* stream) {
+    HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && co_off >= 0 && co_off + Cout <= Cout_total, "pack_conv_weight_slice: bad arguments");
+    const int64_t n = (int64_t)KH * KW * Cout * Cin;
+    hipLaunchKernelGGL(pack_weight_slice_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wp, Cout, Cin, KH, KW,
+                       transposed, Cout_total, co_off);
+    HESIC_LAUNCH_RETURN("pack_conv_weight_slice");
 }

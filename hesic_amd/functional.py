@@ -616,6 +616,94 @@ def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=F
                       f32_out="both" if want_lo else "only")
 
 
+class PackedGroup:
+    """Packed bf16 weights (+ concatenated fp32 bias) of several same-geometry convs side by side along Cout, for
+    ``conv2d_grouped``; inference cache with the tag policy of ``PackedWeight``."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, weights, biases, k, transposed):
+        """Returns (packed weights, bias, per-branch cout offsets, padded total): every branch starts on a multiple of 128 couts (the
+        cout tile of the kernel; pad rows are zero weights / zero bias -- 960 -> 1024 for the mixture-parameter layers)."""
+        tag = tuple((w.data_ptr(), w._version) for w in weights) + tuple((b.data_ptr(), b._version) for b in biases if b is not None) + (_cache_epoch,)
+        if self._hit is not None and self._hit[0] == tag:
+            return self._hit[1:]
+        couts = [(w.shape[1] if transposed else w.shape[0]) for w in weights]
+        cin = weights[0].shape[0] if transposed else weights[0].shape[1]
+        offs, total = [], 0
+        for co in couts:
+            offs.append(total)
+            total += -(-co // 128) * 128
+        dev = weights[0].device
+        wp = torch.empty(k * k * total * cin, dtype=torch.bfloat16, device=dev).fill_(0)
+        bias = torch.empty(total, dtype=torch.float32, device=dev).fill_(0)
+        for w, b, co, off in zip(weights, biases, couts, offs):
+            L.call("hesic_pack_conv_weight_slice", L.ptr(w.detach().contiguous()), L.ptr(wp), co, cin, k, k, int(transposed), total, off, L.stream())
+            if b is not None:
+                bias[off:off + co].copy_(b.detach())
+        self._hit = (tag, wp, bias, offs, total)
+        return wp, bias, offs, total
+
+
+def grouped_ok(x):
+    """The grouped hyper-synthesis launches exist for bf16 inference."""
+    return GROUP_HYPER and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+
+
+GROUP_HYPER = _os.environ.get("HESIC_NO_GROUP_HYPER") is None      # A/B switch
+
+
+def conv2d_grouped(x, weights, biases, packer, *, kernel_size, stride, padding, transposed=False, shared_input=True, x_c_off=0,
+                   x_group_step=None, acts=None, f32_out=None):
+    """Several convs of one geometry as ONE implicit-GEMM launch (``hesic_conv2d_forward_grouped``): ``weights`` / ``biases`` are the
+    branches' tensors; with ``shared_input`` every branch reads channels [x_c_off, x_c_off + Cin) of ``x``, otherwise branch g reads
+    [x_c_off + g * x_group_step, ...) (default step: Cin).  ``acts``: one activation per branch (at most two distinct values,
+    switching once).  Returns ``(out, offsets)``: the concatenated output (B, padded sum of Cout, Ho, Wo) -- bf16, or with
+    ``f32_out="only"`` fp32 from the accumulators -- and each branch's first channel in it (branches start on multiples of 128)."""
+    L.require_cuda(x, *weights)
+    k = kernel_size
+    couts = [(w.shape[1] if transposed else w.shape[0]) for w in weights]
+    cin = weights[0].shape[0] if transposed else weights[0].shape[1]
+    G = len(weights)
+    if not shared_input and len(set(couts)) != 1:
+        raise ValueError("conv2d_grouped: branches with their own input slices need equal Cout")
+    wp, bias, offs, total = packer.get(weights, biases, k, transposed)
+    acts = list(acts) if acts is not None else [L.ACT_NONE] * G
+    act, act2, split = acts[0], acts[0], 0
+    for g in range(1, G):
+        if acts[g] != acts[g - 1]:
+            if split:
+                raise ValueError("conv2d_grouped: the activation may switch once along the branches")
+            act2, split = acts[g], offs[g]
+    B, _, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    x = _nhwc(x)
+    out = None if f32_out == "only" else _empty_nhwc(B, total, Ho, Wo, torch.bfloat16, x.device)
+    out32 = _empty_nhwc(B, total, Ho, Wo, torch.float32, x.device) if f32_out else None
+    groups = 1 if shared_input else G
+    step = 0 if shared_input else (cin if x_group_step is None else int(x_group_step))
+    d = L.ConvDesc(B, H, W, cin, Ho, Wo, total, k, k, stride, padding, int(transposed), L.BF16, act, 0, x.shape[1], x_c_off, total, 0, 0)
+    L.call("hesic_conv2d_forward_grouped", C.byref(d), groups, step, act2, split, L.ptr(x), L.ptr(wp), L.ptr(bias),
+           L.ptr(out), L.ptr(out32), total, 0, L.stream())
+    return (out32 if f32_out == "only" else (out if not f32_out else (out, out32))), offs
+
+
+def conv2d_slice(x, x_c_off, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, packer=None):
+    """Inference conv on the channel slice [x_c_off, x_c_off + Cin) of a wider NHWC tensor, read in place (no slice copy)."""
+    L.require_cuda(x, weight)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("conv2d_slice is an inference form")
+    k = kernel_size
+    Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    B, _, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    x = _nhwc(x)
+    packer = packer if packer is not None else PackedWeight()
+    wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
+    return _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, padding, transposed, act, 0, 0, x_c_off=x_c_off)
+
+
 def round_to(x, dtype):
     """round-half-even(x) stored as ``dtype``: ``_quantize(x, "dequantize")`` without means on an fp32 latent."""
     L.require_cuda(x)

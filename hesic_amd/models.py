@@ -231,8 +231,32 @@ class gmm_hyper_y1(nn.Module):
         self.gmm_weights = nn.Sequential(deconv(N, N, kernel_size=5), nn.LeakyReLU(), deconv(N, M * K, kernel_size=5),
                                          spatial_pool2d(), nn.LeakyReLU(), conv(M * K, M * K, kernel_size=1, stride=1))
 
+    def _forward_grouped(self, z):
+        """bf16 inference: 4 implicit-GEMM launches instead of 8 (+ their split-K reduces).  The three first layers share their
+        input -> one transposed conv with Cout = 3 x 128 (ReLU on the sigma third, LeakyReLU on the rest); the sigma / mean second
+        layers -> one launch of two groups; the two 128 -> 960 output convs -> one launch of two groups writing sigma | means as
+        one fp32 tensor straight from the accumulators.  The weights branch's 128 -> 960 layer runs beside them on a side stream."""
+        s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        if not hasattr(self, "_pg"):
+            self._pg = [Fn.PackedGroup() for _ in range(3)]
+        t1, o1 = Fn.conv2d_grouped(z, [s[0].weight, m[0].weight, w[0].weight], [s[0].bias, m[0].bias, w[0].bias], self._pg[0], kernel_size=5,
+                                   stride=2, padding=2, transposed=True, shared_input=True, acts=[RELU, LEAKY, LEAKY])
+
+        def sigma_means():
+            t2, o2 = Fn.conv2d_grouped(t1, [s[2].weight, m[2].weight], [s[2].bias, m[2].bias], self._pg[1], kernel_size=5, stride=2, padding=2,
+                                       transposed=True, shared_input=False, x_c_off=o1[0], x_group_step=o1[1] - o1[0], acts=[RELU, LEAKY])
+            return Fn.conv2d_grouped(t2, [s[4].weight, m[4].weight], [s[4].bias, m[4].bias], self._pg[2], kernel_size=5, stride=1, padding=2,
+                                     shared_input=False, x_c_off=o2[0], x_group_step=o2[1] - o2[0], acts=[RELU, NONE],
+                                     f32_out="only" if Fn.fp32_latents() else None)
+
+        (sm, o3), weights = _branches(z, sigma_means, lambda: _mixture_weights(w, w[2].run_slice(t1, o1[2]), self.K, self.M))
+        MK = self.M * self.K
+        return sm[:, o3[0]:o3[0] + MK], sm[:, o3[1]:o3[1] + MK], weights
+
     def forward(self, z, hi=False):
         """``hi``: sigma / means as they feed the likelihood (fp32 from the accumulators at bf16 inference)."""
+        if hi and Fn.grouped_ok(z):
+            return self._forward_grouped(z)
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
         last = (lambda c, t, act=NONE: c.run_latent(t, act=act, want_lo=False)[1]) if hi else (lambda c, t, act=NONE: c.run(t, act=act))
         sigma, means, weights = _branches(
@@ -259,8 +283,30 @@ class gmm_hyper_y2(nn.Module):
                                          conv(N, M * K, kernel_size=5, stride=1), spatial_pool2d(), nn.LeakyReLU(),
                                          conv(M * K, M * K, kernel_size=1, stride=1))
 
+    def _forward_grouped(self, c):
+        """As ``gmm_hyper_y1._forward_grouped``: 320 -> 3 x 128 on the shared concat buffer, sigma / mean 128 -> 128 as two groups,
+        128 -> 960 twice as two groups with fp32 output; the weights branch's 128 -> 960 on a side stream."""
+        s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
+        if not hasattr(self, "_pg"):
+            self._pg = [Fn.PackedGroup() for _ in range(3)]
+        t1, o1 = Fn.conv2d_grouped(c, [s[0].weight, m[0].weight, w[0].weight], [s[0].bias, m[0].bias, w[0].bias], self._pg[0], kernel_size=5,
+                                   stride=1, padding=2, shared_input=True, acts=[RELU, LEAKY, LEAKY])
+
+        def sigma_means():
+            t2, o2 = Fn.conv2d_grouped(t1, [s[2].weight, m[2].weight], [s[2].bias, m[2].bias], self._pg[1], kernel_size=5, stride=1, padding=2,
+                                       shared_input=False, x_c_off=o1[0], x_group_step=o1[1] - o1[0], acts=[RELU, LEAKY])
+            return Fn.conv2d_grouped(t2, [s[4].weight, m[4].weight], [s[4].bias, m[4].bias], self._pg[2], kernel_size=5, stride=1, padding=2,
+                                     shared_input=False, x_c_off=o2[0], x_group_step=o2[1] - o2[0], acts=[RELU, NONE],
+                                     f32_out="only" if Fn.fp32_latents() else None)
+
+        (sm, o3), weights = _branches(c, sigma_means, lambda: _mixture_weights(w, w[2].run_slice(t1, o1[2]), self.K, self.M))
+        MK = self.M * self.K
+        return sm[:, o3[0]:o3[0] + MK], sm[:, o3[1]:o3[1] + MK], weights
+
     def forward(self, z2, y1, hi=False):
         c = Fn.upsample4_cat(z2, y1)
+        if hi and Fn.grouped_ok(c):
+            return self._forward_grouped(c)
         s, m, w = self.gmm_sigma, self.gmm_means, self.gmm_weights
         last = (lambda cv, t, act=NONE: cv.run_latent(t, act=act, want_lo=False)[1]) if hi else (lambda cv, t, act=NONE: cv.run(t, act=act))
         sigma, means, weights = _branches(

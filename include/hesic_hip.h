@@ -105,6 +105,19 @@ int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void* x, const v
                                 void* y, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                                 void* stream);
 
+/* Several convolutions of the same geometry in ONE launch (bf16 storage): the packed weight holds `groups` weights side by side along
+ * Cout ([KH*KW][Cout][Cin], d->Cout = total, each slice written by hesic_pack_conv_weight_slice), group g's couts read input
+ * channels [x_c_off + g * x_group_step, + d->Cin) of x (x_group_step = 0: all groups share one input).  Couts >= act_split take
+ * activation act2 instead of d->act (0 = no split).  y and / or y_f32 as hesic_conv2d_forward_f32out.  This is how the three
+ * branches of gmm_hyper_y1 / y2 (sigma: ReLU, means / weights: LeakyReLU; newnet1.py:456-577) run: first layers = one launch with
+ * Cout = 3 * 128 on the shared input, the sigma / mean second layers = one launch of two groups, the two 128 -> 960 output layers
+ * = one launch of two groups whose fp32 output holds sigma | means.  Couts per group and act_split must be multiples of 128.   */
+int hesic_conv2d_forward_grouped(const hesic_conv_desc* d, int groups, int x_group_step, int act2, int act_split, const void* x,
+                                 const void* w_packed, const float* bias, void* y, float* y_f32, int y32_pix_stride,
+                                 int y32_c_off, void* stream);
+int hesic_pack_conv_weight_slice(const float* w, void* w_packed_bf16, int Cout, int Cin, int KH, int KW, int transposed,
+                                 int Cout_total, int co_off, void* stream);
+
 /* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);

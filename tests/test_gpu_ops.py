@@ -842,3 +842,45 @@ def test_image_side_conv_gdn_is_bit_stable_across_launches():
         assert bad == 0, bad
     finally:
         Fn.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("transposed", [False, True], ids=["conv", "deconv"])
+def test_grouped_conv_matches_separate_convs(transposed):
+    """hesic_conv2d_forward_grouped (the hyper-synthesis branches as one launch): shared input with an activation split, and two
+    groups reading their own input slices with fp32 output, against the oracle per branch and against the one-conv-at-a-time path."""
+    Fn, O = _imp()
+    from hesic_amd import _lib as L
+    B, Cin, H = 2, 128, 8
+    cl = torch.channels_last
+    ws = [bf(rnd(f"g{transposed}w{i}", ((Cin, co, 5, 5) if transposed else (co, Cin, 5, 5))) * 0.03) for i, co in enumerate((128, 128, 128))]
+    bs = [rnd(f"g{transposed}b{i}", (128,), -0.1, 0.1) for i in range(3)]
+    x = bf(rnd(f"g{transposed}x", (B, Cin, H, H), -2, 2))
+    op = (lambda x_, w_, b_: O.deconv(x_, w_, b_, 2)) if transposed else (lambda x_, w_, b_: O.conv(x_, w_, b_, 1))
+    acts = [torch.relu, lambda t: torch.nn.functional.leaky_relu(t, 0.01), lambda t: torch.nn.functional.leaky_relu(t, 0.01)]
+    ref = torch.cat([a(op(x, w, b)) for a, w, b in zip(acts, ws, bs)], 1)
+    torch.set_grad_enabled(False)
+    try:
+        xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=cl)
+        wd, bd = [w.to(DEV) for w in ws], [b.to(DEV) for b in bs]
+        kw = dict(kernel_size=5, stride=2 if transposed else 1, padding=2, transposed=transposed)
+        y, offs = Fn.conv2d_grouped(xd, wd, bd, Fn.PackedGroup(), shared_input=True, acts=[L.ACT_RELU, L.ACT_LEAKY, L.ACT_LEAKY], **kw)
+        assert offs == [0, 128, 256] and y.shape == ref.shape and rel_err(y, ref) < 2e-2
+        one = torch.cat([Fn.conv2d(xd, w, b, act=a, **kw) for w, b, a in zip(wd, bd, (L.ACT_RELU, L.ACT_LEAKY, L.ACT_LEAKY))], 1)
+        assert rel_err(y, one) < 4e-3                                 # split-K vs one block per tile: one bf16 ulp
+        # second layer: two groups, each reading its own 128-channel slice of y, fp32 output, second branch without activation
+        ref2 = torch.cat([torch.relu(op(bf(ref[:, :128]), ws[0], bs[0])), op(bf(ref[:, 128:256]), ws[1], bs[1])], 1)
+        y2, _ = Fn.conv2d_grouped(y, wd[:2], bd[:2], Fn.PackedGroup(), shared_input=False, acts=[L.ACT_RELU, L.ACT_NONE], f32_out="only", **kw)
+        assert y2.dtype == torch.float32 and y2.shape == ref2.shape and rel_err(y2, ref2) < 2e-2
+        sl = Fn.conv2d_slice(y, 128, wd[1], bd[1], **kw)               # in-place channel slice == the second group
+        assert torch.equal(sl, y2[:, 128:].to(torch.bfloat16)) or rel_err(sl, y2[:, 128:]) < 4e-3
+        if not transposed:      # branches whose Cout is not a multiple of the 128-cout tile start on padded offsets (960 -> 1024)
+            w9 = [bf(rnd(f"g9w{i}", (192, Cin, 5, 5)) * 0.03).to(DEV) for i in range(2)]
+            b9 = [rnd(f"g9b{i}", (192,), -0.1, 0.1).to(DEV) for i in range(2)]
+            y9, o9 = Fn.conv2d_grouped(y, w9, b9, Fn.PackedGroup(), shared_input=False, acts=[L.ACT_RELU, L.ACT_NONE], f32_out="only", **kw)
+            assert o9 == [0, 256] and y9.shape[1] == 512
+            for g in range(2):
+                r9 = O.conv(bf(ref[:, 128 * g:128 * (g + 1)]), w9[g].cpu(), b9[g].cpu(), 1)
+                assert rel_err(y9[:, o9[g]:o9[g] + 192], torch.relu(r9) if g == 0 else r9) < 2e-2
+            assert float(y9[:, 192:256].abs().max()) == 0            # pad couts: zero weights, zero bias, ReLU
+    finally:
+        torch.set_grad_enabled(True)
