@@ -317,6 +317,20 @@ class gmm_hyper_y2(nn.Module):
         return sigma, means, weights
 
 
+def _check_pair(x1, x2, h_matrix):
+    """Argument errors up front, with a usable message (the reference fails deep inside with a size mismatch: SURVEY.md 5)."""
+    if x1.dim() != 4 or x1.shape != x2.shape or x1.shape[1] != 3:
+        raise RuntimeError(f"HSIC.forward: x1 and x2 must be (B, 3, H, W) tensors of one shape, got {tuple(x1.shape)} and {tuple(x2.shape)}")
+    B, _, H, W = x1.shape
+    if B == 0:
+        raise RuntimeError("HSIC.forward: empty batch")
+    if H % 64 or W % 64:
+        raise RuntimeError(f"HSIC.forward: H and W must be multiples of 64 (the hyper path down-samples by 64), got {H}x{W}; "
+                           "zero-pad with hesic_amd.models.pad_to_multiple and crop the reconstructions")
+    if h_matrix.shape[-2:] != (3, 3) or h_matrix.dim() != 3 or h_matrix.shape[0] not in (1, B):
+        raise RuntimeError(f"HSIC.forward: h_matrix must be (B, 3, 3) (or (1, 3, 3)), got {tuple(h_matrix.shape)}")
+
+
 def _noise(nz, key, like, training):
     if not training:
         return None
@@ -358,6 +372,7 @@ class HSIC(StereoCompressionModel):
     def forward(self, x1, x2, h_matrix, noise=None):
         """``noise`` (training only, optional): dict z1,y1,y1w,z2,y2 of U(-1/2,1/2) draws, in the order the
         reference makes them; absent keys are drawn on the device."""
+        _check_pair(x1, x2, h_matrix)
         if not self.training and not torch.is_grad_enabled() and x1.is_cuda:
             return self._forward_eval(x1, x2, h_matrix, two_streams=OVERLAP_STREAMS)
         tr = self.training
@@ -612,6 +627,7 @@ class HSICJoint(StereoCompressionModel):
 
     def forward(self, x1, x2, h_matrix, noise=None):
         """noise keys (training): z1, y1, y1b, z2, y1w, y2, y2b (reference draw order)."""
+        _check_pair(x1, x2, h_matrix)
         if not self.training and not torch.is_grad_enabled() and x1.is_cuda:
             return self._forward_eval(x1, x2, h_matrix)
         tr = self.training

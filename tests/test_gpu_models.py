@@ -643,3 +643,29 @@ def test_train_trace_256_matches_reference(kind):
     for s in range(2):
         for j, nm in enumerate(("loss", "bpp", "mse", "aux")):
             assert trace[s][j] == pytest.approx(float(g["trace"][s][j]), rel=5e-3), (s, nm, trace, g["trace"])
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_forward_edge_cases(kind):
+    """Ragged / empty / strided inputs: sizes that are not multiples of 64 (the reference dies with a size mismatch deep inside,
+    SURVEY.md 5), an empty batch and mismatched views raise up front; non-contiguous views of the images and a broadcast
+    (1, 3, 3) homography give the result of their contiguous / expanded copies bit for bit; the smallest legal image works."""
+    net = build(kind)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 2, 64, 128))
+    with torch.no_grad():
+        ref = net(x1, x2, Hm)
+        for bad in ((x1[..., :60, :], x2[..., :60, :], Hm), (x1[:0], x2[:0], Hm[:0]), (x1, x2[:, :, :, :64], Hm), (x1, x2, Hm[:, :2])):
+            with pytest.raises(RuntimeError):
+                net(*bad)
+        wide1, wide2 = torch.zeros(2, 3, 64, 256, device=DEV), torch.zeros(2, 3, 64, 256, device=DEV)
+        wide1[..., 64:192], wide2[..., 64:192] = x1, x2
+        v1, v2 = wide1[..., 64:192], wide2[..., 64:192]                      # row stride 256, not contiguous
+        assert not v1.is_contiguous()
+        out = net(v1, v2, Hm)
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(out[k], ref[k]), k
+        one = net(x1, x2, Hm[:1])                                               # (1, 3, 3) homography for the whole batch
+        exp = net(x1, x2, Hm[:1].expand(2, 3, 3).contiguous())
+        assert torch.equal(one["x2_hat"], exp["x2_hat"]) and torch.equal(one["y2_hat"], exp["y2_hat"])
+        tiny = net(x1[:1, :, :, :64], x2[:1, :, :, :64], Hm[:1])              # 64 x 64: one z value per channel
+        assert tiny["likelihoods"]["z1"].shape == (1, 128, 1, 1) and bool(torch.isfinite(tiny["x2_hat"]).all())
