@@ -340,29 +340,30 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
         elapsed = float(t)
     losses = {k: float(v) for k, v in crit.items()}
 
-    # roofline of the weight-gradient MFMA kernel, measured live (eager steps, events on the launch stream); launch census
+    # roofline of the weight-gradient MFMA kernel, measured live (eager steps, events on the launch stream); launch census.
+    # EVERY rank runs these extra steps (a step contains the gradient collectives: a rank that skipped them would hang the
+    # others); only rank 0's events are reported.
     roof, census = None, {}
-    if rank == 0:
-        eager = Trainer.step          # the un-graphed step of the same trainer object
-        orig_call = L_.call
+    eager = Trainer.step          # the un-graphed step of the same trainer object
+    orig_call = L_.call
 
-        def counting(name, *a):
-            census[name] = census.get(name, 0) + 1
-            return orig_call(name, *a)
-        L_.call = counting
-        try:
+    def counting(name, *a):
+        census[name] = census.get(name, 0) + 1
+        return orig_call(name, *a)
+    L_.call = counting
+    try:
+        eager(tr, x1, x2, Hm)
+    finally:
+        L_.call = orig_call
+    with WgradMeter(L_) as wm:
+        for _ in range(2):
             eager(tr, x1, x2, Hm)
-        finally:
-            L_.call = orig_call
-        with WgradMeter(L_) as wm:
-            for _ in range(2):
-                eager(tr, x1, x2, Hm)
-            s = wm.summary()
-        if s:
-            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-            roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
-                    "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
+        s = wm.summary()
+    if s and rank == 0:
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
+                "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
     if world > 1:
         dist.barrier()
 
@@ -379,7 +380,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
                        "pairs_per_step": world * args.batch, "global_batch": world * args.batch,
                        "sharding": f"data parallel over {world} GPU(s): one in-place bucketed RCCL all-reduce of the "
                                    f"{tr.main_group.numel * 4 / 1e6:.1f} MB flat gradient per step" + ("" if world > 1 else " (single rank: no collective)"),
-                       "step": "eager" if args.eager else "HIP graph replay"},
+                       "step": "eager" if (args.eager or not getattr(tr, "capturable", True)) else "HIP graph replay"},
             "model_tflops": round(pairs * gflop_pair / elapsed / 1e3, 2) if args.model == "hsic" else None,
             "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype == "bf16" else None,
             "roofline": roof,

@@ -333,6 +333,12 @@ class GraphedTrainer(Trainer):
                              "eager step)")
         self.warmup, self.calls, self.graph = int(warmup), 0, None
         self._in = self._noise = self._out = None
+        # only RCCL's collectives are stream work; gloo stages through the host (synchronises) and cannot be captured
+        self.capturable = not (self.main_reducer.active and not self.main_reducer.avg_op)
+        if not self.capturable:
+            import warnings
+            warnings.warn("GraphedTrainer: the process group's backend is not nccl/RCCL -- its collectives cannot be captured into a HIP "
+                          "graph, steps run eagerly")
 
     def _stage(self, x1, x2, h_matrix, noise):
         if self._in is None:
@@ -349,6 +355,8 @@ class GraphedTrainer(Trainer):
                     dst.copy_(noise[k])
 
     def step(self, x1, x2, h_matrix, noise=None):
+        if not self.capturable:
+            return super().step(x1, x2, h_matrix, noise=noise)
         self._stage(x1, x2, h_matrix, noise)
         self.calls += 1
         if self.graph is None and self.calls <= self.warmup:
@@ -378,8 +386,12 @@ def init_distributed(backend=None):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        # HESIC_DIST_BACKEND=gloo + HESIC_SINGLE_DEVICE=1: several ranks sharing ONE GPU (functional check of the multi-rank code
+        # paths on a 1-GPU box; RCCL itself refuses two ranks on one device)
+        backend = os.environ.get("HESIC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("HESIC_SINGLE_DEVICE"):
+        local = 0
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -1,0 +1,31 @@
+"""bench.py's N > 1 code paths on a 1-GPU box: two ranks sharing the device over gloo (HESIC_DIST_BACKEND / HESIC_SINGLE_DEVICE;
+RCCL refuses two ranks on one GPU).  Regression for a deadlock found in round 2: the training leg ran its metering steps --
+which contain the gradient collectives -- on rank 0 only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(port, *flags):
+    env = dict(os.environ, HESIC_DIST_BACKEND="gloo", HESIC_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *flags]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                      # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_two_rank_inference_and_training_bench_lines():
+    d = _run(29541, "--batch", "2", "--size", "256")
+    assert d["n_gpus"] == 2 and d["config"]["pairs_per_step"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    t = _run(29542, "--mode", "train", "--batch", "2", "--size", "256")
+    assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 4 and t["value"] > 0 and t["roofline"]["kernel"] == "wgrad_tr_kernel"
+    assert all(v == v for v in t["losses_last_step"].values())    # finite
