@@ -77,43 +77,55 @@ __global__ void warp_fwd_kernel(const WArgs a) {
 // of a pixel are branch-free buffer loads (an out-of-image tap is a poisoned offset that reads 0, its weight is forced to
 // 0 as well so non-finite coordinates stay silent) and all in flight together; 32-bit indexing, one row of output per
 // block row so the pixel index needs no division.  The generic kernel took a branch and a 64-bit address per tap.
+constexpr int WARP_ROWS = 4;     // output rows per block: one 3x3 inversion and one block start-up per 4 x 256 pixels, 48 taps in flight per lane
 __global__ __launch_bounds__(256) void warp_fwd_f32c3_kernel(const WArgs a) {
     const hesic_warp_desc& d = a.d;
     __shared__ double iv[9];
     const int b = blockIdx.z;
     if (threadIdx.x == 0) invert_h(a.M, b, iv, a.d.m_is_dst_to_src);
     __syncthreads();
-    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
     if (ox >= d.Wo) return;
     constexpr uint32_t POISON = 0x80000000u;
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)a.src + (int64_t)b * d.ss_b), 0, (int)POISON, 0x00020000);
-    float sx, sy;
-    const bool fin = src_coords(d, iv, ox, oy, sx, sy);
-    const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-    const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
-    const int x0 = big ? -10 : (int)fx0, y0 = big ? -10 : (int)fy0;
-    const bool vx0 = x0 >= 0 && x0 < d.W, vx1 = x0 + 1 >= 0 && x0 + 1 < d.W;
-    const bool vy0 = y0 >= 0 && y0 < d.H, vy1 = y0 + 1 >= 0 && y0 + 1 < d.H;
     const int sy_ = (int)d.ss_y, sc_ = (int)d.ss_c;
-    const uint32_t o00 = (uint32_t)((y0 * sy_ + x0) * 4);
-    const bool ok[4] = {vy0 && vx0, vy0 && vx1, vy1 && vx0, vy1 && vx1};
-    const uint32_t off[4] = {ok[0] ? o00 : POISON, ok[1] ? o00 + 4u : POISON, ok[2] ? o00 + (uint32_t)(sy_ * 4) : POISON,
-                             ok[3] ? o00 + (uint32_t)(sy_ * 4) + 4u : POISON};
-    const float wt[4] = {ok[0] ? wx0 * wy0 : 0.f, ok[1] ? wx1 * wy0 : 0.f, ok[2] ? wx0 * wy1 : 0.f, ok[3] ? wx1 * wy1 : 0.f};
-    float t[3][4];
+    float t[WARP_ROWS][3][4], wt[WARP_ROWS][4];
+    bool ok[WARP_ROWS][4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < WARP_ROWS; ++r) {
+        const int oy = blockIdx.y * WARP_ROWS + r;
+        float sx, sy;
+        const bool fin = src_coords(d, iv, ox, oy, sx, sy) && oy < d.Ho;
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
+        const int x0 = big ? -10 : (int)fx0, y0 = big ? -10 : (int)fy0;
+        const bool vx0 = x0 >= 0 && x0 < d.W, vx1 = x0 + 1 >= 0 && x0 + 1 < d.W;
+        const bool vy0 = y0 >= 0 && y0 < d.H, vy1 = y0 + 1 >= 0 && y0 + 1 < d.H;
+        const uint32_t o00 = (uint32_t)((y0 * sy_ + x0) * 4);
+        ok[r][0] = vy0 && vx0; ok[r][1] = vy0 && vx1; ok[r][2] = vy1 && vx0; ok[r][3] = vy1 && vx1;
+        const uint32_t off[4] = {ok[r][0] ? o00 : POISON, ok[r][1] ? o00 + 4u : POISON, ok[r][2] ? o00 + (uint32_t)(sy_ * 4) : POISON,
+                                 ok[r][3] ? o00 + (uint32_t)(sy_ * 4) + 4u : POISON};
+        wt[r][0] = ok[r][0] ? wx0 * wy0 : 0.f; wt[r][1] = ok[r][1] ? wx1 * wy0 : 0.f;
+        wt[r][2] = ok[r][2] ? wx0 * wy1 : 0.f; wt[r][3] = ok[r][3] ? wx1 * wy1 : 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)off[k], c * sc_ * 4, 0));
-    float* dp = (float*)a.dst + (int64_t)b * d.ds_b + (int64_t)oy * d.ds_y + ox;
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float v = 0.f;
+            for (int k = 0; k < 4; ++k) t[r][c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)off[k], c * sc_ * 4, 0));
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ok[k]) v += t[c][k] * wt[k];           // the generic kernel skips invalid taps: keep its sums (no 0 * x terms)
-        dp[(int64_t)c * d.ds_c] = v;
+    for (int r = 0; r < WARP_ROWS; ++r) {
+        const int oy = blockIdx.y * WARP_ROWS + r;
+        if (oy >= d.Ho) break;
+        float* dp = (float*)a.dst + (int64_t)b * d.ds_b + (int64_t)oy * d.ds_y + ox;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[r][k]) v += t[r][c][k] * wt[r][k];           // the generic kernel skips invalid taps: keep its sums (no 0 * x terms)
+            dp[(int64_t)c * d.ds_c] = v;
+        }
     }
 }
 
@@ -165,7 +177,7 @@ extern "C" int hesic_warp_perspective_forward(const hesic_warp_desc* d, const vo
                       d->ss_y > 0 && d->ss_c > 0 && (2 * d->ss_c + (int64_t)(d->H + 1) * d->ss_y + d->W + 2) * 4 < (1ll << 31) &&
                       d->Ho < 65536 && d->B < 65536;
     if (fast)
-        hipLaunchKernelGGL(warp_fwd_f32c3_kernel, dim3((d->Wo + 255) / 256, d->Ho, d->B), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(warp_fwd_f32c3_kernel, dim3((d->Wo + 255) / 256, (d->Ho + WARP_ROWS - 1) / WARP_ROWS, d->B), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)d->Ho * d->Wo, 256), d->B), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("warp_perspective_forward");
