@@ -89,6 +89,9 @@ _SIGS = {
     "hesic_sconv2d_forward_cat": ([_P(SConvDesc), _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, _vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward_train": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
+    "hesic_sconv_pack_weight_image": ([_i32, _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_forward_prepacked": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_gdn_forward_prepacked": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_dgrad": ([_P(SConvDesc), _vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_wgrad_ws_bytes": ([_P(SConvDesc)], _i64),
     "hesic_sconv2d_wgrad": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i32),

@@ -20,6 +20,8 @@ struct SArgs {
     // optional second input (hesic_sconv2d_forward_cat): channels [c_split, Cin) come from x2 -- the torch.cat in front of
     // pre_conv / after_conv (newnet1.py:643,686) never materialises
     const void* x2; int64_t x2s_b, x2s_c, x2s_y, x2s_x; int x2_dtype, c_split;
+    const void* w_img;   // optional: the kernel's LDS weight image, pre-packed once per weight update (hesic_sconv_pack_weight_image)
+    int dbg;     // HESIC_N2W_DBG profiling ablations of the fused 3 -> 128 kernel (garbage results): 1 no loads, 2 no conv MFMAs, 4 no GDN MFMAs, 8 no global stores
 };
 
 // weight element for (co, ci, ky, kx) in either PyTorch layout
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
             const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (a.dbg & 2) break;
                 const int row = i * 32 + frow;
                 const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
             const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (a.dbg & 4) break;
                 const int row = i * 32 + frow;
                 const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
                 nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
@@ -528,6 +532,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
     };
     auto request = [&](int tile) {                    // issue the 24 row-pair loads of a tile
         decode(tile);
+        if (a.dbg & 1) return;
         // the resource starts 8 bytes in front of the image so that every in-image pair has a non-negative lane offset
         // (row 0, ox = 0: the second pair sits at byte 0, its lane offset without the shift would be -8 = out of range)
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)a.x + (int64_t)tb * a.xs_b - 2), 0, (int)POISON, 0x00020000);
@@ -553,7 +558,18 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
     int tile = lb * NW + wave;
     if (tile < ntiles) request(tile);                 // in flight while the block packs its weights
 
-    {
+    if (a.w_img) {
+        // both LDS images (conv weights, K-permuted gamma') were laid out once per weight update by sconv_pack_n2w_image_kernel:
+        // the block start-up is a straight 64 KB copy, 8 independent 16-byte loads per thread (one memory round trip).  The
+        // in-kernel gather below (4 + 4 dependent round trips of scalar loads) cost ~14 us of a 49 us launch.
+        const u32x4* src = (const u32x4*)a.w_img;
+        u32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[tid + j * 512];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(u32x4*)(smem + (tid + j * 512) * 16) = v[j];
+        if (tid < 128) { bl[tid] = a.bias ? a.bias[tid] : 0.f; bl[128 + tid] = beta_packed[tid]; }
+    } else {
         const int r = tid & 15, ci = r / KS, ky = r % KS;
         for (int co = tid >> 4; co < 128; co += 32) {
             float v[8];
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
         if (tid < 128) { bl[tid] = a.bias ? a.bias[tid] : 0.f; bl[128 + tid] = beta_packed[tid]; }
     }
     __syncthreads();
+    if (a.dbg & 16) return;          // prologue only
 
     // lane part of the output row addresses: store instruction `it` writes pixel it*4 + (lane >> 4), 16-byte chunk lane & 15
     const uint32_t st_lane = (uint32_t)(((lane >> 4) * (int)a.ys_x + (lane & 15) * 8) * 2);
@@ -583,6 +600,11 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
             const f32x2 p0 = __builtin_bit_cast(f32x2, raw[ks][0]), p1 = __builtin_bit_cast(f32x2, raw[ks][1]), p2 = __builtin_bit_cast(f32x2, raw[ks][2]);
             frag[ks] = u32x4{pack_bf2_fast(p0.x, p0.y), pack_bf2_fast(p1.x, p1.y), pack_bf2_fast(p2.x, 0.f), 0u};
         }
+        // the rows of the NEXT tile are requested now: `raw` is free (its values live on in `frag`), and the loads then have
+        // both MFMA phases (~2000 matrix-pipe cycles) to come back instead of the epilogue alone
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + tstride < ntiles) request(tile + tstride);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -596,6 +618,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
             const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (a.dbg & 2) break;
                 const int row = i * 32 + frow;
                 const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
@@ -619,14 +642,12 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
             const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (a.dbg & 4) break;
                 const int row = i * 32 + frow;
                 const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
                 nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tile + tstride < ntiles) request(tile + tstride);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
                 // form it scheduled the next store's v_cndmask into data dword 0 right behind the store -- on gfx950 that is NOT
                 // safe: ~1 forward in 25 came back with the first two channels of a few 16-byte chunks replaced by offset bits
                 // (found in round 2 by a bit-identity stress test).  With an immediate soffset the compiler inserts the s_nop.
-                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)(ok ? st_lane + (uint32_t)so : POISON), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)((ok && !(a.dbg & 8)) ? st_lane + (uint32_t)so : POISON), 0, 0);
             }
         };
         store_rows((bf16_t*)a.y);
@@ -718,13 +739,25 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, Fast
     const int gstep = (int)gridDim.x;
     if (lb < ntiles) fetch(sa, lb);                           // in flight while the weight panel is packed
     if (lb + gstep < ntiles) fetch(sb, lb + gstep);
-    for (int i = tid; i < NP * SPR; i += 256) {
-        const int n = i / SPR, sl = i % SPR;
-        const int co = n % COUT, tap = n / COUT;
-        float v[8];
+    if (a.w_img) {
+        // pre-packed weight panel (sconv_pack_w2n_image_kernel): straight copy, NP * SPR / 256 independent 16-byte loads per thread
+        constexpr int PER = NP * SPR / 256;
+        static_assert(NP * SPR % 256 == 0, "panel size");
+        const u32x4* src = (const u32x4*)a.w_img;
+        u32x4 v[PER];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = n < N ? a.w[((int64_t)(sl * 8 + e) * COUT + co) * 25 + tap] : 0.f;   // w[ci][co][ky][kx]
-        *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        for (int j = 0; j < PER; ++j) v[j] = src[tid + j * 256];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) *(u32x4*)(wl + (tid + j * 256) * 16) = v[j];
+    } else {
+        for (int i = tid; i < NP * SPR; i += 256) {
+            const int n = i / SPR, sl = i % SPR;
+            const int co = n % COUT, tap = n / COUT;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = n < N ? a.w[((int64_t)(sl * 8 + e) * COUT + co) * 25 + tap] : 0.f;   // w[ci][co][ky][kx]
+            *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        }
     }
     // col2im role of this thread: output channel cq of the 2x2 output quad around input pixel (qy, qx) of the 6x14 patch --
     // 252 of the 256 threads busy, every lane the same 25 taps (no divergence between output parities)
@@ -1123,6 +1156,8 @@ SArgs make_args(const hesic_sconv_desc* d) {
 
 }  // namespace
 
+static thread_local const void* g_w_img = nullptr;       // set by the *_prepacked entry points around the ordinary launchers
+
 extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
                                          int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream) {
     if (int e = check_desc(d, "sconv2d_forward_cat")) return e;
@@ -1152,11 +1187,62 @@ extern "C" int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, c
     HESIC_CHECK_ARG(x && w && y, "sconv2d_forward: null pointer");
     SArgs a = make_args(d);
     a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.w_img = g_w_img;
     launch_forward(a, (hipStream_t)stream);
     HESIC_LAUNCH_RETURN("sconv2d_forward");
 }
 
+extern "C" int hesic_sconv2d_forward_prepacked(const hesic_sconv_desc* d, const void* x, const float* w, const void* w_image, const float* bias,
+                                               void* y, void* stream) {
+    HESIC_CHECK_ARG(d && d->transposed && d->Cin == 128 && d->Cout == 3 && d->KH == 5 && d->KW == 5 && d->stride == 2,
+                    "sconv2d_forward_prepacked: the image is the weight panel of the 128 -> 3 transposed 5x5 stride-2 stage");
+    g_w_img = w_image;
+    const int rc = hesic_sconv2d_forward(d, x, w, bias, y, stream);
+    g_w_img = nullptr;
+    return rc;
+}
+
 // conv (3 -> 128, 5x5 s2) + GDN fused; gamma_packed / beta_packed from hesic_gdn_pack_params.
+// LDS weight images of the two image-side MFMA kernels, built once per weight update instead of by every block of every launch.
+//   kind 0 (g_a_conv1 + GDN, 3 -> 128 5x5 s2): 64 KB = conv weights [128 co][16 slots ^ (co & 15)] of 8 bf16 (row r = ci*5+ky, 8 kx slots)
+//                                              followed by gamma' in the K-permuted order the GDN contraction reads it
+//   kind 1 (g_s_conv4, 128 -> 3 transposed):   24 KB = [96 (tap*3+co, padded)][16 slots ^ (n & 15)] of 8 cin
+__global__ void sconv_pack_n2w_image_kernel(const float* __restrict__ w, const unsigned char* __restrict__ gamma_packed, unsigned char* __restrict__ img) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // 2048 weight slots + 2048 gamma slots
+    if (idx < 2048) {
+        const int co = idx >> 4, r = idx & 15, ci = r / 5, ky = r % 5;
+        float v[8];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((co * 3 + ci) * 5 + ky) * 5 + kx] : 0.f;
+        *(u32x4*)(img + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    } else if (idx < 4096) {
+        const int j = idx - 2048, row = j >> 4, q = j & 15, ks = q >> 1, h = q & 1;
+        const unsigned char* srow = gamma_packed + row * 256;
+        const u32x2 lo = *(const u32x2*)(srow + (((2 * ks) ^ (row & 15)) << 4) + 8 * h);
+        const u32x2 hi = *(const u32x2*)(srow + (((2 * ks + 1) ^ (row & 15)) << 4) + 8 * h);
+        *(u32x4*)(img + 32768 + row * 256 + ((q ^ (row & 15)) << 4)) = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+}
+
+__global__ void sconv_pack_w2n_image_kernel(const float* __restrict__ w, unsigned char* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // 96 rows x 16 slots
+    if (i >= 96 * 16) return;
+    const int n = i / 16, sl = i % 16, co = n % 3, tap = n / 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = n < 75 ? w[((sl * 8 + e) * 3 + co) * 25 + tap] : 0.f;       // w[ci][co][ky][kx]
+    *(u32x4*)(img + (n * 16 + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
+extern "C" int hesic_sconv_pack_weight_image(int kind, const float* w, const void* gamma_packed, void* image, void* stream) {
+    HESIC_CHECK_ARG(w && image && (kind == 0 || kind == 1) && (kind == 1 || gamma_packed), "sconv_pack_weight_image: bad arguments");
+    if (kind == 0)
+        hipLaunchKernelGGL(sconv_pack_n2w_image_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, (const unsigned char*)gamma_packed, (unsigned char*)image);
+    else
+        hipLaunchKernelGGL(sconv_pack_w2n_image_kernel, dim3(6), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)image);
+    HESIC_LAUNCH_RETURN("sconv_pack_weight_image");
+}
+
 static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, const void* gamma_packed,
                             const float* beta_packed, int inverse, void* y, void* y_pre, void* stream) {
     if (int e = check_desc(d, "sconv2d_gdn_forward")) return e;
@@ -1167,6 +1253,9 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
                     "sconv2d_gdn_forward: built for the 3 -> 128 5x5 stride-2 stage with bf16 NHWC output");
     SArgs a = make_args(d);
     a.x = x; a.w = w; a.bias = bias; a.y = y;
+    static const int n2w_dbg = getenv("HESIC_N2W_DBG") ? atoi(getenv("HESIC_N2W_DBG")) : 0;
+    a.dbg = n2w_dbg;
+    a.w_img = g_w_img;
     const size_t lds = 65536 + 1024 + 8 * 32 * (128 * 2 + 16);
     const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 1) / 2) * d->B;
     const unsigned grid = (unsigned)((tiles + 7) / 8 < 256 ? (tiles + 7) / 8 : 256);
@@ -1236,4 +1325,13 @@ extern "C" int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, co
         hipLaunchKernelGGL(sconv_generic_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
     }
     HESIC_LAUNCH_RETURN("sconv2d_dgrad");
+}
+
+extern "C" int hesic_sconv2d_gdn_forward_prepacked(const hesic_sconv_desc* d, const void* x, const float* w, const void* w_image, const float* bias,
+                                                   const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                                   void* stream) {
+    g_w_img = w_image;
+    const int rc = sconv_gdn_launch(d, x, w, bias, gamma_packed, beta_packed, inverse, y, y_pre, stream);
+    g_w_img = nullptr;
+    return rc;
 }

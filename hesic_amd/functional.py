@@ -223,6 +223,25 @@ class PackedWeight:
         return wp
 
 
+_img_cache = {}
+
+
+def _weight_image(kind, weight, gp=None, gtag=None):
+    """LDS weight image of an image-side MFMA kernel (``hesic_sconv_pack_weight_image``), cached per weight (+ GDN parameters)
+    version: kind 0 = g_a_conv1 + GDN (64 KB, needs the packed gamma'), kind 1 = g_s_conv4 (24 KB)."""
+    key = (kind, weight.data_ptr())
+    tag = (weight._version, gtag, _cache_epoch)
+    hit = _img_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
+        return hit[1]
+    img = hit[1] if (hit is not None and hit[1].device == weight.device) else torch.empty(65536 if kind == 0 else 24576, dtype=torch.uint8, device=weight.device)
+    L.call("hesic_sconv_pack_weight_image", kind, L.ptr(weight.detach().contiguous()), L.ptr(gp), L.ptr(img), L.stream())
+    if len(_img_cache) > 64:
+        _img_cache.clear()
+    _img_cache[key] = (tag, img)
+    return img
+
+
 def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transposed, act=0, in_abs=0, tap_mask=0,
                out=None, out_c_off=0, x_c_off=0, f32_out=None):
     """Launch the implicit-GEMM kernel. ``x`` NHWC (may be wider than Cin), returns / fills NHWC ``out``.
@@ -395,7 +414,12 @@ class _ConvFn(torch.autograd.Function):
                 torch.empty((B, Cout, Ho, Wo), dtype=ydt, device=x.device)
             w = weight.detach() if mask is None else (weight.detach() * mask)
             d = _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act)
-            L.call("hesic_sconv2d_forward", C.byref(d), L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(y), L.stream())
+            if transposed and Cin == 128 and Cout == 3 and k == 5 and stride == 2 and mask is None and x.dtype == torch.bfloat16 and weight.dtype == torch.float32:
+                # g_s_conv4: the kernel's LDS weight panel is pre-packed once per weight update
+                L.call("hesic_sconv2d_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(w.contiguous()), L.ptr(_weight_image(1, weight)), L.ptr(bias),
+                       L.ptr(y), L.stream())
+            else:
+                L.call("hesic_sconv2d_forward", C.byref(d), L.ptr(x), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(y), L.stream())
         else:
             x = _nhwc(x)
             wp = packer.get(weight, mask, Cout, Cin, k, k, transposed, False, x.dtype)
@@ -488,6 +512,14 @@ def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
     return gv, dbeta, dgamma
 
 
+def _n2w_image(weight, beta, gamma, gp, x):
+    """LDS image of g_a_conv1's weights + the K-permuted gamma' for the fused 3 -> 128 kernel's fast form (fp32 planar image,
+    5x5 stride 2); None -> the kernel gathers in its prologue (other layouts)."""
+    if tuple(weight.shape) != (128, 3, 5, 5) or weight.dtype != torch.float32 or x.dtype != torch.float32:
+        return None
+    return _weight_image(0, weight, gp, (gamma.data_ptr(), gamma._version, beta._version, gp.data_ptr()))
+
+
 class _SConvGdnFn(torch.autograd.Function):
     """g_a_gdn1(g_a_conv1(image)) fused under autograd (the 3 -> 128 stage): v = conv output is stored next to y."""
 
@@ -501,8 +533,8 @@ class _SConvGdnFn(torch.autograd.Function):
         y = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         v = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         d = _sdesc(x, y, Cin, Cout, k, stride, pad, False)
-        L.call("hesic_sconv2d_gdn_forward_train", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
-               L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
+        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()),
+               L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
         ctx.save_for_backward(x, weight, v, beta, gamma)
         ctx.cfg, ctx.dims, ctx.has_bias, ctx.bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None, bias
         return y
@@ -562,8 +594,8 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
         out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         d = _sdesc(x, out, Cin, Cout, k, stride, padding, False)
-        L.call("hesic_sconv2d_gdn_forward", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(gp),
-               L.ptr(bp), int(inverse), L.ptr(out), L.stream())
+        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()),
+               L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(out), None, L.stream())
         return out
     if torch.is_grad_enabled():
         return _ConvGdnFn.apply(x, weight, bias, beta, gamma, (k, stride, padding, transposed, inverse, beta_min, packer, gdn_packer))

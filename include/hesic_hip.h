@@ -166,6 +166,18 @@ int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const fl
 int hesic_sconv2d_gdn_forward_train(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,
                                     const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
                                     void* stream);
+/* The two image-side MFMA kernels keep their whole weight panel in LDS.  Building that LDS image inside the kernel (scalar
+ * gathers from the PyTorch layout, several dependent round trips, by every block of every launch) cost ~14 us of a ~49 us launch;
+ * hesic_sconv_pack_weight_image builds it ONCE per weight update and the *_prepacked forms start with a straight copy.
+ *   kind 0: g_a_conv1 + GDN (3 -> 128, 5x5 s2): image = 65536 bytes, needs gamma_packed (hesic_gdn_pack_params)
+ *   kind 1: g_s_conv4 (128 -> 3 transposed, 5x5 s2): image = 24576 bytes, gamma_packed ignored
+ * w is still passed (other geometries fall back to the ordinary kernels, which read it).                              */
+int hesic_sconv_pack_weight_image(int kind, const float* w, const void* gamma_packed, void* image, void* stream);
+int hesic_sconv2d_forward_prepacked(const hesic_sconv_desc* d, const void* x, const float* w, const void* w_image, const float* bias,
+                                    void* y, void* stream);
+int hesic_sconv2d_gdn_forward_prepacked(const hesic_sconv_desc* d, const void* x, const float* w, const void* w_image, const float* bias,
+                                        const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* y_pre,
+                                        void* stream);
 /* dx of the same op (dy has y's strides, dx has x's strides). */
 int hesic_sconv2d_dgrad(const hesic_sconv_desc* d, const void* dy, const float* w, void* dx, void* stream);
 /* dw (raw PyTorch layout, fp32) and dbias (may be NULL).  ws (hesic_sconv2d_wgrad_ws_bytes(d) bytes, may be NULL/0) enables the
