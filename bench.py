@@ -52,7 +52,8 @@ class KernelMeter:
     NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward", "hesic_conv2d_forward_grouped")
 
     STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
-              "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)"}
+              "hesic_sconv2d_gdn_forward_prepacked": "conv1_3to128_gdn (n2w)", "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)",
+              "hesic_sconv2d_forward_prepacked": "g_s_conv4_128to3 (w2n)"}
 
     def __init__(self, L):
         self.L, self.orig, self.rec, self.stream = L, L.call, [], {}
@@ -62,7 +63,7 @@ class KernelMeter:
         size = lambda dt: 2 if dt == self.L.BF16 else 4
         if name == "hesic_warp_perspective_forward":
             return d.B * d.C * (d.H * d.W * size(d.src_dtype) + d.Ho * d.Wo * size(d.dst_dtype))
-        if name == "hesic_sconv2d_forward" and not (d.transposed and d.Cin >= 32):
+        if name.startswith("hesic_sconv2d_forward") and not (d.transposed and d.Cin >= 32):
             return None                       # only the 128 -> 3 synthesis output stage is priced here
         return d.B * (d.H * d.W * d.Cin * size(d.x_dtype) + d.Ho * d.Wo * d.Cout * size(d.y_dtype))
 

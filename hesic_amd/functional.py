@@ -228,17 +228,22 @@ _img_cache = {}
 
 def _weight_image(kind, weight, gp=None, gtag=None):
     """LDS weight image of an image-side MFMA kernel (``hesic_sconv_pack_weight_image``), cached per weight (+ GDN parameters)
-    version: kind 0 = g_a_conv1 + GDN (64 KB, needs the packed gamma'), kind 1 = g_s_conv4 (24 KB)."""
+    version: kind 0 = g_a_conv1 + GDN (64 KB, needs the packed gamma'), kind 1 = g_s_conv4 (24 KB).  The entry remembers the
+    tensor OBJECT (weak reference): an address / version pair alone would also match a new tensor allocated where a dead one was."""
+    import weakref
     key = (kind, weight.data_ptr())
     tag = (weight._version, gtag, _cache_epoch)
     hit = _img_cache.get(key)
-    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
+    if hit is not None and hit[0] == tag and hit[2]() is weight:
         return hit[1]
-    img = hit[1] if (hit is not None and hit[1].device == weight.device) else torch.empty(65536 if kind == 0 else 24576, dtype=torch.uint8, device=weight.device)
+    img = torch.empty(65536 if kind == 0 else 24576, dtype=torch.uint8, device=weight.device)
     L.call("hesic_sconv_pack_weight_image", kind, L.ptr(weight.detach().contiguous()), L.ptr(gp), L.ptr(img), L.stream())
     if len(_img_cache) > 64:
         _img_cache.clear()
-    _img_cache[key] = (tag, img)
+    try:
+        _img_cache[key] = (tag, img, weakref.ref(weight))
+    except TypeError:
+        pass
     return img
 
 
