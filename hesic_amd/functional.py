@@ -1074,27 +1074,15 @@ class _GmmFn(torch.autograd.Function):
         y = _nhwc(y)
         if means is None:
             means = _zeros(scales.shape, scales.dtype, scales.device).contiguous(memory_format=_CL) if scales.dim() == 4 else _zeros(scales.shape, scales.dtype, scales.device)
-        # scales / means may be the two halves of one tensor (chunk(2,1)): keep them in place
-        same = (scales.dim() == 4 and means.dim() == 4 and scales._base is not None and scales._base is means._base
-                and scales._base.is_contiguous(memory_format=_CL) and scales._base.dtype == y.dtype)
-        ok = False
-        if same:
-            base = scales._base
-            ps = base.shape[1]
-            s_off = scales.storage_offset() - base.storage_offset()
-            m_off = means.storage_offset() - base.storage_offset()
-            sp = mp = base
-            ok = 0 <= s_off < ps and 0 <= m_off < ps and base.shape[0] == B and base.shape[2:] == y.shape[2:]
-        if not ok:
-            scales, means = _nhwc(scales.to(y.dtype)), _nhwc(means.to(y.dtype))
-            ps, s_off, m_off, sp, mp = K * M, 0, 0, scales, means
+        # scales / means may be channel slices of one tensor (chunk(2,1)): read in place
+        ps, sptr, mptr, _keep = _sm_pointers(scales.detach(), means.detach(), y, B, K, M)
+        if ps == K * M:
+            scales, means = _keep
         wts = None if weights is None else weights.detach().reshape(B, K * M).to(torch.float32).contiguous()
         yh = torch.empty_like(y, memory_format=_CL)
         lik = _empty_nhwc(B, M, H, W, torch.float32, y.device)
         nz = None if noise is None else _nhwc(noise.to(y.dtype))
         d = L.GmmDesc(B, H * W, M, K, L.dt(y), int(use_means_in_quant), ps, 0, 0, float(scale_bound), float(lik_bound))
-        sptr = C.c_void_p(sp.data_ptr() + s_off * sp.element_size())
-        mptr = C.c_void_p(mp.data_ptr() + m_off * mp.element_size())
         L.call("hesic_gmm_forward", C.byref(d), L.ptr(y), sptr, mptr, L.ptr(wts), L.ptr(nz), L.ptr(yh), L.ptr(lik), None,
                L.stream())
         ctx.save_for_backward(y, scales, means, wts, nz)
@@ -1122,18 +1110,19 @@ class _GmmFn(torch.autograd.Function):
 
 
 def _sm_pointers(scales, means, y, B, K, M):
-    """(stride, scales ptr, means ptr, keep-alive) of the two parameter maps in ``y``'s dtype; the two halves of one
-    channels_last tensor (``chunk(2, 1)``) stay in place."""
-    same = (scales.dim() == 4 and means.dim() == 4 and scales._base is not None and scales._base is means._base
-            and scales._base.is_contiguous(memory_format=_CL) and scales._base.dtype == y.dtype)
-    if same:
-        base = scales._base
-        ps = base.shape[1]
-        s_off = scales.storage_offset() - base.storage_offset()
-        m_off = means.storage_offset() - base.storage_offset()
-        if 0 <= s_off < ps and 0 <= m_off < ps and base.shape[0] == B and base.shape[2:] == y.shape[2:]:
-            es = base.element_size()
-            return ps, C.c_void_p(base.data_ptr() + s_off * es), C.c_void_p(base.data_ptr() + m_off * es), (base,)
+    """(pixel stride, scales ptr, means ptr, keep-alive) of the two parameter maps in ``y``'s dtype.  Channel slices of wider
+    channels_last tensors (``chunk(2, 1)`` of HESIC+'s entropy parameters, the sigma | means halves of the grouped hyper-synthesis
+    output) are read in place: all the kernels need is NHWC with one common pixel stride."""
+    def nhwc_stride(t):
+        if t.dim() != 4 or t.dtype != y.dtype or t.shape[0] != B or t.shape[2:] != y.shape[2:]:
+            return None
+        sb, sc, sh, sw = t.stride()
+        H, W = t.shape[2], t.shape[3]
+        ok = sc == 1 and sw >= t.shape[1] and (W == 1 or sh == W * sw) and (B == 1 or sb == H * W * sw) and (H == 1 or sh == W * sw)
+        return sw if ok else None
+    ps_s, ps_m = nhwc_stride(scales), nhwc_stride(means)
+    if ps_s is not None and ps_s == ps_m and scales.shape[1] == K * M and means.shape[1] == K * M:
+        return ps_s, L.ptr(scales), L.ptr(means), (scales, means)
     scales, means = _nhwc(scales.to(y.dtype)), _nhwc(means.to(y.dtype))
     return K * M, L.ptr(scales), L.ptr(means), (scales, means)
 
