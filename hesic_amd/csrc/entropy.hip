@@ -165,42 +165,61 @@ __device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* r
     return dv;
 }
 
+// block = 64 channels x EB_PL pixel lanes: the lanes of a channel walk different pixels and meet in LDS before the block's
+// 59 atomics per channel (round 1 ran one pixel lane: 8 serial pixels of ~1000 flops each per thread on the 8 x 8 maps)
+constexpr int EB_PL = 4;
 template <typename T>
-__global__ __launch_bounds__(64) void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+__global__ __launch_bounds__(64 * EB_PL) void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
                               const float* __restrict__ glik, const T* __restrict__ gzhat, T* __restrict__ dz,
                               float* __restrict__ dparams, int64_t P, int C) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float* raw = params + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    __shared__ float red[EB_PL - 1][64][EB_NP + 1];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < C;
+    const float* raw = params + (int64_t)(live ? c : 0) * HESIC_EB_PARAM_STRIDE;
     EBParams q;
     eb_load(raw, q);
     const float med = raw[EB_MED], bound = raw[EB_BOUND];
     float gp[EB_NP + 1];
 #pragma unroll
     for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
-    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
-        const int64_t i = p * C + c;
-        const float zv = elem<T>::ld(z + i);
-        const float v = noise ? zv + elem<T>::ld(noise + i) : rintf(zv - med) + med;
-        const float lo = eb_logits(q, v - 0.5f, nullptr, nullptr), up = eb_logits(q, v + 0.5f, nullptr, nullptr);
-        const float s = -signf(lo + up);
-        const float A = sigmoidf(s * up), Bv = sigmoidf(s * lo), dlt = A - Bv;
-        float g = glik[i];
-        if (!(fabsf(dlt) >= bound || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
-        const float sg = signf(dlt) * g;
-        const float gU = sg * A * (1.f - A) * s, gL = -sg * Bv * (1.f - Bv) * s;
-        float dv = eb_logits_bwd(q, raw, v + 0.5f, gU, gp) + eb_logits_bwd(q, raw, v - 0.5f, gL, gp);
-        if (gzhat) dv += elem<T>::ld(gzhat + i);
-        if (noise) {
-            elem<T>::st(dz + i, dv);
-        } else {
-            elem<T>::st(dz + i, 0.f);     // round() has zero gradient; "+ median" passes it to the median
-            gp[EB_MED] += dv;
+    if (live) {
+        for (int64_t p = (int64_t)blockIdx.x * EB_PL + pl; p < P; p += (int64_t)gridDim.x * EB_PL) {
+            const int64_t i = p * C + c;
+            const float zv = elem<T>::ld(z + i);
+            const float v = noise ? zv + elem<T>::ld(noise + i) : rintf(zv - med) + med;
+            const float lo = eb_logits(q, v - 0.5f, nullptr, nullptr), up = eb_logits(q, v + 0.5f, nullptr, nullptr);
+            const float s = -signf(lo + up);
+            const float A = sigmoidf(s * up), Bv = sigmoidf(s * lo), dlt = A - Bv;
+            float g = glik[i];
+            if (!(fabsf(dlt) >= bound || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
+            const float sg = signf(dlt) * g;
+            const float gU = sg * A * (1.f - A) * s, gL = -sg * Bv * (1.f - Bv) * s;
+            float dv = eb_logits_bwd(q, raw, v + 0.5f, gU, gp) + eb_logits_bwd(q, raw, v - 0.5f, gL, gp);
+            if (gzhat) dv += elem<T>::ld(gzhat + i);
+            if (noise) {
+                elem<T>::st(dz + i, dv);
+            } else {
+                elem<T>::st(dz + i, 0.f);     // round() has zero gradient; "+ median" passes it to the median
+                gp[EB_MED] += dv;
+            }
         }
     }
-    float* out = dparams + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+    if (pl > 0) {
 #pragma unroll
-    for (int i = 0; i <= EB_NP; ++i) atomicAdd(out + i, gp[i]);
+        for (int i = 0; i <= EB_NP; ++i) red[pl - 1][cl][i] = gp[i];
+    }
+    __syncthreads();
+    if (pl == 0 && live) {
+        float* out = dparams + (int64_t)c * HESIC_EB_PARAM_STRIDE;
+#pragma unroll
+        for (int i = 0; i <= EB_NP; ++i) {
+            float v = gp[i];
+#pragma unroll
+            for (int l = 0; l < EB_PL - 1; ++l) v += red[l][cl][i];
+            atomicAdd(out + i, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------- Gaussian / Gaussian mixture
@@ -470,15 +489,15 @@ extern "C" int hesic_eb_prepare_params(const float* params, float* prepared, int
 extern "C" int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
                                  void* dz, float* dparams, int64_t P, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(z && params && g_lik && dz && dparams && P > 0 && C > 0, "eb_backward: bad arguments");
-    const int bx = 64;
-    // every thread ends in 59 atomics on its channel's gradient row; they serialise per address, so keep the number of
+    // every block ends in 59 atomics per channel on the gradient row; they serialise per address, so keep the number of
     // pixel slices (= contenders per address) at 64
-    const dim3 grid((unsigned)(P < 64 ? P : 64), (C + bx - 1) / bx);
+    const int64_t slices = (P + EB_PL - 1) / EB_PL;
+    const dim3 grid((unsigned)(slices < 64 ? slices : 64), (C + 63) / 64), block(64 * EB_PL);
     if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const bf16_t*)z, params,
+        hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)z, params,
                            (const bf16_t*)noise, g_lik, (const bf16_t*)g_zhat, (bf16_t*)dz, dparams, P, C);
     else
-        hipLaunchKernelGGL(eb_bwd_kernel<float>, grid, dim3(bx), 0, (hipStream_t)stream, (const float*)z, params,
+        hipLaunchKernelGGL(eb_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)z, params,
                            (const float*)noise, g_lik, (const float*)g_zhat, (float*)dz, dparams, P, C);
     HESIC_LAUNCH_RETURN("eb_backward");
 }
