@@ -309,8 +309,9 @@ def gmm_hyper_y2(P, z_hat, y1, K, M):
 
 
 # -------------------------------------------------------------------- whole models
-def hsic_forward(P, x1, x2, Hm, K=5, M=192, training=False, noise=None, align_corners=True):
-    """HSIC.forward (ywz/mywork/newnet1.py:724-783).
+def hsic_forward(P, x1, x2, Hm, K=5, M=192, training=False, noise=None, align_corners=True, return_gmm=False):
+    """HSIC.forward (ywz/mywork/newnet1.py:724-783).  ``return_gmm``: also hand back the (sigma, means, weights) triples and the
+    un-quantised z of both views (what ``HSIC.compress``, :823-906, codes).
 
     ``noise`` (training only): dict with keys z1,y1,y1w,z2,y2 -- the five U(-1/2,1/2)
     draws in the order the reference makes them (SURVEY.md §7 hard parts).
@@ -335,9 +336,12 @@ def hsic_forward(P, x1, x2, Hm, K=5, M=192, training=False, noise=None, align_co
     s2, m2, w2 = gmm_hyper_y2(P, z2_hat, y1_hat_w, K, M)
     y2_hat, y2_lik = gmm_forward(y2, s2, m2, w2, K, training, nz.get("y2"))
     x2_hat = decoder2(P, y2_hat, x1_hat_warp)
-    return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
-            "z1_hat": z1_hat, "z2_hat": z2_hat,
-            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+    out = {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+           "z1_hat": z1_hat, "z2_hat": z2_hat,
+           "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+    if return_gmm:
+        out.update(gmm1=(s1, m1, w1), gmm2=(s2, m2, w2), z1=z1, z2=z2)
+    return out
 
 
 def _seq(P, pre, x, spec):
@@ -389,9 +393,12 @@ def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=
     sc2, mu2 = gp2.chunk(2, 1)
     _, y2_lik = gc_forward(y2, sc2, mu2, training, nz.get("y2b"))
     x2_hat = decoder2(P, y2_hat, x1_hat_warp)
-    return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
-            "z1_hat": z1_hat, "z2_hat": z2_hat,
-            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+    out = {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
+           "z1_hat": z1_hat, "z2_hat": z2_hat,
+           "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+    if return_gmm:
+        out.update(gmm1=(s1, m1, w1), gmm2=(s2, m2, w2), z1=z1, z2=z2)
+    return out
 
 
 # ------------------------------------------------------ enhancement

@@ -90,6 +90,64 @@ def test_oracle_cdf_tables_shape_and_monotone():
     assert (np.abs(t[..., -1].astype(np.int64) - 65536) <= 9).all()
 
 
+def _ref_compress_case():
+    from conftest import load_golden
+    from oracle import hesic_oracle as O
+    from test_oracle_golden import _model_params
+    g = load_golden("codec_model_64.npz")
+    P = _model_params("hsic")
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 64, 64)
+    with torch.no_grad():
+        out = O.hsic_forward(P, x1, x2, Hm, return_gmm=True)
+    return g, P, out
+
+
+def test_oracle_tables_and_symbols_match_the_reference_compress_run():
+    """tests/golden/codec_model_64.npz is a run of the reference's own HSIC.compress (newnet1.py:823-1066) with a recording
+    stand-in for its third-party range-coder object: every encode([symbol], cdf) call in order.  The oracle reproduces the
+    latent range, the coding order (channel-major over the non-zero channels, rows, columns; view 1 then view 2), every symbol
+    and every cumulative-frequency table of view 1 (every third of view 2) EXACTLY."""
+    from oracle import hesic_oracle as O
+    g, P, out = _ref_compress_case()
+    n1, pos = int(g["n_view1"]), 0
+    for v, (yk, gk) in enumerate((("y1_hat", "gmm1"), ("y2_hat", "gmm2"))):
+        y = out[yk][0].numpy().astype(np.int64)
+        minmax = int(max(np.abs(y).max(), 1))
+        assert minmax == int(g["minmax"][v])
+        channels = [c for c in range(192) if np.abs(y[c]).sum() > 0]
+        sym = (y[channels] + minmax).reshape(-1)
+        want = g["symbols"][pos:pos + sym.size]
+        assert np.array_equal(sym, want)
+        s_, m_, w_ = out[gk]
+        tables = O.compress_cdf_tables(s_, m_, w_, channels, minmax, 5, 192).reshape(-1, 2 * minmax + 2)
+        ref = g["tables1"] if v == 0 else g["tables2_every3"]
+        assert np.array_equal(tables if v == 0 else tables[::3], ref)
+        pos += sym.size
+    assert pos == g["symbols"].size and n1 == 192 * 16
+
+
+def test_side_information_file_matches_the_reference_byte_for_byte():
+    """The header file the reference writes (uint16 H, W; per view uint16 len(z), uint16 minmax, M/8 flag bytes, the
+    EntropyBottleneck rANS string; newnet1.py:876-906) rebuilt from the oracle's latents with THIS repository's
+    EntropyBottleneck.update / compress (host C++ coder): identical bytes."""
+    from compressai.entropy_models import EntropyBottleneck
+    g, P, out = _ref_compress_case()
+    head = bytearray(np.array([64, 64], dtype=np.uint16).tobytes())
+    for v in (1, 2):
+        eb = EntropyBottleneck(128)
+        eb.load_state_dict({k.split(".", 1)[1]: t for k, t in P.items() if k.startswith(f"entropy_bottleneck{v}.") and "_offset" not in k
+                            and "_quantized_cdf" not in k and "_cdf_length" not in k}, strict=False)
+        eb.update(force=True)
+        z_string = eb.compress(out[f"z{v}"])[0]
+        y = out[f"y{v}_hat"][0].numpy().astype(np.int64)
+        flag = (np.abs(y).sum(axis=(1, 2)) > 0).astype(np.uint8)
+        head += np.array([len(z_string), max(int(np.abs(y).max()), 1)], dtype=np.uint16).tobytes() + np.packbits(flag).tobytes() + z_string
+        assert len(z_string) == int(g["zlen"][v - 1])
+        back = eb.decompress([z_string], out[f"z{v}"].shape[-2:])
+        assert torch.equal(back, out[f"z{v}_hat"])
+    assert bytes(head) == g["header"].tobytes()
+
+
 # ----------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -188,5 +246,45 @@ def test_gpu_joint_compress_decompress_round_trip(tmp_path, dtype):
         # loose: the forward's likelihood is evaluated at round(y - mu) + mu (GaussianConditional quantises around the mean,
         # newnet1_joint.py:689-691) while the stream, like the reference's, codes round(y) under the same Gaussian
         assert abs(enc["bpp_real"] - est) < 0.15 * est + 0.05, (enc["bpp_real"], est)
+    finally:
+        hesic_amd.set_compute_dtype(prev)
+
+
+@pytest.mark.gpu
+def test_gpu_compress_matches_the_reference_compress_run(tmp_path):
+    """HSIC.compress on the HIP path (fp32) against the recorded reference run: the side-information file byte for byte, and the
+    cumulative-frequency tables of hesic_gmm_cdf in the reference's coding order (a frequency on a rounding boundary may move
+    by one count of 65536 where the device erfc differs in the last ulp)."""
+    import hesic_amd
+    from conftest import load_golden
+    from hesic_amd import models
+    g = load_golden("codec_model_64.npz")
+    prev = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.float32)
+    try:
+        net = models.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.cuda().eval()
+        net.update(force=True)
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 1, 64, 64))
+        net.compress(x1, x2, Hm, "pair0", str(tmp_path))
+        assert open(tmp_path / "pair0.npz", "rb").read() == g["header"].tobytes()
+        with torch.no_grad():
+            v1, v2 = net._analysis(x1, x2, Hm)
+        n1, pos = int(g["n_view1"]), 0
+        for v, (y_hat, _z, _s, gmm) in enumerate((v1, v2)):
+            minmax = int(g["minmax"][v])
+            chans = list(range(192))
+            sym, tabs = [], []
+            for _ch, s_, cdf in net._cdf_chunks(gmm, chans, minmax, net.gaussian1._bound(), y_hat):
+                sym.append(s_)
+                tabs.append(cdf.astype(np.int64))
+            sym, tabs = np.concatenate(sym), np.concatenate(tabs)
+            assert np.array_equal(sym, g["symbols"][pos:pos + sym.size])
+            ref = (g["tables1"] if v == 0 else g["tables2_every3"]).astype(np.int64)
+            got = tabs if v == 0 else tabs[::3]
+            dfreq = np.abs(np.diff(got, axis=-1) - np.diff(ref, axis=-1))
+            assert dfreq.max() <= 1 and (dfreq.max(axis=1) > 0).mean() < 0.05
+            pos += sym.size
     finally:
         hesic_amd.set_compute_dtype(prev)
