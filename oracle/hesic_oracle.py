@@ -396,8 +396,6 @@ def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=
     out = {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
            "z1_hat": z1_hat, "z2_hat": z2_hat,
            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
-    if return_gmm:
-        out.update(gmm1=(s1, m1, w1), gmm2=(s2, m2, w2), z1=z1, z2=z2)
     return out
 
 
