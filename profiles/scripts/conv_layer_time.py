@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256, help="input height = width of the layer")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--dump", default="", help="save the layer output here (to compare A/B variants bit for bit)")
+    ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph (no host launch cost in the figure)")
     args = ap.parse_args()
     import hesic_amd
     from compressai.layers import GDN
@@ -38,11 +40,30 @@ def main():
         for _ in range(5):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            f()
-        e1.record()
+        if args.graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                f()
+            torch.cuda.current_stream().wait_stream(s)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                for _ in range(args.iters):
+                    f()
+            g_.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            g_.replay()
+            e1.record()
+        else:
+            e0.record()
+            for _ in range(args.iters):
+                f()
+            e1.record()
         torch.cuda.synchronize()
+    if args.dump:
+        with torch.no_grad():
+            torch.save(f().float().cpu(), args.dump)
     us = e0.elapsed_time(e1) / args.iters * 1e3
     print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   WS={os.environ.get('HESIC_IGEMM_WS', '0')} DBG={os.environ.get('HESIC_IGEMM_DBG', '0')}")
 
