@@ -29,17 +29,28 @@ _side_streams = {}
 
 
 def _side_stream(device, idx=0):
+    """Side stream ``idx`` of the schedule: a fixed small set per device.  torch hands out streams from a pool of 32 per device
+    round-robin, so a NEW stream object may alias one that already exists (another side stream or the caller's current / capture
+    stream); a fork onto an alias is a stream waiting for itself or a nested fork (which crashes hipStreamEndCapture) -- checked here."""
     key = (device.type, device.index, idx)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
+    cur = torch.cuda.current_stream(device).cuda_stream
+    taken = {cur} | {st.cuda_stream for k, st in _side_streams.items() if k[:2] == key[:2] and k != key}
+    st = _side_streams.get(key)
+    tries = 0
+    while st is None or st.cuda_stream in taken:
+        st = torch.cuda.Stream(device=device)
+        tries += 1
+        if tries > 64:
+            raise RuntimeError("no free HIP stream for the inference schedule")
+    _side_streams[key] = st
+    return st
 
 
 def _branches(ref, *fns):
     """Run independent branches; at inference each extra branch gets its own HIP stream (forked from / joined to the
     current one) so their small kernels overlap.  Returns the branch results in order."""
-    if not (OVERLAP_STREAMS and ref.is_cuda and not torch.is_grad_enabled()):
-        return [f() for f in fns]
+    if not (OVERLAP_STREAMS and ref.is_cuda and not torch.is_grad_enabled()) or _Fork.depth:
+        return [f() for f in fns]          # inside a fork: in order (a fork joined back into a forked stream crashes hipStreamEndCapture, ROCm 7.2)
     cur = torch.cuda.current_stream()
     outs = [None] * len(fns)
     streams = [_side_stream(ref.device, 1 + i) for i in range(len(fns) - 1)]
@@ -55,6 +66,55 @@ def _branches(ref, *fns):
         for t in (o if isinstance(o, (tuple, list)) else (o,)):
             t.record_stream(cur)
     return outs
+
+
+def _tensors(o):
+    if torch.is_tensor(o):
+        yield o
+    elif isinstance(o, (tuple, list)):
+        for t in o:
+            yield from _tensors(t)
+
+
+class _Fork:
+    """One branch of the inference schedule on its own HIP stream: starts where the forking stream stands (plus the branches it
+    needs), ``join`` makes a stream wait for it and hands its tensors over to that stream's allocator bookkeeping."""
+
+    depth = 0
+
+    def __init__(self, stream, fn, after=()):
+        self.stream = stream
+        stream.wait_stream(torch.cuda.current_stream())
+        for f in after:
+            stream.wait_stream(f.stream)
+        with torch.cuda.stream(stream):
+            for f in after:
+                for t in _tensors(f.out):
+                    t.record_stream(stream)
+            _Fork.depth += 1
+            try:
+                self.out = fn()
+            finally:
+                _Fork.depth -= 1
+
+    def then(self, fn):
+        """More work on the same stream, after everything the forking stream has issued so far."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            _Fork.depth += 1
+            try:
+                out = fn()
+            finally:
+                _Fork.depth -= 1
+        self.out = (self.out, out)
+        return self
+
+    def join(self, stream=None):
+        stream = stream or torch.cuda.current_stream()
+        stream.wait_stream(self.stream)
+        for t in _tensors(self.out):
+            t.record_stream(stream)
+        return self.out
 
 
 class StereoCompressionModel(nn.Module):
@@ -532,10 +592,13 @@ class HSIC(StereoCompressionModel):
                 "dectime": time.time() - start}
 
     def _forward_eval(self, x1, x2, h_matrix, two_streams=True):
-        """Inference schedule.  View 2's analysis (warp -> encoder2 -> h_a2 -> bottleneck) depends only on the inputs, so
-        with ``two_streams`` it runs on a side HIP stream while the main stream walks view 1's chain
-        (encoder1 -> hyper path -> decoder1 -> warp -> encoder1); the many small hyper-path kernels of one stream fill
-        the CUs the other stream's tail blocks leave idle.  Results are identical to the single-stream order.
+        """Inference schedule.  The chain that bounds the step is encoder1 -> round -> decoder1 -> warp -> {decoder2 | encoder1 ->
+        h_s2 -> likelihood}: the reconstructions need the ROUNDED latents only (the mixture's quantiser takes no means,
+        entropy_models.py:661-702), the hyper paths only price them.  With ``two_streams`` the main stream walks that chain and
+        everything else is forked beside it: view 2's analysis (warp -> encoder2 -> round; h_a2 -> bottleneck), which depends only
+        on the inputs; view 1's rate (h_a1 -> bottleneck -> h_s1 -> likelihood), as soon as y1 exists; decoder2, as soon as the
+        warped reconstruction and y2_hat exist.  The small-grid kernels of one branch fill the CUs the others leave idle.  Results
+        are identical to the single-stream order (``HESIC_NO_OVERLAP=1``; the tests run both).
 
         What feeds round() and the likelihoods -- y, z, sigma, mu -- is fp32 even in the bf16 mode (``Fn.fp32_latents``):
         those convs also / only write their fp32 accumulators, the entropy kernels read fp32 and store the integer-valued
@@ -543,36 +606,60 @@ class HSIC(StereoCompressionModel):
         size = (x1.shape[-2], x1.shape[-1])
         cdt = Fn.compute_dtype()
 
-        def view2_front():
+        def view2_latents():
             x1_warp = warp_perspective(x1, h_matrix, size)
             y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
-            z2 = self._h_a2.latent(y2_lo)
-            z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None, out_dtype=cdt)
-            return y2, z2_hat, z2_lik
+            return y2_lo, y2, _round_latent(self.gaussian2, y2)
 
-        if two_streams:
-            main = torch.cuda.current_stream()
-            side = _side_stream(x1.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                y2, z2_hat, z2_lik = view2_front()
-        y1_lo, y1 = self.encoder1.latent(x1)
-        z1 = self._h_a1.latent(y1_lo)
-        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None, out_dtype=cdt)
-        s1, m1, w1 = self._h_s1(z1_hat, hi=True)
-        y1_hat, y1_lik = self.gaussian1(y1, s1, m1, w1, out_dtype=cdt)
-        x1_hat = self.decoder1(y1_hat)
-        x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)          # :753 and :767 are the same tensor
-        y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
-        if two_streams:
-            main.wait_stream(side)
-            for t in (y2, z2_hat, z2_lik):            # produced on the side stream, consumed / freed on the main one
-                t.record_stream(main)
+        def view2_hyper(y2_lo):
+            return self.entropy_bottleneck2.forward_with_noise(self._h_a2.latent(y2_lo), None, out_dtype=cdt)
+
+        def view1_rate(y1_lo, y1):
+            z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(self._h_a1.latent(y1_lo), None, out_dtype=cdt)
+            s1, m1, w1 = self._h_s1(z1_hat, hi=True)
+            return self.gaussian1(y1, s1, m1, w1, out_dtype=cdt)[1], z1_lik
+
+        if not (two_streams and x1.is_cuda):
+            y1_lo, y1 = self.encoder1.latent(x1)
+            y1_hat = _round_latent(self.gaussian1, y1)
+            y1_lik, z1_lik = view1_rate(y1_lo, y1)
+            x1_hat = self.decoder1(y1_hat)
+            x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)          # :753 and :767 are the same tensor
+            y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+            y2_lo, y2, y2_hat = view2_latents()
+            z2_hat, z2_lik = view2_hyper(y2_lo)
+            s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
+            y2_lik = self.gaussian2(y2, s2, m2, w2, out_dtype=cdt)[1]
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         else:
-            y2, z2_hat, z2_lik = view2_front()
-        s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
-        y2_hat, y2_lik = self.gaussian2(y2, s2, m2, w2, out_dtype=cdt)
-        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+            main, dev = torch.cuda.current_stream(), x1.device
+            # Four streams in all: main, view 2 (its analysis, then decoder2), view 1's rate, h_s2's side branch.  Measured on one
+            # box, 512^2 B=8, ms per step: the round-1/2 schedule (decoders behind the likelihoods) 2.19; this one 2.06-2.09; decoder2
+            # and h_a2 on streams of their own 2.05 in five runs of six and 2.19 in the sixth (five streams share the runtime's four
+            # hardware queues; which two share changes the result); the same with GPU_MAX_HW_QUEUES=8: 2.80 (two full-grid kernels
+            # side by side slow each other more than the overlap buys); everything off the chain on ONE side stream: 2.14-2.17.
+            def view2_front():
+                y2_lo, y2, y2_hat = view2_latents()
+                return y2, y2_hat, view2_hyper(y2_lo)
+
+            v2 = _Fork(_side_stream(dev, 10), view2_front)
+            y1_lo, y1 = self.encoder1.latent(x1)
+            y1_hat = _round_latent(self.gaussian1, y1)
+            r1 = _Fork(_side_stream(dev, 12), lambda: view1_rate(y1_lo, y1))
+            x1_hat = self.decoder1(y1_hat)
+            x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+            ev2 = torch.cuda.Event()
+            ev2.record(v2.stream)                       # view 2's latents and hyper-latents exist from here on
+            v2.then(lambda: self.decoder2(v2.out[1], x1_hat_warp))
+            y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+            main.wait_event(ev2)
+            y2, y2_hat, (z2_hat, z2_lik) = v2.out[0]
+            for t in (y2, z2_hat, z2_lik):
+                t.record_stream(main)
+            s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
+            y2_lik = self.gaussian2(y2, s2, m2, w2, out_dtype=cdt)[1]
+            y1_lik, z1_lik = r1.join()
+            x2_hat = v2.join()[1]
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
@@ -662,30 +749,56 @@ class HSICJoint(StereoCompressionModel):
 
 
     def _forward_eval(self, x1, x2, h_matrix):
-        """Inference: y, z and the (scale, mean) maps are fp32 even in the bf16 mode (see ``HSIC._forward_eval``)."""
+        """Inference: y, z and the (scale, mean) maps are fp32 even in the bf16 mode, and the same schedule as ``HSIC._forward_eval``:
+        the main stream walks encoder1 -> round -> decoder1 -> warp -> encoder1 -> view 2's context model; view 2's analysis with
+        its whole hyper path (inputs only) and then decoder2 run on a second stream, view 1's rate on a third."""
         size = (x1.shape[-2], x1.shape[-1])
         cdt = Fn.compute_dtype()
-        y1_lo, y1 = self.encoder1.latent(x1)
-        z1 = _seq3_hi(self.h_a1, y1_lo)
-        z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(z1, None, out_dtype=cdt)
-        params1 = _seq3(self.h_s1, z1_hat)
-        y1_hat = _round_latent(self.gaussian_conditional1, y1)
-        sc1, mu1 = self._gauss_full(1, params1, y1_hat)
-        _, y1_lik = self.gaussian_conditional1(y1, sc1, means=mu1, out_dtype=cdt)
-        x1_hat = self.decoder1(y1_hat)
 
-        x1_warp = warp_perspective(x1, h_matrix, size)
-        y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
-        z2 = _seq3_hi(self.h_a2, y2_lo)
-        z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(z2, None, out_dtype=cdt)
+        def view2_front():
+            x1_warp = warp_perspective(x1, h_matrix, size)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            y2_hat = _round_latent(self.gaussian_conditional2, y2)
+            z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(_seq3_hi(self.h_a2, y2_lo), None, out_dtype=cdt)
+            return y2, y2_hat, _seq3(self.h_s2, z2_hat), z2_lik
+
+        def view1_rate(y1_lo, y1, y1_hat):
+            z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(_seq3_hi(self.h_a1, y1_lo), None, out_dtype=cdt)
+            sc1, mu1 = self._gauss_full(1, _seq3(self.h_s1, z1_hat), y1_hat)
+            return self.gaussian_conditional1(y1, sc1, means=mu1, out_dtype=cdt)[1], z1_lik
+
+        overlap = OVERLAP_STREAMS and x1.is_cuda
+        if overlap:
+            main, dev = torch.cuda.current_stream(), x1.device
+            v2 = _Fork(_side_stream(dev, 10), view2_front)
+        y1_lo, y1 = self.encoder1.latent(x1)
+        y1_hat = _round_latent(self.gaussian_conditional1, y1)
+        if overlap:
+            r1 = _Fork(_side_stream(dev, 12), lambda: view1_rate(y1_lo, y1, y1_hat))
+        else:
+            y1_lik, z1_lik = view1_rate(y1_lo, y1, y1_hat)
+        x1_hat = self.decoder1(y1_hat)
         x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
+        if overlap:
+            ev2 = torch.cuda.Event()
+            ev2.record(v2.stream)
+            y2, y2_hat, params2, z2_lik = v2.out
+            v2.then(lambda: self.decoder2(y2_hat, x1_hat_warp))
+        else:
+            y2, y2_hat, params2, z2_lik = view2_front()
         y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
-        params2 = _seq3(self.h_s2, z2_hat)
-        y2_hat = _round_latent(self.gaussian_conditional2, y2)
+        if overlap:
+            main.wait_event(ev2)
+            for t in (y2, y2_hat, params2, z2_lik):
+                t.record_stream(main)
         sc2, mu2 = self._gauss_full(2, params2, y2_hat, y1_hat_w)
         # the reference evaluates view 2 with gaussian_conditional1 as well (:725); no learnable state, harmless
         _, y2_lik = self.gaussian_conditional1(y2, sc2, means=mu2, out_dtype=cdt)
-        x2_hat = self.decoder2(y2_hat, x1_hat_warp)
+        if overlap:
+            y1_lik, z1_lik = r1.join()
+            x2_hat = v2.join()[1]
+        else:
+            x2_hat = self.decoder2(y2_hat, x1_hat_warp)
         return {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
                 "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
 
