@@ -82,9 +82,12 @@ class _Fork:
 
     depth = 0
 
-    def __init__(self, stream, fn, after=()):
+    def __init__(self, stream, fn, after=(), start=None):
         self.stream = stream
-        stream.wait_stream(torch.cuda.current_stream())
+        if start is not None:
+            stream.wait_event(start)                    # fork from an EARLIER point of the forking stream
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
         for f in after:
             stream.wait_stream(f.stream)
         with torch.cuda.stream(stream):
@@ -97,9 +100,12 @@ class _Fork:
             finally:
                 _Fork.depth -= 1
 
-    def then(self, fn):
-        """More work on the same stream, after everything the forking stream has issued so far."""
-        self.stream.wait_stream(torch.cuda.current_stream())
+    def then(self, fn, start=None):
+        """More work on the same stream, after everything the forking stream has issued so far (or up to the event ``start``)."""
+        if start is not None:
+            self.stream.wait_event(start)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             _Fork.depth += 1
             try:
@@ -642,16 +648,24 @@ class HSIC(StereoCompressionModel):
                 y2_lo, y2, y2_hat = view2_latents()
                 return y2, y2_hat, view2_hyper(y2_lo)
 
+            # The chain is ISSUED first and the side branches fork from events on it: kernels reach a stream -- and nodes a captured
+            # graph -- in issue order, and a branch issued in front of the chain's next kernel was seen to run in front of it.
+            def here(stream):
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                return ev
+
             v2 = _Fork(_side_stream(dev, 10), view2_front)
             y1_lo, y1 = self.encoder1.latent(x1)
             y1_hat = _round_latent(self.gaussian1, y1)
-            r1 = _Fork(_side_stream(dev, 12), lambda: view1_rate(y1_lo, y1))
+            ev_y1 = here(main)
             x1_hat = self.decoder1(y1_hat)
             x1_hat_warp = warp_perspective(x1_hat, h_matrix, size)
-            ev2 = torch.cuda.Event()
-            ev2.record(v2.stream)                       # view 2's latents and hyper-latents exist from here on
-            v2.then(lambda: self.decoder2(v2.out[1], x1_hat_warp))
+            ev_xw = here(main)
             y1_hat_w = _round_latent(self.gaussian1, self.encoder1.latent(x1_hat_warp, want_lo=False)[1])
+            ev2 = here(v2.stream)                       # view 2's latents and hyper-latents exist from here on
+            v2.then(lambda: self.decoder2(v2.out[1], x1_hat_warp), start=ev_xw)
+            r1 = _Fork(_side_stream(dev, 12), lambda: view1_rate(y1_lo, y1), start=ev_y1)
             main.wait_event(ev2)
             y2, y2_hat, (z2_hat, z2_lik) = v2.out[0]
             for t in (y2, z2_hat, z2_lik):
@@ -1082,12 +1096,20 @@ def rate_distortion(out, x1, x2):
     returns dict(bits_{y1,y2,z1,z2}, sse1, sse2, num_pixels)."""
     keys = list(out["likelihoods"].keys())
     acc = Fn._zeros(len(keys) + 2, torch.float64, x1.device)      # one zero-fill (a kernel, not a memset: graph-safe) for all six accumulators
-    for i, k in enumerate(keys):
-        Fn.sum_log2(out["likelihoods"][k], out=acc[i:i + 1])
     h, w = x1.shape[-2:]                      # x1/x2 are the ORIGINAL images: padded reconstructions are cropped (views)
     n = len(keys)
-    Fn.sum_sq_diff(out["x1_hat"][..., :h, :w], x1, out=acc[n:n + 1])
-    Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2, out=acc[n + 1:n + 2])
+
+    def bits_sums():
+        for i, k in enumerate(keys):
+            Fn.sum_log2(out["likelihoods"][k], out=acc[i:i + 1])
+        return acc
+
+    def sq_sums():
+        Fn.sum_sq_diff(out["x1_hat"][..., :h, :w], x1, out=acc[n:n + 1])
+        Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2, out=acc[n + 1:n + 2])
+        return acc
+
+    _branches(x1, bits_sums, sq_sums)         # six small-grid reductions: the two families side by side (disjoint accumulators)
     bits = -acc[:n]
     res = {"bits_" + k: bits[i:i + 1] for i, k in enumerate(keys)}
     res["sse1"], res["sse2"] = acc[n:n + 1], acc[n + 1:n + 2]
