@@ -226,6 +226,55 @@ def test_stream_overlap_and_fusion_do_not_change_results():
         models.OVERLAP_STREAMS, Fn.FUSE_CONV_GDN = keep
 
 
+@pytest.mark.parametrize("which", ["hsic", "joint"])
+def test_critical_chain_schedule_is_race_free_back_to_back(which):
+    """The forked inference schedule (chain on the main stream; view 2 + decoder2 and view 1's rate on side streams) under the
+    conditions that expose a missing cross-stream dependency: forwards back to back without a host sync, every stream's
+    allocator pool seeded with NaN / 1e30 garbage of random sizes in between.  Every output of every forward equals the
+    single-stream order bit for bit."""
+    import random
+    from hesic_amd import models
+    rng = random.Random(7)
+    net = build(which, torch.bfloat16)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(1, 2, 256, 256))
+
+    def perturb():
+        junk = []
+        for st in [torch.cuda.current_stream()] + [models._side_stream(x1.device, i) for i in (1, 2, 10, 12)]:
+            with torch.cuda.stream(st):
+                for _ in range(rng.randint(1, 5)):
+                    n = rng.choice([1 << 10, 1 << 16, 1 << 20, 3 << 20, 1 << 24])
+                    junk.append(torch.full((n,), float("nan") if rng.random() < 0.5 else 1e30, device=DEV))
+        torch.cuda.synchronize()
+        del junk
+        if rng.random() < 0.3:
+            torch.cuda.empty_cache()
+
+    def run(overlap, n):
+        models.OVERLAP_STREAMS = overlap
+        outs = []
+        with torch.no_grad():
+            for _ in range(n):
+                o = net(x1, x2, Hm)
+                d = {k: o[k].clone() for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat")}
+                d.update({"lik_" + k: v.clone() for k, v in o["likelihoods"].items()})
+                outs.append(d)
+                del o
+        torch.cuda.synchronize()
+        return outs
+
+    keep = models.OVERLAP_STREAMS
+    try:
+        ref = run(False, 1)[0]
+        for _ in range(4):
+            perturb()
+            for i, got in enumerate(run(True, 4)):
+                for k, v in got.items():
+                    assert torch.equal(v, ref[k]), (which, i, k)
+    finally:
+        models.OVERLAP_STREAMS = keep
+
+
 def test_graphed_forward_replays_the_eager_result():
     """HIP-graph capture of the whole eval forward (side streams included) + reductions: replay == eager, bit for bit, also
     for new inputs copied into the static buffers."""
