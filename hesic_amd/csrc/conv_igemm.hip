@@ -1102,6 +1102,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (fast) {
         if (count_blocks(128) < 384) bm = 64;
         if (bm == 64 && count_blocks(64) < 384 && BN == 128 && d->Cin % 64 == 0) bm = 32;
+        static const int force_bm = getenv("HESIC_IGEMM_BM") ? atoi(getenv("HESIC_IGEMM_BM")) : 0;      // A/B switch
+        if (force_bm == 128 || force_bm == 64 || (force_bm == 32 && BN == 128 && d->Cin % 64 == 0)) bm = force_bm;
     }
     // Split-K for the low-resolution layers (hyper path: 8x8 .. 32x32 maps): with so few pixels a full-K block per tile
     // leaves most CUs idle and makes every block stream the whole weight tensor.  Given a workspace, the K loop is cut
