@@ -42,6 +42,16 @@ def _is_narrow(c):
     return c <= 8
 
 
+def _c(t):
+    """``t`` for its pointer: contiguous storage without the ~5 us ``detach()`` + ``contiguous()`` make of a new tensor object per
+    launch (parameters are contiguous leaves; ``data_ptr()`` needs no detach)."""
+    return t if t.is_contiguous() else t.detach().contiguous()
+
+
+def _nd(t):
+    return t.detach() if t.requires_grad else t
+
+
 def _zeros(shape, dtype, device):
     """Zero-filled scratch for kernels that ACCUMULATE into it.  ``torch.zeros`` is a hipMemsetAsync on ROCm, and a memset
     node recorded into a HIP graph did not reliably run before the accumulating kernel on replays (see csrc/wgrad.hip:
@@ -237,7 +247,7 @@ def _weight_image(kind, weight, gp=None, gtag=None):
     if hit is not None and hit[0] == tag and hit[2]() is weight:
         return hit[1]
     img = torch.empty(65536 if kind == 0 else 24576, dtype=torch.uint8, device=weight.device)
-    L.call("hesic_sconv_pack_weight_image", kind, L.ptr(weight.detach().contiguous()), L.ptr(gp), L.ptr(img), L.stream())
+    L.call("hesic_sconv_pack_weight_image", kind, L.ptr(_c(weight)), L.ptr(gp), L.ptr(img), L.stream())
     if len(_img_cache) > 64:
         _img_cache.clear()
     try:
@@ -470,7 +480,7 @@ class PackedGdn:
             return self._hit[1], self._hit[2]
         gp = torch.empty(2 * 128 * 128, dtype=torch.bfloat16, device=gamma.device)
         bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
-        L.call("hesic_gdn_pack_params", L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), float(beta_min), L.ptr(gp),
+        L.call("hesic_gdn_pack_params", L.ptr(_c(beta)), L.ptr(_c(gamma)), float(beta_min), L.ptr(gp),
                L.ptr(bp), 128, L.stream())
         self._hit = (tag, gp, bp)
         return gp, bp
@@ -508,7 +518,7 @@ def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
     dbeta = sb.grad if direct else torch.empty_like(beta, dtype=torch.float32)
     dgamma = sg.grad if direct else torch.empty_like(gamma, dtype=torch.float32)
     ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=v.device)
-    L.call("hesic_gdn_backward_acc", L.ptr(v), L.ptr(gy), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(gv), L.ptr(dbeta),
+    L.call("hesic_gdn_backward_acc", L.ptr(v), L.ptr(gy), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(gv), L.ptr(dbeta),
            L.ptr(dgamma), int(direct), L.ptr(ws), P, Cc, int(inverse), float(beta_min), L.dt(v), L.stream())
     if direct:
         _slot_done(sb)
@@ -538,7 +548,7 @@ class _SConvGdnFn(torch.autograd.Function):
         y = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         v = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         d = _sdesc(x, y, Cin, Cout, k, stride, pad, False)
-        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()),
+        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(_c(weight)),
                L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
         ctx.save_for_backward(x, weight, v, beta, gamma)
         ctx.cfg, ctx.dims, ctx.has_bias, ctx.bias = cfg, (B, H, W, Cin, Ho, Wo, Cout), bias is not None, bias
@@ -599,7 +609,7 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
         out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
         d = _sdesc(x, out, Cin, Cout, k, stride, padding, False)
-        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(weight.detach().contiguous()),
+        L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(_c(weight)),
                L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(out), None, L.stream())
         return out
     if torch.is_grad_enabled():
@@ -809,7 +819,7 @@ def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed
     d = _sdesc(xa, y, cin, cout, kernel_size, stride, padding, transposed)
     xbs = (C.c_int64 * 4)(*xb.stride())
     L.call("hesic_sconv2d_forward_cat", C.byref(d), L.ptr(xa), L.ptr(xb), xbs, L.dt(xb), int(xa.shape[1]),
-           L.ptr(weight.detach().contiguous()), L.ptr(bias), L.ptr(y), L.stream())
+           L.ptr(_c(weight)), L.ptr(bias), L.ptr(y), L.stream())
     return y
 
 
@@ -822,7 +832,7 @@ class _GdnFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         x = _nhwc(x)
         y = torch.empty_like(x, memory_format=_CL)
-        L.call("hesic_gdn_forward", L.ptr(x), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(y),
+        L.call("hesic_gdn_forward", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y),
                B * H * W, Cc, int(inverse), float(beta_min), L.dt(x), L.stream())
         ctx.save_for_backward(x, beta, gamma)
         ctx.inverse, ctx.beta_min = inverse, beta_min
@@ -840,7 +850,7 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
         # image-side GDN on a planar tensor at inference: no NHWC round trip
         B, Cc, H, W = x.shape
         y = torch.empty_like(x)
-        L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(beta.detach()), L.ptr(gamma.detach().contiguous()), L.ptr(y), B, Cc, H * W,
+        L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y), B, Cc, H * W,
                int(inverse), float(beta_min), L.dt(x), L.stream())
         return y
     return _GdnFn.apply(x, beta, gamma, inverse, beta_min)
@@ -1047,7 +1057,7 @@ class _EbAuxFn(torch.autograd.Function):
         table = _eb_table(matrices, biases, factors, quantiles, 0.0)
         loss = _zeros(1, torch.float32, quantiles.device)
         dq = torch.empty_like(quantiles, dtype=torch.float32)
-        L.call("hesic_eb_aux_loss", L.ptr(table), L.ptr(quantiles.detach().contiguous()), float(tail_mass), L.ptr(loss), L.ptr(dq), Cc, 0, L.stream())
+        L.call("hesic_eb_aux_loss", L.ptr(table), L.ptr(_c(quantiles)), float(tail_mass), L.ptr(loss), L.ptr(dq), Cc, 0, L.stream())
         ctx.save_for_backward(dq)
         ctx.n_params = len(params)
         return loss.reshape(())
@@ -1075,7 +1085,7 @@ class _GmmFn(torch.autograd.Function):
         if means is None:
             means = _zeros(scales.shape, scales.dtype, scales.device).contiguous(memory_format=_CL) if scales.dim() == 4 else _zeros(scales.shape, scales.dtype, scales.device)
         # scales / means may be channel slices of one tensor (chunk(2,1)): read in place
-        ps, sptr, mptr, _keep = _sm_pointers(scales.detach(), means.detach(), y, B, K, M)
+        ps, sptr, mptr, _keep = _sm_pointers(_nd(scales), _nd(means), y, B, K, M)
         if ps == K * M:
             scales, means = _keep
         wts = None if weights is None else weights.detach().reshape(B, K * M).to(torch.float32).contiguous()
