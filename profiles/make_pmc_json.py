@@ -2,7 +2,7 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, csv output) of one HESIC forward into
 profiles/pmc_igemm.json, the per-launch HBM-side traffic that bench.py reports as roofline.traffic.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex igemm_glds_kernel --output-format csv -d gpurun_out/pmc_f -- python <fwd script>
+    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex igemm_glds_kernel --output-format csv -d gpurun_out/pmc_f -- python profiles/scripts/forward_n.py hsic 4   (with HESIC_NO_OVERLAP=1)
     rocprofv3 --pmc WRITE_SIZE ...                                                          -d gpurun_out/pmc_w -- ...
     python profiles/make_pmc_json.py gpurun_out/pmc_f gpurun_out/pmc_w hsic_bf16_b8_512
 
