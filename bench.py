@@ -473,7 +473,9 @@ def main():
 
     # bits / squared error of a batch are reduced on a stream of their own: the six small-grid reductions (and the joins in
     # front of them) then run beside the first kernels of the NEXT batch instead of holding the main stream for ~100 us
-    mstream = torch.cuda.Stream(device=dev)
+    # (no fifth stream: the schedule's streams fill the runtime's four hardware queues; the stream view 1's rate branch uses is idle
+    # from the middle of a forward to ~0.3 ms into the next one)
+    mstream = models._side_stream(dev, 12)
 
     def metrics_async(out, a, b):
         mstream.wait_stream(torch.cuda.current_stream())

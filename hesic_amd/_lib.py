@@ -87,6 +87,8 @@ _SIGS = {
     "hesic_unpack_conv_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_sconv2d_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_forward_cat": ([_P(SConvDesc), _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, _vp, _vp, _vp, _vp], _i32),
+    "hesic_sconv2d_forward_cat_gdn": ([_P(SConvDesc), _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32,
+                                       _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward_train": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
     "hesic_sconv_pack_weight_image": ([_i32, _vp, _vp, _vp, _vp], _i32),

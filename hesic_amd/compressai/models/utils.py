@@ -59,11 +59,12 @@ class HipConv2d(nn.Conv2d):
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
         return gdn(self.run(x))
 
-    def run_cat(self, xa, xb):
-        """self(torch.cat((xa, xb), 1)) without materialising the cat where the kernels allow it (inference)."""
+    def run_cat(self, xa, xb, gdn=None, gdn_on_input=False):
+        """self(torch.cat((xa, xb), 1)) without materialising the cat where the kernels allow it (inference); ``gdn``: the
+        3-channel GDN module behind the conv (or, ``gdn_on_input``, in front of it on ``xa``) rides on the same launch."""
         self._check()
         return Fn.conv2d_cat(xa, xb, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
-                             padding=self.padding[0], transposed=False)
+                             padding=self.padding[0], transposed=False, gdn=gdn, gdn_on_input=gdn_on_input)
 
     def forward(self, x):
         return self.run(x)
@@ -109,10 +110,10 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
         return gdn(self.run(x))
 
-    def run_cat(self, xa, xb):
+    def run_cat(self, xa, xb, gdn=None, gdn_on_input=False):
         self._check()
         return Fn.conv2d_cat(xa, xb, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
-                             padding=self.padding[0], transposed=True)
+                             padding=self.padding[0], transposed=True, gdn=gdn, gdn_on_input=gdn_on_input)
 
     def forward(self, x, output_size=None):
         if output_size is not None:

@@ -1125,7 +1125,10 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // measured on MI355X (B=8): it pays when even 32-pixel tiles leave half the CUs idle, or when K is very long;
         // the short K loops of transposed phases and mid-sized maps lose more to the reduce pass than they gain
         const bool starved = !d->transposed && count_blocks(32) < 128;
-        const bool long_k = !d->transposed && min_steps >= 100;
+        // long K on a small map (>= 64 stages: the 192 -> 128 5x5 layer of encode_hyper at 32x32, 75 stages): four K slices on 128-pixel
+        // tiles instead of 256 blocks of 32 pixels, 46.6 -> 27.5 + 5 us (round 2; 100 was the round-1 threshold)
+        static const int longk_min = getenv("HESIC_IGEMM_LONGK") ? atoi(getenv("HESIC_IGEMM_LONGK")) : 64;      // A/B switch
+        const bool long_k = !d->transposed && min_steps >= longk_min;
         if (nb < 256 && S >= 2 && (starved || long_k)) { ksplit = S; bm = bm_s; }
     }
     // 256-pixel tile, 8 waves of 64 x 64 (2 cout x 4 pixel slices), one block per CU: the weight tile is shared by twice the

@@ -20,6 +20,10 @@ struct SArgs {
     // optional second input (hesic_sconv2d_forward_cat): channels [c_split, Cin) come from x2 -- the torch.cat in front of
     // pre_conv / after_conv (newnet1.py:643,686) never materialises
     const void* x2; int64_t x2s_b, x2s_c, x2s_y, x2s_x; int x2_dtype, c_split;
+    // optional 3-channel (I)GDN fused into the 6 -> 3 stages (hesic_sconv2d_forward_cat_gdn): gdn_mode 1 = GDN / IGDN (gdn_inverse) on the
+    // three OUTPUT channels (pre_conv -> GDN(3), newnet1.py:643-644), 2 = on the first three INPUT channels before the conv
+    // (IGDN(3) -> cat -> after_conv, newnet1.py:684-686); raw beta / gamma, reparametrised here like gdn_planar_kernel does
+    const float* gdn_beta; const float* gdn_gamma; float gdn_bound; int gdn_mode, gdn_inverse;
     const void* w_img;   // optional: the kernel's LDS weight image, pre-packed once per weight update (hesic_sconv_pack_weight_image)
     int dbg;     // HESIC_N2W_DBG profiling ablations of the fused 3 -> 128 kernel (garbage results): 1 no loads, 2 no conv MFMAs, 4 no GDN MFMAs, 8 no global stores
 };
@@ -903,6 +907,38 @@ __global__ __launch_bounds__(256) void sconv_small_s1_lds_kernel(const SArgs a) 
         }
 }
 
+// 3-channel (I)GDN of one pixel, the arithmetic of gdn_planar_kernel<3> (csrc/gdn.hip) statement for statement
+struct Gdn3 {
+    float g[3][3], bt[3];
+    int inverse;
+    __device__ __forceinline__ void load(const float* beta, const float* gamma, float bound, int inv) {
+        constexpr float kPed = 1.0f / 68719476736.0f, kGb = 1.0f / 262144.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = fmaxf(beta[c], bound);
+            bt[c] = t * t - kPed;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { t = fmaxf(gamma[c * 3 + j], kGb); g[c][j] = t * t - kPed; }
+        }
+        inverse = inv;
+    }
+    __device__ __forceinline__ void apply(float (&v)[3]) const {
+        float sq[3], o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sq[c] = v[c] * v[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float norm = bt[c];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) norm += g[c][j] * sq[j];
+            o[c] = v[c] * (inverse ? sqrtf(norm) : rsqrtf(norm));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = o[c];
+    }
+};
+
+
 // ---------------------------------------------------------------- 6 -> 3, 5x5, stride 1 (pre_conv / after_conv)
 // 16 x 128 output tile per block, all 6 input planes of the tile (+halo) in LDS as fp32, 8 consecutive pixels x 3 couts
 // per thread: per (ci, ky) three ds_read_b128 of pixels and five broadcast weight reads feed 120 FMAs.  The 132-float
@@ -972,6 +1008,17 @@ __global__ __launch_bounds__(256, PX == 4 ? 4 : 2) void sconv_6to3_s1_kernel(con
         }
     }
     __syncthreads();
+    if (a.gdn_mode == 2) {
+        // (I)GDN of the first three staged channels in place, halo included (padding pixels are zeros and stay zeros)
+        Gdn3 gd;
+        gd.load(a.gdn_beta, a.gdn_gamma, a.gdn_bound, a.gdn_inverse);
+        for (int i = tid; i < PH * PW; i += 256) {
+            float v[3] = {xs[i], xs[PH * PW + i], xs[2 * PH * PW + i]};
+            gd.apply(v);
+            xs[i] = v[0]; xs[PH * PW + i] = v[1]; xs[2 * PH * PW + i] = v[2];
+        }
+        __syncthreads();
+    }
     const int ly = tid >> 4, lx = (tid & 15) * PX;
     float acc[PX][COUT];
 #pragma unroll
@@ -1001,12 +1048,26 @@ __global__ __launch_bounds__(256, PX == 4 ? 4 : 2) void sconv_6to3_s1_kernel(con
     const int oy = ty * TH + ly, ox0 = tx * TW + lx;
     if (oy >= a.Ho) return;
     const bool vec = a.y_dtype == HESIC_F32 && a.ys_x == 1 && !(a.Wo & 3) && !((a.ys_b | a.ys_c | a.ys_y) & 3) && !((uintptr_t)a.y & 15);
+    if (a.gdn_mode == 1) {
+        // conv + bias (+ act) of a pixel's three channels are all in this thread: the 3-channel (I)GDN needs nothing else
+        Gdn3 gd;
+        gd.load(a.gdn_beta, a.gdn_gamma, a.gdn_bound, a.gdn_inverse);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            float v[3];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) v[co] = apply_act(acc[p][co] + (a.bias ? a.bias[co] : 0.f), a.act);
+            gd.apply(v);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[p][co] = v[co];
+        }
+    }
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-        const float bv = a.bias ? a.bias[co] : 0.f;
+        const float bv = (a.bias && a.gdn_mode != 1) ? a.bias[co] : 0.f;
         float o[PX];
 #pragma unroll
-        for (int p = 0; p < PX; ++p) o[p] = apply_act(acc[p][co] + bv, a.act);
+        for (int p = 0; p < PX; ++p) o[p] = a.gdn_mode == 1 ? acc[p][co] : apply_act(acc[p][co] + bv, a.act);
         const int64_t base = b * a.ys_b + co * a.ys_c + oy * a.ys_y;
         if (vec && ox0 + PX <= a.Wo) {
             float* yp = (float*)a.y + base + ox0;
@@ -1158,6 +1219,26 @@ SArgs make_args(const hesic_sconv_desc* d) {
 
 static thread_local const void* g_w_img = nullptr;       // set by the *_prepacked entry points around the ordinary launchers
 
+static thread_local const float* g_cat_beta = nullptr;    // set by hesic_sconv2d_forward_cat_gdn around the ordinary launcher
+static thread_local const float* g_cat_gamma = nullptr;
+static thread_local float g_cat_bound = 0.f;
+static thread_local int g_cat_mode = 0, g_cat_inverse = 0;
+
+extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
+                                         int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream);
+
+extern "C" int hesic_sconv2d_forward_cat_gdn(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
+                                             int xb_dtype, int ca, const float* w, const float* bias, const float* gdn_beta,
+                                             const float* gdn_gamma, float beta_min, int inverse, int gdn_on_input, void* y, void* stream) {
+    HESIC_CHECK_ARG(gdn_beta && gdn_gamma, "sconv2d_forward_cat_gdn: null pointer");
+    HESIC_CHECK_ARG(!gdn_on_input || ca == 3, "sconv2d_forward_cat_gdn: the input-side (I)GDN covers the first tensor's three channels");
+    g_cat_beta = gdn_beta; g_cat_gamma = gdn_gamma; g_cat_bound = sqrtf(beta_min + 1.0f / 68719476736.0f);
+    g_cat_mode = gdn_on_input ? 2 : 1; g_cat_inverse = inverse ? 1 : 0;
+    const int rc = hesic_sconv2d_forward_cat(d, xa, xb, xb_strides, xb_dtype, ca, w, bias, y, stream);
+    g_cat_beta = g_cat_gamma = nullptr; g_cat_mode = 0;
+    return rc;
+}
+
 extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
                                          int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream) {
     if (int e = check_desc(d, "sconv2d_forward_cat")) return e;
@@ -1170,6 +1251,7 @@ extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* 
     a.x = xa; a.w = w; a.bias = bias; a.y = y;
     a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
     a.x2_dtype = xb_dtype; a.c_split = ca;
+    a.gdn_beta = g_cat_beta; a.gdn_gamma = g_cat_gamma; a.gdn_bound = g_cat_bound; a.gdn_mode = g_cat_mode; a.gdn_inverse = g_cat_inverse;
     static const int px = getenv("HESIC_6TO3_PX") ? atoi(getenv("HESIC_6TO3_PX")) : 4;           // A/B switch
     if (px == 8) {
         const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;

@@ -42,6 +42,9 @@ def _is_narrow(c):
     return c <= 8
 
 
+FUSE_GDN3 = __import__("os").environ.get("HESIC_NO_FUSE_GDN3") is None      # A/B switch: 3-channel (I)GDN inside the 6 -> 3 cat-conv launch
+
+
 def _c(t):
     """``t`` for its pointer: contiguous storage without the ~5 us ``detach()`` + ``contiguous()`` make of a new tensor object per
     launch (parameters are contiguous leaves; ``data_ptr()`` needs no detach)."""
@@ -802,24 +805,38 @@ def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     return y
 
 
-def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed=False, packer=None):
+def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed=False, packer=None, gdn=None, gdn_on_input=False):
     """conv(torch.cat((xa, xb), 1)) (newnet1.py:643,686).  At inference the 6 -> 3 image-side stages read their two
     3-channel halves straight from the two tensors (``hesic_sconv2d_forward_cat``: no concatenated copy); otherwise the
-    ordinary cat + conv2d (autograd) path runs."""
+    ordinary cat + conv2d (autograd) path runs.  ``gdn``: the 3-channel GDN module next to the conv -- applied to the conv's
+    output (pre_conv -> GDN, :643-644) or, with ``gdn_on_input``, to ``xa`` before the cat (IGDN -> cat -> after_conv, :684-686);
+    fused into the same launch on the fast path."""
     cin = weight.shape[0] if transposed else weight.shape[1]
     cout = weight.shape[1] if transposed else weight.shape[0]
     ok = (not torch.is_grad_enabled() and xa.is_cuda and xb.is_cuda and cin == 6 and cout == 3 and kernel_size == 5 and stride == 1
           and padding == 2 and xa.shape[1] + xb.shape[1] == 6 and xa.shape[-1] >= 128 and xa.shape[0] == xb.shape[0]
           and xa.shape[2:] == xb.shape[2:] and xa.dtype in (torch.float32, torch.bfloat16) and xb.dtype in (torch.float32, torch.bfloat16))
-    if not ok:
-        return conv2d(torch.cat((xa.float(), xb.float()), 1), weight, bias, kernel_size=kernel_size, stride=stride,
-                      padding=padding, transposed=transposed, packer=packer)
+    fuse = ok and gdn is not None and FUSE_GDN3 and (not gdn_on_input or xa.shape[1] == 3)
+    if not ok or (gdn is not None and not fuse):
+        if gdn is not None and gdn_on_input:
+            xa = gdn(xa)
+        if ok:
+            y = conv2d_cat(xa, xb, weight, bias, kernel_size=kernel_size, stride=stride, padding=padding, transposed=transposed, packer=packer)
+        else:
+            y = conv2d(torch.cat((xa.float(), xb.float()), 1), weight, bias, kernel_size=kernel_size, stride=stride,
+                       padding=padding, transposed=transposed, packer=packer)
+        return gdn(y) if (gdn is not None and not gdn_on_input) else y
     B, _, H, W = xa.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=xa.device)
     d = _sdesc(xa, y, cin, cout, kernel_size, stride, padding, transposed)
     xbs = (C.c_int64 * 4)(*xb.stride())
-    L.call("hesic_sconv2d_forward_cat", C.byref(d), L.ptr(xa), L.ptr(xb), xbs, L.dt(xb), int(xa.shape[1]),
-           L.ptr(_c(weight)), L.ptr(bias), L.ptr(y), L.stream())
+    if fuse:
+        L.call("hesic_sconv2d_forward_cat_gdn", C.byref(d), L.ptr(xa), L.ptr(xb), xbs, L.dt(xb), int(xa.shape[1]), L.ptr(_c(weight)),
+               L.ptr(bias), L.ptr(_c(gdn.beta)), L.ptr(_c(gdn.gamma)), float(gdn.beta_min), int(bool(gdn.inverse)), int(bool(gdn_on_input)),
+               L.ptr(y), L.stream())
+    else:
+        L.call("hesic_sconv2d_forward_cat", C.byref(d), L.ptr(xa), L.ptr(xb), xbs, L.dt(xb), int(xa.shape[1]),
+               L.ptr(_c(weight)), L.ptr(bias), L.ptr(y), L.stream())
     return y
 
 

@@ -202,11 +202,11 @@ class Encoder2(Encoder1):
         self.g_a_conv4 = conv(N, M)
 
     def forward(self, x1_warp, x2):
-        t = self.pre_gdn(self.pre_conv.run_cat(x1_warp, x2))
+        t = self.pre_conv.run_cat(x1_warp, x2, gdn=self.pre_gdn)
         return self.stack(t)
 
     def latent(self, x1_warp, x2, want_lo=True):
-        t = self.pre_gdn(self.pre_conv.run_cat(x1_warp, x2))
+        t = self.pre_conv.run_cat(x1_warp, x2, gdn=self.pre_gdn)
         return self.g_a_conv4.run_latent(self.trunk(t), want_lo=want_lo)
 
 
@@ -239,8 +239,7 @@ class Decoder2(Decoder1):
         self.after_conv = deconv(6, 3, stride=1)
 
     def forward(self, y_hat, x1_hat_warp):
-        t = self.after_gdn(self.stack(y_hat))
-        return self.after_conv.run_cat(t, x1_hat_warp)
+        return self.after_conv.run_cat(self.stack(y_hat), x1_hat_warp, gdn=self.after_gdn, gdn_on_input=True)
 
 
 # ----------------------------------------------------------------------------------- hyper networks

@@ -158,6 +158,14 @@ int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float*
  * cat(IGDN(.), x1_hat_warp) (newnet1.py:643,686).                                                                      */
 int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
                               int xb_dtype, int ca, const float* w, const float* bias, void* y, void* stream);
+
+/* The same launch with the 3-channel (I)GDN next to it fused in (compressai/layers/gdn.py:55-70 on three channels):
+ * gdn_on_input = 0: y = (I)GDN(conv(cat(xa, xb)))        -- pre_conv -> GDN(3) of the second encoder (ywz/mywork/newnet1.py:643-644);
+ * gdn_on_input = 1: y = conv(cat((I)GDN(xa), xb)), ca == 3 -- IGDN(3) -> cat -> after_conv of the second decoder (newnet1.py:684-686).
+ * gdn_beta [3] / gdn_gamma [3][3] are the RAW parameters (reparametrised in the kernel like hesic_gdn_forward_planar). */
+int hesic_sconv2d_forward_cat_gdn(const hesic_sconv_desc* d, const void* xa, const void* xb, const int64_t xb_strides[4],
+                                  int xb_dtype, int ca, const float* w, const float* bias, const float* gdn_beta,
+                                  const float* gdn_gamma, float beta_min, int inverse, int gdn_on_input, void* y, void* stream);
 /* g_a_gdn1(g_a_conv1(image)) in one kernel (inference; 3 -> 128, 5x5 stride 2, bf16 NHWC output): newnet1.py:594-595.
  * gamma_packed / beta_packed from hesic_gdn_pack_params.                                                              */
 int hesic_sconv2d_gdn_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias,

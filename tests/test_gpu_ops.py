@@ -164,6 +164,39 @@ def test_cat_free_6to3_conv(tr):
     assert rel_err(yg, ref) < 1e-5 and xg.grad is not None
 
 
+@pytest.mark.parametrize("on_input", [0, 1])
+def test_cat_conv_with_fused_three_channel_gdn(on_input):
+    """pre_conv -> GDN(3) (newnet1.py:643-644) and IGDN(3) -> cat -> after_conv (:684-686) as ONE launch
+    (hesic_sconv2d_forward_cat_gdn) against the oracle and against the two-launch path; partial tiles, lower-bounded beta."""
+    Fn, O = _imp()
+    from compressai.layers import GDN
+    B, H, W = 2, 37, 200
+    xa, xb = rnd("cg_a", (B, 3, H, W)), rnd("cg_b", (B, 3, H, W))
+    w = rnd("cg_w", (6, 3, 5, 5) if on_input else (3, 6, 5, 5)) * 0.1
+    b = rnd("cg_bias", (3,), -0.1, 0.1)
+    g = GDN(3, inverse=bool(on_input))
+    with torch.no_grad():
+        g.beta.copy_(rnd("cg_beta", (3,), 0.0, 1.5))                  # some below the lower bound
+        g.gamma.copy_(rnd("cg_gamma", (3, 3), -0.1, 0.6))
+    if on_input:
+        ref = O.deconv(torch.cat((O.gdn(xa, g.beta.detach(), g.gamma.detach(), True), xb), 1), w, b, 1)
+    else:
+        ref = O.gdn(O.conv(torch.cat((xa, xb), 1), w, b, 1), g.beta.detach(), g.gamma.detach(), False)
+    g = g.to(DEV)
+    args = dict(kernel_size=5, stride=1, padding=2, transposed=bool(on_input), gdn=g, gdn_on_input=bool(on_input))
+    keep = Fn.FUSE_GDN3
+    try:
+        with torch.no_grad():
+            Fn.FUSE_GDN3 = True
+            y = Fn.conv2d_cat(xa.to(DEV), xb.to(DEV), w.to(DEV), b.to(DEV), **args)
+            Fn.FUSE_GDN3 = False
+            y2 = Fn.conv2d_cat(xa.to(DEV), xb.to(DEV), w.to(DEV), b.to(DEV), **args)
+    finally:
+        Fn.FUSE_GDN3 = keep
+    assert rel_err(y, ref) < 2e-5 and rel_err(y2, ref) < 2e-5
+    assert rel_err(y, y2) < 2e-6
+
+
 def test_masked_conv_matches_golden(ops_golden):
     Fn, O = _imp()
     g = ops_golden
