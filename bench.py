@@ -274,7 +274,7 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
             acc[m, 3] += x1.shape[0]
         return rd
 
-    for k in range(max(args.warmup, 4)):           # every model packs its weights before the timed region
+    for k in range(max(args.warmup, 12)):          # every model packs its weights, and the side streams' allocator pools settle (three rounds)
         step(k, False)
     if world > 1:
         dist.barrier()
