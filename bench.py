@@ -274,8 +274,9 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
             acc[m, 3] += x1.shape[0]
         return rd
 
-    for k in range(max(args.warmup, 12)):          # every model packs its weights, and the side streams' allocator pools settle (three rounds)
-        step(k, False)
+    for k in range(max(args.warmup, 12)):          # three rounds: every model packs its weights, the allocator pools settle, and the
+        step(k, True)                              # accumulation ops are loaded too (their first launches cost ~60 ms in all)
+    acc.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -481,7 +482,7 @@ def main():
         mstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(mstream), torch.no_grad():
             for t in (out["x1_hat"], out["x2_hat"], *out["likelihoods"].values()):
-                t.record_stream(mstream)
+                models._rec(t, mstream)
             return models.rate_distortion(out, a, b)
 
     def step(i=0):

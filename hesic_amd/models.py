@@ -28,6 +28,14 @@ OVERLAP_STREAMS = _os.environ.get("HESIC_NO_OVERLAP") is None
 _side_streams = {}
 
 
+_RECORD = _os.environ.get("HESIC_NO_RECORD_STREAM") is None
+
+
+def _rec(t, stream):
+    if _RECORD:
+        t.record_stream(stream)
+
+
 def _side_stream(device, idx=0):
     """Side stream ``idx`` of the schedule: a fixed small set per device.  torch hands out streams from a pool of 32 per device
     round-robin, so a NEW stream object may alias one that already exists (another side stream or the caller's current / capture
@@ -64,7 +72,7 @@ def _branches(ref, *fns):
         cur.wait_stream(st)
         o = outs[i + 1]
         for t in (o if isinstance(o, (tuple, list)) else (o,)):
-            t.record_stream(cur)
+            _rec(t, cur)
     return outs
 
 
@@ -93,7 +101,7 @@ class _Fork:
         with torch.cuda.stream(stream):
             for f in after:
                 for t in _tensors(f.out):
-                    t.record_stream(stream)
+                    _rec(t, stream)
             _Fork.depth += 1
             try:
                 self.out = fn()
@@ -119,7 +127,7 @@ class _Fork:
         stream = stream or torch.cuda.current_stream()
         stream.wait_stream(self.stream)
         for t in _tensors(self.out):
-            t.record_stream(stream)
+            _rec(t, stream)
         return self.out
 
 
@@ -668,7 +676,7 @@ class HSIC(StereoCompressionModel):
             main.wait_event(ev2)
             y2, y2_hat, (z2_hat, z2_lik) = v2.out[0]
             for t in (y2, z2_hat, z2_lik):
-                t.record_stream(main)
+                _rec(t, main)
             s2, m2, w2 = self._h_s2(z2_hat, y1_hat_w, hi=True)
             y2_lik = self.gaussian2(y2, s2, m2, w2, out_dtype=cdt)[1]
             y1_lik, z1_lik = r1.join()
@@ -803,7 +811,7 @@ class HSICJoint(StereoCompressionModel):
         if overlap:
             main.wait_event(ev2)
             for t in (y2, y2_hat, params2, z2_lik):
-                t.record_stream(main)
+                _rec(t, main)
         sc2, mu2 = self._gauss_full(2, params2, y2_hat, y1_hat_w)
         # the reference evaluates view 2 with gaussian_conditional1 as well (:725); no learnable state, harmless
         _, y2_lik = self.gaussian_conditional1(y2, sc2, means=mu2, out_dtype=cdt)
