@@ -1119,16 +1119,21 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int bk_ = d->Cin % 64 == 0 ? 64 : 32;
         const int min_taps = d->transposed ? (d->KH / s) * (d->KW / s) : a.ntaps_live;
         const int min_steps = min_taps * (d->Cin / bk_);
-        int S = (int)((256 + nb - 1) / nb);
+        // one block per CU is the target; a very long K loop (>= 200 stages: the 960-channel data gradients) is cut further, to two
+        // co-resident blocks per CU (183 us unsplit -> 108 us at 4 slices -> measured below at 8)
+        static const int split_target_long = getenv("HESIC_IGEMM_SPLIT_LONG") ? atoi(getenv("HESIC_IGEMM_SPLIT_LONG")) : 512;   // A/B switch
+        const int target = min_steps >= 200 ? split_target_long : 256;
+        int S = (int)((target + nb - 1) / nb);
         if (S > 8) S = 8;
         if (S > min_steps / 4) S = min_steps / 4;
         // measured on MI355X (B=8): it pays when even 32-pixel tiles leave half the CUs idle, or when K is very long;
         // the short K loops of transposed phases and mid-sized maps lose more to the reduce pass than they gain
-        const bool starved = !d->transposed && count_blocks(32) < 128;
+        const bool one_phase = !d->transposed || s == 1;      // a stride-1 transposed conv (the data gradient of a stride-1 conv) is one phase with the full K loop
+        const bool starved = one_phase && count_blocks(32) < 128;
         // long K on a small map (>= 64 stages: the 192 -> 128 5x5 layer of encode_hyper at 32x32, 75 stages): four K slices on 128-pixel
         // tiles instead of 256 blocks of 32 pixels, 46.6 -> 27.5 + 5 us (round 2; 100 was the round-1 threshold)
         static const int longk_min = getenv("HESIC_IGEMM_LONGK") ? atoi(getenv("HESIC_IGEMM_LONGK")) : 64;      // A/B switch
-        const bool long_k = !d->transposed && min_steps >= longk_min;
+        const bool long_k = one_phase && min_steps >= longk_min;
         if (nb < 256 && S >= 2 && (starved || long_k)) { ksplit = S; bm = bm_s; }
     }
     // 256-pixel tile, 8 waves of 64 x 64 (2 cout x 4 pixel slices), one block per CU: the weight tile is shared by twice the

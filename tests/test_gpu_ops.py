@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from conftest import T, load_golden
+import hesic_amd
 from hesic_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -136,6 +137,34 @@ def test_wide_conv_split_k_matches_plain_launch():
     assert rel_err(outs[0], outs[1]) < 4e-3                      # one bf16 ulp of the output scale
     with pytest.raises(RuntimeError):                            # too small a workspace is an error, not a silent fallback
         L.call("hesic_conv2d_forward_ws", C.byref(d), L.ptr(xd), L.ptr(wp), L.ptr(b.to(DEV)), L.ptr(buf), L.ptr(ws), 16, L.stream())
+
+
+def test_stride1_transposed_conv_takes_split_k():
+    """The data gradient of a stride-1 conv is a stride-1 TRANSPOSED conv: one output phase with the full K loop.  With Cin = 960
+    (the 128 -> 960 layers of gmm_hyper_y1/y2 backwards) on a 32 x 32 map it is a long-K, few-tile launch and takes the split-K form;
+    same result as the one-block-per-tile launch and as the oracle's conv_transpose2d."""
+    Fn, O = _imp()
+    B, Cin, Cout, H = 2, 960, 128, 32
+    x = bf(rnd("st_x", (B, Cin, H, H), -1, 1))
+    w = bf(rnd("st_w", (Cin, Cout, 5, 5)) * 0.02)
+    b = rnd("st_b", (Cout,), -0.1, 0.1)
+    ref = torch.nn.functional.conv_transpose2d(x, w, b, stride=1, padding=2)
+    xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    from hesic_amd import _lib as L
+    import ctypes as C
+    d = L.ConvDesc(B, H, H, Cin, H, H, Cout, 5, 5, 1, 2, 1, L.dt(torch.bfloat16), 0, 0, Cin, 0, Cout, 0, 0)
+    assert int(L.lib().hesic_conv2d_ws_bytes(C.byref(d))) >= 2 * B * H * H * Cout * 4
+    keep = hesic_amd.functional.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            y_split = Fn.conv2d(xd, w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=True).float()
+            with Fn.no_split_k():
+                y_plain = Fn.conv2d(xd, w.to(DEV), b.to(DEV), kernel_size=5, stride=1, padding=2, transposed=True).float()
+    finally:
+        hesic_amd.set_compute_dtype(keep)
+    assert rel_err(y_split, ref) < 2e-2 and rel_err(y_plain, ref) < 2e-2
+    assert rel_err(y_split, y_plain) < 4e-3
 
 
 @pytest.mark.parametrize("tr", [0, 1], ids=["pre_conv", "after_conv"])
