@@ -26,9 +26,21 @@ class MaskedConv2d(HipConv2d):
         live = (h // 2) * w + w // 2 + (mask_type == "B")
         self._tap_mask = (1 << live) - 1
 
+    def _fold_mask(self):
+        """``weight.data *= mask`` (reference layers.py:43).  Idempotent, so at inference it is skipped while the parameter's
+        version counter stands where the last fold left it (a load_state_dict / optimiser step moves it)."""
+        if torch.is_grad_enabled() or getattr(self, "_folded", None) != (self.weight.data_ptr(), self.weight._version):
+            self.weight.data *= self.mask
+            self._folded = (self.weight.data_ptr(), self.weight._version)
+
     def forward(self, x):
-        self.weight.data *= self.mask
+        self._fold_mask()
         return self.run(x, mask=self.mask, tap_mask=self._tap_mask)
+
+    def forward_into(self, x, out, c_off):
+        """``out[:, c_off:c_off + out_channels] = self(x)`` at inference (see ``HipConv2d.run_into``)."""
+        self._fold_mask()
+        return self.run_into(x, out, c_off, mask=self.mask, tap_mask=self._tap_mask)
 
 
 def conv3x3(in_ch, out_ch, stride=1):

@@ -30,6 +30,14 @@ class HipConv2d(nn.Conv2d):
                          padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                          mask=mask, tap_mask=tap_mask)
 
+    def run_into(self, x, out, c_off, act=L.ACT_NONE, mask=None, tap_mask=0):
+        """out[:, c_off:c_off + out_channels] = act(self(x)) at inference, written in place (no cat afterwards)."""
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight()
+        return Fn.conv2d_into(x, self.weight, self.bias, out, c_off, kernel_size=self.kernel_size[0], stride=self.stride[0],
+                              padding=self.padding[0], transposed=False, act=act, packer=self._packer, mask=mask, tap_mask=tap_mask)
+
     def run_slice(self, x, c_off, act=L.ACT_NONE):
         """self(x[:, c_off:c_off + in_channels]) at inference, reading the channel slice in place."""
         self._check()

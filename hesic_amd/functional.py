@@ -754,6 +754,36 @@ def conv2d_slice(x, x_c_off, weight, bias, *, kernel_size, stride, padding, tran
     return _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, padding, transposed, act, 0, 0, x_c_off=x_c_off)
 
 
+def conv2d_into(x, weight, bias, out, out_c_off, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, packer=None,
+                mask=None, tap_mask=0):
+    """Inference conv whose output lands in channels [out_c_off, out_c_off + Cout) of the wider NHWC tensor ``out`` (the kernels
+    write a channel slice in place): what a ``torch.cat`` of conv outputs would otherwise copy together."""
+    L.require_cuda(x, weight, out)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("conv2d_into is an inference form")
+    k = kernel_size
+    Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    B, _, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
+    if out.shape[0] != B or tuple(out.shape[2:]) != (Ho, Wo) or out_c_off + Cout > out.shape[1] or not out.is_contiguous(memory_format=_CL) \
+            or out.dtype != x.dtype:
+        raise ValueError("conv2d_into: `out` must be an NHWC tensor of the conv's dtype and output size with room for the channel slice")
+    x = _nhwc(x)
+    packer = packer if packer is not None else PackedWeight()
+    wp = packer.get(weight, mask, Cout, Cin, k, k, transposed, False, x.dtype)
+    _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, padding, transposed, act, 0, tap_mask, out=out, out_c_off=out_c_off)
+    return out
+
+
+def copy_into(x, out, out_c_off):
+    """``out[:, out_c_off:out_c_off + C] = x`` for NHWC tensors of one dtype (``hesic_copy_channels``)."""
+    L.require_cuda(x, out)
+    B, Cx, H, W = x.shape
+    x = _nhwc(x)
+    L.call("hesic_copy_channels", L.ptr(x), L.ptr(out), B * H * W, Cx, Cx, 0, out.shape[1], out_c_off, L.dt(x), L.stream())
+    return out
+
+
 def round_to(x, dtype):
     """round-half-even(x) stored as ``dtype``: ``_quantize(x, "dequantize")`` without means on an fp32 latent."""
     L.require_cuda(x)

@@ -25,6 +25,7 @@ RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
 # inference runs the two views' independent front ends on two HIP streams (set False for a single-stream schedule)
 import os as _os
 OVERLAP_STREAMS = _os.environ.get("HESIC_NO_OVERLAP") is None
+CAT_FREE_EP = _os.environ.get("HESIC_CAT_EP") is None          # A/B switch (HESIC+): set to go back to torch.cat in front of entropy_parameters
 _side_streams = {}
 
 
@@ -775,17 +776,23 @@ class HSICJoint(StereoCompressionModel):
         its whole hyper path (inputs only) and then decoder2 run on a second stream, view 1's rate on a third."""
         size = (x1.shape[-2], x1.shape[-1])
         cdt = Fn.compute_dtype()
+        catfree = x1.is_cuda and CAT_FREE_EP      # the convs feeding entropy_parameters write their channel slices of ONE buffer (no torch.cat)
 
         def view2_front():
             x1_warp = warp_perspective(x1, h_matrix, size)
             y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
             y2_hat = _round_latent(self.gaussian_conditional2, y2)
             z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(_seq3_hi(self.h_a2, y2_lo), None, out_dtype=cdt)
-            return y2, y2_hat, _seq3(self.h_s2, z2_hat), z2_lik
+            params2 = self._params_buffer(self.h_s2, z2_hat, y2_hat, self.M) if catfree else _seq3(self.h_s2, z2_hat)
+            return y2, y2_hat, params2, z2_lik
 
         def view1_rate(y1_lo, y1, y1_hat):
             z1_hat, z1_lik = self.entropy_bottleneck1.forward_with_noise(_seq3_hi(self.h_a1, y1_lo), None, out_dtype=cdt)
-            sc1, mu1 = self._gauss_full(1, _seq3(self.h_s1, z1_hat), y1_hat)
+            if catfree:
+                buf1 = self._params_buffer(self.h_s1, z1_hat, y1_hat)
+                sc1, mu1 = self._gauss_full(1, None, y1_hat, buf=buf1)
+            else:
+                sc1, mu1 = self._gauss_full(1, _seq3(self.h_s1, z1_hat), y1_hat)
             return self.gaussian_conditional1(y1, sc1, means=mu1, out_dtype=cdt)[1], z1_lik
 
         overlap = OVERLAP_STREAMS and x1.is_cuda
@@ -812,7 +819,10 @@ class HSICJoint(StereoCompressionModel):
             main.wait_event(ev2)
             for t in (y2, y2_hat, params2, z2_lik):
                 _rec(t, main)
-        sc2, mu2 = self._gauss_full(2, params2, y2_hat, y1_hat_w)
+        if catfree:
+            sc2, mu2 = self._gauss_full(2, None, y2_hat, y1_hat_w, buf=params2)
+        else:
+            sc2, mu2 = self._gauss_full(2, params2, y2_hat, y1_hat_w)
         # the reference evaluates view 2 with gaussian_conditional1 as well (:725); no learnable state, harmless
         _, y2_lik = self.gaussian_conditional1(y2, sc2, means=mu2, out_dtype=cdt)
         if overlap:
@@ -835,12 +845,29 @@ class HSICJoint(StereoCompressionModel):
         h_s = self.h_s1 if which == 1 else self.h_s2
         return _seq3(h_s, z_hat)
 
-    def _gauss_full(self, which, params, y_hat, extra=None):
+    def _gauss_full(self, which, params, y_hat, extra=None, buf=None):
+        """(scales, means) = entropy_parameters(cat(params, context(y_hat)[, extra])) (newnet1_joint.py:703-707, :741-746).
+        ``buf``: inference form without the cat -- an NHWC buffer whose first channels already hold ``params`` (the hyper-synthesis
+        wrote them there); the masked conv writes its slice in place and ``extra`` is copied behind it."""
         ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
         ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
+        if buf is not None:
+            c0 = buf.shape[1] - ctx_m.out_channels - (0 if extra is None else extra.shape[1])
+            ctx_m.forward_into(y_hat, buf, c0)
+            if extra is not None:
+                Fn.copy_into(extra, buf, c0 + ctx_m.out_channels)
+            return _seq3_hi(ep, buf).chunk(2, 1)
         ctx = ctx_m(y_hat)
         cat = (params, ctx) if extra is None else (params, ctx, extra)
         return _seq3_hi(ep, torch.cat(cat, 1)).chunk(2, 1)
+
+    def _params_buffer(self, seq, z_hat, y_like, extra_channels=0):
+        """h_s(z_hat) written straight into the first channels of the entropy-parameter net's input buffer."""
+        B, _, H, W = y_like.shape
+        c_par = seq[4].out_channels
+        buf = Fn._empty_nhwc(B, c_par + 2 * self.M + extra_channels, H, W, Fn.compute_dtype(), z_hat.device)
+        seq[4].run_into(seq[2].run(seq[0].run(z_hat, act=LEAKY), act=LEAKY), buf, 0)
+        return buf
 
     def _gauss_pixel(self, which, params, y_pad, h, w, extra=None):
         """(scales, means) of pixel (h, w) from the 5x5 crop of the padded, partially decoded map (:903-911)."""
