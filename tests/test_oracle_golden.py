@@ -203,6 +203,34 @@ def test_whole_model_forward(kind, size, batch):
         close(out["likelihoods"]["z1"], g["lik_z1"], 1e-3, 1e-8)
 
 
+def test_warp_against_a_third_party_sampler():
+    """kornia is absent, so the warp cannot be pinned by a run of it.  What CAN be pinned by code the builder did
+    not write: the align_corners=True semantics -- destination pixel p samples the source at H^-1 p, bilinear, zeros outside (what
+    kornia >= 0.5 and cv2.warpPerspective document) -- against scipy.ndimage.map_coordinates(order=1, mode="constant")."""
+    import numpy as np
+    from scipy.ndimage import map_coordinates
+    g = torch.Generator().manual_seed(11)
+    src = torch.rand(2, 3, 20, 28, generator=g)
+    Hs = []
+    for b in range(2):
+        H = torch.eye(3)
+        H[:2, :] += (torch.rand(2, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.2, 6.0])
+        H[2, :2] = (torch.rand(2, generator=g) - 0.5) * 4e-3
+        Hs.append(H)
+    Hm = torch.stack(Hs)
+    Ho, Wo = 20, 28
+    out = O.warp_perspective(src, Hm, (Ho, Wo), align_corners=True).numpy()
+    ys, xs = np.meshgrid(np.arange(Ho, dtype=np.float64), np.arange(Wo, dtype=np.float64), indexing="ij")
+    for b in range(2):
+        s = np.linalg.inv(Hm[b].double().numpy()) @ np.stack([xs.ravel(), ys.ravel(), np.ones(Ho * Wo)])
+        sx, sy = s[0] / s[2], s[1] / s[2]
+        for c in range(3):
+            ref = map_coordinates(src[b, c].double().numpy(), [sy, sx], order=1, mode="constant", cval=0.0).reshape(Ho, Wo)
+            inside = ((sx >= 0) & (sx <= 27) & (sy >= 0) & (sy <= 19)).reshape(Ho, Wo)      # scipy drops the half-covered border taps
+            assert inside.mean() > 0.5
+            np.testing.assert_allclose(out[b, c][inside], ref[inside], rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
 @pytest.mark.parametrize("align", [True, False], ids=["ac1", "ac0"])
 def test_whole_model_forward_non_square_both_warp_conventions(kind, align):
