@@ -275,6 +275,26 @@ def test_critical_chain_schedule_is_race_free_back_to_back(which):
         models.OVERLAP_STREAMS = keep
 
 
+def test_auto_forward_picks_a_mode_and_returns_the_eager_tensors():
+    from hesic_amd import models
+    net = build("hsic", torch.bfloat16)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(2, 2, 128, 128))
+    auto = models.AutoForward(net, x1, x2, Hm, trial=5)
+    assert auto.mode in ("eager", "graph") and set(auto.timings) == {"eager", "graph"}
+    with torch.no_grad():
+        ref = net(x1, x2, Hm)
+    for forced in ("eager", "graph"):
+        auto.mode = forced
+        out = auto(x1, x2, Hm)
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(out[k], ref[k]), (forced, k)
+    a, b, h = (t.to(DEV) for t in synthetic.stereo_batch(3, 1, 128, 128))       # another shape: eager, whatever the mode
+    out = auto(a, b, h)
+    with torch.no_grad():
+        ref1 = net(a, b, h)
+    assert torch.equal(out["x2_hat"], ref1["x2_hat"])
+
+
 def test_graphed_forward_replays_the_eager_result():
     """HIP-graph capture of the whole eval forward (side streams included) + reductions: replay == eager, bit for bit, also
     for new inputs copied into the static buffers."""

@@ -224,6 +224,15 @@ def test_cat_conv_with_fused_three_channel_gdn(on_input):
         Fn.FUSE_GDN3 = keep
     assert rel_err(y, ref) < 2e-5 and rel_err(y2, ref) < 2e-5
     assert rel_err(y, y2) < 2e-6
+    if on_input:         # the input-side form covers exactly the first tensor's three channels: anything else is an error, not a guess
+        from hesic_amd import _lib as L
+        import ctypes as C
+        out = torch.empty((B, 3, H, W), device=DEV)
+        d = Fn._sdesc(xa.to(DEV), out, 6, 3, 5, 1, 2, True)
+        xb4 = torch.cat((xb, xb[:, :1]), 1).to(DEV)
+        with pytest.raises(RuntimeError, match="first tensor's three channels"):
+            L.call("hesic_sconv2d_forward_cat_gdn", C.byref(d), L.ptr(xa[:, :2].contiguous().to(DEV)), L.ptr(xb4), (C.c_int64 * 4)(*xb4.stride()),
+                   L.dt(xb4), 2, L.ptr(w.to(DEV)), L.ptr(b.to(DEV)), L.ptr(g.beta), L.ptr(g.gamma), float(g.beta_min), 1, 1, L.ptr(out), L.stream())
 
 
 def test_masked_conv_matches_golden(ops_golden):
