@@ -42,6 +42,35 @@ def _is_narrow(c):
     return c <= 8
 
 
+class _AllFalse:
+    def __getitem__(self, i):
+        return False
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when grad mode is off: ``Function.apply`` costs ~10 us of host time per call (16+ calls
+    per eval forward) to build a graph node nobody will use; ``_apply`` calls ``forward`` directly then."""
+    needs_input_grad = _AllFalse()
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def mark_dirty(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+def _apply(fn, *args):
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoCtx(), *args)
+
+
 FUSE_GDN3 = __import__("os").environ.get("HESIC_NO_FUSE_GDN3") is None      # A/B switch: 3-channel (I)GDN inside the 6 -> 3 cat-conv launch
 
 
@@ -607,7 +636,7 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
     B, _, H, W = x.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
     if Cin == 3 and torch.is_grad_enabled():
-        return _SConvGdnFn.apply(x, weight, bias, beta, gamma, (k, stride, padding, inverse, beta_min, gdn_packer))
+        return _apply(_SConvGdnFn, x, weight, bias, beta, gamma, (k, stride, padding, inverse, beta_min, gdn_packer))
     if Cin == 3:      # image-side stage: strided fp32/bf16 image in, bf16 NHWC out
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
         out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
@@ -616,7 +645,7 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
                L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(out), None, L.stream())
         return out
     if torch.is_grad_enabled():
-        return _ConvGdnFn.apply(x, weight, bias, beta, gamma, (k, stride, padding, transposed, inverse, beta_min, packer, gdn_packer))
+        return _apply(_ConvGdnFn, x, weight, bias, beta, gamma, (k, stride, padding, transposed, inverse, beta_min, packer, gdn_packer))
     x = _nhwc(x)
     wp = packer.get(weight, None, Cout, Cin, k, k, transposed, False, x.dtype)
     gp, bp = gdn_packer.get(beta, gamma, beta_min)
@@ -630,7 +659,7 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
 def conv2d(x, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, in_abs=False,
            tap_mask=0, packer=None, mask=None):
     packer = packer if packer is not None else PackedWeight()
-    return _ConvFn.apply(x, weight, bias, (kernel_size, stride, padding, transposed, act, int(in_abs), tap_mask, packer, mask))
+    return _apply(_ConvFn, x, weight, bias, (kernel_size, stride, padding, transposed, act, int(in_abs), tap_mask, packer, mask))
 
 
 FP32_LATENTS = _os.environ.get("HESIC_BF16_LATENTS") is None      # A/B switch: set to store latents / sigma / mu as bf16 again
@@ -900,7 +929,7 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
         L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y), B, Cc, H * W,
                int(inverse), float(beta_min), L.dt(x), L.stream())
         return y
-    return _GdnFn.apply(x, beta, gamma, inverse, beta_min)
+    return _apply(_GdnFn, x, beta, gamma, inverse, beta_min)
 
 
 # ----------------------------------------------------------------------------------- warp
@@ -940,7 +969,7 @@ class _WarpFn(torch.autograd.Function):
 def warp_perspective(src, M, dsize, align_corners=True, inverse_map=False):
     """``inverse_map``: ``M`` already maps destination pixels to source pixels, i.e. this is the warp by ``M^-1``
     (Independent_EN warps view 2 by ``torch.inverse(h_matrix)``, newnet1.py:1290-1291: no 3x3 inversion launches)."""
-    return _WarpFn.apply(src, M, dsize, align_corners, inverse_map)
+    return _apply(_WarpFn, src, M, dsize, align_corners, inverse_map)
 
 
 # ---------------------------------------------------------------------- entropy bottleneck
@@ -1089,7 +1118,7 @@ def entropy_bottleneck(z, matrices, biases, factors, quantiles, noise=None, pack
         lik = _empty_nhwc(B, Cc, H, W, torch.float32, z.device)
         L.call("hesic_eb_forward", L.ptr(z), L.ptr(table), None, L.ptr(zh), L.ptr(lik), None, B * H * W, Cc, L.dt(z), L.stream())
         return zh, lik
-    return _EbFn.apply(z, noise, quantiles, len(matrices), float(lik_bound), *matrices, *biases, *factors)
+    return _apply(_EbFn, z, noise, quantiles, len(matrices), float(lik_bound), *matrices, *biases, *factors)
 
 
 class _EbAuxFn(torch.autograd.Function):
@@ -1207,13 +1236,13 @@ def _use_f32in(y, noise, out_dtype, K, M):
 def gaussian_mixture(y, scales, means, weights, K, noise=None, scale_bound=0.11, lik_bound=1e-9, out_dtype=None):
     if _use_f32in(y, noise, out_dtype, K, y.shape[1]):
         return _gmm_f32in(y, scales, means, weights, K, False, scale_bound, lik_bound, out_dtype)
-    return _GmmFn.apply(y, scales, means, weights, noise, K, False, scale_bound, lik_bound)
+    return _apply(_GmmFn, y, scales, means, weights, noise, K, False, scale_bound, lik_bound)
 
 
 def gaussian_conditional(y, scales, means=None, noise=None, scale_bound=0.11, lik_bound=1e-9, out_dtype=None):
     if means is not None and _use_f32in(y, noise, out_dtype, 1, y.shape[1]):
         return _gmm_f32in(y, scales, means, None, 1, True, scale_bound, lik_bound, out_dtype)
-    return _GmmFn.apply(y, scales, means, None, noise, 1, means is not None, scale_bound, lik_bound)
+    return _apply(_GmmFn, y, scales, means, None, noise, 1, means is not None, scale_bound, lik_bound)
 
 
 def gmm_cdf_tables(scales, means, weights, channels, minmax, K, b=0, scale_bound=0.11):
@@ -1280,7 +1309,7 @@ class _Upsample4CatFn(torch.autograd.Function):
 
 
 def upsample4_cat(z, y1):
-    return _Upsample4CatFn.apply(z, y1)
+    return _apply(_Upsample4CatFn, z, y1)
 
 
 class _Upsample4Fn(torch.autograd.Function):
@@ -1304,7 +1333,7 @@ class _Upsample4Fn(torch.autograd.Function):
 
 
 def upsample4(z):
-    return _Upsample4Fn.apply(z)
+    return _apply(_Upsample4Fn, z)
 
 
 class _SpatialMaxFn(torch.autograd.Function):
@@ -1337,7 +1366,7 @@ class _SpatialMaxFn(torch.autograd.Function):
 
 
 def spatial_max(x, leaky=False):
-    return _SpatialMaxFn.apply(x, leaky)
+    return _apply(_SpatialMaxFn, x, leaky)
 
 
 class _SoftmaxKFn(torch.autograd.Function):
@@ -1366,7 +1395,7 @@ class _SoftmaxKFn(torch.autograd.Function):
 
 
 def softmax_k(logits, K, M):
-    return _SoftmaxKFn.apply(logits, K, M)
+    return _apply(_SoftmaxKFn, logits, K, M)
 
 
 class _PooledLinearFn(torch.autograd.Function):
@@ -1414,7 +1443,7 @@ class _PooledLinearFn(torch.autograd.Function):
 
 
 def pooled_linear(pooled, weight, bias):
-    return _PooledLinearFn.apply(pooled, weight, bias)
+    return _apply(_PooledLinearFn, pooled, weight, bias)
 
 
 def mix_weights(pooled, weight, bias, K, M):
