@@ -49,7 +49,8 @@ class KernelMeter:
     """One HIP event pair around every implicit-GEMM launch (hesic_conv2d_forward[_ws|_f32out] / hesic_conv2d_gdn_forward),
     recorded on the stream the kernel is launched on; the launch descriptor gives the algorithmic FLOPs and
     hesic_conv2d_variant names the instantiation the library picked."""
-    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward", "hesic_conv2d_forward_grouped")
+    NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward", "hesic_conv2d_forward_grouped",
+             "hesic_conv2d_forward_hilo")
 
     STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
               "hesic_sconv2d_gdn_forward_prepacked": "conv1_3to128_gdn (n2w)", "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)",
@@ -88,10 +89,13 @@ class KernelMeter:
             e1.record()
             ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
             fl = conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)
-            fused = name.endswith("gdn_forward")
+            hilo = name.endswith("_hilo")
+            fused = name.endswith("gdn_forward") or (hilo and args[4] is not None and getattr(args[4], "value", None))
             if fused:
                 fl += 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cout          # the GDN 1x1 contraction (SURVEY 8d counts it)
-            self.rec.append((e0, e1, fl, self.variant(d, fused) + (" grouped" if name.endswith("grouped") else "")))
+            # a hi/lo (bf16x3) launch EXECUTES three bf16 MFMA products per algorithmic MAC: x_hi w_hi + x_lo w_hi + x_hi w_lo
+            self.rec.append((e0, e1, fl, self.variant(d, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else ""),
+                             3.0 if hilo else 1.0))
             return rc
         self.L.call = call
         return self
@@ -111,14 +115,14 @@ class KernelMeter:
         """Per kernel instantiation: launches, summed event time, algorithmic FLOPs; returns the dominant one."""
         torch.cuda.synchronize()
         agg = {}
-        for e0, e1, f, name in self.rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for e0, e1, f, name, mult in self.rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0, mult])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += f
         if not agg:
             return None
-        name, (n, t, f) = max(agg.items(), key=lambda kv: kv[1][1])
+        name, (n, t, f, mult) = max(agg.items(), key=lambda kv: kv[1][1])
         streaming = {}
         for k, recs in self.stream.items():
             ts = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
@@ -126,8 +130,10 @@ class KernelMeter:
             streaming[k] = {"bound": "hbm", "achieved": round(by / ts / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / ts / 1e9 / HBM_PEAK_GBS, 4),
                             "launches": len(recs), "avg_launch_us": round(1e6 * ts / len(recs), 2), "bytes_per_launch": int(by / len(recs))}
         self.streaming = streaming
-        return {"kernel": name, "launches": n, "avg_us": 1e6 * t / n, "tflops": f / t / 1e12, "flops_per_launch": f / n,
-                "all": {k: {"launches": v[0], "avg_us": round(1e6 * v[1] / v[0], 2), "tflops": round(v[2] / v[1] / 1e12, 1)}
+        return {"kernel": name, "launches": n, "avg_us": 1e6 * t / n, "tflops": mult * f / t / 1e12, "flops_per_launch": mult * f / n,
+                "mfma_products_per_mac": mult, "algorithmic_tflops": f / t / 1e12,
+                "all": {k: {"launches": v[0], "avg_us": round(1e6 * v[1] / v[0], 2), "tflops": round(v[3] * v[2] / v[1] / 1e12, 1),
+                            **({"algorithmic_tflops": round(v[2] / v[1] / 1e12, 1)} if v[3] != 1.0 else {})}
                         for k, v in agg.items()}}
 
 
@@ -418,6 +424,9 @@ def main():
                     "one (model, batch) unit per rank and step, models rotating over ranks and steps")
     ap.add_argument("--warp-align-corners", type=int, choices=[0, 1], default=None,
                     help="0: kornia <= 0.4 sampling (what torch-1.6-era checkpoints were trained with), 1: kornia >= 0.5 (default)")
+    ap.add_argument("--analysis", choices=["bf16", "bf16x3"], default=None,
+                    help="operand precision of the analysis transforms + hyper-analysis at bf16 inference: bf16x3 (default) = hi/lo bf16 pairs, "
+                         "fp32-grade latents; bf16 = single-bf16 operands (round 2: ~1 %% of the latents flip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (models.GraphedForward) instead of issuing it eagerly")
     ap.add_argument("--exec", dest="exec_mode", choices=["auto", "eager", "graph"], default="auto",
@@ -432,6 +441,8 @@ def main():
     import torch.distributed as dist
     if args.warp_align_corners is not None:
         geometry.DEFAULT_ALIGN_CORNERS = bool(args.warp_align_corners)
+    if args.analysis is not None:
+        Fn.set_analysis_precision(args.analysis)
     if args.sweep and not (args.height or args.width):
         args.height, args.width = 860, 1080
 

@@ -56,6 +56,22 @@ class HipConv2d(nn.Conv2d):
                                 padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                                 want_lo=want_lo)
 
+    def run_hilo(self, x_hilo, act=L.ACT_NONE, out="hilo", out_abs=False, gdn=None):
+        """self on a hi/lo bf16 map (the bf16x3 analysis mode, ``Fn.conv2d_hilo``): ``x_hilo`` is the (B, 2*Cin, H, W) tensor;
+        ``gdn``: the GDN module behind the conv (fused hi/lo epilogue)."""
+        self._check()
+        if not hasattr(self, "_packer_hl"):
+            self._packer_hl = Fn.PackedWeightHiLo()
+        g = None
+        if gdn is not None:
+            if not hasattr(gdn, "_packer_lo"):
+                gdn._packer_lo = Fn.PackedGdnLo()
+            gp, bp = gdn.packer().get(gdn.beta, gdn.gamma, gdn.beta_min)
+            g = (gp, gdn._packer_lo.get(gdn.gamma), bp, gdn.inverse)
+        return Fn.conv2d_hilo(x_hilo, self._packer_hl.get(self.weight), self.bias, self.weight.shape[1], self.weight.shape[0],
+                              kernel_size=self.kernel_size[0], stride=self.stride[0], padding=self.padding[0], gdn=g, act=act, out=out,
+                              out_abs=out_abs)
+
     def run_gdn(self, x, gdn):
         """gdn(self(x)); one fused kernel when eligible (inference, bf16 storage, 128 channels), else two ops."""
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False) and (self.weight.shape[1] != 3 or self.stride[0] == 2):

@@ -52,6 +52,12 @@ struct IgemmArgs {
     int dbg;                   // profiling ablations (HESIC_IGEMM_DBG, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMAs
     float* y32;                // bf16 fast path: also (or, with y == nullptr, only) store act(conv + bias) as fp32 straight from the
     int y32_ps, y32_co;        //      accumulators -- what feeds round() and the likelihoods must not pass through bf16 storage
+    // bf16x3 ("hi/lo") operands, hesic_conv2d_forward_hilo (kernel template flag HL): x holds [hi(C) | lo(C)] per pixel (v = hi + lo
+    // to 2^-17), the packed weights [w_hi(C) | w_lo(C)] per (tap, cout) (Cin = 2C here).  A stage brings BK/2 channels of all four
+    // operand halves into LDS -- LDS row = [hi chunk | lo chunk] -- and the matrix cores form x_hi w_hi + x_lo w_hi + x_hi w_lo in
+    // the fp32 accumulators: 3 MFMAs per staged byte pair instead of a 3x longer K loop (x_lo w_lo, 2^-18, is dropped).
+    int y_hilo, y_abs;         // plain epilogue: y as [hi(Cout) | lo(Cout)] pairs, optionally of |v|
+    const void* gdn_gamma_lo;  // hi/lo GDN epilogue (GDN = 3 | 4): fragment-order lo half of gamma' (hesic_gdn_pack_params_lo)
 };
 
 // Tap geometry of one launch phase, all wave-uniform scalars.
@@ -355,7 +361,7 @@ constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { retur
 // an L1-resident source (DBG=14 vs 6: 53 us from L2) -- 1.64 GB through the ~64 B/clk/CU global->LDS path, which a 128 x 128
 // tile needs at 62.5 B/clk/CU to feed the matrix cores at peak.  The bound is the tile's arithmetic intensity against that
 // path (and against L2: 33 TB/s), not issue scheduling; only a larger (cout x pixel) tile moves it.
-template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS = 0>
+template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS = 0, int HL = 0>
 __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
     constexpr int NTHREADS = NW * 64;          // COMPUTE threads (the epilogue's copy loops stride by this)
     using T = bf16_t;
@@ -372,6 +378,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
     static_assert(!WS || (BMP == 128 && BN == 128 && NW == 4), "the wave-specialised form is built for the 128 x 128 tile");
     static_assert(GDN == 0 || BN == 128, "fused GDN needs every channel of a pixel in the block");
+    static_assert(!HL || !WS, "hi/lo operands: self-loading form only");
+    constexpr int BKH = HL ? BK / 2 : BK;     // channels a stage advances by (HL: a row holds BK/2 hi channels and their BK/2 lo partners)
     constexpr int YOFF = BM * 256;                            // fused GDN: squared tile at 0, output tile behind it
     constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
     constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
@@ -446,13 +454,15 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         const bool ok = qy < a.QH && qx < a.QW;
         iy0[i] = ok ? qy * a.in_step : (int)0xc0000000;            // far outside: every tap of a dead row reads zeros
         ix0[i] = qx * a.in_step;
-        xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + gco + ls * 8) * 2);
+        const int lc = HL ? (ls % (CPR / 2)) * 8 + (ls / (CPR / 2)) * (a.Cin / 2) : ls * 8;     // HL: slots >= CPR/2 come from the lo half, C channels further
+        xoff[i] = (uint32_t)((((qy * a.in_step - row0) * a.W + qx * a.in_step) * a.x_ps + a.x_co + gco + lc) * 2);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int row = (lw * WI + i) * (64 / CPR) + prow;
         const int ls = pslot ^ ((row / RPB) & (CPR - 1));
-        wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2) : OOB;
+        const int lc = HL ? (ls % (CPR / 2)) * 8 + (ls / (CPR / 2)) * (a.Cin / 2) : ls * 8;
+        wv[i] = (n0 + row) < a.Cout ? (uint32_t)(((n0 + row) * a.Cin + lc) * 2) : OOB;
     }
     // tap cursor (all SGPR): input displacement moves by +1 (conv) / -1 (transposed phase) per tap index
     const int dstep = a.transposed ? -1 : 1;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     };
     auto issue = [&](int buf) {
         if (a.dbg & 1) return;
-        uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+        uint32_t sx = s_x + (uint32_t)(cur_chunk * BKH * 2), sw = s_w + (uint32_t)(cur_chunk * BKH * 2);
         if (a.dbg & 8) {          // every piece re-reads the first kilobytes of its tensor: L1-resident source, same LDS traffic
             sx = (uint32_t)(neg * 2); sw = 0;
 #pragma unroll
@@ -563,6 +573,44 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XT;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
+            if constexpr (HL) {
+                // hi/lo operands: per 16-deep k-substep four fragment groups (w_hi, w_lo, x_hi, x_lo) feed 3 * MI * NI MFMAs
+                constexpr int KSH = BK / 32, LO = CPR / 2;
+                bf16x8 wh[2][MI], wl[2][MI], xh[2][NI], xl[2][NI];
+                auto ldh = [&](int set, int ks) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int r = wm * (BN / WM) + i * 32 + frow;
+                        wh[set][i] = *(const bf16x8*)(ws + off(r, ks * 2 + fh));
+                        wl[set][i] = *(const bf16x8*)(ws + off(r, LO + ks * 2 + fh));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int r = wn * (BM / WN) + j * 32 + frow;
+                        xh[set][j] = *(const bf16x8*)(xs + off(r, ks * 2 + fh));
+                        xl[set][j] = *(const bf16x8*)(xs + off(r, LO + ks * 2 + fh));
+                    }
+                };
+                ldh(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + NS - 1 < nsteps) issue(nxt);
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) {
+                    if (ks + 1 < KSH) ldh((ks + 1) & 1, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], xl[ks & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             bf16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
                 if (a.dbg & 2) return;
@@ -650,39 +698,181 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             }
             if (!a.y) return;
         }
-        __syncthreads();     // every wave is done with the ring before the epilogue reuses it
+        // plain epilogue; with a.y_hilo the output is written twice through the same staging tile: channels [y_co, +Cout) take
+        // hi = bf16(v), channels [y_co + Cout, +Cout) lo = bf16(v - hi), v = act(conv + bias) (|v| with a.y_abs: the hyper-analysis reads |y|)
+        T* __restrict__ yg = (T*)a.y;
+        const int oyo = taps.ry, oxo = taps.rx;
+        const int nhalf = a.y_hilo ? 2 : 1;
+        for (int half = 0; half < nhalf; ++half) {
+            __syncthreads();     // every wave is done with the ring (or with the previous half's rows) before the tile is rewritten
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                    float bv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int pr = wn * (BM / WN) + j * 32 + frow;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], act_eff);
+                            if (a.y_abs) v[e] = fabsf(v[e]);
+                        }
+                        u32x2 o = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        if (half)
+                            o = u32x2{pack_bf2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xffff0000u)),
+                                      pack_bf2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xffff0000u))};
+                        *(u32x2*)(smem + pr * OROW + cl * 2) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int CPO = BN * 2 / 16;
+            constexpr int TOT = BM * CPO;
+#pragma unroll
+            for (int c = tid; c < TOT; c += NTHREADS) {
+                const int pr = c / CPO, cc = c % CPO;
+                const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+                const int ch = n0 + cc * 8;
+                if (qy < a.QH && qx < a.QW && ch < a.Cout) {
+                    const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
+                    const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + half * a.Cout + ch;
+                    *(u32x4*)(yg + o) = *(const u32x4*)(smem + pr * OROW + cc * 16);
+                }
+            }
+        }
+    } else if constexpr (GDN >= 3) {
+        // ---- fused (I)GDN epilogue on hi/lo operands (analysis path of the bf16x3 mode): same data flow as the epilogue below,
+        // but nothing passes through ONE bf16: the squares go to LDS as a hi tile and a lo tile, the contraction is
+        // gamma_hi sq_hi + gamma_hi sq_lo + gamma_lo sq_hi on top of beta' (fp32 accumulators), the product v * rsqrt(nrm) stays
+        // fp32 and leaves as [hi(128) | lo(128)] per pixel -- 2^-17 relative instead of 2^-9 at every layer boundary.
+        constexpr bool INV = GDN == 4;
+        f32x16 nrm[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
-                float bv[4];
+                const f32x4 t = a.bias ? *(const f32x4*)(a.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 be = *(const f32x4*)(a.gdn_beta + cl);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = (a.bias && (n0 + cl + e) < a.Cout) ? a.bias[n0 + cl + e] : 0.f;
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) { acc[i][j][4 * g + e] += t[e]; nrm[i][j][4 * g + e] = be[e]; }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 gq[MI][8];
+        {
+            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) {
+            hi = pack_bf2(p, q);
+            lo = pack_bf2(p - __uint_as_float(hi << 16), q - __uint_as_float(hi & 0xffff0000u));
+        };
+        asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int pr = wn * (BM / WN) + j * 32 + frow;
+                    const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                    uint32_t h0, l0, h1, l1;
+                    split2(v0 * v0, v1 * v1, h0, l0);
+                    split2(v2 * v2, v3 * v3, h1, l1);
+                    const u32x2 h = u32x2{h0, h1}, l = u32x2{l0, l1};
+                    const int o = pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2;
+                    *(u32x2*)(smem + o) = h;
+                    *(u32x2*)(smem + YOFF + o) = l;
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // squares visible to every wave
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            bf16x8 qh[NI], ql[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                qh[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                ql[j] = *(const bf16x8*)(smem + YOFF + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+                    nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], ql[j], nrm[i][j], 0, 0, 0);
+                }
+        }
+        {
+            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma_lo;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            bf16x8 qh[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pr = wn * (BM / WN) + j * 32 + frow;
+                qh[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has consumed both square tiles
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], act_eff);
-                    *(u32x2*)(smem + pr * OROW + cl * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    for (int e = 0; e < 4; ++e) {
+                        const float n = nrm[i][j][4 * g + e];
+                        v[e] = acc[i][j][4 * g + e] * (INV ? sqrtf(n) : rsqrtf(n));
+                    }
+                    uint32_t h0, l0, h1, l1;
+                    split2(v[0], v[1], h0, l0);
+                    split2(v[2], v[3], h1, l1);
+                    const u32x2 h = u32x2{h0, h1}, l = u32x2{l0, l1};
+                    const int o = pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2;
+                    *(u32x2*)(smem + o) = h;
+                    *(u32x2*)(smem + YOFF + o) = l;
                 }
             }
-        }
-        __syncthreads();
-        constexpr int CPO = BN * 2 / 16;
-        constexpr int TOT = BM * CPO;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        constexpr int TOT = BM * 16;
         T* __restrict__ yg = (T*)a.y;
-        const int oyo = taps.ry, oxo = taps.rx;
 #pragma unroll
-        for (int c = tid; c < TOT; c += NTHREADS) {
-            const int pr = c / CPO, cc = c % CPO;
-            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
-            const int ch = n0 + cc * 8;
-            if (qy < a.QH && qx < a.QW && ch < a.Cout) {
-                const int oy = qy * a.out_step + oyo, ox = qx * a.out_step + oxo;
-                const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + ch;
-                *(u32x4*)(yg + o) = *(const u32x4*)(smem + pr * OROW + cc * 16);
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int c = tid; c < TOT; c += NTHREADS) {
+                const int pr = c >> 4, cc = c & 15;
+                const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+                if (qy < a.QH && qx < a.QW) {
+                    const int oy = qy * a.out_step + taps.ry, ox = qx * a.out_step + taps.rx;
+                    const int64_t o = (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.y_ps + a.y_co + half * 128 + cc * 8;
+                    *(u32x4*)(yg + o) = *(const u32x4*)(smem + half * YOFF + pr * 256 + ((cc ^ (pr & 15)) << 4));
+                }
             }
         }
     } else {
@@ -821,7 +1011,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
 // y = act(sum of the K-slice partials + bias) as bf16 (y) and / or fp32 (y32): one thread per pixel and 8 channels
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int64_t npix, int Cout,
                                                             const float* __restrict__ bias, int act, bf16_t* __restrict__ y,
-                                                            int y_ps, int y_co, float* __restrict__ y32, int y32_ps, int y32_co) {
+                                                            int y_ps, int y_co, float* __restrict__ y32, int y32_ps, int y32_co,
+                                                            int y_hilo, int y_abs) {
     const int cg = Cout >> 3;
     const int64_t total = npix * cg, slice = npix * Cout;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -840,9 +1031,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             *(f32x4*)(y32 + p * y32_ps + y32_co + c) = lo;
             *(f32x4*)(y32 + p * y32_ps + y32_co + c + 4) = hi;
         }
-        if (y)
-            *(u32x4*)(y + p * y_ps + y_co + c) =
-                u32x4{pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+        if (y) {
+            if (y_abs) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = fabsf(lo[e]); hi[e] = fabsf(hi[e]); }
+            }
+            const u32x4 o = u32x4{pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+            *(u32x4*)(y + p * y_ps + y_co + c) = o;
+            if (y_hilo)       // second half of a hi/lo pair map: bf16(v - bf16(v)) at channel offset Cout
+                *(u32x4*)(y + p * y_ps + y_co + Cout + c) =
+                    u32x4{pack_bf2(lo[0] - __uint_as_float(o.x << 16), lo[1] - __uint_as_float(o.x & 0xffff0000u)),
+                          pack_bf2(lo[2] - __uint_as_float(o.y << 16), lo[3] - __uint_as_float(o.y & 0xffff0000u)),
+                          pack_bf2(hi[0] - __uint_as_float(o.z << 16), hi[1] - __uint_as_float(o.z & 0xffff0000u)),
+                          pack_bf2(hi[2] - __uint_as_float(o.w << 16), hi[3] - __uint_as_float(o.w & 0xffff0000u))};
+        }
     }
 }
 
@@ -951,6 +1153,22 @@ __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __r
     }
 }
 
+// lo half of gamma' for the hi/lo GDN epilogue, MFMA A-fragment order (as the second half of gdn_pack_kernel's buffer):
+// gamma'_lo = bf16(gamma' - float(bf16(gamma'))), so gamma'_hi + gamma'_lo = gamma' to 2^-17
+__global__ void gdn_pack_lo_kernel(const float* __restrict__ gamma, bf16_t* __restrict__ glo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * 16) return;
+    const int row = i >> 4, slot = i & 15;
+    const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
+    bf16_t* frag = glo + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = fmaxf(gamma[row * 128 + slot * 8 + e], gb);
+        const float g = t * t - ped;
+        frag[e] = f2bf(g - bf2f(f2bf(g)));
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- C ABI
@@ -994,6 +1212,9 @@ static thread_local size_t* g_ws_need = nullptr;         // set by hesic_conv2d_
 static thread_local int g_groups = 1, g_x_group_step = 0, g_act2 = 0, g_act_split = 0;   // set by hesic_conv2d_forward_grouped
 static thread_local float* g_y32 = nullptr;              // set by hesic_conv2d_forward_f32out: fp32 copy of the output
 static thread_local int g_y32_ps = 0, g_y32_co = 0;
+static thread_local int g_hilo = 0;                      // set by hesic_conv2d_forward_hilo: bf16x3 operands
+static thread_local const void* g_gdn_gamma_lo = nullptr;
+static thread_local int g_y_hilo = 0, g_y_abs = 0;
 
 extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                                      int C, void* stream) {
@@ -1003,6 +1224,13 @@ extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, floa
                        (bf16_t*)gamma_packed, beta_packed);
     HESIC_LAUNCH_RETURN("gdn_pack_params");
 }   // when set, hesic_conv2d_forward only reports its tile choice
+
+extern "C" int hesic_gdn_pack_params_lo(const float* gamma, void* gamma_lo_packed, int C, void* stream) {
+    HESIC_CHECK_ARG(gamma && gamma_lo_packed, "gdn_pack_params_lo: null pointer");
+    HESIC_CHECK_ARG(C == 128, "gdn_pack_params_lo: the fused conv+GDN epilogue is built for C == 128 (got %d)", C);
+    hipLaunchKernelGGL(gdn_pack_lo_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, gamma, (bf16_t*)gamma_lo_packed);
+    HESIC_LAUNCH_RETURN("gdn_pack_params_lo");
+}
 
 extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                     void* y, void* stream);
@@ -1040,6 +1268,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
                                     void* y, void* stream) {
     HESIC_CHECK_ARG(d && x && w_packed && (y || g_y32), "conv2d_forward: null pointer");
     HESIC_CHECK_ARG(d->Cin % BK == 0, "conv2d_forward: Cin=%d must be a multiple of %d (use hesic_sconv2d_forward)", d->Cin, BK);
+    HESIC_CHECK_ARG(!g_hilo || ((g_gdn_mode == 0 || g_gdn_mode >= 3) && g_groups == 1 && !g_act_split), "conv2d_forward_hilo: plain or hi/lo GDN epilogue, no groups");
+    const int hilo = g_hilo;                       // bf16x3 operands: x = [hi | lo] (2 Cin channels), weights [w_hi | w_lo] (2 Cin per tap and cout)
+    HESIC_CHECK_ARG(!hilo || d->Cin % 32 == 0, "conv2d_forward_hilo: Cin must be a multiple of 32");
+    const int cin_k = hilo ? 2 * d->Cin : d->Cin;  // channels per tap of the packed weights; a stage of BK covers BK/2 logical channels then,
+                                                   // so every "Cin % BK" tile-selection rule below applies to cin_k
     const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
     HESIC_CHECK_ARG(d->Cout % ce == 0 && d->y_c_off % ce == 0 && d->y_pix_stride % ce == 0 && d->x_c_off % ce == 0 &&
                         d->x_pix_stride % ce == 0,
@@ -1047,18 +1280,18 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     HESIC_CHECK_ARG(d->KH * d->KW <= MAX_TAPS, "conv2d_forward: at most %d taps", MAX_TAPS);
     HESIC_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv2d_forward: stride must be 1 or 2");
     HESIC_CHECK_ARG(d->dtype == HESIC_BF16 || d->dtype == HESIC_F32, "conv2d_forward: bad dtype");
-    HESIC_CHECK_ARG(d->x_c_off + d->Cin <= d->x_pix_stride && d->y_c_off + d->Cout <= d->y_pix_stride,
+    HESIC_CHECK_ARG(d->x_c_off + (hilo ? 2 : 1) * d->Cin <= d->x_pix_stride && d->y_c_off + ((hilo && (g_gdn_mode || g_y_hilo)) ? 2 : 1) * d->Cout <= d->y_pix_stride,
                     "conv2d_forward: channel slice out of range");
 
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
-    a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre;
+    a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre; a.gdn_gamma_lo = g_gdn_gamma_lo; a.y_hilo = g_y_hilo; a.y_abs = g_y_abs;
     a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
     static const int dbg = getenv("HESIC_IGEMM_DBG") ? atoi(getenv("HESIC_IGEMM_DBG")) : 0;
     a.dbg = dbg;
     const int gdn = g_gdn_mode;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = cin_k; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
     a.act = d->act; a.in_abs = d->in_abs;
     const int s = d->stride, p = d->pad;
@@ -1101,9 +1334,9 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     };
     if (fast) {
         if (count_blocks(128) < 384) bm = 64;
-        if (bm == 64 && count_blocks(64) < 384 && BN == 128 && d->Cin % 64 == 0) bm = 32;
+        if (bm == 64 && count_blocks(64) < 384 && BN == 128 && cin_k % 64 == 0) bm = 32;
         static const int force_bm = getenv("HESIC_IGEMM_BM") ? atoi(getenv("HESIC_IGEMM_BM")) : 0;      // A/B switch
-        if (force_bm == 128 || force_bm == 64 || (force_bm == 32 && BN == 128 && d->Cin % 64 == 0)) bm = force_bm;
+        if (force_bm == 128 || force_bm == 64 || (force_bm == 32 && BN == 128 && cin_k % 64 == 0)) bm = force_bm;
     }
     // Split-K for the low-resolution layers (hyper path: 8x8 .. 32x32 maps): with so few pixels a full-K block per tile
     // leaves most CUs idle and makes every block stream the whole weight tensor.  Given a workspace, the K loop is cut
@@ -1114,11 +1347,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (fast && !gdn && !nosplit && (g_ws || g_ws_need)) {
         const int qpix = a.QH * a.QW;
         int bm_s = qpix >= 128 ? 128 : (qpix >= 64 ? 64 : 32);
-        if (bm_s == 32 && !(BN == 128 && d->Cin % 64 == 0)) bm_s = 64;
+        if (bm_s == 32 && !(BN == 128 && cin_k % 64 == 0)) bm_s = 64;
         const int64_t nb = count_blocks(bm_s);
-        const int bk_ = d->Cin % 64 == 0 ? 64 : 32;
+        const int bk_ = cin_k % 64 == 0 ? 64 : 32;
         const int min_taps = d->transposed ? (d->KH / s) * (d->KW / s) : a.ntaps_live;
-        const int min_steps = min_taps * (d->Cin / bk_);
+        const int min_steps = min_taps * (cin_k / bk_);
         // one block per CU is the target; a very long K loop (>= 200 stages: the 960-channel data gradients) is cut further, to two
         // co-resident blocks per CU (183 us unsplit -> 108 us at 4 slices -> measured below at 8)
         static const int split_target_long = getenv("HESIC_IGEMM_SPLIT_LONG") ? atoi(getenv("HESIC_IGEMM_SPLIT_LONG")) : 512;   // A/B switch
@@ -1142,7 +1375,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     // step's 7 fused launches 132 vs 124 us -- no gain (one 8-wave block per CU marches through its barriers in lockstep and loses
     // the overlap two independent 4-wave blocks give), so it stays an A/B switch, off by default.
     static const int big = getenv("HESIC_IGEMM_BM256") ? atoi(getenv("HESIC_IGEMM_BM256")) : 0;      // A/B switch
-    if (fast && big && bm == 128 && BN == 128 && d->Cin % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
+    if (fast && big && !hilo && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
         HESIC_CHECK_ARG(d->Cout % g_groups == 0 && (d->Cout / g_groups) % BN == 0 && g_act_split % BN == 0,
@@ -1168,7 +1401,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase * ksplit;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
     if (g_plan_out) {
-        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (((bm == 32) || (bm == 64 && BN == 64)) && d->Cin % 128 == 0 ? 128 : (d->Cin % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
+        g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (((bm == 32) || (bm == 64 && BN == 64)) && cin_k % 128 == 0 ? 128 : (cin_k % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
     a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
@@ -1178,7 +1411,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \
     do {                                                                                                    \
-        if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);       \
+        if (hilo) {                                                                                         \
+            if (N_ == 128 && gdn == 3) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 3, 4, 0, 1>), grid, block, 0, st, a);       \
+            else if (N_ == 128 && gdn == 4) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 4, 4, 0, 1>), grid, block, 0, st, a);  \
+            else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 4, 0, 1>), grid, block, 0, st, a);                              \
+        }                                                                                                   \
+        else if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);  \
         else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
     } while (0)
@@ -1194,9 +1432,9 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         static const bool force_bk32 = getenv("HESIC_IGEMM_BK32") != nullptr;    // A/B switch for profiling
         // the buffer-addressed DMA keeps 32-bit offsets relative to the tile's first input row and the packed weights
         HESIC_CHECK_ARG(((int64_t)(TH * a.in_step + 2 * d->KH) * a.W + 2 * d->KW) * a.x_ps * 2 < (1ll << 31) &&
-                            (int64_t)d->KH * d->KW * d->Cout * d->Cin * 2 < (1ll << 31),
+                            (int64_t)d->KH * d->KW * d->Cout * cin_k * 2 < (1ll << 31),
                         "conv2d_forward: image rows / weights too large for 32-bit tile offsets");
-        const int bk = (d->Cin % 64 == 0 && !force_bk32) ? 64 : 32;
+        const int bk = (cin_k % 64 == 0 && !force_bk32) ? 64 : 32;
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
@@ -1206,7 +1444,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 1, 8>), grid, block2, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 2, 8>), grid, block2, 0, st, a);
             else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 0, 8>), grid, block2, 0, st, a);
-        } else if (bm == 128 && bk == 64 && BN == 128 && ws_mode && ksplit == 1) {
+        } else if (bm == 128 && bk == 64 && BN == 128 && ws_mode && !hilo && ksplit == 1) {
             const dim3 block_ws(2 * NTHREADS);
             if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
@@ -1218,8 +1456,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             // same lever as for the 32-pixel tile: BK = 128 where two 2-stage blocks still fit a CU (64 x 64 tiles: 64 KB; 128 ->
             // 192 5x5 s2 @64x64 B=8: 28.4 -> 22.3 us) or where the grid is one block per CU anyway (64 x 128 tiles, 96 KB)
             static const int bk128m = getenv("HESIC_IGEMM_BK128M") ? atoi(getenv("HESIC_IGEMM_BK128M")) : 1;       // A/B switch: 0 off, 2 = also 64x128
-            if (bk == 64 && BN == 64 && bk128m && d->Cin % 128 == 0) LAUNCH_GLDS(64, 64, 128, 2);
-            else if (bk == 64 && BN == 128 && bk128m == 2 && d->Cin % 128 == 0 && nblocks <= 256) LAUNCH_GLDS(64, 128, 128, 2);
+            if (bk == 64 && BN == 64 && bk128m && cin_k % 128 == 0) LAUNCH_GLDS(64, 64, 128, 2);
+            else if (bk == 64 && BN == 128 && bk128m == 2 && cin_k % 128 == 0 && nblocks <= 256) LAUNCH_GLDS(64, 128, 128, 2);
             else if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 32); else LAUNCH_GLDS_NS(64, 64, 32); }
         } else {
@@ -1227,7 +1465,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             // MFMAs): BK = 128 halves the stage count (8 MFMAs per wave and stage, 2-deep ring of 40 KB stages) --
             // 128 -> 128 5x5 s1 @32x32 B=8: 23.4 -> 18.8 us; a 3-deep ring was slower (20.7).  HESIC_IGEMM_BK128=0 = A/B switch.
             static const bool bk128 = !(getenv("HESIC_IGEMM_BK128") && atoi(getenv("HESIC_IGEMM_BK128")) == 0);
-            if (bk128 && d->Cin % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
+            if (bk128 && cin_k % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
             else LAUNCH_GLDS_NS(32, 128, 64);
         }
     } else if (d->dtype == HESIC_BF16) {
@@ -1240,7 +1478,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (ksplit > 1) {
         const int64_t npix = (int64_t)d->B * d->Ho * d->Wo;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(npix * (d->Cout / 8), 256)), dim3(256), 0, st, (const float*)g_ws, ksplit,
-                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off, g_y32, g_y32_ps, g_y32_co);
+                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off, g_y32, g_y32_ps, g_y32_co, g_y_hilo, g_y_abs);
     }
     HESIC_LAUNCH_RETURN("conv2d_forward");
 }
@@ -1315,4 +1553,39 @@ extern "C" int hesic_pack_conv_weight_slice(const float* w, void* wp, int Cout, 
     hipLaunchKernelGGL(pack_weight_slice_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wp, Cout, Cin, KH, KW,
                        transposed, Cout_total, co_off);
     HESIC_LAUNCH_RETURN("pack_conv_weight_slice");
+}
+
+/* bf16x3 implicit GEMM (kernel template flag HL): d->Cin / d->Cout are the LOGICAL channel counts. */
+extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+                                         const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                         void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
+    HESIC_CHECK_ARG(d && x_hilo && w_packed_hilo && (y_hilo || y_f32), "conv2d_forward_hilo: null pointer");
+    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 && !d->in_abs, "conv2d_forward_hilo: bf16 storage, no |x| on load (use y_abs on the producer)");
+    const bool gdn = gamma_packed != nullptr;
+    if (gdn) {
+        HESIC_CHECK_ARG(gamma_lo_packed && beta_packed && y_hilo && !y_f32 && !y_abs, "conv2d_forward_hilo: the fused GDN form writes y_hilo only and needs both gamma' halves");
+        HESIC_CHECK_ARG(d->Cout == 128 && d->act == HESIC_ACT_NONE, "conv2d_forward_hilo: fused GDN needs Cout == 128 and no activation");
+    }
+    HESIC_CHECK_ARG(!y_f32 || (y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride),
+                    "conv2d_forward_hilo: fp32 channel slice must be 16-byte aligned and in range");
+    g_hilo = 1;
+    g_gdn_gamma = gamma_packed; g_gdn_gamma_lo = gamma_lo_packed; g_gdn_beta = beta_packed; g_gdn_mode = gdn ? (inverse ? 4 : 3) : 0;
+    g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
+    g_y_hilo = (!gdn && y_hilo) ? 1 : 0; g_y_abs = y_abs ? 1 : 0;
+    g_ws = (float*)ws; g_ws_bytes = ws ? ws_bytes : 0;
+    const int rc = hesic_conv2d_forward(d, x_hilo, w_packed_hilo, bias, y_hilo, stream);
+    g_ws = nullptr; g_ws_bytes = 0;
+    g_hilo = 0; g_y_hilo = g_y_abs = 0;
+    g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
+    g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
+    return rc;
+}
+
+extern "C" size_t hesic_conv2d_hilo_ws_bytes(const hesic_conv_desc* d) {
+    size_t need = 0;
+    if (!d) return 0;
+    g_ws_need = &need; g_hilo = 1;
+    const int rc = hesic_conv2d_forward(d, (const void*)16, (const void*)16, nullptr, (void*)16, nullptr);
+    g_ws_need = nullptr; g_hilo = 0;
+    return rc == 0 ? need : 0;
 }

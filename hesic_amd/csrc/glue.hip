@@ -605,3 +605,53 @@ extern "C" int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int6
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n);
     HESIC_LAUNCH_RETURN("cast");
 }
+
+// ------------------------------------------------------------------------------ im2col of the image side as hi/lo bf16
+// First analysis layer of the bf16x3 mode (g_a_conv1, newnet1.py:583 / :633): the 3-channel fp32 image becomes the column
+// matrix P[pixel][k], k = (ci*KH + ky)*KW + kx (the row-major flattening of a PyTorch conv weight (Cout, Cin, KH, KW)), zero
+// beyond Cin*KH*KW up to KP, written as [hi(KP) | lo(KP)] bf16 per output pixel -- so the layer runs as a 1x1 implicit GEMM on
+// hi/lo operands (hesic_conv2d_forward_hilo) with the hi/lo GDN epilogue, and no value passes through a single bf16.
+namespace {
+__global__ __launch_bounds__(256) void im2col_hilo_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C,
+                                                          int H, int W, int KH, int KW, int stride, int pad, int Ho, int Wo, int KP,
+                                                          bf16_t* __restrict__ cols) {
+    const int chunks = KP >> 3, kk = KH * KW, kmax = C * kk;
+    const int64_t total = (int64_t)B * Ho * Wo * chunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % chunks);
+        int64_t p = i / chunks;
+        const int ox = (int)(p % Wo);
+        int64_t r = p / Wo;
+        const int oy = (int)(r % Ho), b = (int)(r / Ho);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = q * 8 + e;
+            const int ci = k / kk, t = k - ci * kk, ky = t / KW, kx = t - ky * KW;
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            const bool ok = k < kmax && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            v[e] = ok ? x[b * sb + ci * sc + iy * sy + ix * sx] : 0.f;
+        }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_bf2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+        }
+        bf16_t* dst = cols + p * (2 * KP) + q * 8;
+        *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *(u32x4*)(dst + KP) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+}  // namespace
+
+extern "C" int hesic_im2col_hilo(const float* x, const int64_t x_strides[4], int B, int C, int H, int W, int KH, int KW, int stride, int pad,
+                                 int Ho, int Wo, int KP, void* cols, void* stream) {
+    HESIC_CHECK_ARG(x && x_strides && cols, "im2col_hilo: null pointer");
+    HESIC_CHECK_ARG(B > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && KP % 8 == 0 && KP >= C * KH * KW, "im2col_hilo: bad geometry (KP must be a multiple of 8 >= C*KH*KW)");
+    HESIC_CHECK_ARG(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "im2col_hilo: output size does not match");
+    const int64_t total = (int64_t)B * Ho * Wo * (KP / 8);
+    hipLaunchKernelGGL(im2col_hilo_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, x_strides[0], x_strides[1],
+                       x_strides[2], x_strides[3], B, C, H, W, KH, KW, stride, pad, Ho, Wo, KP, (bf16_t*)cols);
+    HESIC_LAUNCH_RETURN("im2col_hilo");
+}

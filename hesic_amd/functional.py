@@ -695,6 +695,128 @@ def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=F
                       f32_out="both" if want_lo else "only")
 
 
+# ------------------------------------------------------------------------------ bf16x3 ("hi/lo") analysis path
+# The reference computes g_a in fp32 and round()s its output; single-bf16 operands move y by ~3e-3 relative and flip ~1 % of
+# the latents.  In the "bf16x3" analysis mode every value on the way to y is a PAIR of bf16 (hi = bf16(v), lo = bf16(v - hi)):
+# activations [hi(C) | lo(C)] per pixel, weights [w_hi | w_lo] along Cin, three MFMA products per staged operand pair
+# (x_hi w_hi + x_lo w_hi + x_hi w_lo; x_lo w_lo, 2^-18, is dropped) -- bf16 arithmetic on the matrix cores at ~2^-17 relative per operand.  Inference only.
+ANALYSIS_MODES = ("bf16", "bf16x3")
+_analysis_mode = _os.environ.get("HESIC_ANALYSIS", "bf16x3")
+if _analysis_mode not in ANALYSIS_MODES:
+    raise ValueError(f"HESIC_ANALYSIS must be one of {ANALYSIS_MODES}")
+
+
+def set_analysis_precision(mode):
+    """"bf16x3" (default): the analysis transforms and hyper-analysis of a bf16 inference forward run on hi/lo bf16 pairs
+    (fp32-grade latents: what round() sees matches the reference's fp32 path to ~1e-5); "bf16": single-bf16 operands (round 2)."""
+    global _analysis_mode
+    if mode not in ANALYSIS_MODES:
+        raise ValueError(f"analysis precision must be one of {ANALYSIS_MODES}")
+    prev, _analysis_mode = _analysis_mode, mode
+    return prev
+
+
+def analysis_precision():
+    return _analysis_mode
+
+
+def analysis_hilo(x):
+    """True when the analysis stack should take the hi/lo route for input ``x``: bf16 inference on the GPU."""
+    return (_analysis_mode == "bf16x3" and _compute_dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.is_cuda)
+
+
+class PackedWeightHiLo:
+    """[w_hi | w_lo] (bf16, the kernels' [tap][Cout][2 Cin] layout) of a conv weight; inference cache keyed like ``PackedWeight``.
+    ``as_1x1``: flatten (Cout, Cin, k, k) to a 1x1 weight over the im2col columns, zero-padded to ``kp`` columns."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, weight, as_1x1=False, kp=0):
+        tag = (weight.data_ptr(), weight._version, _cache_epoch, as_1x1, kp)
+        if self._hit is not None and self._hit[0] == tag:
+            return self._hit[1]
+        w = weight.detach().float()
+        if as_1x1:
+            cout = w.shape[0]
+            flat = w.reshape(cout, -1)
+            w = torch.cat([flat, flat.new_zeros(cout, kp - flat.shape[1])], 1).reshape(cout, kp, 1, 1)
+        hi = w.bfloat16().float()
+        lo = (w - hi).bfloat16().float()
+        w2 = torch.cat([hi, lo], 1).contiguous()
+        cout, cin2, kh, kw = w2.shape
+        wp = torch.empty(kh * kw * cout * cin2, dtype=torch.bfloat16, device=w2.device)
+        L.call("hesic_pack_conv_weight", L.ptr(w2), None, L.ptr(wp), cout, cin2, kh, kw, 0, 0, L.BF16, L.stream())
+        self._hit = (tag, wp)
+        return wp
+
+
+class PackedGdnLo:
+    """Fragment-order lo half of gamma' for the hi/lo GDN epilogue (``hesic_gdn_pack_params_lo``); inference cache."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, gamma):
+        tag = (gamma.data_ptr(), gamma._version, _cache_epoch)
+        if self._hit is not None and self._hit[0] == tag:
+            return self._hit[1]
+        glo = torch.empty(128 * 128, dtype=torch.bfloat16, device=gamma.device)
+        L.call("hesic_gdn_pack_params_lo", L.ptr(_c(gamma)), L.ptr(glo), 128, L.stream())
+        self._hit = (tag, glo)
+        return glo
+
+
+def im2col_hilo(x, k, stride, padding, kp):
+    """Column matrix of a few-channel fp32 image as hi/lo bf16: (B, 2*kp, Ho, Wo) NHWC (``hesic_im2col_hilo``)."""
+    L.require_cuda(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, Cc, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, False)
+    cols = _empty_nhwc(B, 2 * kp, Ho, Wo, torch.bfloat16, x.device)
+    st = (C.c_int64 * 4)(*x.stride())
+    L.call("hesic_im2col_hilo", L.ptr(x), st, B, Cc, H, W, k, k, stride, padding, Ho, Wo, kp, L.ptr(cols), L.stream())
+    return cols
+
+
+class HiLo(tuple):
+    """A feature map stored as [hi(C) | lo(C)] bf16 pairs per pixel: ``HiLo((tensor (B, 2C, H, W) NHWC bf16, C))``.  A tuple, so the
+    stream bookkeeping of the inference schedule (``models._tensors``) sees the tensor inside."""
+    __slots__ = ()
+    t = property(lambda self: self[0])
+    c = property(lambda self: self[1])
+
+
+def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, gdn=None, act=L.ACT_NONE, out="f32", out_abs=False):
+    """Implicit GEMM on hi/lo operands (``hesic_conv2d_forward_hilo``).  ``gdn`` = (gamma_packed, gamma_lo_packed, beta_packed,
+    inverse): fused hi/lo (I)GDN, returns the (B, 2*cout, Ho, Wo) hi/lo map.  Otherwise ``out``: "f32" -> act(conv + bias) as fp32
+    (B, cout, Ho, Wo); "hilo" -> the hi/lo map (of |.| with ``out_abs``); "both" -> (hilo, f32)."""
+    L.require_cuda(x_hilo)
+    k = kernel_size
+    B, c2, H, W = x_hilo.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, False)
+    x_hilo = _nhwc(x_hilo)
+    if gdn is not None:
+        gp, glo, bp, inverse = gdn
+        y = _empty_nhwc(B, 2 * cout, Ho, Wo, torch.bfloat16, x_hilo.device)
+        d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.BF16, 0, 0, c2, 0, 2 * cout, 0, 0)
+        L.call("hesic_conv2d_forward_hilo", C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
+               L.ptr(y), 0, None, 0, 0, None, 0, L.stream())
+        return y
+    y = _empty_nhwc(B, 2 * cout, Ho, Wo, torch.bfloat16, x_hilo.device) if out in ("hilo", "both") else None
+    y32 = _empty_nhwc(B, cout, Ho, Wo, torch.float32, x_hilo.device) if out in ("f32", "both") else None
+    d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.BF16, act, 0, c2, 0, 2 * cout if y is not None else cout, 0, 0)
+    key = ("hilo", B, H, W, cin, cout, k, stride, padding)
+    need = _ws_bytes.get(key)
+    if need is None:
+        need = _ws_bytes[key] = int(L.lib().hesic_conv2d_hilo_ws_bytes(C.byref(d)))
+    ws = torch.empty(need, dtype=torch.uint8, device=x_hilo.device) if (need and SPLIT_K) else None
+    L.call("hesic_conv2d_forward_hilo", C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), None, None, None, 0, L.ptr(y), int(out_abs),
+           L.ptr(y32), cout, 0, L.ptr(ws), need if ws is not None else 0, L.stream())
+    return (y, y32) if out == "both" else (y if out == "hilo" else y32)
+
+
 class PackedGroup:
     """Packed bf16 weights (+ concatenated fp32 bias) of several same-geometry convs side by side along Cout, for
     ``conv2d_grouped``; inference cache with the tag policy of ``PackedWeight``."""

@@ -192,10 +192,37 @@ class Encoder1(nn.Module):
     def forward(self, x):
         return self.stack(x)
 
-    def latent(self, x, want_lo=True):
+    def latent(self, x, want_lo=True, exact=False, lo_abs=False):
         """(lo, hi): the latent in the storage dtype for the hyper-analysis convs (None unless ``want_lo``) and as it feeds
-        round() / the likelihood (fp32 from the accumulators at bf16 inference, see ``Fn.conv2d_latent``)."""
+        round() / the likelihood (fp32 from the accumulators at bf16 inference, see ``Fn.conv2d_latent``).  ``exact`` (the passes
+        whose rounded output the reference transmits: y1 and y2) takes the hi/lo route in the bf16x3 analysis mode: ``hi`` then has
+        fp32-grade accuracy and ``lo`` is a ``Fn.HiLo`` map of y (of |y| with ``lo_abs``: HESIC's hyper-analysis reads |y|)."""
+        if exact and Fn.analysis_hilo(x) and self._hilo_ok():
+            return self.latent_hilo(x, want_lo, lo_abs)
         return self.g_a_conv4.run_latent(self.trunk(x), want_lo=want_lo)
+
+    def _hilo_ok(self):
+        c1, c4 = self.g_a_conv1, self.g_a_conv4
+        return (tuple(c1.weight.shape[1:]) == (3, 5, 5) and c1.stride[0] == 2 and c1.weight.shape[0] == 128 and c4.weight.shape[1] == 128
+                and c4.weight.shape[0] % 8 == 0)
+
+    def latent_hilo(self, x, want_lo=True, lo_abs=False):
+        """g_a on hi/lo bf16 pairs (``Fn`` bf16x3 section): im2col of the image -> 1x1 implicit GEMM + GDN -> two 5x5 stride-2
+        layers + GDN -> the 5x5 stride-2 output layer, written as fp32 from the accumulators (newnet1.py:590-601 in ~fp32 accuracy)."""
+        c1, g1 = self.g_a_conv1, self.g_a_gdn1
+        if not hasattr(self, "_hl1"):
+            self._hl1 = Fn.PackedWeightHiLo(), Fn.PackedGdnLo()
+        KP = 96                                            # 3 * 25 = 75 columns, padded to a multiple of the 32-channel K step
+        gp, bp = g1.packer().get(g1.beta, g1.gamma, g1.beta_min)
+        t = Fn.im2col_hilo(x, 5, 2, 2, KP)
+        t = Fn.conv2d_hilo(t, self._hl1[0].get(c1.weight, as_1x1=True, kp=KP), c1.bias, KP, 128, kernel_size=1, stride=1, padding=0,
+                           gdn=(gp, self._hl1[1].get(g1.gamma), bp, g1.inverse))
+        t = self.g_a_conv2.run_hilo(t, gdn=self.g_a_gdn2)
+        t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3)
+        if not want_lo:
+            return None, self.g_a_conv4.run_hilo(t, out="f32")
+        lo, y = self.g_a_conv4.run_hilo(t, out="both", out_abs=lo_abs)
+        return Fn.HiLo((lo, self.g_a_conv4.weight.shape[0])), y
 
 
 class Encoder2(Encoder1):
@@ -214,8 +241,10 @@ class Encoder2(Encoder1):
         t = self.pre_conv.run_cat(x1_warp, x2, gdn=self.pre_gdn)
         return self.stack(t)
 
-    def latent(self, x1_warp, x2, want_lo=True):
+    def latent(self, x1_warp, x2, want_lo=True, exact=False, lo_abs=False):
         t = self.pre_conv.run_cat(x1_warp, x2, gdn=self.pre_gdn)
+        if exact and Fn.analysis_hilo(t) and self._hilo_ok():
+            return self.latent_hilo(t, want_lo, lo_abs)
         return self.g_a_conv4.run_latent(self.trunk(t), want_lo=want_lo)
 
 
@@ -267,8 +296,13 @@ class encode_hyper(nn.Module):
         return s[4].run(t)
 
     def latent(self, y):
-        """z as it feeds the bottleneck (fp32 at bf16 inference)."""
+        """z as it feeds the bottleneck (fp32 at bf16 inference).  A ``Fn.HiLo`` map of |y| (the bf16x3 analysis route) runs the three
+        layers on hi/lo pairs: z then matches the reference's fp32 hyper-analysis like y does."""
         s = self.encode_hyper
+        if isinstance(y, Fn.HiLo):
+            t = s[0].run_hilo(y.t, act=RELU)
+            t = s[2].run_hilo(t, act=RELU)
+            return s[4].run_hilo(t, out="f32")
         t = s[0].run(y, act=RELU, in_abs=True)
         t = s[2].run(t, act=RELU)
         return s[4].run_latent(t, want_lo=False)[1]
@@ -432,6 +466,7 @@ def _round_latent(model, y_hi):
 # --------------------------------------------------------------------------------------------- HESIC
 class HSIC(StereoCompressionModel):
     """HESIC (reference ``HSIC``, ywz/mywork/newnet1.py:696-783)."""
+    _LO_ABS = True            # encode_hyper reads |y| (newnet1.py:434)
 
     def __init__(self, N=128, M=192, K=5, **kwargs):
         super().__init__(entropy_bottleneck_channels=N, **kwargs)
@@ -499,7 +534,7 @@ class HSIC(StereoCompressionModel):
     def _analysis(self, x1, x2, h_matrix):
         size = (x1.shape[-2], x1.shape[-1])
         cdt = Fn.compute_dtype()
-        y1_lo, y1 = self.encoder1.latent(x1)
+        y1_lo, y1 = self.encoder1.latent(x1, exact=True, lo_abs=self._LO_ABS)
         z1 = self._h_a1.latent(y1_lo)
         z1_strings = self.entropy_bottleneck1.compress(z1)
         z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(cdt)
@@ -507,7 +542,7 @@ class HSIC(StereoCompressionModel):
         y1_hat = _round_latent(self.gaussian1, y1)
         x1_hat = self.decoder1(y1_hat)
         x1_warp = warp_perspective(x1, h_matrix, size)
-        y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+        y2_lo, y2 = self.encoder2.latent(x1_warp, x2, exact=True, lo_abs=self._LO_ABS)
         z2 = self._h_a2.latent(y2_lo)
         z2_strings = self.entropy_bottleneck2.compress(z2)
         z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(cdt)
@@ -622,7 +657,7 @@ class HSIC(StereoCompressionModel):
 
         def view2_latents():
             x1_warp = warp_perspective(x1, h_matrix, size)
-            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2, exact=True, lo_abs=self._LO_ABS)
             return y2_lo, y2, _round_latent(self.gaussian2, y2)
 
         def view2_hyper(y2_lo):
@@ -634,7 +669,7 @@ class HSIC(StereoCompressionModel):
             return self.gaussian1(y1, s1, m1, w1, out_dtype=cdt)[1], z1_lik
 
         if not (two_streams and x1.is_cuda):
-            y1_lo, y1 = self.encoder1.latent(x1)
+            y1_lo, y1 = self.encoder1.latent(x1, exact=True, lo_abs=self._LO_ABS)
             y1_hat = _round_latent(self.gaussian1, y1)
             y1_lik, z1_lik = view1_rate(y1_lo, y1)
             x1_hat = self.decoder1(y1_hat)
@@ -664,7 +699,7 @@ class HSIC(StereoCompressionModel):
                 return ev
 
             v2 = _Fork(_side_stream(dev, 10), view2_front)
-            y1_lo, y1 = self.encoder1.latent(x1)
+            y1_lo, y1 = self.encoder1.latent(x1, exact=True, lo_abs=self._LO_ABS)
             y1_hat = _round_latent(self.gaussian1, y1)
             ev_y1 = here(main)
             x1_hat = self.decoder1(y1_hat)
@@ -694,13 +729,17 @@ def _seq3(seq, x, last_act=NONE):
 
 
 def _seq3_hi(seq, x):
-    """``_seq3`` whose last conv feeds an entropy model: returns its ``hi`` output (``run_latent``)."""
+    """``_seq3`` whose last conv feeds an entropy model: returns its ``hi`` output (``run_latent``); a ``Fn.HiLo`` input runs the
+    three layers on hi/lo pairs (bf16x3 analysis route)."""
+    if isinstance(x, Fn.HiLo):
+        return seq[4].run_hilo(seq[2].run_hilo(seq[0].run_hilo(x.t, act=LEAKY), act=LEAKY), out="f32")
     return seq[4].run_latent(seq[2].run(seq[0].run(x, act=LEAKY), act=LEAKY), want_lo=False)[1]
 
 
 class HSICJoint(StereoCompressionModel):
     """HESIC+ (reference ``HSIC`` of ywz/mywork/newnet1_joint.py:585-753): Minnen-style hyperprior +
     masked-conv context model + 1x1 entropy-parameter nets + single Gaussian."""
+    _LO_ABS = False           # h_a reads y itself (newnet1_joint.py:611-617)
 
     def __init__(self, N=128, M=192, K=5, **kwargs):
         super().__init__(entropy_bottleneck_channels=N, **kwargs)
@@ -780,7 +819,7 @@ class HSICJoint(StereoCompressionModel):
 
         def view2_front():
             x1_warp = warp_perspective(x1, h_matrix, size)
-            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2, exact=True, lo_abs=self._LO_ABS)
             y2_hat = _round_latent(self.gaussian_conditional2, y2)
             z2_hat, z2_lik = self.entropy_bottleneck2.forward_with_noise(_seq3_hi(self.h_a2, y2_lo), None, out_dtype=cdt)
             params2 = self._params_buffer(self.h_s2, z2_hat, y2_hat, self.M) if catfree else _seq3(self.h_s2, z2_hat)
@@ -799,7 +838,7 @@ class HSICJoint(StereoCompressionModel):
         if overlap:
             main, dev = torch.cuda.current_stream(), x1.device
             v2 = _Fork(_side_stream(dev, 10), view2_front)
-        y1_lo, y1 = self.encoder1.latent(x1)
+        y1_lo, y1 = self.encoder1.latent(x1, exact=True, lo_abs=self._LO_ABS)
         y1_hat = _round_latent(self.gaussian_conditional1, y1)
         if overlap:
             r1 = _Fork(_side_stream(dev, 12), lambda: view1_rate(y1_lo, y1, y1_hat))
@@ -909,7 +948,7 @@ class HSICJoint(StereoCompressionModel):
             self.context_prediction1.weight.data *= self.context_prediction1.mask
             self.context_prediction2.weight.data *= self.context_prediction2.mask
             cdt = Fn.compute_dtype()
-            y1_lo, y1 = self.encoder1.latent(x1)
+            y1_lo, y1 = self.encoder1.latent(x1, exact=True, lo_abs=self._LO_ABS)
             z1 = _seq3_hi(self.h_a1, y1_lo)
             z1_strings = self.entropy_bottleneck1.compress(z1)
             z1_hat = self.entropy_bottleneck1.decompress(z1_strings, z1.size()[-2:]).to(cdt)
@@ -917,7 +956,7 @@ class HSICJoint(StereoCompressionModel):
             sc1, mu1 = self._gauss_full(1, self._params_view(1, z1_hat), y1_hat)
             x1_hat = self.decoder1(y1_hat)
             x1_warp = warp_perspective(x1, h_matrix, size)
-            y2_lo, y2 = self.encoder2.latent(x1_warp, x2)
+            y2_lo, y2 = self.encoder2.latent(x1_warp, x2, exact=True, lo_abs=self._LO_ABS)
             z2 = _seq3_hi(self.h_a2, y2_lo)
             z2_strings = self.entropy_bottleneck2.compress(z2)
             z2_hat = self.entropy_bottleneck2.decompress(z2_strings, z2.size()[-2:]).to(cdt)

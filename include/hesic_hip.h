@@ -118,6 +118,31 @@ int hesic_conv2d_forward_grouped(const hesic_conv_desc* d, int groups, int x_gro
 int hesic_pack_conv_weight_slice(const float* w, void* w_packed_bf16, int Cout, int Cin, int KH, int KW, int transposed,
                                  int Cout_total, int co_off, void* stream);
 
+/* ---- bf16x3 ("hi/lo") analysis path.  The reference runs g_a in fp32 (newnet1.py:580-601, :626-655) and round()s its output
+ * (entropy_models.py:661-702): with single-bf16 operands ~1 % of the latents land on the other side of .5.  Here a value v is the
+ * pair (hi = bf16(v), lo = bf16(v - hi)), stored [hi(C) | lo(C)] per pixel; the weights are packed as [w_hi | w_lo] along
+ * Cin (twice the logical Cin: pack the concatenated fp32 weight with hesic_pack_conv_weight), a stage of the K loop brings a
+ * channel chunk of all four halves into LDS and the matrix cores form x_hi w_hi + x_lo w_hi + x_hi w_lo in the fp32
+ * accumulators (2^-17 relative per operand instead of 2^-9; Cin % 32 == 0).  d->Cin / d->Cout are
+ * the LOGICAL channel counts, x_pix_stride >= 2 Cin.  With gamma_packed (hesic_gdn_pack_params) + gamma_lo_packed
+ * (hesic_gdn_pack_params_lo) + beta_packed: fused hi/lo (I)GDN (Cout == 128), the output y_hilo is [hi(128) | lo(128)] at
+ * y_c_off of a buffer with y_pix_stride >= 2 * 128 channels, y_f32 must be NULL.  Without: v = act(conv + bias) goes to y_f32 as
+ * in hesic_conv2d_forward_f32out (the latent y = g_a_conv4(.), z = encode_hyper(.)) and / or to y_hilo as [hi(Cout) | lo(Cout)]
+ * pairs -- of |v| when y_abs != 0: encode_hyper reads |y| (newnet1.py:434), and the magnitude is taken where v is still fp32.   */
+int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+                              const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                              void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
+                              void* stream);
+/* split-K scratch for the plain (no GDN) hi/lo launch, as hesic_conv2d_ws_bytes (0: none needed; ws may be NULL) */
+size_t hesic_conv2d_hilo_ws_bytes(const hesic_conv_desc* d);
+/* lo half of gamma' (128*128 bf16, MFMA fragment order) for the hi/lo GDN epilogue; the hi half is hesic_gdn_pack_params'. */
+int hesic_gdn_pack_params_lo(const float* gamma, void* gamma_lo_packed, int C, void* stream);
+/* Column matrix of the image side as hi/lo bf16: cols[pixel][k], k = (ci*KH + ky)*KW + kx (zero for k >= C*KH*KW up to KP, KP % 8
+ * == 0), written [hi(KP) | lo(KP)] per output pixel; x is fp32 with element strides (sb, sc, sy, sx).  g_a_conv1 (conv(3, N),
+ * newnet1.py:583) then is a 1x1 hesic_conv2d_forward_hilo with Cin = KP on it.                                               */
+int hesic_im2col_hilo(const float* x, const int64_t x_strides[4], int B, int C, int H, int W, int KH, int KW, int stride, int pad,
+                      int Ho, int Wo, int KP, void* cols, void* stream);
+
 /* Which kernel instantiation hesic_conv2d_forward picks for `d` (for profiling / roofline accounting):
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);
