@@ -54,7 +54,7 @@ class KernelMeter:
 
     STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
               "hesic_sconv2d_gdn_forward_prepacked": "conv1_3to128_gdn (n2w)", "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)",
-              "hesic_sconv2d_forward_prepacked": "g_s_conv4_128to3 (w2n)"}
+              "hesic_sconv2d_forward_prepacked": "g_s_conv4_128to3 (w2n)", "hesic_sconv2d_gdn_forward_hilo": "conv1_3to128_gdn hi/lo (n2w, bf16x3)"}
 
     def __init__(self, L):
         self.L, self.orig, self.rec, self.stream = L, L.call, [], {}
@@ -66,7 +66,8 @@ class KernelMeter:
             return d.B * d.C * (d.H * d.W * size(d.src_dtype) + d.Ho * d.Wo * size(d.dst_dtype))
         if name.startswith("hesic_sconv2d_forward") and not (d.transposed and d.Cin >= 32):
             return None                       # only the 128 -> 3 synthesis output stage is priced here
-        return d.B * (d.H * d.W * d.Cin * size(d.x_dtype) + d.Ho * d.Wo * d.Cout * size(d.y_dtype))
+        out_mult = 2 if name.endswith("_hilo") else 1            # [hi | lo] pairs: two bf16 per output value
+        return d.B * (d.H * d.W * d.Cin * size(d.x_dtype) + d.Ho * d.Wo * d.Cout * size(d.y_dtype) * out_mult)
 
     def __enter__(self):
         def call(name, *args):

@@ -1,0 +1,320 @@
+// g_a_conv1 + g_a_gdn1 (conv(3, N) 5x5 stride 2 -> GDN, newnet1.py:583-584 / :633-634) on hi/lo bf16 operand pairs: the first
+// layer of the bf16x3 analysis path (include/hesic_hip.h, "hi/lo" section).  Same data flow as sconv_n2w_gdn_fast_kernel
+// (csrc/sconv.hip) -- the image rows of a 32-pixel tile are gathered straight into MFMA B fragments, the weights are the A
+// operand from an LDS image, the GDN contraction takes its squares from the wave's own accumulators (K-permuted gamma' image) --
+// but every operand is a PAIR (hi = bf16(v), lo = bf16(v - hi)) and every product three MFMAs (hi hi + hi lo + lo hi; lo lo,
+// 2^-18, is dropped): x from the fp32 image, w and gamma' from fp32 parameters, the squares and the output from the fp32
+// accumulators.  The output leaves as [hi(128) | lo(128)] per pixel for the hi/lo implicit-GEMM layers behind it.
+//
+// Four 32 KB weight images (w_hi, w_lo, gamma'_hi, gamma'_lo) + 4 KB of row staging per wave (one 16-pixel image row of the tile
+// at a time) = the CU's whole 160 KB of LDS: one block of eight waves per CU, two per SIMD, so one wave's VALU phases (operand
+// splitting, squares, rsqrt, output staging: about as many issue cycles per tile as its 192 MFMAs) run under the other's MFMAs.
+#include "common.h"
+
+namespace {
+
+struct HArgs {
+    const float* x; const unsigned char* img; const float* bias; const float* beta; bf16_t* y;
+    int B, H, W, Ho, Wo;
+    int64_t xs_b, xs_c, xs_y, ys_b, ys_y, ys_x;
+    FastDiv fd_tx, fd_ty;
+};
+
+__device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf2(p, q);
+    lo = pack_bf2(p - __uint_as_float(hi << 16), q - __uint_as_float(hi & 0xffff0000u));
+}
+
+template <int INV>
+__global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
+    constexpr int KS = 5, R = 15, NW = 8;
+    constexpr uint32_t POISON = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned char* wl_hi = smem;                 // conv weights [128 co][16 slots ^ (co & 15)] of 8 bf16: slot r = ci*5 + ky, values kx 0..4
+    const unsigned char* wl_lo = smem + 32768;
+    const unsigned char* gl_hi = smem + 65536;         // gamma' [128 out][16 slots ^ (row & 15)], K order permuted to the accumulator layout
+    const unsigned char* gl_lo = smem + 98304;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    unsigned char* os = smem + 131072 + wave * 4096;   // 16 pixel rows of 256 bytes, 16-byte chunks XOR (pixel & 15)
+    // A-fragment address of (32-row block i, k-step ks) inside an image: row = i*32 + frow, so (row & 15) == (frow & 15) and the lane part
+    // is ONE offset per k-step, the block / image part an immediate -- 8 address registers instead of one per (i, ks, image)
+    auto fa = [&](int ks) { return frow * 256 + ((((ks * 2 + fh) ^ (frow & 15))) << 4); };
+
+    const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 1) / 2;       // wave tile = 2 output rows x 16 columns
+    const int ntiles = tiles_x * tiles_y * a.B;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tstride = (int)gridDim.x * NW;
+    u32x2 raw[8][3];
+    int tb = 0, tty = 0, ttx = 0;
+    auto request = [&](int tile) {                    // the 24 row-pair loads of a tile (see sconv_n2w_gdn_fast_kernel)
+        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
+        ttx = tile - (int)q * tiles_x;
+        tb = (int)fdiv(q, a.fd_ty);
+        tty = (int)q - tb * tiles_y;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)tb * a.xs_b - 2), 0, (int)POISON, 0x00020000);
+        int fhl = fh;                                 // opaque copy: the per-k-step row constants below are two VALU ops each -- recomputed per
+        asm volatile("" : "+v"(fhl));                 // tile instead of hoisted out of the tile loop into ~30 long-lived registers (which spilled)
+        const int oy = tty * 2 + (frow >> 4), ox = ttx * 16 + (frow & 15);
+        const bool pok = oy < a.Ho && ox < a.Wo;
+        const int iy0 = oy * 2 - 2, ix0 = ox * 2 - 2;
+        const uint32_t base = (uint32_t)((iy0 * (int)a.xs_y + ix0) * 4 + 8);
+        const bool ok0 = pok && ox > 0, ok2 = pok && ix0 + 4 < a.W;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ra = 2 * ks, rb = 2 * ks + 1;
+            const int kya = ra % KS, kyb = rb < R ? rb % KS : 0x40000000, cia = ra / KS, cib = rb / KS;
+            const uint32_t offa = (uint32_t)((cia * (int)a.xs_c + kya * (int)a.xs_y) * 4), offb = (uint32_t)((cib * (int)a.xs_c + (rb % KS) * (int)a.xs_y) * 4);
+            const bool okr = (unsigned)(iy0 + (fhl ? kyb : kya)) < (unsigned)a.H;
+            const uint32_t v = base + (fhl ? offb : offa);
+            const uint32_t v0 = (okr && ok0) ? v : POISON, v1 = (okr && pok) ? v : POISON, v2 = (okr && ok2) ? v : POISON;
+            raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v0, 0, 0);
+            raw[ks][1] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, 8, 0);
+            raw[ks][2] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v2, 16, 0);
+        }
+    };
+    int tile = lb * NW + wave;
+    if (tile < ntiles) request(tile);                 // in flight while the block copies its weight images
+
+    {
+        const u32x4* src = (const u32x4*)a.img;       // 8192 slots of 16 bytes, laid out by n2w_hilo_pack_kernel
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[tid + (r * 8 + j) * 512];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(u32x4*)(smem + (tid + (r * 8 + j) * 512) * 16) = v[j];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t st_lane = (uint32_t)(((lane >> 4) * (int)a.ys_x + (lane & 15) * 8) * 2);
+    const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? 512 : 0, 0x00020000);      // no bias: every load returns zeros
+    const __amdgpu_buffer_rsrc_t beta_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.beta, 0, 512, 0x00020000);
+    for (; tile < ntiles; tile += tstride) {
+        const int b = tb, ty = tty, tx = ttx;        // of the tile whose rows are in `raw`
+        u32x4 xh[8], xl[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x2 p0 = __builtin_bit_cast(f32x2, raw[ks][0]), p1 = __builtin_bit_cast(f32x2, raw[ks][1]), p2 = __builtin_bit_cast(f32x2, raw[ks][2]);
+            uint32_t h0, l0, h1, l1, h2, l2;
+            split2(p0.x, p0.y, h0, l0);
+            split2(p1.x, p1.y, h1, l1);
+            split2(p2.x, 0.f, h2, l2);
+            xh[ks] = u32x4{h0, h1, h2, 0u};
+            xl[ks] = u32x4{l0, l1, l2, 0u};
+        }
+        // bias / beta' are re-read per tile (buffer loads, L1 hits) through an offset the optimiser cannot see through: hoisted out of
+        // the tile loop their 2 x 64 values per lane would sit in registers next to the accumulators and spill.  (A laundered
+        // POINTER turned them into flat loads, which also count on lgkmcnt and stalled every LDS wait behind a global round trip.)
+        uint32_t pofs = (uint32_t)(fh * 16);
+        asm volatile("" : "+v"(pofs));
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
+                acc[i][4 * g] = bv.x; acc[i][4 * g + 1] = bv.y; acc[i][4 * g + 2] = bv.z; acc[i][4 * g + 3] = bv.w;
+            }
+        // conv: the w_hi fragments are double-buffered one k-step ahead; the w_lo fragments of a k-step are requested at its start and
+        // used last (behind 8 MFMAs = their LDS latency)
+        {
+            bf16x8 wh[2][4], wl[4];
+            auto ldh = [&](int set, int ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wh[set][i] = *(const bf16x8*)(wl_hi + fa(ks) + i * 8192);
+                }
+            };
+            ldh(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wl[i] = *(const bf16x8*)(wl_lo + fa(ks) + i * 8192);
+                }
+                if (ks + 1 < 8) ldh((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 fxh = __builtin_bit_cast(bf16x8, xh[ks]), fxl = __builtin_bit_cast(bf16x8, xl[ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], fxh, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], fxl, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], fxh, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        f32x16 nrm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 be = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(beta_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
+                nrm[i][4 * g] = be.x; nrm[i][4 * g + 1] = be.y; nrm[i][4 * g + 2] = be.z; nrm[i][4 * g + 3] = be.w;
+            }
+        // GDN contraction: the squares of k-step ks + 1 (VALU) and its gamma'_hi fragments (LDS) are prepared before the 12 MFMAs of
+        // k-step ks are issued; gamma'_lo is requested at the start of its k-step and used last
+        {
+            bf16x8 gh[2][4], gl[4], fq[2][2];
+            auto prep = [&](int set, int ks) {
+                const int si = ks >> 1, so = (ks & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    gh[set][i] = *(const bf16x8*)(gl_hi + fa(ks) + i * 8192);
+                }
+                uint32_t qh[4], ql[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e], s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1];
+                    split2(s0, s1, qh[e], ql[e]);
+                }
+                fq[set][0] = __builtin_bit_cast(bf16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
+                fq[set][1] = __builtin_bit_cast(bf16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
+            };
+            prep(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    gl[i] = *(const bf16x8*)(gl_lo + fa(ks) + i * 8192);
+                }
+                if (ks + 1 < 8) prep((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ks & 1][i], fq[ks & 1][1], nrm[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc; the tile then leaves in four passes through the
+        // wave-private staging rows: (hi | lo) x (first | second image row of the tile), 16 pixels of 256 bytes each
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= INV ? __builtin_amdgcn_sqrtf(nrm[i][r]) : __builtin_amdgcn_rsqf(nrm[i][r]);
+        // the next tile's rows are requested here: `raw` (48 registers) is then not live across the MFMA phases, and the loads have
+        // the staging passes -- and the other wave of the SIMD -- to come back
+        __builtin_amdgcn_sched_barrier(0);
+        request(tile + tstride < ntiles ? tile + tstride : tile);      // unconditional: a conditional update would keep the OLD `raw` live across
+                                                                       // both MFMA phases (48 registers; the allocator spilled them)
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (int64_t)b * a.ys_b), 0, (int)POISON, 0x00020000);
+        const int pl = frow & 15;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int half = pass >> 1, prow = pass & 1;
+            if ((frow >> 4) == prow) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = i * 32 + 8 * g + 4 * fh;
+                        uint32_t h0, l0, h1, l1;
+                        split2(acc[i][4 * g], acc[i][4 * g + 1], h0, l0);
+                        split2(acc[i][4 * g + 2], acc[i][4 * g + 3], h1, l1);
+                        *(u32x2*)(os + pl * 256 + (((cl >> 3) ^ pl) << 4) + (cl & 7) * 2) = half ? u32x2{l0, l1} : u32x2{h0, h1};
+                    }
+            }
+            // the staging rows are written as 8-byte and read as 16-byte vectors: the compiler must not reorder them on type-based
+            // alias grounds (it did: every other pixel came out with the previous pass's data) -- compiler barriers; the LDS itself
+            // executes a wave's accesses in order
+            asm volatile("" ::: "memory");
+            const int y2 = ty * 2 + prow;
+            u32x4 rowv[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = it * 4 + (lane >> 4);
+                rowv[it] = *(const u32x4*)(os + pr * 256 + (((lane & 15) ^ pr) << 4));
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int x2 = tx * 16 + it * 4;
+                const int so = (y2 * (int)a.ys_y + x2 * (int)a.ys_x + half * 128) * 2;                       // scalar
+                const bool ok = y2 < a.Ho && x2 + (lane >> 4) < a.Wo;
+                // tile offset in the VGPR offset, soffset = 0: see the store-hazard note in sconv_n2w_gdn_fast_kernel
+                __builtin_amdgcn_raw_buffer_store_b128(rowv[it], yr, (int)(ok ? st_lane + (uint32_t)so : POISON), 0, 0);
+            }
+        }
+    }
+}
+
+// LDS images of the kernel above, built once per weight update: [w_hi | w_lo | gamma'_hi | gamma'_lo], 32 KB each.
+//   conv:   row co, slot r = ci*5 + ky (r < 15) at position r ^ (co & 15), 8 values = kx 0..4, 0, 0, 0
+//   gamma': row i (output channel), slot q = 2 ks + h at position q ^ (i & 15), 8 values = gamma'[i][16 ks + 4 h + 0..3],
+//           gamma'[i][16 ks + 8 + 4 h + 0..3] -- the order in which a lane of the GDN contraction holds its squares
+__global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4096) return;
+    float v[8];
+    int row, pos;
+    if (idx < 2048) {
+        row = idx >> 4;
+        const int r = idx & 15, ci = r / 5, ky = r % 5;
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((row * 3 + ci) * 5 + ky) * 5 + kx] : 0.f;
+        pos = r ^ (row & 15);
+    } else {
+        const int j = idx - 2048, q = j & 15, ks = q >> 1, h = q & 1;
+        row = j >> 4;
+        const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 4 * h + (e & 3) + (e >> 2) * 8;
+            const float t = fmaxf(gamma[row * 128 + c], gb);
+            v[e] = t * t - ped;
+        }
+        pos = q ^ (row & 15);
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+    unsigned char* dst = img + (idx < 2048 ? 0 : 65536) + (row * 16 + pos) * 16;
+    *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *(u32x4*)(dst + 32768) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+}  // namespace
+
+extern "C" int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image, void* stream) {
+    HESIC_CHECK_ARG(w && gamma && image, "sconv_pack_weight_image_hilo: null pointer");
+    hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image);
+    HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo");
+}
+
+extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                                              const float* beta_packed, int inverse, void* y_hilo, void* stream) {
+    HESIC_CHECK_ARG(d && x && image_hilo && beta_packed && y_hilo, "sconv2d_gdn_forward_hilo: null pointer");
+    HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
+                        d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_BF16 && d->act == HESIC_ACT_NONE && d->ys_c == 1 && d->ys_x >= 256 &&
+                        (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 && (d->ys_b % 8) == 0,
+                    "sconv2d_gdn_forward_hilo: built for the 3 -> 128 5x5 stride-2 stage, fp32 image in, [hi | lo] bf16 NHWC out (pixel stride >= 256)");
+    HESIC_CHECK_ARG(d->Ho == (d->H + 4 - 5) / 2 + 1 && d->Wo == (d->W + 4 - 5) / 2 + 1, "sconv2d_gdn_forward_hilo: output size does not match");
+    const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 1) / 2) * d->B;
+    HESIC_CHECK_ARG(d->xs_x == 1 && d->W % 2 == 0 && tiles < (1ll << 30) && d->xs_c >= 0 && d->xs_y >= 0 &&
+                        (2 * d->xs_c + (int64_t)(d->H + 4) * d->xs_y + d->W) * 4 < (1ll << 31) &&
+                        ((int64_t)d->Ho * d->ys_y + (int64_t)d->Wo * d->ys_x) * 2 < (1ll << 31),
+                    "sconv2d_gdn_forward_hilo: needs fp32 planes with unit pixel stride, an even width and 32-bit offsets inside one image");
+    HArgs a;
+    a.x = x; a.img = (const unsigned char*)image_hilo; a.bias = bias; a.beta = beta_packed; a.y = (bf16_t*)y_hilo;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.xs_b = d->xs_b; a.xs_c = d->xs_c; a.xs_y = d->xs_y; a.ys_b = d->ys_b; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
+    a.fd_tx = make_fastdiv((uint32_t)((d->Wo + 15) / 16)); a.fd_ty = make_fastdiv((uint32_t)((d->Ho + 1) / 2));
+    const size_t lds = 160 * 1024;
+    const unsigned grid = (unsigned)((tiles + 7) / 8 < 256 ? (tiles + 7) / 8 : 256);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
+}

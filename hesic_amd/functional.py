@@ -767,6 +767,39 @@ class PackedGdnLo:
         return glo
 
 
+class PackedN2wHiLo:
+    """LDS images [w_hi | w_lo | gamma'_hi | gamma'_lo] (128 KB) of the fused hi/lo g_a_conv1 + GDN kernel; inference cache."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, weight, gamma):
+        tag = (weight.data_ptr(), weight._version, gamma.data_ptr(), gamma._version, _cache_epoch)
+        if self._hit is not None and self._hit[0] == tag:
+            return self._hit[1]
+        img = torch.empty(128 * 1024, dtype=torch.uint8, device=weight.device)
+        L.call("hesic_sconv_pack_weight_image_hilo", L.ptr(_c(weight)), L.ptr(_c(gamma)), L.ptr(img), L.stream())
+        self._hit = (tag, img)
+        return img
+
+
+def sconv_gdn_hilo_ok(x, weight):
+    """The fused hi/lo 3 -> 128 kernel takes an fp32 image with unit pixel stride and an even width."""
+    return (x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1 and x.shape[3] % 2 == 0 and tuple(weight.shape) == (128, 3, 5, 5)
+            and weight.dtype == torch.float32 and min(x.stride()) >= 0)
+
+
+def sconv_gdn_hilo(x, image, bias, beta_packed, inverse):
+    """GDN(conv(x)) of the 3 -> 128 5x5 stride-2 stage on hi/lo pairs in one kernel: (B, 256, H/2, W/2) [hi | lo] bf16 NHWC."""
+    L.require_cuda(x)
+    B, Cc, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, 5, 2, 2, False)
+    y = _empty_nhwc(B, 256, Ho, Wo, torch.bfloat16, x.device)
+    d = _sdesc(x, y, 3, 128, 5, 2, 2, False)
+    L.call("hesic_sconv2d_gdn_forward_hilo", C.byref(d), L.ptr(x), L.ptr(image), L.ptr(bias), L.ptr(beta_packed), int(inverse), L.ptr(y), L.stream())
+    return y
+
+
 def im2col_hilo(x, k, stride, padding, kp):
     """Column matrix of a few-channel fp32 image as hi/lo bf16: (B, 2*kp, Ho, Wo) NHWC (``hesic_im2col_hilo``)."""
     L.require_cuda(x)

@@ -211,12 +211,15 @@ class Encoder1(nn.Module):
         layers + GDN -> the 5x5 stride-2 output layer, written as fp32 from the accumulators (newnet1.py:590-601 in ~fp32 accuracy)."""
         c1, g1 = self.g_a_conv1, self.g_a_gdn1
         if not hasattr(self, "_hl1"):
-            self._hl1 = Fn.PackedWeightHiLo(), Fn.PackedGdnLo()
-        KP = 96                                            # 3 * 25 = 75 columns, padded to a multiple of the 32-channel K step
+            self._hl1 = Fn.PackedWeightHiLo(), Fn.PackedGdnLo(), Fn.PackedN2wHiLo()
         gp, bp = g1.packer().get(g1.beta, g1.gamma, g1.beta_min)
-        t = Fn.im2col_hilo(x, 5, 2, 2, KP)
-        t = Fn.conv2d_hilo(t, self._hl1[0].get(c1.weight, as_1x1=True, kp=KP), c1.bias, KP, 128, kernel_size=1, stride=1, padding=0,
-                           gdn=(gp, self._hl1[1].get(g1.gamma), bp, g1.inverse))
+        if Fn.sconv_gdn_hilo_ok(x, c1.weight) and not _os.environ.get("HESIC_N2W_HILO_IM2COL"):
+            t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse)       # conv + GDN in one kernel
+        else:
+            KP = 96                                        # other layouts: 3 * 25 = 75 im2col columns (padded) -> 1x1 implicit GEMM + GDN
+            t = Fn.im2col_hilo(x, 5, 2, 2, KP)
+            t = Fn.conv2d_hilo(t, self._hl1[0].get(c1.weight, as_1x1=True, kp=KP), c1.bias, KP, 128, kernel_size=1, stride=1, padding=0,
+                               gdn=(gp, self._hl1[1].get(g1.gamma), bp, g1.inverse))
         t = self.g_a_conv2.run_hilo(t, gdn=self.g_a_gdn2)
         t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3)
         if not want_lo:

@@ -175,6 +175,16 @@ typedef struct {
     int64_t xs_b, xs_c, xs_y, xs_x;   /* element strides of x */
     int64_t ys_b, ys_c, ys_y, ys_x;   /* element strides of y */
 } hesic_sconv_desc;
+
+/* g_a_conv1 + g_a_gdn1 of the hi/lo analysis path in ONE kernel (conv(3, N) 5x5 stride 2 -> GDN(N), N == 128; newnet1.py:583-584,
+ * :633-634): fp32 planar image in (unit pixel stride, even width), [hi(128) | lo(128)] bf16 out (ys_x >= 256, ys_c == 1).
+ * image_hilo (128 KB) = hesic_sconv_pack_weight_image_hilo(w (128,3,5,5) fp32, raw GDN gamma (128,128) fp32): the LDS images
+ * [w_hi | w_lo | gamma'_hi | gamma'_lo]; beta_packed as hesic_gdn_pack_params.  Other layouts: hesic_im2col_hilo + a 1x1
+ * hesic_conv2d_forward_hilo.                                                                                                    */
+int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image_hilo, void* stream);
+int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                                   const float* beta_packed, int inverse, void* y_hilo, void* stream);
+
 /* w is the raw fp32 PyTorch weight ((Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW)). */
 int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,
                           void* stream);

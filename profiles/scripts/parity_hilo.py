@@ -55,6 +55,8 @@ def ops():
     with torch.no_grad():
         cols = Fn.im2col_hilo(x.to(dev), 5, 2, 2, 96)
         t1 = Fn.conv2d_hilo(cols, pw[0].get(w1.to(dev), as_1x1=True, kp=96), b1.to(dev), 96, 128, kernel_size=1, stride=1, padding=0, gdn=(gp, glo, bp, False))
+        w1d, b1d = w1.to(dev), b1.to(dev)
+        t1f = Fn.sconv_gdn_hilo(x.to(dev), Fn.PackedN2wHiLo().get(w1d, gd.gamma), b1d, bp, False)
         t2 = Fn.conv2d_hilo(t1, pw[1].get(w2.to(dev)), b2.to(dev), 128, 128, kernel_size=5, stride=2, padding=2, gdn=(gp, glo, bp, False))
         y = Fn.conv2d_hilo(t2, pw[2].get(w4.to(dev)), None, 128, 192, kernel_size=5, stride=2, padding=2)
     torch.cuda.synchronize()
@@ -66,7 +68,7 @@ def ops():
 
     def err(a, r):
         return float((a - r).abs().max() / r.abs().max()), float(((a - r) ** 2).mean().sqrt() / (r ** 2).mean().sqrt())
-    for name, a, r in (("conv1+gdn (im2col 1x1)", val(t1), r1), ("conv2+gdn", val(t2), r2), ("conv4 fp32 out", y.double().cpu(), r4)):
+    for name, a, r in (("conv1+gdn (im2col 1x1)", val(t1), r1), ("conv1+gdn (fused hi/lo kernel)", val(t1f), r1), ("conv2+gdn", val(t2), r2), ("conv4 fp32 out", y.double().cpu(), r4)):
         mx, rms = err(a, r)
         print(json.dumps({"op": name, "max_rel_to_peak": mx, "rms_rel": rms}), flush=True)
     # single-bf16 reference point for the same chain

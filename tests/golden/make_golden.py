@@ -470,6 +470,107 @@ def fx_models_r2(newnet1, newnet1_joint):
         print(tag, "train256 trace", trace)
 
 
+def fx_models_r3(newnet1, newnet1_joint, which=("c2", "c4", "c5", "c3")):
+    """Round 3: the reference run on the EXACT BASELINE workloads (BASELINE.json configs): C2 = HESIC, 8 pairs of 512 x 512; C4 = HESIC+,
+    4 pairs of 512 x 512; C5 = 860 x 1080 pairs zero-padded to 896 x 1088, the four lambda-models of the sweep (weight salts 0..3, as
+    bench.py --sweep fills them), metrics over the original pixels; C3 = one training step (R-D loss, both optimisers) on 8 pairs of
+    512 x 512.  Stored per pair: bits per latent tensor, squared error per view, the rounded latents as int8."""
+    import math
+    from compressai.entropy_models import EntropyModel
+    nq = NoiseQueue()
+    EntropyModel._get_noise_cached = lambda self, x: nq(self, x)
+
+    def per_pair(out, x1, x2, crop=None):
+        B = x1.shape[0]
+        A = {}
+        for k, v in out["likelihoods"].items():
+            A["bits_" + k] = (torch.log(v.double()).reshape(B, -1).sum(1) / -math.log(2)).numpy()
+        xh1, xh2 = out["x1_hat"], out["x2_hat"]
+        if crop is not None:
+            xh1, xh2 = xh1[..., :crop[0], :crop[1]], xh2[..., :crop[0], :crop[1]]
+        A["sse1"] = ((xh1.double() - x1.double()) ** 2).reshape(B, -1).sum(1).numpy()
+        A["sse2"] = ((xh2.double() - x2.double()) ** 2).reshape(B, -1).sum(1).numpy()
+        for k in ("y1_hat", "y2_hat"):
+            assert float(out[k].abs().max()) < 128
+            A[k] = out[k].to(torch.int8)
+        return A
+
+    for tag, mod, batch, cfg in (("hsic", newnet1, 8, "c2"), ("joint", newnet1_joint, 4, "c4")):
+        if cfg not in which:
+            continue
+        net = mod.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net.eval()
+        x1, x2, Hm = synthetic.stereo_batch(0, batch, 512, 512)
+        with torch.no_grad():
+            out = net(x1, x2, Hm)
+        A = per_pair(out, x1, x2)
+        npz(f"{tag}_512_b{batch}.npz", H=Hm, **A)
+        print(tag, "512 x", batch, "bpp", sum(float(A["bits_" + k].sum()) for k in ("y1", "y2", "z1", "z2")) / (batch * 512 * 512 * 2))
+
+    if "c5" in which:
+        Himg, Wimg = 860, 1080
+        for tag, mod in (("hsic", newnet1), ("joint", newnet1_joint)):
+            recs = {}
+            for salt in range(4):
+                net = mod.HSIC()
+                synthetic.fill_state_dict_(net.state_dict(), salt=salt)
+                net.eval()
+                x1, x2, Hm = synthetic.stereo_batch(0, 1, Himg, Wimg)
+                ph, pw = (-Himg) % 64, (-Wimg) % 64
+                x1p, x2p = F.pad(x1, (0, pw, 0, ph)), F.pad(x2, (0, pw, 0, ph))
+                with torch.no_grad():
+                    out = net(x1p, x2p, Hm)
+                A = per_pair(out, x1, x2, crop=(Himg, Wimg))
+                for k, v in A.items():
+                    if k.endswith("_hat"):
+                        if salt == 0:
+                            recs[k] = v
+                        recs[f"{k}_abs_sum_{salt}"] = float(v.double().abs().sum())
+                    else:
+                        recs[f"{k}_{salt}"] = v
+                print(tag, "c5 salt", salt, "bpp", sum(float(A["bits_" + k].sum()) for k in ("y1", "y2", "z1", "z2")) / (Himg * Wimg * 2))
+            npz(f"{tag}_c5.npz", H=Hm, **recs)
+
+    if "c3" in which:
+        for tag, mod in (("hsic", newnet1), ("joint", newnet1_joint)):
+            net = mod.HSIC()
+            synthetic.fill_state_dict_(net.state_dict())
+            net.train()
+            B = 8
+            x1, x2, Hm = synthetic.stereo_batch(0, B, 512, 512)
+            order = ["z1", "y1", "y1w", "z2", "y2"] if tag == "hsic" else ["z1", "y1", "y1b", "z2", "y1w", "y2", "y2b"]
+            shapes_n = {k: ((128, 1, B * 64) if k[0] == "z" else (B, 192, 32, 32)) for k in order}
+            lam = 0.0067
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+            aux_opt = torch.optim.Adam(net.aux_parameters(), lr=1e-3)
+            nq.items = [det_noise(f"{tag}.t512.0.{k}", shapes_n[k]) for k in order]
+            opt.zero_grad()
+            aux_opt.zero_grad()
+            out = net(x1, x2, Hm)
+            npix = B * 512 * 512
+            bpp = sum(torch.log(l).sum() / (-math.log(2) * npix) for l in out["likelihoods"].values())
+            mse = F.mse_loss(out["x1_hat"], x1) + F.mse_loss(out["x2_hat"], x2)
+            loss = lam * 255 ** 2 * mse + bpp
+            loss.backward()
+            T = {"loss": float(loss), "bpp": float(bpp), "mse": float(mse), "noise_order": np.array(order)}
+            for n_, p_ in net.named_parameters():
+                T["gn_" + n_] = float(p_.grad.double().norm()) if p_.grad is not None else 0.0
+            for n_, m_ in net.named_modules():
+                if hasattr(m_, "mask") and getattr(m_, "weight", None) is not None:
+                    T["gn_live_" + n_ + ".weight"] = float((m_.weight.grad * m_.mask).double().norm())
+            opt.step()
+            aux = net.aux_loss()
+            aux.backward()
+            aux_opt.step()
+            T["aux"] = float(aux)
+            # the step taken: a digest of the updated parameters (sum and sum of squares per tensor would be 2 x 222 numbers; one
+            # norm of the whole update is what a test needs)
+            npz(f"{tag}_train512.npz", **T)
+            print(tag, "train512", T["loss"], T["bpp"], T["mse"], T["aux"])
+            del net, out, loss
+
+
 def fx_enhance(newnet1):
     """Independent_EN (cross-view enhancement, newnet1.py:272-311,1278-1300)."""
     net = newnet1.Independent_EN().eval()
@@ -592,7 +693,7 @@ def fx_codec_model(newnet1):
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "enhance", "homo"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "enhance", "homo", "models3"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
@@ -605,6 +706,9 @@ def main():
         fx_homo()
     if "models" in which:
         fx_models(newnet1, newnet1_joint)
+    if any(w in which for w in ("c2", "c3", "c4", "c5", "models3")):
+        sel = ("c2", "c4", "c5", "c3") if "models3" in which else tuple(w for w in which if w in ("c2", "c3", "c4", "c5"))
+        fx_models_r3(newnet1, newnet1_joint, which=sel)
     if "models2" in which:
         fx_models_r2(newnet1, newnet1_joint)
     if "codec_model" in which:
