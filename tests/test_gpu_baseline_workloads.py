@@ -1,0 +1,203 @@
+"""The EXACT BASELINE.json workloads on the GPU against fixtures recorded from the reference itself
+(tests/golden/make_golden.py models3: the reference's ``HSIC.forward`` / training step run in the build container):
+
+  C2  HESIC, 8 pairs of 512 x 512, bf16 maps with the bf16x3 analysis path (the benchmark's headline configuration)
+  C3  one R-D training step on 8 pairs of 512 x 512 (per GPU; the 8-GPU job averages eight of these gradients)
+  C4  HESIC+, 4 pairs of 512 x 512
+  C5  the four lambda-models on an 860 x 1080 pair zero-padded to 896 x 1088, metrics over the original pixels
+
+Bars (written next to each assert): the integer latents may differ from the reference's in at most 1e-3 of the positions
+(measured: <= 2e-5), per-pair bits within 2e-3 relative / squared error within 1e-3 relative, PSNR within 1e-3 dB."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+from hesic_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(kind, dtype, salt=0):
+    import hesic_amd
+    from hesic_amd import models
+    hesic_amd.set_compute_dtype(dtype)
+    net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
+    synthetic.fill_state_dict_(net.state_dict(), salt=salt)
+    return net.to(DEV).eval()
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    yield
+    import hesic_amd
+    from hesic_amd import functional as Fn
+    hesic_amd.set_compute_dtype(torch.float32)
+    Fn.set_analysis_precision("bf16x3")
+
+
+def per_pair(out, x1, x2):
+    B = x1.shape[0]
+    bits = {k: (torch.log2(v.double()).reshape(B, -1).sum(1) * -1).cpu().numpy() for k, v in out["likelihoods"].items()}
+    h, w = x1.shape[-2:]
+    sse = [((out[k][..., :h, :w].double() - x.double()) ** 2).reshape(B, -1).sum(1).cpu().numpy() for k, x in (("x1_hat", x1), ("x2_hat", x2))]
+    return bits, sse
+
+
+def check_against(g, out, x1, x2, flips_max, bits_rel, sse_rel, psnr_db, view_psnr_db=None):
+    """Per-pair comparison with a golden recorded from the reference; every measured maximum is in the assertion message.
+    ``psnr_db`` bounds the PSNR the reference reports (mean of the two views, test3real.py:110-122), ``view_psnr_db`` each view."""
+    B, _, h, w = x1.shape
+    bits, sse = per_pair(out, x1, x2)
+    meas = {}
+    for k in ("y1_hat", "y2_hat"):
+        flips = (out[k].float().cpu().to(torch.int16) != T(g[k]).to(torch.int16)).float().reshape(B, -1).mean(1)
+        meas["flips_" + k] = float(flips.max())
+    for k in ("y1", "y2", "z1", "z2"):
+        meas["bits_rel_" + k] = float(np.abs(bits[k] / g["bits_" + k] - 1).max())
+    dps = []
+    for i, k in enumerate(("sse1", "sse2")):
+        meas["sse_rel_" + k] = float(np.abs(sse[i] / g[k] - 1).max())
+        dps.append(10 * np.log10(g[k] / sse[i]))
+        meas["dpsnr_db_view%d" % (i + 1)] = float(np.abs(dps[-1]).max())
+    meas["dpsnr_db"] = float(np.abs((dps[0] + dps[1]) / 2).max())
+    tot = sum(bits[k] for k in bits) / (h * w * 2)
+    ref = sum(g["bits_" + k] for k in ("y1", "y2", "z1", "z2")) / (h * w * 2)
+    meas["dbpp_abs"] = float(np.abs(tot - ref).max())
+    meas["dbpp_rel"] = float(np.abs(tot / ref - 1).max())
+    ok = (max(meas["flips_y1_hat"], meas["flips_y2_hat"]) <= flips_max and max(meas["bits_rel_" + k] for k in ("y1", "y2", "z1", "z2")) <= bits_rel
+          and max(meas["sse_rel_sse1"], meas["sse_rel_sse2"]) <= sse_rel and meas["dpsnr_db"] < psnr_db
+          and max(meas["dpsnr_db_view1"], meas["dpsnr_db_view2"]) < (view_psnr_db or psnr_db))
+    assert ok, meas
+    print("measured:", {k: float("%.3g" % v) for k, v in meas.items()})
+    return meas
+
+
+@pytest.mark.parametrize("kind,batch", [("hsic", 8), ("joint", 4)], ids=["C2-hesic-b8", "C4-hesicplus-b4"])
+def test_bf16x3_512_batch_matches_the_reference_pair_by_pair(kind, batch):
+    """BASELINE configs C2 / C4 in the benchmark's own mode (bf16 maps, bf16x3 analysis): every pair of the batch against the
+    reference's fp32 run.  Measured on MI355X: <= 2e-5 of the latents differ, per-pair bits within 4e-4, squared error within 1e-4."""
+    from hesic_amd import functional as Fn
+    g = load_golden(f"{kind}_512_b{batch}.npz")
+    net = build(kind, torch.bfloat16)
+    assert Fn.analysis_precision() == "bf16x3"
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, batch, 512, 512))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+        meas = check_against(g, out, x1, x2, flips_max=1e-3, bits_rel=2e-3, sse_rel=1e-3, psnr_db=1e-3, view_psnr_db=2.5e-3)
+        assert meas["dbpp_rel"] < 1e-3, meas
+        # pairs are independent: the last pair alone reproduces its slice of the batch bit for bit
+        one = net(x1[-1:], x2[-1:], Hm[-1:])
+    for k in ("y1_hat", "y2_hat", "x1_hat", "x2_hat"):
+        assert torch.equal(out[k][-1:], one[k]), k
+
+
+@pytest.mark.parametrize("kind,batch", [("hsic", 8), ("joint", 4)], ids=["C2-hesic-b8", "C4-hesicplus-b4"])
+def test_single_bf16_analysis_512_batch_stays_inside_its_wider_bars(kind, batch):
+    """The same workloads with single-bf16 analysis operands (``set_analysis_precision("bf16")``, the round-2 path, 1.4x faster):
+    ~1 % of the latents land on the other side of .5 (bar 2 %), bits within 5e-3, PSNR within 2e-3 dB."""
+    from hesic_amd import functional as Fn
+    g = load_golden(f"{kind}_512_b{batch}.npz")
+    net = build(kind, torch.bfloat16)
+    Fn.set_analysis_precision("bf16")
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, batch, 512, 512))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+    check_against(g, out, x1, x2, flips_max=2e-2, bits_rel=5e-3, sse_rel=1e-3, psnr_db=2e-3, view_psnr_db=3e-3)
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_fp32_512_batch_matches_the_reference(kind):
+    """fp32 storage (exact-fp32 MFMA) on two pairs of the 512 x 512 workloads: latents differ only at rounding boundaries."""
+    batch = 8 if kind == "hsic" else 4
+    g = load_golden(f"{kind}_512_b{batch}.npz")
+    g2 = {k: (v[:2] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == batch else v) for k, v in g.items()}
+    net = build(kind, torch.float32)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 2, 512, 512))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+    check_against(g2, out, x1, x2, flips_max=2e-4, bits_rel=1e-3, sse_rel=1e-3, psnr_db=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_c5_lambda_sweep_accumulators_match_the_reference(kind):
+    """BASELINE config C5 through ``evaluate.LambdaSweep`` (what ``bench.py --sweep`` times): four lambda-models on an 860 x 1080 pair
+    padded to 896 x 1088, bits and squared error accumulated on the device, bpp / PSNR over the original pixels -- against the
+    reference's run of the same four weight sets on the same padded pair."""
+    import hesic_amd
+    from hesic_amd import models
+    from hesic_amd.evaluate import SWEEP_LAMBDAS, LambdaSweep
+    g = load_golden(f"{kind}_c5.npz")
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    sweep = LambdaSweep(kind, torch.device(DEV))
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 860, 1080)
+    x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)
+    assert x1p.shape[-2:] == (896, 1088)
+    x1, x2, x1p, x2p, Hm = (t.to(DEV) for t in (x1, x2, x1p, x2p, Hm))
+    outs = [sweep.step(m, x1, x2, x1p, x2p, Hm)[0] for m in range(4)]
+    per = sweep.summary(860, 1080)
+    for m, lam in enumerate(SWEEP_LAMBDAS):
+        ref_bits = sum(float(g[f"bits_{k}_{m}"].sum()) for k in ("y1", "y2", "z1", "z2"))
+        s1, s2 = float(g[f"sse1_{m}"].sum()), float(g[f"sse2_{m}"].sum())
+        npx = 860 * 1080
+        ref_psnr = (10 * math.log10(npx * 3 / s1) + 10 * math.log10(npx * 3 / s2)) / 2
+        got = per[str(lam)]
+        assert got["pairs"] == 1
+        assert got["bits"] == pytest.approx(ref_bits, rel=1e-3), (lam, got["bits"], ref_bits)
+        assert abs(got["psnr"] - ref_psnr) < 1e-3, (lam, got["psnr"], ref_psnr)
+        for k in ("y1_hat", "y2_hat"):          # digest of every model's latents; the full tensors of model 0
+            assert float(outs[m][k].double().abs().sum()) == pytest.approx(float(g[f"{k}_abs_sum_{m}"]), rel=2e-4), (lam, k)
+    for k in ("y1_hat", "y2_hat"):
+        assert outs[0][k].shape == (1, 192, 56, 68)
+        assert float((outs[0][k].float().cpu().to(torch.int16) != T(g[k]).to(torch.int16)).float().mean()) <= 1e-3, k
+
+
+def _train_noise(kind, order, B):
+    noise = {}
+    for k in order:
+        if k[0] == "z":      # reference layout (C, 1, H*W*B) with B fastest -> (B, C, H, W)
+            nz = synthetic._uniform(f"noise.{kind}.t512.0.{k}", (128, 1, B * 64), -0.5, 0.5).reshape(128, 8, 8, B).permute(3, 0, 1, 2).contiguous()
+        else:
+            nz = synthetic._uniform(f"noise.{kind}.t512.0.{k}", (B, 192, 32, 32), -0.5, 0.5)
+        noise[k] = nz.to(DEV)
+    return noise
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_c3_training_step_512_b8_matches_the_reference(kind, dtype):
+    """BASELINE config C3, one rank's share: a training step on 8 pairs of 512 x 512 with the reference's noise draws -- loss terms
+    and every parameter's gradient norm of the first backward against the reference's own step, then ``Trainer.step``."""
+    import hesic_amd
+    from hesic_amd import functional as Fn
+    from hesic_amd.train import Trainer
+    g = load_golden(f"{kind}_train512.npz")
+    net = build(kind, dtype)
+    B = 8
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, B, 512, 512))
+    noise = _train_noise(kind, [str(s) for s in g["noise_order"]], B)
+    rel_loss, rel_gn = (2e-3, 1e-2) if dtype == torch.float32 else (5e-3, 5e-2)
+    net.train()
+    out = net(x1, x2, Hm, noise=noise)
+    crit = Fn.rd_loss(out, x1, x2, 0.0067)
+    crit["loss"].backward()
+    assert float(crit["loss"]) == pytest.approx(float(g["loss"]), rel=rel_loss)
+    assert float(crit["bpp_loss"]) == pytest.approx(float(g["bpp"]), rel=rel_loss)
+    assert float(crit["mse_loss"]) == pytest.approx(float(g["mse"]), rel=rel_loss)
+    bad = []
+    for name, p in net.named_parameters():
+        live = "gn_live_" + name
+        ref = float(g[live] if live in g else g["gn_" + name])
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        if abs(got - ref) > rel_gn * max(ref, 1e-6) + 1e-7:
+            bad.append((name, got, ref))
+    assert not bad, bad[:8]
+    del out, crit
+    net.zero_grad(set_to_none=True)
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.0067)
+    c = tr.step(x1, x2, Hm, noise=noise)
+    assert float(c["loss"]) == pytest.approx(float(g["loss"]), rel=rel_loss)
+    assert float(c["aux_loss"]) == pytest.approx(float(g["aux"]), rel=5e-3)

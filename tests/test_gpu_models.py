@@ -2,8 +2,10 @@
 produced by the reference itself (tests/golden/{hsic,joint}_{64,256}.npz) and against the CPU oracle.
 
 fp32 storage: integer latents may flip only at rounding boundaries (<= 2e-4 of them), bits and MSE within
-1e-3 relative -- the BASELINE bar.  bf16 feature maps (fp32 latents): bits 4e-3, MSE 1e-3 relative, <= 2 % flipped latents
-(measured 1.6e-3 / 1.5e-4 / 1.0 %)."""
+1e-3 relative -- the BASELINE bar.  bf16 feature maps with the bf16x3 analysis path (default): <= 1e-3 of the latents differ
+(measured 4e-5), bits 2e-3, PSNR 1e-3 dB; with single-bf16 analysis operands: bits 4e-3, MSE 1e-3 relative, <= 2 % flipped
+latents (measured 1.6e-3 / 1.5e-4 / 1.0 %).  The exact BASELINE workloads (512 x 512 batches, C5, the C3 step) are in
+tests/test_gpu_baseline_workloads.py."""
 import math
 import os
 
@@ -65,29 +67,39 @@ def test_forward_fp32_matches_reference_golden(kind, size, batch):
 
 
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
-def test_forward_bf16_within_stated_tolerance(kind):
-    """bf16 feature maps with fp32 latents (y, z, sigma, mu from the fp32 accumulators): measured on MI355X against the
-    reference golden at 256x256 -- 1.0 % of the rounded latents sit on the other side of a bin edge (bf16 operand rounding
-    inside the four analysis layers moves y by ~0.3 %, i.e. ~0.02 at |y| ~ 7), total bits off by 1.6e-3 (HESIC) / 7e-4
-    (HESIC+) relative, PSNR by 6e-4 dB.  Bars = measured value + margin."""
+@pytest.mark.parametrize("analysis", ["bf16x3", "bf16"])
+def test_forward_bf16_within_stated_tolerance(kind, analysis):
+    """bf16 feature maps against the reference golden at 256x256 (BASELINE config C1's input on the GPU).
+    analysis = "bf16x3" (default; g_a and the hyper-analysis on hi/lo bf16 pairs, fp32 latents): measured on MI355X <= 4e-5 of the
+    rounded latents differ from the reference's (bar 1e-3), total bits within 9e-4 relative (bar 2e-3), PSNR within 4e-4 dB (bar 1e-3).
+    analysis = "bf16" (single-bf16 operands, round 2): 1.0 % of the latents sit on the other side of a bin edge (bf16 operand rounding
+    inside the four analysis layers moves y by ~0.3 %), bits 1.6e-3, PSNR 6e-4 dB; bars 2 % / 4e-3 / 2e-3 dB."""
     from hesic_amd import functional as Fn, models
     g = load_golden(f"{kind}_256.npz")
     net = build(kind, torch.bfloat16)
+    flips_max, bits_rel, psnr_db = (1e-3, 2e-3, 1e-3) if analysis == "bf16x3" else (0.02, 4e-3, 2e-3)
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 1, 256, 256))
-    with torch.no_grad():
-        assert Fn.fp32_latents()
-        out = net(x1, x2, Hm)
-        m = models.metrics_from(models.rate_distortion(out, x1, x2))
+    prev = Fn.set_analysis_precision(analysis)
+    try:
+        with torch.no_grad():
+            assert Fn.fp32_latents()
+            out = net(x1, x2, Hm)
+            m = models.metrics_from(models.rate_distortion(out, x1, x2))
+    finally:
+        Fn.set_analysis_precision(prev)
     assert out["y1_hat"].dtype == torch.bfloat16            # integer-valued: exact in the storage dtype of the synthesis convs
     total = sum(float(g["bits_" + k]) for k in ("y1", "y2", "z1", "z2"))
-    assert sum(m["bits"].values()) == pytest.approx(total, rel=4e-3)
+    assert sum(m["bits"].values()) == pytest.approx(total, rel=bits_rel)
     assert m["mse1"] == pytest.approx(float(g["mse1"]), rel=1e-3)
     assert m["mse2"] == pytest.approx(float(g["mse2"]), rel=1e-3)
     ref_psnr = (10 * math.log10(1 / float(g["mse1"])) + 10 * math.log10(1 / float(g["mse2"]))) / 2
-    assert abs(m["psnr"] - ref_psnr) < 2e-3
+    assert abs(m["psnr"] - ref_psnr) < psnr_db
     for k in ("y1_hat", "y2_hat"):
         flips = (out[k].float().cpu().to(torch.int16) != T(g[k])).float().mean()
-        assert float(flips) < 0.02, (k, float(flips))
+        assert float(flips) <= flips_max, (k, float(flips))
+    if analysis == "bf16x3":        # the hyper-latents of the hi/lo route are the reference's: z bits to 1e-5
+        for k in ("z1", "z2"):
+            assert m["bits"][k] == pytest.approx(float(g["bits_" + k]), rel=1e-5), k
 
 
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
