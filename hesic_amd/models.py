@@ -725,6 +725,11 @@ class HSIC(StereoCompressionModel):
 
 
 # -------------------------------------------------------------------------------------------- HESIC+
+def _nhwc_rows(t):
+    """(1, C, H, W) map -> (H * W, C) rows, one per pixel (a view when the map is channels_last)."""
+    return t.permute(0, 2, 3, 1).reshape(t.shape[2] * t.shape[3], t.shape[1])
+
+
 def _seq3(seq, x, last_act=NONE):
     """conv/deconv -> LeakyReLU -> conv/deconv -> LeakyReLU -> conv (the h_a / h_s / entropy_parameters
     Sequentials of newnet1_joint.py:611-665) with the activations fused."""
@@ -936,13 +941,34 @@ class HSICJoint(StereoCompressionModel):
         head = np.array([len(z_strings[0]), minmax], dtype=np.uint16).tobytes() + np.packbits(flag).tobytes() + z_strings[0]
         return head, minmax, [int(c) for c in np.nonzero(flag)[0]]
 
-    def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
+    @staticmethod
+    def _wavefronts(H, W):
+        """Pixels grouped by t = w + 3 h.  The 5x5 mask-'A' context of pixel (h, w) is rows h-2, h-1 (columns w-2 .. w+2) and
+        (h, w-2), (h, w-1): every one of them has a smaller t, so the pixels of one group only depend on earlier groups and
+        can be decoded together -- W + 3 (H - 1) device steps instead of H * W.  Returns a list of int64 arrays of raster
+        indices h * W + w (ascending inside a group)."""
+        import numpy as np
+        hh, ww = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        t = (ww + 3 * hh).reshape(-1)
+        order = np.argsort(t, kind="stable")
+        cuts = np.flatnonzero(np.diff(t[order])) + 1
+        return np.split(order.astype(np.int64), cuts)
+
+    ORDER_RASTER, ORDER_WAVEFRONT = 0, 1
+
+    def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None, order="wavefront"):
+        """``order``: the sequence in which the pixels' symbols enter the range coder.  "raster" is the reference's (rows, then
+        columns; newnet1_joint.py:903-1040) and forces a decoder to walk the map pixel by pixel; "wavefront" (default) codes the
+        pixels group by group of ``_wavefronts`` so the decoder evaluates every group in one batch.  Same symbols, same
+        tables; the first payload byte says which (the payload is this repository's own range coder either way)."""
         import os
         import time
         import numpy as np
         from ._host import RangeEncoder
         if x1.shape[0] != 1:
             raise ValueError("compress codes one stereo pair per call (batch size 1, as the reference)")
+        if order not in ("raster", "wavefront"):
+            raise ValueError('compress: order must be "raster" or "wavefront"')
         if self.entropy_bottleneck1._offset.numel() == 0:
             self.update()
         size = (x1.shape[-2], x1.shape[-1])
@@ -977,13 +1003,23 @@ class HSICJoint(StereoCompressionModel):
                     continue
                 H, W = y_hat.shape[-2:]
                 rows = max(1, (256 << 20) // (len(channels) * W * (2 * minmax + 2) * 4))
-                for r0 in range(0, H, rows):                     # raster order: row blocks keep the table buffer bounded
+                tabs, syms = [], []
+                for r0 in range(0, H, rows):                     # row blocks keep the device table buffer bounded
                     r1 = min(H, r0 + rows)
                     cdf = Fn.gmm_cdf_tables(sc[:, :, r0:r1], mu[:, :, r0:r1], None, channels, minmax, 1, scale_bound=bound)
-                    cdf = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(-1, 2 * minmax + 2)
+                    cdf = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(-1, len(channels), 2 * minmax + 2)
                     sym = y_hat[0, channels, r0:r1].float().cpu().numpy().astype(np.int64) + minmax
-                    enc.encode(sym.transpose(1, 2, 0).reshape(-1).astype(np.int32), np.ascontiguousarray(cdf))
-        payload = enc.finish()
+                    sym = sym.transpose(1, 2, 0).reshape(-1, len(channels)).astype(np.int32)
+                    if order == "raster":
+                        enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf.reshape(-1, 2 * minmax + 2)))
+                    else:
+                        tabs.append(cdf)
+                        syms.append(sym)
+                if order == "wavefront":                         # pixel-major tables of the whole map, re-ordered group by group
+                    perm = np.concatenate(self._wavefronts(H, W))
+                    cdf, sym = np.concatenate(tabs)[perm], np.concatenate(syms)[perm]
+                    enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf.reshape(-1, 2 * minmax + 2)))
+        payload = bytes([self.ORDER_WAVEFRONT if order == "wavefront" else self.ORDER_RASTER]) + enc.finish()
         with open(os.path.join(output_path, str(output_name) + ".npz"), "wb") as f:
             f.write(bytes(head))
         with open(os.path.join(output_path, str(output_name) + ".bin"), "wb") as f:
@@ -1015,21 +1051,67 @@ class HSICJoint(StereoCompressionModel):
         yh, yw = int(x_shape[0]) // 16, int(x_shape[1]) // 16
         size = (int(x_shape[0]), int(x_shape[1]))
         with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
-            dec = RangeDecoder(f.read())
+            payload = f.read()
+        if not payload or payload[0] not in (self.ORDER_RASTER, self.ORDER_WAVEFRONT):
+            raise ValueError("decompress: not a HESIC+ payload of this coder (unknown pixel-order byte)")
+        wavefront = payload[0] == self.ORDER_WAVEFRONT
+        dec = RangeDecoder(payload[1:])
         cdt = Fn.compute_dtype()
         bound = self.gaussian_conditional1._bound()
         start = time.time()
 
         def decode_view(which, params, minmax, channels, extra=None):
+            """Raster payload: the reference's walk, one pixel per step (newnet1_joint.py:1190-1260).  Wavefront payload: one step
+            per group of mutually independent pixels -- their 5x5 crops gathered into one batch, ONE masked-conv launch, ONE pass
+            of the 1x1 entropy-parameter net, ONE table launch and ONE device -> host copy for the whole group."""
             y_pad = torch.zeros((1, self.M, yh + 4, yw + 4), dtype=cdt, device=dev).contiguous(memory_format=torch.channels_last)
-            if channels:
-                ch_t = torch.as_tensor(channels, device=dev)
+            if not channels:
+                return y_pad[:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
+            ch_t = torch.as_tensor(channels, device=dev)
+            if not wavefront:
                 for h in range(yh):
                     for w in range(yw):
                         sc, mu = self._gauss_pixel(which, params, y_pad, h, w, extra)
                         cdf = Fn.gmm_cdf_tables(sc, mu, None, channels, minmax, 1, scale_bound=bound)
                         sym = dec.decode(cdf.cpu().numpy().view(np.uint32).reshape(len(channels), -1))
                         y_pad[0, ch_t, h + 2, w + 2] = torch.from_numpy(sym.astype(np.float32) - minmax).to(dev, cdt)
+                return y_pad[:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
+            ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
+            ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
+            if not hasattr(ctx_m, "_packer"):
+                ctx_m._packer = Fn.PackedWeight()
+            Wp = yw + 4
+            y_flat = y_pad.permute(0, 2, 3, 1).reshape((yh + 4) * Wp, self.M)            # views of the NHWC storage: one row per padded pixel
+            par_flat = _nhwc_rows(params)
+            ext_flat = None if extra is None else _nhwc_rows(extra)
+            groups = self._wavefronts(yh, yw)
+            # gather indices of every group, uploaded once: the 25 padded-map rows of each pixel's crop, its own padded row, its raster row
+            win = (np.arange(5)[:, None] * Wp + np.arange(5)[None, :]).reshape(-1)
+            all_pix = np.concatenate(groups)
+            top_left = (all_pix // yw) * Wp + (all_pix % yw)
+            crop_idx = torch.from_numpy((top_left[:, None] + win[None, :]).reshape(-1)).to(dev)
+            centre_idx = torch.from_numpy(top_left + 2 * Wp + 2).to(dev)
+            pix_idx = torch.from_numpy(all_pix).to(dev)
+            pos = 0
+            for grp in groups:
+                P = len(grp)
+                crops = y_flat[crop_idx[pos * 25:(pos + P) * 25]].view(P, 5, 5, self.M).permute(0, 3, 1, 2)      # (P, M, 5, 5), NHWC in memory
+                ctx = Fn.conv2d(crops, ctx_m.weight, ctx_m.bias, kernel_size=5, stride=1, padding=0, mask=ctx_m.mask,
+                                tap_mask=ctx_m._tap_mask, packer=ctx_m._packer)                                    # (P, 2M, 1, 1)
+                rows = pix_idx[pos:pos + P]
+                parts = [par_flat[rows], ctx.reshape(P, -1)]
+                if ext_flat is not None:
+                    parts.append(ext_flat[rows])
+                feat = torch.cat(parts, 1)
+                sc, mu = _seq3_hi(ep, feat.view(P, feat.shape[1], 1, 1).contiguous(memory_format=torch.channels_last)).chunk(2, 1)
+                # (P, M, 1, 1) -> one image row of P pixels for the table kernel: the same P x M memory
+                sc_r, mu_r = (t.reshape(P, self.M).contiguous().t().reshape(1, self.M, 1, P) for t in (sc, mu))
+                cdf = Fn.gmm_cdf_tables(sc_r, mu_r, None, channels, minmax, 1, scale_bound=bound)               # (C, 1, P, n)
+                tab = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(P * len(channels), -1)
+                sym = dec.decode(np.ascontiguousarray(tab)).reshape(P, len(channels))
+                vals = torch.from_numpy(sym.astype(np.float32) - minmax).to(dev, cdt)
+                y_flat[centre_idx[pos:pos + P].unsqueeze(1), ch_t.unsqueeze(0)] = vals
+                pos += P
             return y_pad[:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
 
         with torch.no_grad(), Fn.no_split_k():

@@ -364,8 +364,9 @@ _H_S = [(0, "deconv", 2), (2, "deconv", 2), (4, "conv", 1)]
 _EP = [(0, "1x1", 1), (2, "1x1", 1), (4, "1x1", 1)]
 
 
-def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=True):
-    """HESIC+ forward (ywz/mywork/newnet1_joint.py:675-753)."""
+def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=True, return_params=False):
+    """HESIC+ forward (ywz/mywork/newnet1_joint.py:675-753).  ``return_params``: also out["gauss1"/"gauss2"] = (scales, means),
+    what compress() builds its per-pixel tables from (:903-911 -- the per-pixel crop evaluates the same masked conv)."""
     nz = noise or {}
     size = x1.shape[-2:]
     q = (lambda t, k: quantize(t, "noise", None, nz.get(k))) if training else (lambda t, k: quantize(t, "dequantize"))
@@ -396,6 +397,8 @@ def hsic_joint_forward(P, x1, x2, Hm, training=False, noise=None, align_corners=
     out = {"x1_hat": x1_hat, "x2_hat": x2_hat, "y1_hat": y1_hat, "y2_hat": y2_hat,
            "z1_hat": z1_hat, "z2_hat": z2_hat,
            "likelihoods": {"y1": y1_lik, "y2": y2_lik, "z1": z1_lik, "z2": z2_lik}}
+    if return_params:
+        out["gauss1"], out["gauss2"], out["z1"], out["z2"] = (sc1, mu1), (sc2, mu2), z1, z2
     return out
 
 

@@ -690,10 +690,61 @@ def fx_codec_model(newnet1):
     print("codec model: views (len z, minmax, non-zero channels)", views, "calls", len(log), "table widths", t1.shape, t2.shape)
 
 
+def fx_codec_model_joint(newnet1_joint):
+    """Round 3: the reference's own HESIC+ ``HSIC.compress`` (newnet1_joint.py:793-1079) at 64 x 64 with the same recording stand-in
+    for the absent range coder as ``fx_codec_model``: the side-information file byte for byte, the coding order (raster over the
+    pixels, all non-zero channels of a pixel together; view 1 then view 2), every symbol and every cumulative-frequency table the
+    per-pixel crop -> masked conv -> entropy-parameter net of the reference produces."""
+    import tempfile
+    np.int = int                                   # newnet1_joint.py:858,967 still use the alias NumPy 2 removed
+    log = []
+
+    class Recorder:
+        def __init__(self, path):
+            open(path, "wb").close()           # the reference stats the file afterwards
+
+        def encode(self, symbols, cdf):
+            log.append((int(symbols[0]), np.asarray(cdf, dtype=np.int64)))
+
+        def close(self):
+            pass
+
+    newnet1_joint.RangeEncoder = Recorder
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], str) and a[0].startswith("cuda")) else orig_to(self, *a, **k)
+    try:
+        torch.manual_seed(0)
+        net = newnet1_joint.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net.eval()
+        net.entropy_bottleneck1.update(force=True)
+        net.entropy_bottleneck2.update(force=True)
+        x1, x2, Hm = synthetic.stereo_batch(0, 1, 64, 64)
+        with tempfile.TemporaryDirectory() as td, torch.no_grad():
+            net.compress(x1, x2, Hm, "pair0", td)
+            head = np.frombuffer(open(os.path.join(td, "pair0.npz"), "rb").read(), dtype=np.uint8).copy()
+    finally:
+        torch.Tensor.to = orig_to
+    pos, views = 4, []
+    for _ in range(2):
+        ln, mm = (int(v) for v in np.frombuffer(head[pos:pos + 4].tobytes(), dtype=np.uint16))
+        flags = np.unpackbits(head[pos + 4:pos + 4 + 24])
+        views.append((ln, mm, int(flags.sum())))
+        pos += 4 + 24 + ln
+    n1 = views[0][2] * 16                          # latents of view 1: 4 x 4 pixels x non-zero channels
+    assert len(log) == n1 + views[1][2] * 16, (len(log), views)
+    sym = np.array([s_ for s_, _ in log], dtype=np.int32)
+    t1 = np.stack([c for _, c in log[:n1]]).astype(np.uint32)
+    t2 = np.stack([c for _, c in log[n1:]]).astype(np.uint32)
+    npz("codec_model_joint_64.npz", header=head, symbols=sym, n_view1=np.int64(n1), tables1=t1, tables2=t2,
+        minmax=np.array([views[0][1], views[1][1]]), zlen=np.array([views[0][0], views[1][0]]))
+    print("codec model joint: views (len z, minmax, non-zero channels)", views, "calls", len(log), "table widths", t1.shape, t2.shape)
+
+
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "enhance", "homo", "models3"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "codec_model_joint", "enhance", "homo", "models3"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
@@ -713,6 +764,8 @@ def main():
         fx_models_r2(newnet1, newnet1_joint)
     if "codec_model" in which:
         fx_codec_model(newnet1)
+    if "codec_model_joint" in which:
+        fx_codec_model_joint(newnet1_joint)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import T
+from conftest import T, load_golden
 from hesic_amd import synthetic, _host
 
 
@@ -128,6 +128,40 @@ def test_oracle_tables_and_symbols_match_the_reference_compress_run():
         assert dfreq.max() <= 1 and (dfreq.max(axis=1) > 0).mean() < 0.02
         pos += sym.size
     assert pos == g["symbols"].size and n1 == 192 * 16
+
+
+def test_oracle_joint_tables_and_symbols_match_the_reference_compress_run():
+    """tests/golden/codec_model_joint_64.npz: the reference's own HESIC+ ``HSIC.compress`` (newnet1_joint.py:793-1079) recorded call
+    by call.  The oracle's full-map context model reproduces what the reference computes crop by crop: the latent range, the
+    coding order (raster over the pixels, the non-zero channels of a pixel together; view 1 then view 2), every symbol and every
+    cumulative-frequency table."""
+    from oracle import hesic_oracle as O
+    g = load_golden("codec_model_joint_64.npz")
+    from hesic_amd import models
+    net = models.HSICJoint()
+    synthetic.fill_state_dict_(net.state_dict())
+    P = {k: v.clone() for k, v in net.state_dict().items()}
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 64, 64)
+    with torch.no_grad():
+        out = O.hsic_joint_forward(P, x1, x2, Hm, return_params=True)
+    pos = 0
+    for v, (yk, gk) in enumerate((("y1_hat", "gauss1"), ("y2_hat", "gauss2"))):
+        y = out[yk][0].numpy().astype(np.int64)
+        minmax = int(max(np.abs(y).max(), 1))
+        assert minmax == int(g["minmax"][v])
+        channels = [c for c in range(192) if np.abs(y[c]).sum() > 0]
+        sym = (y[channels] + minmax).transpose(1, 2, 0).reshape(-1)            # pixel-major, channels inside
+        assert np.array_equal(sym, g["symbols"][pos:pos + sym.size])
+        sc, mu = out[gk]
+        tables = O.compress_cdf_tables(sc, mu, torch.ones(1, 192, 1, 1), channels, minmax, 1, 192)      # (C, H, W, n)
+        got = tables.transpose(1, 2, 0, 3).reshape(-1, 2 * minmax + 2).astype(np.int64)
+        ref = g["tables1" if v == 0 else "tables2"].astype(np.int64)
+        dfreq = np.abs(np.diff(got, axis=-1) - np.diff(ref, axis=-1))
+        # the reference evaluates the masked conv on 5x5 crops, the oracle on the whole map: the same sums in another blocking -- a
+        # frequency on a rounding boundary may move by one count of 65536
+        assert dfreq.max() <= 1 and (dfreq.max(axis=1) > 0).mean() < 0.05, (v, dfreq.max(), (dfreq.max(axis=1) > 0).mean())     # measured: 3 % of the rows
+        pos += sym.size
+    assert pos == g["symbols"].size
 
 
 def test_side_information_file_matches_the_reference_byte_for_byte():
@@ -290,5 +324,95 @@ def test_gpu_compress_matches_the_reference_compress_run(tmp_path):
             dfreq = np.abs(np.diff(got, axis=-1) - np.diff(ref, axis=-1))
             assert dfreq.max() <= 1 and (dfreq.max(axis=1) > 0).mean() < 0.05
             pos += sym.size
+    finally:
+        hesic_amd.set_compute_dtype(prev)
+
+
+@pytest.mark.gpu
+def test_gpu_joint_compress_matches_the_reference_compress_run(tmp_path):
+    """HSICJoint.compress(order="raster") on the HIP path (fp32) against the recorded reference run of newnet1_joint.HSIC.compress:
+    the side-information file byte for byte, the symbols in the reference's coding order, the tables within one count of 65536."""
+    import hesic_amd
+    from conftest import load_golden
+    from hesic_amd import functional as Fn, models
+    g = load_golden("codec_model_joint_64.npz")
+    prev = Fn.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.float32)
+    try:
+        net = models.HSICJoint()
+        synthetic.fill_state_dict_(net.state_dict())
+        net.update(force=True)           # host-built z tables, carried like a checkpoint's buffers (see the HESIC test above)
+        net = net.cuda().eval()
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 1, 64, 64))
+        calls = []
+        from hesic_amd import _host
+        real = _host.RangeEncoder
+
+        class Spy(real):
+            def encode(self, sym, cdf):
+                calls.append((np.array(sym), np.array(cdf)))
+                return super().encode(sym, cdf)
+
+        _host.RangeEncoder = Spy
+        try:
+            net.compress(x1, x2, Hm, "pair0", str(tmp_path), order="raster")
+        finally:
+            _host.RangeEncoder = real
+        assert open(tmp_path / "pair0.npz", "rb").read() == g["header"].tobytes()
+        sym = np.concatenate([c[0].reshape(-1) for c in calls])
+        assert np.array_equal(sym, g["symbols"])
+        n1 = int(g["n_view1"])
+        tabs = [np.concatenate([c[1] for c in calls if c[1].shape[-1] == 2 * int(g["minmax"][v]) + 2]) for v in (0, 1)]
+        if int(g["minmax"][0]) == int(g["minmax"][1]):
+            both = tabs[0]
+            tabs = [both[:n1], both[n1:]]
+        for v in (0, 1):
+            got, ref = tabs[v].astype(np.int64), g["tables1" if v == 0 else "tables2"].astype(np.int64)
+            assert got.shape == ref.shape
+            dfreq = np.abs(np.diff(got, axis=-1) - np.diff(ref, axis=-1))
+            assert dfreq.max() <= 1 and (dfreq.max(axis=1) > 0).mean() < 0.05, (v, dfreq.max(), (dfreq.max(axis=1) > 0).mean())
+        dec = net.decompress(None, None, Hm, "pair0", str(tmp_path))
+        assert np.array_equal((dec["y1_hat"][0].float().cpu().numpy().astype(np.int64) + int(g["minmax"][0])).transpose(1, 2, 0).reshape(-1),
+                              g["symbols"][:n1])
+    finally:
+        hesic_amd.set_compute_dtype(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gpu_joint_wavefront_and_raster_payloads_decode_to_the_same_latents(tmp_path, dtype):
+    """The wavefront payload (default: pixels grouped by w + 3h, one batched device step per group) and the raster payload (the
+    reference's order, one step per pixel) carry the same symbols under the same tables: both decode to the encoder's latents and
+    reconstructions bit for bit, and the payloads have the same length to within the coder's termination bytes."""
+    import time
+    import hesic_amd
+    from hesic_amd import functional as Fn, models
+    prev = Fn.compute_dtype()
+    hesic_amd.set_compute_dtype(dtype)
+    try:
+        net = models.HSICJoint()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.cuda().eval()
+        net.update(force=True)
+        x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(5, 1, 128, 192))
+        outs, times, sizes = {}, {}, {}
+        for order in ("wavefront", "raster"):
+            enc = net.compress(x1, x2, Hm, order, str(tmp_path), order=order)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec = net.decompress(None, None, Hm, order, str(tmp_path))
+            torch.cuda.synchronize()
+            times[order] = time.perf_counter() - t0
+            sizes[order] = len((tmp_path / (order + ".bin")).read_bytes())
+            assert (tmp_path / (order + ".bin")).read_bytes()[0] == (1 if order == "wavefront" else 0)
+            for k in ("y1_hat", "y2_hat"):
+                assert torch.equal(dec[k].float().cpu(), enc[k].float().cpu()), (order, k)
+            outs[order] = dec
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(outs["wavefront"][k].float().cpu(), outs["raster"][k].float().cpu()), k
+        assert abs(sizes["wavefront"] - sizes["raster"]) <= 8
+        assert (tmp_path / "wavefront.npz").read_bytes() == (tmp_path / "raster.npz").read_bytes()
+        print("decode seconds", times)
+        assert times["wavefront"] < times["raster"]          # 8 x 12 latent pixels: 33 groups against 96 pixel steps per view
     finally:
         hesic_amd.set_compute_dtype(prev)
