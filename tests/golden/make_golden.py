@@ -741,10 +741,90 @@ def fx_codec_model_joint(newnet1_joint):
     print("codec model joint: views (len z, minmax, non-zero channels)", views, "calls", len(log), "table widths", t1.shape, t2.shape)
 
 
+def fx_dataset():
+    """Round 3: the reference's own stereo ``ImageFolder`` (compressai/datasets/utils.py:68-214) run on a small
+    synthetic left/right folder with Python's ``random`` seeded per item.  Absent third parties are stood in for by their
+    published semantics -- ``cv2.imread`` / ``cvtColor`` (PIL + channel flip), ``cv2.resize`` (INTER_LINEAR: half-pixel centres, no
+    anti-aliasing; float form rounded to uint8), torchvision ``ToTensor`` / ``Normalize`` / ``Compose`` -- and ``get_H`` (SURF + RANSAC,
+    opencv-contrib non-free) by a fixed matrix.  What the fixture pins is everything the reference's code itself decides: the
+    pairing, the crop rule and its random draws, the shared offset of the two views, the 256 -> 128 grey windows with their
+    normalisation and corner order, the item layouts."""
+    import random
+    import tempfile
+    from PIL import Image
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB = 4
+
+    def imread(path):
+        with Image.open(path) as im:
+            return np.array(im.convert("RGB"))[:, :, ::-1].copy()
+    cv2.imread = imread
+    cv2.cvtColor = lambda img, code: img[:, :, ::-1].copy()
+
+    def resize(img, size):
+        t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).unsqueeze(0).float()
+        t = F.interpolate(t, size=(size[1], size[0]), mode="bilinear", align_corners=False)
+        return t.round().clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+    tvt = sys.modules["torchvision.transforms"]
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            return (t - self.mean.view(-1, 1, 1)) / self.std.view(-1, 1, 1)
+    tvt.Compose, tvt.ToTensor, tvt.Normalize = Compose, ToTensor, Normalize
+    for m in [k for k in sys.modules if k.startswith("compressai.datasets")]:
+        del sys.modules[m]
+    import compressai.datasets.utils as U
+    Hfix = np.array([[1.01, 0.02, -3.0], [-0.01, 0.99, 1.5], [1e-5, -2e-5, 1.0]])
+    U.get_H = lambda a, b: [torch.from_numpy(Hfix.astype(np.float32))]
+    Himg, Wimg, n = 96, 128, 3
+    x1, x2, _ = synthetic.stereo_batch(0, n, Himg, Wimg)
+    A = {"Hfix": Hfix.astype(np.float32)}
+    with tempfile.TemporaryDirectory() as td:
+        for side, x in (("left", x1), ("right", x2)):
+            os.makedirs(os.path.join(td, "train", side))
+            for i in range(n):
+                Image.fromarray((x[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)).save(os.path.join(td, "train", side, f"{i:04d}.png"))
+        ds = U.ImageFolder(td, transform=ToTensor(), patch_size=(64, 80), split="train")
+        for i in range(n):
+            random.seed(1000 + i)
+            a, b, h, g1, g2, corners = ds[i]
+            A[f"x1_{i}"], A[f"x2_{i}"] = (a * 255).round().to(torch.uint8), (b * 255).round().to(torch.uint8)
+            A[f"H_{i}"], A[f"corners_{i}"] = h, corners
+            A[f"homo1_sub_{i}"], A[f"homo2_sub_{i}"] = g1[:, ::4, ::4], g2[:, ::4, ::4]
+            A[f"homo_sums_{i}"] = np.array([float(g1.double().sum()), float((g1.double() ** 2).sum()), float(g2.double().sum()), float((g2.double() ** 2).sum())])
+        full = U.ImageFolder(td, transform=ToTensor(), patch_size=(96, 128), split="train", need_file_name=True)
+        random.seed(7)
+        item = full[1]
+        A["full_len"], A["full_name"] = np.int64(len(item)), np.array(item[3])
+        A["full_x1_sum"], A["full_corners"] = float(item[0].double().sum()), item[6]
+        U.get_H = lambda a, b: [None]
+        random.seed(8)
+        A["none_len"] = np.int64(len(ds[0]))
+    npz("dataset.npz", **A)
+
+
 def main():
     torch.set_num_threads(8)
     newnet1, newnet1_joint = import_reference()
-    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "codec_model_joint", "enhance", "homo", "models3"]
+    which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "codec_model_joint", "dataset", "enhance", "homo", "models3"]
     if "ops" in which:
         fx_ops(newnet1)
     if "warp" in which:
@@ -764,6 +844,8 @@ def main():
         fx_models_r2(newnet1, newnet1_joint)
     if "codec_model" in which:
         fx_codec_model(newnet1)
+    if "dataset" in which:
+        fx_dataset()
     if "codec_model_joint" in which:
         fx_codec_model_joint(newnet1_joint)
 

@@ -77,3 +77,41 @@ def test_item_layouts_and_error_paths(tmp_path):
     os.rename(tmp_path / "a" / "train" / "right" / "0001.png", tmp_path / "a" / "train" / "right" / "0009.png")
     with pytest.raises(ValueError, match="cannot compare pictures"):
         ImageFolder(str(tmp_path / "a"), transform=to_tensor, patch_size=(64, 64))[1]
+
+
+def test_items_match_the_reference_loader(tmp_path):
+    """tests/golden/dataset.npz: the reference's own ``ImageFolder`` (compressai/datasets/utils.py:68-214) run on a synthetic folder
+    with ``random`` seeded per item (third parties stood in for by their published semantics, ``get_H`` by a fixed matrix -- see
+    ``make_golden.py dataset``).  Same folder, same seeds: the crops (crop rule, draw order, one offset for both views), the
+    homography hand-over, the 256 -> 128 grey windows and their corners, the item layouts are the reference's."""
+    from PIL import Image
+    from conftest import load_golden
+    from compressai.datasets import ImageFolder, to_tensor
+    g = load_golden("dataset.npz")
+    Himg, Wimg, n = 96, 128, 3
+    x1, x2, _ = synthetic.stereo_batch(0, n, Himg, Wimg)
+    for side, x in (("left", x1), ("right", x2)):
+        os.makedirs(tmp_path / "train" / side)
+        for i in range(n):
+            Image.fromarray((x[i].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)).save(tmp_path / "train" / side / f"{i:04d}.png")
+    Hfix = g["Hfix"]
+    ds = ImageFolder(str(tmp_path), transform=to_tensor, patch_size=(64, 80), split="train", homography=lambda a, b: Hfix)
+    for i in range(n):
+        random.seed(1000 + i)
+        a, b, h, g1, g2, corners = ds[i]
+        np.testing.assert_array_equal((a * 255).round().to(torch.uint8).numpy(), g[f"x1_{i}"])
+        np.testing.assert_array_equal((b * 255).round().to(torch.uint8).numpy(), g[f"x2_{i}"])
+        np.testing.assert_array_equal(h.numpy(), g[f"H_{i}"])
+        np.testing.assert_array_equal(corners.numpy(), g[f"corners_{i}"])
+        np.testing.assert_allclose(g1[:, ::4, ::4].numpy(), g[f"homo1_sub_{i}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g2[:, ::4, ::4].numpy(), g[f"homo2_sub_{i}"], rtol=0, atol=1e-6)
+        sums = [float(g1.double().sum()), float((g1.double() ** 2).sum()), float(g2.double().sum()), float((g2.double() ** 2).sum())]
+        np.testing.assert_allclose(sums, g[f"homo_sums_{i}"], rtol=1e-6)
+    full = ImageFolder(str(tmp_path), transform=to_tensor, patch_size=(96, 128), split="train", need_file_name=True, homography=lambda a, b: Hfix)
+    random.seed(7)
+    item = full[1]
+    assert len(item) == int(g["full_len"]) and item[3] == str(g["full_name"])
+    assert float(item[0].double().sum()) == pytest.approx(float(g["full_x1_sum"]), rel=1e-9)
+    np.testing.assert_array_equal(item[6].numpy(), g["full_corners"])
+    random.seed(8)
+    assert len(ImageFolder(str(tmp_path), transform=to_tensor, patch_size=(64, 80), homography=lambda a, b: None)[0]) == int(g["none_len"])
