@@ -362,7 +362,15 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
     x1, x2, Hm = batch
     net.train()
     param_names = [n for n, _ in net.named_parameters()]
-    tr = (Trainer if args.eager else GraphedTrainer)(net, lr=1e-4, aux_lr=1e-3, lmbda=args.lmbda)
+    force = False
+    if world == 1 and os.environ.get("HESIC_FORCE_COLLECTIVES"):
+        # 1-GPU box: a one-rank RCCL group, so that the bucketed all-reduces (and the ``comm`` diagnostics below) run for real
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        force = True
+    tr = (Trainer if args.eager else GraphedTrainer)(net, lr=1e-4, aux_lr=1e-3, lmbda=args.lmbda, force_collectives=force)
     for _ in range(max(args.warmup, 0 if args.eager else tr.warmup + 1)):
         crit = tr.step(x1, x2, Hm)
     if world > 1:
@@ -405,6 +413,22 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
         roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
                 "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
+    # gradient all-reduce, self-diagnosing (N > 1 on RCCL): ONE eager step whose buckets run synchronously on a communication stream
+    # between events -- per-bucket duration, bus bandwidth and the share of the communication hidden under the backward pass
+    comm = None
+    if tr.main_reducer.active and tr.main_reducer.avg_op:
+        from hesic_amd.train import comm_report
+        tr.main_reducer.timing = True
+        eager(tr, x1, x2, Hm)
+        tr.main_reducer._timed.clear()               # first timed step: stream creation / RCCL channel set-up
+        eager(tr, x1, x2, Hm)
+        rep = comm_report(tr.main_reducer)
+        tr.main_reducer.timing = False
+        nb = len(rep["buckets"])
+        comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "gradient_mb": round(tr.main_group.numel * 4 / 1e6, 1),
+                "buckets": rep["buckets"], "allreduce_total_ms": rep["total_ms"], "hidden_under_backward_frac": rep["hidden_frac"],
+                "ring_busbw_gbps": round(2 * (world - 1) / world * tr.main_group.numel * 4 / 1e6 / max(rep["total_ms"], 1e-6), 1) if nb else None,
+                "note": "one eager step, every bucket's all-reduce synchronous on its own stream between HIP events (rank 0's view)"}
     if world > 1:
         dist.barrier()
 
@@ -425,6 +449,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
             "model_tflops": round(pairs * gflop_pair / elapsed / 1e3, 2) if args.model == "hsic" else None,
             "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype == "bf16" else None,
             "roofline": roof,
+            "comm": comm,
             "launches_per_step": {"c_abi_calls": sum(census.values()), "note": "C-ABI calls of one eager step (each is 1-2 kernel launches); "
                                   "ATen launches not included -- see profiles/ for the rocprofv3 count"},
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
@@ -435,7 +460,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 
@@ -524,13 +549,12 @@ def main():
     # front of them) then run beside the first kernels of the NEXT batch instead of holding the main stream for ~100 us
     # (no fifth stream: the schedule's streams fill the runtime's four hardware queues; the stream view 1's rate branch uses is idle
     # from the middle of a forward to ~0.3 ms into the next one)
-    mstream = models._side_stream(dev, 12)
+    mstream = models.metrics_stream(dev)
 
     def metrics_async(out, a, b):
         mstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(mstream), torch.no_grad():
-            for t in (out["x1_hat"], out["x2_hat"], *out["likelihoods"].values()):
-                models._rec(t, mstream)
+            models.hand_over((out["x1_hat"], out["x2_hat"], *out["likelihoods"].values()), mstream)
             return models.rate_distortion(out, a, b)
 
     def step(i=0):
@@ -598,17 +622,21 @@ def main():
     models.OVERLAP_STREAMS = overlap
     if s:
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        traffic = None            # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/make_pmc_json.py)
+        traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/make_pmc_json.py)
         pj = os.path.join(ROOT, "profiles", "pmc_igemm.json")
         if os.path.exists(pj):
             try:
                 key = f"{args.model}_{args.dtype}_b{args.batch}_{args.size}"
-                traffic = json.load(open(pj)).get(key, {}).get("per_kernel", {}).get(s["kernel"], {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pj))
+                traffic = pmc.get(key, {}).get("per_kernel", {}).get(s["kernel"], {}).get("hbm_bytes_per_launch")
+                if traffic is not None:       # NOT measured by this run: rocprofv3 --pmc passes of an earlier commit, kept under profiles/
+                    traffic_src = {"file": "profiles/pmc_igemm.json", "commit": pmc.get("_commit"), "collected": pmc.get("_collected"),
+                                   "note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/make_pmc_json.py), not from this run"}
             except Exception:
                 traffic = None
         roof = {"kernel": s["kernel"], "bound": "mfma",
                 "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
-                "traffic": traffic, "launches_per_step": s["launches"] // 3, "avg_launch_us": round(s["avg_us"], 2),
+                "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": s["launches"] // 3, "avg_launch_us": round(s["avg_us"], 2),
                 "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3), "other_conv_kernels": s["all"],
                 # the HBM-bound kernels of the path against the 8 TB/s peak (north_star: "achieved HBM GB/s for the warp")
                 "streaming_kernels": km.streaming}

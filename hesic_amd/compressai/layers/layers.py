@@ -29,9 +29,10 @@ class MaskedConv2d(HipConv2d):
     def _fold_mask(self):
         """``weight.data *= mask`` (reference layers.py:43).  Idempotent, so at inference it is skipped while the parameter's
         version counter stands where the last fold left it (a load_state_dict / optimiser step moves it)."""
-        if torch.is_grad_enabled() or getattr(self, "_folded", None) != (self.weight.data_ptr(), self.weight._version):
+        tag = (self.weight.data_ptr(), self.weight._version, Fn._cache_epoch)      # the epoch moves on raw-pointer updates (graph replays)
+        if torch.is_grad_enabled() or getattr(self, "_folded", None) != tag:
             self.weight.data *= self.mask
-            self._folded = (self.weight.data_ptr(), self.weight._version)
+            self._folded = (self.weight.data_ptr(), self.weight._version, Fn._cache_epoch)
 
     def forward(self, x):
         self._fold_mask()

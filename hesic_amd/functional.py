@@ -127,8 +127,21 @@ def clear_grad_slots(keys=None):
             _grad_slots.pop(k, None)
 
 
+_slots_active = False
+
+
+def grad_slots_active(on):
+    """Gate of the direct-write path.  Only inside ``train.Trainer.step`` (which clears the flat buffer first and reads it with
+    its own optimiser) do the gradient kernels add into the slots and hand ``None`` to autograd; everywhere else -- a plain
+    ``loss.backward()``, ``torch.autograd.grad``, tensor / DDP hooks on the parameters -- gradients are returned to autograd as
+    usual (``p.grad`` is still the slot view, so AccumulateGrad lands in the flat buffer all the same)."""
+    global _slots_active
+    prev, _slots_active = _slots_active, bool(on)
+    return prev
+
+
 def _slot_for(t):
-    if t is None or not _grad_slots:
+    if t is None or not _grad_slots or not _slots_active:
         return None
     s = _grad_slots.get(t.data_ptr())
     if s is None:

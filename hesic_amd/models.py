@@ -55,6 +55,21 @@ def _side_stream(device, idx=0):
     return st
 
 
+def metrics_stream(device):
+    """A stream for work that follows a forward without holding the main stream (``bench.py`` reduces bits / squared error on it):
+    the schedule's view-1 rate stream, idle from the middle of a forward to ~0.3 ms into the next one -- a fifth stream would share
+    one of the runtime's four hardware queues with the schedule."""
+    return _side_stream(device, 12)
+
+
+def hand_over(tensors, stream):
+    """Tell the caching allocator that ``tensors`` (an iterable) are also in use on ``stream`` (``Tensor.record_stream``); with
+    HESIC_NO_RECORD_STREAM set -- an UNSAFE debugging switch: a side-stream tensor can then be reused while a kernel on another
+    stream still reads it -- nothing is recorded."""
+    for t in tensors:
+        _rec(t, stream)
+
+
 def _branches(ref, *fns):
     """Run independent branches; at inference each extra branch gets its own HIP stream (forked from / joined to the
     current one) so their small kernels overlap.  Returns the branch results in order."""
@@ -1249,19 +1264,37 @@ class GraphedForward:
         return self.out
 
 
+def _clone_out(o):
+    if torch.is_tensor(o):
+        return o.clone()
+    if isinstance(o, dict):
+        return {k: _clone_out(v) for k, v in o.items()}
+    if isinstance(o, (tuple, list)):
+        return type(o)(_clone_out(v) for v in o)
+    return o
+
+
 class AutoForward:
     """``net(x1, x2, h)`` issued the faster way for THIS host, model and input size: eager launches (the host pays ~1.1 ms per
     forward: fine when the GPU needs longer) or a ``GraphedForward`` replay (no host cost, but the runtime orders a graph's parallel
-    branches its own way: ~7 % slower than eager issue for HESIC at 8 x 512^2, faster for small batches).  Both produce the same
-    tensors; the choice is made once, by timing ``trial`` forwards of each on the example inputs.  Inputs of other shapes fall
-    back to eager.  ``mode`` reports the choice ("eager" | "graph"), ``timings`` both per-forward times in ms."""
+    branches its own way: ~7 % slower than eager issue for HESIC at 8 x 512^2, faster for small batches).  The choice is made once,
+    by timing ``trial`` forwards of each on the example inputs; inputs of other shapes fall back to eager.  ``mode`` reports the
+    choice ("eager" | "graph"), ``timings`` both per-forward times in ms.
 
-    def __init__(self, net, x1, x2, h_matrix, trial=30):
+    A drop-in for ``net(x1, x2, h)``: the result is the caller's own in both modes -- in graph mode the graph's static output
+    buffers are CLONED before they are returned (``static_outputs=True`` hands out the buffers themselves, which the next call
+    overwrites: for loops that consume a result before asking for the next).  The graph holds the packed weights of the moment
+    of capture: every call checks the parameters' (storage, version) tags and ``Fn``'s cache epoch and re-captures when a
+    ``load_state_dict`` / optimiser step / ``invalidate_weight_cache()`` moved them.  When eager wins the trial the graph and its
+    memory pool are dropped."""
+
+    def __init__(self, net, x1, x2, h_matrix, trial=30, static_outputs=False):
         import time
         if net.training:
             raise RuntimeError("AutoForward wraps the inference schedule: call net.eval() first")
-        self.net = net
+        self.net, self.static_outputs = net, static_outputs
         self._graph = GraphedForward(net, x1, x2, h_matrix, with_metrics=False)
+        self._tag = self._weights_tag()
 
         def eager():
             with torch.no_grad():
@@ -1280,10 +1313,20 @@ class AutoForward:
         self.timings = {"eager": timed(eager), "graph": timed(self._graph)}
         self.mode = "graph" if self.timings["graph"] < self.timings["eager"] else "eager"
         self._shape = (tuple(x1.shape), tuple(x2.shape), tuple(h_matrix.shape))
+        if self.mode == "eager":
+            self._graph = None                     # frees the captured graph and its private memory pool
+
+    def _weights_tag(self):
+        return (Fn._cache_epoch,) + tuple((t.data_ptr(), t._version) for t in list(self.net.state_dict(keep_vars=True).values()))
 
     def __call__(self, x1, x2, h_matrix):
         if self.mode == "graph" and (tuple(x1.shape), tuple(x2.shape), tuple(h_matrix.shape)) == self._shape:
-            return self._graph(x1, x2, h_matrix)[0]
+            tag = self._weights_tag()
+            if self._graph is None or tag != self._tag:      # parameters changed since capture (the graph would replay stale packed weights), or no graph yet
+                self._graph = GraphedForward(self.net, x1, x2, h_matrix, with_metrics=False)
+                self._tag = tag
+            out = self._graph(x1, x2, h_matrix)[0]
+            return out if self.static_outputs else _clone_out(out)
         with torch.no_grad():
             return self.net(x1, x2, h_matrix)
 

@@ -211,9 +211,36 @@ class FlatReducer:
         for bi, b in enumerate(self.buckets):
             for i in b["members"]:
                 self._bucket_of[i] = bi
+        # the closures hold the reducer only weakly and the hook handles are kept: a second reducer / Trainer on the same model
+        # must not leave this one's hooks firing (and its flat buffers alive) -- ``close()`` removes them
+        import weakref
+        me = weakref.ref(self)
+
+        def fire(i):
+            r = me()
+            if r is not None:
+                r._event(i)
+        self._handles = []
         for i, (p, s) in enumerate(zip(group.params, group.slots)):
-            s.on_write = (lambda slot, i=i: self._event(i))
-            p.register_post_accumulate_grad_hook(lambda p_, i=i: self._event(i))
+            s.on_write = (lambda slot, i=i: fire(i))
+            self._handles.append(p.register_post_accumulate_grad_hook(lambda p_, i=i: fire(i)))
+        # diagnostics (``timing = True``, eager steps on RCCL only): every bucket's all-reduce runs synchronously on a communication
+        # stream of its own between two events, ``report()`` gives per-bucket durations and the share hidden under the backward pass
+        self.timing, self._comm, self._timed, self._bwd_end = False, None, [], None
+
+    def close(self):
+        """Detach from the parameters (hooks, slot callbacks)."""
+        for h in getattr(self, "_handles", []):
+            h.remove()
+        self._handles = []
+        for s in self.group.slots:
+            s.on_write = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def begin(self):
         """Call before the backward pass of every step."""
@@ -235,15 +262,32 @@ class FlatReducer:
     def _launch(self, b):
         b["launched"] = True
         op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
-        self._work.append(dist.all_reduce(self.group.flat_g[b["lo"]:b["hi"]], op=op, group=self.pg, async_op=True))
+        buf = self.group.flat_g[b["lo"]:b["hi"]]
+        if self.timing and self.avg_op and buf.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=buf.device)
+            self._comm.wait_stream(torch.cuda.current_stream())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._comm):
+                e0.record()
+                dist.all_reduce(buf, op=op, group=self.pg)          # synchronous on the communication stream: e1 is its completion
+                e1.record()
+            self._timed.append((b["hi"] - b["lo"], e0, e1))
+            return
+        self._work.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
 
     def finish(self):
         """Call once after the backward pass: launches the remaining buckets, waits, averages."""
         if not self.active:
             return
+        if self.timing and self.avg_op and self.group.flat_g.is_cuda:
+            self._bwd_end = torch.cuda.Event(enable_timing=True)
+            self._bwd_end.record()                       # the backward pass ends here on the compute stream
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
+        if self._comm is not None and self._timed:
+            torch.cuda.current_stream().wait_stream(self._comm)
         for w in self._work:
             w.wait()
         self._work.clear()
@@ -290,18 +334,24 @@ class Trainer:
         self.aux_reducer.begin()
         prev = Fn.train_pack_cache(True)          # packed conv weights persist across the step, one batched repack below
         scaled, Fn.SCALED_LOSS = Fn.SCALED_LOSS, False     # backward() starts at the unscaled loss: no g_loss multiplies
+        slots = Fn.grad_slots_active(True)        # gradient kernels add straight into the flat buffer (cleared above) for THIS step only
         try:
             crit = self._forward_loss(x1, x2, h_matrix, noise)
             crit["loss"].backward()
         finally:
             Fn.train_pack_cache(prev)
             Fn.SCALED_LOSS = scaled
+            Fn.grad_slots_active(slots)
         self.main_reducer.finish()
         self.optimizer.step()
         if self.on_gpu:
             Fn.repack_all()                       # every packed conv weight of the step refreshed (and re-tagged) in ONE launch
         aux = self.model.aux_loss()
-        aux.backward()
+        slots = Fn.grad_slots_active(True)
+        try:
+            aux.backward()
+        finally:
+            Fn.grad_slots_active(slots)
         self.aux_reducer.finish()
         self.aux_optimizer.step()
         # detached scalars only: a returned loss that still requires grad would keep this step's autograd graph (and its
@@ -375,6 +425,25 @@ class GraphedTrainer(Trainer):
         # every cache keyed on them (bottleneck tables, packed GDN parameters, inference weight packs) must start a new epoch
         Fn.invalidate_weight_cache()
         return self._out
+
+
+def comm_report(reducer):
+    """Per-bucket all-reduce timings of the steps run with ``reducer.timing = True`` (synchronises the device): a list of
+    {mb, ms, gbps} per launch order, the total, and ``hidden_frac`` = the share of the communication time that lay before the end
+    of the backward pass on the compute stream (what the overlap hides; 0 for a reducer built with overlap=False)."""
+    torch.cuda.synchronize()
+    recs, total, hidden = [], 0.0, 0.0
+    for numel, e0, e1 in reducer._timed:
+        ms = e0.elapsed_time(e1)
+        recs.append({"mb": round(numel * 4 / 1e6, 2), "ms": round(ms, 4), "gbps": round(numel * 4 / 1e6 / max(ms, 1e-6), 1)})
+        total += ms
+        if reducer._bwd_end is not None:
+            # [t0, t1]: this all-reduce on a clock whose zero is the end of the backward pass (event times are comparable across
+            # streams; negative = before it); the part before zero ran under the backward pass
+            t0, t1 = reducer._bwd_end.elapsed_time(e0), reducer._bwd_end.elapsed_time(e1)
+            hidden += max(0.0, min(t1, 0.0) - min(t0, 0.0))
+    reducer._timed.clear()
+    return {"buckets": recs, "total_ms": round(total, 4), "hidden_frac": round(hidden / total, 4) if total > 0 else None}
 
 
 def init_distributed(backend=None):

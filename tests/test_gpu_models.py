@@ -305,6 +305,18 @@ def test_auto_forward_picks_a_mode_and_returns_the_eager_tensors():
     with torch.no_grad():
         ref1 = net(a, b, h)
     assert torch.equal(out["x2_hat"], ref1["x2_hat"])
+    # graph mode is a drop-in: results of successive calls do not alias, and a parameter update after capture is picked up
+    auto.mode = "graph"
+    x1b, x2b, Hb = (t.to(DEV) for t in synthetic.stereo_batch(7, 2, 128, 128))
+    first = auto(x1, x2, Hm)
+    second = auto(x1b, x2b, Hb)
+    assert first["x2_hat"].data_ptr() != second["x2_hat"].data_ptr()
+    assert torch.equal(first["x2_hat"], ref["x2_hat"]) and not torch.equal(second["x2_hat"], ref["x2_hat"])
+    with torch.no_grad():
+        net.decoder2.after_conv.bias.add_(0.25)
+        want = net(x1, x2, Hm)
+    got = auto(x1, x2, Hm)
+    assert torch.equal(got["x2_hat"], want["x2_hat"]) and not torch.equal(got["x2_hat"], ref["x2_hat"])
 
 
 def test_graphed_forward_replays_the_eager_result():
@@ -605,7 +617,11 @@ def test_flat_gradients_match_autograd_accumulation():
         groups = [FlatGroup(list(net.parameters())), FlatGroup(list(net.aux_parameters()))] if flat else []
         for g in groups:
             g.zero_grad()
-        Fn.rd_loss(net(x1, x2, Hm, noise=noise), x1, x2, 0.0067)["loss"].backward()
+        prev = Fn.grad_slots_active(flat)          # the direct-write path is gated: Trainer.step opens it for its own backward passes
+        try:
+            Fn.rd_loss(net(x1, x2, Hm, noise=noise), x1, x2, 0.0067)["loss"].backward()
+        finally:
+            Fn.grad_slots_active(prev)
         if flat:
             assert all(s.writes > 0 for g in groups for s, p in zip(g.slots, g.params))          # every gradient took the in-place path
             assert dict(net.named_parameters())["encoder1.g_a_conv2.weight"].grad.data_ptr() == groups[0].grad_views[
