@@ -49,7 +49,6 @@ struct IgemmArgs {
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
     int x_group_step, tiles_per_group;   // grouped launch: cout tile nt reads input channels [x_co + (nt / tiles_per_group) * x_group_step, + Cin)
     int act2, act_split;       // couts >= act_split (a multiple of the cout tile) take activation act2 instead of act
-    int dbg;                   // profiling ablations (HESIC_IGEMM_DBG, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMAs
     float* y32;                // bf16 fast path: also (or, with y == nullptr, only) store act(conv + bias) as fp32 straight from the
     int y32_ps, y32_co;        //      accumulators -- what feeds round() and the likelihoods must not pass through bf16 storage
     // bf16x3 ("hi/lo") operands, hesic_conv2d_forward_hilo (kernel template flag HL): x holds [hi(C) | lo(C)] per pixel (v = hi + lo
@@ -355,7 +354,7 @@ constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { retur
 // LDS-DMA issue, its address bookkeeping and the vmcnt waits live in the loaders (one block per CU, NS = 3 stages of 32 KB).
 // This is the per-SIMD ping-pong pairing of MI355X_MICROARCH.md ("two waves per SIMD") in its cleanest form.  Measured
 // (round 2, conv 128 -> 128 5x5 s2 @256^2 B=8 + GDN, same box, back to back): 144.0 us against 143.8 us for the self-loading
-// form at two blocks per CU -- no gain, and the ablations (HESIC_IGEMM_DBG) say why: with the DMA removed the self-loading
+// form at two blocks per CU -- no gain, and the ablations (run-time HESIC_IGEMM_DBG switches, removed in round 3: their branches cut the K loop into basic blocks) say why: with the DMA removed the self-loading
 // form runs at 84 us, with the MFMAs removed at 86 us, with both removed at 33 us (loop + barriers + GDN epilogue): the
 // matrix phase (~58 us) and the LDS-fill phase (~60 us) ADD instead of overlapping, and the fill alone costs 39 us even from
 // an L1-resident source (DBG=14 vs 6: 53 us from L2) -- 1.64 GB through the ~64 B/clk/CU global->LDS path, which a 128 x 128
@@ -506,15 +505,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         set_tap();
     };
     auto issue = [&](int buf) {
-        if (a.dbg & 1) return;
-        uint32_t sx = s_x + (uint32_t)(cur_chunk * BKH * 2), sw = s_w + (uint32_t)(cur_chunk * BKH * 2);
-        if (a.dbg & 8) {          // every piece re-reads the first kilobytes of its tensor: L1-resident source, same LDS traffic
-            sx = (uint32_t)(neg * 2); sw = 0;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) xv[i] = (xoff[i] & 0xff0u);
-#pragma unroll
-            for (int i = 0; i < WI; ++i) wv[i] &= 0xff0u;
-        }
+        const uint32_t sx = s_x + (uint32_t)(cur_chunk * BKH * 2), sw = s_w + (uint32_t)(cur_chunk * BKH * 2);
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
 #pragma unroll
@@ -613,7 +604,6 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             }
             bf16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
-                if (a.dbg & 2) return;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
@@ -637,13 +627,11 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                         xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
                     }
                 }
-                if (!(a.dbg & 4)) {
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1288,8 +1276,6 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre; a.gdn_gamma_lo = g_gdn_gamma_lo; a.y_hilo = g_y_hilo; a.y_abs = g_y_abs;
     a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
-    static const int dbg = getenv("HESIC_IGEMM_DBG") ? atoi(getenv("HESIC_IGEMM_DBG")) : 0;
-    a.dbg = dbg;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = cin_k; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;

@@ -6,7 +6,7 @@
 // 2^-18, is dropped): x from the fp32 image, w and gamma' from fp32 parameters, the squares and the output from the fp32
 // accumulators.  The output leaves as [hi(128) | lo(128)] per pixel for the hi/lo implicit-GEMM layers behind it.
 //
-// Four 32 KB weight images (w_hi, w_lo, gamma'_hi, gamma'_lo) + 4 KB of row staging per wave (one 16-pixel image row of the tile
+// Four 32 KB weight images (w_hi, w_lo, gamma'_hi, gamma'_lo) + 4 KB of row staging per wave (the tile's 32 pixels x 64 channels of one half
 // at a time) = the CU's whole 160 KB of LDS: one block of eight waves per CU, two per SIMD, so one wave's VALU phases (operand
 // splitting, squares, rsqrt, output staging: about as many issue cycles per tile as its 192 MFMAs) run under the other's MFMAs.
 #include "common.h"
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     const unsigned char* gl_lo = smem + 98304;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fh = lane >> 5;
-    unsigned char* os = smem + 131072 + wave * 4096;   // 16 pixel rows of 256 bytes, 16-byte chunks XOR (pixel & 15)
+    unsigned char* os = smem + 131072 + wave * 4096;   // 32 pixel rows of 128 bytes (64 channels of one half), 16-byte chunks XOR (pixel & 7)
     // A-fragment address of (32-row block i, k-step ks) inside an image: row = i*32 + frow, so (row & 15) == (frow & 15) and the lane part
     // is ONE offset per k-step, the block / image part an immediate -- 8 address registers instead of one per (i, ks, image)
     auto fa = [&](int ks) { return frow * 256 + ((((ks * 2 + fh) ^ (frow & 15))) << 4); };
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     }
     __syncthreads();
 
-    const uint32_t st_lane = (uint32_t)(((lane >> 4) * (int)a.ys_x + (lane & 15) * 8) * 2);
+    const uint32_t st_lane = (uint32_t)(((lane >> 3) * (int)a.ys_x + (lane & 7) * 8) * 2);       // store lane = (pixel of 8, 16-byte chunk of a 128-byte line)
     const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? 512 : 0, 0x00020000);      // no bias: every load returns zeros
     const __amdgpu_buffer_rsrc_t beta_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.beta, 0, 512, 0x00020000);
     for (; tile < ntiles; tile += tstride) {
@@ -192,8 +192,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc; the tile then leaves in four passes through the
-        // wave-private staging rows: (hi | lo) x (first | second image row of the tile), 16 pixels of 256 bytes each
+        // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -205,39 +204,40 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                                                                        // both MFMA phases (48 registers; the allocator spilled them)
         __builtin_amdgcn_sched_barrier(0);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (int64_t)b * a.ys_b), 0, (int)POISON, 0x00020000);
-        const int pl = frow & 15;
+        // four passes through the 4 KB of wave-private staging: (hi | lo) x (channels 0..63 | 64..127), all 32 pixels of the tile, 128
+        // bytes (one cache line) per pixel and pass.  Every lane takes part in every pass, the hi passes cost one pack per channel
+        // pair, only the lo passes form the residual.
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            const int half = pass >> 1, prow = pass & 1;
-            if ((frow >> 4) == prow) {
+            const int half = pass >> 1, cg = pass & 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = i * 32 + 8 * g + 4 * fh;
-                        uint32_t h0, l0, h1, l1;
-                        split2(acc[i][4 * g], acc[i][4 * g + 1], h0, l0);
-                        split2(acc[i][4 * g + 2], acc[i][4 * g + 3], h1, l1);
-                        *(u32x2*)(os + pl * 256 + (((cl >> 3) ^ pl) << 4) + (cl & 7) * 2) = half ? u32x2{l0, l1} : u32x2{h0, h1};
+                for (int g = 0; g < 4; ++g) {
+                    const int i = cg * 2 + ii, cl = ii * 32 + 8 * g + 4 * fh;              // channel inside this pass's 64
+                    uint32_t h0 = pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), h1 = pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                    if (half) {
+                        h0 = pack_bf2(acc[i][4 * g] - __uint_as_float(h0 << 16), acc[i][4 * g + 1] - __uint_as_float(h0 & 0xffff0000u));
+                        h1 = pack_bf2(acc[i][4 * g + 2] - __uint_as_float(h1 << 16), acc[i][4 * g + 3] - __uint_as_float(h1 & 0xffff0000u));
                     }
-            }
+                    *(u32x2*)(os + frow * 128 + (((cl >> 3) ^ (frow & 7)) << 4) + (cl & 7) * 2) = u32x2{h0, h1};
+                }
             // the staging rows are written as 8-byte and read as 16-byte vectors: the compiler must not reorder them on type-based
             // alias grounds (it did: every other pixel came out with the previous pass's data) -- compiler barriers; the LDS itself
             // executes a wave's accesses in order
             asm volatile("" ::: "memory");
-            const int y2 = ty * 2 + prow;
             u32x4 rowv[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int pr = it * 4 + (lane >> 4);
-                rowv[it] = *(const u32x4*)(os + pr * 256 + (((lane & 15) ^ pr) << 4));
+                const int pr = it * 8 + (lane >> 3);
+                rowv[it] = *(const u32x4*)(os + pr * 128 + (((lane & 7) ^ (pr & 7)) << 4));
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int x2 = tx * 16 + it * 4;
-                const int so = (y2 * (int)a.ys_y + x2 * (int)a.ys_x + half * 128) * 2;                       // scalar
-                const bool ok = y2 < a.Ho && x2 + (lane >> 4) < a.Wo;
+                const int y2 = ty * 2 + (it >> 1), x2 = tx * 16 + (it & 1) * 8;
+                const int so = (y2 * (int)a.ys_y + x2 * (int)a.ys_x + half * 128 + cg * 64) * 2;                       // scalar
+                const bool ok = y2 < a.Ho && x2 + (lane >> 3) < a.Wo;
                 // tile offset in the VGPR offset, soffset = 0: see the store-hazard note in sconv_n2w_gdn_fast_kernel
                 __builtin_amdgcn_raw_buffer_store_b128(rowv[it], yr, (int)(ok ? st_lane + (uint32_t)so : POISON), 0, 0);
             }

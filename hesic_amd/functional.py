@@ -128,6 +128,15 @@ def clear_grad_slots(keys=None):
 
 
 _slots_active = False
+_wgrad_stream = None
+
+
+def set_wgrad_stream(stream):
+    """Stream for the weight-gradient launches of the flat-slot path (``_wide_conv_grads``); None = the current stream.  The caller
+    joins it back (``current_stream().wait_stream(stream)``) before anything reads the flat gradient buffer."""
+    global _wgrad_stream
+    prev, _wgrad_stream = _wgrad_stream, stream
+    return prev
 
 
 def grad_slots_active(on):
@@ -432,16 +441,33 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=
         d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(x), 0, in_abs,
                        x.shape[1], 0, gy.shape[1], 0, tap_mask)
         nws = L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d))
-        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
         ws_, bs_ = _slot_for(weight), (_slot_for(bias) if has_bias else None)
         if ws_ is not None and weight.dtype == torch.float32 and (not has_bias or bs_ is not None) and (mask is None or tap_mask):
-            # flat gradient buffer: the finishing kernel adds dW (PyTorch layout) and dbias into the slots
+            # flat gradient buffer: the finishing kernel adds dW (PyTorch layout) and dbias into the slots.  Nothing downstream in
+            # the backward pass reads a weight gradient, so with a weight-gradient stream set (train.Trainer) the two launches go
+            # there: the chain of data gradients -- the critical path of the step -- does not wait for them, and they fill the gaps
+            # between its launches.  ONE such stream: the two gradients of a twice-used weight (encoder1) add into their slot in order.
+            side = _wgrad_stream if x.is_cuda else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                x.record_stream(side)
+                gy.record_stream(side)
+                with torch.cuda.stream(side):
+                    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+                    L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
+                           L.ptr(ws), nws, L.stream())
+                    _slot_done(ws_)
+                    if has_bias:
+                        _slot_done(bs_)
+                return dx, None, None
+            ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
             L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
                    L.ptr(ws), nws, L.stream())
             _slot_done(ws_)
             if has_bias:
                 _slot_done(bs_)
             return dx, None, None
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)      # dead taps of a masked conv are zero-filled by the call
         L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), 0, L.ptr(ws), nws, L.stream())
         if mask is not None and not tap_mask:

@@ -2,7 +2,7 @@
 """One layer of the analysis / synthesis stacks on the implicit-GEMM kernel, timed with HIP events.
 
     python profiles/scripts/conv_layer_time.py [--layer conv2|deconv3|conv3|plain] [--batch 8] [--size 256]
-Environment A/B switches of csrc/conv_igemm.hip apply (HESIC_IGEMM_WS, HESIC_IGEMM_DBG = ablations with garbage results)."""
+Environment A/B switches of csrc/conv_igemm.hip apply (HESIC_IGEMM_WS; the HESIC_IGEMM_DBG ablation switches of rounds 1-2 were removed in round 3: their run-time branches split the K loop into basic blocks)."""
 import argparse
 import os
 import sys
