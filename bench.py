@@ -95,7 +95,12 @@ class KernelMeter:
             if fused:
                 fl += 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cout          # the GDN 1x1 contraction (SURVEY 8d counts it)
             # a hi/lo (bf16x3) launch EXECUTES three bf16 MFMA products per algorithmic MAC: x_hi w_hi + x_lo w_hi + x_hi w_lo
-            self.rec.append((e0, e1, fl, self.variant(d, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else ""),
+            dv = d
+            if hilo:                              # the tile choice of a hi/lo launch follows the packed K extent per tap, 2 Cin
+                import copy
+                dv = copy.copy(d)
+                dv.Cin, dv.x_pix_stride = 2 * d.Cin, max(d.x_pix_stride, 2 * d.Cin)
+            self.rec.append((e0, e1, fl, self.variant(dv, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else ""),
                              3.0 if hilo else 1.0))
             return rc
         self.L.call = call

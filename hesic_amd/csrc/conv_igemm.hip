@@ -45,6 +45,7 @@ struct IgemmArgs {
     void* y_pre;               // fused GDN, training: also store the conv output v = conv + bias (bf16, y's geometry) for GDN's backward
     FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
+    int chunk_major;           // with tap_parity: class -> channel chunk -> tap instead of class -> tap -> chunk (hi/lo operands)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
     int x_group_step, tiles_per_group;   // grouped launch: cout tile nt reads input channels [x_co + (nt / tiles_per_group) * x_group_step, + Cin)
@@ -516,7 +517,26 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         for (int i = 0; i < WI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (lw * WI + i) * 1024),
                                                      16, (int)wv[i], (int)sw, 0, 0);
-        if (++cur_chunk == kchunks) {
+        if (a.chunk_major) {
+            // parity walk, class -> channel chunk -> tap: the taps of a class re-read the same quarter of the input pixels, and with
+            // the chunk OUTSIDE the taps only 1/kchunks of every pixel row is live at a time -- the hi/lo operand maps are twice as
+            // wide, and with the chunk innermost the co-resident blocks of an XCD (~5.9 MB per class) cycled their input through
+            // the 4 MB L2 (PMC: 867 MB fetched per launch for 336 MB of operands on the 128 -> 128 layer at 256^2)
+            dx += 2;
+            if (++cur_c == nkx_e) {
+                cur_c = 0; dx = dx_row; ++cur_j; dy += 2;
+                if (cur_j == nky_e) {
+                    if (++cur_chunk == kchunks) {
+                        cur_chunk = 0;
+                        ++cls;
+                        ky0_e = cls >> 1; kx0_e = cls & 1;
+                        nkx_e = (a.KW - kx0_e + 1) >> 1; nky_e = (a.KH - ky0_e + 1) >> 1;
+                    }
+                    cur_j = 0; dy = ky0_e - a.pad; dx_row = kx0_e - a.pad; dx = dx_row;
+                }
+            }
+            set_tap();
+        } else if (++cur_chunk == kchunks) {
             cur_chunk = 0;
             next_tap();
         }
@@ -1391,6 +1411,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         return 0;
     }
     a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
+    static const int chunk_major_env = getenv("HESIC_IGEMM_CHUNK_MAJOR") ? atoi(getenv("HESIC_IGEMM_CHUNK_MAJOR")) : -1;      // A/B switch: 0 off, 1 all parity walks
+    a.chunk_major = a.tap_parity && (chunk_major_env >= 0 ? chunk_major_env : hilo);
     a.fd_nt = make_fastdiv((uint32_t)a.n_tiles); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     a.fd_b = make_fastdiv((uint32_t)a.B); a.fd_ph = make_fastdiv((uint32_t)a.nphase);
     const dim3 grid((unsigned)nblocks), block(NTHREADS);

@@ -44,7 +44,7 @@ def main():
     merged = {}
     for inst, v in res.items():
         p = inst.split(",")
-        name = f"igemm_glds_kernel<{p[0]},{p[1]},{p[2]}{',gdn' if p[4] != '0' else ''}>"
+        name = f"igemm_glds_kernel<{p[0]},{p[1]},{p[2]}{',gdn' if p[4] != '0' else ''}>" + (" hilo" if len(p) > 7 and p[7] == "1" else "")
         m = merged.setdefault(name, {"launches": 0, "bytes": 0.0})
         m["launches"] += v["launches"]
         m["bytes"] += v["hbm_bytes_per_launch"] * v["launches"]

@@ -1,0 +1,22 @@
+set -x
+O=$GRAFT_REPO_ROOT/gpurun_out/r03a; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+python bench.py --parity-trained 4 > $O/bench.json 2> $O/bench.err
+python bench.py --analysis bf16 > $O/bench_bf16.json 2>/dev/null
+python bench.py --model joint --batch 4 > $O/bench_joint.json 2>/dev/null
+python bench.py --model joint --batch 8 --no-cpu-baseline > $O/bench_joint_b8.json 2>/dev/null
+python bench.py --dtype f32 --steps 20 > $O/bench_f32.json 2>/dev/null
+python bench.py --sweep --batch 4 --steps 16 > $O/bench_c5_sweep.json 2>/dev/null
+python bench.py --sweep --model joint --batch 4 --steps 16 > $O/bench_c5_sweep_joint.json 2>/dev/null
+HESIC_FORCE_COLLECTIVES=1 python bench.py --mode train > $O/bench_train.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/p1 -o d --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --exec eager > /dev/null 2>&1
+cp /tmp/p1/d_kernel_stats.csv $O/default_kernel_stats.csv
+HESIC_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/p2 -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --exec eager > /dev/null 2>&1
+cp /tmp/p2/s_kernel_stats.csv $O/single_stream_kernel_stats.csv
+HESIC_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "igemm_glds_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_f -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
+HESIC_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "igemm_glds_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_w -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p3 -o t --output-format csv -- python $GRAFT_REPO_ROOT/profiles/scripts/train_step.py --size 512 --only g --steps 10 > /dev/null 2>&1
+cp /tmp/p3/t_kernel_stats.csv $O/graphed_train_step_512_kernel_stats.csv
+ls -la $O $O/pmc_f/* | head -40
+du -sh $O
