@@ -141,6 +141,8 @@ _SIGS = {
     "hesic_gdn_pack_params_lo": ([_vp, _vp, _i32, _vp], _i32),
     "hesic_sconv_pack_weight_image_hilo": ([_vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward_hilo": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
+    "hesic_conv3x3_c32_wgrad_ws_bytes": ([], _i64),
+    "hesic_conv3x3_c32_wgrad": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     "hesic_im2col_hilo": ([_vp, _P(_i64), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
 }
 

@@ -75,8 +75,13 @@ class ResidualBlock(nn.Module):
         if self.skip is None and Fn.conv3x3_c32_ok(x, self.conv1.weight) and Fn.conv3x3_c32_ok(x, self.conv2.weight):
             out = Fn.conv3x3_c32(x, self.conv1.weight, self.conv1.bias, act=L.ACT_LEAKY)
             return Fn.conv3x3_c32(out, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY, res1=x, res2=outer_skip)
-        out = self.conv1.run(x, act=L.ACT_LEAKY)
-        out = self.conv2.run(out, act=L.ACT_LEAKY)
+        if self.skip is None and Fn.conv3x3_c32_train_ok(x, self.conv1.weight) and Fn.conv3x3_c32_train_ok(x, self.conv2.weight):
+            # training (stage 2): forward and data gradient of both convs on the 32-channel kernel
+            out = Fn.conv3x3_c32_train(x, self.conv1.weight, self.conv1.bias, act=L.ACT_LEAKY)
+            out = Fn.conv3x3_c32_train(out, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY)
+        else:
+            out = self.conv1.run(x, act=L.ACT_LEAKY)
+            out = self.conv2.run(out, act=L.ACT_LEAKY)
         identity = x if self.skip is None else self.skip(x)
         out = out + identity.to(out.dtype)
         return out if outer_skip is None else out + outer_skip.to(out.dtype)

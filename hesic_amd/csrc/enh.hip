@@ -220,3 +220,180 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
     else hipLaunchKernelGGL(c32_conv3x3_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("conv3x3_c32_forward");
 }
+
+// ---------------------------------------------------------------------------------------------- weight gradient, 32 channels
+// dW[co][ci][ky][kx] = sum over pixels of g[p][co] * x[p + (ky-1, kx-1)][ci] for the 3x3 convs above (stage 2 trains the enhancement
+// net, newnet1.py:272-311): 9 x 32 x 32 numbers out of 2 M pixels per layer.  The implicit-GEMM weight-gradient kernel serves this
+// shape with a 128 x 128 channel tile and one block per tap (16x the MFMA work, 9x the reads): 828 us per layer at B=8 512x512,
+// 36 layers per step.  Here a wave owns a strip of 64 pixels of one image row: the strip of g (4 KB) and the three halo rows of x
+// (3 x 66 pixels) go to wave-private LDS with LDS-DMA (NHWC rows of 32 bf16 channels are contiguous: lane-linear copies), double
+// buffered; per 16 pixels one transposing fragment read of g (ds_read_tr16_b64: a lane wants 8 consecutive PIXELS of one channel)
+// feeds ten MFMAs -- nine taps against the shifted x fragments and one against a fragment of ones for the bias gradient.  Every
+// wave keeps its 10 accumulators over all its strips, a block leaves one [10][32][32] fp32 partial; a finishing kernel sums the
+// partials into the PyTorch layout.  HBM-bound: g and x are read once (134 + 134 MB per layer).
+namespace {
+
+struct C32WgArgs {
+    const bf16_t* x; const bf16_t* g; float* part;
+    int B, H, W, strips_x, nstrips;
+    FastDiv fd_sx, fd_h;
+};
+
+constexpr int WG_STRIP = 64, WG_ROWB = (WG_STRIP + 2) * 64 + 64;      // bytes of a staged x halo row (66 pixels, padded to 5 x 1 KB DMA pieces = 5120? no: see below)
+constexpr int WG_XROW = 5 * 1024;                                     // a halo row is fetched as 5 lane-linear 1 KB pieces (80 pixels, 66 used)
+constexpr int WG_BUF = 4096 + 3 * WG_XROW;                            // one stage: g strip + three x rows = 19456 bytes
+
+__global__ __launch_bounds__(256, 1) void c32_wgrad_kernel(const C32WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    constexpr uint32_t OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* mine = wsm + wave * (2 * WG_BUF);
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)wsm) : "memory");
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)OOB, 0x00020000);
+    const int gw = (int)(blockIdx.x * 4 + wave), nw = (int)gridDim.x * 4;
+
+    auto issue = [&](int strip, int buf) {
+        const uint32_t q = fdiv((uint32_t)strip, a.fd_sx);
+        const int sx = strip - (int)q * a.strips_x;
+        const int b = (int)fdiv(q, a.fd_h), y = (int)q - b * a.H;
+        const int x0 = sx * WG_STRIP;
+        unsigned char* base = mine + buf * WG_BUF;
+        // g strip: pixels [x0, x0 + 64) of row y, 4 pieces of 16 pixels; lane = (pixel of 16, 16-byte chunk of its 64 bytes)
+        const uint32_t rowoff = (uint32_t)(((b * a.H + y) * a.W) * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = x0 + i * 16 + (lane >> 2);
+            const uint32_t v = px < a.W ? rowoff + (uint32_t)(px * 64 + (lane & 3) * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, (int)v, 0, 0, 0);
+        }
+        // x halo rows y-1, y, y+1: pixels [x0 - 1, x0 + 79) as 5 pieces (66 used); outside the image -> zeros
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            const bool rok = (unsigned)yy < (unsigned)a.H;
+            const uint32_t ro = (uint32_t)(((b * a.H + yy) * a.W) * 64);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int px = x0 - 1 + i * 16 + (lane >> 2);
+                const bool ok = rok && (unsigned)px < (unsigned)a.W && (i < 4 || (lane >> 2) < 2);
+                const uint32_t v = ok ? ro + (uint32_t)(px * 64 + (lane & 3) * 16) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(base + 4096 + r * WG_XROW + i * 1024), 16, (int)v, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int gq = lane >> 4, t16 = lane & 15;
+    // transposing read: a 16-lane group reads [4 pixels][16 channels]; lane -> (pixel t16 >> 2, channels 4 (t16 & 3) ..), and receives
+    // 4 pixels of ONE channel.  Fragment lane (channel = lane & 31, k half = lane >> 5): channels (gq & 1) * 16 + .., pixels (gq >> 1) * 8 + ..
+    const int choff = ((gq & 1) * 16 + 4 * (t16 & 3)) * 2, pixl = (gq >> 1) * 8 + (t16 >> 2);
+
+    int strip = gw, buf = 0;
+    if (strip < a.nstrips) issue(strip, 0);
+    for (; strip < a.nstrips; strip += nw) {
+        if (strip + nw < a.nstrips) {
+            issue(strip + nw, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(19)" ::: "memory");        // the 19 pieces of the next strip may stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char* gt = mine + buf * WG_BUF;
+        const unsigned char* xt = gt + 4096;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int pix = ks * 16 + pixl;
+            const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gt + pix * 64 + choff));
+            const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gt + (pix + 4) * 64 + choff));
+            const bf16x8 df = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, dx = t % 3;                       // halo row, pixel shift (halo pixel 0 = image pixel x0 - 1)
+                const unsigned char* xp = xt + r * WG_XROW + (pix + dx) * 64 + choff;
+                const s16x4 xlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)xp);
+                const s16x4 xhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp + 4 * 64));
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, xf, acc[t], 0, 0, 0);
+            }
+            acc[9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, ones, acc[9], 0, 0, 0);
+        }
+        buf ^= 1;
+        asm volatile("" ::: "memory");
+    }
+    // the block's four partials meet in LDS (the staging buffers are free now), wave 0 writes ONE [10][32 co][32 ci] partial per block:
+    // D row = co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = ci = lane & 31
+    __syncthreads();
+    float* red = (float*)wsm;
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave - 1) * 10240 + (t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.part + (int64_t)blockIdx.x * (10 * 1024);
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), o = (t * 16 + r) * 64 + lane;
+                out[t * 1024 + co * 32 + (lane & 31)] = (acc[t][r] + red[o]) + (red[10240 + o] + red[20480 + o]);
+            }
+    }
+}
+
+// dw[co][ci][ky][kx] (+)= sum of the partials' [tap][co][ci]; db[co] (+)= sum of [9][co][0]
+__global__ __launch_bounds__(256) void c32_wgrad_finish_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw,
+                                                               float* __restrict__ db, int co_n, int ci_n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // over [10][32][32]
+    if (i >= 10 * 1024) return;
+    const int t = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    if (t == 9 ? (ci != 0 || !db || co >= co_n) : (co >= co_n || ci >= ci_n)) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+        s0 += part[(int64_t)p * 10240 + i]; s1 += part[(int64_t)(p + 1) * 10240 + i];
+        s2 += part[(int64_t)(p + 2) * 10240 + i]; s3 += part[(int64_t)(p + 3) * 10240 + i];
+    }
+    for (; p < nparts; ++p) s0 += part[(int64_t)p * 10240 + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (t == 9) { db[co] = accumulate ? db[co] + s : s; return; }
+    float* d = dw + ((int64_t)co * ci_n + ci) * 9 + t;
+    *d = accumulate ? *d + s : s;
+}
+
+}  // namespace
+
+extern "C" int64_t hesic_conv3x3_c32_wgrad_ws_bytes(void) { return (int64_t)256 * 10 * 1024 * sizeof(float); }
+
+extern "C" int hesic_conv3x3_c32_wgrad(const void* x, const void* g, float* dw, float* dbias, int Cout, int Cin, int accumulate, void* ws,
+                                       int64_t ws_bytes, int B, int H, int W, void* stream) {
+    HESIC_CHECK_ARG(x && g && dw && ws && B > 0 && H > 0 && W > 0, "conv3x3_c32_wgrad: bad arguments");
+    HESIC_CHECK_ARG(Cout >= 1 && Cout <= 32 && Cin >= 1 && Cin <= 32, "conv3x3_c32_wgrad: 1 <= Cout, Cin <= 32 (x and g are 32-channel maps; narrower convs use their first channels)");
+    HESIC_CHECK_ARG((int64_t)B * H * W * 64 < (1ll << 31), "conv3x3_c32_wgrad: tensors too large for 32-bit offsets");
+    HESIC_CHECK_ARG(ws_bytes >= hesic_conv3x3_c32_wgrad_ws_bytes(), "conv3x3_c32_wgrad: workspace too small");
+    C32WgArgs a;
+    a.x = (const bf16_t*)x; a.g = (const bf16_t*)g; a.part = (float*)ws;
+    a.B = B; a.H = H; a.W = W; a.strips_x = (W + WG_STRIP - 1) / WG_STRIP;
+    const int64_t ns = (int64_t)a.strips_x * H * B;
+    HESIC_CHECK_ARG(ns < (1ll << 31), "conv3x3_c32_wgrad: too many strips");
+    a.nstrips = (int)ns;
+    a.fd_sx = make_fastdiv((uint32_t)a.strips_x); a.fd_h = make_fastdiv((uint32_t)H);
+    const int grid = (int)((ns + 3) / 4 < 256 ? (ns + 3) / 4 : 256);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)c32_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(c32_wgrad_kernel, dim3(grid), dim3(256), 4 * 2 * WG_BUF, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(c32_wgrad_finish_kernel, dim3(40), dim3(256), 0, (hipStream_t)stream, (const float*)ws, grid, dw, dbias, Cout, Cin, accumulate);
+    HESIC_LAUNCH_RETURN("conv3x3_c32_wgrad");
+}

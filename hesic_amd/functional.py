@@ -1058,6 +1058,117 @@ def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     return y
 
 
+EN_TRAIN_FAST = _os.environ.get("HESIC_EN_GENERIC") is None      # A/B switch
+
+
+def conv3x3_c32_train_ok(x, weight):
+    """Training form of the 32 -> 32 fast path: autograd on, bf16 storage (stage 2 trains the enhancement net with HSIC frozen,
+    newnet1.py:272-311, newtrain6_real.py)."""
+    return (EN_TRAIN_FAST and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == torch.bfloat16
+            and weight.shape[0] == 32 and weight.shape[1] <= 32 and tuple(weight.shape[2:]) == (3, 3) and weight.dtype == torch.float32
+            and _compute_dtype == torch.bfloat16)
+
+
+def conv3x3_c32_wgrad(x, g, weight, bias):
+    """(dw, dbias) of a 3x3 conv over 32-channel NHWC bf16 maps (``hesic_conv3x3_c32_wgrad``): ``x`` the layer input, ``g`` the gradient
+    w.r.t. conv + bias; ``weight`` (Cout <= 32, Cin <= 32, 3, 3) and ``bias`` only give shapes / flat gradient slots (with slots the
+    gradients are added in place and come back as None)."""
+    B, _, H, W = x.shape
+    cout, cin = weight.shape[0], weight.shape[1]
+    nws = int(L.lib().hesic_conv3x3_c32_wgrad_ws_bytes())
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    sw, sb = _slot_for(weight), (_slot_for(bias) if bias is not None else None)
+    if sw is not None and (bias is None or sb is not None):
+        L.call("hesic_conv3x3_c32_wgrad", L.ptr(x), L.ptr(g), L.ptr(sw.grad), L.ptr(None if bias is None else sb.grad), cout, cin, 1,
+               L.ptr(ws), nws, B, H, W, L.stream())
+        _slot_done(sw)
+        if bias is not None:
+            _slot_done(sb)
+        return None, None
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if bias is not None else None
+    L.call("hesic_conv3x3_c32_wgrad", L.ptr(x), L.ptr(g), L.ptr(dw), L.ptr(db), cout, cin, 0, L.ptr(ws), nws, B, H, W, L.stream())
+    return dw, db
+
+
+def _mirror_t(weight, pad_to=None):
+    """(Cout, Cin, 3, 3) -> the weight of the data-gradient conv: (Cin, Cout, 3, 3) with the taps mirrored, Cout zero-padded to ``pad_to``."""
+    wt = weight.detach().flip(2, 3).transpose(0, 1)
+    if pad_to is not None and wt.shape[1] < pad_to:
+        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, pad_to - wt.shape[1]))
+    return wt.contiguous()
+
+
+class _Conv3x3C32Fn(torch.autograd.Function):
+    """act(conv3x3(x) + bias) of the 32-channel enhancement layers under autograd, forward, data gradient AND weight gradient on kernels
+    built for the shape: dx = conv3x3(act'(y) * dy, W^T with the taps mirrored) is ``hesic_conv3x3_c32_forward`` on another weight tensor,
+    dW / dbias come from ``hesic_conv3x3_c32_wgrad`` (flat slots included).  ``weight`` may have fewer than 32 input channels (the
+    6 -> 32 input layer on the zero-padded image map: the kernel then sees the zero-padded weight).  Residual adds stay outside (the
+    activation's derivative needs the sign of the un-added output)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _nhwc(x)
+        w = weight.detach()
+        if w.shape[1] < 32:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 32 - w.shape[1]))
+        y = conv3x3_c32(x, w, bias, act=act)
+        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.act, ctx.bias = act, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y_act = ctx.saved_tensors
+        gy = _nhwc(gy.to(torch.bfloat16))
+        if ctx.act:
+            g = torch.empty_like(y_act)
+            L.call("hesic_act_backward", L.ptr(y_act), L.ptr(gy), L.ptr(g), y_act.numel(), ctx.act, L.dt(y_act), L.stream())
+        else:
+            g = gy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_c32(g, _mirror_t(weight, 32), None)          # (a narrower conv's extra input channels get zero gradient)
+        if ctx.needs_input_grad[1]:
+            dw, db = conv3x3_c32_wgrad(x, g, weight, ctx.bias)
+        return dx, dw, db, None
+
+
+class _Conv3x3C32OutFn(torch.autograd.Function):
+    """The 32 -> 3 output conv of ``Enhancement`` plus the image it refines (fp32 planar out) under autograd: the incoming gradient
+    goes into channels 0..2 of a zero-padded 32-channel map, after which data and weight gradient are the 32-channel kernels'."""
+
+    @staticmethod
+    def forward(ctx, t, weight, bias, image):
+        t = _nhwc(t)
+        y = conv3x3_c32(t, weight, bias, res1=image)
+        ctx.save_for_backward(t, weight)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, weight = ctx.saved_tensors
+        gy = gy.float().contiguous()
+        g32 = pack_images_c32(gy, torch.zeros_like(gy))
+        if weight.shape[0] != 3:
+            raise NotImplementedError("conv3x3_c32 output layer: 3 output channels")
+        dt = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dt = conv3x3_c32(g32, _mirror_t(weight, 32), None)
+        if ctx.needs_input_grad[1]:
+            dw, db = conv3x3_c32_wgrad(t, g32, weight, ctx.bias)
+        return dt, dw, db, (gy if ctx.needs_input_grad[3] else None)
+
+
+def conv3x3_c32_train(x, weight, bias, act=L.ACT_NONE, packer=None):
+    return _Conv3x3C32Fn.apply(x, weight, bias, act)
+
+
+def conv3x3_c32_out_train(t, weight, bias, image):
+    return _Conv3x3C32OutFn.apply(t, weight, bias, image)
+
+
 def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed=False, packer=None, gdn=None, gdn_on_input=False):
     """conv(torch.cat((xa, xb), 1)) (newnet1.py:643,686).  At inference the 6 -> 3 image-side stages read their two
     3-channel halves straight from the two tensors (``hesic_sconv2d_forward_cat``: no concatenated copy); otherwise the

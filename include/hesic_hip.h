@@ -375,6 +375,16 @@ int hesic_pooled_linear_backward(const float* pooled, const float* w, const floa
 int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,
                               const void* res2, void* y, int B, int H, int W, void* stream);
 
+/* Weight / bias gradient of the same convs (stage 2 trains the enhancement net with HSIC frozen: newnet1.py:272-311,
+ * ywz/mywork/newtrain6_real.py): x and g are 32-channel NHWC bf16 maps (B,H,W,32) -- the layer input and the gradient w.r.t.
+ * conv + bias (after the activation's derivative); dw is fp32 (Cout,Cin,3,3) with Cout, Cin <= 32 (a narrower conv -- the 6 -> 32
+ * input layer on the zero-padded image map, the 32 -> 3 output layer on a zero-padded gradient map -- takes the first channels),
+ * dbias fp32 (Cout) or NULL; accumulate != 0: dw += ..., dbias += ....  ws: hesic_conv3x3_c32_wgrad_ws_bytes() bytes of scratch.
+ * (The data gradient is hesic_conv3x3_c32_forward itself on the mirrored, transposed weight.)                              */
+int64_t hesic_conv3x3_c32_wgrad_ws_bytes(void);
+int hesic_conv3x3_c32_wgrad(const void* x, const void* g, float* dw, float* dbias, int Cout, int Cin, int accumulate, void* ws,
+                            int64_t ws_bytes, int B, int H, int W, void* stream);
+
 /* torch.cat((xa, xb), 1) of two fp32 planar (B,3,H,W) images (Enhancement.forward, newnet1.py:300) written as channels 0..5
  * of a zero-padded (B,H,W,32) bf16 NHWC map: the 6 -> 32 input conv then runs on hesic_conv3x3_c32_forward with its weight
  * zero-padded along Cin.                                                                                  */

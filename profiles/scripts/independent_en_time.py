@@ -26,3 +26,29 @@ with torch.no_grad():
     e1.record()
     torch.cuda.synchronize()
 print("Independent_EN B=8 512^2 bf16: %.2f ms/forward" % (e0.elapsed_time(e1) / 10))
+
+
+# stage-2 training step (HSIC frozen: only the enhancement net learns; newtrain6_real.py): forward + MSE backward + Adam
+net.train()
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+t1, t2 = x1.clone(), x2.clone()
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = net(x1, x2, Hm)
+    loss = ((out["x1_hat"].float() - t1) ** 2).mean() + ((out["x2_hat"].float() - t2) ** 2).mean()
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    step()
+e1.record()
+torch.cuda.synchronize()
+print("Independent_EN stage-2 training step B=8 512^2 bf16: %.2f ms/step (fast 32-channel path: %s)" % (e0.elapsed_time(e1) / 10, os.environ.get("HESIC_EN_GENERIC") is None))

@@ -766,3 +766,36 @@ def test_forward_edge_cases(kind):
         assert torch.equal(one["x2_hat"], exp["x2_hat"]) and torch.equal(one["y2_hat"], exp["y2_hat"])
         tiny = net(x1[:1, :, :, :64], x2[:1, :, :, :64], Hm[:1])              # 64 x 64: one z value per channel
         assert tiny["likelihoods"]["z1"].shape == (1, 128, 1, 1) and bool(torch.isfinite(tiny["x2_hat"]).all())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)], ids=["f32", "bf16"])
+def test_independent_en_training_gradients_match_oracle_autograd(dtype, tol):
+    """Stage 2 trains the enhancement net with HSIC frozen (newnet1.py:272-311, 1278-1300; newtrain6_real.py): the gradient of an MSE
+    loss w.r.t. every Independent_EN parameter on the HIP path -- bf16: forward and data gradients of the eighteen 32 -> 32 convs per
+    view on the register-resident-weight kernel -- against torch autograd through the CPU oracle."""
+    import hesic_amd
+    from hesic_amd import models
+    from oracle import hesic_oracle as O
+    from test_oracle_golden import _en_params
+    hesic_amd.set_compute_dtype(dtype)
+    P = _en_params()
+    net = models.Independent_EN()
+    net.load_state_dict(P, strict=True)
+    net = net.to(DEV).train()
+    x1, x2, Hm = synthetic.stereo_batch(5, 2, 64, 64)
+    t1, t2, _ = synthetic.stereo_batch(6, 2, 64, 64)
+    out = net(x1.to(DEV), x2.to(DEV), Hm.to(DEV))
+    loss = ((out["x1_hat"].float() - t1.to(DEV)) ** 2).mean() + ((out["x2_hat"].float() - t2.to(DEV)) ** 2).mean()
+    loss.backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = O.independent_en(Pr, x1, x2, Hm)
+    lref = ((ref["x1_hat"] - t1) ** 2).mean() + ((ref["x2_hat"] - t2) ** 2).mean()
+    lref.backward()
+    assert float(loss) == pytest.approx(float(lref), rel=tol)
+    bad = []
+    for name, p in net.named_parameters():
+        g, r = p.grad.float().cpu(), Pr[name].grad
+        rel = float((g - r).norm() / r.norm().clamp_min(1e-12))
+        if rel > tol:
+            bad.append((name, rel))
+    assert not bad, bad[:8]

@@ -955,3 +955,25 @@ def test_grouped_conv_matches_separate_convs(transposed):
             assert float(y9[:, 192:256].abs().max()) == 0            # pad couts: zero weights, zero bias, ReLU
     finally:
         torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 96), (1, 7, 50), (3, 16, 64)])
+def test_conv3x3_c32_weight_gradient_matches_autograd(shape):
+    """hesic_conv3x3_c32_wgrad (the stage-2 enhancement layers' weight / bias gradient) against torch autograd on the same bf16-rounded
+    operands, incl. strips that end inside an image row, an odd height and a narrower conv (6 input / 3 output channels)."""
+    from hesic_amd import functional as Fn
+    B, H, W = shape
+    g_ = torch.Generator().manual_seed(3)
+    x = (torch.rand(B, 32, H, W, generator=g_) - 0.5).bfloat16()
+    gy = (torch.rand(B, 32, H, W, generator=g_) - 0.5).bfloat16()
+    for cout, cin in ((32, 32), (32, 6), (3, 32)):
+        w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+        b = torch.zeros(cout, requires_grad=True)
+        y = torch.nn.functional.conv2d(x.float()[:, :cin], w, b, padding=1)
+        (y * gy.float()[:, :cout]).sum().backward()
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        gd = gy.to(DEV).contiguous(memory_format=torch.channels_last)
+        dw, db = Fn.conv3x3_c32_wgrad(xd, gd, w.detach().to(DEV), b.detach().to(DEV))
+        scale = float(w.grad.abs().max())
+        assert float((dw.cpu() - w.grad).abs().max()) <= 2e-3 * scale, (cout, cin)
+        torch.testing.assert_close(db.cpu(), b.grad, rtol=2e-3, atol=2e-3 * float(b.grad.abs().max()))
