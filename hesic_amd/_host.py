@@ -36,6 +36,7 @@ def lib():
         l.hesic_rc_decoder_new.restype = _vp
         l.hesic_rc_decoder_free.argtypes = [_vp]
         l.hesic_rc_decoder_decode.argtypes = [_vp, pu32, _i64, _i32, _pi32]
+        l.hesic_rc_decoder_decode_grid.argtypes = [_vp, pu32, _i64, _i64, _i64, _i64, _i32, _pi32]
         _lib = l
     return _lib
 
@@ -164,6 +165,17 @@ class RangeDecoder:
         if rc:
             raise ValueError("RangeDecoder.decode: bad table")
         return out
+
+    def decode_grid(self, cdf, n_outer, n_inner, row_step_outer, row_step_inner):
+        """Symbols (p, q), p outer, under table row ``p * row_step_outer + q * row_step_inner`` of ``cdf`` (rows, n): (n_outer, n_inner) int32."""
+        import numpy as np
+        cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        out = np.empty(n_outer * n_inner, dtype=np.int32)
+        rc = lib().hesic_rc_decoder_decode_grid(self._h, cdf.ctypes.data_as(C.POINTER(C.c_uint32)), n_outer, n_inner, row_step_outer,
+                                                row_step_inner, cdf.shape[1], out.ctypes.data_as(_pi32))
+        if rc:
+            raise ValueError("RangeDecoder.decode_grid: bad table")
+        return out.reshape(n_outer, n_inner)
 
     def __del__(self):
         try:

@@ -90,7 +90,7 @@ class EntropyModel(nn.Module):
             if means is None:
                 # round-half-even of the stored value: one elementwise kernel (the conditional kernel below would also evaluate a
                 # likelihood nobody reads, on a ones / zeros scale and mean map filled just for it)
-                return torch.round(inputs.detach())
+                return Fn.round_to(inputs, inputs.dtype)            # hesic_round: round-half-even, one launch
             sc = torch.ones_like(inputs)
             out, _ = Fn.gaussian_conditional(inputs.detach(), sc, None if means is None else means.detach().expand_as(inputs))
             return out

@@ -242,10 +242,15 @@ extern "C" hesic_rc_decoder* hesic_rc_decoder_new(const uint8_t* bytes, int64_t 
 }
 extern "C" void hesic_rc_decoder_free(hesic_rc_decoder* d) { delete d; }
 
-extern "C" int hesic_rc_decoder_decode(hesic_rc_decoder* d, const uint32_t* cdf, int64_t n, int32_t stride, int32_t* symbols_out) {
-    if (!d || !cdf || !symbols_out || n < 0 || stride < 2) return -1;
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t* c = cdf + i * stride;
+// Symbol (p, q), p outer, decoded under table row p * row_step_outer + q * row_step_inner: lets a decoder walk tables that lie in
+// another order than the stream (the HESIC+ wavefront decode gets them channel-major from the device and codes pixel-major)
+// without a host-side transpose.  hesic_rc_decoder_decode is the (n, 1) case.
+extern "C" int hesic_rc_decoder_decode_grid(hesic_rc_decoder* d, const uint32_t* cdf, int64_t n_outer, int64_t n_inner, int64_t row_step_outer,
+                                            int64_t row_step_inner, int32_t stride, int32_t* symbols_out) {
+    if (!d || !cdf || !symbols_out || n_outer < 0 || n_inner < 0 || stride < 2) return -1;
+    for (int64_t i = 0; i < n_outer * n_inner; ++i) {
+        const int64_t po = i / (n_inner > 0 ? n_inner : 1), qi = i - po * n_inner;
+        const uint32_t* c = cdf + (po * row_step_outer + qi * row_step_inner) * stride;
         const uint64_t tot = c[stride - 1];
         if (tot == 0 || tot >= RC_BOT) return -2;
         d->range /= tot;
@@ -267,4 +272,8 @@ extern "C" int hesic_rc_decoder_decode(hesic_rc_decoder* d, const uint32_t* cdf,
         }
     }
     return 0;
+}
+
+extern "C" int hesic_rc_decoder_decode(hesic_rc_decoder* d, const uint32_t* cdf, int64_t n, int32_t stride, int32_t* symbols_out) {
+    return hesic_rc_decoder_decode_grid(d, cdf, n, 1, 1, 0, stride, symbols_out);
 }

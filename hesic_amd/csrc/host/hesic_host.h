@@ -58,6 +58,9 @@ int64_t hesic_rc_encoder_finish(hesic_rc_encoder*, uint8_t* out, int64_t cap);
 hesic_rc_decoder* hesic_rc_decoder_new(const uint8_t* bytes, int64_t nbytes);     /* copies the stream */
 void hesic_rc_decoder_free(hesic_rc_decoder*);
 int hesic_rc_decoder_decode(hesic_rc_decoder*, const uint32_t* cdf, int64_t n, int32_t stride, int32_t* symbols_out);
+/* symbol (p, q), p outer, under table row p * row_step_outer + q * row_step_inner (tables in another order than the stream) */
+int hesic_rc_decoder_decode_grid(hesic_rc_decoder*, const uint32_t* cdf, int64_t n_outer, int64_t n_inner, int64_t row_step_outer,
+                                 int64_t row_step_inner, int32_t stride, int32_t* symbols_out);
 
 #ifdef __cplusplus
 }

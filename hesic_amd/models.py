@@ -1122,8 +1122,8 @@ class HSICJoint(StereoCompressionModel):
                 # (P, M, 1, 1) -> one image row of P pixels for the table kernel: the same P x M memory
                 sc_r, mu_r = (t.reshape(P, self.M).contiguous().t().reshape(1, self.M, 1, P) for t in (sc, mu))
                 cdf = Fn.gmm_cdf_tables(sc_r, mu_r, None, channels, minmax, 1, scale_bound=bound)               # (C, 1, P, n)
-                tab = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(P * len(channels), -1)
-                sym = dec.decode(np.ascontiguousarray(tab)).reshape(P, len(channels))
+                tab = cdf.cpu().numpy().view(np.uint32).reshape(len(channels) * P, -1)                 # channel-major rows, as the kernel wrote them
+                sym = dec.decode_grid(tab, P, len(channels), 1, P)                                       # pixel-major stream order, no host transpose
                 vals = torch.from_numpy(sym.astype(np.float32) - minmax).to(dev, cdt)
                 y_flat[centre_idx[pos:pos + P].unsqueeze(1), ch_t.unsqueeze(0)] = vals
                 pos += P
