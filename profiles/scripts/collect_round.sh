@@ -1,5 +1,5 @@
 set -x
-O=$GRAFT_REPO_ROOT/gpurun_out/r03a; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/${ROUND_TAG:-r03c}; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python bench.py --parity-trained 4 > $O/bench.json 2> $O/bench.err
 python bench.py --analysis bf16 > $O/bench_bf16.json 2>/dev/null
