@@ -1412,8 +1412,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         return 0;
     }
     a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
-    static const int chunk_major_env = getenv("HESIC_IGEMM_CHUNK_MAJOR") ? atoi(getenv("HESIC_IGEMM_CHUNK_MAJOR")) : -1;      // A/B switch: 0 off, 1 all parity walks
-    a.chunk_major = a.tap_parity && (chunk_major_env >= 0 ? chunk_major_env : hilo);
+    // A/B switch, OFF: 1 = the hi/lo parity walks, 2 = all parity walks.  It cuts the hi/lo launch's fetch traffic (800 -> 655 MB on the big
+    // layer) at equal time (343 vs 346 us), but the summation order then depends on the K step of the tile variant, and with it the last
+    // bit of y on the batch size (the tile choice follows the grid): pairs must not depend on what else is in the batch
+    static const int chunk_major_env = getenv("HESIC_IGEMM_CHUNK_MAJOR") ? atoi(getenv("HESIC_IGEMM_CHUNK_MAJOR")) : 0;
+    a.chunk_major = a.tap_parity && (chunk_major_env == 2 || (chunk_major_env == 1 && hilo));
     a.fd_nt = make_fastdiv((uint32_t)a.n_tiles); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     a.fd_b = make_fastdiv((uint32_t)a.B); a.fd_ph = make_fastdiv((uint32_t)a.nphase);
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
