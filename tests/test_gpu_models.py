@@ -743,11 +743,12 @@ def test_train_trace_256_matches_reference(kind):
 
 
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
-def test_forward_edge_cases(kind):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16x3"])
+def test_forward_edge_cases(kind, dtype):
     """Ragged / empty / strided inputs: sizes that are not multiples of 64 (the reference dies with a size mismatch deep inside,
     SURVEY.md 5), an empty batch and mismatched views raise up front; non-contiguous views of the images and a broadcast
     (1, 3, 3) homography give the result of their contiguous / expanded copies bit for bit; the smallest legal image works."""
-    net = build(kind)
+    net = build(kind, dtype)
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 2, 64, 128))
     with torch.no_grad():
         ref = net(x1, x2, Hm)
