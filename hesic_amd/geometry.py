@@ -16,6 +16,21 @@ from . import functional as Fn
 # HESIC_WARP_ALIGN_CORNERS=0) for them.  True = kornia >= 0.5 = cv2.warpPerspective.
 import os as _os
 DEFAULT_ALIGN_CORNERS = _os.environ.get("HESIC_WARP_ALIGN_CORNERS", "1") not in ("0", "false", "False")
+_CONVENTION_CHOSEN = "HESIC_WARP_ALIGN_CORNERS" in _os.environ      # True once the user has picked a convention (env or the call below)
+
+
+def use_reference_era_warp(enable=True):
+    """Pick the warp convention explicitly.  ``enable=True``: kornia <= 0.4.x sampling (``align_corners=False``) -- what checkpoints
+    trained in the reference's pinned environment (torch 1.6.0, ``pip install kornia`` of that time; Readme.md:11,16) were trained
+    with.  ``enable=False``: kornia >= 0.5 / cv2.warpPerspective (``align_corners=True``, this package's default).  Returns the
+    previous ``DEFAULT_ALIGN_CORNERS``."""
+    global DEFAULT_ALIGN_CORNERS, _CONVENTION_CHOSEN
+    prev, DEFAULT_ALIGN_CORNERS, _CONVENTION_CHOSEN = DEFAULT_ALIGN_CORNERS, not bool(enable), True
+    return prev
+
+
+def warp_convention():
+    return "kornia>=0.5 (align_corners=True)" if DEFAULT_ALIGN_CORNERS else "kornia<=0.4 (align_corners=False)"
 
 
 def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_corners=None, inverse_map=False):

@@ -184,6 +184,21 @@ class StereoCompressionModel(nn.Module):
             if isinstance(m, EntropyBottleneck):
                 m.update(force=force)
 
+    _warned_warp = False
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """``nn.Module.load_state_dict`` + one note, once per process, while no warp convention has been chosen: a checkpoint carries
+        no trace of the kornia release it was trained with, and the two conventions differ (``geometry.use_reference_era_warp``)."""
+        from . import geometry
+        if not geometry._CONVENTION_CHOSEN and not StereoCompressionModel._warned_warp:
+            import warnings
+            StereoCompressionModel._warned_warp = True
+            warnings.warn("hesic_amd: loading a checkpoint with the default warp convention " + geometry.warp_convention() + ". Checkpoints "
+                          "trained in the reference's pinned environment (torch 1.6 / kornia 0.4.x) expect align_corners=False: call "
+                          "hesic_amd.geometry.use_reference_era_warp() (or set HESIC_WARP_ALIGN_CORNERS=0) for them; "
+                          "use_reference_era_warp(False) keeps the default and silences this note.", stacklevel=2)
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
 
 # ------------------------------------------------------------------------------ analysis / synthesis
 class Encoder1(nn.Module):

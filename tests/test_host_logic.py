@@ -187,3 +187,29 @@ def test_geometry_point_transform():
     M = get_perspective_transform(src, dst)
     p = torch.cat([src[0], torch.ones(4, 1)], 1) @ M[0].T
     assert torch.allclose(p[:, :2] / p[:, 2:], dst[0], atol=1e-3)
+
+
+def test_loading_a_checkpoint_mentions_the_warp_convention_once():
+    """A checkpoint does not say which kornia release it was trained with; the two warp conventions differ.  While none has been chosen
+    explicitly, ``load_state_dict`` says so (once); choosing one silences it."""
+    import warnings
+    from hesic_amd import geometry, models
+    keep = (geometry.DEFAULT_ALIGN_CORNERS, geometry._CONVENTION_CHOSEN, models.StereoCompressionModel._warned_warp)
+    try:
+        geometry._CONVENTION_CHOSEN, models.StereoCompressionModel._warned_warp = False, False
+        net = models.HSIC()
+        sd = net.state_dict()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            net.load_state_dict(sd)
+            net.load_state_dict(sd)
+        assert sum("warp convention" in str(x.message) for x in w) == 1
+        prev = geometry.use_reference_era_warp()
+        assert prev is True and geometry.DEFAULT_ALIGN_CORNERS is False and "0.4" in geometry.warp_convention()
+        models.StereoCompressionModel._warned_warp = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            net.load_state_dict(sd)
+        assert not any("warp convention" in str(x.message) for x in w)
+    finally:
+        geometry.DEFAULT_ALIGN_CORNERS, geometry._CONVENTION_CHOSEN, models.StereoCompressionModel._warned_warp = keep
