@@ -977,3 +977,31 @@ def test_conv3x3_c32_weight_gradient_matches_autograd(shape):
         scale = float(w.grad.abs().max())
         assert float((dw.cpu() - w.grad).abs().max()) <= 2e-3 * scale, (cout, cin)
         torch.testing.assert_close(db.cpu(), b.grad, rtol=2e-3, atol=2e-3 * float(b.grad.abs().max()))
+
+
+def test_hilo_analysis_kernels_are_bit_stable_across_launches():
+    """The bf16x3 analysis stack (fused hi/lo conv1 + GDN with wave-private LDS staging, hi/lo implicit-GEMM layers with their GDN
+    epilogue, the fp32 + |y| pair outputs) launched 300 times with allocator churn in between: every launch bit-identical to the
+    first (the class of bug of the round-2 store hazard and of the staging reorder found while writing the hi/lo conv1 kernel)."""
+    Fn, O = _imp()
+    from hesic_amd import models
+    prev = Fn.compute_dtype()
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        enc = models.Encoder1(128, 192).to(DEV).eval()
+        synthetic.fill_state_dict_(enc.state_dict())
+        x = synthetic.stereo_batch(2, 2, 256, 320)[0].to(DEV)
+        with torch.no_grad():
+            lo0, y0 = enc.latent_hilo(x, True, True)
+            lo0, y0 = lo0.t.clone(), y0.clone()
+            bad = 0
+            for it in range(300):
+                if it % 7 == 0:
+                    junk = torch.full((1 << (10 + it % 13),), 1e30, device=DEV)
+                    del junk
+                lo, y = enc.latent_hilo(x, True, True)
+                bad += int(not (torch.equal(y, y0) and torch.equal(lo.t, lo0)))
+        assert bad == 0, bad
+        assert torch.equal(lo0[:, :192].float() + lo0[:, 192:].float() >= 0, torch.ones_like(y0, dtype=torch.bool))      # |y| pairs
+    finally:
+        Fn.set_compute_dtype(prev)
