@@ -1381,7 +1381,10 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     // step's 7 fused launches 132 vs 124 us -- no gain (one 8-wave block per CU marches through its barriers in lockstep and loses
     // the overlap two independent 4-wave blocks give), so it stays an A/B switch, off by default.
     static const int big = getenv("HESIC_IGEMM_BM256") ? atoi(getenv("HESIC_IGEMM_BM256")) : 0;      // A/B switch
-    static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 0;      // A/B switch for the hi/lo GDN form
+    // hi/lo GDN form, same box back to back (conv 128->128 s2 @256^2 B=8, graph replay): 128-pixel tile 339.8 us; 1 = 256 pixels, 8 waves
+    // of 64 x 64: 331.2 us; 2 = 256 pixels, 4 waves of 64 couts x 128 pixels (25 % fewer fragment bytes per MFMA, one wave per SIMD):
+    // 359.0 us -- fragment-read bandwidth is not what bounds the loop, a lone wave per SIMD just loses its latency cover
+    static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 0;      // A/B switch, off
     if (fast && (hilo ? (big_hl && gdn == 3) : big) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
@@ -1453,7 +1456,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
         if (bm == 256) {
             const dim3 block2(512);
-            if (hilo) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, block2, 0, st, a);
+            if (hilo && big_hl == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 4, 0, 1>), grid, block, 0, st, a);     // 4 waves of 64 couts x 128 pixels
+            else if (hilo) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, block2, 0, st, a);
             else if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 1, 8>), grid, block2, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 2, 8>), grid, block2, 0, st, a);
             else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 0, 8>), grid, block2, 0, st, a);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="input height = width of the layer")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dump", default="", help="save the layer output here (to compare A/B variants bit for bit)")
+    ap.add_argument("--hilo", action="store_true", help="the bf16x3 form of conv2 / conv3 / plain: hi/lo operand pairs, fused hi/lo GDN")
     ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph (no host launch cost in the figure)")
     args = ap.parse_args()
     import hesic_amd
@@ -36,6 +37,11 @@ def main():
         layer, g = deconv(128, 128).cuda(), GDN(128, inverse=True).cuda()
         flops = 2.0 * B * S * S * 128 * 128 * 25 + 2.0 * B * (2 * S) ** 2 * 128 * 128
     f = (lambda: layer.run(x)) if args.layer == "plain" else (lambda: layer.run_gdn(x, g))
+    if args.hilo:
+        xf = torch.randn(B, 128, S, S, device="cuda") * 0.5
+        hi = xf.to(torch.bfloat16)
+        xh = torch.cat((hi, (xf - hi.float()).to(torch.bfloat16)), 1).contiguous(memory_format=torch.channels_last)
+        f = (lambda: layer.run_hilo(xh, out="hilo")) if args.layer == "plain" else (lambda: layer.run_hilo(xh, gdn=g))
     with torch.no_grad():
         for _ in range(5):
             f()
@@ -65,7 +71,7 @@ def main():
         with torch.no_grad():
             torch.save(f().float().cpu(), args.dump)
     us = e0.elapsed_time(e1) / args.iters * 1e3
-    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   WS={os.environ.get('HESIC_IGEMM_WS', '0')} DBG={os.environ.get('HESIC_IGEMM_DBG', '0')}")
+    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   WS={os.environ.get('HESIC_IGEMM_WS', '0')} hilo={int(args.hilo)} BM256_HILO={os.environ.get('HESIC_IGEMM_BM256_HILO', '0')}")
 
 
 if __name__ == "__main__":
