@@ -1090,10 +1090,18 @@ __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float
 // LDS tiles, so no block barrier is needed inside the tile loop.
 __device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (slot ^ (row & 15))) * 16; }   // 256-byte rows
 
+// PAR = 1 (the default path): the parameter gradients ride on the same pass.  dgamma'[i][j] = sum_p dn[p][i] x[p][j]^2 is a third GEMM
+// with the PIXELS as K: both operands come out of the two LDS tiles through transposing reads
+// (ds_read_b64_tr_b16: lane = one channel, 4 consecutive pixels per read), 8 k-steps x 4 MFMAs per wave and tile into a 128 x 128 fp32
+// accumulator per block -- wave w owns columns 32 w .. 32 w + 31 (64 accumulation registers) and walks all 128 pixels of the tile, so the
+// tile loop gains two block barriers; dbeta'[i] = sum_p dn[p][i] is summed from the same A fragments.  The block writes ONE
+// (128 x 128 + 128) partial (`part`) at the end; dn never goes to HBM.  Before (round 2): dn written out (134 MB on a 256^2 map), read back with x by a 1-tap
+// launch of wgrad_tr_kernel cut into 256 pixel slices, whose 256 partial tiles a third launch reduced next to the column sums of dn.
+template <bool PAR>
 __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy,
                                                          const float* __restrict__ beta, const float* __restrict__ gamma,
-                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out, int64_t P,
-                                                         int inverse, float beta_bound) {
+                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out, float* __restrict__ part,
+                                                         int64_t P, int inverse, float beta_bound) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* gs = smem;                   // gamma'   [i][j]
     unsigned char* gt = smem + 32768;           // gamma'^T [j][i]
@@ -1112,13 +1120,8 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
         *(u32x4*)(gs + gb_off(row, slot)) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
         *(u32x4*)(gt + gb_off(row, slot)) = u32x4{pack_bf2(vt[0], vt[1]), pack_bf2(vt[2], vt[3]), pack_bf2(vt[4], vt[5]), pack_bf2(vt[6], vt[7])};
     }
-    float bv[4][4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[i][g][e] = reparam(beta[i * 32 + 8 * g + 4 * fh + e], beta_bound);
+    float* bl = (float*)(smem + 131072);        // beta' (read back per tile: 64 registers of a lone wave's budget go to the third GEMM)
+    if (tid < 128) bl[tid] = reparam(beta[tid], beta_bound);
     __syncthreads();
     const int64_t ntiles = (P + 127) / 128;
     const int r0 = wave * 32;                   // this wave's rows in both tiles
@@ -1138,6 +1141,14 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
         }
     };
     if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    f32x16 g3[4];                               // dgamma' partial of this block's pixels, columns 32 wave .. + 31: [i block]
+    float cs = 0.f;                             // dbeta' partial: channel 32 wave + (lane & 31), this lane's pixel halves
+    if constexpr (PAR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g3[j][r] = 0.f;
+    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t p0 = tile * 128 + r0;
         // wave-private 32 rows x 16 slots of x and gy: registers -> LDS, then the next tile's loads go out
@@ -1179,9 +1190,11 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
                 const float gv[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xffff0000u), __uint_as_float(gr.y << 16), __uint_as_float(gr.y & 0xffff0000u)};
                 float dn[4];
+                const f32x4 bq = *(const f32x4*)(bl + ch);
+                const float bvv[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float n = acc[i][4 * g + e] + bv[i][g][e];
+                    const float n = acc[i][4 * g + e] + bvv[e];
                     if (inverse) {
                         const float rs = rsqrtf(n);                   // one v_rsq instead of sqrt + division (outputs are bf16)
                         dn[e] = 0.5f * gv[e] * xv[e] * rs;
@@ -1209,6 +1222,43 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 s2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, df, s2[i], 0, 0, 0);
             }
         }
+        if constexpr (PAR) {
+            // GEMM3: A[i][p] = dn (ds tile), B[p][j] = x^2 (xs tile, still x here), K = the tile's 128 pixels; wave w owns the columns
+            // j = 32 w .. 32 w + 31 of the result.  It reads every wave's rows: a barrier after dn is complete, another one before the
+            // x tile turns into dx.  Rows past P are zero-filled on load (gy = 0 -> dn = 0): they add nothing.
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const int tg = lane >> 4, tt = lane & 15, wv = __builtin_amdgcn_readfirstlane(wave);
+            __syncthreads();
+#pragma unroll 2
+            for (int ks = 0; ks < 8; ++ks) {
+                const int pix = ks * 16 + (tg >> 1) * 8 + (tt >> 2);
+                auto tr = [&](const unsigned char* tile_, int cb, int px_) {
+                    const int ch = cb + (tg & 1) * 16 + 4 * (tt & 3);
+                    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile_ + gb_off(px_, ch >> 3) + (ch & 7) * 2));
+                };
+                // B: x^2 for the wave's own column block (squared once per block and element, not once per wave)
+                const s16x8 vx = __builtin_shufflevector(tr(xs, wv * 32, pix), tr(xs, wv * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                u32x4 ux = __builtin_bit_cast(u32x4, vx);
+                uint32_t* w4 = (uint32_t*)&ux;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
+                    w4[q] = pack_bf2(l2 * l2, h2 * h2);
+                }
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, ux);
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const s16x8 va = __builtin_shufflevector(tr(ds, ib * 32, pix), tr(ds, ib * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (ib == wv) {             // wave-uniform: the column sums of dn, each channel block by one wave
+                        const u32x4 ua = __builtin_bit_cast(u32x4, va);
+                        cs += ((__uint_as_float(ua.x << 16) + __uint_as_float(ua.x & 0xffff0000u)) + (__uint_as_float(ua.y << 16) + __uint_as_float(ua.y & 0xffff0000u))) +
+                              ((__uint_as_float(ua.z << 16) + __uint_as_float(ua.z & 0xffff0000u)) + (__uint_as_float(ua.w << 16) + __uint_as_float(ua.w & 0xffff0000u)));
+                    }
+                    g3[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), xf, g3[ib], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1228,9 +1278,18 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
             if (p0 + row < P) {
                 *(u32x4*)(dx + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(xs + gb_off(r0 + row, slot));
-                *(u32x4*)(dn_out + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(ds + gb_off(r0 + row, slot));
+                if constexpr (!PAR) *(u32x4*)(dn_out + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(ds + gb_off(r0 + row, slot));
             }
         }
+    }
+    if constexpr (PAR) {
+        float* out = part + (int64_t)blockIdx.x * (128 * 128 + 128);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 128 + wave * 32 + frow] = g3[ib][r];
+        cs += __shfl_xor(cs, 32);
+        if (fh == 0) out[128 * 128 + wave * 32 + frow] = cs;
     }
 }
 
@@ -1536,6 +1595,9 @@ extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) {
         fill_args(&d, a);
         const int64_t fast = P * 128 * 2 + 256 + (int64_t)a.nsplit * 128 * 128 * 4 + (128 * 128 + 128) * 4;
         if (fast > generic) generic = fast;
+        const int64_t tiles = (P + 127) / 128;
+        const int64_t fused = ((tiles < 256 ? tiles : 256) + 1) * (128 * 128 + 128) * 4;       // one partial per block + the reduced gradient
+        if (fused > generic) generic = fused;
     }
     return generic;
 }
@@ -1566,10 +1628,32 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         float* dgp = (float*)(base + off);
         float* dbp = dgp + 128 * 128;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            attr = true;
+        }
         const int64_t tiles = (P + 127) / 128;
-        hipLaunchKernelGGL(gdn128_bwd_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), 131072, st, (const bf16_t*)x,
-                           (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, P, inverse, bound);
+        const int nb = (int)(tiles < 256 ? tiles : 256);
+        static const bool split_params = getenv("HESIC_GDN_BWD_SPLIT") != nullptr;      // A/B switch: the three-launch form of round 2
+        if (!split_params) {
+            // one pass: dx + a (128 x 128 + 128) parameter-gradient partial per block, then the block partials summed in a fixed order
+            constexpr int NP = 128 * 128 + 128;
+            float* part = (float*)base;
+            float* dgp1 = part + (int64_t)nb * NP;          // dgamma' (128 x 128) followed by dbeta' (128)
+            hipLaunchKernelGGL(gdn128_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
+                               (bf16_t*)dx, (bf16_t*)nullptr, part, P, inverse, bound);
+            {
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            a.tap_id[0] = 0;
+            hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)(NP / 64)), dim3(256), 0, st, (const float*)part, dgp1, nb, 1, (int64_t)NP, a);
+            hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp1, dgp1 + 128 * 128, dgamma, dbeta, C, bound, accumulate);
+            HESIC_LAUNCH_RETURN("gdn_backward");
+        }
+        hipLaunchKernelGGL(gdn128_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
+                           (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, inverse, bound);
         {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
