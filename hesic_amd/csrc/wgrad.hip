@@ -1097,11 +1097,16 @@ __device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (s
 // tile loop gains two block barriers; dbeta'[i] = sum_p dn[p][i] is summed from the same A fragments.  The block writes ONE
 // (128 x 128 + 128) partial (`part`) at the end; dn never goes to HBM.  Before (round 2): dn written out (134 MB on a 256^2 map), read back with x by a 1-tap
 // launch of wgrad_tr_kernel cut into 256 pixel slices, whose 256 partial tiles a third launch reduced next to the column sums of dn.
-template <bool PAR>
+// The tile loop is ONE basic block: `inverse` is a template parameter, loads and stores are buffer-addressed (rows past P read zeros /
+// are dropped by the range check, no branches), so the compiler can count the outstanding memory operations exactly -- the loop top
+// waits for the next tile's loads only, not for the stores of the tile before (the branchy form waited vmcnt(0): a store round trip
+// per tile) -- and can batch the LDS reads of the epilogues across channel groups.
+template <bool PAR, bool INV>
 __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy,
                                                          const float* __restrict__ beta, const float* __restrict__ gamma,
                                                          bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out, float* __restrict__ part,
-                                                         int64_t P, int inverse, float beta_bound) {
+                                                         int64_t P, float beta_bound) {
+    constexpr bool inverse = INV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* gs = smem;                   // gamma'   [i][j]
     unsigned char* gt = smem + 32768;           // gamma'^T [j][i]
@@ -1128,19 +1133,27 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
     // 128 KB of LDS = one block (one wave per SIMD) per CU: nothing else hides the HBM latency, so the rows of tile t+1
     // are requested into registers before tile t is computed (64 VGPRs; the budget of a lone wave is 512)
     u32x4 px[8], pg[8];
+    const int nbytes = (int)(P * 256);          // P < 2^22 (host): 32-bit byte offsets
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dnr = __builtin_amdgcn_make_buffer_rsrc((void*)(PAR ? dx : dn_out), 0, nbytes, 0x00020000);
+    const int lofs = (r0 + (lane >> 4)) * 256 + (lane & 15) * 16;      // this lane's first row / slot, bytes
     auto fetch = [&](int64_t t) {
-        const int64_t q0 = t * 128 + r0;
+        const int o = (int)t * 32768 + lofs;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
-            px[it] = u32x4{0, 0, 0, 0}; pg[it] = u32x4{0, 0, 0, 0};
-            if (q0 + row < P) {
-                px[it] = *(const u32x4*)(x + (q0 + row) * 128 + slot * 8);
-                pg[it] = *(const u32x4*)(gy + (q0 + row) * 128 + slot * 8);
-            }
+            px[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + it * 1024, 0, 0);
+            pg[it] = __builtin_amdgcn_raw_buffer_load_b128(gr, o + it * 1024, 0, 0);
         }
     };
-    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    fetch(blockIdx.x);
+    // eight stores the range check drops: the loop is then entered with the same queue of memory operations its back edge carries
+    // (16 loads, then 8 stores), and the wait at its top can be "all but the last 8" instead of "everything" on both paths
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, dxr, nbytes + it * 1024 + lofs, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 g3[4];                               // dgamma' partial of this block's pixels, columns 32 wave .. + 31: [i block]
     float cs = 0.f;                             // dbeta' partial: channel 32 wave + (lane & 31), this lane's pixel halves
     if constexpr (PAR) {
@@ -1158,7 +1171,7 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             *(u32x4*)(xs + gb_off(r0 + row, slot)) = px[it];
             *(u32x4*)(ds + gb_off(r0 + row, slot)) = pg[it];
         }
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        fetch(tile + gridDim.x);                 // past the last tile: every offset out of range, zeros
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1196,11 +1209,11 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 for (int e = 0; e < 4; ++e) {
                     const float n = acc[i][4 * g + e] + bvv[e];
                     if (inverse) {
-                        const float rs = rsqrtf(n);                   // one v_rsq instead of sqrt + division (outputs are bf16)
+                        const float rs = __builtin_amdgcn_rsqf(n);    // one v_rsq instead of sqrt + division (outputs are bf16); n >= beta' > 0 is a normal number: no range scaling
                         dn[e] = 0.5f * gv[e] * xv[e] * rs;
                         acc[i][4 * g + e] = gv[e] * (n * rs);
                     } else {
-                        const float rs = rsqrtf(n);
+                        const float rs = __builtin_amdgcn_rsqf(n);
                         dn[e] = -0.5f * gv[e] * xv[e] * rs * rs * rs;
                         acc[i][4 * g + e] = gv[e] * rs;
                     }
@@ -1229,7 +1242,7 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const int tg = lane >> 4, tt = lane & 15, wv = __builtin_amdgcn_readfirstlane(wave);
             __syncthreads();
-#pragma unroll 2
+#pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int pix = ks * 16 + (tg >> 1) * 8 + (tt >> 2);
                 auto tr = [&](const unsigned char* tile_, int cb, int px_) {
@@ -1246,14 +1259,15 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                     w4[q] = pack_bf2(l2 * l2, h2 * h2);
                 }
                 const bf16x8 xf = __builtin_bit_cast(bf16x8, ux);
+                {   // the column sums of dn: channel block `wave` by this wave (its own pair of reads: no wave-dependent branch in the loop)
+                    const s16x8 vc = __builtin_shufflevector(tr(ds, wv * 32, pix), tr(ds, wv * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const u32x4 ua = __builtin_bit_cast(u32x4, vc);
+                    cs += ((__uint_as_float(ua.x << 16) + __uint_as_float(ua.x & 0xffff0000u)) + (__uint_as_float(ua.y << 16) + __uint_as_float(ua.y & 0xffff0000u))) +
+                          ((__uint_as_float(ua.z << 16) + __uint_as_float(ua.z & 0xffff0000u)) + (__uint_as_float(ua.w << 16) + __uint_as_float(ua.w & 0xffff0000u)));
+                }
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
                     const s16x8 va = __builtin_shufflevector(tr(ds, ib * 32, pix), tr(ds, ib * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (ib == wv) {             // wave-uniform: the column sums of dn, each channel block by one wave
-                        const u32x4 ua = __builtin_bit_cast(u32x4, va);
-                        cs += ((__uint_as_float(ua.x << 16) + __uint_as_float(ua.x & 0xffff0000u)) + (__uint_as_float(ua.y << 16) + __uint_as_float(ua.y & 0xffff0000u))) +
-                              ((__uint_as_float(ua.z << 16) + __uint_as_float(ua.z & 0xffff0000u)) + (__uint_as_float(ua.w << 16) + __uint_as_float(ua.w & 0xffff0000u)));
-                    }
                     g3[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), xf, g3[ib], 0, 0, 0);
                 }
             }
@@ -1273,13 +1287,12 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 *(u32x2*)(xs + off) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             }
         // wave-private copy-out of dx and dn (full 256-byte rows)
+        const int so = (int)tile * 32768 + lofs;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
-            if (p0 + row < P) {
-                *(u32x4*)(dx + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(xs + gb_off(r0 + row, slot));
-                if constexpr (!PAR) *(u32x4*)(dn_out + (p0 + row) * 128 + slot * 8) = *(const u32x4*)(ds + gb_off(r0 + row, slot));
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(xs + gb_off(r0 + row, slot)), dxr, so + it * 1024, 0, 0);
+            if constexpr (!PAR) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(ds + gb_off(r0 + row, slot)), dnr, so + it * 1024, 0, 0);
         }
     }
     if constexpr (PAR) {
@@ -1629,8 +1642,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         float* dbp = dgp + 128 * 128;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
-            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+            (void)hipFuncSetAttribute((const void*)gdn128_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
             attr = true;
         }
         const int64_t tiles = (P + 127) / 128;
@@ -1641,8 +1656,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             constexpr int NP = 128 * 128 + 128;
             float* part = (float*)base;
             float* dgp1 = part + (int64_t)nb * NP;          // dgamma' (128 x 128) followed by dbeta' (128)
-            hipLaunchKernelGGL(gdn128_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
-                               (bf16_t*)dx, (bf16_t*)nullptr, part, P, inverse, bound);
+            if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
+                                            (bf16_t*)dx, (bf16_t*)nullptr, part, P, bound);
+            else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
+                                    (bf16_t*)dx, (bf16_t*)nullptr, part, P, bound);
             {
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
@@ -1652,8 +1669,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp1, dgp1 + 128 * 128, dgamma, dbeta, C, bound, accumulate);
             HESIC_LAUNCH_RETURN("gdn_backward");
         }
-        hipLaunchKernelGGL(gdn128_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
-                           (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, inverse, bound);
+        if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<false, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
+                                        (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, bound);
+        else hipLaunchKernelGGL((gdn128_bwd_kernel<false, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
+                                (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, bound);
         {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
