@@ -1114,16 +1114,20 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
     unsigned char* ds = smem + 98304;           // gy tile  (becomes dn)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fh = lane >> 5;
+    // gamma' -> LDS in both orientations from ONE coalesced read: row-major 16-byte chunks as they come, the transpose as 2-byte scatters
+    // (the strided gather gamma[(8 slot + e) * 128 + row] this replaces -- 32 dependent 4-byte loads 512 bytes apart per thread -- was most
+    // of the ~10 us a launch spends outside its tiles)
     for (int c = tid; c < 128 * 16; c += 256) {
         const int row = c >> 4, slot = c & 15;
-        float v[8], vt[8];
+        const f32x4 a0 = *(const f32x4*)(gamma + row * 128 + slot * 8), a1 = *(const f32x4*)(gamma + row * 128 + slot * 8 + 4);
+        const float v[8] = {reparam(a0.x, kGammaBound), reparam(a0.y, kGammaBound), reparam(a0.z, kGammaBound), reparam(a0.w, kGammaBound),
+                            reparam(a1.x, kGammaBound), reparam(a1.y, kGammaBound), reparam(a1.z, kGammaBound), reparam(a1.w, kGammaBound)};
+        const u32x4 pk = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(gs + gb_off(row, slot)) = pk;
+        const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = reparam(gamma[row * 128 + slot * 8 + e], kGammaBound);
-            vt[e] = reparam(gamma[(slot * 8 + e) * 128 + row], kGammaBound);
-        }
-        *(u32x4*)(gs + gb_off(row, slot)) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *(u32x4*)(gt + gb_off(row, slot)) = u32x4{pack_bf2(vt[0], vt[1]), pack_bf2(vt[2], vt[3]), pack_bf2(vt[4], vt[5]), pack_bf2(vt[6], vt[7])};
+        for (int e = 0; e < 8; ++e)
+            *(bf16_t*)(gt + gb_off(slot * 8 + e, row >> 3) + (row & 7) * 2) = (bf16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
     }
     float* bl = (float*)(smem + 131072);        // beta' (read back per tile: 64 registers of a lone wave's budget go to the third GEMM)
     if (tid < 128) bl[tid] = reparam(beta[tid], beta_bound);
