@@ -1096,19 +1096,74 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const hesic_p
     const int co0 = (lb / tiles_ci) * 8, ci0 = (lb % tiles_ci) * 32;
     const int run = (j.transposed ? 8 : 32) * khw;              // consecutive source floats per outer index
     const int n_outer = j.transposed ? 32 : 8;
-    for (int e = threadIdx.x; e < 256 * khw; e += 256) {
-        const int ol = e / run, rem = e - ol * run;
-        const int il = rem / khw;
-        const int co = j.transposed ? co0 + il : co0 + ol, ci = j.transposed ? ci0 + ol : ci0 + il;
-        float v = 0.f;
-        if (ol < n_outer && co < j.Cout && ci < j.Cin) {
-            const int64_t src = j.transposed ? ((int64_t)ci * j.Cout + co0) * khw + rem : ((int64_t)co * j.Cin + ci0) * khw + rem;
-            v = j.w[src];
-            if (j.mask) v *= j.mask[src];
+    // (outer index, position inside its run of consecutive source floats): two nested loops, no division per element -- the flat form
+    // `e / run`, `rem / khw` with run-time divisors spent more issue cycles on the index split than on the move (172 us per step)
+    // Loads first, LDS stores after, sixteen loads in flight per lane: written as load-store pairs in a loop with run-time bounds the
+    // compiler issued them one by one, ~25 dependent HBM round trips per block (172 us per step for 108 MB).
+    auto row = [&](int ol, int64_t& base, int64_t& lim) {
+        const int co_o = j.transposed ? co0 : co0 + ol, ci_o = j.transposed ? ci0 + ol : ci0;
+        const bool outer_ok = j.transposed ? ci_o < j.Cin : co_o < j.Cout;
+        base = j.transposed ? ((int64_t)ci_o * j.Cout + co0) * khw : ((int64_t)co_o * j.Cin + ci0) * khw;
+        lim = outer_ok ? (j.transposed ? (int64_t)j.Cout - co0 : (int64_t)j.Cin - ci0) * khw : 0;       // floats of this run that exist
+    };
+    if (j.transposed) {                     // 32 runs of 8 * khw <= 200 floats: one load per lane and run
+        for (int o8 = 0; o8 < 32; o8 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                int64_t base, lim;
+                row(o8 + u, base, lim);
+                const int rem = threadIdx.x;
+                v[u] = 0.f;
+                if (rem < run && rem < lim) {
+                    v[u] = j.w[base + rem];
+                    if (j.mask) v[u] *= j.mask[base + rem];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((int)threadIdx.x < run) tile[(o8 + u) * run + threadIdx.x] = v[u];
         }
-        tile[e] = v;
+    } else {                                // 8 runs of 32 * khw <= 800 floats: four loads per lane and run, four runs at a time
+        for (int o2 = 0; o2 < 8; o2 += 4) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t base, lim;
+                row(o2 + u, base, lim);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rem = threadIdx.x + 256 * k;
+                    v[u][k] = 0.f;
+                    if (rem < run && rem < lim) {
+                        v[u][k] = j.w[base + rem];
+                        if (j.mask) v[u][k] *= j.mask[base + rem];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((int)threadIdx.x + 256 * k < run) tile[(o2 + u) * run + threadIdx.x + 256 * k] = v[u][k];
+        }
     }
     __syncthreads();
+    if (j.dtype == HESIC_BF16 && (j.Cin & 7) == 0) {
+        // bf16 destination: 8 cins = one 16-byte store per lane (2-byte stores moved 128 bytes per wave instruction: 175 us per step)
+        for (int o = threadIdx.x; o < 32 * khw; o += 256) {
+            const int t = o >> 5, cl = (o >> 2) & 7, il = (o & 3) * 8;    // tap, cout in tile, first of 8 cins in tile
+            const int co = co0 + cl, ci = ci0 + il;
+            if (co >= j.Cout || ci >= j.Cin) continue;
+            const int ts = j.flip ? khw - 1 - t : t;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = j.transposed ? tile[((il + e) * 8 + cl) * khw + ts] : tile[(cl * 32 + il + e) * khw + ts];
+            *(u32x4*)((bf16_t*)j.w_packed + ((int64_t)t * j.Cout + co) * j.Cin + ci) =
+                u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        }
+        return;
+    }
     for (int o = threadIdx.x; o < 256 * khw; o += 256) {
         const int t = o >> 8, cl = (o >> 5) & 7, il = o & 31;    // tap, cout in tile, cin in tile (fastest)
         const int co = co0 + cl, ci = ci0 + il;
