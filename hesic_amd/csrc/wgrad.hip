@@ -1082,6 +1082,43 @@ __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float
     }
 }
 
+// The fused GDN backward's last step: sum the <= 256 block partials of (dgamma' | dbeta') in a fixed order (16 lanes of 4 floats x 16 slice
+// groups per block, the groups meet in LDS: the shape of reduce_wide_body) and apply the reparametrisation chain on the way out --
+// gdn_bwd_chain_kernel folded in, one launch per GDN less.
+__global__ __launch_bounds__(256) void gdn_param_finish_kernel(const float* __restrict__ part, int nb, const float* __restrict__ beta,
+                                                               const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float beta_bound, int accumulate) {
+    constexpr int NP = 128 * 128 + 128;
+    __shared__ f32x4 red[16][16];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = (blockIdx.x * 16 + el) * 4;          // NP is a multiple of 64: every lane is in range
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int k = grp;
+    for (; k + 16 < nb; k += 32) {
+        s0 += *(const f32x4*)(part + (int64_t)k * NP + i);
+        s1 += *(const f32x4*)(part + (int64_t)(k + 16) * NP + i);
+    }
+    if (k < nb) s0 += *(const f32x4*)(part + (int64_t)k * NP + i);
+    red[grp][el] = s0 + s1;
+    __syncthreads();
+    if (grp == 0) {
+        f32x4 sum = red[0][el];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) sum += red[g][el];
+        const bool is_beta = i >= 128 * 128;
+        const float* th_p = is_beta ? beta + (i - 128 * 128) : gamma + i;
+        float* out = is_beta ? dbeta + (i - 128 * 128) : dgamma + i;
+        const float bound = is_beta ? beta_bound : kGammaBound;
+        const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {          // scalar accesses: parameters and gradient slots of a flat buffer are only 4-byte aligned
+            const float th = th_p[e], g = sv[e] * 2.f * fmaxf(th, bound);
+            const float v = (th >= bound || g < 0.f) ? g : 0.f;
+            out[e] = accumulate ? out[e] + v : v;
+        }
+    }
+}
+
 // ---- GDN backward, bf16 storage, C = 128: one pass over (x, gy) on the matrix cores.
 //   GEMM1  n = beta' + gamma' x^2          -> r = n^-1/2 | n^1/2,  t1 = g r,  dn = -1/2 g x r^3 | +1/2 g x / r
 //   GEMM2  s_j = sum_i gamma'[i,j] dn_i     -> dx = t1 + 2 x s
@@ -1167,7 +1204,6 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             for (int r = 0; r < 16; ++r) g3[j][r] = 0.f;
     }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t p0 = tile * 128 + r0;
         // wave-private 32 rows x 16 slots of x and gy: registers -> LDS, then the next tile's loads go out
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1659,7 +1695,6 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             // one pass: dx + a (128 x 128 + 128) parameter-gradient partial per block, then the block partials summed in a fixed order
             constexpr int NP = 128 * 128 + 128;
             float* part = (float*)base;
-            float* dgp1 = part + (int64_t)nb * NP;          // dgamma' (128 x 128) followed by dbeta' (128)
             if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
                                             (bf16_t*)dx, (bf16_t*)nullptr, part, P, bound);
             else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
@@ -1668,9 +1703,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
             }
-            a.tap_id[0] = 0;
-            hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)(NP / 64)), dim3(256), 0, st, (const float*)part, dgp1, nb, 1, (int64_t)NP, a);
-            hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp1, dgp1 + 128 * 128, dgamma, dbeta, C, bound, accumulate);
+            hipLaunchKernelGGL(gdn_param_finish_kernel, dim3((unsigned)(NP / 64)), dim3(256), 0, st, (const float*)part, nb, beta, gamma, dgamma, dbeta, bound, accumulate);
             HESIC_LAUNCH_RETURN("gdn_backward");
         }
         if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<false, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,

@@ -1272,7 +1272,8 @@ class GraphedForward:
                 self._run()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # "thread_local": a process group's watchdog thread may poll events while this thread captures (see train.GraphedTrainer)
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = self._run()
 
     def _run(self):

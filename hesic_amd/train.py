@@ -442,7 +442,12 @@ class GraphedTrainer(Trainer):
             return out
         if self.graph is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # The process group's watchdog thread polls the events of the warm-up steps' collectives; under the default ("global")
+            # capture mode such a query from ANOTHER thread while this one captures is an error that takes the process down
+            # ("operation not permitted when stream is capturing", seen with one RCCL rank).  Drain first, and confine the capture
+            # rules to this thread.
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._out = super().step(*self._in, noise=self._noise)
         self.graph.replay()
         # a replay runs no Python: the captured Adam kernels moved the parameters without touching their version counters, so

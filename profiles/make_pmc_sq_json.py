@@ -40,10 +40,14 @@ def main():
         if "SQ_BUSY_CYCLES" in mean and "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
             e["kernel_kcycles"] = round(mean["SQ_BUSY_CYCLES"] / 32 / 1e3, 1)
             e["mfma_busy_share_of_kernel_cycles"] = round((mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (mean["SQ_BUSY_CYCLES"] / 32), 4)
+        if mean.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in mean:       # SQ_INSTS_VALU counts the MFMAs too
+            e["non_mfma_valu_per_mfma"] = round((mean["SQ_INSTS_VALU"] - mean["SQ_INSTS_MFMA"]) / mean["SQ_INSTS_MFMA"], 3)
+            if "SQ_INSTS_SALU" in mean:
+                e["salu_per_mfma"] = round(mean["SQ_INSTS_SALU"] / mean["SQ_INSTS_MFMA"], 3)
         if "SQ_LDS_IDX_ACTIVE" in mean and "SQ_LDS_BANK_CONFLICT" in mean and mean["SQ_LDS_IDX_ACTIVE"]:
             e["lds_bank_conflict_share_of_lds_cycles"] = round(mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"], 4)
         res[k] = e
-    json.dump({"note": "rocprofv3 --pmc passes over HESIC_NO_OVERLAP=1 python profiles/scripts/forward_n.py hsic 3 (B=8, 512x512, bf16, one stream); "
+    json.dump({"note": "rocprofv3 --pmc passes over HESIC_NO_OVERLAP=1 python profiles/scripts/forward_n.py hsic N (B=8, 512x512, bf16 maps, default analysis mode, one stream); "
                        "see the docstring of profiles/make_pmc_sq_json.py for the units", "kernels": res}, open(out, "w"), indent=1)
     for k, e in sorted(res.items(), key=lambda kv: -kv[1]["mean_per_launch"].get("SQ_BUSY_CYCLES", 0))[:8]:
         print(k, json.dumps({x: e[x] for x in e if x != "mean_per_launch"}))
