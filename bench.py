@@ -311,6 +311,18 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
     return recs
 
 
+
+def emit_line(obj):
+    """The run's ONE JSON line, as the LAST thing on stdout: whatever native libraries have queued on the C stdio buffer (RCCL's
+    NCCL_DEBUG=VERSION banner, which this image exports) is flushed first, then the line, flushed."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(obj) + "\n")
+    sys.stdout.flush()
+
 def sweep_main(args, batch, rank, world, dev, H_img, W_img):
     """--sweep: BASELINE config C5.  Four lambda-models (four independent weight sets; there are no trained checkpoints
     offline, so four deterministic synthetic fills), InStereo2K-size pairs zero-padded to x64, reconstructions cropped, bpp
@@ -347,7 +359,7 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
     if rank == 0:
         pairs = world * args.batch * args.steps
         per = {lam: {"pairs": v["pairs"], "bpp": round(v["bpp"], 5), "psnr": round(v["psnr"], 4)} for lam, v in sweep.summary(H_img, W_img).items()}
-        print(json.dumps({
+        emit_line({
             "metric": "stereo-pairs/sec encode+decode @512x512; bpp & PSNR delta vs reference",
             "value": round(pairs / elapsed, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -356,7 +368,7 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
                                    f"{H_img}x{W_img} pairs (zero-padded to {x1p.shape[-2]}x{x1p.shape[-1]}, bpp over the original pixels), batch {args.batch}/GPU",
                        "pairs_per_step": world * args.batch, "sharding": f"one (lambda-model, batch) unit per rank and step over {world} GPU(s), no collective on the path",
                        "lambdas": list(SWEEP_LAMBDAS)},
-            "per_lambda": per, "roofline": None, "cpu_baseline": None}))
+            "per_lambda": per, "roofline": None, "cpu_baseline": None})
     if world > 1:
         dist.destroy_process_group()
 
@@ -466,7 +478,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
             res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        emit_line(res)
     if world > 1 or force:
         dist.destroy_process_group()
 
@@ -692,7 +704,7 @@ def main():
                                                           log=lambda t: print(t, file=sys.stderr, flush=True))
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        emit_line(res)
     if world > 1:
         dist.destroy_process_group()
 
