@@ -73,6 +73,8 @@ class ResidualBlock(nn.Module):
         """``outer_skip``: an extra tensor added to the result (the Enhancement_Block's ``+ x``, newnet1.py:286), fused
         into the last conv's epilogue on the 32-channel inference path."""
         if self.skip is None and Fn.conv3x3_c32_ok(x, self.conv1.weight) and Fn.conv3x3_c32_ok(x, self.conv2.weight):
+            if Fn.RESBLOCK_FUSED:       # both convs, the identity and the outer skip in one launch: the intermediate map stays on the CU
+                return Fn.resblock_c32(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY, res2=outer_skip)
             out = Fn.conv3x3_c32(x, self.conv1.weight, self.conv1.bias, act=L.ACT_LEAKY)
             return Fn.conv3x3_c32(out, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY, res1=x, res2=outer_skip)
         if self.skip is None and Fn.conv3x3_c32_train_ok(x, self.conv1.weight) and Fn.conv3x3_c32_train_ok(x, self.conv2.weight):

@@ -176,6 +176,213 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- a whole ResidualBlock per launch
+// leaky(conv2(leaky(conv1(x)))) + x (+ the Enhancement_Block's outer skip), compressai/layers/layers.py:125-147: the two launches of the
+// kernel above move 64 B in + 64 B out per pixel TWICE; here the intermediate map never leaves the CU.  One block of EIGHT waves per CU,
+// two roles, software-pipelined over the block's tiles:
+//   producer waves 0..3 (conv1 weights in registers): stage s evaluates conv1 on the (16+2) x (32+2) intermediate pixels of tile s from
+//     the (16+4) x (32+4)-pixel input halo in LDS -- 20 groups of 32 consecutive pixels of that region, 5 per wave; +20 % MFMAs for the
+//     ring that neighbouring tiles also compute -- and writes them (bias, LeakyReLU, bf16, ZERO outside the image: conv2 pads the
+//     intermediate map, not conv1's extrapolation) into intermediate halo s & 1, in the layout conv2's fragment reads expect;
+//   consumer waves 4..7 (conv2 weights): stage s runs conv2 of tile s - 1 from the other intermediate halo exactly like the single-layer
+//     kernel (output staging, identity and outer skip in the row-major view, 1 KB stores).
+// Every SIMD hosts one producer and one consumer wave, i.e. two different phases at any time (a first form with four waves doing both
+// convs in turn, one wave per SIMD, ran 270 us per block against 2 x 90 for the two launches; this one 178 us -- the same kernel time,
+// but half the launches: an eager Independent_EN forward at B=8 512x512 3.56 ms against 4.02).  Two block barriers per stage; 139.5 KB of
+// LDS.  Rounding points are those of the two-launch path (bf16 intermediate, fp32 accumulation in the same tap order): bit-identical.
+struct RBArgs {
+    const bf16_t* x; const float* w1; const float* b1; const float* w2; const float* b2; const void* res2; void* y;
+    int B, H, W, act, tiles_x, tiles_y;
+    FastDiv fd_tx, fd_ty;
+};
+
+constexpr int RB_IW = TW + 4, RB_IH = TH + 4, RB_IPIX = RB_IW * RB_IH;      // input halo: 20 x 36 pixels
+constexpr int RB_NPC = (RB_IPIX * 4 + 511) / 512;                            // 16-byte pieces per thread: 6
+constexpr int RB_MCH = (HPIX + 31) / 32;                                     // 32-pixel groups of the 18 x 34 intermediate region: 20
+constexpr int RB_LDS = RB_IPIX * 64 + 2 * HPIX * 64 + 4 * 32 * OPITCH * 4;
+
+template <bool RES2>
+__global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+    unsigned char* hin = rb_smem;                              // input halo, 64-byte pixels, chunk slot ^ ((pixel >> 2) & 3)
+    unsigned char* hmid0 = rb_smem + RB_IPIX * 64;             // two intermediate halos, same layout
+    float* ostage_all = (float*)(rb_smem + RB_IPIX * 64 + 2 * HPIX * 64);
+    constexpr uint32_t POISON = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, w4 = wave & 3;                 // 0: producer (conv1), 1: consumer (conv2)
+    const int p = lane & 31, h = lane >> 5;
+    bf16x8 wf[9][2];
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        float* wst = (float*)hin;                                // 32 x 289 floats = 37 KB <= the input halo buffer
+        const float* w = which ? a.w2 : a.w1;
+        for (int i = tid; i < 32 * 288; i += 512) {
+            const int co = i / 288, r = i - co * 288;
+            wst[co * 289 + r] = w[i];
+        }
+        __syncthreads();
+        if (role == which) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
+                    wf[t][k] = __builtin_bit_cast(bf16x8, u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+                }
+        }
+        __syncthreads();
+    }
+    float bv[4][4];
+    {
+        const float* bp = role ? a.b2 : a.b1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = bp ? bp[8 * j + 4 * h + e] : 0.f;
+    }
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    u32x4 pc[RB_NPC];
+    int cb = 0, cty = 0, ctx = 0;
+    auto request = [&](int tile) {
+        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
+        ctx = tile - (int)q * a.tiles_x;
+        cb = (int)fdiv(q, a.fd_ty);
+        cty = (int)q - cb * a.tiles_y;
+        const int y0 = cty * TH - 2, x0 = ctx * TW - 2;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)cb * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < RB_NPC; ++u) {
+            const int i = tid + 512 * u;
+            const int hp = i >> 2, slot = i & 3;
+            const int hy = hp / RB_IW, hx = hp - hy * RB_IW;
+            const int iy = y0 + hy, ix = x0 + hx;
+            const bool ok = hp < RB_IPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int chunk = slot ^ ((hp >> 2) & 3);
+            pc[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, 0, 0);
+        }
+    };
+    request((int)blockIdx.x);
+    int pb = 0, pty = 0, ptx = 0;          // tile of the previous stage (the consumer's)
+#pragma unroll 1
+    for (int s = 0; s <= n_my; ++s) {
+        const int b = cb, ty = cty, tx = ctx;                     // tile s, whose halo is in `pc`
+        if (s < n_my) {
+#pragma unroll
+            for (int u = 0; u < RB_NPC; ++u) {
+                const int i = tid + 512 * u;
+                if (i < RB_IPIX * 4) *(u32x4*)(hin + i * 16) = pc[u];
+            }
+        }
+        __syncthreads();
+        {   // unconditional (the old pieces are dead here); past the last tile the request repeats the last one
+            const int nt = (int)blockIdx.x + (s + 1 < n_my ? s + 1 : (n_my > 0 ? n_my - 1 : 0)) * (int)gridDim.x;
+            request(nt);
+        }
+        if (role == 0) {
+            if (s < n_my) {
+                unsigned char* hmid = hmid0 + (s & 1) * (HPIX * 64);
+#pragma unroll 1
+                for (int cc = 0; cc < RB_MCH / 4; ++cc) {
+                    const int m_raw = (w4 + 4 * cc) * 32 + p;
+                    const int m = m_raw < HPIX ? m_raw : HPIX - 1;
+                    const int mr = m / HW_, mc = m - mr * HW_;
+                    f32x16 acc, acc1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int hp = (mr + t / 3) * RB_IW + mc + t % 3;
+                        const unsigned char* row = hin + hp * 64;
+                        const int sw = (hp >> 2) & 3;
+                        const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+                    const int iy = ty * TH - 1 + mr, ix = tx * TW - 1 + mc;
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (m_raw < HPIX) {
+                        unsigned char* dst = hmid + m * 64 + 8 * h;
+                        const int sw = (m >> 2) & 3;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = inside ? apply_act(acc[4 * j + e] + bv[j][e], a.act) : 0.f;
+                            *(u32x2*)(dst + ((j ^ sw) << 4)) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        }
+                    }
+                }
+            }
+        } else if (s >= 1) {
+            const unsigned char* hmid = hmid0 + ((s - 1) & 1) * (HPIX * 64);
+#pragma unroll 1
+            for (int rq = 0; rq < TH / 4; ++rq) {
+                const int yl = w4 + 4 * rq;
+                const int y = pty * TH + yl;
+                const int rpx = lane >> 2, rch = lane & 3;
+                // identity and outer skip of this row group, requested in front of its MFMAs.  Measured alternatives, all SLOWER here (one
+                // block per CU: 256 registers per wave, and what they added spilled or cost its own round trip): the identity of all four
+                // row groups requested a stage ahead (202 us per launch against 178), bias re-read per stage from LDS, the outer skip one
+                // row group ahead (237 against 178 for the launches that carry one).
+                u32x4 r1v[2], r2v[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int xx = ptx * TW + rpx + 16 * it;
+                    const bool lv = y < a.H && xx < a.W;
+                    const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8;
+                    r1v[it] = lv ? *(const u32x4*)(a.x + o) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
+                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                }
+                f32x16 acc, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hp = (yl + t / 3) * HW_ + p + t % 3;
+                    const unsigned char* row = hmid + hp * 64;
+                    const int sw = (hp >> 2) & 3;
+                    const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+                float* os = ostage_all + w4 * (32 * OPITCH);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[4 * j + e] + bv[j][e], a.act);
+                    *(f32x4*)(os + p * OPITCH + 8 * j + 4 * h) = v;
+                }
+                // (wave-private slice: the LDS pipe keeps a wave's own writes and reads in order, no barrier)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = rpx + 16 * it, xx = ptx * TW + q;
+                    const f32x4 lo = *(const f32x4*)(os + q * OPITCH + rch * 8), hi = *(const f32x4*)(os + q * OPITCH + rch * 8 + 4);
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(ra[e] << 16) + __uint_as_float(rb[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(ra[e] & 0xffff0000u) + __uint_as_float(rb[e] & 0xffff0000u);
+                    }
+                    if (y < a.H && xx < a.W)
+                        *(u32x4*)((bf16_t*)a.y + (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8) =
+                            u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                }
+            }
+        }
+        __syncthreads();
+        pb = b; pty = ty; ptx = tx;
+    }
+}
+
 // cat(xa, xb) (two fp32 planar 3-channel images, newnet1.py:300) as channels 0..5 of a zero-padded 32-channel NHWC bf16 map:
 // the input of the 6 -> 32 conv in the layout of the kernel above.  One thread per pixel: six coalesced plane reads, one
 // 64-byte row out.
@@ -219,6 +426,30 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
     if (Cout == 32) hipLaunchKernelGGL(c32_conv3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(c32_conv3x3_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("conv3x3_c32_forward");
+}
+
+extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, int act,
+                                          const void* res2, void* y, int B, int H, int W, void* stream) {
+    HESIC_CHECK_ARG(x && w1 && w2 && y && B > 0 && H > 0 && W > 0, "resblock_c32_forward: bad arguments");
+    HESIC_CHECK_ARG(x != y, "resblock_c32_forward: in-place is not supported (neighbouring tiles read the input halo)");
+    HESIC_CHECK_ARG((int64_t)H * W * 64 < (1ll << 31), "resblock_c32_forward: image too large for 32-bit offsets");
+    RBArgs a;
+    a.x = (const bf16_t*)x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.res2 = res2; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.act = act;
+    a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+    a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
+    const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * B;
+    HESIC_CHECK_ARG(ntiles < (1ll << 31), "resblock_c32_forward: too many tiles");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
+        (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
+        attr = true;
+    }
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);          // persistent: one block per CU, both weight sets packed once per block
+    if (res2) hipLaunchKernelGGL(c32_resblock_kernel<true>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(c32_resblock_kernel<false>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("resblock_c32_forward");
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient, 32 channels

@@ -1058,6 +1058,23 @@ def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     return y
 
 
+RESBLOCK_FUSED = _os.environ.get("HESIC_EN_TWO_LAUNCH") is None      # A/B switch: unset = a ResidualBlock is ONE launch at inference
+
+
+def resblock_c32(x, w1, b1, w2, b2, act=L.ACT_LEAKY, res2=None):
+    """act(conv3x3(act(conv3x3(x, w1) + b1), w2) + b2) + x + res2 in one launch (``hesic_resblock_c32_forward``): the ResidualBlock of
+    the enhancement stage at inference (layers.py:125-147), x (B,32,H,W) bf16; bit-identical to two ``conv3x3_c32`` calls."""
+    L.require_cuda(x, w1, w2)
+    B, _, H, W = x.shape
+    x = _nhwc(x)
+    y = _empty_nhwc(B, 32, H, W, torch.bfloat16, x.device)
+    r2 = None if res2 is None else _nhwc(res2.to(torch.bfloat16))
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    L.call("hesic_resblock_c32_forward", L.ptr(x), L.ptr(f32(w1)), L.ptr(f32(b1)), L.ptr(f32(w2)), L.ptr(f32(b2)), int(act), L.ptr(r2), L.ptr(y),
+           B, H, W, L.stream())
+    return y
+
+
 EN_TRAIN_FAST = _os.environ.get("HESIC_EN_GENERIC") is None      # A/B switch
 
 

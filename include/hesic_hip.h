@@ -375,6 +375,14 @@ int hesic_pooled_linear_backward(const float* pooled, const float* w, const floa
 int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,
                               const void* res2, void* y, int B, int H, int W, void* stream);
 
+/* A whole ResidualBlock of that net in one launch (compressai/layers/layers.py:125-147 with in_ch == out_ch == 32, inference):
+ *   y = act(conv(act(conv(x, w1) + b1), w2) + b2) + x + res2
+ * x, y, res2 bf16 NHWC (B,H,W,32) (res2 may be NULL: the Enhancement_Block's outer skip, newnet1.py:286), w1 / w2 fp32 (32,32,3,3),
+ * b1 / b2 fp32 (32) or NULL.  The intermediate map stays in LDS; results are bit-identical to two hesic_conv3x3_c32_forward calls.
+ * y must not alias x.                                                                                          */
+int hesic_resblock_c32_forward(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, int act,
+                               const void* res2, void* y, int B, int H, int W, void* stream);
+
 /* Weight / bias gradient of the same convs (stage 2 trains the enhancement net with HSIC frozen: newnet1.py:272-311,
  * ywz/mywork/newtrain6_real.py): x and g are 32-channel NHWC bf16 maps (B,H,W,32) -- the layer input and the gradient w.r.t.
  * conv + bias (after the activation's derivative); dw is fp32 (Cout,Cin,3,3) with Cout, Cin <= 32 (a narrower conv -- the 6 -> 32

@@ -774,6 +774,38 @@ def test_conv3x3_c32_enhancement_kernel(hw):
     assert rel_err(y6, O.conv(bf(torch.cat((a6, b6), 1)), bf(w6), b, 1)) < 1e-2
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (37, 45), (16, 32), (5, 3), (50, 130), (96, 160)])
+@pytest.mark.parametrize("skip", [False, True])
+def test_resblock_c32_is_the_two_launch_path_bit_for_bit(hw, skip):
+    """hesic_resblock_c32_forward (a whole ResidualBlock of the enhancement stage per launch, layers.py:125-147): bit-identical to two
+    hesic_conv3x3_c32_forward launches (same rounding points: bf16 intermediate, fp32 accumulation in the same tap order) on sizes that
+    end in partial tiles and on single-tile images (every intermediate pixel of the ring outside the image must be ZERO, not conv1
+    evaluated there), and close to the oracle composition."""
+    Fn, O = _imp()
+    H, W = hw
+    x = bf(rnd(f"rb_x{hw}", (2, 32, H, W), -2, 2))
+    r2 = bf(rnd(f"rb_r2{hw}", (2, 32, H, W))) if skip else None
+    w1, w2 = rnd("rb_w1", (32, 32, 3, 3)) * 0.1, rnd("rb_w2", (32, 32, 3, 3)) * 0.1
+    b1, b2 = rnd("rb_b1", (32,), -0.2, 0.2), rnd("rb_b2", (32,), -0.2, 0.2)
+    leaky = torch.nn.functional.leaky_relu
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        xd = x.to(DEV, torch.bfloat16)
+        r2d = None if r2 is None else r2.to(DEV, torch.bfloat16)
+        with torch.no_grad():
+            mid = Fn.conv3x3_c32(xd, w1.to(DEV), b1.to(DEV), act=2)
+            two = Fn.conv3x3_c32(mid, w2.to(DEV), b2.to(DEV), act=2, res1=xd, res2=r2d)
+            one = Fn.resblock_c32(xd, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), act=2, res2=r2d)
+            nob = Fn.resblock_c32(xd, w1.to(DEV), None, w2.to(DEV), None, act=2, res2=r2d)
+            two_nob = Fn.conv3x3_c32(Fn.conv3x3_c32(xd, w1.to(DEV), None, act=2), w2.to(DEV), None, act=2, res1=xd, res2=r2d)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    assert one.dtype == torch.bfloat16 and one.shape == two.shape
+    assert torch.equal(one, two) and torch.equal(nob, two_nob)
+    ref = leaky(O.conv(bf(leaky(O.conv(x, bf(w1), b1, 1), 0.01)), bf(w2), b2, 1), 0.01) + x + (0 if r2 is None else r2)
+    assert rel_err(one, ref) < 1e-2
+
+
 # ------------------------------------------------------------------ fp32 latents of the bf16 mode (round 2)
 @pytest.mark.parametrize("shape,split", [((2, 128, 192, 5, 2, 64), False), ((2, 128, 128, 5, 2, 16), True), ((1, 128, 960, 5, 1, 32), False)],
                          ids=["conv4", "hyper_z_splitk", "sigma960"])
