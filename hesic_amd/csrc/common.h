@@ -63,10 +63,13 @@ __device__ __forceinline__ void st_any(void* p, int64_t i, int dtype, float v) {
     else ((float*)p)[i] = v;
 }
 
+// Branch-free on purpose: `act` is a launch parameter, and written as `if (act == ...) return ...` every ELEMENT of an epilogue became
+// its own chain of scalar compare-and-branch blocks (three branches per value, no scheduling across values).  Same results bit for
+// bit: NONE is v * 1, RELU yields +0 (not 0 * v = -0) for v <= 0 and for NaN, LEAKY 0.01f * v.
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == HESIC_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == HESIC_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
-    return v;
+    const float slope = act == HESIC_ACT_LEAKY ? 0.01f : 1.0f;
+    const float neg = act == HESIC_ACT_RELU ? 0.0f : v * slope;
+    return v > 0.f ? v : neg;
 }
 
 // division of a 31-bit unsigned by a launch-time constant without the ~20-instruction rcp sequence: q = (mulhi(n, magic) + n) >> shift
