@@ -24,7 +24,28 @@ constexpr int TH = 16, TW = 32, HW_ = TW + 2, HH = TH + 2, HPIX = HH * HW_;     
 
 constexpr int OPITCH = 36;       // floats per staged output pixel (32 + 4: bank spread)
 
-template <int MODE>      // 0: 32 couts, bf16 NHWC out (+ bf16 NHWC residuals); 1: <= 4 couts, fp32 planar out (+ fp32 planar residual)
+// Next-tile halo pieces through inline-asm buffer loads the compiler cannot see: tracked loads pending at the head of the row-group loop
+// (which has stores in it) made it flush them there -- `s_waitcnt vmcnt(0)` right behind the request, the whole round trip exposed once per
+// tile.  The pieces are waited for by hand at the top of the next tile (c32_wait_pieces: vmcnt(0) -- the younger stores of partial tiles
+// are predicated, their number is not a constant).
+__device__ __forceinline__ u32x4 c32_rsrc(const void* p) {
+    const uint64_t a_ = (uint64_t)p;
+    return u32x4{(uint32_t)a_, (uint32_t)(a_ >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
+}
+__device__ __forceinline__ void c32_load_piece(u32x4& dst, int off, const u32x4& rs) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(rs) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void c32_wait_pieces(u32x4 (&pc)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < N; ++u) asm volatile("" : "+v"(pc[u]));       // the values are defined from here on
+}
+
+// NRES (MODE 0): how many residual tensors the launch carries, at compile time -- with run-time null checks the row loop of a plain layer
+// still ended every row group in `s_waitcnt vmcnt(0)` (for loads it never issues), i.e. waited out the next tile's halo prefetch and
+// the previous row group's stores.
+template <int MODE, int NRES = 2>      // 0: 32 couts, bf16 NHWC out (+ bf16 NHWC residuals); 1: <= 4 couts, fp32 planar out (+ fp32 planar residual)
 __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char halo[HPIX * 64];
     __shared__ __attribute__((aligned(16))) float ostage[4][32 * OPITCH];        // per wave: 32 pixels x 32 couts fp32, padded rows
@@ -74,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
         cb = (int)fdiv(q, a.fd_ty);
         cty = (int)q - cb * a.tiles_y;
         const int y0 = cty * TH - 1, x0 = ctx * TW - 1;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)cb * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
+        const u32x4 xr = c32_rsrc(a.x + (int64_t)cb * a.H * a.W * 32);
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int i = tid + 256 * u;
@@ -83,20 +104,21 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             const int iy = y0 + hy, ix = x0 + hx;
             const bool ok = hp < HPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const int chunk = slot ^ ((hp >> 2) & 3);
-            pc[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, 0, 0);
+            c32_load_piece(pc[u], ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, xr);
         }
     };
     int tile = blockIdx.x;
-    if (tile < ntiles) request(tile);
+    request(tile < ntiles ? tile : 0);
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = cb, ty = cty, tx = ctx;                     // of the tile whose halo is in `pc`
+        c32_wait_pieces(pc);
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int i = tid + 256 * u;
             if (i < HPIX * 4) *(u32x4*)(halo + i * 16) = pc[u];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) request(tile + (int)gridDim.x);
+        request(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile);      // unconditional (asm outputs must be defined on every path)
 #pragma unroll 1
         for (int rq = 0; rq < TH / 4; ++rq) {
             const int yl = wave + 4 * rq;
@@ -115,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                     const int xx = tx * TW + rpx + 16 * it;
                     const bool lv = y < a.H && xx < a.W;
                     const int64_t o = (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8;
-                    r1v[it] = (a.res1 && lv) ? *(const u32x4*)((const bf16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
-                    r2v[it] = (a.res2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r1v[it] = (NRES >= 1 && lv) ? *(const u32x4*)((const bf16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r2v[it] = (NRES >= 2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
                 }
             } else {
 #pragma unroll
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
         cb = (int)fdiv(q, a.fd_ty);
         cty = (int)q - cb * a.tiles_y;
         const int y0 = cty * TH - 2, x0 = ctx * TW - 2;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)cb * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
+        const u32x4 xr = c32_rsrc(a.x + (int64_t)cb * a.H * a.W * 32);
 #pragma unroll
         for (int u = 0; u < RB_NPC; ++u) {
             const int i = tid + 512 * u;
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
             const int iy = y0 + hy, ix = x0 + hx;
             const bool ok = hp < RB_IPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const int chunk = slot ^ ((hp >> 2) & 3);
-            pc[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, 0, 0);
+            c32_load_piece(pc[u], ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, xr);
         }
     };
     request((int)blockIdx.x);
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
 #pragma unroll 1
     for (int s = 0; s <= n_my; ++s) {
         const int b = cb, ty = cty, tx = ctx;                     // tile s, whose halo is in `pc`
+        c32_wait_pieces(pc);
         if (s < n_my) {
 #pragma unroll
             for (int u = 0; u < RB_NPC; ++u) {
@@ -423,8 +446,12 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
     const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * B;
     HESIC_CHECK_ARG(ntiles < (1ll << 31), "conv3x3_c32_forward: too many tiles");
     const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);          // persistent: two blocks per CU, weights packed once per block
-    if (Cout == 32) hipLaunchKernelGGL(c32_conv3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(c32_conv3x3_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (Cout == 32) {
+        if (!a.res1 && a.res2) { a.res1 = a.res2; a.res2 = nullptr; }        // one residual: it is res1
+        if (a.res2) hipLaunchKernelGGL((c32_conv3x3_kernel<0, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        else if (a.res1) hipLaunchKernelGGL((c32_conv3x3_kernel<0, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((c32_conv3x3_kernel<0, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else hipLaunchKernelGGL((c32_conv3x3_kernel<1, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("conv3x3_c32_forward");
 }
 
