@@ -855,13 +855,14 @@ __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restri
 // 16 rows of the 16x64 LDS tile: per row and pair 5 shifted reads of S feed NA*5 FMAs.  Persistent blocks: the cross-lane
 // reduction and the atomics happen once per block.
 template <int NA, int NS_>
-__global__ __launch_bounds__(256) void sconv_wgrad_nn_kernel(const void* __restrict__ A, int a_dtype, int64_t as_b, int64_t as_c,
+__global__ __launch_bounds__(256, 2) void sconv_wgrad_nn_kernel(const void* __restrict__ A, int a_dtype, int64_t as_b, int64_t as_c,
                                                              int64_t as_y, int64_t as_x, const void* __restrict__ S, int s_dtype,
                                                              int64_t ss_b, int64_t ss_c, int64_t ss_y, int64_t ss_x,
                                                              float* __restrict__ dw, float* __restrict__ part, int a_major, int B, int H,
                                                              int W) {
     constexpr int TH = 16, TW = 64, PH = TH + 4, PW = TW + 4;
     constexpr int NP = NS_ * 5, NPW = (NP + 3) / 4;              // (s, ky) pairs, pairs per wave
+    constexpr int SB = NS_ > NA ? 4 : 8;                         // staging loads in flight per lane (the <3, 6> form has no registers for 8)
     __shared__ float at[NA * TH * TW];
     __shared__ float st[NS_ * PH * PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -877,16 +878,47 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nn_kernel(const void* __restr
     for (int64_t tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((int64_t)tiles_x * tiles_y);
         __syncthreads();
-        for (int i = tid; i < NA * TH * TW; i += 256) {
-            const int px = i % TW, py = (i / TW) % TH, c = i / (TW * TH);
-            const int y = ty * TH + py, x = tx * TW + px;
-            at[i] = (y < H && x < W) ? ld_any(A, b * as_b + c * as_c + (int64_t)y * as_y + (int64_t)x * as_x, a_dtype) : 0.f;
-        }
-        for (int i = tid; i < NS_ * PH * PW; i += 256) {
-            const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
-            const int y = ty * TH - 2 + py, x = tx * TW - 2 + px;
-            st[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ld_any(S, b * ss_b + c * ss_c + (int64_t)y * ss_y + (int64_t)x * ss_x, s_dtype) : 0.f;
-        }
+        // staging: SB loads in flight per lane, then the LDS stores (as load / store pairs in a loop the compiler issued them one by
+        // one: ~45 dependent memory round trips per tile, 150 us per launch for 75 MB); the storage type is chosen OUTSIDE the loops (a
+        // per-element dtype branch keeps the loads in separate basic blocks, i.e. serial again)
+        auto stage_a = [&](auto tag) {
+            using T = decltype(tag);
+            for (int i0 = 0; i0 < NA * TH * TW; i0 += 256 * SB) {
+                float v[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = i0 + tid + 256 * u;
+                    const int px = i % TW, py = (i / TW) % TH, c = i / (TW * TH);
+                    const int y = ty * TH + py, x = tx * TW + px;
+                    const bool ok = i < NA * TH * TW && y < H && x < W;
+                    v[u] = elem<T>::ld((const T*)A + (ok ? b * as_b + c * as_c + (int64_t)y * as_y + (int64_t)x * as_x : 0));
+                    v[u] = ok ? v[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u)
+                    if (i0 + tid + 256 * u < NA * TH * TW) at[i0 + tid + 256 * u] = v[u];
+            }
+        };
+        auto stage_s = [&](auto tag) {
+            using T = decltype(tag);
+            for (int i0 = 0; i0 < NS_ * PH * PW; i0 += 256 * SB) {
+                float v[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = i0 + tid + 256 * u;
+                    const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+                    const int y = ty * TH - 2 + py, x = tx * TW - 2 + px;
+                    const bool ok = i < NS_ * PH * PW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                    v[u] = elem<T>::ld((const T*)S + (ok ? b * ss_b + c * ss_c + (int64_t)y * ss_y + (int64_t)x * ss_x : 0));
+                    v[u] = ok ? v[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u)
+                    if (i0 + tid + 256 * u < NS_ * PH * PW) st[i0 + tid + 256 * u] = v[u];
+            }
+        };
+        if (a_dtype == HESIC_BF16) stage_a(bf16_t{}); else stage_a(float{});
+        if (s_dtype == HESIC_BF16) stage_s(bf16_t{}); else stage_s(float{});
         __syncthreads();
 #pragma unroll 2
         for (int r = 0; r < TH; ++r) {
