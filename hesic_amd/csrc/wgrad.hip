@@ -809,27 +809,36 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nw_kernel(const WT* __restric
 
 // MFMA route for the same gradient: materialise the narrow side's im2col matrix P[q][nc*25 + tap] (bf16, 96 columns, the
 // last 21 zero) and feed it with WIDE to the 1x1 weight-gradient kernel above: dW[wc][n] = sum_q WIDE[q][wc] P[q][n].
-__global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtype, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
-                                     bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
+// The eight gathers of a chunk are issued together: offsets clamped to element 0 for padding / unused columns and the value replaced by
+// zero afterwards, storage type chosen outside the loop (as nested `if`s around a per-element dtype switch every gather was a basic block of
+// its own: eight dependent round trips per chunk, 64 us per launch for 100 MB).
+template <typename T>
+__device__ __forceinline__ void im2col_narrow_body(const T* __restrict__ narrow, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
+                                                   bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
     const int64_t total = (int64_t)B * QH * QW * 12;          // 12 chunks of 8 columns per pixel
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ck = i % 12;
         const int64_t q = i / 12;
         const int qx = q % QW, qy = (q / QW) % QH, b = q / ((int64_t)QW * QH);
         float v[8];
+        bool ok[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int n = ck * 8 + e;
-            v[e] = 0.f;
-            if (n < NC * 25) {
-                const int nc = n / 25, tap = n % 25, ky = tap / 5, kx = tap % 5;
-                const int ny = 2 * qy - 2 + ky, nx = 2 * qx - 2 + kx;
-                if ((unsigned)ny < (unsigned)NH && (unsigned)nx < (unsigned)NW)
-                    v[e] = ld_any(narrow, b * ns_b + nc * ns_c + (int64_t)ny * ns_y + (int64_t)nx * ns_x, n_dtype);
-            }
+            const int nc = n / 25, tap = n % 25, ky = tap / 5, kx = tap % 5;
+            const int ny = 2 * qy - 2 + ky, nx = 2 * qx - 2 + kx;
+            ok[e] = n < NC * 25 && (unsigned)ny < (unsigned)NH && (unsigned)nx < (unsigned)NW;
+            v[e] = elem<T>::ld(narrow + (ok[e] ? b * ns_b + nc * ns_c + (int64_t)ny * ns_y + (int64_t)nx * ns_x : 0));
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ok[e] ? v[e] : 0.f;
         *(u32x4*)(P + q * 96 + ck * 8) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
     }
+}
+__global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtype, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
+                                     bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
+    if (n_dtype == HESIC_BF16) im2col_narrow_body<bf16_t>((const bf16_t*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
+    else im2col_narrow_body<float>((const float*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
 }
 // dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
 __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
