@@ -489,10 +489,12 @@ extern "C" int hesic_eb_prepare_params(const float* params, float* prepared, int
 extern "C" int hesic_eb_backward(const void* z, const float* params, const void* noise, const float* g_lik, const void* g_zhat,
                                  void* dz, float* dparams, int64_t P, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(z && params && g_lik && dz && dparams && P > 0 && C > 0, "eb_backward: bad arguments");
-    // every block ends in 59 atomics per channel on the gradient row; they serialise per address, so keep the number of
-    // pixel slices (= contenders per address) at 64
+    // every block ends in 59 atomics per channel on the gradient row, which serialise per address; fewer pixel slices mean fewer
+    // contenders but more serial pixels (~2000 flops each) per thread.  Sweep on the 8 x 8 hyper-latents of a training step (us per
+    // launch): 128 slices 111 | 64: 76 | 32: 70 | 16: 89 | 8: 147 | 4: 265
+    static const int max_slices = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
     const int64_t slices = (P + EB_PL - 1) / EB_PL;
-    const dim3 grid((unsigned)(slices < 64 ? slices : 64), (C + 63) / 64), block(64 * EB_PL);
+    const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + 63) / 64), block(64 * EB_PL);
     if (dtype == HESIC_BF16)
         hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)z, params,
                            (const bf16_t*)noise, g_lik, (const bf16_t*)g_zhat, (bf16_t*)dz, dparams, P, C);
