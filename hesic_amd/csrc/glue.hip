@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void spatial_max_split_kernel(const T* __restr
     }
 }
 
-// logits[b,n] = sum_j w[n,j] * pooled[b,j] + bias[n]: one wave per output
+// logits[b,n] = sum_j w[n,j] * pooled[b,j] + bias[n]: one wave per output.  (One wave per ROW n for all samples -- W read once instead of
+// B times -- leaves 960 waves with 15 serial steps each: 73 - 98 us against 35 - 46 us for this form at B = 8.)
 __global__ __launch_bounds__(256) void mix_logits_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ logits, int B, int N) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -425,10 +426,23 @@ __global__ void round_cast_kernel(const void* __restrict__ x, int xd, void* __re
         st_any(y, i, yd, rintf(ld_any(x, i, xd)));
 }
 
+// the case the inference schedule issues three times per forward (fp32 latent -> rounded bf16 copy): 8 values per thread
+__global__ void round_f32_to_bf16_v8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(x + i * 8), b = *(const f32x4*)(x + i * 8 + 4);
+        *(u32x4*)(y + i * 8) = u32x4{pack_bf2(rintf(a.x), rintf(a.y)), pack_bf2(rintf(a.z), rintf(a.w)), pack_bf2(rintf(b.x), rintf(b.y)),
+                                     pack_bf2(rintf(b.z), rintf(b.w))};
+    }
+}
+
 }  // namespace
 
 extern "C" int hesic_round(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream) {
     HESIC_CHECK_ARG(x && y && n > 0, "round: bad arguments");
+    if (x_dtype == HESIC_F32 && y_dtype == HESIC_BF16 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+        hipLaunchKernelGGL(round_f32_to_bf16_v8_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (bf16_t*)y, n / 8);
+        HESIC_LAUNCH_RETURN("round");
+    }
     hipLaunchKernelGGL(round_cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n);
     HESIC_LAUNCH_RETURN("round");
 }
@@ -504,8 +518,7 @@ extern "C" int hesic_mix_weights_forward(const float* pooled, const float* w, co
                                          int B, int K, int M, void* stream) {
     HESIC_CHECK_ARG(pooled && w && logits && weights && B > 0 && K > 0 && M > 0, "mix_weights_forward: bad arguments");
     const int N = K * M;
-    const int64_t waves = (int64_t)B * N;
-    hipLaunchKernelGGL(mix_logits_kernel, dim3((unsigned)cdiv64(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, pooled, w, bias, logits, B, N);
+    hipLaunchKernelGGL(mix_logits_kernel, dim3((unsigned)cdiv64((int64_t)B * N * 64, 256)), dim3(256), 0, (hipStream_t)stream, pooled, w, bias, logits, B, N);
     hipLaunchKernelGGL(softmax_k_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, weights, B, K, M);
     HESIC_LAUNCH_RETURN("mix_weights_forward");
 }
