@@ -662,11 +662,36 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinishArgs f, c
     const int tg = bid / f.tiles_co;
     const int t0 = tg * f.taps_per_group;
     const int tn = (t0 + f.taps_per_group <= f.ntaps ? f.taps_per_group : f.ntaps - t0);
+    const int64_t per_tap = (int64_t)f.Cout * f.Cin, n = (int64_t)f.ntaps * per_tap;
+    if ((f.Cin & 3) == 0) {
+        // 16-byte lanes: thread = (tap lane tq of 4, cout cl of 8, 4 consecutive cins), the K slices of its value all in flight at once --
+        // a quarter of the load instructions of the 4-byte form below for the same 128-byte row segments
+        const int tq = threadIdx.x >> 6, cl4 = (threadIdx.x >> 3) & 7, i4 = threadIdx.x & 7;
+        const int co4 = tco * 8 + cl4, ci4 = tci * 32 + i4 * 4;
+        const bool in4 = co4 < f.Cout && ci4 < f.Cin;
+        for (int tl = tq; tl < tn; tl += 4) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            if (in4) {
+                const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co4 * f.Cin + ci4;
+                int k = 0;
+                for (; k + 7 < f.nsplit; k += 8) {
+                    const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * n), a1 = *(const f32x4*)(src + (int64_t)(k + 1) * n);
+                    const f32x4 a2 = *(const f32x4*)(src + (int64_t)(k + 2) * n), a3 = *(const f32x4*)(src + (int64_t)(k + 3) * n);
+                    const f32x4 a4 = *(const f32x4*)(src + (int64_t)(k + 4) * n), a5 = *(const f32x4*)(src + (int64_t)(k + 5) * n);
+                    const f32x4 a6 = *(const f32x4*)(src + (int64_t)(k + 6) * n), a7 = *(const f32x4*)(src + (int64_t)(k + 7) * n);
+                    s0 += a0; s1 += a1; s0 += a2; s1 += a3; s0 += a4; s1 += a5; s0 += a6; s1 += a7;
+                }
+                for (; k < f.nsplit; ++k) s0 += *(const f32x4*)(src + (int64_t)k * n);
+            }
+            const f32x4 sv = s0 + s1;
+            float* d = scratch + tl * 257 + cl4 * 32 + i4 * 4;
+            d[0] = sv.x; d[1] = sv.y; d[2] = sv.z; d[3] = sv.w;
+        }
+    }
     const int cl = threadIdx.x >> 5, il = threadIdx.x & 31;
     const int co = tco * 8 + cl, ci = tci * 32 + il;
-    const int64_t per_tap = (int64_t)f.Cout * f.Cin, n = (int64_t)f.ntaps * per_tap;
     const bool in = co < f.Cout && ci < f.Cin;
-    for (int tl = 0; tl < tn; ++tl) {
+    for (int tl = 0; tl < ((f.Cin & 3) == 0 ? 0 : tn); ++tl) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (in) {
             const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co * f.Cin + ci;
