@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                 launches / their summed HIP-event durations, measured live on the launch stream
   cpu_baseline  the CPU oracle (a port of the reference's forward, oracle/hesic_oracle.py) timed on this box's host
                 cores on a bounded sample of the same workload (rank 0, N=1 only)
-  parity        |bpp - bpp_oracle|, |PSNR - PSNR_oracle| of the first pair: bf16 GPU path vs fp32 CPU oracle
+  parity        |bpp - bpp_oracle|, |PSNR - PSNR_oracle| averaged over the distinct pairs of the batch (and per pair): bf16 GPU path vs fp32 CPU oracle
 """
 import argparse
 import json
@@ -221,7 +221,7 @@ def cpu_train_baseline(kind, P_cpu, param_names, size, lmbda, budget_s=15.0):
                       f"{torch.get_num_threads()} of {cores} host cores"}
 
 
-def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
+def cpu_baseline(kind, P_cpu, size, budget_s=12.0, parity_pairs=1):
     from hesic_amd import synthetic
     from oracle import hesic_oracle as O
     fwd = O.hsic_forward if kind == "hsic" else O.hsic_joint_forward
@@ -252,6 +252,16 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0):
                 break
     m = O.metrics(out, x1, x2)
     m["y_hat"] = {k: out[k].to(torch.int16) for k in ("y1_hat", "y2_hat")}      # rounded latents of the sample: the bit-exactness check
+    # the other distinct pairs of the timed batch (it tiles four): the parity block reports the set average the reference's own
+    # evaluation reports (test3real.py:110-122) next to every pair
+    m["more"] = []
+    for j in range(1, parity_pairs):
+        xa, xb, hh = synthetic.stereo_batch(j, 1, size, size)
+        with torch.no_grad():
+            oj = fwd(P_cpu, xa, xb, hh)
+        mj = O.metrics(oj, xa, xb)
+        mj["y_hat"] = {k: oj[k].to(torch.int16) for k in ("y1_hat", "y2_hat")}
+        m["more"].append(mj)
     return {"value": n / el, "unit": "stereo-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} x (1 pair {size}x{size}, fp32, torch CPU ops) after 1 warm-up, {el:.1f} s; threads calibrated "
                       f"over 8/16/32/64 of {cores} host cores"}, m
@@ -681,24 +691,42 @@ def main():
             "gpu_metrics_last_batch": {"bpp": round(m_gpu["bpp"], 5), "psnr": round(m_gpu["psnr"], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, m_cpu = cpu_baseline(args.model, P_cpu, args.size if not (args.height or args.width) else 512)
+            square = not (args.height or args.width)
+            npar = min(4, args.batch) if square else 1          # the timed batch tiles min(batch, 4) distinct pairs
+            base, m_cpu = cpu_baseline(args.model, P_cpu, args.size if square else 512, parity_pairs=npar)
             res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
-            with torch.no_grad():
-                xa, xb, hh = (t.to(dev) for t in synthetic.stereo_batch(0, 1, 512, 512)) if (args.height or args.width) else (x1[:1], x2[:1], Hm[:1])
-                o1 = net(xa, xb, hh)
-                m1 = models.metrics_from(models.rate_distortion(o1, xa, xb))
-            flips = {k: float((o1[k].float().cpu().to(torch.int16) != v).float().mean()) for k, v in m_cpu["y_hat"].items()}
-            dbpp, dpsnr = abs(m1["bpp"] - m_cpu["bpp"]), abs(m1["psnr"] - m_cpu["psnr"])
-            res["parity"] = {"abs_dbpp": round(dbpp, 6), "rel_dbpp": round(dbpp / m_cpu["bpp"], 6), "abs_dpsnr_db": round(dpsnr, 6),
-                             "bpp_oracle": round(m_cpu["bpp"], 5), "psnr_oracle": round(m_cpu["psnr"], 4),
+            per_pair = []
+            for j, mc in enumerate([m_cpu] + m_cpu["more"]):
+                with torch.no_grad():
+                    xa, xb, hh = (t.to(dev) for t in synthetic.stereo_batch(j, 1, 512, 512)) if not square else (x1[j:j + 1], x2[j:j + 1], Hm[j:j + 1])
+                    oj = net(xa, xb, hh)
+                    mj = models.metrics_from(models.rate_distortion(oj, xa, xb))
+                fl = {k: float((oj[k].float().cpu().to(torch.int16) != v).float().mean()) for k, v in mc["y_hat"].items()}
+                per_pair.append({"dbpp": mj["bpp"] - mc["bpp"], "dpsnr": mj["psnr"] - mc["psnr"], "flips": fl, "bpp": mc["bpp"], "psnr": mc["psnr"]})
+            # the set average is what the reference's evaluation reports (test3real.py:110-122: bpp and PSNR averaged over the pairs);
+            # pair 0 alone (the figure of rounds 1-3 so far) and the worst pair stand next to it
+            dbpp = abs(sum(q["dbpp"] for q in per_pair) / len(per_pair))
+            dpsnr = abs(sum(q["dpsnr"] for q in per_pair) / len(per_pair))
+            bpp_o = sum(q["bpp"] for q in per_pair) / len(per_pair)
+            flips = {k: max(q["flips"][k] for q in per_pair) for k in per_pair[0]["flips"]}
+            worst_dbpp, worst_dpsnr = max(abs(q["dbpp"]) for q in per_pair), max(abs(q["dpsnr"]) for q in per_pair)
+            res["parity"] = {"abs_dbpp": round(dbpp, 6), "rel_dbpp": round(dbpp / bpp_o, 6), "abs_dpsnr_db": round(dpsnr, 6),
+                             "pairs": len(per_pair),
+                             "pair0": {"abs_dbpp": round(abs(per_pair[0]["dbpp"]), 6), "abs_dpsnr_db": round(abs(per_pair[0]["dpsnr"]), 6)},
+                             "worst_pair": {"abs_dbpp": round(worst_dbpp, 6), "abs_dpsnr_db": round(worst_dpsnr, 6)},
+                             "per_pair_dbpp": [round(q["dbpp"], 6) for q in per_pair], "per_pair_dpsnr_db": [round(q["dpsnr"], 6) for q in per_pair],
+                             "bpp_oracle": round(bpp_o, 5), "psnr_oracle": round(sum(q["psnr"] for q in per_pair) / len(per_pair), 4),
                              "latent_flips": {k: round(v, 6) for k, v in flips.items()},
                              "bars": {"latent_flips": 1e-3, "abs_dpsnr_db": 1e-3, "abs_dbpp": 1e-3, "rel_dbpp": 1e-3},
                              "met": {"latent_flips": bool(max(flips.values()) <= 1e-3), "abs_dpsnr_db": bool(dpsnr < 1e-3),
-                                     "abs_dbpp": bool(dbpp < 1e-3), "rel_dbpp": bool(dbpp < 1e-3 * m_cpu["bpp"])},
+                                     "abs_dbpp": bool(dbpp < 1e-3), "rel_dbpp": bool(dbpp < 1e-3 * bpp_o),
+                                     "abs_dbpp_every_pair": bool(worst_dbpp < 1e-3), "abs_dpsnr_db_every_pair": bool(worst_dpsnr < 1e-3)},
                              "analysis": Fn.analysis_precision() if args.dtype == "bf16" else "fp32",
                              "latents": "fp32 (y, z, sigma, mu from the fp32 accumulators)" if (args.dtype == "f32" or Fn.FP32_LATENTS) else "bf16",
-                             "note": f"{args.dtype} GPU path vs fp32 CPU oracle, pair 0 of the timed workload, random-init-shaped weights (bpp ~5.5: the "
-                                     "absolute bpp bar is 1.8e-4 RELATIVE here); --parity-trained adds trained operating points"}
+                             "note": f"{args.dtype} GPU path vs fp32 CPU oracle on the {len(per_pair)} distinct pair(s) of the timed workload, random-init-shaped "
+                                     "weights (bpp ~5.5: the absolute bpp bar is 1.8e-4 RELATIVE here).  abs_* = |mean over the pairs| (the reference "
+                                     "reports set averages), latent_flips = the worst pair; pair0 / worst_pair / per_pair_* give every pair; "
+                                     "--parity-trained adds trained operating points"}
             if args.parity_trained > 0:
                 res["parity"]["trained"] = trained_parity(args.model, args.parity_trained, args.parity_train_steps, 512, lmbda=args.lmbda,
                                                           log=lambda t: print(t, file=sys.stderr, flush=True))
