@@ -1426,7 +1426,10 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zer
 int pick_splits(int64_t Q, int bk, int tiles) {
     // aim at ~384 blocks (measured best on MI355X for the step as a whole: every extra slice is another fp32 partial tile
     // to write and reduce), at least 4 K-steps per block
-    static const int target = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
+    static const int target0 = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
+    // A/B: another target for the layers with Q >= 100000 pixels (measured on the training step, ms: off 10.77 | 448: 10.70 | 512: 11.01 | 640: 10.91 -- noise level, off)
+    static const int big_target = getenv("HESIC_WGRAD_BLOCKS_BIG") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG")) : 0;
+    const int target = (big_target && Q >= 100000) ? big_target : target0;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
     if (s > maxs) s = maxs;
