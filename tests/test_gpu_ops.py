@@ -436,6 +436,23 @@ def test_gaussian_conditional_golden(ops_golden):
     torch.testing.assert_close(lik2.cpu().contiguous(), T(g["gc_eval_lik"]), rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize("cz,cy", [(128, 192), (12, 20)], ids=["vector", "scalar"])
+def test_hyper_glue_bf16_vector_and_scalar_forms(cz, cy):
+    """upsample4 / upsample4_cat / round_to in bf16: channel counts that are multiples of 8 take the 16-byte vector kernels (the inference
+    schedule's case), others the element-wise ones; both against the oracle on the bf16-rounded input, the copied half and the rounding exact."""
+    Fn, O = _imp()
+    z, y1 = bf(rnd("hgv_z", (2, cz, 6, 5), -2, 2)), bf(rnd("hgv_y", (2, cy, 24, 20), -8, 8))
+    ref = O.upsample_bilinear_x4(z)
+    with torch.no_grad():
+        up = Fn.upsample4(z.to(DEV, torch.bfloat16))
+        cat = Fn.upsample4_cat(z.to(DEV, torch.bfloat16), y1.to(DEV, torch.bfloat16))
+    assert up.dtype == torch.bfloat16 and rel_err(up, ref) < 4e-3                       # one bf16 rounding of the interpolated value
+    assert torch.equal(cat[:, :cz].float().cpu(), up.float().cpu()) and torch.equal(cat[:, cz:].float().cpu(), y1)
+    v = rnd("hgv_r", (2, cy, 8, 8 if cy % 8 == 0 else 7), -6, 6)
+    r = Fn.round_to(v.to(DEV), torch.bfloat16)
+    assert r.dtype == torch.bfloat16 and torch.equal(r.float().cpu(), torch.round(v))
+
+
 def test_hyper_glue(ops_golden):
     Fn, O = _imp()
     g = ops_golden
