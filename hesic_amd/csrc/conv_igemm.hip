@@ -1016,6 +1016,310 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     }
 }
 
+// ------------------------------------------------------------------------- transposed stride-2 conv: the four output phases in ONE block
+// deconv() (compressai/models/utils.py:112-118) on the big maps of g_s (ywz/mywork/newnet1.py:603-624) and the data gradient of the
+// stride-2 analysis convs.  igemm_glds_kernel runs a transposed layer as 4 x tiles blocks of 18 / 12 / 12 / 8 K stages (9 / 6 / 6 / 4 taps
+// x 2 channel chunks): per block ~6 us of fixed cost (launch, tile decode, pipeline fill, epilogue, the store drain in front of the exit)
+// on ~15 us of K loop.  Here a block keeps its 128 q-pixels x 128 couts and walks the phases in turn as ONE 50-stage pipeline:
+//   * the LDS-DMA cursor runs ahead of the matrix cores ACROSS the phase boundary: stage 0 of phase p+1 is requested in the last stage
+//     of phase p and lands under p's epilogue;
+//   * the epilogue lives in the ring buffer the last stage of the phase was read from (32 KB = 128 pixels x 256 B; the (I)GDN form
+//     reuses it for squares, then output), the other buffer belongs to the DMA in flight -- 64 KB per block, two blocks per CU as before;
+//   * output rows leave through buffer stores (out-of-range pixels: dropped by the address check, always 8 stores per lane) and the
+//     first stage of the next phase waits with a COUNTED vmcnt: the stores drain under the next K loop, not in front of it;
+//   * the per-row DMA offsets do not depend on the phase (same q-tile), only the tap displacement does.
+// Summation order per output value is the one of igemm_glds_kernel (taps in raster order, channel chunk innermost): bit-identical.
+template <int GDN>
+__global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
+    using T = bf16_t;
+    constexpr int BM = 128, BN = 128, BK = 64, NW = 4, NT = NW * 64;
+    constexpr int CPR = BK * 2 / 16, RPB = 256 / (BK * 2);
+    constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
+    constexpr int XI = BM * CPR / 64 / NW, WI = BN * CPR / 64 / NW;
+    constexpr int WM = 2, MI = BN / WM / 32, NI = BM / 2 / 32;
+    constexpr int NST = BM * 16 / NT;                         // 16-byte stores per lane and output tile
+    static_assert(STAGE == BM * 256 && NST == 8, "the epilogue tile takes exactly one stage buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + (GDN ? 512 : 0)];   // ring + beta' (fp32 [128])
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (GDN && tid < 128) *(float*)(smem + 2 * STAGE + tid * 4) = a.gdn_beta[tid];     // read behind the K loop's barriers
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t rest = fdiv((uint32_t)bid, a.fd_nt);
+    const int nt = bid - (int)rest * a.n_tiles;
+    uint32_t q_ = fdiv(rest, a.fd_tx);
+    const int tx = (int)(rest - q_ * (uint32_t)a.tiles_x);
+    rest = q_; q_ = fdiv(rest, a.fd_ty);
+    const int ty = (int)(rest - q_ * (uint32_t)a.tiles_y);
+    const int b = (int)q_;
+    const int n0 = nt * BN;
+    const int kchunks = a.Cin / BK;
+    const T* __restrict__ xg = (const T*)a.x;
+
+    const int wm = wave % WM, wn = wave / WM;
+    const int frow = lane & 31, fh = lane >> 5;
+    auto off = [&](int row, int slot) { return (row * CPR + (slot ^ ((row / RPB) & (CPR - 1)))) * 16; };
+
+    // ---- producer: buffer-addressed LDS-DMA, as in igemm_glds_kernel (q-grid step 1: in_step == 1)
+    constexpr uint32_t OOB = 0x80000000u;
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+    const int neg = (a.KH * a.W + a.KW) * a.x_ps;
+    const int row0 = ty * a.TH;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)OOB, 0x00020000);
+    const int prow = lane / CPR, pslot = lane % CPR;
+    uint32_t xoff[XI], xv[XI], wv[WI];
+    int iy0[XI], ix0[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        const int qy = ty * a.TH + (row >> a.tw_shift), qx = tx * a.TW + (row & (a.TW - 1));
+        const bool ok = qy < a.QH && qx < a.QW;
+        iy0[i] = ok ? qy : (int)0xc0000000;
+        ix0[i] = qx;
+        xoff[i] = (uint32_t)((((qy - row0) * a.W + qx) * a.x_ps + a.x_co + ls * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave * WI + i) * (64 / CPR) + prow;
+        const int ls = pslot ^ ((row / RPB) & (CPR - 1));
+        wv[i] = (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2);
+    }
+    // phase (ry, rx) = (ph >> 1, ph & 1): taps k = k0 + 2 j with k0 = (r + pad) & 1, input displacement (r + pad - k) / 2 = d0 - j
+    auto phase_geo = [&](int ph, int& ky0, int& kx0, int& nky, int& nkx, int& dyb, int& dxb) {
+        const int ry = ph >> 1, rx = ph & 1;
+        ky0 = (ry + a.pad) & 1; kx0 = (rx + a.pad) & 1;
+        nky = (a.KH - ky0 + 1) >> 1; nkx = (a.KW - kx0 + 1) >> 1;
+        dyb = (ry + a.pad - ky0) >> 1; dxb = (rx + a.pad - kx0) >> 1;
+    };
+    const uint32_t wtap = (uint32_t)(a.Cout * a.Cin * 2);
+    int p_ph = 0, p_ky0, p_kx0, p_nky, p_nkx, p_dyb, p_dxb;
+    phase_geo(0, p_ky0, p_kx0, p_nky, p_nkx, p_dyb, p_dxb);
+    int cur_j = 0, cur_c = 0, cur_chunk = 0, dy = p_dyb, dx = p_dxb;
+    uint32_t s_x = 0, s_w = 0;
+    auto set_tap = [&]() {
+        s_x = (uint32_t)(((dy * a.W + dx) * a.x_ps + neg) * 2);
+        s_w = (uint32_t)((p_ky0 + cur_j * 2) * a.KW + p_kx0 + cur_c * 2) * wtap;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+            xv[i] = ok ? xoff[i] : OOB;
+        }
+    };
+    set_tap();
+    auto issue = [&](int buf) {
+        const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, (int)xv[i], (int)sx, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, (int)wv[i], (int)sw, 0, 0);
+        if (++cur_chunk == kchunks) {
+            cur_chunk = 0;
+            dx -= 1;
+            if (++cur_c == p_nkx) {
+                cur_c = 0; dx = p_dxb; ++cur_j; dy -= 1;
+                if (cur_j == p_nky) {                                      // the cursor moves on to the next output phase
+                    p_ph = (p_ph + 1) & 3;
+                    phase_geo(p_ph, p_ky0, p_kx0, p_nky, p_nkx, p_dyb, p_dxb);
+                    cur_j = 0; dy = p_dyb; dx = p_dxb;
+                }
+            }
+            set_tap();
+        }
+    };
+
+    // ---- output side: one buffer resource per image, the phase enters as a scalar offset
+    const int Wo = a.Wo;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)a.y + (int64_t)b * a.Ho * Wo * a.y_ps), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)(a.y_pre ? a.y_pre : a.y) + (int64_t)b * a.Ho * Wo * a.y_ps), 0, (int)OOB, 0x00020000);
+    auto store_tile = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned char* eb, int ry, int rx) {
+        int t = tid;
+        asm volatile("" : "+v"(t));                                      // keep the address arithmetic inside the epilogue (registers)
+        const uint32_t so = (uint32_t)((ry * Wo + rx) * a.y_ps * 2);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int pr = (t >> 4) + k * (NT / 16), cc = t & 15;
+            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+            const uint32_t vo = (qy < a.QH && qx < a.QW) ? (uint32_t)(((2 * qy * Wo + 2 * qx) * a.y_ps + a.y_co + n0 + cc * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(eb + pr * 256 + ((cc ^ (pr & 15)) << 4)), rs, (int)vo, (int)so, 0);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+    int gbuf = 0;
+    issue(0);
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+        int c_ky0, c_kx0, c_nky, c_nkx, c_dyb, c_dxb;
+        phase_geo(ph, c_ky0, c_kx0, c_nky, c_nkx, c_dyb, c_dxb);
+        const int nsteps = c_nky * c_nkx * kchunks;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto stage = [&](auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            constexpr int KS = BK / 16;
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* xs = smem + gbuf * STAGE;
+            const unsigned char* ws = xs + XT;
+            gbuf ^= 1;
+            bf16x8 wf[2][MI], xf[2][NI];
+            auto ldf = [&](int set, int ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / 2) + j * 32 + frow, ks * 2 + fh));
+            };
+            ldf(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!LAST || ph < 3) issue(gbuf);                      // LAST: stage 0 of the next phase, into the buffer the epilogue does not use
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // first stage of a later phase: everything but the previous epilogue's stores (the newest vector-memory operations of this wave)
+        // has to be back; the lgkmcnt part covers that epilogue's last LDS reads before the barrier hands its buffer to the DMA
+        if (ph == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (GDN && a.y_pre) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
+        for (int step = 0; step < nsteps - 1; ++step) {
+            stage(std::false_type{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        stage(std::true_type{});
+
+        // ---- epilogue in the buffer of the stage just computed
+        unsigned char* eb = smem + (gbuf ^ 1) * STAGE;
+        const int ry = ph >> 1, rx = ph & 1;
+        if constexpr (GDN == 0) {
+            const int act_eff = a.act;
+            int fr_ = frow, fh_ = fh;
+            asm volatile("" : "+v"(fr_), "+v"(fh_));
+            asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring buffer
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh_;
+                    const f32x4 bq = a.bias ? *(const f32x4*)(a.bias + n0 + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int pr = wn * (BM / 2) + j * 32 + fr_;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bq[e], act_eff);
+                        *(u32x2*)(eb + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            store_tile(yr, eb, ry, rx);
+        } else {
+            // fused (I)GDN (compressai/layers/gdn.py:55-70), the data flow of igemm_glds_kernel's epilogue in ONE 32 KB tile: squares in,
+            // contraction on the matrix cores one cout half at a time (32 norm registers live instead of 64: the DMA cursor's state
+            // stays in registers through the epilogue), the product in place in the accumulators, barrier, output over the squares
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
+                    const f32x4 t = a.bias ? *(const f32x4*)(a.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) acc[i][j][4 * g + e] += t[e];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 gq[MI][8];
+            {
+                const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto put_tile = [&](auto sq_tag) {
+                constexpr bool SQ = decltype(sq_tag)::value;
+                int fr_ = frow, fh_ = fh;
+                asm volatile("" : "+v"(fr_), "+v"(fh_));               // the 16 swizzled addresses are rebuilt here, not carried through the K loop
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh_;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int pr = wn * (BM / 2) + j * 32 + fr_;
+                            const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                            *(u32x2*)(eb + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
+                                SQ ? u32x2{pack_bf2(v0 * v0, v1 * v1), pack_bf2(v2 * v2, v3 * v3)} : u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
+                        }
+                    }
+            };
+            asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring buffer
+            if (a.y_pre) {
+                // training: v = conv + bias for GDN's backward leaves first (the accumulators turn into the output below)
+                put_tile(std::false_type{});
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                store_tile(ypr, eb, ry, rx);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            put_tile(std::true_type{});
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // squares visible to every wave
+            int fr2 = frow, fh2 = fh;
+            asm volatile("" : "+v"(fr2), "+v"(fh2));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f32x16 nrm[NI];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh2;
+                    const f32x4 be = *(const f32x4*)(smem + 2 * STAGE + cl * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) nrm[j][4 * g + e] = be[e];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    bf16x8 qf[NI];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int pr = wn * (BM / 2) + j * 32 + fr2;
+                        qf[j] = *(const bf16x8*)(eb + pr * 256 + (((ks * 2 + fh2) ^ (pr & 15)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) nrm[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qf[j], nrm[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= (GDN == 2 ? __builtin_amdgcn_sqrtf(nrm[j][r]) : rsqrtf(nrm[j][r]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has its square fragments: the tile may be overwritten
+            put_tile(std::false_type{});
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            store_tile(yr, eb, ry, rx);
+        }
+    }
+}
+
 // y = act(sum of the K-slice partials + bias) as bf16 (y) and / or fp32 (y32): one thread per pixel and 8 channels
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int64_t npix, int Cout,
                                                             const float* __restrict__ bias, int act, bf16_t* __restrict__ y,
@@ -1508,6 +1812,9 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
+        // A/B switch: HESIC_IGEMM_PHASE4=0 runs every transposed layer as one block per (tile, phase); _MIN = fewest fused blocks it is used for
+        static const int phase4 = getenv("HESIC_IGEMM_PHASE4") ? atoi(getenv("HESIC_IGEMM_PHASE4")) : 1;
+        static const int phase4_min = getenv("HESIC_IGEMM_PHASE4_MIN") ? atoi(getenv("HESIC_IGEMM_PHASE4_MIN")) : 512;
         static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
         if (bm == 256) {
             const dim3 block2(512);
@@ -1521,6 +1828,14 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
             else hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 0, 4, 1>), grid, block_ws, 0, st, a);
+        } else if (bm == 128 && bk == 64 && BN == 128 && d->transposed && s == 2 && phase4 && !hilo && ksplit == 1 && !g_y32 && g_groups == 1 &&
+                   !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2 && nblocks / 4 >= phase4_min &&
+                   (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31)) {
+            // the four output phases of a tile in one block (igemm_tr4_kernel): a quarter of the blocks, one 50-stage pipeline each
+            const dim3 grid4((unsigned)(nblocks / 4));
+            if (gdn == 1) hipLaunchKernelGGL((igemm_tr4_kernel<1>), grid4, block, 0, st, a);
+            else if (gdn == 2) hipLaunchKernelGGL((igemm_tr4_kernel<2>), grid4, block, 0, st, a);
+            else hipLaunchKernelGGL((igemm_tr4_kernel<0>), grid4, block, 0, st, a);
         } else if (bm == 128) {
             if (bk == 64) { if (BN == 128) LAUNCH_GLDS(128, 128, 64, 2); else LAUNCH_GLDS_NS(128, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(128, 128, 32); else LAUNCH_GLDS_NS(128, 64, 32); }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One layer of the analysis / synthesis stacks on the implicit-GEMM kernel, timed with HIP events.
 
-    python profiles/scripts/conv_layer_time.py [--layer conv2|deconv3|conv3|plain] [--batch 8] [--size 256]
+    python profiles/scripts/conv_layer_time.py [--layer conv2|deconv3|deconv_plain|conv3|plain] [--batch 8] [--size 256]
 Environment A/B switches of csrc/conv_igemm.hip apply (HESIC_IGEMM_WS; the HESIC_IGEMM_DBG ablation switches of rounds 1-2 were removed in round 3: their run-time branches split the K loop into basic blocks)."""
 import argparse
 import os
@@ -36,7 +36,7 @@ def main():
     else:
         layer, g = deconv(128, 128).cuda(), GDN(128, inverse=True).cuda()
         flops = 2.0 * B * S * S * 128 * 128 * 25 + 2.0 * B * (2 * S) ** 2 * 128 * 128
-    f = (lambda: layer.run(x)) if args.layer == "plain" else (lambda: layer.run_gdn(x, g))
+    f = (lambda: layer.run(x)) if args.layer in ("plain", "deconv_plain") else (lambda: layer.run_gdn(x, g))
     if args.hilo:
         xf = torch.randn(B, 128, S, S, device="cuda") * 0.5
         hi = xf.to(torch.bfloat16)
@@ -71,7 +71,7 @@ def main():
         with torch.no_grad():
             torch.save(f().float().cpu(), args.dump)
     us = e0.elapsed_time(e1) / args.iters * 1e3
-    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   WS={os.environ.get('HESIC_IGEMM_WS', '0')} hilo={int(args.hilo)} BM256_HILO={os.environ.get('HESIC_IGEMM_BM256_HILO', '0')}")
+    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   PHASE4={os.environ.get('HESIC_IGEMM_PHASE4', '1')} WS={os.environ.get('HESIC_IGEMM_WS', '0')} hilo={int(args.hilo)} BM256_HILO={os.environ.get('HESIC_IGEMM_BM256_HILO', '0')}")
 
 
 if __name__ == "__main__":
