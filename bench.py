@@ -113,6 +113,8 @@ class KernelMeter:
         import ctypes as C
         v = (C.c_int32 * 4)()
         self.orig("hesic_conv2d_variant", C.byref(d), v)
+        if v[3] == 2:
+            return f"igemm_tr4_kernel<{'gdn' if fused else 'plain'}>"
         if v[3]:
             return f"igemm_glds_kernel<{v[0]},{v[1]},{v[2]}{',gdn' if fused else ''}>"
         return f"igemm_conv_kernel<{'bf16' if d.dtype == self.L.BF16 else 'f32'},{v[1]}>"

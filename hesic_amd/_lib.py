@@ -82,6 +82,7 @@ _SIGS = {
     "hesic_conv2d_gdn_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
     "hesic_conv2d_gdn_forward_train": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
     "hesic_conv2d_variant": ([_P(ConvDesc), _P(_i32)], _i32),
+    "hesic_conv2d_set_phase_fusion": ([_i32], _i32),
     "hesic_conv2d_wgrad_ws_bytes": ([_P(ConvDesc)], _i64),
     "hesic_conv2d_wgrad": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i32),
     "hesic_unpack_conv_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
@@ -130,6 +131,7 @@ _SIGS = {
     "hesic_conv2d_forward_grouped": ([_P(ConvDesc), _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_slice": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
+    "hesic_conv2d_wgrad_finish_batched": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i32, _vp], _i32),
     "hesic_gdn_backward_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
     "hesic_eb_pack_table": ([_P(EbLayout), _vp, _i32, _vp], _i32),
     "hesic_eb_scatter_grads": ([_P(EbLayout), _vp, _i32, _i32, _vp], _i32),

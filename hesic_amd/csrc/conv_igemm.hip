@@ -17,6 +17,7 @@
 // used for the tight-parity mode); accumulation is fp32 in both.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -1568,6 +1569,11 @@ extern "C" int hesic_unpack_conv_wgrad(const float* dwp, const float* mask, floa
     HESIC_LAUNCH_RETURN("unpack_conv_wgrad");
 }
 
+static std::atomic<int> g_phase4_mode{getenv("HESIC_IGEMM_PHASE4") ? atoi(getenv("HESIC_IGEMM_PHASE4")) : 1};
+extern "C" int hesic_conv2d_set_phase_fusion(int mode) {
+    if (mode < 0 || mode > 2) { hesic_set_error("conv2d_set_phase_fusion: mode must be 0 (off), 1 (auto) or 2 (always)"); return -1; }
+    return g_phase4_mode.exchange(mode);
+}
 static thread_local int* g_plan_out = nullptr;
 static thread_local const void* g_gdn_gamma = nullptr;   // set by hesic_conv2d_gdn_forward around its call to the launcher
 static thread_local const float* g_gdn_beta = nullptr;
@@ -1769,7 +1775,23 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     a.tiles_x = (a.QW + TW - 1) / TW; a.tiles_y = (a.QH + TH - 1) / TH;
     const int64_t nblocks = (int64_t)a.n_tiles * a.tiles_x * a.tiles_y * a.B * a.nphase * ksplit;
     HESIC_CHECK_ARG(nblocks > 0 && nblocks < (1ll << 31), "conv2d_forward: bad grid");
+    // The four output phases of a transposed stride-2 layer in one block (igemm_tr4_kernel).  Fused blocks are 4x as long, so a ragged
+    // last round of the 512 block slots (256 CUs x 2) costs 4x as much: measured on MI355X (128 -> 128, +IGDN / plain, us unfused ->
+    // fused): 1024 blocks 180.7 -> 161.5 / 177 -> 148; 512: 104 -> 93.6 / 101 -> 84.9; 576: 113.9 -> 117.4 / 115.3 -> 108.5; 256: 59.6 ->
+    // 51.0 and 48.5 -> 54.0 / ties.  Auto mode uses it from 384 fused blocks on when its rounds are >= 70 % full.
+    // hesic_conv2d_set_phase_fusion / HESIC_IGEMM_PHASE4 = 0: never, 1: auto, 2: whenever the shape is eligible.
+    bool use_tr4 = false;
+    {
+        const int mode = g_phase4_mode.load(std::memory_order_relaxed);
+        const int64_t nb4 = nblocks / 4, rounds = (nb4 + 511) / 512;
+        const bool fills = mode >= 2 || (nb4 >= 384 && nb4 * 10 >= rounds * 512 * 7);
+        static const bool force_bk32_ = getenv("HESIC_IGEMM_BK32") != nullptr;
+        use_tr4 = fast && mode && fills && bm == 128 && BN == 128 && cin_k % 64 == 0 && !force_bk32_ && d->transposed && s == 2 && !hilo && ksplit == 1 &&
+                  !g_y32 && g_groups == 1 && !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2 &&
+                  (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31);
+    }
     if (g_plan_out) {
+        if (use_tr4) { g_plan_out[0] = 128; g_plan_out[1] = 128; g_plan_out[2] = 64; g_plan_out[3] = 2; return 0; }
         g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (((bm == 32) || (bm == 64 && BN == 64)) && cin_k % 128 == 0 ? 128 : (cin_k % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
@@ -1812,9 +1834,6 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
-        // A/B switch: HESIC_IGEMM_PHASE4=0 runs every transposed layer as one block per (tile, phase); _MIN = fewest fused blocks it is used for
-        static const int phase4 = getenv("HESIC_IGEMM_PHASE4") ? atoi(getenv("HESIC_IGEMM_PHASE4")) : 1;
-        static const int phase4_min = getenv("HESIC_IGEMM_PHASE4_MIN") ? atoi(getenv("HESIC_IGEMM_PHASE4_MIN")) : 512;
         static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
         if (bm == 256) {
             const dim3 block2(512);
@@ -1828,9 +1847,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
             else hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 0, 4, 1>), grid, block_ws, 0, st, a);
-        } else if (bm == 128 && bk == 64 && BN == 128 && d->transposed && s == 2 && phase4 && !hilo && ksplit == 1 && !g_y32 && g_groups == 1 &&
-                   !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2 && nblocks / 4 >= phase4_min &&
-                   (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31)) {
+        } else if (use_tr4) {
             // the four output phases of a tile in one block (igemm_tr4_kernel): a quarter of the blocks, one 50-stage pipeline each
             const dim3 grid4((unsigned)(nblocks / 4));
             if (gdn == 1) hipLaunchKernelGGL((igemm_tr4_kernel<1>), grid4, block, 0, st, a);

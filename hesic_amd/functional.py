@@ -139,6 +139,47 @@ def set_wgrad_stream(stream):
     return prev
 
 
+import os as _os
+
+# Deferred finishing passes of the wide weight gradients (see _wide_conv_grads): a list while train.Trainer.step collects them
+_finish_queue = None
+WGRAD_FINISH_BATCH = int(_os.environ.get("HESIC_WGRAD_FINISH_BATCH", "8"))     # A/B switch: 0 = one finishing launch per layer (rounds 2-3)
+
+
+def defer_wgrad_finish(on):
+    """Gate of the batched finishing pass; returns the previous state.  Turning it off flushes what is queued."""
+    global _finish_queue
+    prev = _finish_queue is not None
+    if not on:
+        flush_wgrad_finish()
+        _finish_queue = None
+    elif _finish_queue is None and WGRAD_FINISH_BATCH > 0:
+        _finish_queue = []
+    return prev
+
+
+def flush_wgrad_finish():
+    """One ``hesic_conv2d_wgrad_finish_batched`` call for the queued layers, on the current stream (the stream their split-K launches
+    went to); the gradient slots report afterwards, so a bucket's all-reduce is still issued behind its last finishing launch."""
+    q = _finish_queue
+    if not q:
+        return
+    n = len(q)
+    descs = (L.ConvDesc * n)(*[j[0] for j in q])
+    vp = C.c_void_p * n
+    ws = vp(*[j[1].data_ptr() for j in q])
+    dy = vp(*[j[2].data_ptr() for j in q])
+    dw = vp(*[j[3].grad.data_ptr() for j in q])
+    db = vp(*[(j[4].grad.data_ptr() if j[4] is not None else None) for j in q])
+    L.call("hesic_conv2d_wgrad_finish_batched", n, descs, ws, dy, dw, db, 1, L.stream())
+    jobs = list(q)
+    q.clear()
+    for j in jobs:
+        _slot_done(j[3])
+        if j[4] is not None:
+            _slot_done(j[4])
+
+
 def grad_slots_active(on):
     """Gate of the direct-write path.  Only inside ``train.Trainer.step`` (which clears the flat buffer first and reads it with
     its own optimiser) do the gradient kernels add into the slots and hand ``None`` to autograd; everywhere else -- a plain
@@ -461,6 +502,15 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=
                         _slot_done(bs_)
                 return dx, None, None
             ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+            if _finish_queue is not None:
+                # deferred finishing pass (train.Trainer.step): only the split-K MFMA launch now; the K-slice reduce + layout change +
+                # bias column sums of up to 8 layers share one launch (flush_wgrad_finish).  The job keeps ws and gy alive until then.
+                dwp = ws_.grad.data_ptr()
+                if len(_finish_queue) >= WGRAD_FINISH_BATCH or any(j[5] == dwp for j in _finish_queue) or (_finish_queue and _finish_queue[0][0].dtype != d.dtype):
+                    flush_wgrad_finish()
+                L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws), nws, L.stream())
+                _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp))
+                return dx, None, None
             L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
                    L.ptr(ws), nws, L.stream())
             _slot_done(ws_)
@@ -1864,3 +1914,13 @@ def rd_loss(out, x1, x2, lmbda):
     lk = out["likelihoods"]
     loss, bpp, mse = _RdLossFn.apply(lmbda, x1, x2, out["x1_hat"], out["x2_hat"], lk["y1"], lk["y2"], lk["z1"], lk["z2"])
     return {"loss": loss, "bpp_loss": bpp.detach(), "mse_loss": mse.detach()}
+
+
+def set_phase_fusion(mode):
+    """How transposed stride-2 layers run on the implicit-GEMM kernels (``hesic_conv2d_set_phase_fusion``): 0 = one block per (tile,
+    output phase), 1 = auto (the four phases of a tile in one block when the launch fills the chip that way; default), 2 = whenever the
+    shape is eligible.  Results are bit-identical in every mode.  Returns the previous mode."""
+    prev = int(L.lib().hesic_conv2d_set_phase_fusion(int(mode)))
+    if prev < 0:
+        raise ValueError(f"set_phase_fusion: bad mode {mode}: {L.lib().hesic_last_error().decode()}")
+    return prev

@@ -356,10 +356,12 @@ class Trainer:
             wst.wait_stream(torch.cuda.current_stream())       # behind zero_grad
             self.main_reducer.side_stream = wst
         wprev = Fn.set_wgrad_stream(wst)
+        defer = Fn.defer_wgrad_finish(self.on_gpu and wst is None)     # finishing passes of the weight gradients: batches of 8 layers per launch
         try:
             crit = self._forward_loss(x1, x2, h_matrix, noise)
             crit["loss"].backward()
         finally:
+            Fn.defer_wgrad_finish(defer)          # flushes what is still queued: every weight gradient is in (or on its way into) the flat buffer
             Fn.train_pack_cache(prev)
             Fn.SCALED_LOSS = scaled
             Fn.grad_slots_active(slots)

@@ -147,6 +147,14 @@ int hesic_im2col_hilo(const float* x, const int64_t x_strides[4], int B, int C, 
  * out[0..3] = {pixel tile BM, cout tile BN, K step BK, 1 if the LDS-DMA (bf16) kernel else 0}.        */
 int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds);
 
+/* deconv() (compressai/models/utils.py:112-118; g_s of ywz/mywork/newnet1.py:603-624, and the data gradient of the stride-2 analysis
+ * convs): a transposed stride-2 layer is four stride-1 output phases.  By default (mode 1) hesic_conv2d_forward / _gdn_forward[_train]
+ * run the four phases of a 128-pixel x 128-cout tile in ONE block (one LDS-DMA pipeline across the phases, igemm_tr4_kernel) when
+ * the launch is large enough to fill the chip that way; results are bit-identical to the one-block-per-phase form.  mode 0: never
+ * (A/B measurements), 2: whenever the shape is eligible (tests).  Process-wide; returns the previous mode, -1 on a bad argument.
+ * hesic_conv2d_variant reports the fused form as out[3] == 2.  Environment default: HESIC_IGEMM_PHASE4.                          */
+int hesic_conv2d_set_phase_fusion(int mode);
+
 /* Weight gradient of the same op: dw_packed[KH*KW][Cout][Cin] (fp32, packed layout) = sum over pixels of
  * dy (x) x; dbias (Cout, fp32) may be NULL.  Pixels are split over blocks; the partial tiles live in `ws`
  * (hesic_conv2d_wgrad_ws_bytes(d) bytes) and are summed in a fixed order, so the result is deterministic.
@@ -165,6 +173,13 @@ int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const voi
 /* Only the first of its two launches -- the split-K MFMA kernel that leaves the fp32 partial tiles in ws -- for profiling
  * (bench.py brackets it with HIP events to price the weight-gradient kernel against the MFMA roofline).               */
 int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* x, const void* dy, void* ws, int64_t ws_bytes, void* stream);
+/* The second launch of hesic_conv2d_wgrad_direct for n layers at once: job j reduces the K slices hesic_conv2d_wgrad_partial(descs + j,
+ * ..) left in ws[j] into dw[j] (PyTorch layout) and sums dy[j]'s columns into dbias[j] (NULL: no bias), `accumulate` as above.  The
+ * backward pass of a training step (newtrain1.py:85-96) has one such pass per conv layer -- 37 launches of ~17 us on small grids;
+ * batches of 8 jobs share a launch.  Two jobs of one launch must not name the same dw (a weight used twice per step goes into
+ * two calls); one storage type per call.                                                                                        */
+int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* descs, const void* const* ws, const void* const* dy, float* const* dw,
+                                      float* const* dbias, int accumulate, void* stream);
 
 /* 3-channel image convs with arbitrary element strides on the image side (conv1 3->N, pre_conv 6->3,
  * g_s_conv4 N->3, after_conv 6->3: newnet1.py:583,629,612,670).  `img_*` strides describe the tensor

@@ -1,0 +1,118 @@
+"""Weight gradients of the wide convs (the backward pass of newtrain1.py:85-96): the finishing passes of several layers in one launch
+(hesic_conv2d_wgrad_finish_batched) against one hesic_conv2d_wgrad_direct call per layer.  Both sum the K slices of a value in the
+same fixed order, so dW is compared bit for bit (also when a weight receives two gradients per step, encoder1); the bias column
+sums end in fp32 atomics in both forms: 1e-5 relative."""
+import ctypes as C
+
+import pytest
+import torch
+
+from hesic_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0):
+    return synthetic._uniform("wb." + name, shape, lo, hi)
+
+
+LAYERS = [
+    # Cin, Cout, k, stride, transposed, (B, H, W) of the conv input, bias
+    (128, 128, 5, 2, 0, (2, 24, 40), True),
+    (128, 192, 5, 2, 1, (1, 12, 20), True),
+    (192, 128, 3, 1, 0, (2, 16, 16), False),
+    (128, 128, 5, 2, 1, (2, 8, 8), True),
+    (64, 128, 5, 1, 0, (1, 20, 12), True),
+    (128, 128, 5, 2, 0, (3, 16, 16), True),
+    (128, 64, 3, 1, 1, (2, 9, 11), False),
+    (128, 128, 5, 2, 0, (1, 32, 32), True),
+    (128, 128, 5, 2, 1, (1, 16, 16), True),       # ninth job: a second launch inside one call
+]
+
+
+def _layer(i, L):
+    Cin, Cout, k, s, tr, (B, H, W), has_b = LAYERS[i]
+    pad = k // 2
+    Ho, Wo = (H * s, W * s) if tr else ((H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1)
+    x = rnd(f"x{i}", (B, Cin, H, W), -2, 2).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = rnd(f"g{i}", (B, Cout, Ho, Wo)).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, tr, L.BF16, 0, 0, Cin, 0, Cout, 0, 0)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    return d, x, gy, wshape, Cout, has_b
+
+
+def test_batched_finish_equals_the_per_layer_launches():
+    from hesic_amd import _lib as L
+    st = L.stream()
+    n = len(LAYERS)
+    layers = [_layer(i, L) for i in range(n)]
+    ref_dw, ref_db, bat_dw, bat_db, wss = [], [], [], [], []
+    for d, x, gy, wshape, Cout, has_b in layers:
+        nws = int(L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d)))
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+        dw = torch.full(wshape, 0.25, dtype=torch.float32, device=DEV)         # accumulate: the slot already holds a value
+        db = torch.full((Cout,), -0.5, dtype=torch.float32, device=DEV) if has_b else None
+        L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), 1, L.ptr(ws), nws, st)
+        ref_dw.append(dw); ref_db.append(db)
+        ws2 = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+        L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws2), nws, st)
+        wss.append(ws2)
+        bat_dw.append(torch.full(wshape, 0.25, dtype=torch.float32, device=DEV))
+        bat_db.append(torch.full((Cout,), -0.5, dtype=torch.float32, device=DEV) if has_b else None)
+    vp = C.c_void_p * n
+    descs = (L.ConvDesc * n)(*[l[0] for l in layers])
+    L.call("hesic_conv2d_wgrad_finish_batched", n, descs, vp(*[w.data_ptr() for w in wss]), vp(*[l[2].data_ptr() for l in layers]),
+           vp(*[w.data_ptr() for w in bat_dw]), vp(*[(b.data_ptr() if b is not None else None) for b in bat_db]), 1, st)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(bat_dw[i], ref_dw[i]), f"layer {i}: dW differs"
+        assert float((ref_dw[i] - 0.25).abs().max()) > 1e-3
+        if ref_db[i] is not None:
+            assert float((bat_db[i] - ref_db[i]).abs().max()) <= 1e-5 * float(ref_db[i].abs().max())
+
+
+def test_batched_finish_rejects_two_jobs_on_one_gradient():
+    from hesic_amd import _lib as L
+    d, x, gy, wshape, Cout, _ = _layer(0, L)
+    nws = int(L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d)))
+    ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.zeros(wshape, dtype=torch.float32, device=DEV)
+    vp = C.c_void_p * 2
+    descs = (L.ConvDesc * 2)(d, d)
+    with pytest.raises(RuntimeError, match="same gradient"):
+        L.call("hesic_conv2d_wgrad_finish_batched", 2, descs, vp(ws.data_ptr(), ws.data_ptr()), vp(gy.data_ptr(), gy.data_ptr()),
+               vp(dw.data_ptr(), dw.data_ptr()), vp(None, None), 1, L.stream())
+
+
+def test_trainer_step_is_the_same_with_and_without_the_batched_finish():
+    """One Trainer.step from the same state with the finishing passes batched (default) and one per layer: identical weight
+    gradients up to the bias atomics, i.e. parameters after Adam agree to 1e-6 relative."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, models, train
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    outs = []
+    x1, x2, h = (t.to(DEV) for t in synthetic.stereo_batch(0, 2, 128, 128))
+    try:
+        for batch in (8, 0):
+            prev, Fn.WGRAD_FINISH_BATCH = Fn.WGRAD_FINISH_BATCH, batch
+            try:
+                net = models.HSIC()
+                synthetic.fill_state_dict_(net.state_dict())
+                net = net.to(DEV)
+                tr = train.Trainer(net, lmbda=0.0067)
+                torch.manual_seed(3)                     # the quantisation noise of the step
+                crit = tr.step(x1, x2, h)
+                torch.cuda.synchronize()
+                outs.append((float(crit["loss"]), tr.main_group.flat_g.clone(), tr.main_group.flat_p.clone()))
+                tr.main_reducer.close()
+                tr.aux_reducer.close()
+            finally:
+                Fn.WGRAD_FINISH_BATCH = prev
+    finally:
+        hesic_amd.set_compute_dtype(torch.float32)
+    (l0, g0, p0), (l1, g1, p1) = outs
+    assert l0 == l1
+    assert float(g1.abs().max()) > 0
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float((p0 - p1).abs().max()) <= 1e-5 * float(p1.abs().max())
