@@ -1138,6 +1138,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
     const int Wo = a.Wo;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)a.y + (int64_t)b * a.Ho * Wo * a.y_ps), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)(a.y_pre ? a.y_pre : a.y) + (int64_t)b * a.Ho * Wo * a.y_ps), 0, (int)OOB, 0x00020000);
+    // gamma' fragments (fragment order: one 16-byte piece per lane and (cout slice, k-step)): ONE 32-bit lane offset + scalar offsets --
+    // as 64-bit global pointers the 16 addresses were hoisted out of the phase loop into 32 registers (and spilled)
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const bf16x8*)(GDN ? a.gdn_gamma : a.w) + (GDN ? 128 * 16 : 0)), 0, 128 * 128 * 2, 0x00020000);
     auto store_tile = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned char* eb, int ry, int rx) {
         int t = tid;
         asm volatile("" : "+v"(t));                                      // keep the address arithmetic inside the epilogue (registers)
@@ -1203,6 +1207,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             stage(std::false_type{});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // (I)GDN: the gamma' fragments of the epilogue are requested in front of the phase's last stage -- an L2 round trip that would
+        // otherwise sit between the two barriers of the epilogue (and, the counter being in-order, drag the next phase's first DMA with it)
+        // (first cout half only: all of it costs 16 spilled registers; the second half is requested at the top of the epilogue and is
+        // not needed before the first half's contraction has been issued)
+        bf16x8 gq[GDN ? MI : 1][8];
+        if constexpr (GDN != 0) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                gq[0][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + 0) * 8 + ks) * 1024, 0));
+        }
         stage(std::true_type{});
 
         // ---- epilogue in the buffer of the stage just computed
@@ -1246,14 +1260,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                         for (int j = 0; j < NI; ++j) acc[i][j][4 * g + e] += t[e];
                 }
             __builtin_amdgcn_sched_barrier(0);
-            bf16x8 gq[MI][8];
-            {
-                const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int i = 1; i < MI; ++i)
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
-            }
+                for (int ks = 0; ks < 8; ++ks)
+                    gq[i][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + i) * 8 + ks) * 1024, 0));
             __builtin_amdgcn_sched_barrier(0);
             auto put_tile = [&](auto sq_tag) {
                 constexpr bool SQ = decltype(sq_tag)::value;
@@ -1703,7 +1714,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int th = m / tw;
         return (int64_t)a.n_tiles * ((a.QW + tw - 1) / tw) * ((a.QH + th - 1) / th) * a.B * a.nphase;
     };
-    if (fast) {
+    // hesic_conv2d_set_phase_fusion(2): eligible transposed layers take the 128-pixel tile whatever the grid (the fused kernel's only tile)
+    const bool tr4_shape = d->dtype == HESIC_BF16 && d->transposed && s == 2 && BN == 128 && cin_k % 64 == 0 && !hilo && !g_y32 && g_groups == 1 &&
+                           !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2;
+    const bool tr4_forced = tr4_shape && g_phase4_mode.load(std::memory_order_relaxed) >= 2;
+    if (fast && !tr4_forced) {
         if (count_blocks(128) < 384) bm = 64;
         if (bm == 64 && count_blocks(64) < 384 && BN == 128 && cin_k % 64 == 0) bm = 32;
         static const int force_bm = getenv("HESIC_IGEMM_BM") ? atoi(getenv("HESIC_IGEMM_BM")) : 0;      // A/B switch
@@ -1786,9 +1801,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int64_t nb4 = nblocks / 4, rounds = (nb4 + 511) / 512;
         const bool fills = mode >= 2 || (nb4 >= 384 && nb4 * 10 >= rounds * 512 * 7);
         static const bool force_bk32_ = getenv("HESIC_IGEMM_BK32") != nullptr;
-        use_tr4 = fast && mode && fills && bm == 128 && BN == 128 && cin_k % 64 == 0 && !force_bk32_ && d->transposed && s == 2 && !hilo && ksplit == 1 &&
-                  !g_y32 && g_groups == 1 && !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2 &&
-                  (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31);
+        use_tr4 = fast && mode && fills && bm == 128 && tr4_shape && !force_bk32_ && ksplit == 1 && (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31);
     }
     if (g_plan_out) {
         if (use_tr4) { g_plan_out[0] = 128; g_plan_out[1] = 128; g_plan_out[2] = 64; g_plan_out[3] = 2; return 0; }

@@ -69,7 +69,7 @@ PLAIN_CASES = [
     ("5x5_64_one_chunk", 64, 128, 5, 2, (2, 8, 24), "relu"),
     ("5x5_two_cout_tiles", 128, 256, 5, 2, (1, 11, 17), "none"),
     ("3x3", 128, 128, 3, 1, (2, 10, 18), "none"),
-    ("4x4", 128, 128, 4, 1, (1, 16, 9), "leaky"),
+    ("3x3_leaky_tall", 128, 128, 3, 1, (1, 16, 9), "leaky"),
     ("5x5_1x1_map", 128, 128, 5, 2, (2, 1, 1), "none"),
 ]
 
