@@ -27,6 +27,9 @@ def load(d, counter):
             m = re.search(r"igemm_glds_kernel<([^>]*)>", r["Kernel_Name"])
             if m:
                 out[m.group(1).replace(" ", "")].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            m = re.search(r"igemm_tr4_kernel<([^>]*)>", r["Kernel_Name"])      # phase-fused transposed form: template argument = GDN mode
+            if m:
+                out["tr4:" + m.group(1).replace(" ", "")].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return out
 
 
@@ -44,6 +47,12 @@ def main():
     merged = {}
     for inst, v in res.items():
         p = inst.split(",")
+        if inst.startswith("tr4:"):
+            name = f"igemm_tr4_kernel<{'gdn' if inst[4:] != '0' else 'plain'}>"
+            m = merged.setdefault(name, {"launches": 0, "bytes": 0.0})
+            m["launches"] += v["launches"]
+            m["bytes"] += v["hbm_bytes_per_launch"] * v["launches"]
+            continue
         name = f"igemm_glds_kernel<{p[0]},{p[1]},{p[2]}{',gdn' if p[4] != '0' else ''}>" + (" hilo" if len(p) > 7 and p[7] == "1" else "")
         m = merged.setdefault(name, {"launches": 0, "bytes": 0.0})
         m["launches"] += v["launches"]

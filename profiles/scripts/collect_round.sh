@@ -14,12 +14,12 @@ rocprofv3 --kernel-trace --stats -d /tmp/p1 -o d --output-format csv -- python $
 cp /tmp/p1/d_kernel_stats.csv $O/default_kernel_stats.csv
 HESIC_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/p2 -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --exec eager > /dev/null 2>&1
 cp /tmp/p2/s_kernel_stats.csv $O/single_stream_kernel_stats.csv
-HESIC_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "igemm_glds_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_f -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
-HESIC_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "igemm_glds_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_w -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
+HESIC_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "igemm_glds_kernel|igemm_tr4_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_f -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
+HESIC_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "igemm_glds_kernel|igemm_tr4_kernel|n2w_gdn_hilo" --output-format csv -d $O/pmc_w -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 4 > /dev/null 2>&1
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  HESIC_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc $set --kernel-include-regex "igemm_glds_kernel|n2w_gdn_hilo|sconv_n2w|sconv_w2n" --output-format csv -d $O/pmcsq/p$i -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 3 > /dev/null 2>&1
+  HESIC_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc $set --kernel-include-regex "igemm_glds_kernel|igemm_tr4_kernel|n2w_gdn_hilo|sconv_n2w|sconv_w2n" --output-format csv -d $O/pmcsq/p$i -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 3 > /dev/null 2>&1
 done
 python $GRAFT_REPO_ROOT/profiles/make_pmc_sq_json.py $O/pmcsq $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p3 -o t --output-format csv -- python $GRAFT_REPO_ROOT/profiles/scripts/train_step.py --size 512 --only g --steps 10 > /dev/null 2>&1
