@@ -1,10 +1,5 @@
-mkdir -p gpurun_out/r03g
-timeout 600 python -m pytest tests/test_gpu_phase_fusion.py tests/test_gpu_wgrad_batched.py -x -q -m gpu > gpurun_out/r03g/pytest_new.txt 2>&1; grep -v "^NCCL\|^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" gpurun_out/r03g/pytest_new.txt | tail -25
-L=profiles/scripts/conv_layer_time.py
-for lay in deconv3 deconv_plain; do
-  HESIC_IGEMM_PHASE4=0 python $L --layer $lay --size 128 --graph --dump gpurun_out/r03g/${lay}_0.pt 2>&1 | grep us
-  HESIC_IGEMM_PHASE4=1 python $L --layer $lay --size 128 --graph --dump gpurun_out/r03g/${lay}_1.pt 2>&1 | grep us
-  python profiles/scripts/cmp_dump.py gpurun_out/r03g/${lay}_0.pt gpurun_out/r03g/${lay}_1.pt
-done
-rm -f gpurun_out/r03g/*.pt
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03g/pytest_gpu.txt 2>&1; grep "passed\|failed" gpurun_out/r03g/pytest_gpu.txt | tail -3
+# end-of-session check: smoke, the whole GPU suite, the default bench line
+mkdir -p gpurun_out/final
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1800 python -m pytest tests -q -m gpu > gpurun_out/final/pytest_gpu.txt 2>&1; grep "passed\|failed" gpurun_out/final/pytest_gpu.txt | tail -3
+python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; tail -c 400 gpurun_out/final/bench.json

@@ -120,7 +120,8 @@ def test_fused_phases_with_the_gdn_epilogue(inv, Cin, bhw, fusion_modes):
 
 def test_fused_phases_training_form_stores_the_same_conv_output_and_gradients(fusion_modes):
     """Autograd on: the kernel also stores v = conv + bias for GDN's backward (first, through the same epilogue tile); the data
-    gradient of a stride-2 conv is the plain transposed launch.  Output and every gradient are bit-identical between the forms."""
+    gradient of a stride-2 conv is the plain transposed launch.  Output, data and weight gradients are bit-identical between the forms (the bias / GDN
+    parameter gradients are sums of identical values in atomics order)."""
     Fn, L, O = _imp()
     hesic_amd.set_compute_dtype(torch.bfloat16)
     sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
@@ -145,8 +146,13 @@ def test_fused_phases_training_form_stores_the_same_conv_output_and_gradients(fu
         yc.backward(gyc.to(DEV, torch.bfloat16))
         return [y.detach()] + [p.grad for p in t] + [xc.grad]
     per_phase, fused = fusion_modes(run)
-    for a, c in zip(fused, per_phase):
-        assert a is not None and torch.equal(a, c)
+    names = ["y", "dx", "dw", "dbias", "dbeta", "dgamma", "dx of the stride-2 conv"]
+    for name, a, c in zip(names, fused, per_phase):
+        assert a is not None, name
+        if name in ("dbias", "dbeta", "dgamma"):      # column sums that end in fp32 atomics (any two runs differ in the last bits)
+            assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()), name
+        else:
+            assert torch.equal(a, c), name
 
 
 def test_set_phase_fusion_rejects_bad_modes():
