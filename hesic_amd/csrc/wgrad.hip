@@ -40,6 +40,11 @@ struct WgArgs {
     int64_t Q, chunk;
     int co_tiles, ci_tiles, ntaps, nsplit;
     int8_t tap_id[25];
+    // bias gradient on the matrix cores (wgrad_tr_kernel only): the blocks of the taps listed in b_tap (indices into the live taps)
+    // with ci tile 0 also form the column sums of their dY slice -- one more MFMA per cout fragment and k-step against a fragment of
+    // ones -- and leave them in bias_part[split][nb_taps][Cout].  A conv reads every dY pixel in every tap (one tap is listed); a
+    // transposed conv reads dY at q * stride + k - pad: the stride^2 taps with k - pad in [0, stride) cover every pixel exactly once.
+    float* bias_part; int nb_taps; int8_t b_tap[4];
 };
 
 template <typename T> struct WC;
@@ -403,13 +408,24 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int bslot = -1;                                   // block-uniform: which bias_part slot this block's column sums go to
+    if (a.bias_part && cit == 0)
+        for (int k = 0; k < a.nb_taps; ++k)
+            if (tapi == a.b_tap[k]) bslot = k;
+    f32x16 bacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
 
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int64_t nsteps = (q_end - q_begin + BK - 1) / BK;
     // the transform of the X operand (|x| for the abs-conv of encode_hyper, x^2 for the GDN gamma gradient) is a
     // compile-time variant of the loop: no branches between the transpose reads and the MFMAs
-    auto main_loop = [&](auto abs_tag, auto sq_tag, auto fast_tag) {
-        constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value, FASTQ = decltype(fast_tag)::value;
+    auto main_loop = [&](auto abs_tag, auto sq_tag, auto fast_tag, auto bias_tag) {
+        constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value, FASTQ = decltype(fast_tag)::value, BIAS = decltype(bias_tag)::value;
+        const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
         auto issue = [&](int buf) {
             if constexpr (FASTQ) issue_fast(buf);
             else issue_slow(buf);
@@ -468,18 +484,42 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], ones, bacc[i], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    if (A.fastq) {
-        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::true_type{});
-        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::true_type{});
-        else main_loop(std::false_type{}, std::false_type{}, std::true_type{});
+    if (bslot >= 0) {
+        // one block in ntaps * ci_tiles (x stride^2 for a transposed conv): the squared-input (GDN gamma) form never carries a bias
+        if (A.fastq) {
+            if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::true_type{}, std::true_type{});
+            else main_loop(std::false_type{}, std::false_type{}, std::true_type{}, std::true_type{});
+        } else {
+            if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::false_type{}, std::true_type{});
+            else main_loop(std::false_type{}, std::false_type{}, std::false_type{}, std::true_type{});
+        }
+        // every column of bacc holds the same sums: column 0 (lanes 0 and 32) of the waves of ci half 0 writes them
+        if (wn == 0 && frow == 0) {
+            float* bp = a.bias_part + ((int64_t)split * a.nb_taps + bslot) * a.Cout;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (co < a.Cout) bp[co] = bacc[i][r];
+                }
+        }
+    } else if (A.fastq) {
+        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::true_type{}, std::false_type{});
+        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::true_type{}, std::false_type{});
+        else main_loop(std::false_type{}, std::false_type{}, std::true_type{}, std::false_type{});
     } else {
-        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::false_type{});
-        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::false_type{});
-        else main_loop(std::false_type{}, std::false_type{}, std::false_type{});
+        if (a.in_sq) main_loop(std::false_type{}, std::true_type{}, std::false_type{}, std::false_type{});
+        else if (a.in_abs) main_loop(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
+        else main_loop(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
     }
 
     float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
@@ -646,12 +686,24 @@ struct FinishArgs {
     const float* ws; float* dw; int nsplit, ntaps, T_all, Cout, Cin, transposed, accumulate;
     int tiles_ci, tiles_co, tap_groups, taps_per_group, n_red;
     int8_t tap_id[25];
+    const float* bias_part; int nb_parts, accumulate_bias;      // bias column sums left by wgrad_tr_kernel: [nb_parts][Cout], summed in order by ONE block
 };
 
 template <typename T>
 __device__ __forceinline__ void finish_body(const FinishArgs& f, const T* __restrict__ dy, float* __restrict__ db, int64_t P, int y_ps, int y_co,
                                             int64_t rows_per_block, int bid, float* scratch) {
     if (bid >= f.n_red) {
+        if (f.bias_part) {
+            // dbias (+)= sum of the per-slice column sums, fixed order (deterministic; the column-sum route below ends in atomics)
+            for (int co = threadIdx.x; co < f.Cout; co += 256) {
+                float s0 = 0.f, s1 = 0.f;
+                int k = 0;
+                for (; k + 1 < f.nb_parts; k += 2) { s0 += f.bias_part[(int64_t)k * f.Cout + co]; s1 += f.bias_part[(int64_t)(k + 1) * f.Cout + co]; }
+                if (k < f.nb_parts) s0 += f.bias_part[(int64_t)k * f.Cout + co];
+                db[co] = f.accumulate_bias ? db[co] + (s0 + s1) : (s0 + s1);
+            }
+            return;
+        }
         colsum_body<T>(dy, db, P, f.Cout, y_ps, y_co, rows_per_block, bid - f.n_red, scratch);
         return;
     }
@@ -1480,11 +1532,36 @@ int fill_args(const hesic_conv_desc* d, WgArgs& a) {
 
 }  // namespace
 
+// ---- bias gradient through wgrad_tr_kernel (see WgArgs::bias_part): room for [nsplit][stride^2][Cout] floats behind the K-slice partials
+static int64_t bias_part_bytes(const hesic_conv_desc* d, const WgArgs& a) { return (int64_t)a.nsplit * 4 * d->Cout * 4; }
+// the launch conditions of wgrad_tr_kernel, shared by the callers that have to agree on who produced the bias sums
+static bool wgrad_tr_path(const hesic_conv_desc* d, const WgArgs& a) {
+    bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
+    for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
+    const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
+    return d->dtype == HESIC_BF16 && prefix && a.Q < (1ll << 31) && off32;
+}
+// point a.bias_part behind the weight partials in ws and list the taps whose blocks sum dY's columns; false: no such tap set
+static bool setup_bias_part(const hesic_conv_desc* d, WgArgs& a, void* ws) {
+    static const bool off = getenv("HESIC_WGRAD_BIAS_COLSUM") != nullptr;      // A/B switch: the separate column-sum blocks of rounds 1-3
+    a.bias_part = nullptr; a.nb_taps = 0;
+    if (off || !wgrad_tr_path(d, a) || a.ntaps < 1) return false;
+    if (!d->transposed) { a.nb_taps = 1; a.b_tap[0] = 0; }
+    else {
+        if (d->tap_mask_lo || d->pad + d->stride > d->KH || d->pad + d->stride > d->KW) return false;
+        for (int ry = 0; ry < d->stride; ++ry)
+            for (int rx = 0; rx < d->stride; ++rx) a.b_tap[a.nb_taps++] = (int8_t)((d->pad + ry) * d->KW + d->pad + rx);
+        if (a.nb_taps > 4) { a.nb_taps = 0; return false; }
+    }
+    a.bias_part = (float*)ws + (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin;
+    return true;
+}
+
 extern "C" int64_t hesic_conv2d_wgrad_ws_bytes(const hesic_conv_desc* d) {
     if (!d || d->KH * d->KW > 25) return 0;
     WgArgs a;
     fill_args(d, a);
-    return (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4;
+    return (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
 }
 
 extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
@@ -1550,7 +1627,7 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
 
 // finishing pass of one layer: the block layout of wgrad_finish_kernel; returns the number of bias column-sum blocks behind the n_red reduce blocks
 static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws, float* dw, int accumulate, bool with_bias, FinishArgs& f,
-                       int64_t& P, int64_t& rpb) {
+                       int64_t& P, int64_t& rpb, int accumulate_bias = 1) {
     const int T_all = d->KH * d->KW;
     memset(&f, 0, sizeof(f));
     f.ws = (const float*)ws; f.dw = dw; f.nsplit = a.nsplit; f.ntaps = a.ntaps; f.T_all = T_all; f.Cout = d->Cout; f.Cin = d->Cin;
@@ -1566,6 +1643,10 @@ static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws
     f.n_red = tiles * f.tap_groups;
     P = (int64_t)d->B * d->Ho * d->Wo;
     rpb = P / 256 > 0 ? (P + 255) / 256 : 1;
+    if (with_bias && a.bias_part) {                   // wgrad_tr_kernel left the column sums: one block adds them up
+        f.bias_part = a.bias_part; f.nb_parts = a.nsplit * a.nb_taps; f.accumulate_bias = accumulate_bias;
+        return 1;
+    }
     return with_bias ? (int)((P + rpb - 1) / rpb) : 0;
 }
 
@@ -1581,17 +1662,15 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     HESIC_CHECK_ARG(d->KH * d->KW <= 25, "conv2d_wgrad_direct: at most 25 taps");
     WgArgs a;
     fill_args(d, a);
-    const int64_t need = (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4;
+    const int64_t need = (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
     HESIC_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad_direct: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     hipStream_t st = (hipStream_t)stream;
     a.x = x; a.dy = dy; a.out = (float*)ws;
     const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-    bool prefix = true;
-    for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
-    const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
-    float* zero_me = (dbias && !accumulate) ? dbias : nullptr;       // accumulate: the caller's buffer already holds a value
+    const bool bias_in_tr = setup_bias_part(d, a, ws);               // always (the partial-only call has no dbias, its finishing call does)
+    float* zero_me = (dbias && !accumulate && !bias_in_tr) ? dbias : nullptr;       // accumulate: the caller's buffer already holds a value
     bool db_zeroed = false;
-    if (d->dtype == HESIC_BF16 && prefix && a.Q < (1ll << 31) && off32) {
+    if (wgrad_tr_path(d, a)) {
         launch_wgrad_tr(a, blocks, st, zero_me, zero_me ? d->Cout : 0);
         db_zeroed = true;
     } else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
@@ -1602,7 +1681,7 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     if (a.ntaps < T_all && !accumulate) zero_async(dw, (int64_t)T_all * d->Cout * d->Cin, st);      // dead taps of a masked conv
     FinishArgs f;
     int64_t P, rpb;
-    const int n_col = make_finish(d, a, ws, dw, accumulate, dbias != nullptr, f, P, rpb);
+    const int n_col = make_finish(d, a, ws, dw, accumulate, dbias != nullptr, f, P, rpb, accumulate);
     if (d->dtype == HESIC_BF16)
         hipLaunchKernelGGL(wgrad_finish_kernel<bf16_t>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const bf16_t*)dy, dbias, P,
                            d->y_pix_stride, d->y_c_off, rpb);
@@ -1879,9 +1958,10 @@ extern "C" int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* d
             WgArgs a;
             fill_args(d, a);
             FinishExtra& e = fb.e[j];
-            const int n_col = make_finish(d, a, ws[j0 + j], dw[j0 + j], accumulate, dbias[j0 + j] != nullptr, fb.f[j], e.P, e.rpb);
+            const bool bias_in_tr = setup_bias_part(d, a, (void*)ws[j0 + j]);      // the same decision hesic_conv2d_wgrad_partial took
+            const int n_col = make_finish(d, a, ws[j0 + j], dw[j0 + j], accumulate, dbias[j0 + j] != nullptr, fb.f[j], e.P, e.rpb, accumulate);
             if (a.ntaps < d->KH * d->KW && !accumulate) zero_async(dw[j0 + j], (int64_t)d->KH * d->KW * d->Cout * d->Cin, st);
-            if (dbias[j0 + j] && !accumulate) zero_async(dbias[j0 + j], d->Cout, st);
+            if (dbias[j0 + j] && !accumulate && !bias_in_tr) zero_async(dbias[j0 + j], d->Cout, st);
             e.dy = dy[j0 + j]; e.db = dbias[j0 + j]; e.y_ps = d->y_pix_stride; e.y_co = d->y_c_off;
             fb.start[j + 1] = fb.start[j] + fb.f[j].n_red + n_col;
         }

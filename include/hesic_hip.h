@@ -168,6 +168,8 @@ int hesic_unpack_conv_wgrad(const float* dw_packed, const float* mask, float* dw
  * K-slice reduce, the layout change and the bias column sums in ONE finishing launch; accumulate != 0: dw += ..., dbias += ...
  * (the gradients of a training step live in one flat buffer that is cleared once per step; a weight used twice per step --
  * encoder1, newnet1.py:726,754 -- simply adds twice).  Dead taps of a masked conv are left untouched when accumulating.  */
+/* bf16 storage: the bias column sums are formed inside the split-K launch (one more MFMA per fragment against ones in the blocks of one tap)
+ * and added up in a fixed order by the finishing launch -- deterministic, no second pass over dy.                        */
 int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
                               void* ws, int64_t ws_bytes, void* stream);
 /* Only the first of its two launches -- the split-K MFMA kernel that leaves the fp32 partial tiles in ws -- for profiling

@@ -1,7 +1,7 @@
 """Weight gradients of the wide convs (the backward pass of newtrain1.py:85-96): the finishing passes of several layers in one launch
 (hesic_conv2d_wgrad_finish_batched) against one hesic_conv2d_wgrad_direct call per layer.  Both sum the K slices of a value in the
 same fixed order, so dW is compared bit for bit (also when a weight receives two gradients per step, encoder1); the bias column
-sums end in fp32 atomics in both forms: 1e-5 relative."""
+sums are per-slice partials of the weight-gradient kernel added in a fixed order: bit for bit as well, and checked against torch."""
 import ctypes as C
 
 import pytest
@@ -69,7 +69,11 @@ def test_batched_finish_equals_the_per_layer_launches():
         assert torch.equal(bat_dw[i], ref_dw[i]), f"layer {i}: dW differs"
         assert float((ref_dw[i] - 0.25).abs().max()) > 1e-3
         if ref_db[i] is not None:
-            assert float((bat_db[i] - ref_db[i]).abs().max()) <= 1e-5 * float(ref_db[i].abs().max())
+            # the column sums of dY come out of the weight-gradient kernel itself (a fragment of ones on the matrix cores, per-slice
+            # partials summed in a fixed order): deterministic, and equal to the plain fp32 sum up to the summation order
+            assert torch.equal(bat_db[i], ref_db[i]), f"layer {i}: dbias differs"
+            want = layers[i][2].float().sum((0, 2, 3)) - 0.5
+            assert float((bat_db[i] - want).abs().max()) <= 2e-5 * float(want.abs().max() + 1.0), f"layer {i}: dbias vs torch"
 
 
 def test_batched_finish_rejects_two_jobs_on_one_gradient():
