@@ -119,4 +119,6 @@ def test_trainer_step_is_the_same_with_and_without_the_batched_finish():
     assert l0 == l1
     assert float(g1.abs().max()) > 0
     assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
-    assert float((p0 - p1).abs().max()) <= 1e-5 * float(p1.abs().max())
+    # parameters after the first Adam step move by lr * g / (|g| + eps): compared where the gradient is not within rounding of zero
+    big = g1.abs() > 1e-4 * float(g1.abs().max())
+    assert float((p0 - p1)[big].abs().max()) <= 1e-5 * float(p1.abs().max())
