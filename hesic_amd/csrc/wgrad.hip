@@ -1500,12 +1500,14 @@ int pick_splits(int64_t Q, int bk, int tiles) {
     // aim at ~384 blocks (measured best on MI355X for the step as a whole: every extra slice is another fp32 partial tile
     // to write and reduce), at least 4 K-steps per block
     static const int target0 = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
-    // The layers with Q >= 100000 pixels (128 -> 128 5x5 on 256^2 inputs at B=8: 25 tap blocks per slice): 16 slices = 400 blocks leave 22 % of
+    // The layers with many pixels (first measured from Q >= 100000 on: 128 -> 128 5x5 on 256^2 inputs at B=8, 25 tap blocks per slice): 16 slices = 400 blocks leave 22 % of
     // the 512 block slots (256 CUs x 2) empty for the whole launch, 21 slices = 525 blocks run a second round for 13 of them; 20 slices = 500
     // blocks fill one round.  Training step, same box, alternating runs (ms): 384: 10.65 / 10.66 / 10.48 | 448: 10.70 (earlier box) | 475: 10.57 |
     // 500: 10.53 / 10.53 / 10.33 / 10.33 | 512: 11.01 (earlier box) | 1000: 10.64; 500 for EVERY layer: 10.48 (no gain).  0 = off (A/B).
     static const int big_target = getenv("HESIC_WGRAD_BLOCKS_BIG") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG")) : 500;
-    const int target = (big_target && Q >= 100000) ? big_target : target0;
+    // from which pixel count on (same box, alternating runs, ms): 100000: 10.62 / 10.61 | 30000 (adds the 128 -> 128 layers on 128^2 inputs): 10.57 / 10.59 | 8000: 10.71
+    static const int64_t big_q = getenv("HESIC_WGRAD_BIG_Q") ? atoll(getenv("HESIC_WGRAD_BIG_Q")) : 30000;      // A/B switch
+    const int target = (big_target && Q >= big_q) ? big_target : target0;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
     if (s > maxs) s = maxs;
