@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dump", default="", help="save the layer output here (to compare A/B variants bit for bit)")
     ap.add_argument("--hilo", action="store_true", help="the bf16x3 form of conv2 / conv3 / plain: hi/lo operand pairs, fused hi/lo GDN")
+    ap.add_argument("--cin", type=int, default=128, help="--layer plain / deconv_plain: input channels")
+    ap.add_argument("--cout", type=int, default=128, help="--layer plain / deconv_plain: output channels")
+    ap.add_argument("--stride", type=int, default=2, help="--layer plain: stride (kernel 5x5)")
     ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph (no host launch cost in the figure)")
     args = ap.parse_args()
     import hesic_amd
@@ -29,13 +32,15 @@ def main():
     hesic_amd.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)
     B, S = args.batch, args.size
-    x = (torch.randn(B, 128, S, S, device="cuda") * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ci, co = (args.cin, args.cout) if args.layer in ("plain", "deconv_plain") else (128, 128)
+    x = (torch.randn(B, ci, S, S, device="cuda") * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if args.layer in ("conv2", "conv3", "plain"):
-        layer, g = conv(128, 128).cuda(), GDN(128).cuda()
-        flops = 2.0 * B * (S // 2) ** 2 * 128 * 128 * 25 + (0 if args.layer == "plain" else 2.0 * B * (S // 2) ** 2 * 128 * 128)
+        st = args.stride if args.layer == "plain" else 2
+        layer, g = conv(ci, co, stride=st).cuda(), GDN(128).cuda()
+        flops = 2.0 * B * (S // st) ** 2 * ci * co * 25 + (0 if args.layer == "plain" else 2.0 * B * (S // 2) ** 2 * 128 * 128)
     else:
-        layer, g = deconv(128, 128).cuda(), GDN(128, inverse=True).cuda()
-        flops = 2.0 * B * S * S * 128 * 128 * 25 + 2.0 * B * (2 * S) ** 2 * 128 * 128
+        layer, g = deconv(ci, co).cuda(), GDN(128, inverse=True).cuda()
+        flops = 2.0 * B * S * S * ci * co * 25 + (0 if args.layer == "deconv_plain" else 2.0 * B * (2 * S) ** 2 * 128 * 128)
     f = (lambda: layer.run(x)) if args.layer in ("plain", "deconv_plain") else (lambda: layer.run_gdn(x, g))
     if args.hilo:
         xf = torch.randn(B, 128, S, S, device="cuda") * 0.5
@@ -71,7 +76,7 @@ def main():
         with torch.no_grad():
             torch.save(f().float().cpu(), args.dump)
     us = e0.elapsed_time(e1) / args.iters * 1e3
-    print(f"{args.layer} B={B} in {S}x{S}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   PHASE4={os.environ.get('HESIC_IGEMM_PHASE4', '1')} WS={os.environ.get('HESIC_IGEMM_WS', '0')} hilo={int(args.hilo)} BM256_HILO={os.environ.get('HESIC_IGEMM_BM256_HILO', '0')}")
+    print(f"{args.layer} {ci}->{co} B={B} in {S}x{S} BM={os.environ.get('HESIC_IGEMM_BM', 'auto')}: {us:.1f} us  {flops / us / 1e6:.0f} TFLOP/s   PHASE4={os.environ.get('HESIC_IGEMM_PHASE4', '1')} WS={os.environ.get('HESIC_IGEMM_WS', '0')} hilo={int(args.hilo)} BM256_HILO={os.environ.get('HESIC_IGEMM_BM256_HILO', '0')}")
 
 
 if __name__ == "__main__":
