@@ -939,6 +939,15 @@ __global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtyp
     else im2col_narrow_body<float>((const float*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
 }
 // dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
+// dbias[co] = sum_s bpart[s][co] (the column sums wgrad_tr_kernel formed next to the 1x1 weight-gradient GEMM), fixed order
+__global__ void nw_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ db, int nsplit) {
+    const int co = threadIdx.x;           // 128 threads
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nsplit; k += 2) { s0 += bpart[k * 128 + co]; s1 += bpart[(k + 1) * 128 + co]; }
+    if (k < nsplit) s0 += bpart[k * 128 + co];
+    db[co] = s0 + s1;
+}
 __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
     // one wave per output value (the K split of this route is up to 256 deep: a serial sum per thread was 74 us)
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1726,7 +1735,7 @@ extern "C" int64_t hesic_sconv2d_wgrad_ws_bytes(const hesic_sconv_desc* d) {
     nw_gemm_desc(Q, g);
     WgArgs a;
     fill_args(&g, a);
-    return (Q * 96 * 2 + 255) / 256 * 256 + (int64_t)a.nsplit * 128 * 96 * 4;
+    return (Q * 96 * 2 + 255) / 256 * 256 + (int64_t)a.nsplit * 128 * 96 * 4 + (int64_t)a.nsplit * 128 * 4;      // im2col matrix, weight partials, bias partials
 }
 
 extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
@@ -1763,8 +1772,17 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         WgArgs a2;
         fill_args(&g, a2);
         a2.x = P; a2.dy = conv1 ? dy : x; a2.out = part;
+        // conv1: the GEMM's "dY" operand IS dy (128 channels, 134 MB at B=8 512^2) -- its column sums (the bias gradient) come out of the same
+        // launch (WgArgs::bias_part) instead of a second pass over it
+        static const bool bias_colsum = getenv("HESIC_WGRAD_BIAS_COLSUM") != nullptr;      // A/B switch
+        float* bpart = part + (int64_t)a2.nsplit * 128 * 96;
+        if (conv1 && dbias && !bias_colsum) { a2.bias_part = bpart; a2.nb_taps = 1; a2.b_tap[0] = 0; }
         launch_wgrad_tr(a2, (int64_t)a2.ntaps * a2.co_tiles * a2.ci_tiles * a2.nsplit, st);
         hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, a2.nsplit, 75);
+        if (a2.bias_part) {
+            hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(128), 0, st, (const float*)bpart, dbias, a2.nsplit);
+            dbias = nullptr;                          // done: skip the column-sum pass below
+        }
     } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
         d->H == 2 * d->Ho && d->W == 2 * d->Wo) {
         // conv1: WIDE = dy (output grid), NARROW = x
