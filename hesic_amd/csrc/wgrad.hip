@@ -938,6 +938,46 @@ __global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtyp
     if (n_dtype == HESIC_BF16) im2col_narrow_body<bf16_t>((const bf16_t*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
     else im2col_narrow_body<float>((const float*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
 }
+// The same matrix with one THREAD per pixel row: a wave's lanes are 64 consecutive pixels of an image row, so each of the 75 gathers reads
+// 64 values at stride 2 from ONE image row (4 cache lines per instruction; the chunk-per-thread form above spreads every instruction over
+// ~15 rows x 5 pixels), and the row leaves as twelve 16-byte stores.  Same values, same layout.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_narrow_rows_kernel(const T* __restrict__ narrow, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
+                                                                 bf16_t* __restrict__ P, int64_t Q, int QH, int QW, int NH, int NW, FastDiv dqw, FastDiv dqh) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const uint32_t r1 = fdiv((uint32_t)q, dqw);
+    const int qx = (int)((uint32_t)q - r1 * (uint32_t)QW);
+    const uint32_t b = fdiv(r1, dqh);
+    const int qy = (int)(r1 - b * (uint32_t)QH);
+    const T* base = narrow + (int64_t)b * ns_b + (int64_t)(2 * qy - 2) * ns_y + (int64_t)(2 * qx - 2) * ns_x;
+    float v[76];
+    v[75] = 0.f;
+#pragma unroll
+    for (int nc = 0; nc < 3; ++nc)
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const bool rowok = (unsigned)(2 * qy - 2 + ky) < (unsigned)NH;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const bool ok = rowok && (unsigned)(2 * qx - 2 + kx) < (unsigned)NW;
+                const float t = elem<T>::ld(ok ? base + nc * ns_c + ky * ns_y + kx * ns_x : narrow);      // padding: element 0, replaced by zero
+                v[nc * 25 + ky * 5 + kx] = ok ? t : 0.f;
+            }
+        }
+    u32x4* dst = (u32x4*)(P + q * 96);
+#pragma unroll
+    for (int ck = 0; ck < 12; ++ck) {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        uint32_t* w4 = (uint32_t*)&o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int n = ck * 8 + 2 * h;
+            if (n < 75) w4[h] = pack_bf2(v[n], v[n + 1]);
+        }
+        dst[ck] = o;
+    }
+}
 // dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
 // dbias[co] = sum_s bpart[s][co] (the column sums wgrad_tr_kernel formed next to the 1x1 weight-gradient GEMM), fixed order
 __global__ void nw_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ db, int nsplit) {
@@ -1773,12 +1813,19 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         const int QH = conv1 ? d->Ho : d->H, QW = conv1 ? d->Wo : d->W, NH = conv1 ? d->H : d->Ho, NW = conv1 ? d->W : d->Wo;
         bf16_t* P = (bf16_t*)ws;
         float* part = (float*)((unsigned char*)ws + (Q * 96 * 2 + 255) / 256 * 256);
-        if (conv1)
-            hipLaunchKernelGGL(im2col_narrow_kernel, dim3(grid_for(Q * 12, 256)), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y,
-                               d->xs_x, P, d->B, QH, QW, NH, NW, 3);
-        else
-            hipLaunchKernelGGL(im2col_narrow_kernel, dim3(grid_for(Q * 12, 256)), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y,
-                               d->ys_x, P, d->B, QH, QW, NH, NW, 3);
+        static const bool chunk_form = getenv("HESIC_IM2COL_CHUNKS") != nullptr;      // A/B switch: the thread-per-chunk kernel of rounds 1-3
+        const void* nimg = conv1 ? x : dy;
+        const int ndt = conv1 ? d->x_dtype : d->y_dtype;
+        const int64_t nsb = conv1 ? d->xs_b : d->ys_b, nsc = conv1 ? d->xs_c : d->ys_c, nsy = conv1 ? d->xs_y : d->ys_y, nsx = conv1 ? d->xs_x : d->ys_x;
+        if (!chunk_form && Q < (1ll << 31)) {
+            const FastDiv dqw = make_fastdiv((uint32_t)QW), dqh = make_fastdiv((uint32_t)QH);
+            const dim3 grid((unsigned)((Q + 255) / 256));
+            if (ndt == HESIC_BF16)
+                hipLaunchKernelGGL(im2col_narrow_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)nimg, nsb, nsc, nsy, nsx, P, Q, QH, QW, NH, NW, dqw, dqh);
+            else
+                hipLaunchKernelGGL(im2col_narrow_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)nimg, nsb, nsc, nsy, nsx, P, Q, QH, QW, NH, NW, dqw, dqh);
+        } else
+            hipLaunchKernelGGL(im2col_narrow_kernel, dim3(grid_for(Q * 12, 256)), dim3(256), 0, st, nimg, ndt, nsb, nsc, nsy, nsx, P, d->B, QH, QW, NH, NW, 3);
         hesic_conv_desc g;
         nw_gemm_desc(Q, g);
         WgArgs a2;
