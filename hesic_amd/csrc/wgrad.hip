@@ -990,14 +990,25 @@ __global__ __launch_bounds__(256) void im2col_narrow_rows_kernel(const T* __rest
     }
 }
 // dw[wc*NCT + n] = sum_s part[s][wc][n]  (NCT = NC*25 real columns of the 96)
-// dbias[co] = sum_s bpart[s][co] (the column sums wgrad_tr_kernel formed next to the 1x1 weight-gradient GEMM), fixed order
-__global__ void nw_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ db, int nsplit) {
-    const int co = threadIdx.x;           // 128 threads
-    float s0 = 0.f, s1 = 0.f;
-    int k = 0;
-    for (; k + 1 < nsplit; k += 2) { s0 += bpart[k * 128 + co]; s1 += bpart[(k + 1) * 128 + co]; }
-    if (k < nsplit) s0 += bpart[k * 128 + co];
-    db[co] = s0 + s1;
+// dbias[co] = sum_s bpart[s][co] (the column sums wgrad_tr_kernel formed next to the 1x1 weight-gradient GEMM), fixed order: 8 slice groups x
+// 128 couts per block, eight loads in flight per thread, the groups meet in LDS (one thread per cout walking up to 256 slices serially: 31 us)
+__global__ __launch_bounds__(1024) void nw_bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ db, int nsplit) {
+    __shared__ float red[8][128];
+    const int co = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = grp * 8; k0 < nsplit; k0 += 64) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nsplit) s[u] += bpart[(k0 + u) * 128 + co];
+    }
+    red[grp][co] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (grp == 0) {
+        float t = red[0][co];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][co];
+        db[co] = t;
+    }
 }
 __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
     // one wave per output value (the K split of this route is up to 256 deep: a serial sum per thread was 74 us)
@@ -1850,7 +1861,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         launch_wgrad_tr(a2, (int64_t)a2.ntaps * a2.co_tiles * a2.ci_tiles * a2.nsplit, st);
         hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, a2.nsplit, 75);
         if (a2.bias_part) {
-            hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(128), 0, st, (const float*)bpart, dbias, a2.nsplit);
+            hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)bpart, dbias, a2.nsplit);
             dbias = nullptr;                          // done: skip the column-sum pass below
         }
     } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
