@@ -1288,6 +1288,79 @@ __global__ __launch_bounds__(256) void gdn_bwd_param_small_kernel(const void* __
     }
 }
 
+// The three passes above in ONE for the 3-channel image-side GDNs (pre_gdn / after_gdn, newnet1.py:630,669, under autograd): thread = pixel,
+// gamma' / beta' in registers, dn never leaves them -- dx and the C*C + C parameter sums come out of one read of x and gy (the passes
+// took 42 + ~30 + 31 us per GDN on a 512^2 batch-8 image and wrote / re-read two fp32 workspaces).  Same formulas in the same order:
+// dx is bit-identical; the parameter sums keep the per-thread accumulation and the one-atomic-per-block finish of the kernel above.
+template <int C, typename T>
+__global__ __launch_bounds__(256) void gdn_bwd_small_fused_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ beta,
+                                                                  const float* __restrict__ gamma, T* __restrict__ dx, float* __restrict__ dgp,
+                                                                  float* __restrict__ dbp, int64_t P, int inverse, float beta_bound) {
+    float gm[C][C], bt[C], g[C][C], bsum[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        bt[i] = reparam(beta[i], beta_bound);
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) { gm[i][j] = reparam(gamma[i * C + j], kGammaBound); g[i][j] = 0.f; }
+    }
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        float xv[C], gv[C], sq[C], dn[C], d0[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            xv[c] = elem<T>::ld(x + p * C + c);
+            gv[c] = elem<T>::ld(gy + p * C + c);
+            sq[c] = xv[c] * xv[c];
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            float norm = bt[i];
+#pragma unroll
+            for (int j = 0; j < C; ++j) norm += gm[i][j] * xv[j] * xv[j];
+            if (inverse) {
+                const float sqn = sqrtf(norm);
+                dn[i] = 0.5f * gv[i] * xv[i] / sqn;
+                d0[i] = gv[i] * sqn;
+            } else {
+                const float rs = rsqrtf(norm);
+                dn[i] = -0.5f * gv[i] * xv[i] * rs * rs * rs;
+                d0[i] = gv[i] * rs;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float sj = 0.f;
+#pragma unroll
+            for (int k = 0; k < C; ++k) sj += gm[k][j] * dn[k];
+            elem<T>::st(dx + p * C + j, d0[j] + 2.f * xv[j] * sj);
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            bsum[i] += dn[i];
+#pragma unroll
+            for (int j = 0; j < C; ++j) g[i][j] = fmaf(dn[i], sq[j], g[i][j]);
+        }
+    }
+    __shared__ float red[4][C * C + C];
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float b = wave_sum(bsum[i]);
+        if ((threadIdx.x & 63) == 0) red[wv][C * C + i] = b;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float v = wave_sum(g[i][j]);
+            if ((threadIdx.x & 63) == 0) red[wv][i * C + j] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C * C + C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < C * C) atomicAdd(dgp + threadIdx.x, v);
+        else atomicAdd(dbp + (threadIdx.x - C * C), v);
+    }
+}
+
 __global__ void gdn_bwd_chain_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, const float* __restrict__ dgp,
                                      const float* __restrict__ dbp, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                      float beta_bound, int accumulate) {
@@ -2016,6 +2089,16 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     float* dgp = dx0 + P * C;
     float* dbp = dgp + (int64_t)C * C;
     zero_async(dgp, (int64_t)C * C + C, st);
+    static const bool small_split = getenv("HESIC_GDN3_BWD_SPLIT") != nullptr;      // A/B switch: the three passes
+    if (C == 3 && !small_split) {
+        const dim3 g3(grid_for(P, 256 * 2, 1024));      // 128 blocks (the parameter pass's grid: few atomics) left half the CUs idle: 57.9 us
+        if (dtype == HESIC_BF16)
+            hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, bf16_t>), g3, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dgp, dbp, P, inverse, bound);
+        else
+            hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, float>), g3, dim3(256), 0, st, (const float*)x, (const float*)dy, beta, gamma, (float*)dx, dgp, dbp, P, inverse, bound);
+        hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(1), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate);
+        HESIC_LAUNCH_RETURN("gdn_backward");
+    }
     hipLaunchKernelGGL(gdn_bwd_dn_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, dy, beta, gamma, dn, dx0, P, C, inverse, bound, dtype);
     hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, gamma, dn, dx0, dx, P, C, dtype);
     const int gx = (C * C + 255) / 256;
