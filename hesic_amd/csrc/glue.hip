@@ -391,6 +391,19 @@ __global__ void log_bwd_kernel(const float* __restrict__ lik, float scale, float
 }
 __global__ void sq_diff_bwd_kernel(const SqArgs q, float scale, float* __restrict__ g) {
     const int64_t n = (int64_t)q.B * q.C * q.H * q.W;
+    const int64_t hw = (int64_t)q.H * q.W;
+    auto dense = [&](const int64_t* st) { return st[3] == 1 && st[2] == q.W && st[1] == hw && st[0] == hw * q.C; };
+    if (q.a_dt == HESIC_F32 && q.b_dt == HESIC_F32 && dense(q.as) && dense(q.bs) && (n & 3) == 0 && !(((uintptr_t)q.a | (uintptr_t)q.b | (uintptr_t)g) & 15)) {
+        // both images planar fp32 and dense (x_hat of a 512^2 batch against x): 16-byte lanes, no index arithmetic (the loop below: 26 us on 25 MB)
+        const f32x4* a4 = (const f32x4*)q.a;
+        const f32x4* b4 = (const f32x4*)q.b;
+        f32x4* g4 = (f32x4*)g;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+            const f32x4 va = a4[i], vb = b4[i];
+            g4[i] = f32x4{scale * (va.x - vb.x), scale * (va.y - vb.y), scale * (va.z - vb.z), scale * (va.w - vb.w)};
+        }
+        return;
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         const int x = r % q.W; r /= q.W;
