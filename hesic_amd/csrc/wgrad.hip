@@ -1292,10 +1292,13 @@ __global__ __launch_bounds__(256) void gdn_bwd_param_small_kernel(const void* __
 // gamma' / beta' in registers, dn never leaves them -- dx and the C*C + C parameter sums come out of one read of x and gy (the passes
 // took 42 + ~30 + 31 us per GDN on a 512^2 batch-8 image and wrote / re-read two fp32 workspaces).  Same formulas in the same order:
 // dx is bit-identical; the parameter sums keep the per-thread accumulation and the one-atomic-per-block finish of the kernel above.
-template <int C, typename T>
+// PL: planar (B, C, HW) tensors -- blockIdx.y = image, P = HW, channel stride HW; otherwise NHWC with P = all pixels.
+template <int C, typename T, bool PL = false>
 __global__ __launch_bounds__(256) void gdn_bwd_small_fused_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ beta,
                                                                   const float* __restrict__ gamma, T* __restrict__ dx, float* __restrict__ dgp,
                                                                   float* __restrict__ dbp, int64_t P, int inverse, float beta_bound) {
+    const int64_t cs = PL ? P : 1, ps = PL ? 1 : C;              // element strides of channel and pixel
+    if (PL) { x += blockIdx.y * (int64_t)C * P; gy += blockIdx.y * (int64_t)C * P; dx += blockIdx.y * (int64_t)C * P; }
     float gm[C][C], bt[C], g[C][C], bsum[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
@@ -1308,8 +1311,8 @@ __global__ __launch_bounds__(256) void gdn_bwd_small_fused_kernel(const T* __res
         float xv[C], gv[C], sq[C], dn[C], d0[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            xv[c] = elem<T>::ld(x + p * C + c);
-            gv[c] = elem<T>::ld(gy + p * C + c);
+            xv[c] = elem<T>::ld(x + p * ps + c * cs);
+            gv[c] = elem<T>::ld(gy + p * ps + c * cs);
             sq[c] = xv[c] * xv[c];
         }
 #pragma unroll
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(256) void gdn_bwd_small_fused_kernel(const T* __res
             float sj = 0.f;
 #pragma unroll
             for (int k = 0; k < C; ++k) sj += gm[k][j] * dn[k];
-            elem<T>::st(dx + p * C + j, d0[j] + 2.f * xv[j] * sj);
+            elem<T>::st(dx + p * ps + j * cs, d0[j] + 2.f * xv[j] * sj);
         }
 #pragma unroll
         for (int i = 0; i < C; ++i) {
@@ -2119,6 +2122,28 @@ extern "C" int hesic_gdn_backward_acc(const void* x, const void* dy, const float
     const int rc = hesic_gdn_backward(x, dy, beta, gamma, dx, dbeta, dgamma, ws, P, C, inverse, beta_min, dtype, stream);
     g_gdn_accumulate = 0;
     return rc;
+}
+
+extern "C" int hesic_gdn_backward_planar_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
+                                             float* dgamma, int accumulate, void* ws, int B, int64_t HW, int C, int inverse, float beta_min,
+                                             int dtype, void* stream) {
+    HESIC_CHECK_ARG(x && dy && beta && gamma && dx && dbeta && dgamma && ws && B > 0 && HW > 0, "gdn_backward_planar: bad arguments");
+    HESIC_CHECK_ARG(C == 3, "gdn_backward_planar: built for the 3-channel image-side GDNs");
+    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "gdn_backward_planar: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const float bound = sqrtf(beta_min + kPedestal);
+    float* dgp = (float*)ws;
+    float* dbp = dgp + C * C;
+    zero_async(dgp, C * C + C, st);
+    int gx = grid_for(HW, 256 * 2, 1024);
+    if ((int64_t)gx * B > 2048) gx = (int)(2048 / B > 0 ? 2048 / B : 1);
+    const dim3 g3((unsigned)gx, (unsigned)B);
+    if (dtype == HESIC_BF16)
+        hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, bf16_t, true>), g3, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dgp, dbp, HW, inverse, bound);
+    else
+        hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, float, true>), g3, dim3(256), 0, st, (const float*)x, (const float*)dy, beta, gamma, (float*)dx, dgp, dbp, HW, inverse, bound);
+    hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(1), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate ? 1 : 0);
+    HESIC_LAUNCH_RETURN("gdn_backward_planar");
 }
 
 extern "C" int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* x, const void* dy, void* ws, int64_t ws_bytes, void* stream) {

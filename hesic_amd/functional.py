@@ -1293,6 +1293,44 @@ class _GdnFn(torch.autograd.Function):
         return dx, dbeta, dgamma, None, None
 
 
+class _Gdn3PlanarFn(torch.autograd.Function):
+    """The 3-channel image-side GDN / IGDN (pre_gdn / after_gdn, newnet1.py:630,669) on a planar tensor under autograd: forward
+    ``hesic_gdn_forward_planar``, backward one fused pass (``hesic_gdn_backward_planar_acc``) -- no NHWC copies, planar in and out."""
+
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_min):
+        L.require_cuda(x, beta, gamma)
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y), B, Cc, H * W,
+               int(inverse), float(beta_min), L.dt(x), L.stream())
+        ctx.save_for_backward(x, beta, gamma)
+        ctx.inverse, ctx.beta_min = inverse, beta_min
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, beta, gamma = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        gy = gy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        sb, sg = _slot_for(beta), _slot_for(gamma)
+        direct = sb is not None and sg is not None
+        dbeta = sb.grad if direct else torch.empty_like(beta, dtype=torch.float32)
+        dgamma = sg.grad if direct else torch.empty_like(gamma, dtype=torch.float32)
+        ws = torch.empty(64, dtype=torch.uint8, device=x.device)
+        L.call("hesic_gdn_backward_planar_acc", L.ptr(x), L.ptr(gy), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(dx), L.ptr(dbeta),
+               L.ptr(dgamma), int(direct), L.ptr(ws), B, H * W, Cc, int(ctx.inverse), float(ctx.beta_min), L.dt(x), L.stream())
+        if direct:
+            _slot_done(sb)
+            _slot_done(sg)
+            return dx, None, None, None, None
+        return dx, dbeta, dgamma, None, None
+
+
+GDN3_PLANAR_TRAIN = _os.environ.get("HESIC_GDN3_NHWC_TRAIN") is None      # A/B switch: the NHWC route of rounds 1-3 under autograd
+
+
 def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
     if x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16):
         # image-side GDN on a planar tensor at inference: no NHWC round trip
@@ -1301,6 +1339,9 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
         L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y), B, Cc, H * W,
                int(inverse), float(beta_min), L.dt(x), L.stream())
         return y
+    if (GDN3_PLANAR_TRAIN and x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+            and beta.dtype == torch.float32 and gamma.dtype == torch.float32):
+        return _apply(_Gdn3PlanarFn, x, beta, gamma, inverse, beta_min)
     return _apply(_GdnFn, x, beta, gamma, inverse, beta_min)
 
 

@@ -266,6 +266,12 @@ int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const f
 int hesic_gdn_backward_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx,
                            float* dbeta, float* dgamma, int accumulate, void* ws, int64_t P, int C, int inverse,
                            float beta_min, int dtype, void* stream);
+/* The 3-channel image-side GDNs (pre_gdn / after_gdn, newnet1.py:630,669) under autograd on PLANAR (B, 3, HW) tensors, as
+ * hesic_gdn_forward_planar: dx and the parameter gradients from one pass over x and dy (no NHWC copies on either side, so the conv
+ * behind pre_gdn keeps its planar-input kernel).  ws: at least 64 bytes.  accumulate as hesic_gdn_backward_acc.                    */
+int hesic_gdn_backward_planar_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
+                                  float* dgamma, int accumulate, void* ws, int B, int64_t HW, int C, int inverse, float beta_min, int dtype,
+                                  void* stream);
 
 /* ------------------------------------------------------------------- warp_perspective (row A10)
  * Replaces kornia.warp_perspective(src, M, dsize) (third party; call sites newnet1.py:746,753,767).
