@@ -697,7 +697,9 @@ __global__ void eb_scatter_grads_kernel(const hesic_eb_layout L, const float* __
 // target[q]| with the cumulative's parameters detached, so the only gradient is d/dquantiles = sign(.) * dc/dv.
 __global__ void eb_aux_loss_kernel(const float* __restrict__ params, const float* __restrict__ quantiles, float t_hi,
                                    float* __restrict__ loss, float* __restrict__ dq, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // thread = (channel, quantile): the three evaluations of a channel side by side (one thread per channel walked them in turn: 28 us for 128 channels)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = idx / 3, j = idx - c * 3;
     float part = 0.f;
     if (c < C) {
         const float* raw = params + (int64_t)c * HESIC_EB_PARAM_STRIDE;
@@ -706,14 +708,12 @@ __global__ void eb_aux_loss_kernel(const float* __restrict__ params, const float
         float gp[EB_NP + 1];
 #pragma unroll
         for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
-        for (int j = 0; j < 3; ++j) {
-            const float v = quantiles[c * 3 + j], tgt = j == 0 ? -t_hi : (j == 1 ? 0.f : t_hi);
-            const float diff = eb_logits(q, v, nullptr, nullptr) - tgt;
-            part += fabsf(diff);
-            if (dq) {
-                const float g = eb_logits_bwd(q, raw, v, signf(diff), gp);
-                dq[c * 3 + j] = accumulate ? dq[c * 3 + j] + g : g;
-            }
+        const float v = quantiles[idx], tgt = j == 0 ? -t_hi : (j == 1 ? 0.f : t_hi);
+        const float diff = eb_logits(q, v, nullptr, nullptr) - tgt;
+        part = fabsf(diff);
+        if (dq) {
+            const float g = eb_logits_bwd(q, raw, v, signf(diff), gp);
+            dq[idx] = accumulate ? dq[idx] + g : g;
         }
     }
     part = wave_sum(part);
@@ -780,6 +780,6 @@ extern "C" int hesic_eb_aux_loss(const float* params, const float* quantiles, fl
                                  int accumulate, void* stream) {
     HESIC_CHECK_ARG(params && quantiles && loss && C > 0 && tail_mass > 0.f && tail_mass < 1.f, "eb_aux_loss: bad arguments");
     const float t_hi = logf(2.f / tail_mass - 1.f);
-    hipLaunchKernelGGL(eb_aux_loss_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, quantiles, t_hi, loss, dquantiles, C, accumulate);
+    hipLaunchKernelGGL(eb_aux_loss_kernel, dim3((3 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, quantiles, t_hi, loss, dquantiles, C, accumulate);
     HESIC_LAUNCH_RETURN("eb_aux_loss");
 }
