@@ -1,6 +1,8 @@
-"""ctypes binding of ``libhesic_hip.so`` (C ABI: ``include/hesic_hip.h``).
+"""ctypes binding of ``libhesic_hip.so`` / ``libhesic_hip_f16.so`` (C ABI: ``include/hesic_hip.h``).
 
-The library is built in-tree by ``__graft_entry__.build()`` / ``make -C hesic_amd/csrc``.
+The libraries are built in-tree by ``__graft_entry__.build()`` / ``make -C hesic_amd/csrc`` from the same sources: one per
+16-bit storage / matrix-core operand format (bfloat16: training + inference; IEEE float16: inference).  ``use_h16()`` selects
+which one ``call()`` goes to; fp32 tensors are served by either.
 There is NO fallback: if the shared object is missing or a kernel call fails, the caller gets
 an exception -- the product path never routes through the CPU oracle.
 """
@@ -14,9 +16,11 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhesic_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "libhesic_hip_f16.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hesic_hip.h")
 
-F32, BF16 = 0, 1
+F32, H16 = 0, 1
+BF16 = H16       # historical name: the library's 16-bit format (hesic_h16_format())
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 EB_PARAM_STRIDE = 64
 
@@ -66,6 +70,7 @@ class GmmDesc(C.Structure):
 _P = C.POINTER
 _SIGS = {
     "hesic_abi_version": ([], _i32),
+    "hesic_h16_format": ([], _i32),
     "hesic_last_error": ([], C.c_char_p),
     "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weights_batched": ([_vp, _i32, _i32, _vp], _i32),
@@ -150,7 +155,9 @@ _SIGS = {
     "hesic_im2col_hilo": ([_vp, _P(_i64), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
 }
 
-_lib = None
+_libs = {}                      # torch 16-bit dtype -> CDLL
+_h16 = torch.bfloat16           # the active 16-bit format
+_lib = None                     # the active library (None until first use)
 
 
 def declared_symbols():
@@ -160,21 +167,49 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(hesic_[a-z0-9_]+)\s*\(", text)))
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def _load(h16):
+    l = _libs.get(h16)
+    if l is None:
+        path = LIB_PATH_F16 if h16 == torch.float16 else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"hesic_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"hesic_amd: {path} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C hesic_amd/csrc`. There is no CPU fallback.")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)
             fn.argtypes, fn.restype = args, res
         if l.hesic_abi_version() != 1:
-            raise RuntimeError("hesic_amd: libhesic_hip.so ABI version mismatch")
-        _lib = l
+            raise RuntimeError(f"hesic_amd: {os.path.basename(path)} ABI version mismatch")
+        if l.hesic_h16_format() != (1 if h16 == torch.float16 else 0):
+            raise RuntimeError(f"hesic_amd: {os.path.basename(path)} was built for the other 16-bit format")
+        _libs[h16] = l
+    return l
+
+
+def lib(h16=None):
+    """The active library (or the one built for ``h16`` = torch.bfloat16 / torch.float16)."""
+    global _lib
+    if h16 is not None:
+        return _load(h16)
+    if _lib is None:
+        _lib = _load(_h16)
     return _lib
+
+
+def use_h16(dtype):
+    """Select the 16-bit format (torch.bfloat16 or torch.float16) -- i.e. the library -- every following call goes to."""
+    global _h16, _lib
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("the 16-bit storage format is torch.bfloat16 or torch.float16")
+    if dtype != _h16 or _lib is None:
+        _lib = _load(dtype)
+        _h16 = dtype
+
+
+def h16_dtype():
+    """torch dtype of HESIC_H16 storage in the active library."""
+    return _h16
 
 
 def call(name, *args):
@@ -187,9 +222,11 @@ def dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
     if d == torch.float32:
         return F32
-    if d == torch.bfloat16:
-        return BF16
-    raise TypeError(f"hesic_amd: unsupported dtype {d} (float32 or bfloat16)")
+    if d == _h16:
+        return H16
+    if d in (torch.bfloat16, torch.float16):
+        raise TypeError(f"hesic_amd: a {d} tensor while the active 16-bit format is {_h16} (set_compute_dtype selects it)")
+    raise TypeError(f"hesic_amd: unsupported dtype {d} (float32, bfloat16 or float16)")
 
 
 def ptr(t):

@@ -84,7 +84,7 @@ class EntropyModel(nn.Module):
             raise ValueError(f'Invalid quantization mode: "{mode}"')
         if mode == "noise":
             return inputs + self._noise_like(inputs)
-        if inputs.is_cuda and inputs.dim() == 4 and inputs.dtype in (torch.float32, torch.bfloat16):
+        if inputs.is_cuda and inputs.dim() == 4 and inputs.dtype in (torch.float32, torch.bfloat16, torch.float16):
             if mode == "symbols":
                 return Fn.quantize_symbols(inputs, means)
             if means is None:

@@ -7,8 +7,30 @@
 
 #include "../../include/hesic_hip.h"
 
-typedef uint16_t bf16_t;   // raw bfloat16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// ---- the 16-bit storage / matrix-core operand format of THIS build of the library.
+// The same sources build twice: libhesic_hip.so with bfloat16 (HESIC_H16_IS_F16 == 0: training and inference, 8-bit significand, fp32 range)
+// and libhesic_hip_f16.so with IEEE binary16 (== 1: inference, 11-bit significand -- v_mfma_f32_32x32x16_f16 issues at the bf16 rate on
+// gfx950 and honours subnormal inputs, profiles/scripts/micro/f16_probe.hip).  Every kernel goes through the helpers below (h16_t raw bits,
+// h2f / h2f_lo / h2f_hi, pack_h2, mfma_32x32x16_h16), so nothing else knows which format it is; hesic_h16_format() reports it.
+#ifndef HESIC_H16_IS_F16
+#define HESIC_H16_IS_F16 0
+#endif
+typedef uint16_t h16_t;   // raw bits of a 16-bit float (format: see above)
+#if HESIC_H16_IS_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+#define mfma_32x32x16_h16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define H16_ONE_PAIR 0x3c003c00u          /* two 1.0 */
+// squares that go through 16-bit storage inside the fused (I)GDN contractions are scaled by H16_SQ_SCALE (gamma' by its inverse, in
+// hesic_gdn_pack_params*): v^2 * 2^-6 stays finite up to |v| = 2047 where fp16 itself ends at 255
+#define H16_SQ_SCALE 0.015625f
+#define H16_SQ_UNSCALE 64.0f
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
+#define mfma_32x32x16_h16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define H16_ONE_PAIR 0x3f803f80u
+#define H16_SQ_SCALE 1.0f
+#define H16_SQ_UNSCALE 1.0f
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -34,32 +56,51 @@ void hesic_set_error(const char* fmt, ...);
         return 0;                                                              \
     } while (0)
 
-// ---- bf16 <-> f32 (round to nearest even, NaN kept quiet)
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-typedef __bf16 hw_bf2_t __attribute__((ext_vector_type(2)));
+// ---- 16-bit <-> f32 (round to nearest even)
 typedef float hw_f2_t __attribute__((ext_vector_type(2)));
-// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_bf2_t));
+#if HESIC_H16_IS_F16
+typedef _Float16 hw_h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f(h16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// the two halves of a packed pair (element 0 in the low 16 bits)
+__device__ __forceinline__ float h2f_lo(uint32_t p) { return (float)__builtin_bit_cast(hw_h2_t, p)[0]; }
+__device__ __forceinline__ float h2f_hi(uint32_t p) { return (float)__builtin_bit_cast(hw_h2_t, p)[1]; }
+// two values per instruction, round to nearest even; finite inputs beyond the fp16 range saturate at +-65504 instead of turning into
+// infinities (a too-large activation then costs accuracy at that pixel, not a NaN map)
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
+    hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_h2_t));
 }
-__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+#else
+typedef __bf16 hw_h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f(h16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float h2f_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float h2f_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_h2_t));
+}
+#endif
+__device__ __forceinline__ h16_t f2h(float f) { return (h16_t)(pack_h2(f, 0.f) & 0xffffu); }
+// the squares of a fused (I)GDN contraction in 16-bit storage (scaled: see H16_SQ_SCALE; gamma' carries the inverse factor)
+__device__ __forceinline__ uint32_t pack_sq2(float a, float b) { return pack_h2(a * a * H16_SQ_SCALE, b * b * H16_SQ_SCALE); }
 
 template <typename T> struct elem;
 template <> struct elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 };
-template <> struct elem<bf16_t> {
-    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
-    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+template <> struct elem<h16_t> {
+    static __device__ __forceinline__ float ld(const h16_t* p) { return h2f(*p); }
+    static __device__ __forceinline__ void st(h16_t* p, float v) { *p = f2h(v); }
 };
 
 // dtype-erased scalar access for the strided (image-side) kernels
 __device__ __forceinline__ float ld_any(const void* p, int64_t i, int dtype) {
-    return dtype == HESIC_BF16 ? bf2f(((const bf16_t*)p)[i]) : ((const float*)p)[i];
+    return dtype == HESIC_H16 ? h2f(((const h16_t*)p)[i]) : ((const float*)p)[i];
 }
 __device__ __forceinline__ void st_any(void* p, int64_t i, int dtype, float v) {
-    if (dtype == HESIC_BF16) ((bf16_t*)p)[i] = f2bf(v);
+    if (dtype == HESIC_H16) ((h16_t*)p)[i] = f2h(v);
     else ((float*)p)[i] = v;
 }
 

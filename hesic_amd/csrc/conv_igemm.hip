@@ -92,7 +92,7 @@ __device__ __forceinline__ void tap_at(const IgemmArgs& a, const Taps& t, int i,
 }
 
 template <typename T> struct Cfg;
-template <> struct Cfg<bf16_t> {
+template <> struct Cfg<h16_t> {
     static constexpr int CE = 8;    // elements per 16-byte chunk
     static constexpr int CPR = 4;   // chunks per LDS row (BK*2/16)
     static constexpr int RPB = 4;   // LDS rows per 256-byte bank row
@@ -111,7 +111,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return (row * Cfg<T>::CPR + sw) * 16;
 }
 
-__device__ __forceinline__ u32x4 abs_chunk(u32x4 v, bf16_t) {
+__device__ __forceinline__ u32x4 abs_chunk(u32x4 v, h16_t) {
     return u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
 }
 __device__ __forceinline__ u32x4 abs_chunk(u32x4 v, float) {
@@ -241,18 +241,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 wf[MI], xf[NI];
+                h16x8 wf[MI], xf[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    wf[i] = *(const bf16x8*)(ws + lds_off<T>(wm * (BN / 2) + i * 32 + frow, ks * 2 + fh));
+                    wf[i] = *(const h16x8*)(ws + lds_off<T>(wm * (BN / 2) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    xf[j] = *(const bf16x8*)(xs + lds_off<T>(wn * 64 + j * 32 + frow, ks * 2 + fh));
+                    xf[j] = *(const h16x8*)(xs + lds_off<T>(wn * 64 + j * 32 + frow, ks * 2 + fh));
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16_h16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             }
         } else {
             // fp32: lane half h owns k = 16h..16h+15 of the step (any consistent k order is a valid GEMM)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], a.act);
                 unsigned char* dst = smem + prow * OROW + cl * (int)sizeof(T);
                 if constexpr (sizeof(T) == 2) {
-                    *(u32x2*)dst = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *(u32x2*)dst = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
                 } else {
                     *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
                 }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_conv_kernel(const IgemmArgs a)
 }
 
 // ------------------------------------------------------------------------- bf16 fast path (LDS-DMA staging)
-// Same tiling and math as igemm_conv_kernel<bf16_t, BN>, but the tiles go global -> LDS directly with
+// Same tiling and math as igemm_conv_kernel<h16_t, BN>, but the tiles go global -> LDS directly with
 // global_load_lds_dwordx4 (no VGPR round trip, no ds_write), BK is 64 when Cin allows it, and the loads of
 // step s+1 are in flight while step s runs on the matrix cores.  The DMA writes LDS lane-linearly, so the
 // XOR swizzle is applied on the SOURCE side: lane j of a wave instruction fetches the 16-byte chunk that
@@ -365,7 +365,7 @@ constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { retur
 template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS = 0, int HL = 0>
 __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
     constexpr int NTHREADS = NW * 64;          // COMPUTE threads (the epilogue's copy loops stride by this)
-    using T = bf16_t;
+    using T = h16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
     constexpr int CPR = BK * 2 / 16;          // 16-byte chunks per LDS row
     constexpr int RPB = 256 / (BK * 2);       // rows per 256-byte bank row
@@ -588,19 +588,19 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             if constexpr (HL) {
                 // hi/lo operands: per 16-deep k-substep four fragment groups (w_hi, w_lo, x_hi, x_lo) feed 3 * MI * NI MFMAs
                 constexpr int KSH = BK / 32, LO = CPR / 2;
-                bf16x8 wh[2][MI], wl[2][MI], xh[2][NI], xl[2][NI];
+                h16x8 wh[2][MI], wl[2][MI], xh[2][NI], xl[2][NI];
                 auto ldh = [&](int set, int ks) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         const int r = wm * (BN / WM) + i * 32 + frow;
-                        wh[set][i] = *(const bf16x8*)(ws + off(r, ks * 2 + fh));
-                        wl[set][i] = *(const bf16x8*)(ws + off(r, LO + ks * 2 + fh));
+                        wh[set][i] = *(const h16x8*)(ws + off(r, ks * 2 + fh));
+                        wl[set][i] = *(const h16x8*)(ws + off(r, LO + ks * 2 + fh));
                     }
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int r = wn * (BM / WN) + j * 32 + frow;
-                        xh[set][j] = *(const bf16x8*)(xs + off(r, ks * 2 + fh));
-                        xl[set][j] = *(const bf16x8*)(xs + off(r, LO + ks * 2 + fh));
+                        xh[set][j] = *(const h16x8*)(xs + off(r, ks * 2 + fh));
+                        xl[set][j] = *(const h16x8*)(xs + off(r, LO + ks * 2 + fh));
                     }
                 };
                 ldh(0, 0);
@@ -615,20 +615,20 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NI; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], xl[ks & 1][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_32x32x16_h16(wh[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_32x32x16_h16(wh[ks & 1][i], xl[ks & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_32x32x16_h16(wl[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 continue;
             }
-            bf16x8 wf[2][MI], xf[2][NI];
+            h16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+                for (int i = 0; i < MI; ++i) wf[set][i] = *(const h16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
-                for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
+                for (int j = 0; j < NI; ++j) xf[set][j] = *(const h16x8*)(xs + off(wn * (BM / WN) + j * 32 + frow, ks * 2 + fh));
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -645,14 +645,14 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int j = 0; j < NI; ++j) {
                         u32x4 v = __builtin_bit_cast(u32x4, xf[ks & 1][j]);
                         v = u32x4{v.x & 0x7fff7fffu, v.y & 0x7fff7fffu, v.z & 0x7fff7fffu, v.w & 0x7fff7fffu};
-                        xf[ks & 1][j] = __builtin_bit_cast(bf16x8, v);
+                        xf[ks & 1][j] = __builtin_bit_cast(h16x8, v);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16_h16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -731,10 +731,10 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                             v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], act_eff);
                             if (a.y_abs) v[e] = fabsf(v[e]);
                         }
-                        u32x2 o = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        u32x2 o = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
                         if (half)
-                            o = u32x2{pack_bf2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xffff0000u)),
-                                      pack_bf2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xffff0000u))};
+                            o = u32x2{pack_h2(v[0] - h2f_lo(o.x), v[1] - h2f_hi(o.x)),
+                                      pack_h2(v[2] - h2f_lo(o.y), v[3] - h2f_hi(o.y))};
                         *(u32x2*)(smem + pr * OROW + cl * 2) = o;
                     }
                 }
@@ -774,9 +774,9 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int j = 0; j < NI; ++j) { acc[i][j][4 * g + e] += t[e]; nrm[i][j][4 * g + e] = be[e]; }
             }
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 gq[MI][8];
+        h16x8 gq[MI][8];
         {
-            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;
+            const h16x8* gfr = (const h16x8*)a.gdn_gamma + 128 * 16;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -784,8 +784,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         }
         __builtin_amdgcn_sched_barrier(0);
         auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) {
-            hi = pack_bf2(p, q);
-            lo = pack_bf2(p - __uint_as_float(hi << 16), q - __uint_as_float(hi & 0xffff0000u));
+            hi = pack_h2(p, q);
+            lo = pack_h2(p - h2f_lo(hi), q - h2f_hi(hi));
         };
         asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
 #pragma unroll
@@ -798,8 +798,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
                     uint32_t h0, l0, h1, l1;
-                    split2(v0 * v0, v1 * v1, h0, l0);
-                    split2(v2 * v2, v3 * v3, h1, l1);
+                    split2(v0 * v0 * H16_SQ_SCALE, v1 * v1 * H16_SQ_SCALE, h0, l0);
+                    split2(v2 * v2 * H16_SQ_SCALE, v3 * v3 * H16_SQ_SCALE, h1, l1);
                     const u32x2 h = u32x2{h0, h1}, l = u32x2{l0, l1};
                     const int o = pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2;
                     *(u32x2*)(smem + o) = h;
@@ -809,23 +809,23 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // squares visible to every wave
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            bf16x8 qh[NI], ql[NI];
+            h16x8 qh[NI], ql[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int pr = wn * (BM / WN) + j * 32 + frow;
-                qh[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
-                ql[j] = *(const bf16x8*)(smem + YOFF + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                qh[j] = *(const h16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                ql[j] = *(const h16x8*)(smem + YOFF + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
-                    nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], ql[j], nrm[i][j], 0, 0, 0);
+                    nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+                    nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], ql[j], nrm[i][j], 0, 0, 0);
                 }
         }
         {
-            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma_lo;
+            const h16x8* gfr = (const h16x8*)a.gdn_gamma_lo;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -833,16 +833,16 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            bf16x8 qh[NI];
+            h16x8 qh[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int pr = wn * (BM / WN) + j * 32 + frow;
-                qh[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                qh[j] = *(const h16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has consumed both square tiles
 #pragma unroll
@@ -911,9 +911,9 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 gq[MI][8];
+        h16x8 gq[MI][8];
         {
-            const bf16x8* gfr = (const bf16x8*)a.gdn_gamma + 128 * 16;       // second half of the packed buffer: fragment order
+            const h16x8* gfr = (const h16x8*)a.gdn_gamma + 128 * 16;       // second half of the packed buffer: fragment order
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -933,7 +933,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                         v[e] = acc[i][j][4 * g + e] + bv[i][g][e];
                         acc[i][j][4 * g + e] = v[e];                   // keep the fp32 conv output for the final product
                     }
-                    sq[i][j][g] = u32x2{pack_bf2(v[0] * v[0], v[1] * v[1]), pack_bf2(v[2] * v[2], v[3] * v[3])};
+                    sq[i][j][g] = u32x2{pack_sq2(v[0], v[1]), pack_sq2(v[2], v[3])};
                 }
         asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
 #pragma unroll
@@ -950,16 +950,16 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // squares visible to every wave
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            bf16x8 qf[NI];
+            h16x8 qf[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int pr = wn * (BM / WN) + j * 32 + frow;
-                qf[j] = *(const bf16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                qf[j] = *(const h16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qf[j], nrm[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], qf[j], nrm[i][j], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -976,7 +976,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                         v[e] = acc[i][j][4 * g + e] * (GDN == 2 ? __builtin_amdgcn_sqrtf(n) : rsqrtf(n));   // n >= beta' > 0: raw v_sqrt_f32 (1 ulp; the output is bf16)
                     }
                     *(u32x2*)(smem + YOFF + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
-                        u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int j = 0; j < NI; ++j) {
                         const int pr = wn * (BM / WN) + j * 32 + frow;
                         *(u32x2*)(smem + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
-                            u32x2{pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                            u32x2{pack_h2(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_h2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
                     }
                 }
         }
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
 // Summation order per output value is the one of igemm_glds_kernel (taps in raster order, channel chunk innermost): bit-identical.
 template <int GDN>
 __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
-    using T = bf16_t;
+    using T = h16_t;
     constexpr int BM = 128, BN = 128, BK = 64, NW = 4, NT = NW * 64;
     constexpr int CPR = BK * 2 / 16, RPB = 256 / (BK * 2);
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
     // gamma' fragments (fragment order: one 16-byte piece per lane and (cout slice, k-step)): ONE 32-bit lane offset + scalar offsets --
     // as 64-bit global pointers the 16 addresses were hoisted out of the phase loop into 32 registers (and spilled)
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const bf16x8*)(GDN ? a.gdn_gamma : a.w) + (GDN ? 128 * 16 : 0)), 0, 128 * 128 * 2, 0x00020000);
+        (void*)((const h16x8*)(GDN ? a.gdn_gamma : a.w) + (GDN ? 128 * 16 : 0)), 0, 128 * 128 * 2, 0x00020000);
     auto store_tile = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned char* eb, int ry, int rx) {
         int t = tid;
         asm volatile("" : "+v"(t));                                      // keep the address arithmetic inside the epilogue (registers)
@@ -1176,12 +1176,12 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             const unsigned char* xs = smem + gbuf * STAGE;
             const unsigned char* ws = xs + XT;
             gbuf ^= 1;
-            bf16x8 wf[2][MI], xf[2][NI];
+            h16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) wf[set][i] = *(const bf16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+                for (int i = 0; i < MI; ++i) wf[set][i] = *(const h16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
-                for (int j = 0; j < NI; ++j) xf[set][j] = *(const bf16x8*)(xs + off(wn * (BM / 2) + j * 32 + frow, ks * 2 + fh));
+                for (int j = 0; j < NI; ++j) xf[set][j] = *(const h16x8*)(xs + off(wn * (BM / 2) + j * 32 + frow, ks * 2 + fh));
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16_h16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1211,11 +1211,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         // otherwise sit between the two barriers of the epilogue (and, the counter being in-order, drag the next phase's first DMA with it)
         // (first cout half only: all of it costs 16 spilled registers; the second half is requested at the top of the epilogue and is
         // not needed before the first half's contraction has been issued)
-        bf16x8 gq[GDN ? MI : 1][8];
+        h16x8 gq[GDN ? MI : 1][8];
         if constexpr (GDN != 0) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                gq[0][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + 0) * 8 + ks) * 1024, 0));
+                gq[0][ks] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + 0) * 8 + ks) * 1024, 0));
         }
         stage(std::true_type{});
 
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] + bq[e], act_eff);
-                        *(u32x2*)(eb + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        *(u32x2*)(eb + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
                     }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             for (int i = 1; i < MI; ++i)
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
-                    gq[i][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + i) * 8 + ks) * 1024, 0));
+                    gq[i][ks] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + i) * 8 + ks) * 1024, 0));
             __builtin_amdgcn_sched_barrier(0);
             auto put_tile = [&](auto sq_tag) {
                 constexpr bool SQ = decltype(sq_tag)::value;
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                             const int pr = wn * (BM / 2) + j * 32 + fr_;
                             const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
                             *(u32x2*)(eb + pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2) =
-                                SQ ? u32x2{pack_bf2(v0 * v0, v1 * v1), pack_bf2(v2 * v2, v3 * v3)} : u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
+                                SQ ? u32x2{pack_sq2(v0, v1), pack_sq2(v2, v3)} : u32x2{pack_h2(v0, v1), pack_h2(v2, v3)};
                         }
                     }
             };
@@ -1310,14 +1310,14 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                 }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    bf16x8 qf[NI];
+                    h16x8 qf[NI];
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int pr = wn * (BM / 2) + j * 32 + fr2;
-                        qf[j] = *(const bf16x8*)(eb + pr * 256 + (((ks * 2 + fh2) ^ (pr & 15)) << 4));
+                        qf[j] = *(const h16x8*)(eb + pr * 256 + (((ks * 2 + fh2) ^ (pr & 15)) << 4));
                     }
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) nrm[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gq[i][ks], qf[j], nrm[j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j) nrm[j] = mfma_32x32x16_h16(gq[i][ks], qf[j], nrm[j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
 
 // y = act(sum of the K-slice partials + bias) as bf16 (y) and / or fp32 (y32): one thread per pixel and 8 channels
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int64_t npix, int Cout,
-                                                            const float* __restrict__ bias, int act, bf16_t* __restrict__ y,
+                                                            const float* __restrict__ bias, int act, h16_t* __restrict__ y,
                                                             int y_ps, int y_co, float* __restrict__ y32, int y32_ps, int y32_co,
                                                             int y_hilo, int y_abs) {
     const int cg = Cout >> 3;
@@ -1360,14 +1360,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { lo[e] = fabsf(lo[e]); hi[e] = fabsf(hi[e]); }
             }
-            const u32x4 o = u32x4{pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+            const u32x4 o = u32x4{pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3])};
             *(u32x4*)(y + p * y_ps + y_co + c) = o;
             if (y_hilo)       // second half of a hi/lo pair map: bf16(v - bf16(v)) at channel offset Cout
                 *(u32x4*)(y + p * y_ps + y_co + Cout + c) =
-                    u32x4{pack_bf2(lo[0] - __uint_as_float(o.x << 16), lo[1] - __uint_as_float(o.x & 0xffff0000u)),
-                          pack_bf2(lo[2] - __uint_as_float(o.y << 16), lo[3] - __uint_as_float(o.y & 0xffff0000u)),
-                          pack_bf2(hi[0] - __uint_as_float(o.z << 16), hi[1] - __uint_as_float(o.z & 0xffff0000u)),
-                          pack_bf2(hi[2] - __uint_as_float(o.w << 16), hi[3] - __uint_as_float(o.w & 0xffff0000u))};
+                    u32x4{pack_h2(lo[0] - h2f_lo(o.x), lo[1] - h2f_hi(o.x)),
+                          pack_h2(lo[2] - h2f_lo(o.y), lo[3] - h2f_hi(o.y)),
+                          pack_h2(hi[0] - h2f_lo(o.z), hi[1] - h2f_hi(o.z)),
+                          pack_h2(hi[2] - h2f_lo(o.w), hi[3] - h2f_hi(o.w))};
         }
     }
 }
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const hesic_p
         }
     }
     __syncthreads();
-    if (j.dtype == HESIC_BF16 && (j.Cin & 7) == 0) {
+    if (j.dtype == HESIC_H16 && (j.Cin & 7) == 0) {
         // bf16 destination: 8 cins = one 16-byte store per lane (2-byte stores moved 128 bytes per wave instruction: 175 us per step)
         for (int o = threadIdx.x; o < 32 * khw; o += 256) {
             const int t = o >> 5, cl = (o >> 2) & 7, il = (o & 3) * 8;    // tap, cout in tile, first of 8 cins in tile
@@ -1475,8 +1475,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const hesic_p
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = j.transposed ? tile[((il + e) * 8 + cl) * khw + ts] : tile[(cl * 32 + il + e) * khw + ts];
-            *(u32x4*)((bf16_t*)j.w_packed + ((int64_t)t * j.Cout + co) * j.Cin + ci) =
-                u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            *(u32x4*)((h16_t*)j.w_packed + ((int64_t)t * j.Cout + co) * j.Cin + ci) =
+                u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         }
         return;
     }
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const hesic_p
         const int ts = j.flip ? khw - 1 - t : t;
         const float v = j.transposed ? tile[(il * 8 + cl) * khw + ts] : tile[(cl * 32 + il) * khw + ts];
         const int64_t dst = ((int64_t)t * j.Cout + co) * j.Cin + ci;
-        if (j.dtype == HESIC_BF16) ((bf16_t*)j.w_packed)[dst] = f2bf(v);
+        if (j.dtype == HESIC_H16) ((h16_t*)j.w_packed)[dst] = f2h(v);
         else ((float*)j.w_packed)[dst] = v;
     }
 }
@@ -1514,17 +1514,17 @@ int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 // (sconv_n2w_gdn_kernel), [128*128, 2*128*128) in MFMA A-fragment order for igemm_glds_kernel -- fragment (rb, ks) holds,
 // for lane l, gamma'[rb*32 + (l & 31)][ks*16 + (l >> 5)*8 + 0..7].  beta' likewise (fp32).
 __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
-                                bf16_t* __restrict__ gp, float* __restrict__ bp) {
+                                h16_t* __restrict__ gp, float* __restrict__ bp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte slot (8 values) per thread: 128 rows x 16 slots
     if (i >= 128 * 16) return;
     const int row = i >> 4, slot = i & 15;
     const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
-    bf16_t* dst = gp + (row * 16 + (slot ^ (row & 15))) * 8;
-    bf16_t* frag = gp + 128 * 128 + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
+    h16_t* dst = gp + (row * 16 + (slot ^ (row & 15))) * 8;
+    h16_t* frag = gp + 128 * 128 + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float t = fmaxf(gamma[row * 128 + slot * 8 + e], gb);
-        dst[e] = frag[e] = f2bf(t * t - ped);
+        dst[e] = frag[e] = f2h((t * t - ped) * H16_SQ_UNSCALE);
     }
     if (i < 128) {
         const float t = fmaxf(beta[i], beta_bound);
@@ -1534,17 +1534,17 @@ __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __r
 
 // lo half of gamma' for the hi/lo GDN epilogue, MFMA A-fragment order (as the second half of gdn_pack_kernel's buffer):
 // gamma'_lo = bf16(gamma' - float(bf16(gamma'))), so gamma'_hi + gamma'_lo = gamma' to 2^-17
-__global__ void gdn_pack_lo_kernel(const float* __restrict__ gamma, bf16_t* __restrict__ glo) {
+__global__ void gdn_pack_lo_kernel(const float* __restrict__ gamma, h16_t* __restrict__ glo) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 128 * 16) return;
     const int row = i >> 4, slot = i & 15;
     const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
-    bf16_t* frag = glo + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
+    h16_t* frag = glo + ((((row >> 5) * 8 + (slot >> 1)) * 64) + (slot & 1) * 32 + (row & 31)) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float t = fmaxf(gamma[row * 128 + slot * 8 + e], gb);
-        const float g = t * t - ped;
-        frag[e] = f2bf(g - bf2f(f2bf(g)));
+        const float g = (t * t - ped) * H16_SQ_UNSCALE;
+        frag[e] = f2h(g - h2f(f2h(g)));
     }
 }
 
@@ -1556,8 +1556,8 @@ extern "C" int hesic_pack_conv_weight(const float* w, const float* mask, void* w
     HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "pack_conv_weight: bad arguments");
     const int64_t n = (int64_t)KH * KW * Cout * Cin;
     const int g = grid_for(n, 256);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (bf16_t*)wp,
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(pack_weight_kernel<h16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (h16_t*)wp,
                            Cout, Cin, KH, KW, transposed, flip);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, mask, (float*)wp,
@@ -1605,14 +1605,14 @@ extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, floa
     HESIC_CHECK_ARG(beta && gamma && gamma_packed && beta_packed, "gdn_pack_params: null pointer");
     HESIC_CHECK_ARG(C == 128, "gdn_pack_params: the fused conv+GDN epilogue is built for C == 128 (got %d)", C);
     hipLaunchKernelGGL(gdn_pack_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, beta, gamma, sqrtf(beta_min + 1.0f / 68719476736.0f),
-                       (bf16_t*)gamma_packed, beta_packed);
+                       (h16_t*)gamma_packed, beta_packed);
     HESIC_LAUNCH_RETURN("gdn_pack_params");
 }   // when set, hesic_conv2d_forward only reports its tile choice
 
 extern "C" int hesic_gdn_pack_params_lo(const float* gamma, void* gamma_lo_packed, int C, void* stream) {
     HESIC_CHECK_ARG(gamma && gamma_lo_packed, "gdn_pack_params_lo: null pointer");
     HESIC_CHECK_ARG(C == 128, "gdn_pack_params_lo: the fused conv+GDN epilogue is built for C == 128 (got %d)", C);
-    hipLaunchKernelGGL(gdn_pack_lo_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, gamma, (bf16_t*)gamma_lo_packed);
+    hipLaunchKernelGGL(gdn_pack_lo_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, gamma, (h16_t*)gamma_lo_packed);
     HESIC_LAUNCH_RETURN("gdn_pack_params_lo");
 }
 
@@ -1630,7 +1630,7 @@ extern "C" int hesic_conv2d_variant(const hesic_conv_desc* d, int* bm_bn_bk_glds
 extern "C" int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                         const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream) {
     HESIC_CHECK_ARG(d && gamma_packed && beta_packed, "conv2d_gdn_forward: null pointer");
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 && d->Cout == 128 && d->act == HESIC_ACT_NONE && d->Cin % 32 == 0,
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16 && d->Cout == 128 && d->act == HESIC_ACT_NONE && d->Cin % 32 == 0,
                     "conv2d_gdn_forward: needs bf16 storage, Cout == 128, Cin %% 32 == 0 and no activation");
     g_gdn_gamma = gamma_packed; g_gdn_beta = beta_packed; g_gdn_mode = inverse ? 2 : 1;
     const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y, stream);
@@ -1657,13 +1657,13 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     HESIC_CHECK_ARG(!hilo || d->Cin % 32 == 0, "conv2d_forward_hilo: Cin must be a multiple of 32");
     const int cin_k = hilo ? 2 * d->Cin : d->Cin;  // channels per tap of the packed weights; a stage of BK covers BK/2 logical channels then,
                                                    // so every "Cin % BK" tile-selection rule below applies to cin_k
-    const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
+    const int ce = d->dtype == HESIC_H16 ? 8 : 4;
     HESIC_CHECK_ARG(d->Cout % ce == 0 && d->y_c_off % ce == 0 && d->y_pix_stride % ce == 0 && d->x_c_off % ce == 0 &&
                         d->x_pix_stride % ce == 0,
                     "conv2d_forward: channel counts/offsets must be multiples of %d", ce);
     HESIC_CHECK_ARG(d->KH * d->KW <= MAX_TAPS, "conv2d_forward: at most %d taps", MAX_TAPS);
     HESIC_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv2d_forward: stride must be 1 or 2");
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 || d->dtype == HESIC_F32, "conv2d_forward: bad dtype");
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16 || d->dtype == HESIC_F32, "conv2d_forward: bad dtype");
     HESIC_CHECK_ARG(d->x_c_off + (hilo ? 2 : 1) * d->Cin <= d->x_pix_stride && d->y_c_off + ((hilo && (g_gdn_mode || g_y_hilo)) ? 2 : 1) * d->Cout <= d->y_pix_stride,
                     "conv2d_forward: channel slice out of range");
 
@@ -1703,7 +1703,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int BN = (pad128 - pad64) * 8 > pad128 ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
     static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
-    const bool fast = d->dtype == HESIC_BF16 && (!legacy || gdn || g_y32);
+    const bool fast = d->dtype == HESIC_H16 && (!legacy || gdn || g_y32);
     HESIC_CHECK_ARG(!g_y32 || (fast && !gdn), "conv2d_forward_f32out: bf16 storage without the fused GDN epilogue only");
     // pixel tile: 128, shrunk to 64 / 32 (fast path only) until the grid has ~1.5 blocks per CU
     int bm = 128;
@@ -1715,7 +1715,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         return (int64_t)a.n_tiles * ((a.QW + tw - 1) / tw) * ((a.QH + th - 1) / th) * a.B * a.nphase;
     };
     // hesic_conv2d_set_phase_fusion(2): eligible transposed layers take the 128-pixel tile whatever the grid (the fused kernel's only tile)
-    const bool tr4_shape = d->dtype == HESIC_BF16 && d->transposed && s == 2 && BN == 128 && cin_k % 64 == 0 && !hilo && !g_y32 && g_groups == 1 &&
+    const bool tr4_shape = d->dtype == HESIC_H16 && d->transposed && s == 2 && BN == 128 && cin_k % 64 == 0 && !hilo && !g_y32 && g_groups == 1 &&
                            !g_act_split && !a.in_abs && d->Cout % 128 == 0 && gdn <= 2;
     const bool tr4_forced = tr4_shape && g_phase4_mode.load(std::memory_order_relaxed) >= 2;
     if (fast && !tr4_forced) {
@@ -1885,9 +1885,9 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             if (bk128 && cin_k % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
             else LAUNCH_GLDS_NS(32, 128, 64);
         }
-    } else if (d->dtype == HESIC_BF16) {
-        if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 128>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((igemm_conv_kernel<bf16_t, 64>), grid, block, 0, st, a);
+    } else if (d->dtype == HESIC_H16) {
+        if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<h16_t, 128>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((igemm_conv_kernel<h16_t, 64>), grid, block, 0, st, a);
     } else {
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<float, 128>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((igemm_conv_kernel<float, 64>), grid, block, 0, st, a);
@@ -1895,7 +1895,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (ksplit > 1) {
         const int64_t npix = (int64_t)d->B * d->Ho * d->Wo;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(npix * (d->Cout / 8), 256)), dim3(256), 0, st, (const float*)g_ws, ksplit,
-                           npix, d->Cout, bias, d->act, (bf16_t*)y, d->y_pix_stride, d->y_c_off, g_y32, g_y32_ps, g_y32_co, g_y_hilo, g_y_abs);
+                           npix, d->Cout, bias, d->act, (h16_t*)y, d->y_pix_stride, d->y_c_off, g_y32, g_y32_ps, g_y32_co, g_y_hilo, g_y_abs);
     }
     HESIC_LAUNCH_RETURN("conv2d_forward");
 }
@@ -1921,7 +1921,7 @@ extern "C" int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void*
                                            void* y, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                                            void* stream) {
     HESIC_CHECK_ARG(d && y_f32, "conv2d_forward_f32out: null pointer");
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16, "conv2d_forward_f32out: the fp32 copy exists for bf16 storage (fp32 storage is fp32 already)");
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16, "conv2d_forward_f32out: the fp32 copy exists for bf16 storage (fp32 storage is fp32 already)");
     HESIC_CHECK_ARG(y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride,
                     "conv2d_forward_f32out: fp32 channel slice must be 16-byte aligned and in range");
     g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
@@ -1936,7 +1936,7 @@ extern "C" int hesic_conv2d_forward_grouped(const hesic_conv_desc* d, int groups
                                             const void* w_packed, const float* bias, void* y, float* y_f32, int y32_pix_stride,
                                             int y32_c_off, void* stream) {
     HESIC_CHECK_ARG(d && groups >= 1 && x_group_step >= 0 && act_split >= 0 && act_split <= d->Cout, "conv2d_forward_grouped: bad arguments");
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16, "conv2d_forward_grouped: bf16 storage");
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16, "conv2d_forward_grouped: bf16 storage");
     HESIC_CHECK_ARG(!y_f32 || (y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride),
                     "conv2d_forward_grouped: fp32 channel slice must be 16-byte aligned and in range");
     g_groups = groups; g_x_group_step = x_group_step; g_act2 = act2; g_act_split = act_split;
@@ -1949,7 +1949,7 @@ extern "C" int hesic_conv2d_forward_grouped(const hesic_conv_desc* d, int groups
 
 // One weight of a grouped launch into its cout slice [co_off, co_off + Cout) of a packed buffer [KH*KW][Cout_total][Cin].
 namespace {
-__global__ void pack_weight_slice_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KH, int KW, int transposed,
+__global__ void pack_weight_slice_kernel(const float* __restrict__ w, h16_t* __restrict__ wp, int Cout, int Cin, int KH, int KW, int transposed,
                                          int Cout_total, int co_off) {
     const int64_t n = (int64_t)KH * KW * Cout * Cin;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1958,7 +1958,7 @@ __global__ void pack_weight_slice_kernel(const float* __restrict__ w, bf16_t* __
         const int co = r % Cout, tap = r / Cout;
         const int ky = tap / KW, kx = tap % KW;
         const int64_t src = transposed ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
-        wp[((int64_t)tap * Cout_total + co_off + co) * Cin + ci] = f2bf(w[src]);
+        wp[((int64_t)tap * Cout_total + co_off + co) * Cin + ci] = f2h(w[src]);
     }
 }
 }  // namespace
@@ -1967,7 +1967,7 @@ extern "C" int hesic_pack_conv_weight_slice(const float* w, void* wp, int Cout, 
                                             int co_off, void* stream) {
     HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && co_off >= 0 && co_off + Cout <= Cout_total, "pack_conv_weight_slice: bad arguments");
     const int64_t n = (int64_t)KH * KW * Cout * Cin;
-    hipLaunchKernelGGL(pack_weight_slice_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wp, Cout, Cin, KH, KW,
+    hipLaunchKernelGGL(pack_weight_slice_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (h16_t*)wp, Cout, Cin, KH, KW,
                        transposed, Cout_total, co_off);
     HESIC_LAUNCH_RETURN("pack_conv_weight_slice");
 }
@@ -1977,7 +1977,7 @@ extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x
                                          const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                                          void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
     HESIC_CHECK_ARG(d && x_hilo && w_packed_hilo && (y_hilo || y_f32), "conv2d_forward_hilo: null pointer");
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 && !d->in_abs, "conv2d_forward_hilo: bf16 storage, no |x| on load (use y_abs on the producer)");
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16 && !d->in_abs, "conv2d_forward_hilo: bf16 storage, no |x| on load (use y_abs on the producer)");
     const bool gdn = gamma_packed != nullptr;
     if (gdn) {
         HESIC_CHECK_ARG(gamma_lo_packed && beta_packed && y_hilo && !y_f32 && !y_abs, "conv2d_forward_hilo: the fused GDN form writes y_hilo only and needs both gamma' halves");

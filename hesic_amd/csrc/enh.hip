@@ -15,7 +15,7 @@
 namespace {
 
 struct C32Args {
-    const bf16_t* x; const float* w; const float* bias; const void* res1; const void* res2; void* y;
+    const h16_t* x; const float* w; const float* bias; const void* res1; const void* res2; void* y;
     int B, H, W, Cout, act, tiles_x, tiles_y;
     FastDiv fd_tx, fd_ty;
 };
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     // weights -> 18 A fragments: lane (cout = p, half h) holds channels k*16 + h*8 + [0,8) of tap t.  The (Cout,32,3,3) fp32
     // tensor comes in through LDS with coalesced loads (row pitch 289 floats: the per-lane gathers below hit 32 different
     // banks); gathering it straight from global memory cost every block ~9000 scattered cache-line requests.
-    bf16x8 wf[9][2];
+    h16x8 wf[9][2];
     {
         float* wst = (float*)halo;                               // 32 x 289 floats = 37 KB <= the halo buffer
         const int nw = a.Cout * 288;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
-                wf[t][k] = __builtin_bit_cast(bf16x8, u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+                wf[t][k] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
             }
         __syncthreads();
     }
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                     const int xx = tx * TW + rpx + 16 * it;
                     const bool lv = y < a.H && xx < a.W;
                     const int64_t o = (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8;
-                    r1v[it] = (NRES >= 1 && lv) ? *(const u32x4*)((const bf16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
-                    r2v[it] = (NRES >= 2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r1v[it] = (NRES >= 1 && lv) ? *(const u32x4*)((const h16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r2v[it] = (NRES >= 2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
                 }
             } else {
 #pragma unroll
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                 const int hp = (yl + t / 3) * HW_ + p + t % 3;
                 const unsigned char* row = halo + hp * 64;
                 const int sw = (hp >> 2) & 3;
-                const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
+                const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
+                acc = mfma_32x32x16_h16(wf[t][0], xf0, acc, 0, 0, 0);
+                acc1 = mfma_32x32x16_h16(wf[t][1], xf1, acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                     const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(ra[e] << 16) + __uint_as_float(rb[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(ra[e] & 0xffff0000u) + __uint_as_float(rb[e] & 0xffff0000u);
+                        v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
+                        v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
                     }
                     if (y < a.H && xx < a.W)
-                        *(u32x4*)((bf16_t*)a.y + (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8) =
-                            u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                        *(u32x4*)((h16_t*)a.y + (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8) =
+                            u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
                 }
             } else {
                 if (live && h == 0) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
 // but half the launches: an eager Independent_EN forward at B=8 512x512 3.56 ms against 4.02).  Two block barriers per stage; 139.5 KB of
 // LDS.  Rounding points are those of the two-launch path (bf16 intermediate, fp32 accumulation in the same tap order): bit-identical.
 struct RBArgs {
-    const bf16_t* x; const float* w1; const float* b1; const float* w2; const float* b2; const void* res2; void* y;
+    const h16_t* x; const float* w1; const float* b1; const float* w2; const float* b2; const void* res2; void* y;
     int B, H, W, act, tiles_x, tiles_y;
     FastDiv fd_tx, fd_ty;
 };
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, w4 = wave & 3;                 // 0: producer (conv1), 1: consumer (conv2)
     const int p = lane & 31, h = lane >> 5;
-    bf16x8 wf[9][2];
+    h16x8 wf[9][2];
 #pragma unroll 1
     for (int which = 0; which < 2; ++which) {
         float* wst = (float*)hin;                                // 32 x 289 floats = 37 KB <= the input halo buffer
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
-                    wf[t][k] = __builtin_bit_cast(bf16x8, u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+                    wf[t][k] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
                 }
         }
         __syncthreads();
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                         const int hp = (mr + t / 3) * RB_IW + mc + t % 3;
                         const unsigned char* row = hin + hp * 64;
                         const int sw = (hp >> 2) & 3;
-                        const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
+                        const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
+                        acc = mfma_32x32x16_h16(wf[t][0], xf0, acc, 0, 0, 0);
+                        acc1 = mfma_32x32x16_h16(wf[t][1], xf1, acc1, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = inside ? apply_act(acc[4 * j + e] + bv[j][e], a.act) : 0.f;
-                            *(u32x2*)(dst + ((j ^ sw) << 4)) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                            *(u32x2*)(dst + ((j ^ sw) << 4)) = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
                         }
                     }
                 }
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const bool lv = y < a.H && xx < a.W;
                     const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8;
                     r1v[it] = lv ? *(const u32x4*)(a.x + o) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
-                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const bf16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
                 }
                 f32x16 acc, acc1;
 #pragma unroll
@@ -369,9 +369,9 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const int hp = (yl + t / 3) * HW_ + p + t % 3;
                     const unsigned char* row = hmid + hp * 64;
                     const int sw = (hp >> 2) & 3;
-                    const bf16x8 xf0 = *(const bf16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const bf16x8*)(row + (((2 + h) ^ sw) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], xf0, acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], xf1, acc1, 0, 0, 0);
+                    const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
+                    acc = mfma_32x32x16_h16(wf[t][0], xf0, acc, 0, 0, 0);
+                    acc1 = mfma_32x32x16_h16(wf[t][1], xf1, acc1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(ra[e] << 16) + __uint_as_float(rb[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(ra[e] & 0xffff0000u) + __uint_as_float(rb[e] & 0xffff0000u);
+                        v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
+                        v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
                     }
                     if (y < a.H && xx < a.W)
-                        *(u32x4*)((bf16_t*)a.y + (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8) =
-                            u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                        *(u32x4*)((h16_t*)a.y + (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8) =
+                            u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
                 }
             }
         }
@@ -409,14 +409,14 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
 // cat(xa, xb) (two fp32 planar 3-channel images, newnet1.py:300) as channels 0..5 of a zero-padded 32-channel NHWC bf16 map:
 // the input of the 6 -> 32 conv in the layout of the kernel above.  One thread per pixel: six coalesced plane reads, one
 // 64-byte row out.
-__global__ __launch_bounds__(256) void pack_images_c32_kernel(const float* __restrict__ xa, const float* __restrict__ xb, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void pack_images_c32_kernel(const float* __restrict__ xa, const float* __restrict__ xb, h16_t* __restrict__ out,
                                                               int B, int64_t HW) {
     const int64_t total = (int64_t)B * HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW, q = i - b * HW;
         const float* pa = xa + b * 3 * HW + q;
         const float* pb = xb + b * 3 * HW + q;
-        const u32x4 v0 = {pack_bf2(pa[0], pa[HW]), pack_bf2(pa[2 * HW], pb[0]), pack_bf2(pb[HW], pb[2 * HW]), 0u};
+        const u32x4 v0 = {pack_h2(pa[0], pa[HW]), pack_h2(pa[2 * HW], pb[0]), pack_h2(pb[HW], pb[2 * HW]), 0u};
         const u32x4 z = {0u, 0u, 0u, 0u};
         u32x4* o = (u32x4*)(out + i * 32);
         o[0] = v0; o[1] = z; o[2] = z; o[3] = z;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void pack_images_c32_kernel(const float* __res
 extern "C" int hesic_pack_images_c32(const float* xa, const float* xb, void* out, int B, int H, int W, void* stream) {
     HESIC_CHECK_ARG(xa && xb && out && B > 0 && H > 0 && W > 0, "pack_images_c32: bad arguments");
     const int64_t total = (int64_t)B * H * W;
-    hipLaunchKernelGGL(pack_images_c32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, xa, xb, (bf16_t*)out, B, (int64_t)H * W);
+    hipLaunchKernelGGL(pack_images_c32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, xa, xb, (h16_t*)out, B, (int64_t)H * W);
     HESIC_LAUNCH_RETURN("pack_images_c32");
 }
 
@@ -439,7 +439,7 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
     HESIC_CHECK_ARG(Cout == 32 || !res2, "conv3x3_c32_forward: the planar form takes one residual");
     HESIC_CHECK_ARG((int64_t)H * W * 64 < (1ll << 31), "conv3x3_c32_forward: image too large for 32-bit offsets");
     C32Args a;
-    a.x = (const bf16_t*)x; a.w = w; a.bias = bias; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.x = (const h16_t*)x; a.w = w; a.bias = bias; a.res1 = res1; a.res2 = res2; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
     a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
     a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
@@ -461,7 +461,7 @@ extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const 
     HESIC_CHECK_ARG(x != y, "resblock_c32_forward: in-place is not supported (neighbouring tiles read the input halo)");
     HESIC_CHECK_ARG((int64_t)H * W * 64 < (1ll << 31), "resblock_c32_forward: image too large for 32-bit offsets");
     RBArgs a;
-    a.x = (const bf16_t*)x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.res2 = res2; a.y = y;
+    a.x = (const h16_t*)x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.res2 = res2; a.y = y;
     a.B = B; a.H = H; a.W = W; a.act = act;
     a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
     a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
@@ -492,7 +492,7 @@ extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const 
 namespace {
 
 struct C32WgArgs {
-    const bf16_t* x; const bf16_t* g; float* part;
+    const h16_t* x; const h16_t* g; float* part;
     int B, H, W, strips_x, nstrips;
     FastDiv fd_sx, fd_h;
 };
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void c32_wgrad_kernel(const C32WgArgs a) {
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    const h16x8 ones = __builtin_bit_cast(h16x8, u32x4{H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR});
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int gq = lane >> 4, t16 = lane & 15;
@@ -570,17 +570,17 @@ __global__ __launch_bounds__(256, 1) void c32_wgrad_kernel(const C32WgArgs a) {
             const int pix = ks * 16 + pixl;
             const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gt + pix * 64 + choff));
             const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gt + (pix + 4) * 64 + choff));
-            const bf16x8 df = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const h16x8 df = __builtin_bit_cast(h16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, dx = t % 3;                       // halo row, pixel shift (halo pixel 0 = image pixel x0 - 1)
                 const unsigned char* xp = xt + r * WG_XROW + (pix + dx) * 64 + choff;
                 const s16x4 xlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)xp);
                 const s16x4 xhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp + 4 * 64));
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, xf, acc[t], 0, 0, 0);
+                const h16x8 xf = __builtin_bit_cast(h16x8, __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[t] = mfma_32x32x16_h16(df, xf, acc[t], 0, 0, 0);
             }
-            acc[9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, ones, acc[9], 0, 0, 0);
+            acc[9] = mfma_32x32x16_h16(df, ones, acc[9], 0, 0, 0);
         }
         buf ^= 1;
         asm volatile("" ::: "memory");
@@ -639,7 +639,7 @@ extern "C" int hesic_conv3x3_c32_wgrad(const void* x, const void* g, float* dw, 
     HESIC_CHECK_ARG((int64_t)B * H * W * 64 < (1ll << 31), "conv3x3_c32_wgrad: tensors too large for 32-bit offsets");
     HESIC_CHECK_ARG(ws_bytes >= hesic_conv3x3_c32_wgrad_ws_bytes(), "conv3x3_c32_wgrad: workspace too small");
     C32WgArgs a;
-    a.x = (const bf16_t*)x; a.g = (const bf16_t*)g; a.part = (float*)ws;
+    a.x = (const h16_t*)x; a.g = (const h16_t*)g; a.part = (float*)ws;
     a.B = B; a.H = H; a.W = W; a.strips_x = (W + WG_STRIP - 1) / WG_STRIP;
     const int64_t ns = (int64_t)a.strips_x * H * B;
     HESIC_CHECK_ARG(ns < (1ll << 31), "conv3x3_c32_wgrad: too many strips");

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(const hesic_gmm_desc d, co
 
 int check_gmm(const hesic_gmm_desc* d, const char* who) {
     HESIC_CHECK_ARG(d && d->B > 0 && d->HW > 0 && d->M > 0 && d->K >= 1 && d->K <= GMM_MAXK, "%s: bad geometry (K <= %d)", who, GMM_MAXK);
-    HESIC_CHECK_ARG(d->dtype == HESIC_BF16 || d->dtype == HESIC_F32, "%s: bad dtype", who);
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16 || d->dtype == HESIC_F32, "%s: bad dtype", who);
     HESIC_CHECK_ARG(!d->use_means_in_quant || d->K == 1, "%s: use_means_in_quant needs K == 1", who);
     return 0;
 }
@@ -471,9 +471,9 @@ extern "C" int hesic_eb_forward(const void* z, const float* params, const void* 
     HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward: bad arguments");
     const int bx = C >= 128 ? 128 : 64;
     const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(eb_fwd_kernel<bf16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const bf16_t*)z, params,
-                           (const bf16_t*)noise, (bf16_t*)z_hat, lik, symbols, P, C);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(eb_fwd_kernel<h16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const h16_t*)z, params,
+                           (const h16_t*)noise, (h16_t*)z_hat, lik, symbols, P, C);
     else
         hipLaunchKernelGGL(eb_fwd_kernel<float>, grid, dim3(bx), 0, (hipStream_t)stream, (const float*)z, params,
                            (const float*)noise, (float*)z_hat, lik, symbols, P, C);
@@ -495,9 +495,9 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
     static const int max_slices = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
     const int64_t slices = (P + EB_PL - 1) / EB_PL;
     const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + 63) / 64), block(64 * EB_PL);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(eb_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)z, params,
-                           (const bf16_t*)noise, g_lik, (const bf16_t*)g_zhat, (bf16_t*)dz, dparams, P, C);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(eb_bwd_kernel<h16_t>, grid, block, 0, (hipStream_t)stream, (const h16_t*)z, params,
+                           (const h16_t*)noise, g_lik, (const h16_t*)g_zhat, (h16_t*)dz, dparams, P, C);
     else
         hipLaunchKernelGGL(eb_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)z, params,
                            (const float*)noise, g_lik, (const float*)g_zhat, (float*)dz, dparams, P, C);
@@ -508,18 +508,18 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
 // parameter so the 2K parameter loads of a thread are all in flight before the first erfc (the generic kernel's run-time
 // K loop made them K serial HBM round trips: 44 % of its wave cycles were parked at s_waitcnt), 32-bit indexing.
 // One channel pair of an NHWC row as two floats: 4-byte bf16 pairs or 8-byte fp32 pairs.
-__device__ __forceinline__ f32x2 ld_pair(const bf16_t* p) {
+__device__ __forceinline__ f32x2 ld_pair(const h16_t* p) {
     const uint32_t r = *(const uint32_t*)p;
-    return f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+    return f32x2{h2f_lo(r), h2f_hi(r)};
 }
 __device__ __forceinline__ f32x2 ld_pair(const float* p) { return *(const f32x2*)p; }
-__device__ __forceinline__ void st_pair(bf16_t* p, float a, float b) { *(uint32_t*)p = pack_bf2(a, b); }
+__device__ __forceinline__ void st_pair(h16_t* p, float a, float b) { *(uint32_t*)p = pack_h2(a, b); }
 __device__ __forceinline__ void st_pair(float* p, float a, float b) { *(f32x2*)p = f32x2{a, b}; }
 
 // TI: storage of y / scales / means / noise, TO: storage of y_hat.  TI = float with TO = bf16 is the inference form of the
 // bf16 mode: the latents and the entropy parameters come straight from the convs' fp32 accumulators
 // (hesic_conv2d_forward_f32out), only the integer-valued y_hat that feeds the synthesis convs is bf16.
-template <int K, typename TI = bf16_t, typename TO = bf16_t>
+template <int K, typename TI = h16_t, typename TO = h16_t>
 __global__ __launch_bounds__(256) void gmm_fwd_pair_kernel(const hesic_gmm_desc d, const TI* __restrict__ y, const TI* __restrict__ scales,
                                                            const TI* __restrict__ means, const float* __restrict__ weights,
                                                            const TI* __restrict__ noise, TO* __restrict__ yhat, float* __restrict__ lik,
@@ -586,7 +586,7 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
     const dim3 grid(grid_for(total, 256));
     // pair form: even channel geometry (4-byte bf16 pairs, 8-byte fp32 pairs), 32-bit pair index
     static const bool no_pair = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
-    const bool pair = !no_pair && d->dtype == HESIC_BF16 && (d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 &&
+    const bool pair = !no_pair && d->dtype == HESIC_H16 && (d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 &&
                       d->s_c_off % 2 == 0 && d->m_c_off % 2 == 0 && total / 2 < (1ll << 31) && !((uintptr_t)y & 3) &&
                       !((uintptr_t)scales & 3) && !((uintptr_t)means & 3) && !((uintptr_t)noise & 3) && !((uintptr_t)y_hat & 3) &&
                       !((uintptr_t)lik & 7) && !((uintptr_t)weights & 7);
@@ -594,14 +594,14 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
         const dim3 g2(grid_for(total / 2, 256));
         const FastDiv fd = make_fastdiv((uint32_t)(d->M / 2));
         if (d->K == 5)
-            hipLaunchKernelGGL(gmm_fwd_pair_kernel<5>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y, (const bf16_t*)scales,
-                               (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols, fd);
+            hipLaunchKernelGGL(gmm_fwd_pair_kernel<5>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y, (const h16_t*)scales,
+                               (const h16_t*)means, weights, (const h16_t*)noise, (h16_t*)y_hat, lik, symbols, fd);
         else
-            hipLaunchKernelGGL(gmm_fwd_pair_kernel<1>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y, (const bf16_t*)scales,
-                               (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols, fd);
-    } else if (d->dtype == HESIC_BF16)
-        hipLaunchKernelGGL(gmm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
-                           (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, (bf16_t*)y_hat, lik, symbols);
+            hipLaunchKernelGGL(gmm_fwd_pair_kernel<1>, g2, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y, (const h16_t*)scales,
+                               (const h16_t*)means, weights, (const h16_t*)noise, (h16_t*)y_hat, lik, symbols, fd);
+    } else if (d->dtype == HESIC_H16)
+        hipLaunchKernelGGL(gmm_fwd_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y,
+                           (const h16_t*)scales, (const h16_t*)means, weights, (const h16_t*)noise, (h16_t*)y_hat, lik, symbols);
     else
         hipLaunchKernelGGL(gmm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
                            (const float*)scales, (const float*)means, weights, (const float*)noise, (float*)y_hat, lik, symbols);
@@ -616,9 +616,9 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf: weights required for K > 1");
     const int64_t total = (int64_t)n_channels * d->HW;
     const dim3 grid(grid_for(total, 128));
-    if (d->dtype == HESIC_BF16)
-        hipLaunchKernelGGL(gmm_cdf_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const bf16_t*)scales,
-                           (const bf16_t*)means, weights, channels, n_channels, minmax, cdf);
+    if (d->dtype == HESIC_H16)
+        hipLaunchKernelGGL(gmm_cdf_kernel<h16_t>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales,
+                           (const h16_t*)means, weights, channels, n_channels, minmax, cdf);
     else
         hipLaunchKernelGGL(gmm_cdf_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const float*)scales,
                            (const float*)means, weights, channels, n_channels, minmax, cdf);
@@ -641,19 +641,19 @@ extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const 
     if (ppb > 64) ppb = 64;
     const dim3 grid((d->M + 63) / 64, (d->HW + ppb - 1) / ppb, d->B);
     static const bool slow_bwd = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
-    if (d->dtype == HESIC_BF16 && !slow_bwd && (d->K == 5 || d->K == 1)) {
+    if (d->dtype == HESIC_H16 && !slow_bwd && (d->K == 5 || d->K == 1)) {
         if (d->K == 5)
-            hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 5>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
-                               (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
-                               (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
+            hipLaunchKernelGGL((gmm_bwd_kernel<h16_t, 5>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y,
+                               (const h16_t*)scales, (const h16_t*)means, weights, (const h16_t*)noise, g_lik,
+                               (const h16_t*)g_yhat, (h16_t*)dy, (h16_t*)dscales, (h16_t*)dmeans, dweights, ppb);
         else
-            hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
-                               (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
-                               (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
-    } else if (d->dtype == HESIC_BF16)
-        hipLaunchKernelGGL((gmm_bwd_kernel<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const bf16_t*)y,
-                           (const bf16_t*)scales, (const bf16_t*)means, weights, (const bf16_t*)noise, g_lik,
-                           (const bf16_t*)g_yhat, (bf16_t*)dy, (bf16_t*)dscales, (bf16_t*)dmeans, dweights, ppb);
+            hipLaunchKernelGGL((gmm_bwd_kernel<h16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y,
+                               (const h16_t*)scales, (const h16_t*)means, weights, (const h16_t*)noise, g_lik,
+                               (const h16_t*)g_yhat, (h16_t*)dy, (h16_t*)dscales, (h16_t*)dmeans, dweights, ppb);
+    } else if (d->dtype == HESIC_H16)
+        hipLaunchKernelGGL((gmm_bwd_kernel<h16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y,
+                           (const h16_t*)scales, (const h16_t*)means, weights, (const h16_t*)noise, g_lik,
+                           (const h16_t*)g_yhat, (h16_t*)dy, (h16_t*)dscales, (h16_t*)dmeans, dweights, ppb);
     else
         hipLaunchKernelGGL((gmm_bwd_kernel<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const float*)y,
                            (const float*)scales, (const float*)means, weights, (const float*)noise, g_lik,
@@ -727,12 +727,12 @@ __global__ void eb_aux_loss_kernel(const float* __restrict__ params, const float
 extern "C" int hesic_eb_forward_f32in(const float* z, const float* params, void* z_hat, int out_dtype, float* lik, int32_t* symbols,
                                       int64_t P, int C, void* stream) {
     HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward_f32in: bad arguments");
-    HESIC_CHECK_ARG(out_dtype == HESIC_BF16 || out_dtype == HESIC_F32, "eb_forward_f32in: bad dtype");
+    HESIC_CHECK_ARG(out_dtype == HESIC_H16 || out_dtype == HESIC_F32, "eb_forward_f32in: bad dtype");
     const int bx = C >= 128 ? 128 : 64;
     const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
-    if (out_dtype == HESIC_BF16)
-        hipLaunchKernelGGL((eb_fwd_kernel<float, bf16_t>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
-                           (bf16_t*)z_hat, lik, symbols, P, C);
+    if (out_dtype == HESIC_H16)
+        hipLaunchKernelGGL((eb_fwd_kernel<float, h16_t>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
+                           (h16_t*)z_hat, lik, symbols, P, C);
     else
         hipLaunchKernelGGL((eb_fwd_kernel<float, float>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
                            (float*)z_hat, lik, symbols, P, C);
@@ -744,7 +744,7 @@ extern "C" int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, 
     if (int e = check_gmm(d, "gmm_forward_f32in")) return e;
     HESIC_CHECK_ARG(y && scales && means && y_hat && lik, "gmm_forward_f32in: null pointer");
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_forward_f32in: weights required for K > 1");
-    HESIC_CHECK_ARG(out_dtype == HESIC_BF16 || out_dtype == HESIC_F32, "gmm_forward_f32in: bad dtype");
+    HESIC_CHECK_ARG(out_dtype == HESIC_H16 || out_dtype == HESIC_F32, "gmm_forward_f32in: bad dtype");
     const int64_t total = (int64_t)d->B * d->HW * d->M;
     HESIC_CHECK_ARG((d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 && d->s_c_off % 2 == 0 && d->m_c_off % 2 == 0 &&
                         total / 2 < (1ll << 31) && !((uintptr_t)y & 7) && !((uintptr_t)scales & 7) && !((uintptr_t)means & 7) &&
@@ -755,8 +755,8 @@ extern "C" int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, 
     hipStream_t st = (hipStream_t)stream;
 #define GMM_F32IN(K_, TO_) hipLaunchKernelGGL((gmm_fwd_pair_kernel<K_, float, TO_>), g2, dim3(256), 0, st, *d, y, scales, means, weights, \
                                               (const float*)nullptr, (TO_*)y_hat, lik, symbols, fd)
-    if (d->K == 5) { if (out_dtype == HESIC_BF16) GMM_F32IN(5, bf16_t); else GMM_F32IN(5, float); }
-    else { if (out_dtype == HESIC_BF16) GMM_F32IN(1, bf16_t); else GMM_F32IN(1, float); }
+    if (d->K == 5) { if (out_dtype == HESIC_H16) GMM_F32IN(5, h16_t); else GMM_F32IN(5, float); }
+    else { if (out_dtype == HESIC_H16) GMM_F32IN(1, h16_t); else GMM_F32IN(1, float); }
 #undef GMM_F32IN
     HESIC_LAUNCH_RETURN("gmm_forward_f32in");
 }

@@ -91,7 +91,7 @@ __global__ void gdn_planar_kernel(const void* __restrict__ x, const float* __res
 
 // ------------------------------------------------------------------ C = 128 on the matrix cores
 template <typename T> struct G;
-template <> struct G<bf16_t> { static constexpr int BP = 128, CE = 8; };   // pixels per tile, elems / 16 B
+template <> struct G<h16_t> { static constexpr int BP = 128, CE = 8; };   // pixels per tile, elems / 16 B
 template <> struct G<float> { static constexpr int BP = 64, CE = 4; };
 
 template <typename T>
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
         if constexpr (sizeof(T) == 2) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = reparam(gp[e], kGammaBound);
-            *(u32x4*)(gs + g_off<T>(row, slot)) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            for (int e = 0; e < 8; ++e) v[e] = reparam(gp[e], kGammaBound) * H16_SQ_UNSCALE;
+            *(u32x4*)(gs + g_off<T>(row, slot)) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         } else {
             *(f32x4*)(gs + g_off<T>(row, slot)) = f32x4{reparam(gp[0], kGammaBound), reparam(gp[1], kGammaBound),
                                                          reparam(gp[2], kGammaBound), reparam(gp[3], kGammaBound)};
@@ -158,17 +158,16 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
 #pragma unroll
             for (int ks = 0; ks < C / 16; ++ks) {
                 const u32x4 raw = *(const u32x4*)(xs + g_off<T>(pt * 32 + frow, ks * 2 + fh));
-                float f[8] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
-                              __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u),
-                              __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
-                              __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
-                u32x4 sq = u32x4{pack_bf2(f[0] * f[0], f[1] * f[1]), pack_bf2(f[2] * f[2], f[3] * f[3]),
-                                 pack_bf2(f[4] * f[4], f[5] * f[5]), pack_bf2(f[6] * f[6], f[7] * f[7])};
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, sq);
+                float f[8] = {h2f_lo(raw.x), h2f_hi(raw.x),
+                              h2f_lo(raw.y), h2f_hi(raw.y),
+                              h2f_lo(raw.z), h2f_hi(raw.z),
+                              h2f_lo(raw.w), h2f_hi(raw.w)};
+                u32x4 sq = u32x4{pack_sq2(f[0], f[1]), pack_sq2(f[2], f[3]), pack_sq2(f[4], f[5]), pack_sq2(f[6], f[7])};
+                const h16x8 xf = __builtin_bit_cast(h16x8, sq);
 #pragma unroll
                 for (int i = 0; i < CT; ++i) {
-                    const bf16x8 gf = *(const bf16x8*)(gs + g_off<T>((cbase + i) * 32 + frow, ks * 2 + fh));
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[i], 0, 0, 0);
+                    const h16x8 gf = *(const h16x8*)(gs + g_off<T>((cbase + i) * 32 + frow, ks * 2 + fh));
+                    acc[i] = mfma_32x32x16_h16(gf, xf, acc[i], 0, 0, 0);
                 }
             }
         } else {
@@ -195,8 +194,8 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
                 const unsigned char* src = xs + g_off<T>(pt * 32 + frow, ch / CE) + (ch % CE) * (int)sizeof(T);
                 if constexpr (sizeof(T) == 2) {
                     const u32x2 raw = *(const u32x2*)src;
-                    xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
-                    xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
+                    xv[0] = h2f_lo(raw.x); xv[1] = h2f_hi(raw.x);
+                    xv[2] = h2f_lo(raw.y); xv[3] = h2f_hi(raw.y);
                 } else {
                     const f32x4 raw = *(const f32x4*)src;
                     xv[0] = raw.x; xv[1] = raw.y; xv[2] = raw.z; xv[3] = raw.w;
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(256) void gdn128_kernel(const T* __restrict__ x, co
                     o[e] = xv[e] * (inverse ? (sizeof(T) == 2 ? __builtin_amdgcn_sqrtf(n) : sqrtf(n)) : rsqrtf(n));   // bf16 storage: raw v_sqrt_f32
                 }
                 if (p < P) {
-                    if constexpr (sizeof(T) == 2) *(u32x2*)(y + p * C + ch) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                    if constexpr (sizeof(T) == 2) *(u32x2*)(y + p * C + ch) = u32x2{pack_h2(o[0], o[1]), pack_h2(o[2], o[3])};
                     else *(f32x4*)(y + p * C + ch) = f32x4{o[0], o[1], o[2], o[3]};
                 }
             }
@@ -220,7 +219,7 @@ extern "C" int hesic_gdn_forward_planar(const void* x, const float* beta, const 
                                         int inverse, float beta_min, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && beta && gamma && y && B > 0 && HW > 0, "gdn_forward_planar: bad arguments");
     HESIC_CHECK_ARG(C == 3, "gdn_forward_planar: built for the 3-channel image-side GDNs (got C=%d)", C);
-    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "gdn_forward_planar: bad dtype");
+    HESIC_CHECK_ARG(dtype == HESIC_H16 || dtype == HESIC_F32, "gdn_forward_planar: bad dtype");
     const float bound = sqrtf(beta_min + 1.0f / 68719476736.0f);
     hipLaunchKernelGGL(gdn_planar_kernel<3>, dim3(grid_for((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, beta, gamma, y,
                        B, HW, inverse, bound, dtype);
@@ -230,15 +229,15 @@ extern "C" int hesic_gdn_forward_planar(const void* x, const float* beta, const 
 extern "C" int hesic_gdn_forward(const void* x, const float* beta, const float* gamma, void* y, int64_t P, int C,
                                  int inverse, float beta_min, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && beta && gamma && y && P > 0 && C > 0, "gdn_forward: bad arguments");
-    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "gdn_forward: bad dtype");
+    HESIC_CHECK_ARG(dtype == HESIC_H16 || dtype == HESIC_F32, "gdn_forward: bad dtype");
     const float bound = sqrtf(beta_min + kPedestal);
     hipStream_t st = (hipStream_t)stream;
     if (C == 128) {
-        if (dtype == HESIC_BF16) {
-            const int64_t tiles = cdiv64(P, G<bf16_t>::BP);
+        if (dtype == HESIC_H16) {
+            const int64_t tiles = cdiv64(P, G<h16_t>::BP);
             const int grid = (int)(tiles < 512 ? tiles : 512);
-            hipLaunchKernelGGL(gdn128_kernel<bf16_t>, dim3(grid), dim3(256), (128 + G<bf16_t>::BP) * 128 * 2, st,
-                               (const bf16_t*)x, beta, gamma, (bf16_t*)y, P, inverse, bound);
+            hipLaunchKernelGGL(gdn128_kernel<h16_t>, dim3(grid), dim3(256), (128 + G<h16_t>::BP) * 128 * 2, st,
+                               (const h16_t*)x, beta, gamma, (h16_t*)y, P, inverse, bound);
         } else {
             const int64_t tiles = cdiv64(P, G<float>::BP);
             const int grid = (int)(tiles < 256 ? tiles : 256);
@@ -247,7 +246,7 @@ extern "C" int hesic_gdn_forward(const void* x, const float* beta, const float* 
         }
     } else if (C == 3) {
         const dim3 g3(grid_for(P, 256, 2048));
-        if (dtype == HESIC_BF16) hipLaunchKernelGGL((gdn_small_nhwc_kernel<3, bf16_t>), g3, dim3(256), 0, st, (const bf16_t*)x, beta, gamma, (bf16_t*)y, P, inverse, bound);
+        if (dtype == HESIC_H16) hipLaunchKernelGGL((gdn_small_nhwc_kernel<3, h16_t>), g3, dim3(256), 0, st, (const h16_t*)x, beta, gamma, (h16_t*)y, P, inverse, bound);
         else hipLaunchKernelGGL((gdn_small_nhwc_kernel<3, float>), g3, dim3(256), 0, st, (const float*)x, beta, gamma, (float*)y, P, inverse, bound);
     } else {
         hipLaunchKernelGGL(gdn_generic_kernel, dim3(grid_for(P * C, 256)), dim3(256), 0, st, x, beta, gamma, y, P, C, inverse,

@@ -16,6 +16,7 @@ void hesic_set_error(const char* fmt, ...) {
 }
 extern "C" const char* hesic_last_error(void) { return g_err; }
 extern "C" int hesic_abi_version(void) { return HESIC_ABI_VERSION; }
+extern "C" int hesic_h16_format(void) { return HESIC_H16_IS_F16 ? HESIC_H16_FLOAT16 : HESIC_H16_BFLOAT16; }
 
 namespace {
 
@@ -46,7 +47,7 @@ __global__ void upsample4_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 // bf16, channels and offsets multiples of 8: one thread = 8 channels of an output pixel (four 16-byte loads, one 16-byte store) -- the
 // element-wise form above spends a chain of 64-bit divisions and 2-byte accesses on every value: 43 us for the 5 MB concat buffer of
 // gmm_hyper_y2, on the critical path between the third analysis pass and the hyper-synthesis.  Same arithmetic per value.
-__global__ void upsample4_fwd_v8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C8, int yps, int yco) {
+__global__ void upsample4_fwd_v8_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, int B, int H, int W, int C8, int yps, int yco) {
     const int Ho = 4 * H, Wo = 4 * W;
     const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int total = B * Ho * Wo * C8;
@@ -60,7 +61,7 @@ __global__ void upsample4_fwd_v8_kernel(const bf16_t* __restrict__ x, bf16_t* __
         const int y0 = (int)sy, x0 = (int)sx;
         const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
         const float ly = sy - y0, lx = sx - x0;
-        const bf16_t* xb = x + ((int64_t)b * H * W * C8 + c8) * 8;
+        const h16_t* xb = x + ((int64_t)b * H * W * C8 + c8) * 8;
         const int64_t C = (int64_t)C8 * 8;
         const u32x4 q00 = *(const u32x4*)(xb + ((int64_t)y0 * W + x0) * C), q01 = *(const u32x4*)(xb + ((int64_t)y0 * W + x1) * C);
         const u32x4 q10 = *(const u32x4*)(xb + ((int64_t)y1 * W + x0) * C), q11 = *(const u32x4*)(xb + ((int64_t)y1 * W + x1) * C);
@@ -69,11 +70,11 @@ __global__ void upsample4_fwd_v8_kernel(const bf16_t* __restrict__ x, bf16_t* __
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float l = (1.f - ly) * ((1.f - lx) * __uint_as_float(a00[e] << 16) + lx * __uint_as_float(a01[e] << 16)) +
-                            ly * ((1.f - lx) * __uint_as_float(a10[e] << 16) + lx * __uint_as_float(a11[e] << 16));
-            const float h = (1.f - ly) * ((1.f - lx) * __uint_as_float(a00[e] & 0xffff0000u) + lx * __uint_as_float(a01[e] & 0xffff0000u)) +
-                            ly * ((1.f - lx) * __uint_as_float(a10[e] & 0xffff0000u) + lx * __uint_as_float(a11[e] & 0xffff0000u));
-            o[e] = pack_bf2(l, h);
+            const float l = (1.f - ly) * ((1.f - lx) * h2f_lo(a00[e]) + lx * h2f_lo(a01[e])) +
+                            ly * ((1.f - lx) * h2f_lo(a10[e]) + lx * h2f_lo(a11[e]));
+            const float h = (1.f - ly) * ((1.f - lx) * h2f_hi(a00[e]) + lx * h2f_hi(a01[e])) +
+                            ly * ((1.f - lx) * h2f_hi(a10[e]) + lx * h2f_hi(a11[e]));
+            o[e] = pack_h2(l, h);
         }
         *(u32x4*)(y + (((int64_t)b * Ho + oy) * Wo + ox) * yps + yco + c8 * 8) = u32x4{o[0], o[1], o[2], o[3]};
     }
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void spatial_max_kernel(const T* __restrict__ 
             const u32x4 raw = *(const u32x4*)px;
             const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = h2f_lo(w[e]); v[2 * e + 1] = h2f_hi(w[e]); }
         } else {
 #pragma unroll
             for (int e = 0; e < V; ++e) v[e] = c0 + e < C ? elem<T>::ld(px + e) : -INFINITY;
@@ -440,11 +441,11 @@ __global__ void round_cast_kernel(const void* __restrict__ x, int xd, void* __re
 }
 
 // the case the inference schedule issues three times per forward (fp32 latent -> rounded bf16 copy): 8 values per thread
-__global__ void round_f32_to_bf16_v8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+__global__ void round_f32_to_bf16_v8_kernel(const float* __restrict__ x, h16_t* __restrict__ y, int64_t n8) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4*)(x + i * 8), b = *(const f32x4*)(x + i * 8 + 4);
-        *(u32x4*)(y + i * 8) = u32x4{pack_bf2(rintf(a.x), rintf(a.y)), pack_bf2(rintf(a.z), rintf(a.w)), pack_bf2(rintf(b.x), rintf(b.y)),
-                                     pack_bf2(rintf(b.z), rintf(b.w))};
+        *(u32x4*)(y + i * 8) = u32x4{pack_h2(rintf(a.x), rintf(a.y)), pack_h2(rintf(a.z), rintf(a.w)), pack_h2(rintf(b.x), rintf(b.y)),
+                                     pack_h2(rintf(b.z), rintf(b.w))};
     }
 }
 
@@ -452,8 +453,8 @@ __global__ void round_f32_to_bf16_v8_kernel(const float* __restrict__ x, bf16_t*
 
 extern "C" int hesic_round(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, void* stream) {
     HESIC_CHECK_ARG(x && y && n > 0, "round: bad arguments");
-    if (x_dtype == HESIC_F32 && y_dtype == HESIC_BF16 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
-        hipLaunchKernelGGL(round_f32_to_bf16_v8_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (bf16_t*)y, n / 8);
+    if (x_dtype == HESIC_F32 && y_dtype == HESIC_H16 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+        hipLaunchKernelGGL(round_f32_to_bf16_v8_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (h16_t*)y, n / 8);
         HESIC_LAUNCH_RETURN("round");
     }
     hipLaunchKernelGGL(round_cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n);
@@ -463,12 +464,12 @@ extern "C" int hesic_round(const void* x, int x_dtype, void* y, int y_dtype, int
 extern "C" int hesic_upsample4_forward(const void* x, void* y, int B, int H, int W, int C, int yps, int yco, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && yco + C <= yps, "upsample4_forward: bad arguments");
     const int64_t total = (int64_t)B * 16 * H * W * C;
-    if (dtype == HESIC_BF16 && C % 8 == 0 && yps % 8 == 0 && yco % 8 == 0 && total / 8 < (1ll << 31) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
-        hipLaunchKernelGGL(upsample4_fwd_v8_kernel, dim3(grid_for(total / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+    if (dtype == HESIC_H16 && C % 8 == 0 && yps % 8 == 0 && yco % 8 == 0 && total / 8 < (1ll << 31) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(upsample4_fwd_v8_kernel, dim3(grid_for(total / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, (h16_t*)y,
                            B, H, W, C / 8, yps, yco);
-    else if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(upsample4_fwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C, yps, yco);
+    else if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(upsample4_fwd_kernel<h16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)x, (h16_t*)y, B, H, W, C, yps, yco);
     else
         hipLaunchKernelGGL(upsample4_fwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (float*)y, B, H, W, C, yps, yco);
@@ -478,9 +479,9 @@ extern "C" int hesic_upsample4_forward(const void* x, void* y, int B, int H, int
 extern "C" int hesic_upsample4_backward(const void* dy, void* dx, int B, int H, int W, int C, int yps, int yco, int dtype, void* stream) {
     HESIC_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && yco + C <= yps, "upsample4_backward: bad arguments");
     const int64_t total = (int64_t)B * H * W * C;
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(upsample4_bwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, yps, yco);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(upsample4_bwd_kernel<h16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)dy, (h16_t*)dx, B, H, W, C, yps, yco);
     else
         hipLaunchKernelGGL(upsample4_bwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dy, (float*)dx, B, H, W, C, yps, yco);
@@ -489,7 +490,7 @@ extern "C" int hesic_upsample4_backward(const void* dy, void* dx, int B, int H, 
 
 extern "C" int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int xps, int xco, int yps, int yco, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && y && P > 0 && C > 0 && xco + C <= xps && yco + C <= yps, "copy_channels: bad arguments");
-    const int es = dtype == HESIC_BF16 ? 2 : 4;
+    const int es = dtype == HESIC_H16 ? 2 : 4;
     if ((C * es) % 16 == 0 && (xps * es) % 16 == 0 && (xco * es) % 16 == 0 && (yps * es) % 16 == 0 && (yco * es) % 16 == 0 && ((uintptr_t)x & 15) == 0 &&
         ((uintptr_t)y & 15) == 0) {
         // whole 16-byte chunks on both sides: one chunk per thread instead of one element (38 us for 3 MB, on the same critical path)
@@ -498,9 +499,9 @@ extern "C" int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int
                            (unsigned char*)y, P, chunks, (int64_t)xps * es, (int64_t)xco * es, (int64_t)yps * es, (int64_t)yco * es);
         HESIC_LAUNCH_RETURN("copy_channels");
     }
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(P * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, P, C, xps, xco, yps, yco);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(copy_channels_kernel<h16_t>, dim3(grid_for(P * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const h16_t*)x, (h16_t*)y, P, C, xps, xco, yps, yco);
     else
         hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(P * C, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (float*)y, P, C, xps, xco, yps, yco);
@@ -513,15 +514,15 @@ extern "C" int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int
         const int ppb = 64, nz = (HW + ppb - 1) / ppb;
         hipLaunchKernelGGL(fill_neg_inf_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, B * C);
         const dim3 g3((C + 63) / 64, B, nz);
-        if (dtype == HESIC_BF16)
-            hipLaunchKernelGGL(spatial_max_split_kernel<bf16_t>, g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, HW, C, leaky, ppb);
+        if (dtype == HESIC_H16)
+            hipLaunchKernelGGL(spatial_max_split_kernel<h16_t>, g3, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, out, HW, C, leaky, ppb);
         else
             hipLaunchKernelGGL(spatial_max_split_kernel<float>, g3, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, HW, C, leaky, ppb);
         HESIC_LAUNCH_RETURN("spatial_max");
     }
     const dim3 grid((C + 63) / 64, B);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(spatial_max_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, argmax, HW, C, leaky);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(spatial_max_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, out, argmax, HW, C, leaky);
     else
         hipLaunchKernelGGL(spatial_max_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, argmax, HW, C, leaky);
     HESIC_LAUNCH_RETURN("spatial_max");
@@ -675,9 +676,9 @@ extern "C" int hesic_sq_diff_backward(const void* a, int a_dtype, const int64_t 
 
 extern "C" int hesic_act_backward(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, void* stream) {
     HESIC_CHECK_ARG(y && dy && dx && n > 0, "act_backward: bad arguments");
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
-                           (const bf16_t*)dy, (bf16_t*)dx, n, act);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(act_bwd_kernel<h16_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)y,
+                           (const h16_t*)dy, (h16_t*)dx, n, act);
     else
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)y,
                            (const float*)dy, (float*)dx, n, act);
@@ -698,7 +699,7 @@ extern "C" int hesic_cast(const void* x, int x_dtype, void* y, int y_dtype, int6
 namespace {
 __global__ __launch_bounds__(256) void im2col_hilo_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C,
                                                           int H, int W, int KH, int KW, int stride, int pad, int Ho, int Wo, int KP,
-                                                          bf16_t* __restrict__ cols) {
+                                                          h16_t* __restrict__ cols) {
     const int chunks = KP >> 3, kk = KH * KW, kmax = C * kk;
     const int64_t total = (int64_t)B * Ho * Wo * chunks;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -719,10 +720,10 @@ __global__ __launch_bounds__(256) void im2col_hilo_kernel(const float* __restric
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            hi[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-            lo[e] = pack_bf2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+            hi[e] = pack_h2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_h2(v[2 * e] - h2f_lo(hi[e]), v[2 * e + 1] - h2f_hi(hi[e]));
         }
-        bf16_t* dst = cols + p * (2 * KP) + q * 8;
+        h16_t* dst = cols + p * (2 * KP) + q * 8;
         *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
         *(u32x4*)(dst + KP) = u32x4{lo[0], lo[1], lo[2], lo[3]};
     }
@@ -736,6 +737,6 @@ extern "C" int hesic_im2col_hilo(const float* x, const int64_t x_strides[4], int
     HESIC_CHECK_ARG(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "im2col_hilo: output size does not match");
     const int64_t total = (int64_t)B * Ho * Wo * (KP / 8);
     hipLaunchKernelGGL(im2col_hilo_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, x_strides[0], x_strides[1],
-                       x_strides[2], x_strides[3], B, C, H, W, KH, KW, stride, pad, Ho, Wo, KP, (bf16_t*)cols);
+                       x_strides[2], x_strides[3], B, C, H, W, KH, KW, stride, pad, Ho, Wo, KP, (h16_t*)cols);
     HESIC_LAUNCH_RETURN("im2col_hilo");
 }

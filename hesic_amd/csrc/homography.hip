@@ -126,12 +126,12 @@ __global__ void h_from_delta_kernel(const float* __restrict__ corners, const flo
 
 extern "C" int hesic_maxpool2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(x && y && B > 0 && H > 1 && W > 1 && C > 0, "maxpool2_forward: bad arguments");
-    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "maxpool2_forward: bad dtype");
-    const int V = dtype == HESIC_BF16 ? 8 : 4;
+    HESIC_CHECK_ARG(dtype == HESIC_H16 || dtype == HESIC_F32, "maxpool2_forward: bad dtype");
+    const int V = dtype == HESIC_H16 ? 8 : 4;
     HESIC_CHECK_ARG(C % V == 0, "maxpool2_forward: C=%d must be a multiple of %d", C, V);
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / V);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(maxpool2_kernel<h16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, (h16_t*)y, B, H, W, C);
     else
         hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C);
     HESIC_LAUNCH_RETURN("maxpool2_forward");

@@ -131,15 +131,15 @@ __global__ __launch_bounds__(256) void sconv_narrow_to_wide_kernel(const SArgs a
                 }
             }
             const int64_t yb = b * a.ys_b + oy * a.ys_y + ox * a.ys_x + cg * 32;   // ys_c == 1
-            if (a.y_dtype == HESIC_BF16) {
-                bf16_t* yp = (bf16_t*)a.y + yb;
+            if (a.y_dtype == HESIC_H16) {
+                h16_t* yp = (h16_t*)a.y + yb;
 #pragma unroll
                 for (int e = 0; e < 32; e += 8) {
                     u32x4 o;
                     float v[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = apply_act(acc[e + k] + (a.bias ? a.bias[cg * 32 + e + k] : 0.f), a.act);
-                    o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+                    o.x = pack_h2(v[0], v[1]); o.y = pack_h2(v[2], v[3]); o.z = pack_h2(v[4], v[5]); o.w = pack_h2(v[6], v[7]);
                     *(u32x4*)(yp + e) = o;
                 }
             } else {
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(256) void sconv_wide_to_narrow_kernel(const SArgs a
                 float xv[8];
                 if constexpr (sizeof(T) == 2) {
                     const u32x4 raw = *(const u32x4*)(xp + c0);
-                    xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
-                    xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
-                    xv[4] = __uint_as_float(raw.z << 16); xv[5] = __uint_as_float(raw.z & 0xffff0000u);
-                    xv[6] = __uint_as_float(raw.w << 16); xv[7] = __uint_as_float(raw.w & 0xffff0000u);
+                    xv[0] = h2f_lo(raw.x); xv[1] = h2f_hi(raw.x);
+                    xv[2] = h2f_lo(raw.y); xv[3] = h2f_hi(raw.y);
+                    xv[4] = h2f_lo(raw.z); xv[5] = h2f_hi(raw.z);
+                    xv[6] = h2f_lo(raw.w); xv[7] = h2f_hi(raw.w);
                 } else {
                     const f32x4 r0 = *(const f32x4*)(xp + c0), r1 = *(const f32x4*)(xp + c0 + 4);
                     xv[0] = r0.x; xv[1] = r0.y; xv[2] = r0.z; xv[3] = r0.w; xv[4] = r1.x; xv[5] = r1.y; xv[6] = r1.z; xv[7] = r1.w;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void sconv_wide_to_narrow_kernel(const SArgs a
 // (any strides, fp32 or bf16), D -> bias/act -> bf16 -> LDS -> full NHWC rows.  HBM bound on the 128-channel output.
 // Geometry is a template parameter so every loop unrolls and the index arithmetic folds (the first, fully run-time
 // version spent 2250 VALU + 1570 SALU instructions per 32-pixel tile next to 32 MFMAs).
-__device__ __forceinline__ uint32_t pack_bf2_fast(float lo, float hi) { return pack_bf2(lo, hi); }   // v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_h2_fast(float lo, float hi) { return pack_h2(lo, hi); }   // v_cvt_pk_bf16_f32
 
 constexpr int N2W_KPAD = 128;
 template <int CIN, int KS, int ST, typename XT>
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < 8; ++kx)
                     v[kx] = (r < R && kx < KS && n0 + co < a.Cout) ? a.w[(((int64_t)(n0 + co) * CIN + ci) * KS + ky) * KS + kx] : 0.f;
-                *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
             }
             if (tid < 128) bl[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
         }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
                         if (ok) v[kx] = elem<XT>::ld(rp + (int64_t)(ix0 + kx) * a.xs_x);
                     }
                 }
-                frag[ks] = u32x4{pack_bf2_fast(v[0], v[1]), pack_bf2_fast(v[2], v[3]), pack_bf2_fast(v[4], v[5]), pack_bf2_fast(v[6], v[7])};
+                frag[ks] = u32x4{pack_h2_fast(v[0], v[1]), pack_h2_fast(v[2], v[3]), pack_h2_fast(v[4], v[5]), pack_h2_fast(v[6], v[7])};
             }
             f32x16 acc[4];
 #pragma unroll
@@ -307,12 +307,12 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < (R + 1) / 2; ++ks) {        // k-steps beyond the real rows are all zero
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
+                const h16x8 xf = __builtin_bit_cast(h16x8, frag[ks]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 32 + frow;
-                    const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                    const h16x8 wf = *(const h16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                    acc[i] = mfma_32x32x16_h16(wf, xf, acc[i], 0, 0, 0);
                 }
             }
             // D[i = cout][j = pixel]: lane holds pixel frow of this wave, couts i*32 + 8g + 4fh + {0..3}
@@ -324,10 +324,10 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
                     const f32x4 bv = *(const f32x4*)(bl + cl);
                     const float o0 = apply_act(acc[i][4 * g] + bv.x, a.act), o1 = apply_act(acc[i][4 * g + 1] + bv.y, a.act);
                     const float o2 = apply_act(acc[i][4 * g + 2] + bv.z, a.act), o3 = apply_act(acc[i][4 * g + 3] + bv.w, a.act);
-                    *(u32x2*)(os + pl * OROW + cl * 2) = u32x2{pack_bf2_fast(o0, o1), pack_bf2_fast(o2, o3)};
+                    *(u32x2*)(os + pl * OROW + cl * 2) = u32x2{pack_h2_fast(o0, o1), pack_h2_fast(o2, o3)};
                 }
             __syncthreads();
-            bf16_t* yg = (bf16_t*)a.y;
+            h16_t* yg = (h16_t*)a.y;
 #pragma unroll
             for (int c = tid; c < 128 * 16; c += 256) {
                 const int pr = c >> 4, cc = c & 15;
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(256) void sconv_n2w_mfma_kernel(const SArgs a) {
 // each wave owns a 32-pixel tile end to end (gather -> conv MFMAs -> bf16 rows in its private LDS slice -> squared rows
 // back as the B operand of the GDN MFMAs -> normalise -> rows out), so the tile loop needs no block barrier at all.
 template <int CIN, int KS, int ST, typename XT>
-__global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const bf16_t* __restrict__ gamma_packed,
+__global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const h16_t* __restrict__ gamma_packed,
                                                             const float* __restrict__ beta_packed, int inverse,
-                                                            bf16_t* __restrict__ y_pre) {
+                                                            h16_t* __restrict__ y_pre) {
     constexpr int OROW = 128 * 2 + 16, R = CIN * KS, PAD = KS / 2, NW = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;                          // conv weights [128][128] bf16, slot ^ (row & 15)
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
 #pragma unroll
             for (int kx = 0; kx < 8; ++kx)
                 v[kx] = (r < R && kx < KS && co < a.Cout) ? a.w[(((int64_t)co * CIN + ci) * KS + ky) * KS + kx] : 0.f;
-            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         }
         // gamma' image for the GDN contraction.  Its K (input-channel) order is permuted so that the squares a lane needs as
         // MFMA B operand are the accumulator registers it already holds: slab ks = (i, gp) covers channels 32i+16gp+[0,16),
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                     if (ok) v[kx] = elem<XT>::ld(rp + (int64_t)(ix0 + kx) * a.xs_x);
                 }
             }
-            frag[ks] = u32x4{pack_bf2_fast(v[0], v[1]), pack_bf2_fast(v[2], v[3]), pack_bf2_fast(v[4], v[5]), pack_bf2_fast(v[6], v[7])};
+            frag[ks] = u32x4{pack_h2_fast(v[0], v[1]), pack_h2_fast(v[2], v[3]), pack_h2_fast(v[4], v[5]), pack_h2_fast(v[6], v[7])};
         }
         f32x16 acc[4];
 #pragma unroll
@@ -417,13 +417,13 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < (R + 1) / 2; ++ks) {
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
+            const h16x8 xf = __builtin_bit_cast(h16x8, frag[ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (a.dbg & 2) break;
                 const int row = i * 32 + frow;
-                const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                const h16x8 wf = *(const h16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = mfma_32x32x16_h16(wf, xf, acc[i], 0, 0, 0);
             }
         }
         // bias in registers; the squares of lane-half h's own accumulators are the B operand of the GDN contraction (see
@@ -444,17 +444,17 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int si = ks >> 1, so = (ks & 1) * 8;
-            const u32x4 sq = u32x4{pack_bf2_fast(acc[si][so] * acc[si][so], acc[si][so + 1] * acc[si][so + 1]),
-                                   pack_bf2_fast(acc[si][so + 2] * acc[si][so + 2], acc[si][so + 3] * acc[si][so + 3]),
-                                   pack_bf2_fast(acc[si][so + 4] * acc[si][so + 4], acc[si][so + 5] * acc[si][so + 5]),
-                                   pack_bf2_fast(acc[si][so + 6] * acc[si][so + 6], acc[si][so + 7] * acc[si][so + 7])};
-            const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
+            const u32x4 sq = u32x4{pack_sq2(acc[si][so], acc[si][so + 1]),
+                                   pack_sq2(acc[si][so + 2], acc[si][so + 3]),
+                                   pack_sq2(acc[si][so + 4], acc[si][so + 5]),
+                                   pack_sq2(acc[si][so + 6], acc[si][so + 7])};
+            const h16x8 qf = __builtin_bit_cast(h16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (a.dbg & 4) break;
                 const int row = i * 32 + frow;
-                const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
+                const h16x8 gf = *(const h16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                nrm[i] = mfma_32x32x16_h16(gf, qf, nrm[i], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -470,9 +470,9 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                     const float n = nrm[i][4 * g + e] + bb[e];
                     o[e] = acc[i][4 * g + e] * (inverse ? __builtin_amdgcn_sqrtf(n) : rsqrtf(n));
                 }
-                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
+                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_h2_fast(o[0], o[1]), pack_h2_fast(o[2], o[3])};
             }
-        auto store_rows = [&](bf16_t* dstp) {
+        auto store_rows = [&](h16_t* dstp) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int c = it * 64 + lane, pr = c >> 4, cc = c & 15;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
                     *(u32x4*)(dstp + b * a.ys_b + y2 * a.ys_y + x2 * a.ys_x + cc * 8) = *(const u32x4*)(os + pr * OROW + cc * 16);
             }
         };
-        store_rows((bf16_t*)a.y);
+        store_rows((h16_t*)a.y);
         if (y_pre) {
             // training form: the conv output v (still in acc) goes out through the same wave-private rows
 #pragma unroll
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = i * 32 + 8 * g + 4 * fh;
-                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
+                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_h2(acc[i][4 * g], acc[i][4 * g + 1]), pack_h2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
                 }
             store_rows(y_pre);
         }
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_kernel(const SArgs a, const
 //   * accumulators start from bias / beta' (no separate adds), INV is a template parameter, rows leave through buffer
 //     stores with scalar tile offsets.
 template <int INV>
-__global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, const bf16_t* __restrict__ gamma_packed,
-                                                                 const float* __restrict__ beta_packed, bf16_t* __restrict__ y_pre,
+__global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, const h16_t* __restrict__ gamma_packed,
+                                                                 const float* __restrict__ beta_packed, h16_t* __restrict__ y_pre,
                                                                  FastDiv fd_tx, FastDiv fd_ty) {
     constexpr int OROW = 128 * 2 + 16, CIN = 3, KS = 5, R = CIN * KS, NW = 8;
     constexpr uint32_t POISON = 0x80000000u;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
 #pragma unroll
             for (int kx = 0; kx < 8; ++kx)
                 v[kx] = (r < R && kx < KS && co < a.Cout) ? a.w[(((int64_t)co * CIN + ci) * KS + ky) * KS + kx] : 0.f;
-            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            *(u32x4*)(wl + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         }
         for (int idx = tid; idx < 2048; idx += 512) {
             const int row = idx >> 4, q = idx & 15, ks = q >> 1, h = q & 1;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f32x2 p0 = __builtin_bit_cast(f32x2, raw[ks][0]), p1 = __builtin_bit_cast(f32x2, raw[ks][1]), p2 = __builtin_bit_cast(f32x2, raw[ks][2]);
-            frag[ks] = u32x4{pack_bf2_fast(p0.x, p0.y), pack_bf2_fast(p1.x, p1.y), pack_bf2_fast(p2.x, 0.f), 0u};
+            frag[ks] = u32x4{pack_h2_fast(p0.x, p0.y), pack_h2_fast(p1.x, p1.y), pack_h2_fast(p2.x, 0.f), 0u};
         }
         // the rows of the NEXT tile are requested now: `raw` is free (its values live on in `frag`), and the loads then have
         // both MFMA phases (~2000 matrix-pipe cycles) to come back instead of the epilogue alone
@@ -619,13 +619,13 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
             }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, frag[ks]);
+            const h16x8 xf = __builtin_bit_cast(h16x8, frag[ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (a.dbg & 2) break;
                 const int row = i * 32 + frow;
-                const bf16x8 wf = *(const bf16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                const h16x8 wf = *(const h16x8*)(wl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = mfma_32x32x16_h16(wf, xf, acc[i], 0, 0, 0);
             }
         }
         f32x16 nrm[4];
@@ -639,17 +639,17 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int si = ks >> 1, so = (ks & 1) * 8;
-            const u32x4 sq = u32x4{pack_bf2_fast(acc[si][so] * acc[si][so], acc[si][so + 1] * acc[si][so + 1]),
-                                   pack_bf2_fast(acc[si][so + 2] * acc[si][so + 2], acc[si][so + 3] * acc[si][so + 3]),
-                                   pack_bf2_fast(acc[si][so + 4] * acc[si][so + 4], acc[si][so + 5] * acc[si][so + 5]),
-                                   pack_bf2_fast(acc[si][so + 6] * acc[si][so + 6], acc[si][so + 7] * acc[si][so + 7])};
-            const bf16x8 qf = __builtin_bit_cast(bf16x8, sq);
+            const u32x4 sq = u32x4{pack_sq2(acc[si][so], acc[si][so + 1]),
+                                   pack_sq2(acc[si][so + 2], acc[si][so + 3]),
+                                   pack_sq2(acc[si][so + 4], acc[si][so + 5]),
+                                   pack_sq2(acc[si][so + 6], acc[si][so + 7])};
+            const h16x8 qf = __builtin_bit_cast(h16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (a.dbg & 4) break;
                 const int row = i * 32 + frow;
-                const bf16x8 gf = *(const bf16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, qf, nrm[i], 0, 0, 0);
+                const h16x8 gf = *(const h16x8*)(gl + (row * 16 + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                nrm[i] = mfma_32x32x16_h16(gf, qf, nrm[i], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -663,10 +663,10 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
                     const float n = nrm[i][4 * g + e];
                     o[e] = acc[i][4 * g + e] * (INV ? __builtin_amdgcn_sqrtf(n) : __builtin_amdgcn_rsqf(n));
                 }
-                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2_fast(o[0], o[1]), pack_bf2_fast(o[2], o[3])};
+                *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_h2_fast(o[0], o[1]), pack_h2_fast(o[2], o[3])};
             }
         const bool full = ty * 2 + 2 <= a.Ho && tx * 16 + 16 <= a.Wo;     // wave-uniform
-        auto store_rows = [&](bf16_t* dstp) {
+        auto store_rows = [&](h16_t* dstp) {
             const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(dstp + (int64_t)b * a.ys_b), 0, (int)POISON, 0x00020000);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
                 __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)((ok && !(a.dbg & 8)) ? st_lane + (uint32_t)so : POISON), 0, 0);
             }
         };
-        store_rows((bf16_t*)a.y);
+        store_rows((h16_t*)a.y);
         if (y_pre) {
             // training form: the conv output v (still in acc) goes out through the same wave-private rows
 #pragma unroll
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void sconv_n2w_gdn_fast_kernel(const SArgs a, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = i * 32 + 8 * g + 4 * fh;
-                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
+                    *(u32x2*)(os + frow * OROW + cl * 2) = u32x2{pack_h2(acc[i][4 * g], acc[i][4 * g + 1]), pack_h2(acc[i][4 * g + 2], acc[i][4 * g + 3])};
                 }
             store_rows(y_pre);
         }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, Fast
         const int tty = (int)q - tb * tiles_y;
         sl.tb = tb; sl.tty = tty; sl.ttx = ttx;
         // one buffer resource per image: a halo pixel outside the image is a poisoned offset and reads zeros
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)a.x + (int64_t)tb * a.xs_b), 0, (int)POISON, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const h16_t*)a.x + (int64_t)tb * a.xs_b), 0, (int)POISON, 0x00020000);
         const int iy = tty * W2N_TH - 1 + (pl >> 4), ix = ttx * W2N_TW - 1 + (pl & 15);
         const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         const uint32_t off = ok ? (uint32_t)((iy * (int)a.xs_y + ix * (int)a.xs_x + fh * 8) * 2) : POISON;    // xs_c == 1
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, Fast
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = n < N ? a.w[((int64_t)(sl * 8 + e) * COUT + co) * 25 + tap] : 0.f;   // w[ci][co][ky][kx]
-            *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            *(u32x4*)(wl + (n * SPR + (sl ^ (n & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         }
     }
     // col2im role of this thread: output channel cq of the 2x2 output quad around input pixel (qy, qx) of the 6x14 patch --
@@ -782,12 +782,12 @@ __global__ __launch_bounds__(256) void sconv_w2n_mfma_kernel(const SArgs a, Fast
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, raws[ks]);
+            const h16x8 xf = __builtin_bit_cast(h16x8, raws[ks]);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int row = i * 32 + frow;
-                const bf16x8 wf = *(const bf16x8*)(wl + (row * SPR + ((ks * 2 + fh) ^ (row & 15))) * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                const h16x8 wf = *(const h16x8*)(wl + (row * SPR + ((ks * 2 + fh) ^ (row & 15))) * 16);
+                acc[i] = mfma_32x32x16_h16(wf, xf, acc[i], 0, 0, 0);
             }
         }
         if (next_tile < ntiles) fetch(sl, next_tile);
@@ -1140,18 +1140,18 @@ __global__ __launch_bounds__(256) void sconv_small_s1_kernel(const SArgs a) {
 
 int launch_forward(const SArgs& a, hipStream_t st) {
     static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;   // A/B switch for profiling
-    if (!legacy && !a.transposed && a.y_dtype == HESIC_BF16 && a.Cin == 3 && a.KH == 5 && a.KW == 5 && a.stride == 2 && a.pad == 2 &&
+    if (!legacy && !a.transposed && a.y_dtype == HESIC_H16 && a.Cin == 3 && a.KH == 5 && a.KW == 5 && a.stride == 2 && a.pad == 2 &&
         a.Cout % 8 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 && (a.ys_b % 8) == 0) {
         const int64_t tiles = (int64_t)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * a.B;
         const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));      // 2 resident blocks per CU, each loops over tiles
-        if (a.x_dtype == HESIC_BF16) hipLaunchKernelGGL((sconv_n2w_mfma_kernel<3, 5, 2, bf16_t>), grid, dim3(256), 0, st, a);
+        if (a.x_dtype == HESIC_H16) hipLaunchKernelGGL((sconv_n2w_mfma_kernel<3, 5, 2, h16_t>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((sconv_n2w_mfma_kernel<3, 5, 2, float>), grid, dim3(256), 0, st, a);
     } else if (!a.transposed && a.Cin <= 8 && a.Cout % 32 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 &&
         (a.ys_b % 8) == 0 && a.KH * a.KW * a.Cin * a.Cout * 4 <= 60 * 1024) {
         const int tiles = ((a.Wo + 7) / 8) * ((a.Ho + 7) / 8) * a.B;
         const size_t lds = (size_t)a.KH * a.KW * a.Cin * a.Cout * 4;
         hipLaunchKernelGGL(sconv_narrow_to_wide_kernel, dim3(tiles), dim3(256), lds, st, a);
-    } else if (!legacy && a.transposed && a.x_dtype == HESIC_BF16 && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 &&
+    } else if (!legacy && a.transposed && a.x_dtype == HESIC_H16 && a.stride == 2 && a.KH == 5 && a.KW == 5 && a.pad == 2 &&
                a.Cout == 3 && a.Cin == 128 && a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 &&
                a.Ho == 2 * a.H && a.Wo == 2 * a.W && (int64_t)a.H * a.xs_y * 2 < (1ll << 31) && (int64_t)a.B * a.H * a.W < (1ll << 31)) {
         const int64_t tiles = (int64_t)((a.W + W2N_TW - 1) / W2N_TW) * ((a.H + W2N_TH - 1) / W2N_TH) * a.B;
@@ -1161,8 +1161,8 @@ int launch_forward(const SArgs& a, hipStream_t st) {
                a.xs_c == 1 && (a.xs_x % 8) == 0 && (a.xs_y % 8) == 0 && (a.xs_b % 8) == 0 && a.Cin <= 128) {
         const int64_t total = (int64_t)a.B * a.H * a.W;
         const size_t lds = (size_t)25 * a.Cin * 16;
-        if (a.x_dtype == HESIC_BF16)
-            hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<bf16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
+        if (a.x_dtype == HESIC_H16)
+            hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<h16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
     } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
@@ -1246,7 +1246,7 @@ extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* 
     HESIC_CHECK_ARG(d->Cin == 6 && d->Cout == 3 && d->KH == 5 && d->KW == 5 && d->stride == 1 && d->pad == 2 && d->Wo >= 128 &&
                         ca > 0 && ca < d->Cin,
                     "sconv2d_forward_cat: built for the 6 -> 3 5x5 stride-1 stages (pre_conv / after_conv) at width >= 128");
-    HESIC_CHECK_ARG(xb_dtype == HESIC_F32 || xb_dtype == HESIC_BF16, "sconv2d_forward_cat: bad dtype");
+    HESIC_CHECK_ARG(xb_dtype == HESIC_F32 || xb_dtype == HESIC_H16, "sconv2d_forward_cat: bad dtype");
     SArgs a = make_args(d);
     a.x = xa; a.w = w; a.bias = bias; a.y = y;
     a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
@@ -1296,7 +1296,7 @@ __global__ void sconv_pack_n2w_image_kernel(const float* __restrict__ w, const u
         float v[8];
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((co * 3 + ci) * 5 + ky) * 5 + kx] : 0.f;
-        *(u32x4*)(img + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(img + (co * 16 + (r ^ (co & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
     } else if (idx < 4096) {
         const int j = idx - 2048, row = j >> 4, q = j & 15, ks = q >> 1, h = q & 1;
         const unsigned char* srow = gamma_packed + row * 256;
@@ -1313,7 +1313,7 @@ __global__ void sconv_pack_w2n_image_kernel(const float* __restrict__ w, unsigne
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = n < 75 ? w[((sl * 8 + e) * 3 + co) * 25 + tap] : 0.f;       // w[ci][co][ky][kx]
-    *(u32x4*)(img + (n * 16 + (sl ^ (n & 15))) * 16) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    *(u32x4*)(img + (n * 16 + (sl ^ (n & 15))) * 16) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
 }
 
 extern "C" int hesic_sconv_pack_weight_image(int kind, const float* w, const void* gamma_packed, void* image, void* stream) {
@@ -1330,7 +1330,7 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
     if (int e = check_desc(d, "sconv2d_gdn_forward")) return e;
     HESIC_CHECK_ARG(x && w && y && gamma_packed && beta_packed, "sconv2d_gdn_forward: null pointer");
     HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
-                        d->y_dtype == HESIC_BF16 && d->ys_c == 1 && d->act == HESIC_ACT_NONE && (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 &&
+                        d->y_dtype == HESIC_H16 && d->ys_c == 1 && d->act == HESIC_ACT_NONE && (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 &&
                         (d->ys_b % 8) == 0,
                     "sconv2d_gdn_forward: built for the 3 -> 128 5x5 stride-2 stage with bf16 NHWC output");
     SArgs a = make_args(d);
@@ -1344,7 +1344,7 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)sconv_n2w_gdn_kernel<3, 5, 2, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     // fp32 planes, unit pixel stride, even width, everything addressable with 32-bit byte offsets inside one image
@@ -1361,13 +1361,13 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
         }
         const FastDiv fd_tx = make_fastdiv((uint32_t)((d->Wo + 15) / 16)), fd_ty = make_fastdiv((uint32_t)((d->Ho + 1) / 2));
         if (inverse)
-            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<1>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, (bf16_t*)y_pre, fd_tx, fd_ty);
+            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<1>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const h16_t*)gamma_packed, beta_packed, (h16_t*)y_pre, fd_tx, fd_ty);
         else
-            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<0>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, (bf16_t*)y_pre, fd_tx, fd_ty);
-    } else if (d->x_dtype == HESIC_BF16)
-        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, bf16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
+            hipLaunchKernelGGL((sconv_n2w_gdn_fast_kernel<0>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const h16_t*)gamma_packed, beta_packed, (h16_t*)y_pre, fd_tx, fd_ty);
+    } else if (d->x_dtype == HESIC_H16)
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, h16_t>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const h16_t*)gamma_packed, beta_packed, inverse, (h16_t*)y_pre);
     else
-        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const bf16_t*)gamma_packed, beta_packed, inverse, (bf16_t*)y_pre);
+        hipLaunchKernelGGL((sconv_n2w_gdn_kernel<3, 5, 2, float>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a, (const h16_t*)gamma_packed, beta_packed, inverse, (h16_t*)y_pre);
     HESIC_LAUNCH_RETURN("sconv2d_gdn_forward");
 }
 

@@ -14,15 +14,15 @@
 namespace {
 
 struct HArgs {
-    const float* x; const unsigned char* img; const float* bias; const float* beta; bf16_t* y;
+    const float* x; const unsigned char* img; const float* bias; const float* beta; h16_t* y;
     int B, H, W, Ho, Wo;
     int64_t xs_b, xs_c, xs_y, ys_b, ys_y, ys_x;
     FastDiv fd_tx, fd_ty;
 };
 
 __device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t& lo) {
-    hi = pack_bf2(p, q);
-    lo = pack_bf2(p - __uint_as_float(hi << 16), q - __uint_as_float(hi & 0xffff0000u));
+    hi = pack_h2(p, q);
+    lo = pack_h2(p - h2f_lo(hi), q - h2f_hi(hi));
 }
 
 template <int INV>
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
         // conv: the w_hi fragments are double-buffered one k-step ahead; the w_lo fragments of a k-step are requested at its start and
         // used last (behind 8 MFMAs = their LDS latency)
         {
-            bf16x8 wh[2][4], wl[4];
+            h16x8 wh[2][4], wl[4];
             auto ldh = [&](int set, int ks) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    wh[set][i] = *(const bf16x8*)(wl_hi + fa(ks) + i * 8192);
+                    wh[set][i] = *(const h16x8*)(wl_hi + fa(ks) + i * 8192);
                 }
             };
             ldh(0, 0);
@@ -133,17 +133,17 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
             for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    wl[i] = *(const bf16x8*)(wl_lo + fa(ks) + i * 8192);
+                    wl[i] = *(const h16x8*)(wl_lo + fa(ks) + i * 8192);
                 }
                 if (ks + 1 < 8) ldh((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 fxh = __builtin_bit_cast(bf16x8, xh[ks]), fxl = __builtin_bit_cast(bf16x8, xl[ks]);
+                const h16x8 fxh = __builtin_bit_cast(h16x8, xh[ks]), fxl = __builtin_bit_cast(h16x8, xl[ks]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], fxh, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wh[ks & 1][i], fxh, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks & 1][i], fxl, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wh[ks & 1][i], fxl, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], fxh, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wl[i], fxh, acc[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -158,37 +158,37 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
         // GDN contraction: the squares of k-step ks + 1 (VALU) and its gamma'_hi fragments (LDS) are prepared before the 12 MFMAs of
         // k-step ks are issued; gamma'_lo is requested at the start of its k-step and used last
         {
-            bf16x8 gh[2][4], gl[4], fq[2][2];
+            h16x8 gh[2][4], gl[4], fq[2][2];
             auto prep = [&](int set, int ks) {
                 const int si = ks >> 1, so = (ks & 1) * 8;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    gh[set][i] = *(const bf16x8*)(gl_hi + fa(ks) + i * 8192);
+                    gh[set][i] = *(const h16x8*)(gl_hi + fa(ks) + i * 8192);
                 }
                 uint32_t qh[4], ql[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e], s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1];
+                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e] * H16_SQ_SCALE, s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1] * H16_SQ_SCALE;
                     split2(s0, s1, qh[e], ql[e]);
                 }
-                fq[set][0] = __builtin_bit_cast(bf16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
-                fq[set][1] = __builtin_bit_cast(bf16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
+                fq[set][0] = __builtin_bit_cast(h16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
+                fq[set][1] = __builtin_bit_cast(h16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
             };
             prep(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    gl[i] = *(const bf16x8*)(gl_lo + fa(ks) + i * 8192);
+                    gl[i] = *(const h16x8*)(gl_lo + fa(ks) + i * 8192);
                 }
                 if (ks + 1 < 8) prep((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[ks & 1][i], fq[ks & 1][1], nrm[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][1], nrm[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nrm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gl[i], fq[ks & 1][0], nrm[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -215,10 +215,10 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int i = cg * 2 + ii, cl = ii * 32 + 8 * g + 4 * fh;              // channel inside this pass's 64
-                    uint32_t h0 = pack_bf2(acc[i][4 * g], acc[i][4 * g + 1]), h1 = pack_bf2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                    uint32_t h0 = pack_h2(acc[i][4 * g], acc[i][4 * g + 1]), h1 = pack_h2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
                     if (half) {
-                        h0 = pack_bf2(acc[i][4 * g] - __uint_as_float(h0 << 16), acc[i][4 * g + 1] - __uint_as_float(h0 & 0xffff0000u));
-                        h1 = pack_bf2(acc[i][4 * g + 2] - __uint_as_float(h1 << 16), acc[i][4 * g + 3] - __uint_as_float(h1 & 0xffff0000u));
+                        h0 = pack_h2(acc[i][4 * g] - h2f_lo(h0), acc[i][4 * g + 1] - h2f_hi(h0));
+                        h1 = pack_h2(acc[i][4 * g + 2] - h2f_lo(h1), acc[i][4 * g + 3] - h2f_hi(h1));
                     }
                     *(u32x2*)(os + frow * 128 + (((cl >> 3) ^ (frow & 7)) << 4) + (cl & 7) * 2) = u32x2{h0, h1};
                 }
@@ -268,7 +268,7 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
         for (int e = 0; e < 8; ++e) {
             const int c = 16 * ks + 4 * h + (e & 3) + (e >> 2) * 8;
             const float t = fmaxf(gamma[row * 128 + c], gb);
-            v[e] = t * t - ped;
+            v[e] = (t * t - ped) * H16_SQ_UNSCALE;
         }
         pos = q ^ (row & 15);
     }
@@ -292,7 +292,7 @@ extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const f
                                               const float* beta_packed, int inverse, void* y_hilo, void* stream) {
     HESIC_CHECK_ARG(d && x && image_hilo && beta_packed && y_hilo, "sconv2d_gdn_forward_hilo: null pointer");
     HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
-                        d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_BF16 && d->act == HESIC_ACT_NONE && d->ys_c == 1 && d->ys_x >= 256 &&
+                        d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_H16 && d->act == HESIC_ACT_NONE && d->ys_c == 1 && d->ys_x >= 256 &&
                         (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 && (d->ys_b % 8) == 0,
                     "sconv2d_gdn_forward_hilo: built for the 3 -> 128 5x5 stride-2 stage, fp32 image in, [hi | lo] bf16 NHWC out (pixel stride >= 256)");
     HESIC_CHECK_ARG(d->Ho == (d->H + 4 - 5) / 2 + 1 && d->Wo == (d->W + 4 - 5) / 2 + 1, "sconv2d_gdn_forward_hilo: output size does not match");
@@ -302,7 +302,7 @@ extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const f
                         ((int64_t)d->Ho * d->ys_y + (int64_t)d->Wo * d->ys_x) * 2 < (1ll << 31),
                     "sconv2d_gdn_forward_hilo: needs fp32 planes with unit pixel stride, an even width and 32-bit offsets inside one image");
     HArgs a;
-    a.x = x; a.img = (const unsigned char*)image_hilo; a.bias = bias; a.beta = beta_packed; a.y = (bf16_t*)y_hilo;
+    a.x = x; a.img = (const unsigned char*)image_hilo; a.bias = bias; a.beta = beta_packed; a.y = (h16_t*)y_hilo;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.xs_b = d->xs_b; a.xs_c = d->xs_c; a.xs_y = d->xs_y; a.ys_b = d->ys_b; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
     a.fd_tx = make_fastdiv((uint32_t)((d->Wo + 15) / 16)); a.fd_ty = make_fastdiv((uint32_t)((d->Ho + 1) / 2));

@@ -48,7 +48,7 @@ struct WgArgs {
 };
 
 template <typename T> struct WC;
-template <> struct WC<bf16_t> { static constexpr int BK = 64, PB = 8, CB = 8; };
+template <> struct WC<h16_t> { static constexpr int BK = 64, PB = 8, CB = 8; };
 template <> struct WC<float> { static constexpr int BK = 32, PB = 4, CB = 4; };
 
 template <typename T>
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
                         uint32_t* w4 = (uint32_t*)&t[c];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
-                            w4[q] = pack_bf2(lo * lo, hi * hi);
+                            const float lo = h2f_lo(w4[q]), hi = h2f_hi(w4[q]);
+                            w4[q] = pack_h2(lo * lo, hi * hi);
                         }
                     }
                 }
@@ -199,15 +199,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 df[2], xf[2];
+                h16x8 df[2], xf[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) df[i] = *(const bf16x8*)(ds + w_off<T>(wm * 64 + i * 32 + frow, ks * 2 + fh));
+                for (int i = 0; i < 2; ++i) df[i] = *(const h16x8*)(ds + w_off<T>(wm * 64 + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xf[j] = *(const bf16x8*)(xs + w_off<T>(wn * 64 + j * 32 + frow, ks * 2 + fh));
+                for (int j = 0; j < 2; ++j) xf[j] = *(const h16x8*)(xs + w_off<T>(wn * 64 + j * 32 + frow, ks * 2 + fh));
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_h16(df[i], xf[j], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     // compile-time variant of the loop: no branches between the transpose reads and the MFMAs
     auto main_loop = [&](auto abs_tag, auto sq_tag, auto fast_tag, auto bias_tag) {
         constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value, FASTQ = decltype(fast_tag)::value, BIAS = decltype(bias_tag)::value;
-        const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+        const u32x4 ones_u = {H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR};
+        const h16x8 ones = __builtin_bit_cast(h16x8, ones_u);
         auto issue = [&](int buf) {
             if constexpr (FASTQ) issue_fast(buf);
             else issue_slow(buf);
@@ -458,11 +458,11 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16) ldf((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                bf16x8 df[2], xf[2];
+                h16x8 df[2], xf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const s16x8 v = __builtin_shufflevector(dlo[ks & 1][i], dhi[ks & 1][i], 0, 1, 2, 3, 4, 5, 6, 7);
-                    df[i] = __builtin_bit_cast(bf16x8, v);
+                    df[i] = __builtin_bit_cast(h16x8, v);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -473,20 +473,20 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
                         uint32_t* w4 = (uint32_t*)&u;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
-                            w4[q] = pack_bf2(l2 * l2, h2 * h2);
+                            const float l2 = h2f_lo(w4[q]), h2 = h2f_hi(w4[q]);
+                            w4[q] = pack_h2(l2 * l2, h2 * h2);
                         }
                         v = __builtin_bit_cast(s16x8, u);
                     }
-                    xf[j] = __builtin_bit_cast(bf16x8, v);
+                    xf[j] = __builtin_bit_cast(h16x8, v);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_h16(df[i], xf[j], acc[i][j], 0, 0, 0);
                 if constexpr (BIAS) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], ones, bacc[i], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) bacc[i] = mfma_32x32x16_h16(df[i], ones, bacc[i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -600,10 +600,10 @@ __device__ __forceinline__ void colsum_body(const T* __restrict__ dy, float* __r
     if (rsub < rpi) {
         auto add = [&](const u32x4 raw) {
             if constexpr (sizeof(T) == 2) {
-                acc[0] += __uint_as_float(raw.x << 16); acc[1] += __uint_as_float(raw.x & 0xffff0000u);
-                acc[2] += __uint_as_float(raw.y << 16); acc[3] += __uint_as_float(raw.y & 0xffff0000u);
-                acc[4] += __uint_as_float(raw.z << 16); acc[5] += __uint_as_float(raw.z & 0xffff0000u);
-                acc[6] += __uint_as_float(raw.w << 16); acc[7] += __uint_as_float(raw.w & 0xffff0000u);
+                acc[0] += h2f_lo(raw.x); acc[1] += h2f_hi(raw.x);
+                acc[2] += h2f_lo(raw.y); acc[3] += h2f_hi(raw.y);
+                acc[4] += h2f_lo(raw.z); acc[5] += h2f_hi(raw.z);
+                acc[6] += h2f_lo(raw.w); acc[7] += h2f_hi(raw.w);
             } else {
                 acc[0] += __uint_as_float(raw.x); acc[1] += __uint_as_float(raw.y); acc[2] += __uint_as_float(raw.z); acc[3] += __uint_as_float(raw.w);
             }
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void sconv_wgrad_nw_kernel(const WT* __restric
 // its own: eight dependent round trips per chunk, 64 us per launch for 100 MB).
 template <typename T>
 __device__ __forceinline__ void im2col_narrow_body(const T* __restrict__ narrow, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
-                                                   bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
+                                                   h16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
     const int64_t total = (int64_t)B * QH * QW * 12;          // 12 chunks of 8 columns per pixel
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ck = i % 12;
@@ -930,12 +930,12 @@ __device__ __forceinline__ void im2col_narrow_body(const T* __restrict__ narrow,
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ok[e] ? v[e] : 0.f;
-        *(u32x4*)(P + q * 96 + ck * 8) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(P + q * 96 + ck * 8) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
     }
 }
 __global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtype, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
-                                     bf16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
-    if (n_dtype == HESIC_BF16) im2col_narrow_body<bf16_t>((const bf16_t*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
+                                     h16_t* __restrict__ P, int B, int QH, int QW, int NH, int NW, int NC) {
+    if (n_dtype == HESIC_H16) im2col_narrow_body<h16_t>((const h16_t*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
     else im2col_narrow_body<float>((const float*)narrow, ns_b, ns_c, ns_y, ns_x, P, B, QH, QW, NH, NW, NC);
 }
 // The same matrix with one THREAD per pixel row: a wave's lanes are 64 consecutive pixels of an image row, so each of the 75 gathers reads
@@ -943,7 +943,7 @@ __global__ void im2col_narrow_kernel(const void* __restrict__ narrow, int n_dtyp
 // ~15 rows x 5 pixels), and the row leaves as twelve 16-byte stores.  Same values, same layout.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_narrow_rows_kernel(const T* __restrict__ narrow, int64_t ns_b, int64_t ns_c, int64_t ns_y, int64_t ns_x,
-                                                                 bf16_t* __restrict__ P, int64_t Q, int QH, int QW, int NH, int NW, FastDiv dqw, FastDiv dqh) {
+                                                                 h16_t* __restrict__ P, int64_t Q, int QH, int QW, int NH, int NW, FastDiv dqw, FastDiv dqh) {
     // the 64 rows of a wave are 12 KB of CONSECUTIVE bytes of P: they go through LDS (13 slots per row: conflict-free 16-byte writes) and
     // leave lane-linear, 1 KB per store instruction (as twelve 16-byte stores per lane at a 192-byte stride the kernel took 51.7 us)
     __shared__ u32x4 stage[256 * 13];
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void im2col_narrow_rows_kernel(const T* __rest
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int n = ck * 8 + 2 * h;
-            if (n < 75) w4[h] = pack_bf2(v[n], v[n + 1]);
+            if (n < 75) w4[h] = pack_h2(v[n], v[n + 1]);
         }
         stage[threadIdx.x * 13 + ck] = o;
     }
@@ -1095,8 +1095,8 @@ __global__ __launch_bounds__(256, 2) void sconv_wgrad_nn_kernel(const void* __re
                     if (i0 + tid + 256 * u < NS_ * PH * PW) st[i0 + tid + 256 * u] = v[u];
             }
         };
-        if (a_dtype == HESIC_BF16) stage_a(bf16_t{}); else stage_a(float{});
-        if (s_dtype == HESIC_BF16) stage_s(bf16_t{}); else stage_s(float{});
+        if (a_dtype == HESIC_H16) stage_a(h16_t{}); else stage_a(float{});
+        if (s_dtype == HESIC_H16) stage_s(h16_t{}); else stage_s(float{});
         __syncthreads();
 #pragma unroll 2
         for (int r = 0; r < TH; ++r) {
@@ -1437,9 +1437,9 @@ __device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (s
 // waits for the next tile's loads only, not for the stores of the tile before (the branchy form waited vmcnt(0): a store round trip
 // per tile) -- and can batch the LDS reads of the epilogues across channel groups.
 template <bool PAR, bool INV>
-__global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy,
+__global__ __launch_bounds__(256) void gdn128_bwd_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gy,
                                                          const float* __restrict__ beta, const float* __restrict__ gamma,
-                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dn_out, float* __restrict__ part,
+                                                         h16_t* __restrict__ dx, h16_t* __restrict__ dn_out, float* __restrict__ part,
                                                          int64_t P, float beta_bound) {
     constexpr bool inverse = INV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1457,12 +1457,12 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
         const f32x4 a0 = *(const f32x4*)(gamma + row * 128 + slot * 8), a1 = *(const f32x4*)(gamma + row * 128 + slot * 8 + 4);
         const float v[8] = {reparam(a0.x, kGammaBound), reparam(a0.y, kGammaBound), reparam(a0.z, kGammaBound), reparam(a0.w, kGammaBound),
                             reparam(a1.x, kGammaBound), reparam(a1.y, kGammaBound), reparam(a1.z, kGammaBound), reparam(a1.w, kGammaBound)};
-        const u32x4 pk = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        const u32x4 pk = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
         *(u32x4*)(gs + gb_off(row, slot)) = pk;
         const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            *(bf16_t*)(gt + gb_off(slot * 8 + e, row >> 3) + (row & 7) * 2) = (bf16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
+            *(h16_t*)(gt + gb_off(slot * 8 + e, row >> 3) + (row & 7) * 2) = (h16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
     }
     float* bl = (float*)(smem + 131072);        // beta' (read back per tile: 64 registers of a lone wave's budget go to the third GEMM)
     if (tid < 128) bl[tid] = reparam(beta[tid], beta_bound);
@@ -1518,16 +1518,16 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const u32x4 raw = *(const u32x4*)(xs + gb_off(r0 + frow, ks * 2 + fh));
-            const float f0 = __uint_as_float(raw.x << 16), f1 = __uint_as_float(raw.x & 0xffff0000u);
-            const float f2 = __uint_as_float(raw.y << 16), f3 = __uint_as_float(raw.y & 0xffff0000u);
-            const float f4 = __uint_as_float(raw.z << 16), f5 = __uint_as_float(raw.z & 0xffff0000u);
-            const float f6 = __uint_as_float(raw.w << 16), f7 = __uint_as_float(raw.w & 0xffff0000u);
-            const u32x4 sq = u32x4{pack_bf2(f0 * f0, f1 * f1), pack_bf2(f2 * f2, f3 * f3), pack_bf2(f4 * f4, f5 * f5), pack_bf2(f6 * f6, f7 * f7)};
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, sq);
+            const float f0 = h2f_lo(raw.x), f1 = h2f_hi(raw.x);
+            const float f2 = h2f_lo(raw.y), f3 = h2f_hi(raw.y);
+            const float f4 = h2f_lo(raw.z), f5 = h2f_hi(raw.z);
+            const float f6 = h2f_lo(raw.w), f7 = h2f_hi(raw.w);
+            const u32x4 sq = u32x4{pack_h2(f0 * f0, f1 * f1), pack_h2(f2 * f2, f3 * f3), pack_h2(f4 * f4, f5 * f5), pack_h2(f6 * f6, f7 * f7)};
+            const h16x8 xf = __builtin_bit_cast(h16x8, sq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bf16x8 gf = *(const bf16x8*)(gs + gb_off(i * 32 + frow, ks * 2 + fh));
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[i], 0, 0, 0);
+                const h16x8 gf = *(const h16x8*)(gs + gb_off(i * 32 + frow, ks * 2 + fh));
+                acc[i] = mfma_32x32x16_h16(gf, xf, acc[i], 0, 0, 0);
             }
         }
         // lane: pixel r0+frow, channels i*32 + 8g + 4fh + e.  t1 stays in acc, dn replaces gy in LDS
@@ -1538,8 +1538,8 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 const int ch = i * 32 + 8 * g + 4 * fh;
                 const int off = gb_off(r0 + frow, ch >> 3) + (ch & 7) * 2;
                 const u32x2 xr = *(const u32x2*)(xs + off), gr = *(const u32x2*)(ds + off);
-                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
-                const float gv[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xffff0000u), __uint_as_float(gr.y << 16), __uint_as_float(gr.y & 0xffff0000u)};
+                const float xv[4] = {h2f_lo(xr.x), h2f_hi(xr.x), h2f_lo(xr.y), h2f_hi(xr.y)};
+                const float gv[4] = {h2f_lo(gr.x), h2f_hi(gr.x), h2f_lo(gr.y), h2f_hi(gr.y)};
                 float dn[4];
                 const f32x4 bq = *(const f32x4*)(bl + ch);
                 const float bvv[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                         acc[i][4 * g + e] = gv[e] * rs;
                     }
                 }
-                *(u32x2*)(ds + off) = u32x2{pack_bf2(dn[0], dn[1]), pack_bf2(dn[2], dn[3])};
+                *(u32x2*)(ds + off) = u32x2{pack_h2(dn[0], dn[1]), pack_h2(dn[2], dn[3])};
             }
         // GEMM2: s[j][p] = sum_i gamma'^T[j][i] dn[p][i]
         f32x16 s2[4];
@@ -1566,11 +1566,11 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
             for (int r = 0; r < 16; ++r) s2[i][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 df = *(const bf16x8*)(ds + gb_off(r0 + frow, ks * 2 + fh));
+            const h16x8 df = *(const h16x8*)(ds + gb_off(r0 + frow, ks * 2 + fh));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bf16x8 gf = *(const bf16x8*)(gt + gb_off(i * 32 + frow, ks * 2 + fh));
-                s2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, df, s2[i], 0, 0, 0);
+                const h16x8 gf = *(const h16x8*)(gt + gb_off(i * 32 + frow, ks * 2 + fh));
+                s2[i] = mfma_32x32x16_h16(gf, df, s2[i], 0, 0, 0);
             }
         }
         if constexpr (PAR) {
@@ -1593,20 +1593,20 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 uint32_t* w4 = (uint32_t*)&ux;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float l2 = __uint_as_float(w4[q] << 16), h2 = __uint_as_float(w4[q] & 0xffff0000u);
-                    w4[q] = pack_bf2(l2 * l2, h2 * h2);
+                    const float l2 = h2f_lo(w4[q]), h2 = h2f_hi(w4[q]);
+                    w4[q] = pack_h2(l2 * l2, h2 * h2);
                 }
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, ux);
+                const h16x8 xf = __builtin_bit_cast(h16x8, ux);
                 {   // the column sums of dn: channel block `wave` by this wave (its own pair of reads: no wave-dependent branch in the loop)
                     const s16x8 vc = __builtin_shufflevector(tr(ds, wv * 32, pix), tr(ds, wv * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
                     const u32x4 ua = __builtin_bit_cast(u32x4, vc);
-                    cs += ((__uint_as_float(ua.x << 16) + __uint_as_float(ua.x & 0xffff0000u)) + (__uint_as_float(ua.y << 16) + __uint_as_float(ua.y & 0xffff0000u))) +
-                          ((__uint_as_float(ua.z << 16) + __uint_as_float(ua.z & 0xffff0000u)) + (__uint_as_float(ua.w << 16) + __uint_as_float(ua.w & 0xffff0000u)));
+                    cs += ((h2f_lo(ua.x) + h2f_hi(ua.x)) + (h2f_lo(ua.y) + h2f_hi(ua.y))) +
+                          ((h2f_lo(ua.z) + h2f_hi(ua.z)) + (h2f_lo(ua.w) + h2f_hi(ua.w)));
                 }
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
                     const s16x8 va = __builtin_shufflevector(tr(ds, ib * 32, pix), tr(ds, ib * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-                    g3[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), xf, g3[ib], 0, 0, 0);
+                    g3[ib] = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, va), xf, g3[ib], 0, 0, 0);
                 }
             }
             __syncthreads();
@@ -1618,11 +1618,11 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const bf16_t* __restric
                 const int ch = i * 32 + 8 * g + 4 * fh;
                 const int off = gb_off(r0 + frow, ch >> 3) + (ch & 7) * 2;
                 const u32x2 xr = *(const u32x2*)(xs + off);
-                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                const float xv[4] = {h2f_lo(xr.x), h2f_hi(xr.x), h2f_lo(xr.y), h2f_hi(xr.y)};
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = acc[i][4 * g + e] + 2.f * xv[e] * s2[i][4 * g + e];
-                *(u32x2*)(xs + off) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                *(u32x2*)(xs + off) = u32x2{pack_h2(o[0], o[1]), pack_h2(o[2], o[3])};
             }
         // wave-private copy-out of dx and dn (full 256-byte rows)
         const int so = (int)tile * 32768 + lofs;
@@ -1687,7 +1687,7 @@ int fill_args(const hesic_conv_desc* d, WgArgs& a) {
     for (int t = 0; t < d->KH * d->KW; ++t)
         if (!d->tap_mask_lo || ((d->tap_mask_lo >> t) & 1)) a.tap_id[n++] = (int8_t)t;
     a.ntaps = n;
-    const int bk = d->dtype == HESIC_BF16 ? WC<bf16_t>::BK : WC<float>::BK;
+    const int bk = d->dtype == HESIC_H16 ? WC<h16_t>::BK : WC<float>::BK;
     a.nsplit = pick_splits(a.Q, bk, n * a.co_tiles * a.ci_tiles);
     a.chunk = ((a.Q + a.nsplit - 1) / a.nsplit + bk - 1) / bk * bk;
     a.nsplit = (int)((a.Q + a.chunk - 1) / a.chunk);
@@ -1703,7 +1703,7 @@ static bool wgrad_tr_path(const hesic_conv_desc* d, const WgArgs& a) {
     bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
     for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
     const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
-    return d->dtype == HESIC_BF16 && prefix && a.Q < (1ll << 31) && off32;
+    return d->dtype == HESIC_H16 && prefix && a.Q < (1ll << 31) && off32;
 }
 // point a.bias_part behind the weight partials in ws and list the taps whose blocks sum dY's columns; false: no such tap set
 static bool setup_bias_part(const hesic_conv_desc* d, WgArgs& a, void* ws) {
@@ -1731,7 +1731,7 @@ extern "C" int64_t hesic_conv2d_wgrad_ws_bytes(const hesic_conv_desc* d) {
 extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
                                   void* ws, int64_t ws_bytes, void* stream) {
     HESIC_CHECK_ARG(d && x && dy && dw_packed, "conv2d_wgrad: null pointer");
-    const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
+    const int ce = d->dtype == HESIC_H16 ? 8 : 4;
     HESIC_CHECK_ARG(d->Cin % ce == 0 && d->Cout % ce == 0 && d->x_pix_stride % ce == 0 && d->y_pix_stride % ce == 0 &&
                         d->x_c_off % ce == 0 && d->y_c_off % ce == 0,
                     "conv2d_wgrad: channels must be multiples of %d", ce);
@@ -1748,11 +1748,11 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
     const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
     bool db_zeroed = false;
-    if (d->dtype == HESIC_BF16 && !wg_legacy && prefix && a.Q < (1ll << 31) && off32) {
+    if (d->dtype == HESIC_H16 && !wg_legacy && prefix && a.Q < (1ll << 31) && off32) {
         launch_wgrad_tr(a, blocks, st, dbias, dbias ? d->Cout : 0);
         db_zeroed = dbias != nullptr;
     }
-    else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+    else if (d->dtype == HESIC_H16) hipLaunchKernelGGL(wgrad_kernel<h16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
     if (a.ntaps < d->KH * d->KW) zero_async(dw_packed, (int64_t)d->KH * d->KW * per_tap, st);
@@ -1762,9 +1762,9 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: each ends in C atomics
         const int n_col = (int)((P + rpb - 1) / rpb), n_red = grid_for(a.ntaps * per_tap / 4, 256);
-        if (d->dtype == HESIC_BF16)
-            hipLaunchKernelGGL(wgrad_reduce_colsum_kernel<bf16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)ws, dw_packed,
-                               a.nsplit, a.ntaps, per_tap, a, n_red, (const bf16_t*)dy, dbias, P, rpb);
+        if (d->dtype == HESIC_H16)
+            hipLaunchKernelGGL(wgrad_reduce_colsum_kernel<h16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)ws, dw_packed,
+                               a.nsplit, a.ntaps, per_tap, a, n_red, (const h16_t*)dy, dbias, P, rpb);
         else
             hipLaunchKernelGGL(wgrad_reduce_colsum_kernel<float>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)ws, dw_packed,
                                a.nsplit, a.ntaps, per_tap, a, n_red, (const float*)dy, dbias, P, rpb);
@@ -1781,8 +1781,8 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
         const unsigned g = (unsigned)((P + rpb - 1) / rpb);
-        if (d->dtype == HESIC_BF16)
-            hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dy, dbias, P, d->Cout, d->y_pix_stride, d->y_c_off, rpb);
+        if (d->dtype == HESIC_H16)
+            hipLaunchKernelGGL(colsum_kernel<h16_t>, dim3(g), dim3(256), 0, st, (const h16_t*)dy, dbias, P, d->Cout, d->y_pix_stride, d->y_c_off, rpb);
         else
             hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, dbias, P, d->Cout, d->y_pix_stride, d->y_c_off, rpb);
     }
@@ -1819,7 +1819,7 @@ static thread_local int g_wgrad_partial_only = 0;      // set by hesic_conv2d_wg
 extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                          int accumulate, void* ws, int64_t ws_bytes, void* stream) {
     HESIC_CHECK_ARG(d && x && dy && (dw || g_wgrad_partial_only), "conv2d_wgrad_direct: null pointer");
-    const int ce = d->dtype == HESIC_BF16 ? 8 : 4;
+    const int ce = d->dtype == HESIC_H16 ? 8 : 4;
     HESIC_CHECK_ARG(d->Cin % ce == 0 && d->Cout % ce == 0 && d->x_pix_stride % ce == 0 && d->y_pix_stride % ce == 0 &&
                         d->x_c_off % ce == 0 && d->y_c_off % ce == 0,
                     "conv2d_wgrad_direct: channels must be multiples of %d", ce);
@@ -1837,7 +1837,7 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     if (wgrad_tr_path(d, a)) {
         launch_wgrad_tr(a, blocks, st, zero_me, zero_me ? d->Cout : 0);
         db_zeroed = true;
-    } else if (d->dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+    } else if (d->dtype == HESIC_H16) hipLaunchKernelGGL(wgrad_kernel<h16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     if (g_wgrad_partial_only) HESIC_LAUNCH_RETURN("conv2d_wgrad_partial");
     if (zero_me && !db_zeroed) zero_async(dbias, d->Cout, st);
@@ -1846,8 +1846,8 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     FinishArgs f;
     int64_t P, rpb;
     const int n_col = make_finish(d, a, ws, dw, accumulate, dbias != nullptr, f, P, rpb, accumulate);
-    if (d->dtype == HESIC_BF16)
-        hipLaunchKernelGGL(wgrad_finish_kernel<bf16_t>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const bf16_t*)dy, dbias, P,
+    if (d->dtype == HESIC_H16)
+        hipLaunchKernelGGL(wgrad_finish_kernel<h16_t>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const h16_t*)dy, dbias, P,
                            d->y_pix_stride, d->y_c_off, rpb);
     else
         hipLaunchKernelGGL(wgrad_finish_kernel<float>, dim3((unsigned)(f.n_red + n_col)), dim3(256), 0, st, f, (const float*)dy, dbias, P,
@@ -1857,9 +1857,9 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
 
 static bool nw_fast_case(const hesic_sconv_desc* d, bool& conv1) {
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 2;
-    conv1 = k5 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 && d->H == 2 * d->Ho &&
+    conv1 = k5 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_H16 && d->H == 2 * d->Ho &&
             d->W == 2 * d->Wo && d->ys_x == 128 && d->ys_y == (int64_t)d->Wo * 128 && d->ys_b == (int64_t)d->Ho * d->Wo * 128;
-    const bool dec4 = k5 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_BF16 && d->Ho == 2 * d->H &&
+    const bool dec4 = k5 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_H16 && d->Ho == 2 * d->H &&
                       d->Wo == 2 * d->W && d->xs_x == 128 && d->xs_y == (int64_t)d->W * 128 && d->xs_b == (int64_t)d->H * d->W * 128;
     return conv1 || dec4;
 }
@@ -1867,7 +1867,7 @@ static bool nw_fast_case(const hesic_sconv_desc* d, bool& conv1) {
 static void nw_gemm_desc(int64_t Q, hesic_conv_desc& g) {
     memset(&g, 0, sizeof(g));
     g.B = 1; g.H = 1; g.W = (int32_t)Q; g.Cin = 96; g.Ho = 1; g.Wo = (int32_t)Q; g.Cout = 128; g.KH = g.KW = 1; g.stride = 1;
-    g.dtype = HESIC_BF16; g.x_pix_stride = 96; g.y_pix_stride = 128;
+    g.dtype = HESIC_H16; g.x_pix_stride = 96; g.y_pix_stride = 128;
 }
 
 static bool nn_case(const hesic_sconv_desc* d) {
@@ -1909,7 +1909,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         // MFMA route: im2col of the 3-channel side, then the 1x1 weight-gradient kernel with WIDE as "dY"
         const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
         const int QH = conv1 ? d->Ho : d->H, QW = conv1 ? d->Wo : d->W, NH = conv1 ? d->H : d->Ho, NW = conv1 ? d->W : d->Wo;
-        bf16_t* P = (bf16_t*)ws;
+        h16_t* P = (h16_t*)ws;
         float* part = (float*)((unsigned char*)ws + (Q * 96 * 2 + 255) / 256 * 256);
         static const bool chunk_form = getenv("HESIC_IM2COL_CHUNKS") != nullptr;      // A/B switch: the thread-per-chunk kernel of rounds 1-3
         const void* nimg = conv1 ? x : dy;
@@ -1918,8 +1918,8 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         if (!chunk_form && Q < (1ll << 31)) {
             const FastDiv dqw = make_fastdiv((uint32_t)QW), dqh = make_fastdiv((uint32_t)QH);
             const dim3 grid((unsigned)((Q + 255) / 256));
-            if (ndt == HESIC_BF16)
-                hipLaunchKernelGGL(im2col_narrow_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)nimg, nsb, nsc, nsy, nsx, P, Q, QH, QW, NH, NW, dqw, dqh);
+            if (ndt == HESIC_H16)
+                hipLaunchKernelGGL(im2col_narrow_rows_kernel<h16_t>, grid, dim3(256), 0, st, (const h16_t*)nimg, nsb, nsc, nsy, nsx, P, Q, QH, QW, NH, NW, dqw, dqh);
             else
                 hipLaunchKernelGGL(im2col_narrow_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)nimg, nsb, nsc, nsy, nsx, P, Q, QH, QW, NH, NW, dqw, dqh);
         } else
@@ -1940,17 +1940,17 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
             hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)bpart, dbias, a2.nsplit);
             dbias = nullptr;                          // done: skip the column-sum pass below
         }
-    } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_BF16 &&
+    } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_H16 &&
         d->H == 2 * d->Ho && d->W == 2 * d->Wo) {
         // conv1: WIDE = dy (output grid), NARROW = x
         const int64_t tiles = (int64_t)((d->Wo + 15) / 16) * ((d->Ho + 7) / 8) * d->B;
-        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, bf16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const bf16_t*)dy,
+        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, h16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const h16_t*)dy,
                            d->ys_b, d->ys_y, d->ys_x, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, d->B, d->Ho, d->Wo, d->H, d->W);
-    } else if (!legacy && k5 && d->stride == 2 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_BF16 &&
+    } else if (!legacy && k5 && d->stride == 2 && d->transposed && d->Cin == 128 && d->Cout == 3 && d->xs_c == 1 && d->x_dtype == HESIC_H16 &&
                d->Ho == 2 * d->H && d->Wo == 2 * d->W) {
         // deconv4: WIDE = x (input grid), NARROW = dy
         const int64_t tiles = (int64_t)((d->W + 15) / 16) * ((d->H + 7) / 8) * d->B;
-        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, bf16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const bf16_t*)x,
+        hipLaunchKernelGGL((sconv_wgrad_nw_kernel<3, h16_t>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, (const h16_t*)x,
                            d->xs_b, d->xs_y, d->xs_x, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, d->B, d->H, d->W, d->Ho, d->Wo);
     } else if (!legacy && k5 && d->stride == 1 && d->Cin == 6 && d->Cout == 3 && d->Ho == d->H && d->Wo == d->W) {
         const int64_t tiles = (int64_t)((d->W + 63) / 64) * ((d->H + 15) / 16) * d->B;
@@ -1979,7 +1979,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
             d->ys_b == (int64_t)d->Ho * d->Wo * d->Cout) {       // dense NHWC: coalesced column sums
             const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 blocks: every block ends in C atomics
             const unsigned g = (unsigned)((P + rpb - 1) / rpb);
-            if (d->y_dtype == HESIC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
+            if (d->y_dtype == HESIC_H16) hipLaunchKernelGGL(colsum_kernel<h16_t>, dim3(g), dim3(256), 0, st, (const h16_t*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
             else hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, dbias, P, d->Cout, d->Cout, 0, rpb);
         } else {
             hipLaunchKernelGGL(sconv_dbias_kernel, dim3(256, d->Cout), dim3(256), 0, st, a);
@@ -1992,7 +1992,7 @@ static int gdn_fast_desc(int64_t P, hesic_conv_desc& d) {
     // the parameter gradients of the fast path are a 1x1 "conv" weight gradient over P pixels: dY = dn, X = x
     memset(&d, 0, sizeof(d));
     d.B = 1; d.H = 1; d.W = (int32_t)P; d.Cin = 128; d.Ho = 1; d.Wo = (int32_t)P; d.Cout = 128; d.KH = d.KW = 1; d.stride = 1;
-    d.dtype = HESIC_BF16; d.x_pix_stride = 128; d.y_pix_stride = 128;
+    d.dtype = HESIC_H16; d.x_pix_stride = 128; d.y_pix_stride = 128;
     return 0;
 }
 
@@ -2024,13 +2024,13 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
     static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr;
-    if (!legacy && C == 128 && dtype == HESIC_BF16 && P < (1ll << 22)) {
+    if (!legacy && C == 128 && dtype == HESIC_H16 && P < (1ll << 22)) {
         hesic_conv_desc d;
         gdn_fast_desc(P, d);
         WgArgs a;
         fill_args(&d, a);
         unsigned char* base = (unsigned char*)ws;
-        bf16_t* dn = (bf16_t*)base;
+        h16_t* dn = (h16_t*)base;
         int64_t off = (P * 128 * 2 + 255) / 256 * 256;
         void* wws = base + off;
         const int64_t wws_bytes = (int64_t)a.nsplit * 128 * 128 * 4;
@@ -2052,10 +2052,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             // one pass: dx + a (128 x 128 + 128) parameter-gradient partial per block, then the block partials summed in a fixed order
             constexpr int NP = 128 * 128 + 128;
             float* part = (float*)base;
-            if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
-                                            (bf16_t*)dx, (bf16_t*)nullptr, part, P, bound);
-            else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma,
-                                    (bf16_t*)dx, (bf16_t*)nullptr, part, P, bound);
+            if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+                                            (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
+            else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+                                    (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
             {
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
@@ -2063,10 +2063,10 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             hipLaunchKernelGGL(gdn_param_finish_kernel, dim3((unsigned)(NP / 64)), dim3(256), 0, st, (const float*)part, nb, beta, gamma, dgamma, dbeta, bound, accumulate);
             HESIC_LAUNCH_RETURN("gdn_backward");
         }
-        if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<false, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
-                                        (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, bound);
-        else hipLaunchKernelGGL((gdn128_bwd_kernel<false, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const bf16_t*)x,
-                                (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dn, (float*)nullptr, P, bound);
+        if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<false, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x,
+                                        (const h16_t*)dy, beta, gamma, (h16_t*)dx, dn, (float*)nullptr, P, bound);
+        else hipLaunchKernelGGL((gdn128_bwd_kernel<false, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x,
+                                (const h16_t*)dy, beta, gamma, (h16_t*)dx, dn, (float*)nullptr, P, bound);
         {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
@@ -2076,14 +2076,14 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         a.x = x; a.dy = dn; a.out = (float*)wws; a.in_sq = 1;
         const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
         static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
-        if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+        if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<h16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
         else launch_wgrad_tr(a, blocks, st, dbp, 128);
         if (wg_legacy) zero_async(dbp, 128, st);
         const int64_t rpb = P / 256 > 0 ? (P + 255) / 256 : 1;      // <= 256 column-sum blocks: every block ends in C atomics
         // K-slice reduce (slice-parallel form: this 1-tap problem is cut into up to 256 slices) + column sums of dn, one launch
         const int n_red = 128 * 128 / 64, n_col = (int)((P + rpb - 1) / rpb);
-        hipLaunchKernelGGL(wgrad_reduce_wide_colsum_kernel<bf16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
-                           (int64_t)128 * 128, a, n_red, (const bf16_t*)dn, dbp, P, 128, 128, 0, rpb);
+        hipLaunchKernelGGL(wgrad_reduce_wide_colsum_kernel<h16_t>, dim3((unsigned)(n_red + n_col)), dim3(256), 0, st, (const float*)wws, dgp, a.nsplit, 1,
+                           (int64_t)128 * 128, a, n_red, (const h16_t*)dn, dbp, P, 128, 128, 0, rpb);
         hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(64), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate);
         HESIC_LAUNCH_RETURN("gdn_backward");
     }
@@ -2095,8 +2095,8 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     static const bool small_split = getenv("HESIC_GDN3_BWD_SPLIT") != nullptr;      // A/B switch: the three passes
     if (C == 3 && !small_split) {
         const dim3 g3(grid_for(P, 256 * 2, 1024));      // 128 blocks (the parameter pass's grid: few atomics) left half the CUs idle: 57.9 us
-        if (dtype == HESIC_BF16)
-            hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, bf16_t>), g3, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dgp, dbp, P, inverse, bound);
+        if (dtype == HESIC_H16)
+            hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, h16_t>), g3, dim3(256), 0, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma, (h16_t*)dx, dgp, dbp, P, inverse, bound);
         else
             hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, float>), g3, dim3(256), 0, st, (const float*)x, (const float*)dy, beta, gamma, (float*)dx, dgp, dbp, P, inverse, bound);
         hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(1), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate);
@@ -2129,7 +2129,7 @@ extern "C" int hesic_gdn_backward_planar_acc(const void* x, const void* dy, cons
                                              int dtype, void* stream) {
     HESIC_CHECK_ARG(x && dy && beta && gamma && dx && dbeta && dgamma && ws && B > 0 && HW > 0, "gdn_backward_planar: bad arguments");
     HESIC_CHECK_ARG(C == 3, "gdn_backward_planar: built for the 3-channel image-side GDNs");
-    HESIC_CHECK_ARG(dtype == HESIC_BF16 || dtype == HESIC_F32, "gdn_backward_planar: bad dtype");
+    HESIC_CHECK_ARG(dtype == HESIC_H16 || dtype == HESIC_F32, "gdn_backward_planar: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
     float* dgp = (float*)ws;
@@ -2138,8 +2138,8 @@ extern "C" int hesic_gdn_backward_planar_acc(const void* x, const void* dy, cons
     int gx = grid_for(HW, 256 * 2, 1024);
     if ((int64_t)gx * B > 2048) gx = (int)(2048 / B > 0 ? 2048 / B : 1);
     const dim3 g3((unsigned)gx, (unsigned)B);
-    if (dtype == HESIC_BF16)
-        hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, bf16_t, true>), g3, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, beta, gamma, (bf16_t*)dx, dgp, dbp, HW, inverse, bound);
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, h16_t, true>), g3, dim3(256), 0, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma, (h16_t*)dx, dgp, dbp, HW, inverse, bound);
     else
         hipLaunchKernelGGL((gdn_bwd_small_fused_kernel<3, float, true>), g3, dim3(256), 0, st, (const float*)x, (const float*)dy, beta, gamma, (float*)dx, dgp, dbp, HW, inverse, bound);
     hipLaunchKernelGGL(gdn_bwd_chain_kernel, dim3(1), dim3(256), 0, st, beta, gamma, dgp, dbp, dgamma, dbeta, C, bound, accumulate ? 1 : 0);
@@ -2177,7 +2177,7 @@ extern "C" int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* d
             e.dy = dy[j0 + j]; e.db = dbias[j0 + j]; e.y_ps = d->y_pix_stride; e.y_co = d->y_c_off;
             fb.start[j + 1] = fb.start[j] + fb.f[j].n_red + n_col;
         }
-        if (descs[0].dtype == HESIC_BF16) hipLaunchKernelGGL(wgrad_finish_batched_kernel<bf16_t>, dim3((unsigned)fb.start[fb.n]), dim3(256), 0, st, fb);
+        if (descs[0].dtype == HESIC_H16) hipLaunchKernelGGL(wgrad_finish_batched_kernel<h16_t>, dim3((unsigned)fb.start[fb.n]), dim3(256), 0, st, fb);
         else hipLaunchKernelGGL(wgrad_finish_batched_kernel<float>, dim3((unsigned)fb.start[fb.n]), dim3(256), 0, st, fb);
     }
     HESIC_LAUNCH_RETURN("conv2d_wgrad_finish_batched");

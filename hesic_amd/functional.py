@@ -18,12 +18,27 @@ _compute_dtype = torch.float32
 
 
 def set_compute_dtype(dtype):
-    """Storage type of the wide feature maps: torch.float32 (exact-fp32 MFMA, parity mode) or
-    torch.bfloat16 (bf16 MFMA, fp32 accumulate)."""
+    """Storage type of the wide feature maps: torch.float32 (exact-fp32 MFMA, parity mode), torch.bfloat16 (bf16 MFMA, fp32
+    accumulate: training and inference) or torch.float16 (IEEE half operands on the matrix cores at the same rate, 11-bit
+    significand: INFERENCE -- the default of ``bench.py``).  A 16-bit choice also selects the library built for that format
+    (``_lib.use_h16``); packed-weight caches are dropped when the format changes."""
     global _compute_dtype
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
+    if dtype != torch.float32 and dtype != L.h16_dtype():
+        L.use_h16(dtype)
+        invalidate_weight_cache()
     _compute_dtype = dtype
+
+
+def _h16():
+    """torch dtype of the active 16-bit storage format."""
+    return L.h16_dtype()
+
+
+def _is16():
+    """True when the compute dtype is one of the 16-bit formats."""
+    return _compute_dtype != torch.float32
 
 
 def compute_dtype():
@@ -550,7 +565,7 @@ class _ConvFn(torch.autograd.Function):
                 torch.empty((B, Cout, Ho, Wo), dtype=ydt, device=x.device)
             w = weight.detach() if mask is None else (weight.detach() * mask)
             d = _sdesc(x, y, Cin, Cout, k, stride, pad, transposed, act)
-            if transposed and Cin == 128 and Cout == 3 and k == 5 and stride == 2 and mask is None and x.dtype == torch.bfloat16 and weight.dtype == torch.float32:
+            if transposed and Cin == 128 and Cout == 3 and k == 5 and stride == 2 and mask is None and x.dtype == _h16() and weight.dtype == torch.float32:
                 # g_s_conv4: the kernel's LDS weight panel is pre-packed once per weight update
                 L.call("hesic_sconv2d_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(w.contiguous()), L.ptr(_weight_image(1, weight)), L.ptr(bias),
                        L.ptr(y), L.stream())
@@ -599,7 +614,7 @@ class PackedGdn:
         tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
         if self._hit is not None and self._hit[0] == tag and not torch.is_grad_enabled():
             return self._hit[1], self._hit[2]
-        gp = torch.empty(2 * 128 * 128, dtype=torch.bfloat16, device=gamma.device)
+        gp = torch.empty(2 * 128 * 128, dtype=_h16(), device=gamma.device)
         bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
         L.call("hesic_gdn_pack_params", L.ptr(_c(beta)), L.ptr(_c(gamma)), float(beta_min), L.ptr(gp),
                L.ptr(bp), 128, L.stream())
@@ -621,11 +636,11 @@ def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
     if cin == 3:      # g_a_conv1 + g_a_gdn1: image in (any float dtype), bf16 storage out
         if torch.is_grad_enabled() and not FUSE_CONV_GDN_TRAIN:
             return False
-        return (not transposed and _compute_dtype == torch.bfloat16 and weight.shape[-1] == 5
-                and x.dtype in (torch.float32, torch.bfloat16))
+        return (not transposed and _is16() and weight.shape[-1] == 5
+                and x.dtype in (torch.float32, _h16()))
     if torch.is_grad_enabled() and not FUSE_CONV_GDN_TRAIN:
         return False
-    return x.dtype == torch.bfloat16 and cin % 32 == 0
+    return x.dtype == _h16() and cin % 32 == 0
 
 
 def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
@@ -666,8 +681,8 @@ class _SConvGdnFn(torch.autograd.Function):
         Cout = weight.shape[0]
         Ho, Wo = _out_hw(H, W, k, stride, pad, False)
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
-        y = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
-        v = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
+        y = _empty_nhwc(B, Cout, Ho, Wo, _h16(), x.device)
+        v = _empty_nhwc(B, Cout, Ho, Wo, _h16(), x.device)
         d = _sdesc(x, y, Cin, Cout, k, stride, pad, False)
         L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(_c(weight)),
                L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(y), L.ptr(v), L.stream())
@@ -728,7 +743,7 @@ def conv2d_gdn(x, weight, bias, beta, gamma, *, kernel_size, stride, padding, tr
         return _apply(_SConvGdnFn, x, weight, bias, beta, gamma, (k, stride, padding, inverse, beta_min, gdn_packer))
     if Cin == 3:      # image-side stage: strided fp32/bf16 image in, bf16 NHWC out
         gp, bp = gdn_packer.get(beta, gamma, beta_min)
-        out = _empty_nhwc(B, Cout, Ho, Wo, torch.bfloat16, x.device)
+        out = _empty_nhwc(B, Cout, Ho, Wo, _h16(), x.device)
         d = _sdesc(x, out, Cin, Cout, k, stride, padding, False)
         L.call("hesic_sconv2d_gdn_forward_prepacked", C.byref(d), L.ptr(x), L.ptr(_c(weight)),
                L.ptr(_n2w_image(weight, beta, gamma, gp, x)), L.ptr(bias), L.ptr(gp), L.ptr(bp), int(inverse), L.ptr(out), None, L.stream())
@@ -758,7 +773,7 @@ def fp32_latents():
     """True when the inference forward keeps what feeds round() and the likelihoods in fp32 although the feature maps are
     bf16: the latents y, z and the sigma / mu maps are written from the convs' fp32 accumulators (round 1 stored them as
     bf16: one ulp = 1/16 at |y| ~ 10, so latents near .5 flipped and bpp / PSNR sat just outside the 1e-3 target)."""
-    return FP32_LATENTS and _compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
+    return FP32_LATENTS and _is16() and not torch.is_grad_enabled()
 
 
 def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=False, act=L.ACT_NONE, in_abs=False,
@@ -768,7 +783,7 @@ def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=F
     accumulators; otherwise both are the ordinary output."""
     k = kernel_size
     Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
-    ok = (fp32_latents() and x.is_cuda and x.dtype == torch.bfloat16 and not _is_narrow(Cin) and not _is_narrow(Cout)
+    ok = (fp32_latents() and x.is_cuda and x.dtype == _h16() and not _is_narrow(Cin) and not _is_narrow(Cout)
           and Cin % 32 == 0 and Cout % 8 == 0)
     if not ok:
         y = conv2d(x, weight, bias, kernel_size=k, stride=stride, padding=padding, transposed=transposed, act=act, in_abs=in_abs,
@@ -811,7 +826,7 @@ def analysis_precision():
 
 def analysis_hilo(x):
     """True when the analysis stack should take the hi/lo route for input ``x``: bf16 inference on the GPU."""
-    return (_analysis_mode == "bf16x3" and _compute_dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.is_cuda)
+    return (_analysis_mode == "bf16x3" and _is16() and not torch.is_grad_enabled() and x.is_cuda)
 
 
 class PackedWeightHiLo:
@@ -830,12 +845,12 @@ class PackedWeightHiLo:
             cout = w.shape[0]
             flat = w.reshape(cout, -1)
             w = torch.cat([flat, flat.new_zeros(cout, kp - flat.shape[1])], 1).reshape(cout, kp, 1, 1)
-        hi = w.bfloat16().float()
-        lo = (w - hi).bfloat16().float()
+        hi = w.to(_h16()).float()
+        lo = (w - hi).to(_h16()).float()
         w2 = torch.cat([hi, lo], 1).contiguous()
         cout, cin2, kh, kw = w2.shape
-        wp = torch.empty(kh * kw * cout * cin2, dtype=torch.bfloat16, device=w2.device)
-        L.call("hesic_pack_conv_weight", L.ptr(w2), None, L.ptr(wp), cout, cin2, kh, kw, 0, 0, L.BF16, L.stream())
+        wp = torch.empty(kh * kw * cout * cin2, dtype=_h16(), device=w2.device)
+        L.call("hesic_pack_conv_weight", L.ptr(w2), None, L.ptr(wp), cout, cin2, kh, kw, 0, 0, L.H16, L.stream())
         self._hit = (tag, wp)
         return wp
 
@@ -850,7 +865,7 @@ class PackedGdnLo:
         tag = (gamma.data_ptr(), gamma._version, _cache_epoch)
         if self._hit is not None and self._hit[0] == tag:
             return self._hit[1]
-        glo = torch.empty(128 * 128, dtype=torch.bfloat16, device=gamma.device)
+        glo = torch.empty(128 * 128, dtype=_h16(), device=gamma.device)
         L.call("hesic_gdn_pack_params_lo", L.ptr(_c(gamma)), L.ptr(glo), 128, L.stream())
         self._hit = (tag, glo)
         return glo
@@ -883,7 +898,7 @@ def sconv_gdn_hilo(x, image, bias, beta_packed, inverse):
     L.require_cuda(x)
     B, Cc, H, W = x.shape
     Ho, Wo = _out_hw(H, W, 5, 2, 2, False)
-    y = _empty_nhwc(B, 256, Ho, Wo, torch.bfloat16, x.device)
+    y = _empty_nhwc(B, 256, Ho, Wo, _h16(), x.device)
     d = _sdesc(x, y, 3, 128, 5, 2, 2, False)
     L.call("hesic_sconv2d_gdn_forward_hilo", C.byref(d), L.ptr(x), L.ptr(image), L.ptr(bias), L.ptr(beta_packed), int(inverse), L.ptr(y), L.stream())
     return y
@@ -896,7 +911,7 @@ def im2col_hilo(x, k, stride, padding, kp):
         x = x.float()
     B, Cc, H, W = x.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, False)
-    cols = _empty_nhwc(B, 2 * kp, Ho, Wo, torch.bfloat16, x.device)
+    cols = _empty_nhwc(B, 2 * kp, Ho, Wo, _h16(), x.device)
     st = (C.c_int64 * 4)(*x.stride())
     L.call("hesic_im2col_hilo", L.ptr(x), st, B, Cc, H, W, k, k, stride, padding, Ho, Wo, kp, L.ptr(cols), L.stream())
     return cols
@@ -921,14 +936,14 @@ def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, g
     x_hilo = _nhwc(x_hilo)
     if gdn is not None:
         gp, glo, bp, inverse = gdn
-        y = _empty_nhwc(B, 2 * cout, Ho, Wo, torch.bfloat16, x_hilo.device)
-        d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.BF16, 0, 0, c2, 0, 2 * cout, 0, 0)
+        y = _empty_nhwc(B, 2 * cout, Ho, Wo, _h16(), x_hilo.device)
+        d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.H16, 0, 0, c2, 0, 2 * cout, 0, 0)
         L.call("hesic_conv2d_forward_hilo", C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
                L.ptr(y), 0, None, 0, 0, None, 0, L.stream())
         return y
-    y = _empty_nhwc(B, 2 * cout, Ho, Wo, torch.bfloat16, x_hilo.device) if out in ("hilo", "both") else None
+    y = _empty_nhwc(B, 2 * cout, Ho, Wo, _h16(), x_hilo.device) if out in ("hilo", "both") else None
     y32 = _empty_nhwc(B, cout, Ho, Wo, torch.float32, x_hilo.device) if out in ("f32", "both") else None
-    d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.BF16, act, 0, c2, 0, 2 * cout if y is not None else cout, 0, 0)
+    d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.H16, act, 0, c2, 0, 2 * cout if y is not None else cout, 0, 0)
     key = ("hilo", B, H, W, cin, cout, k, stride, padding)
     need = _ws_bytes.get(key)
     if need is None:
@@ -959,7 +974,7 @@ class PackedGroup:
             offs.append(total)
             total += -(-co // 128) * 128
         dev = weights[0].device
-        wp = torch.empty(k * k * total * cin, dtype=torch.bfloat16, device=dev).fill_(0)
+        wp = torch.empty(k * k * total * cin, dtype=_h16(), device=dev).fill_(0)
         bias = torch.empty(total, dtype=torch.float32, device=dev).fill_(0)
         for w, b, co, off in zip(weights, biases, couts, offs):
             L.call("hesic_pack_conv_weight_slice", L.ptr(w.detach().contiguous()), L.ptr(wp), co, cin, k, k, int(transposed), total, off, L.stream())
@@ -971,7 +986,7 @@ class PackedGroup:
 
 def grouped_ok(x):
     """The grouped hyper-synthesis launches exist for bf16 inference."""
-    return GROUP_HYPER and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+    return GROUP_HYPER and not torch.is_grad_enabled() and x.is_cuda and x.dtype == _h16()
 
 
 GROUP_HYPER = _os.environ.get("HESIC_NO_GROUP_HYPER") is None      # A/B switch
@@ -1002,11 +1017,11 @@ def conv2d_grouped(x, weights, biases, packer, *, kernel_size, stride, padding, 
     B, _, H, W = x.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, transposed)
     x = _nhwc(x)
-    out = None if f32_out == "only" else _empty_nhwc(B, total, Ho, Wo, torch.bfloat16, x.device)
+    out = None if f32_out == "only" else _empty_nhwc(B, total, Ho, Wo, _h16(), x.device)
     out32 = _empty_nhwc(B, total, Ho, Wo, torch.float32, x.device) if f32_out else None
     groups = 1 if shared_input else G
     step = 0 if shared_input else (cin if x_group_step is None else int(x_group_step))
-    d = L.ConvDesc(B, H, W, cin, Ho, Wo, total, k, k, stride, padding, int(transposed), L.BF16, act, 0, x.shape[1], x_c_off, total, 0, 0)
+    d = L.ConvDesc(B, H, W, cin, Ho, Wo, total, k, k, stride, padding, int(transposed), L.H16, act, 0, x.shape[1], x_c_off, total, 0, 0)
     L.call("hesic_conv2d_forward_grouped", C.byref(d), groups, step, act2, split, L.ptr(x), L.ptr(wp), L.ptr(bias),
            L.ptr(out), L.ptr(out32), total, 0, L.stream())
     return (out32 if f32_out == "only" else (out if not f32_out else (out, out32))), offs
@@ -1071,16 +1086,16 @@ def round_to(x, dtype):
 # ------------------------------------------------------------------------------------ GDN
 def conv3x3_c32_ok(x, weight):
     """Inference-only fast path of the enhancement net's 32-channel 3x3 convs (``hesic_conv3x3_c32_forward``)."""
-    return (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == torch.bfloat16
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == _h16()
             and weight.shape[1] == 32 and tuple(weight.shape[2:]) == (3, 3) and (weight.shape[0] == 32 or weight.shape[0] <= 4)
-            and weight.dtype == torch.float32 and _compute_dtype == torch.bfloat16)
+            and weight.dtype == torch.float32 and _is16())
 
 
 def pack_images_c32(xa, xb):
     """cat((xa, xb), 1) of two (B,3,H,W) images as channels 0..5 of a zero-padded (B,32,H,W) bf16 NHWC tensor."""
     L.require_cuda(xa, xb)
     B, _, H, W = xa.shape
-    out = _empty_nhwc(B, 32, H, W, torch.bfloat16, xa.device)
+    out = _empty_nhwc(B, 32, H, W, _h16(), xa.device)
     L.call("hesic_pack_images_c32", L.ptr(xa.float().contiguous()), L.ptr(xb.float().contiguous()), L.ptr(out), B, H, W, L.stream())
     return out
 
@@ -1094,9 +1109,9 @@ def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     x = _nhwc(x)
     w = weight.detach().contiguous()
     if cout == 32:
-        y = _empty_nhwc(B, 32, H, W, torch.bfloat16, x.device)
-        r1 = None if res1 is None else _nhwc(res1.to(torch.bfloat16))
-        r2 = None if res2 is None else _nhwc(res2.to(torch.bfloat16))
+        y = _empty_nhwc(B, 32, H, W, _h16(), x.device)
+        r1 = None if res1 is None else _nhwc(res1.to(_h16()))
+        r2 = None if res2 is None else _nhwc(res2.to(_h16()))
     else:
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
         r1 = None if res1 is None else res1.to(torch.float32).contiguous()
@@ -1117,8 +1132,8 @@ def resblock_c32(x, w1, b1, w2, b2, act=L.ACT_LEAKY, res2=None):
     L.require_cuda(x, w1, w2)
     B, _, H, W = x.shape
     x = _nhwc(x)
-    y = _empty_nhwc(B, 32, H, W, torch.bfloat16, x.device)
-    r2 = None if res2 is None else _nhwc(res2.to(torch.bfloat16))
+    y = _empty_nhwc(B, 32, H, W, _h16(), x.device)
+    r2 = None if res2 is None else _nhwc(res2.to(_h16()))
     f32 = lambda t: None if t is None else t.detach().float().contiguous()
     L.call("hesic_resblock_c32_forward", L.ptr(x), L.ptr(f32(w1)), L.ptr(f32(b1)), L.ptr(f32(w2)), L.ptr(f32(b2)), int(act), L.ptr(r2), L.ptr(y),
            B, H, W, L.stream())
@@ -1131,9 +1146,9 @@ EN_TRAIN_FAST = _os.environ.get("HESIC_EN_GENERIC") is None      # A/B switch
 def conv3x3_c32_train_ok(x, weight):
     """Training form of the 32 -> 32 fast path: autograd on, bf16 storage (stage 2 trains the enhancement net with HSIC frozen,
     newnet1.py:272-311, newtrain6_real.py)."""
-    return (EN_TRAIN_FAST and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == torch.bfloat16
+    return (EN_TRAIN_FAST and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[1] == 32 and x.dtype == _h16()
             and weight.shape[0] == 32 and weight.shape[1] <= 32 and tuple(weight.shape[2:]) == (3, 3) and weight.dtype == torch.float32
-            and _compute_dtype == torch.bfloat16)
+            and _is16())
 
 
 def conv3x3_c32_wgrad(x, g, weight, bias):
@@ -1187,7 +1202,7 @@ class _Conv3x3C32Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y_act = ctx.saved_tensors
-        gy = _nhwc(gy.to(torch.bfloat16))
+        gy = _nhwc(gy.to(_h16()))
         if ctx.act:
             g = torch.empty_like(y_act)
             L.call("hesic_act_backward", L.ptr(y_act), L.ptr(gy), L.ptr(g), y_act.numel(), ctx.act, L.dt(y_act), L.stream())
@@ -1246,7 +1261,7 @@ def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed
     cout = weight.shape[1] if transposed else weight.shape[0]
     ok = (not torch.is_grad_enabled() and xa.is_cuda and xb.is_cuda and cin == 6 and cout == 3 and kernel_size == 5 and stride == 1
           and padding == 2 and xa.shape[1] + xb.shape[1] == 6 and xa.shape[-1] >= 128 and xa.shape[0] == xb.shape[0]
-          and xa.shape[2:] == xb.shape[2:] and xa.dtype in (torch.float32, torch.bfloat16) and xb.dtype in (torch.float32, torch.bfloat16))
+          and xa.shape[2:] == xb.shape[2:] and xa.dtype in (torch.float32, _h16()) and xb.dtype in (torch.float32, _h16()))
     fuse = ok and gdn is not None and FUSE_GDN3 and (not gdn_on_input or xa.shape[1] == 3)
     if not ok or (gdn is not None and not fuse):
         if gdn is not None and gdn_on_input:
@@ -1332,14 +1347,14 @@ GDN3_PLANAR_TRAIN = _os.environ.get("HESIC_GDN3_NHWC_TRAIN") is None      # A/B 
 
 
 def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
-    if x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16):
+    if x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and not torch.is_grad_enabled() and x.dtype in (torch.float32, _h16()):
         # image-side GDN on a planar tensor at inference: no NHWC round trip
         B, Cc, H, W = x.shape
         y = torch.empty_like(x)
         L.call("hesic_gdn_forward_planar", L.ptr(x), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(y), B, Cc, H * W,
                int(inverse), float(beta_min), L.dt(x), L.stream())
         return y
-    if (GDN3_PLANAR_TRAIN and x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    if (GDN3_PLANAR_TRAIN and x.shape[1] == 3 and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, _h16())
             and beta.dtype == torch.float32 and gamma.dtype == torch.float32):
         return _apply(_Gdn3PlanarFn, x, beta, gamma, inverse, beta_min)
     return _apply(_GdnFn, x, beta, gamma, inverse, beta_min)
@@ -1354,8 +1369,8 @@ class _WarpFn(torch.autograd.Function):
         L.require_cuda(src, M)
         B, Cc, H, W = src.shape
         Ho, Wo = int(dsize[0]), int(dsize[1])
-        if src.dtype not in (torch.float32, torch.bfloat16):
-            raise TypeError("warp_perspective: float32 or bfloat16 only")
+        if src.dtype not in (torch.float32, _h16()):
+            raise TypeError("warp_perspective: float32 or the active 16-bit format only")
         Mf = M.detach().to(torch.float32).contiguous()
         dst = torch.empty((B, Cc, Ho, Wo), dtype=src.dtype, device=src.device)
         ss, ds = src.stride(), dst.stride()

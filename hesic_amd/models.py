@@ -1182,7 +1182,7 @@ class Enhancement(nn.Module):
         self.conv2 = conv3x3(32, 3)
 
     def forward(self, x, x_another_warp):
-        if (Fn.conv3x3_c32_ok(x.new_empty((1, 32, 1, 1), dtype=torch.bfloat16), self.EB1.RB1.conv1.weight) and x.is_cuda
+        if (Fn.conv3x3_c32_ok(x.new_empty((1, 32, 1, 1), dtype=Fn._h16()), self.EB1.RB1.conv1.weight) and x.is_cuda
                 and tuple(self.conv1.weight.shape) == (32, 6, 3, 3)):
             # inference: the 6 -> 32 input conv runs on the 32-channel kernel too -- the two images go into channels 0..5 of a
             # zero-padded NHWC bf16 map, the weight is zero-padded along Cin (cached)
@@ -1196,7 +1196,7 @@ class Enhancement(nn.Module):
                 self._w32 = (tag, wp)
             t = Fn.conv3x3_c32(xin, self._w32[1], self.conv1.bias)
         elif (x.is_cuda and not x.requires_grad and not x_another_warp.requires_grad and tuple(self.conv1.weight.shape) == (32, 6, 3, 3)
-              and Fn.conv3x3_c32_train_ok(x.new_empty((1, 32, 1, 1), dtype=torch.bfloat16), self.conv1.weight)):
+              and Fn.conv3x3_c32_train_ok(x.new_empty((1, 32, 1, 1), dtype=Fn._h16()), self.conv1.weight)):
             # stage-2 training (HSIC frozen, so the images carry no gradient): the same packed 32-channel input map; the 6-input-channel
             # weight is zero-padded inside the op, its gradient comes back for the six real channels
             t = Fn.conv3x3_c32_train(Fn.pack_images_c32(x, x_another_warp), self.conv1.weight, self.conv1.bias)
@@ -1205,7 +1205,7 @@ class Enhancement(nn.Module):
         t = self.EB3(self.EB2(self.EB1(t)))
         if Fn.conv3x3_c32_ok(t, self.conv2.weight):          # 32 -> 3 output conv + the image it refines, fp32 planar out
             return Fn.conv3x3_c32(t, self.conv2.weight, self.conv2.bias, res1=x)
-        if (Fn.EN_TRAIN_FAST and torch.is_grad_enabled() and t.is_cuda and t.dtype == torch.bfloat16 and t.shape[1] == 32
+        if (Fn.EN_TRAIN_FAST and torch.is_grad_enabled() and t.is_cuda and t.dtype == Fn._h16() and t.shape[1] == 32
                 and tuple(self.conv2.weight.shape) == (3, 32, 3, 3)):
             return Fn.conv3x3_c32_out_train(t, self.conv2.weight, self.conv2.bias, x.float())
         return self.conv2(t) + x

@@ -11,7 +11,10 @@
  *  - every pointer is a DEVICE pointer unless the name ends in _host; sizes are element counts
  *  - feature maps are NHWC ("channels_last"): element (b,y,x,c) at ((b*H+y)*W+x)*pix_stride + c_off + c
  *  - 3-channel images use explicit element strides (sb, sc, sy, sx) so NCHW planar inputs need no copy
- *  - dtype: HESIC_F32 or HESIC_BF16 storage; all arithmetic accumulates in fp32
+ *  - dtype: HESIC_F32 or HESIC_H16 storage; all arithmetic accumulates in fp32.  HESIC_H16 is the 16-bit format the library
+ *    was BUILT for (hesic_h16_format()): libhesic_hip.so = bfloat16 (training + inference), libhesic_hip_f16.so = IEEE binary16
+ *    (inference: same matrix-core rate on gfx950, 11-bit significand; activations saturate at +-65504).  Same entry points, same
+ *    sources; a caller binds the library whose format its tensors have.  "bf16" in the comments below reads "the 16-bit format".
  *  - `stream` is a hipStream_t (0 = the null stream); calls are asynchronous on it
  *  - return value: 0 on success, otherwise a hipError_t (> 0) or HESIC_EINVAL (-1) for bad arguments;
  *    hesic_last_error() returns a static description of the last failure on the calling thread
@@ -28,10 +31,13 @@ extern "C" {
 #define HESIC_ABI_VERSION 1
 #define HESIC_EINVAL (-1)
 
-enum { HESIC_F32 = 0, HESIC_BF16 = 1 };
+enum { HESIC_F32 = 0, HESIC_H16 = 1, HESIC_BF16 = 1 /* historical name of HESIC_H16 */ };
+enum { HESIC_H16_BFLOAT16 = 0, HESIC_H16_FLOAT16 = 1 };
 enum { HESIC_ACT_NONE = 0, HESIC_ACT_RELU = 1, HESIC_ACT_LEAKY = 2 /* slope 0.01 */ };
 
 int hesic_abi_version(void);
+/* HESIC_H16_BFLOAT16 or HESIC_H16_FLOAT16: what HESIC_H16 storage means in this build of the library */
+int hesic_h16_format(void);
 const char* hesic_last_error(void);
 
 /* ------------------------------------------------------------------ convolution (rows A1,A2,A4-A7,A11)
