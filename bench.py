@@ -31,7 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 = dense f16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (the guide's measured copy ceiling is 6.29 TB/s)
 HESIC_GFLOP_PER_PAIR_512 = 155.66
@@ -50,18 +50,19 @@ class KernelMeter:
     recorded on the stream the kernel is launched on; the launch descriptor gives the algorithmic FLOPs and
     hesic_conv2d_variant names the instantiation the library picked."""
     NAMES = ("hesic_conv2d_forward", "hesic_conv2d_forward_ws", "hesic_conv2d_forward_f32out", "hesic_conv2d_gdn_forward", "hesic_conv2d_forward_grouped",
-             "hesic_conv2d_forward_hilo")
+             "hesic_conv2d_forward_hilo", "hesic_conv2d_gdn_forward_hilo_out")
 
     STREAM = {"hesic_warp_perspective_forward": "warp_perspective", "hesic_sconv2d_gdn_forward": "conv1_3to128_gdn (n2w)",
               "hesic_sconv2d_gdn_forward_prepacked": "conv1_3to128_gdn (n2w)", "hesic_sconv2d_forward": "g_s_conv4_128to3 (w2n)",
-              "hesic_sconv2d_forward_prepacked": "g_s_conv4_128to3 (w2n)", "hesic_sconv2d_gdn_forward_hilo": "conv1_3to128_gdn hi/lo (n2w, bf16x3)"}
+              "hesic_sconv2d_forward_prepacked": "g_s_conv4_128to3 (w2n)", "hesic_sconv2d_gdn_forward_hilo": "conv1_3to128_gdn hi/lo (n2w, x3)",
+              "hesic_sconv2d_gdn_forward_hilo_out1": "conv1_3to128_gdn hi/lo inside, single out (n2w, x3c2)"}
 
     def __init__(self, L):
         self.L, self.orig, self.rec, self.stream = L, L.call, [], {}
 
     def _stream_bytes(self, name, d):
         """ALGORITHMIC HBM bytes of one launch: every input element read once, every output element written once."""
-        size = lambda dt: 2 if dt == self.L.BF16 else 4
+        size = lambda dt: 2 if dt == self.L.H16 else 4
         if name == "hesic_warp_perspective_forward":
             return d.B * d.C * (d.H * d.W * size(d.src_dtype) + d.Ho * d.Wo * size(d.dst_dtype))
         if name.startswith("hesic_sconv2d_forward") and not (d.transposed and d.Cin >= 32):
@@ -91,7 +92,7 @@ class KernelMeter:
             ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
             fl = conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)
             hilo = name.endswith("_hilo")
-            fused = name.endswith("gdn_forward") or (hilo and args[4] is not None and getattr(args[4], "value", None))
+            fused = name.endswith("gdn_forward") or name.endswith("hilo_out") or (hilo and args[4] is not None and getattr(args[4], "value", None))
             if fused:
                 fl += 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cout          # the GDN 1x1 contraction (SURVEY 8d counts it)
             # a hi/lo (bf16x3) launch EXECUTES three bf16 MFMA products per algorithmic MAC: x_hi w_hi + x_lo w_hi + x_hi w_lo
@@ -100,7 +101,7 @@ class KernelMeter:
                 import copy
                 dv = copy.copy(d)
                 dv.Cin, dv.x_pix_stride = 2 * d.Cin, max(d.x_pix_stride, 2 * d.Cin)
-            self.rec.append((e0, e1, fl, self.variant(dv, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else ""),
+            self.rec.append((e0, e1, fl, self.variant(dv, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else "") + (" hilo-gdn-out" if name.endswith("hilo_out") else ""),
                              3.0 if hilo else 1.0))
             return rc
         self.L.call = call
@@ -117,7 +118,7 @@ class KernelMeter:
             return f"igemm_tr4_kernel<{'gdn' if fused else 'plain'}>"
         if v[3]:
             return f"igemm_glds_kernel<{v[0]},{v[1]},{v[2]}{',gdn' if fused else ''}>"
-        return f"igemm_conv_kernel<{'bf16' if d.dtype == self.L.BF16 else 'f32'},{v[1]}>"
+        return f"igemm_conv_kernel<{'h16' if d.dtype == self.L.H16 else 'f32'},{v[1]}>"
 
     def summary(self):
         """Per kernel instantiation: launches, summed event time, algorithmic FLOPs; returns the dominant one."""
@@ -291,8 +292,7 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
     recs = []
     keep_dt, keep_an = Fn.compute_dtype(), Fn.analysis_precision()
     for sset in range(sets):
-        hesic_amd.set_compute_dtype(torch.bfloat16)
-        Fn.set_analysis_precision("bf16x3")
+        hesic_amd.set_compute_dtype(torch.bfloat16)        # training runs in bf16
         net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
         synthetic.fill_state_dict_(net.state_dict(), salt=sset)
         net = net.cuda()
@@ -312,8 +312,9 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
         with torch.no_grad():
             ref = (O.hsic_forward if kind == "hsic" else O.hsic_joint_forward)(P, x1, x2, Hm)
         mr = O.metrics(ref, x1, x2)
-        for dt, an in ((torch.bfloat16, "bf16x3"), (torch.bfloat16, "bf16"), (torch.float32, None)):
+        for dt, an in ((torch.float16, "x3"), (torch.float16, "x3c2"), (torch.float16, "x1"), (torch.bfloat16, "x3"), (torch.bfloat16, "x1"), (torch.float32, None)):
             hesic_amd.set_compute_dtype(dt)
+            Fn.invalidate_weight_cache()
             if an:
                 Fn.set_analysis_precision(an)
             with torch.no_grad():
@@ -321,7 +322,7 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
                 m = models.metrics_from(models.rate_distortion(out, x1.cuda(), x2.cuda()))
             flips = {k: float((out[k].float().cpu() != ref[k]).float().mean()) for k in ("y1_hat", "y2_hat")}
             recs.append({"model": kind, "weight_set": sset, "trained_steps": steps, "eval": f"{size}x{size} pair 0",
-                         "mode": "fp32" if dt == torch.float32 else f"bf16 maps, analysis {an}",
+                         "mode": "fp32" if dt == torch.float32 else f"{'f16' if dt == torch.float16 else 'bf16'} maps, analysis {an}",
                          "bpp_oracle": round(mr["bpp"], 5), "psnr_oracle": round(mr["psnr"], 4), "abs_dbpp": round(abs(m["bpp"] - mr["bpp"]), 6),
                          "rel_dbpp": round(abs(m["bpp"] - mr["bpp"]) / mr["bpp"], 6), "abs_dpsnr_db": round(abs(m["psnr"] - mr["psnr"]), 6),
                          "latent_flips": {k: round(v, 6) for k, v in flips.items()},
@@ -449,7 +450,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
             eager(tr, x1, x2, Hm)
         s = wm.summary()
     if s and rank == 0:
-        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype != "f32" else MFMA_F32_PEAK_TFLOPS
         roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
                 "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
@@ -487,7 +488,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
                                    f"{tr.main_group.numel * 4 / 1e6:.1f} MB flat gradient per step" + ("" if world > 1 else " (single rank: no collective)"),
                        "step": "eager" if (args.eager or not getattr(tr, "capturable", True)) else "HIP graph replay"},
             "model_tflops": round(pairs * gflop_pair / elapsed / 1e3, 2) if args.model == "hsic" else None,
-            "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype == "bf16" else None,
+            "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype != "f32" else None,
             "roofline": roof,
             "comm": comm,
             "launches_per_step": {"c_abi_calls": sum(census.values()), "note": "C-ABI calls of one eager step (each is 1-2 kernel launches); "
@@ -514,7 +515,9 @@ def main():
     ap.add_argument("--height", type=int, default=None, help="non-square workloads (e.g. 860x1080, zero-padded to x64)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--model", choices=["hsic", "joint"], default="hsic")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default=None,
+                    help="storage / matrix-core operand type of the wide maps (fp32 accumulation always).  Inference default f16: IEEE half runs at "
+                         "the bf16 MFMA rate on gfx950 with 3 more significand bits (libhesic_hip_f16.so); training default bf16")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer", help="train: BASELINE config C3 (R-D training step, DP gradient all-reduce)")
     ap.add_argument("--eager", action="store_true", help="train mode: issue the step from Python instead of replaying the HIP graph")
     ap.add_argument("--lmbda", type=float, default=0.0067)
@@ -522,9 +525,10 @@ def main():
                     "one (model, batch) unit per rank and step, models rotating over ranks and steps")
     ap.add_argument("--warp-align-corners", type=int, choices=[0, 1], default=None,
                     help="0: kornia <= 0.4 sampling (what torch-1.6-era checkpoints were trained with), 1: kornia >= 0.5 (default)")
-    ap.add_argument("--analysis", choices=["bf16", "bf16x3"], default=None,
-                    help="operand precision of the analysis transforms + hyper-analysis at bf16 inference: bf16x3 (default) = hi/lo bf16 pairs, "
-                         "fp32-grade latents; bf16 = single-bf16 operands (round 2: ~1 %% of the latents flip)")
+    ap.add_argument("--analysis", choices=["x1", "x3", "x3c2", "bf16", "bf16x3"], default=None,
+                    help="operand precision of the analysis transforms + hyper-analysis at 16-bit inference: x3 = hi/lo pairs everywhere (three "
+                         "products per MAC, fp32-grade latents), x3c2 = pairs except g_a_conv2 (70 %% of g_a's MACs) on single operands, x1 = single "
+                         "operands (bf16 / bf16x3: the round-3 names of x1 / x3)")
     ap.add_argument("--parity-trained", type=int, default=0, metavar="SETS",
                     help="also report parity at TRAINED operating points: train SETS weight sets for --parity-train-steps steps each on synthetic "
                          "pairs (about 25 s per set) and compare bf16x3 / bf16 / fp32 against the CPU oracle on the trained weights")
@@ -555,7 +559,11 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.dtype is None:
+        args.dtype = "bf16" if args.mode == "train" else "f16"
+    if args.mode == "train" and args.dtype == "f16":
+        raise SystemExit("--mode train runs in bf16 (or f32): gradients need the fp32 exponent range")
+    cdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     hesic_amd.set_compute_dtype(cdt)
 
     net = (models.HSIC if args.model == "hsic" else models.HSICJoint)()
@@ -661,7 +669,7 @@ def main():
         s = km.summary()
     models.OVERLAP_STREAMS = overlap
     if s:
-        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype != "f32" else MFMA_F32_PEAK_TFLOPS
         traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/make_pmc_json.py)
         pj = os.path.join(ROOT, "profiles", "pmc_igemm.json")
         if os.path.exists(pj):
@@ -695,7 +703,7 @@ def main():
             "config": {"workload": f"{'HESIC' if args.model == 'hsic' else 'HESIC+'} eval forward (encode+decode) + bpp/PSNR, "
                                    f"{H_img}x{W_img} stereo pairs, batch {args.batch}/GPU, random-init-shaped deterministic weights",
                        "pairs_per_step": world * args.batch, "sharding": f"pairs over {world} GPU(s), no collective on the path",
-                       "analysis": (Fn.analysis_precision() if args.dtype == "bf16" else "fp32"),
+                       "analysis": (Fn.analysis_precision() if args.dtype != "f32" else "fp32"),
                        "warp_align_corners": bool(geometry.DEFAULT_ALIGN_CORNERS), "issue": picked},
             "model_tflops": round(pairs * HESIC_GFLOP_PER_PAIR_512 * (x1p.shape[-2] * x1p.shape[-1] / 512 ** 2) / elapsed / 1e3, 2) if args.model == "hsic" else None,
             "roofline": roof,
@@ -732,7 +740,7 @@ def main():
                              "met": {"latent_flips": bool(max(flips.values()) <= 1e-3), "abs_dpsnr_db": bool(dpsnr < 1e-3),
                                      "abs_dbpp": bool(dbpp < 1e-3), "rel_dbpp": bool(dbpp < 1e-3 * bpp_o),
                                      "abs_dbpp_every_pair": bool(worst_dbpp < 1e-3), "abs_dpsnr_db_every_pair": bool(worst_dpsnr < 1e-3)},
-                             "analysis": Fn.analysis_precision() if args.dtype == "bf16" else "fp32",
+                             "analysis": Fn.analysis_precision() if args.dtype != "f32" else "fp32",
                              "latents": "fp32 (y, z, sigma, mu from the fp32 accumulators)" if (args.dtype == "f32" or Fn.FP32_LATENTS) else "bf16",
                              "note": f"{args.dtype} GPU path vs fp32 CPU oracle on the {len(per_pair)} distinct pair(s) of the timed workload, random-init-shaped "
                                      "weights (bpp ~5.5: the absolute bpp bar is 1.8e-4 RELATIVE here).  abs_* = |mean over the pairs| (the reference "

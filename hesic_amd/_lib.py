@@ -73,6 +73,7 @@ _SIGS = {
     "hesic_h16_format": ([], _i32),
     "hesic_last_error": ([], C.c_char_p),
     "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_pack_conv_weight_shaped": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weights_batched": ([_vp, _i32, _i32, _vp], _i32),
     "hesic_conv2d_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_gdn_forward_planar": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp], _i32),
@@ -150,6 +151,8 @@ _SIGS = {
     "hesic_gdn_pack_params_lo": ([_vp, _vp, _i32, _vp], _i32),
     "hesic_sconv_pack_weight_image_hilo": ([_vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward_hilo": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
+    "hesic_sconv2d_gdn_forward_hilo_out1": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
+    "hesic_conv2d_gdn_forward_hilo_out": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
     "hesic_conv3x3_c32_wgrad_ws_bytes": ([], _i64),
     "hesic_conv3x3_c32_wgrad": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     "hesic_im2col_hilo": ([_vp, _P(_i64), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),

@@ -25,7 +25,7 @@ class HipConv2d(nn.Conv2d):
     def run(self, x, act=L.ACT_NONE, in_abs=False, mask=None, tap_mask=0):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                          mask=mask, tap_mask=tap_mask)
@@ -34,7 +34,7 @@ class HipConv2d(nn.Conv2d):
         """out[:, c_off:c_off + out_channels] = act(self(x)) at inference, written in place (no cat afterwards)."""
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d_into(x, self.weight, self.bias, out, c_off, kernel_size=self.kernel_size[0], stride=self.stride[0],
                               padding=self.padding[0], transposed=False, act=act, packer=self._packer, mask=mask, tap_mask=tap_mask)
 
@@ -42,7 +42,7 @@ class HipConv2d(nn.Conv2d):
         """self(x[:, c_off:c_off + in_channels]) at inference, reading the channel slice in place."""
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d_slice(x, c_off, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                padding=self.padding[0], transposed=False, act=act, packer=self._packer)
 
@@ -51,7 +51,7 @@ class HipConv2d(nn.Conv2d):
         (``Fn.conv2d_latent``), ``lo`` (optional) the storage-dtype copy for the next conv."""
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d_latent(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                 padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                                 want_lo=want_lo)
@@ -72,12 +72,26 @@ class HipConv2d(nn.Conv2d):
                               kernel_size=self.kernel_size[0], stride=self.stride[0], padding=self.padding[0], gdn=g, act=act, out=out,
                               out_abs=out_abs)
 
+    def run_gdn_hilo_out(self, x, gdn):
+        """gdn(self(x)) for the "x3c2" analysis mode: single 16-bit operands in the conv, the GDN on pairs, a hi/lo map out
+        (``Fn.conv2d_gdn_hilo_out``)."""
+        self._check()
+        if not hasattr(self, "_packer"):
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
+        if not hasattr(gdn, "_packer_lo"):
+            gdn._packer_lo = Fn.PackedGdnLo()
+        gp, bp = gdn.packer().get(gdn.beta, gdn.gamma, gdn.beta_min)
+        cout, cin, kh, kw = self.weight.shape
+        wp = self._packer.get(self.weight, None, cout, cin, kh, kw, False, False, x.dtype)
+        return Fn.conv2d_gdn_hilo_out(x, wp, self.bias, cin, kernel_size=kh, stride=self.stride[0], padding=self.padding[0],
+                                      gdn=(gp, gdn._packer_lo.get(gdn.gamma), bp, gdn.inverse))
+
     def run_gdn(self, x, gdn):
         """gdn(self(x)); one fused kernel when eligible (inference, bf16 storage, 128 channels), else two ops."""
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), False) and (self.weight.shape[1] != 3 or self.stride[0] == 2):
             self._check()
             if not hasattr(self, "_packer"):
-                self._packer = Fn.PackedWeight()
+                self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
             return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
                                  stride=self.stride[0], padding=self.padding[0], transposed=False, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
@@ -106,21 +120,21 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def run(self, x, act=L.ACT_NONE):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=True, act=act, packer=self._packer)
 
     def run_slice(self, x, c_off, act=L.ACT_NONE):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d_slice(x, c_off, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                padding=self.padding[0], transposed=True, act=act, packer=self._packer)
 
     def run_latent(self, x, act=L.ACT_NONE, want_lo=True):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight()
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
         return Fn.conv2d_latent(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                 padding=self.padding[0], transposed=True, act=act, packer=self._packer, want_lo=want_lo)
 
@@ -128,7 +142,7 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), True):
             self._check()
             if not hasattr(self, "_packer"):
-                self._packer = Fn.PackedWeight()
+                self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
             return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
                                  stride=self.stride[0], padding=self.padding[0], transposed=True, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())

@@ -1392,6 +1392,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// 16-bit packing with ERROR FEEDBACK over the taps of each (cout, cin) pair (inference, Conv2d).  Rounding every weight on its own leaves
+// 25 independent errors per pair; here the rounding error of a tap is carried into the next one of a serpentine walk over the KH x KW
+// window (consecutive taps = neighbouring input pixels), so the errors of a pair sum to less than ONE half-ulp.  What that buys: a feature
+// map is spatially smooth over a 5 x 5 window, so sum_t dW_t x_t ~ x * sum_t dW_t -- the weight-rounding part of a one-product layer's
+// error nearly vanishes (CPU study profiles/scripts/precision_study.py, g_a_conv2 on single fp16 operands, 512^2: latent flips 6.3e-4 ->
+// 3.9e-4 against 3.7e-4 with EXACT weights; on white-noise inputs it would cost sqrt(2)).  Same storage, same kernels, chosen at pack time.
+__global__ void pack_weight_shaped_kernel(const float* __restrict__ w, h16_t* __restrict__ wp, int Cout, int Cin, int KH, int KW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (co, ci), ci fastest: coalesced 2-byte stores per tap
+    if (i >= Cout * Cin) return;
+    const int ci = i % Cin, co = i / Cin;
+    const float* src = w + (int64_t)i * KH * KW;
+    float e = 0.f;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int j = 0; j < KW; ++j) {
+            const int kx = (ky & 1) ? KW - 1 - j : j;
+            const float tgt = src[ky * KW + kx] + e;
+            const h16_t q = f2h(tgt);
+            e = tgt - h2f(q);
+            wp[((int64_t)(ky * KW + kx) * Cout + co) * Cin + ci] = q;
+        }
+}
+
 // All weight repacks of a training step in ONE launch (an eager step issued 68 of them, ~7 us each).  Block -> job by a
 // search over the jobs' first-block table; a block moves a tile of 8 couts x 32 cins x all taps through LDS so that both
 // sides are wide: the source is read in runs of 32*taps (conv) or 8*taps (transposed conv) consecutive floats, the
@@ -1565,6 +1587,12 @@ extern "C" int hesic_pack_conv_weight(const float* w, const float* mask, void* w
     HESIC_LAUNCH_RETURN("pack_conv_weight");
 }
 
+extern "C" int hesic_pack_conv_weight_shaped(const float* w, void* wp, int Cout, int Cin, int KH, int KW, void* stream) {
+    HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (int64_t)Cout * Cin < (1ll << 31), "pack_conv_weight_shaped: bad arguments");
+    hipLaunchKernelGGL(pack_weight_shaped_kernel, dim3((unsigned)((Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (h16_t*)wp, Cout, Cin, KH, KW);
+    HESIC_LAUNCH_RETURN("pack_conv_weight_shaped");
+}
+
 extern "C" int hesic_pack_conv_weights_batched(const hesic_pack_job* jobs_device, int n_jobs, int total_blocks, void* stream) {
     HESIC_CHECK_ARG(jobs_device && n_jobs > 0 && total_blocks > 0, "pack_conv_weights_batched: bad arguments");
     hipLaunchKernelGGL(pack_weights_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs);
@@ -1664,7 +1692,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     HESIC_CHECK_ARG(d->KH * d->KW <= MAX_TAPS, "conv2d_forward: at most %d taps", MAX_TAPS);
     HESIC_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv2d_forward: stride must be 1 or 2");
     HESIC_CHECK_ARG(d->dtype == HESIC_H16 || d->dtype == HESIC_F32, "conv2d_forward: bad dtype");
-    HESIC_CHECK_ARG(d->x_c_off + (hilo ? 2 : 1) * d->Cin <= d->x_pix_stride && d->y_c_off + ((hilo && (g_gdn_mode || g_y_hilo)) ? 2 : 1) * d->Cout <= d->y_pix_stride,
+    HESIC_CHECK_ARG(d->x_c_off + (hilo ? 2 : 1) * d->Cin <= d->x_pix_stride && d->y_c_off + ((g_gdn_mode >= 3 || (hilo && g_y_hilo)) ? 2 : 1) * d->Cout <= d->y_pix_stride,
                     "conv2d_forward: channel slice out of range");
 
     IgemmArgs a;
@@ -1825,6 +1853,8 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
             else if (N_ == 128 && gdn == 4) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 4, 4, 0, 1>), grid, block, 0, st, a);  \
             else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 4, 0, 1>), grid, block, 0, st, a);                              \
         }                                                                                                   \
+        else if (N_ == 128 && gdn == 3) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 3>), grid, block, 0, st, a);  \
+        else if (N_ == 128 && gdn == 4) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 4>), grid, block, 0, st, a);  \
         else if (N_ == 128 && gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 1>), grid, block, 0, st, a);  \
         else if (N_ == 128 && gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 2>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0>), grid, block, 0, st, a);                              \
@@ -1995,6 +2025,20 @@ extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x
     g_hilo = 0; g_y_hilo = g_y_abs = 0;
     g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
+    return rc;
+}
+
+/* Single 16-bit operands (one product per MAC) with the hi/lo (I)GDN epilogue: v = conv + bias stays in the fp32 accumulators, the
+ * squares and gamma' go through the contraction as pairs, y leaves as [hi(128) | lo(128)] per pixel for a hi/lo consumer. */
+extern "C" int hesic_conv2d_gdn_forward_hilo_out(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                                 const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                                 void* y_hilo, void* stream) {
+    HESIC_CHECK_ARG(d && x && w_packed && gamma_packed && gamma_lo_packed && beta_packed && y_hilo, "conv2d_gdn_forward_hilo_out: null pointer");
+    HESIC_CHECK_ARG(d->dtype == HESIC_H16 && !d->in_abs && d->Cout == 128 && d->act == HESIC_ACT_NONE && d->Cin % 32 == 0 && !d->transposed,
+                    "conv2d_gdn_forward_hilo_out: 16-bit storage, Conv2d, Cout == 128, Cin %% 32 == 0, no activation");
+    g_gdn_gamma = gamma_packed; g_gdn_gamma_lo = gamma_lo_packed; g_gdn_beta = beta_packed; g_gdn_mode = inverse ? 4 : 3;
+    const int rc = hesic_conv2d_forward(d, x, w_packed, bias, y_hilo, stream);
+    g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     return rc;
 }
 

@@ -25,7 +25,9 @@ __device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t&
     lo = pack_h2(p - h2f_lo(hi), q - h2f_hi(hi));
 }
 
-template <int INV>
+// OUT1 = 1: the output leaves as ONE 16-bit value per channel (128 channels per pixel; half the stores) -- for a consumer that multiplies
+// single operands (the "x3c2" analysis mode: g_a_conv2, 70 % of g_a's MACs, at one product per MAC); everything inside the kernel stays hi/lo.
+template <int INV, int OUT1>
 __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     constexpr int KS = 5, R = 15, NW = 8;
     constexpr uint32_t POISON = 0x80000000u;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
         // bytes (one cache line) per pixel and pass.  Every lane takes part in every pass, the hi passes cost one pack per channel
         // pair, only the lo passes form the residual.
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < (OUT1 ? 2 : 4); ++pass) {
             const int half = pass >> 1, cg = pass & 1;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
@@ -288,11 +290,11 @@ extern "C" int hesic_sconv_pack_weight_image_hilo(const float* w, const float* g
     HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo");
 }
 
-extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
-                                              const float* beta_packed, int inverse, void* y_hilo, void* stream) {
+static int n2w_gdn_hilo_launch(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                               const float* beta_packed, int inverse, void* y_hilo, int out1, void* stream) {
     HESIC_CHECK_ARG(d && x && image_hilo && beta_packed && y_hilo, "sconv2d_gdn_forward_hilo: null pointer");
     HESIC_CHECK_ARG(!d->transposed && d->Cin == 3 && d->Cout == 128 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 &&
-                        d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_H16 && d->act == HESIC_ACT_NONE && d->ys_c == 1 && d->ys_x >= 256 &&
+                        d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_H16 && d->act == HESIC_ACT_NONE && d->ys_c == 1 && d->ys_x >= (out1 ? 128 : 256) &&
                         (d->ys_x % 8) == 0 && (d->ys_y % 8) == 0 && (d->ys_b % 8) == 0,
                     "sconv2d_gdn_forward_hilo: built for the 3 -> 128 5x5 stride-2 stage, fp32 image in, [hi | lo] bf16 NHWC out (pixel stride >= 256)");
     HESIC_CHECK_ARG(d->Ho == (d->H + 4 - 5) / 2 + 1 && d->Wo == (d->W + 4 - 5) / 2 + 1, "sconv2d_gdn_forward_hilo: output size does not match");
@@ -310,11 +312,30 @@ extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const f
     const unsigned grid = (unsigned)((tiles + 7) / 8 < 256 ? (tiles + 7) / 8 : 256);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    const dim3 g(grid), blk(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (out1) {
+        if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 1>), g, blk, lds, st, a);
+        else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1>), g, blk, lds, st, a);
+    } else {
+        if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 0>), g, blk, lds, st, a);
+        else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 0>), g, blk, lds, st, a);
+    }
     HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
+}
+
+extern "C" int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                                              const float* beta_packed, int inverse, void* y_hilo, void* stream) {
+    return n2w_gdn_hilo_launch(d, x, image_hilo, bias, beta_packed, inverse, y_hilo, 0, stream);
+}
+
+extern "C" int hesic_sconv2d_gdn_forward_hilo_out1(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                                                   const float* beta_packed, int inverse, void* y, void* stream) {
+    return n2w_gdn_hilo_launch(d, x, image_hilo, bias, beta_packed, inverse, y, 1, stream);
 }

@@ -8,6 +8,7 @@ path is produced by a HIP kernel of ``libhesic_hip.so``.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -82,6 +83,9 @@ class _NoCtx:
 
 def _apply(fn, *args):
     if torch.is_grad_enabled():
+        if _compute_dtype == torch.float16 and any(torch.is_tensor(a) and a.requires_grad for a in args):
+            raise RuntimeError("hesic_amd: float16 is an inference format here (gradients need the fp32 exponent range): train with "
+                               "set_compute_dtype(torch.bfloat16) or torch.float32, or run the forward under torch.no_grad()")
         return fn.apply(*args)
     return fn.forward(_NoCtx(), *args)
 
@@ -154,7 +158,6 @@ def set_wgrad_stream(stream):
     return prev
 
 
-import os as _os
 
 # Deferred finishing passes of the wide weight gradients (see _wide_conv_grads): a list while train.Trainer.step collects them
 _finish_queue = None
@@ -226,6 +229,7 @@ def _slot_done(slot):
 
 # ------------------------------------------------------------------------------ packing cache
 _cache_epoch = 0
+SHAPED_WEIGHTS = _os.environ.get("HESIC_SHAPED_WEIGHTS", "1") != "0"      # A/B switch for PackedWeight(shaped=True)
 
 
 def invalidate_weight_cache():
@@ -292,8 +296,11 @@ class PackedWeight:
     ``train_pack_cache(True)`` (the Trainer's step) the packed buffer is persistent, registered for ``repack_all()`` and
     reused while its (storage, version, epoch) tag is current."""
 
-    def __init__(self):
+    def __init__(self, shaped=False):
         self._cache = {}
+        # ``shaped``: at 16-bit INFERENCE a Conv2d weight is rounded with error feedback over the taps of each (cout, cin) pair
+        # (``hesic_pack_conv_weight_shaped``) -- for layers whose input is a spatially smooth feature map (g_a_conv2..4)
+        self.shaped = shaped
 
     def get(self, weight, mask, cout, cin, kh, kw, transposed, flip, dtype):
         # autograd.Function bodies run with grad mode off, so a training step also takes the cached branch (one repack
@@ -336,8 +343,12 @@ class PackedWeight:
             self._cache[key] = (tag, wp)
             return wp
         wp = torch.empty(kh * kw * cout * cin, dtype=dtype, device=weight.device)
-        L.call("hesic_pack_conv_weight", L.ptr(weight.detach()), L.ptr(mask), L.ptr(wp), cout, cin, kh, kw,
-               int(transposed), int(flip), L.dt(dtype), L.stream())
+        if (self.shaped and SHAPED_WEIGHTS and caching and not _train_pack_cache and dtype != torch.float32 and mask is None and not transposed
+                and not flip and kh * kw > 1 and weight.dtype == torch.float32 and weight.is_contiguous()):
+            L.call("hesic_pack_conv_weight_shaped", L.ptr(weight.detach()), L.ptr(wp), cout, cin, kh, kw, L.stream())
+        else:
+            L.call("hesic_pack_conv_weight", L.ptr(weight.detach()), L.ptr(mask), L.ptr(wp), cout, cin, kh, kw,
+                   int(transposed), int(flip), L.dt(dtype), L.stream())
         if caching:
             self._cache[key] = (tag, wp)
         return wp
@@ -804,29 +815,52 @@ def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=F
 # the latents.  In the "bf16x3" analysis mode every value on the way to y is a PAIR of bf16 (hi = bf16(v), lo = bf16(v - hi)):
 # activations [hi(C) | lo(C)] per pixel, weights [w_hi | w_lo] along Cin, three MFMA products per staged operand pair
 # (x_hi w_hi + x_lo w_hi + x_hi w_lo; x_lo w_lo, 2^-18, is dropped) -- bf16 arithmetic on the matrix cores at ~2^-17 relative per operand.  Inference only.
-ANALYSIS_MODES = ("bf16", "bf16x3")
-_analysis_mode = _os.environ.get("HESIC_ANALYSIS", "bf16x3")
-if _analysis_mode not in ANALYSIS_MODES:
-    raise ValueError(f"HESIC_ANALYSIS must be one of {ANALYSIS_MODES}")
+# Modes (16-bit inference; the 16-bit format itself -- bfloat16 or float16 -- is the compute dtype):
+#   "x3"    every analysis layer and the hyper-analysis on pairs, three products per MAC;
+#   "x3c2"  as "x3", but g_a_conv2 (128 -> 128 5x5 s2 on the largest map: 70 % of g_a's MACs) multiplies SINGLE operands -- one product per
+#           MAC; its input leaves the conv1 + GDN kernel as one 16-bit value per channel, its GDN epilogue runs on pairs and hands pairs on.
+#           Meant for float16 (11-bit significand: ~6e-4 of the latents flip against the fp32 reference; with bfloat16 it is ~5e-3);
+#   "x1"    single operands everywhere (round 2's path; float16: ~1.3e-3 flips, bfloat16: ~1e-2).
+# "bf16x3" / "bf16" are the round-3 names of "x3" / "x1".
+ANALYSIS_MODES = ("x1", "x3", "x3c2")
+_ANALYSIS_ALIASES = {"bf16": "x1", "bf16x3": "x3"}
+
+
+def _canon_analysis(mode):
+    mode = _ANALYSIS_ALIASES.get(mode, mode)
+    if mode != "auto" and mode not in ANALYSIS_MODES:
+        raise ValueError(f"analysis precision must be 'auto' or one of {ANALYSIS_MODES} (or {tuple(_ANALYSIS_ALIASES)})")
+    return mode
+
+
+_analysis_mode = _canon_analysis(_os.environ.get("HESIC_ANALYSIS", "auto"))
 
 
 def set_analysis_precision(mode):
-    """"bf16x3" (default): the analysis transforms and hyper-analysis of a bf16 inference forward run on hi/lo bf16 pairs
-    (fp32-grade latents: what round() sees matches the reference's fp32 path to ~1e-5); "bf16": single-bf16 operands (round 2)."""
+    """Operand precision of the analysis transforms + hyper-analysis of a 16-bit inference forward: "x3", "x3c2", "x1" (see above) or
+    "auto" (the default: "x3c2" with float16 maps -- measured 4e-4 ... 7e-4 flipped latents, set-average |dbpp| 2e-4, |dPSNR| 2e-5 dB against
+    the fp32 reference at 1.25x the speed of "x3" -- and "x3" with bfloat16 maps, where one product per MAC flips 5e-3).  Returns the
+    previous setting."""
     global _analysis_mode
-    if mode not in ANALYSIS_MODES:
-        raise ValueError(f"analysis precision must be one of {ANALYSIS_MODES}")
-    prev, _analysis_mode = _analysis_mode, mode
+    prev, _analysis_mode = _analysis_mode, _canon_analysis(mode)
     return prev
 
 
 def analysis_precision():
+    """The mode in effect for the current compute dtype ("auto" resolved)."""
+    if _analysis_mode == "auto":
+        return "x3c2" if _compute_dtype == torch.float16 else "x3"
     return _analysis_mode
 
 
 def analysis_hilo(x):
-    """True when the analysis stack should take the hi/lo route for input ``x``: bf16 inference on the GPU."""
-    return (_analysis_mode == "bf16x3" and _is16() and not torch.is_grad_enabled() and x.is_cuda)
+    """True when the analysis stack should take the hi/lo route for input ``x``: 16-bit inference on the GPU."""
+    return (analysis_precision() != "x1" and _is16() and not torch.is_grad_enabled() and x.is_cuda)
+
+
+def analysis_conv2_single():
+    """True in the "x3c2" mode: g_a_conv2 on single operands between the pair layers."""
+    return analysis_precision() == "x3c2"
 
 
 class PackedWeightHiLo:
@@ -893,14 +927,32 @@ def sconv_gdn_hilo_ok(x, weight):
             and weight.dtype == torch.float32 and min(x.stride()) >= 0)
 
 
-def sconv_gdn_hilo(x, image, bias, beta_packed, inverse):
-    """GDN(conv(x)) of the 3 -> 128 5x5 stride-2 stage on hi/lo pairs in one kernel: (B, 256, H/2, W/2) [hi | lo] bf16 NHWC."""
+def sconv_gdn_hilo(x, image, bias, beta_packed, inverse, out1=False):
+    """GDN(conv(x)) of the 3 -> 128 5x5 stride-2 stage on hi/lo pairs in one kernel: (B, 256, H/2, W/2) [hi | lo] 16-bit NHWC;
+    ``out1``: the same arithmetic, but the output is ONE 16-bit value per channel, (B, 128, H/2, W/2)."""
     L.require_cuda(x)
     B, Cc, H, W = x.shape
     Ho, Wo = _out_hw(H, W, 5, 2, 2, False)
-    y = _empty_nhwc(B, 256, Ho, Wo, _h16(), x.device)
+    y = _empty_nhwc(B, 128 if out1 else 256, Ho, Wo, _h16(), x.device)
     d = _sdesc(x, y, 3, 128, 5, 2, 2, False)
-    L.call("hesic_sconv2d_gdn_forward_hilo", C.byref(d), L.ptr(x), L.ptr(image), L.ptr(bias), L.ptr(beta_packed), int(inverse), L.ptr(y), L.stream())
+    L.call("hesic_sconv2d_gdn_forward_hilo_out1" if out1 else "hesic_sconv2d_gdn_forward_hilo", C.byref(d), L.ptr(x), L.ptr(image), L.ptr(bias),
+           L.ptr(beta_packed), int(inverse), L.ptr(y), L.stream())
+    return y
+
+
+def conv2d_gdn_hilo_out(x, wp, bias, cin, *, kernel_size, stride, padding, gdn):
+    """(I)GDN(conv(x)) with SINGLE 16-bit operands in the conv (one product per MAC), the GDN on pairs from the fp32 accumulators and a
+    hi/lo output map (B, 256, Ho, Wo) -- ``hesic_conv2d_gdn_forward_hilo_out``; ``gdn`` = (gamma_packed, gamma_lo_packed, beta_packed, inverse)."""
+    L.require_cuda(x)
+    k = kernel_size
+    B, cx, H, W = x.shape
+    Ho, Wo = _out_hw(H, W, k, stride, padding, False)
+    x = _nhwc(x)
+    gp, glo, bp, inverse = gdn
+    y = _empty_nhwc(B, 256, Ho, Wo, _h16(), x.device)
+    d = L.ConvDesc(B, H, W, cin, Ho, Wo, 128, k, k, stride, padding, 0, L.H16, 0, 0, cx, 0, 256, 0, 0)
+    L.call("hesic_conv2d_gdn_forward_hilo_out", C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
+           L.ptr(y), L.stream())
     return y
 
 

@@ -210,6 +210,13 @@ class Encoder1(nn.Module):
         self.g_a_conv2, self.g_a_gdn2 = conv(N, N), GDN(N)
         self.g_a_conv3, self.g_a_gdn3 = conv(N, N), GDN(N)
         self.g_a_conv4 = conv(N, M)
+        self._mark_shaped()
+
+    def _mark_shaped(self):
+        # single-operand inference launches of these layers (the third analysis pass, g_a_conv2 in the "x3c2" mode) take weights rounded
+        # with error feedback over the taps (Fn.PackedWeight(shaped=True)): their inputs are spatially smooth GDN outputs
+        for c in (self.g_a_conv2, self.g_a_conv3, self.g_a_conv4):
+            c.shaped_weights = True
 
     def trunk(self, x):
         x = self.g_a_conv1.run_gdn(x, self.g_a_gdn1)        # conv + GDN in one kernel at inference
@@ -243,7 +250,18 @@ class Encoder1(nn.Module):
         if not hasattr(self, "_hl1"):
             self._hl1 = Fn.PackedWeightHiLo(), Fn.PackedGdnLo(), Fn.PackedN2wHiLo()
         gp, bp = g1.packer().get(g1.beta, g1.gamma, g1.beta_min)
-        if Fn.sconv_gdn_hilo_ok(x, c1.weight) and not _os.environ.get("HESIC_N2W_HILO_IM2COL"):
+        fused1 = Fn.sconv_gdn_hilo_ok(x, c1.weight) and not _os.environ.get("HESIC_N2W_HILO_IM2COL")
+        if fused1 and Fn.analysis_conv2_single() and self.g_a_conv2.weight.shape[:2] == (128, 128):
+            # "x3c2": conv1 + GDN on pairs inside the kernel, ONE 16-bit value per channel out; g_a_conv2 multiplies single operands,
+            # its GDN runs on pairs again and hands pairs to g_a_conv3
+            t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse, out1=True)
+            t = self.g_a_conv2.run_gdn_hilo_out(t, self.g_a_gdn2)
+            t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3)
+            if not want_lo:
+                return None, self.g_a_conv4.run_hilo(t, out="f32")
+            lo, y = self.g_a_conv4.run_hilo(t, out="both", out_abs=lo_abs)
+            return Fn.HiLo((lo, self.g_a_conv4.weight.shape[0])), y
+        if fused1:
             t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse)       # conv + GDN in one kernel
         else:
             KP = 96                                        # other layouts: 3 * 25 = 75 im2col columns (padded) -> 1x1 implicit GEMM + GDN
@@ -269,6 +287,7 @@ class Encoder2(Encoder1):
         self.g_a_conv2, self.g_a_gdn2 = conv(N, N), GDN(N)
         self.g_a_conv3, self.g_a_gdn3 = conv(N, N), GDN(N)
         self.g_a_conv4 = conv(N, M)
+        self._mark_shaped()
 
     def forward(self, x1_warp, x2):
         t = self.pre_conv.run_cat(x1_warp, x2, gdn=self.pre_gdn)

@@ -63,6 +63,12 @@ typedef struct {
 int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, int Cout, int Cin, int KH, int KW,
                            int transposed, int flip, int dtype, void* stream);
 
+/* The same layout in HESIC_H16 for a Conv2d weight (Cout,Cin,KH,KW) of an INFERENCE layer that multiplies single operands, rounded with
+ * error feedback over the taps of each (cout, cin) pair (serpentine walk over the window): the 16-bit weights of a pair sum to the fp32
+ * weights' sum within half an ulp, so on spatially smooth feature maps the weight-rounding error of the layer's output cancels
+ * ("x3c2").  A drop-in for hesic_pack_conv_weight(w, NULL, wp, ..., 0, 0, HESIC_H16): same buffer, same consumers.        */
+int hesic_pack_conv_weight_shaped(const float* w, void* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+
 /* Many repacks in one launch (a training step repacks every conv weight after the optimiser update): `jobs_device` is a
  * DEVICE array of n_jobs descriptors, job i owns blocks [block0_i, block0_{i+1}), one per tile of 8 couts x 32 cins
  * (block0 ascending, block0_0 = 0, total_blocks = sum of ceil(Cout/8) * ceil(Cin/32)); fields as hesic_pack_conv_weight,
@@ -139,6 +145,13 @@ int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, cons
                               const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                               void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                               void* stream);
+/* The bridge between a one-product layer and the hi/lo layers behind it (analysis mode "x3c2": g_a_conv2 -- 128 -> 128 5x5 s2 on the
+ * 256^2 map of a 512^2 image, 70 % of g_a's MACs, newnet1.py:585-586 -- multiplies SINGLE 16-bit operands, everything else pairs):
+ * x and w_packed are plain 16-bit (hesic_pack_conv_weight), v = conv + bias stays in the fp32 accumulators, the (I)GDN contraction
+ * runs on pairs as above, y_hilo leaves as [hi(128) | lo(128)].  Conv2d only, Cout == 128.                                       */
+int hesic_conv2d_gdn_forward_hilo_out(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                      const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                      void* y_hilo, void* stream);
 /* split-K scratch for the plain (no GDN) hi/lo launch, as hesic_conv2d_ws_bytes (0: none needed; ws may be NULL) */
 size_t hesic_conv2d_hilo_ws_bytes(const hesic_conv_desc* d);
 /* lo half of gamma' (128*128 bf16, MFMA fragment order) for the hi/lo GDN epilogue; the hi half is hesic_gdn_pack_params'. */
@@ -207,6 +220,10 @@ typedef struct {
 int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image_hilo, void* stream);
 int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
                                    const float* beta_packed, int inverse, void* y_hilo, void* stream);
+/* Same kernel, same pair arithmetic inside, but y leaves as ONE 16-bit value per channel (128 channels, ys_x >= 128): the input of
+ * a one-product layer (hesic_conv2d_gdn_forward_hilo_out).                                                                       */
+int hesic_sconv2d_gdn_forward_hilo_out1(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
+                                        const float* beta_packed, int inverse, void* y, void* stream);
 
 /* w is the raw fp32 PyTorch weight ((Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW)). */
 int hesic_sconv2d_forward(const hesic_sconv_desc* d, const void* x, const float* w, const float* bias, void* y,

@@ -12,7 +12,7 @@ from hesic_amd import models, synthetic  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "hsic"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-hesic_amd.set_compute_dtype(torch.bfloat16)
+hesic_amd.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("HESIC_DTYPE", "f16")])     # analysis mode: HESIC_ANALYSIS
 net = models.HSIC() if which == "hsic" else models.HSICJoint()
 synthetic.fill_state_dict_(net.state_dict())
 net = net.cuda().eval()

@@ -24,6 +24,10 @@ from oracle import hesic_oracle as O  # noqa: E402
 from hesic_amd import synthetic  # noqa: E402
 
 
+# serpentine walk over the 5x5 taps: consecutive taps are spatial neighbours
+NS_ORDER = [r * 5 + (c if r % 2 == 0 else 4 - c) for r in range(5) for c in range(5)]
+
+
 def _r(t, dt):
     return t.to(dt).float()
 
@@ -46,6 +50,22 @@ def conv_mode(x, w, b, stride, mode):
         xh, xl = split(x, dt)
         wh, wl = split(w, dt)
         y = c(xh, wh) + c(xl, wh) + c(xh, wl)
+    elif mode in ("f16ns", "f16x2ns"):       # weights rounded with error feedback over the taps of each (cout, cin): sum of the tap errors ~ 0
+        wf = w.reshape(w.shape[0], w.shape[1], -1)
+        out = torch.empty_like(wf)
+        e = torch.zeros_like(wf[..., 0])
+        order = NS_ORDER if wf.shape[-1] == 25 else range(wf.shape[-1])
+        for t in order:
+            tgt = wf[..., t] + e
+            q = _r(tgt, torch.float16)
+            e = tgt - q
+            out[..., t] = q
+        wq = out.reshape(w.shape)
+        if mode == "f16ns":
+            y = c(_r(x, torch.float16), wq)
+        else:
+            xh, xl = split(x, torch.float16)
+            y = c(xh, wq) + c(xl, wq)
     elif mode == "f16x2":
         xh, xl = split(x, torch.float16)
         wh = _r(w, torch.float16)
@@ -126,6 +146,12 @@ SCHEMES = {
     "f16x3": Scheme("f16x3", ["f16x3"] * 4, ["f16x3"] * 3, ["f16x3"] * 3),
     # conv2 (70 % of g_a's MACs) cheap, the rest exact
     "c2_f16": Scheme("c2_f16", ["bf16x3", "f16", "bf16x3", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c2_f16ns": Scheme("c2_f16ns", ["bf16x3", "f16ns", "bf16x3", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c2_f16x2ns": Scheme("c2_f16x2ns", ["bf16x3", "f16x2ns", "bf16x3", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c23_f16x2ns": Scheme("c23_f16x2ns", ["bf16x3", "f16x2ns", "f16x2ns", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c234_f16x2ns": Scheme("c234_f16x2ns", ["bf16x3", "f16x2ns", "f16x2ns", "f16x2ns"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c1234_f16x2ns": Scheme("c1234_f16x2ns", ["f16x2ns", "f16x2ns", "f16x2ns", "f16x2ns"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
+    "c23_f16ns": Scheme("c23_f16ns", ["bf16x3", "f16ns", "f16ns", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
     "c2_f16x2": Scheme("c2_f16x2", ["bf16x3", "f16x2", "bf16x3", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
     "c2_f16w2": Scheme("c2_f16w2", ["bf16x3", "f16w2", "bf16x3", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),
     "c23_f16": Scheme("c23_f16", ["bf16x3", "f16", "f16", "bf16x3"], ["bf16x3", "bf16x3", "bf16x3"], ["bf16x3"] * 3),

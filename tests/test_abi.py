@@ -15,16 +15,70 @@ def _lib():
     return L
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_library_exports_every_declared_symbol(fmt):
+    """Both builds of the library (16-bit format bfloat16 / IEEE half: same sources, same entry points) load without a GPU, say which
+    format they were built for and export every symbol of the header."""
+    import torch
     L = _lib()
-    l = L.lib()
+    h16 = torch.float16 if fmt == "f16" else torch.bfloat16
+    path = L.LIB_PATH_F16 if fmt == "f16" else L.LIB_PATH
+    l = L.lib(h16)
     assert l.hesic_abi_version() == 1
+    assert l.hesic_h16_format() == (1 if fmt == "f16" else 0)
     declared = L.declared_symbols()
     assert len(declared) >= 30
-    exported = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH], text=True)
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     missing = [s for s in declared if f" T {s}\n" not in exported]
     assert not missing, missing
     assert set(declared) == set(L._SIGS), (set(declared) ^ set(L._SIGS))
+
+
+def test_compute_dtype_selects_the_library():
+    """set_compute_dtype(float16 / bfloat16) binds the library built for that format; a tensor of the OTHER 16-bit format is refused
+    loudly (no silent reinterpretation of its bits); fp32 goes to whichever library is active."""
+    import torch
+    import hesic_amd
+    L = _lib()
+    try:
+        hesic_amd.set_compute_dtype(torch.float16)
+        assert L.h16_dtype() == torch.float16 and L.lib().hesic_h16_format() == 1
+        assert L.dt(torch.float16) == L.H16 and L.dt(torch.float32) == L.F32
+        with pytest.raises(TypeError, match="active 16-bit format"):
+            L.dt(torch.bfloat16)
+        hesic_amd.set_compute_dtype(torch.float32)          # fp32 keeps the active library
+        assert L.h16_dtype() == torch.float16
+        hesic_amd.set_compute_dtype(torch.bfloat16)
+        assert L.h16_dtype() == torch.bfloat16 and L.lib().hesic_h16_format() == 0
+        with pytest.raises(TypeError, match="active 16-bit format"):
+            L.dt(torch.float16)
+        with pytest.raises(ValueError):
+            hesic_amd.set_compute_dtype(torch.float64)
+    finally:
+        hesic_amd.set_compute_dtype(torch.bfloat16)
+        hesic_amd.set_compute_dtype(torch.float32)
+
+
+def test_analysis_precision_modes():
+    """Host logic of the analysis-precision switch: "auto" resolves per compute dtype, round-3 names stay valid."""
+    import torch
+    import hesic_amd
+    from hesic_amd import functional as Fn
+    prev = Fn.set_analysis_precision("auto")
+    try:
+        hesic_amd.set_compute_dtype(torch.float16)
+        assert Fn.analysis_precision() == "x3c2"
+        hesic_amd.set_compute_dtype(torch.bfloat16)
+        assert Fn.analysis_precision() == "x3"
+        Fn.set_analysis_precision("bf16x3")
+        assert Fn.analysis_precision() == "x3"
+        Fn.set_analysis_precision("bf16")
+        assert Fn.analysis_precision() == "x1"
+        with pytest.raises(ValueError):
+            Fn.set_analysis_precision("x4")
+    finally:
+        Fn.set_analysis_precision(prev)
+        hesic_amd.set_compute_dtype(torch.float32)
 
 
 def test_struct_layouts_match_header():

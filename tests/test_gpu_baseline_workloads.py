@@ -36,7 +36,7 @@ def _reset():
     import hesic_amd
     from hesic_amd import functional as Fn
     hesic_amd.set_compute_dtype(torch.float32)
-    Fn.set_analysis_precision("bf16x3")
+    Fn.set_analysis_precision("auto")
 
 
 def per_pair(out, x1, x2):
@@ -68,6 +68,7 @@ def check_against(g, out, x1, x2, flips_max, bits_rel, sse_rel, psnr_db, view_ps
     ref = sum(g["bits_" + k] for k in ("y1", "y2", "z1", "z2")) / (h * w * 2)
     meas["dbpp_abs"] = float(np.abs(tot - ref).max())
     meas["dbpp_rel"] = float(np.abs(tot / ref - 1).max())
+    meas["dbpp_abs_set_mean"] = float(abs((tot - ref).mean()))          # the set average is what the reference reports (test3real.py:110-122)
     ok = (max(meas["flips_y1_hat"], meas["flips_y2_hat"]) <= flips_max and max(meas["bits_rel_" + k] for k in ("y1", "y2", "z1", "z2")) <= bits_rel
           and max(meas["sse_rel_sse1"], meas["sse_rel_sse2"]) <= sse_rel and meas["dpsnr_db"] < psnr_db
           and max(meas["dpsnr_db_view1"], meas["dpsnr_db_view2"]) < (view_psnr_db or psnr_db))
@@ -76,18 +77,34 @@ def check_against(g, out, x1, x2, flips_max, bits_rel, sse_rel, psnr_db, view_ps
     return meas
 
 
+# Bars per (16-bit format, analysis mode) = measured on MI355X + margin (round 4; the measured maxima are printed by every run):
+#   flips: share of the integer latents that differ from the reference's, worst pair;  bits: per-pair, per-latent-group bits, relative;
+#   sse: per-view squared error, relative;  psnr / view: dB of the two-view mean the reference reports / of each view;
+#   dbpp: |mean over the pairs of (bpp - bpp_ref)|, ABSOLUTE (north_star: bpp within 1e-3)
+MODE_BARS = {
+    ("f16", "x3c2"): dict(flips_max=1e-3, bits_rel=1.5e-3, sse_rel=1e-4, psnr_db=4e-4, view_psnr_db=6e-4, dbpp=1e-3),     # the benchmark's default
+    ("f16", "x3"): dict(flips_max=1e-4, bits_rel=1e-3, sse_rel=5e-5, psnr_db=1e-4, view_psnr_db=2e-4, dbpp=1e-3),
+    ("bf16", "x3"): dict(flips_max=2e-4, bits_rel=1e-3, sse_rel=1e-3, psnr_db=1e-3, view_psnr_db=2e-3, dbpp=1e-3),        # round 3's headline mode
+}
+
+
+@pytest.mark.parametrize("fmt,analysis", list(MODE_BARS), ids=["-".join(k) for k in MODE_BARS])
 @pytest.mark.parametrize("kind,batch", [("hsic", 8), ("joint", 4)], ids=["C2-hesic-b8", "C4-hesicplus-b4"])
-def test_bf16x3_512_batch_matches_the_reference_pair_by_pair(kind, batch):
-    """BASELINE configs C2 / C4 in the benchmark's own mode (bf16 maps, bf16x3 analysis): every pair of the batch against the
-    reference's fp32 run.  Measured on MI355X: <= 2e-5 of the latents differ, per-pair bits within 4e-4, squared error within 1e-4."""
+def test_16bit_512_batch_matches_the_reference_pair_by_pair(kind, batch, fmt, analysis):
+    """BASELINE configs C2 / C4 in the benchmark's own modes (16-bit maps, fp32 accumulation, pair arithmetic on the analysis side): every
+    pair of the batch against the reference's fp32 run, and the set-average bpp against the ABSOLUTE 1e-3 bar."""
     from hesic_amd import functional as Fn
     g = load_golden(f"{kind}_512_b{batch}.npz")
-    net = build(kind, torch.bfloat16)
-    assert Fn.analysis_precision() == "bf16x3"
+    net = build(kind, {"f16": torch.float16, "bf16": torch.bfloat16}[fmt])
+    assert Fn.analysis_precision() == ("x3c2" if fmt == "f16" else "x3")           # "auto"
+    Fn.set_analysis_precision(analysis)
+    bars = dict(MODE_BARS[(fmt, analysis)])
+    dbpp_bar = bars.pop("dbpp")
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, batch, 512, 512))
     with torch.no_grad():
         out = net(x1, x2, Hm)
-        meas = check_against(g, out, x1, x2, flips_max=1e-3, bits_rel=2e-3, sse_rel=1e-3, psnr_db=1e-3, view_psnr_db=2.5e-3)
+        meas = check_against(g, out, x1, x2, **bars)
+        assert meas["dbpp_abs_set_mean"] < dbpp_bar, meas
         assert meas["dbpp_rel"] < 1e-3, meas
         # pairs are independent: the last pair alone reproduces its slice of the batch bit for bit
         one = net(x1[-1:], x2[-1:], Hm[-1:])
@@ -102,7 +119,7 @@ def test_single_bf16_analysis_512_batch_stays_inside_its_wider_bars(kind, batch)
     from hesic_amd import functional as Fn
     g = load_golden(f"{kind}_512_b{batch}.npz")
     net = build(kind, torch.bfloat16)
-    Fn.set_analysis_precision("bf16")
+    Fn.set_analysis_precision("x1")
     x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, batch, 512, 512))
     with torch.no_grad():
         out = net(x1, x2, Hm)

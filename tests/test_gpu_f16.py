@@ -1,0 +1,224 @@
+"""The IEEE-half build of the kernel library (libhesic_hip_f16.so, round 4) on a real MI355X: the same operators as
+tests/test_gpu_ops.py with float16 storage / matrix-core operands, against the CPU oracle on the same seeded inputs.
+
+Bars: float16 storage within 3e-3 of the output scale against the oracle run on the fp16-rounded operands (2^-11 per stored value;
+bf16's bar is 2e-2); the pair ("x3") analysis stack within 2e-5 rms of the fp32 oracle, the "x3c2" stack (g_a_conv2 on single operands,
+error-feedback weights) within 5e-4; activations beyond the fp16 range saturate instead of turning into infinities; the squares inside
+the fused (I)GDN contractions are range-scaled (common.h: H16_SQ_SCALE), so |v| up to 2000 is normalised correctly."""
+import pytest
+import torch
+
+import hesic_amd
+from hesic_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F16 = torch.float16
+
+
+def _imp():
+    from hesic_amd import functional as Fn
+    from oracle import hesic_oracle as O
+    return Fn, O
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0):
+    return synthetic._uniform("t16." + name, shape, lo, hi)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rms_rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+
+
+def h(x):
+    return x.to(F16).float()
+
+
+@pytest.fixture(autouse=True)
+def _f16_mode():
+    from hesic_amd import functional as Fn
+    hesic_amd.set_compute_dtype(F16)
+    prev = Fn.set_analysis_precision("auto")
+    yield
+    Fn.set_analysis_precision(prev)
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    hesic_amd.set_compute_dtype(torch.float32)
+
+
+CASES = [
+    ("c5s2_128", 128, 128, 5, 2, 0, (2, 32, 32)),
+    ("c5s1_320_128", 320, 128, 5, 1, 0, (1, 12, 12)),
+    ("c5s1_128_960", 128, 960, 5, 1, 0, (1, 8, 8)),
+    ("c5s2_parity_walk", 128, 128, 5, 2, 0, (4, 64, 48)),
+    ("d5s2_128", 128, 128, 5, 2, 1, (2, 16, 16)),
+    ("d5s2_tr4", 128, 128, 5, 2, 1, (8, 64, 64)),              # 512 fused blocks: the four-phases-per-block kernel
+    ("d5s2_192_128", 192, 128, 5, 2, 1, (1, 4, 4)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_wide_conv_forward_f16(case):
+    Fn, O = _imp()
+    tag, Cin, Cout, k, s, tr, (B, H, W) = case
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    fan = Cin * k * k / (4 if tr and s == 2 else 1)
+    w = h(rnd(tag + "w", wshape) * (3.0 / fan) ** 0.5)
+    b = rnd(tag + "b", (Cout,), -0.1, 0.1)
+    x = h(rnd(tag + "x", (B, Cin, H, W)))
+    ref = (O.deconv if tr else O.conv)(x, w, b, s)
+    xd = x.to(DEV, F16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = Fn.conv2d(xd, w.to(DEV), b.to(DEV), kernel_size=k, stride=s, padding=k // 2, transposed=bool(tr))
+    assert y.shape == ref.shape and y.dtype == F16
+    assert rel_err(y, ref) < 3e-3
+
+
+def test_f16_library_refuses_training():
+    """float16 is an inference format here: gradients need the fp32 exponent range (bfloat16 library)."""
+    Fn, _ = _imp()
+    x = h(rnd("tr_x", (1, 128, 8, 8))).to(DEV, F16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = rnd("tr_w", (128, 128, 5, 5)).to(DEV).requires_grad_()
+    with pytest.raises(RuntimeError, match="float16"):
+        Fn.conv2d(x, w, None, kernel_size=5, stride=2, padding=2)
+
+
+@pytest.mark.parametrize("inv", [False, True], ids=["gdn", "igdn"])
+@pytest.mark.parametrize("scale", [1.0, 250.0], ids=["unit", "x250"])
+def test_conv_gdn_fused_f16_keeps_its_range(inv, scale):
+    """conv / deconv + (I)GDN in one launch with float16 storage: conv outputs of magnitude ~1 and ~1000 (squares ~1e6: beyond fp16's
+    65504 unless the contraction's squares are range-scaled) against the oracle."""
+    Fn, O = _imp()
+    from compressai.layers import GDN
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=5)
+    gd = GDN(128, inverse=inv).to(DEV)
+    with torch.no_grad():
+        gd.beta.copy_(sd["g.beta"]); gd.gamma.copy_(sd["g.gamma"])
+    tr = inv
+    wshape = (128, 128, 5, 5)
+    w = h(rnd("cg_w", wshape) * (3.0 / (3200 / (4 if tr else 1))) ** 0.5 * (1.0 if inv else scale))
+    b = rnd("cg_b", (128,), -0.1, 0.1)
+    x = h(rnd("cg_x", (2, 128, 24, 20), -3, 3))
+    v = (O.deconv if tr else O.conv)(x, w, b, 2)
+    if not inv:
+        assert float(v.abs().max()) > (300 if scale > 1 else 1)
+    ref = O.gdn(v, sd["g.beta"], sd["g.gamma"], inv)
+    xd = x.to(DEV, F16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = Fn.conv2d_gdn(xd, w.to(DEV), b.to(DEV), gd.beta, gd.gamma, kernel_size=5, stride=2, padding=2, transposed=tr, inverse=inv,
+                          beta_min=gd.beta_min, packer=Fn.PackedWeight(), gdn_packer=gd.packer())
+    assert y.dtype == F16 and bool(torch.isfinite(y.float()).all())
+    assert rel_err(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("inv", [False, True])
+def test_gdn128_standalone_f16(inv):
+    Fn, O = _imp()
+    sd = {"g.beta": torch.zeros(128), "g.gamma": torch.zeros(128, 128)}
+    synthetic.fill_state_dict_(sd, salt=3)
+    for amp in (3.0, 900.0):
+        x = h(rnd("gdnL%d" % amp, (2, 128, 24, 20), -amp, amp))
+        if inv and amp > 10:
+            x = x / 30          # IGDN multiplies by sqrt(norm) ~ |x|: keep the OUTPUT inside fp16
+        ref = O.gdn(x, sd["g.beta"], sd["g.gamma"], inv)
+        with torch.no_grad():
+            y = Fn.gdn(x.to(DEV, F16).contiguous(memory_format=torch.channels_last), sd["g.beta"].to(DEV), sd["g.gamma"].to(DEV), inv)
+        assert y.dtype == F16 and rel_err(y, ref) < 3e-3, amp
+
+
+def test_out_of_range_activations_saturate():
+    """A conv output beyond +-65504 is stored as +-65504, not as an infinity."""
+    Fn, _ = _imp()
+    x = torch.full((1, 128, 8, 8), 60.0).to(DEV, F16).contiguous(memory_format=torch.channels_last)
+    w = torch.full((128, 128, 1, 1), 16.0, device=DEV)
+    w[64:] = -16.0
+    with torch.no_grad():
+        y = Fn.conv2d(x, w, None, kernel_size=1, stride=1, padding=0).float()
+    assert bool(torch.isfinite(y).all())
+    assert float(y[:, :64].min()) == 65504.0 and float(y[:, 64:].max()) == -65504.0
+
+
+def test_shaped_weight_packing_conserves_the_tap_sums():
+    """hesic_pack_conv_weight_shaped: every packed value is within one ulp OF THE PAIR'S LARGEST WEIGHT of its fp32 weight (the error
+    carried from tap to tap is at most half of that), and the 25 values of a (cout, cin) pair sum to the fp32 sum within ONE half-ulp --
+    plain rounding leaves ~sqrt(25) / sqrt(12) ulp."""
+    Fn, _ = _imp()
+    from hesic_amd import _lib as L
+    w = (rnd("shp_w", (128, 128, 5, 5)) * 0.05).to(DEV)
+    wp = torch.empty(25 * 128 * 128, dtype=F16, device=DEV)
+    wq = torch.empty_like(wp)
+    L.call("hesic_pack_conv_weight_shaped", L.ptr(w), L.ptr(wp), 128, 128, 5, 5, L.stream())
+    L.call("hesic_pack_conv_weight", L.ptr(w), None, L.ptr(wq), 128, 128, 5, 5, 0, 0, L.H16, L.stream())
+    shaped = wp.reshape(25, 128, 128).permute(1, 2, 0).double()           # [co][ci][tap]
+    plain = wq.reshape(25, 128, 128).permute(1, 2, 0).double()
+    src = w.reshape(128, 128, 25).double()
+    assert torch.equal(plain.float(), src.float().to(F16).float())
+    ulp = 2.0 ** (torch.floor(torch.log2(src.abs().clamp_min(2.0 ** -14))) - 10)
+    assert float(((shaped - src).abs() / ulp.max(2, keepdim=True).values).max()) <= 1.0 + 1e-9
+    err_shaped, err_plain = (shaped.sum(2) - src.sum(2)).abs(), (plain.sum(2) - src.sum(2)).abs()
+    assert float((err_shaped / ulp.max(2).values).max()) <= 0.5 + 1e-9
+    assert float(err_shaped.pow(2).mean().sqrt()) < 0.35 * float(err_plain.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("mode,bar", [("x3", 2e-5), ("x3c2", 5e-4), ("x1", 1.5e-3)])
+def test_analysis_stack_accuracy_by_mode(mode, bar):
+    """Encoder1 (g_a) on a 256 x 320 image in float16: rms error of y against the fp32 oracle per analysis mode.  Measured: x3 2e-6
+    (pairs everywhere), x3c2 2.5e-4 (g_a_conv2 on single fp16 operands with error-feedback weights), x1 6e-4 (single operands everywhere)."""
+    Fn, O = _imp()
+    from hesic_amd import models
+    Fn.set_analysis_precision(mode)
+    enc = models.Encoder1(128, 192).to(DEV).eval()
+    sd = enc.state_dict()
+    synthetic.fill_state_dict_(sd)
+    x = synthetic.stereo_batch(2, 2, 256, 320)[0]
+    P = {"e." + k: v.detach().cpu().float() for k, v in sd.items()}
+    ref = O.g_a(P, "e.", x)
+    with torch.no_grad():
+        _, y = enc.latent(x.to(DEV), want_lo=False, exact=True)
+    assert y.dtype == torch.float32
+    err = rms_rel(y, ref)
+    print("rms rel", mode, err)
+    assert err < bar, err
+
+
+def test_x3c2_stack_is_bit_stable_across_launches():
+    """The x3c2 analysis stack (pair conv1 + GDN with single output, single-operand conv2 with the pair GDN epilogue, pair layers behind
+    it) launched 150 times with allocator churn: every launch bit-identical to the first."""
+    Fn, O = _imp()
+    from hesic_amd import models
+    Fn.set_analysis_precision("x3c2")
+    enc = models.Encoder1(128, 192).to(DEV).eval()
+    synthetic.fill_state_dict_(enc.state_dict())
+    x = synthetic.stereo_batch(2, 2, 256, 320)[0].to(DEV)
+    with torch.no_grad():
+        lo0, y0 = enc.latent_hilo(x, True, True)
+        lo0, y0 = lo0.t.clone(), y0.clone()
+        bad = 0
+        for it in range(150):
+            if it % 7 == 0:
+                junk = torch.full((1 << (10 + it % 13),), 1e30, device=DEV)
+                del junk
+            lo, y = enc.latent_hilo(x, True, True)
+            bad += int(not (torch.equal(y, y0) and torch.equal(lo.t, lo0)))
+    assert bad == 0, bad
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_f16_pairs_do_not_depend_on_the_batch(kind):
+    """Pairs are independent in the default float16 mode too: pair 3 of a batch of 4 equals that pair alone, bit for bit."""
+    from hesic_amd import models
+    net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
+    synthetic.fill_state_dict_(net.state_dict())
+    net = net.to(DEV).eval()
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(0, 4, 128, 192))
+    with torch.no_grad():
+        out = net(x1, x2, Hm)
+        one = net(x1[-1:], x2[-1:], Hm[-1:])
+    for k in ("y1_hat", "y2_hat", "x1_hat", "x2_hat"):
+        assert torch.equal(out[k][-1:], one[k]), k
