@@ -35,6 +35,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 = dense f16, /opt/skills/guides/
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (the guide's measured copy ceiling is 6.29 TB/s)
 HESIC_GFLOP_PER_PAIR_512 = 155.66
+JOINT_GFLOP_PER_PAIR_512 = 126.2   # HESIC+, live masked taps (BASELINE.md section 2 / SURVEY 8d)
+
+
+def gflop_per_pair(model, h, w):
+    return (HESIC_GFLOP_PER_PAIR_512 if model == "hsic" else JOINT_GFLOP_PER_PAIR_512) * (h * w / 512 ** 2)
 
 
 def conv_flops(B, Ho, Wo, H, W, Cin, Cout, k, transposed, ntaps=None):
@@ -334,6 +339,80 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
 
 
 
+def secondary_block(dev, size=512, lmbda=0.0067):
+    """Two more driver-visible numbers, measured AFTER the headline's timed region (rank 0 of a 1-GPU run, a few seconds):
+    BASELINE config C4 (HESIC+, 4 pairs of 512 x 512, the headline's dtype / analysis mode, eager issue) with its dominant conv kernel's
+    roofline fraction, and one graph-replayed TRAINING step of HESIC at B=8 512 x 512 in bf16 (the per-GPU share of config C3)."""
+    import hesic_amd
+    from hesic_amd import _lib as L_, functional as Fn, models, synthetic
+    from hesic_amd.train import GraphedTrainer
+    out = {}
+    keep = Fn.compute_dtype()
+    try:
+        # ---- C4
+        net = models.HSICJoint()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.to(dev).eval()
+        xs = [tuple(t.to(dev) for t in synthetic.stereo_batch(4 * j, 4, size, size)) for j in range(4)]
+
+        def fwd(i):
+            a, b, h = xs[i % 4]
+            with torch.no_grad():
+                o = net(a, b, h)
+                return models.rate_distortion(o, a, b)
+        for i in range(15):
+            fwd(i)
+        torch.cuda.synchronize()
+        n, t0 = 40, time.perf_counter()
+        for i in range(n):
+            fwd(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        overlap, models.OVERLAP_STREAMS = models.OVERLAP_STREAMS, False
+        with KernelMeter(L_) as km:
+            for i in range(3):
+                fwd(i)
+            s = km.summary()
+        models.OVERLAP_STREAMS = overlap
+        gf = gflop_per_pair("joint", size, size)
+        out["c4_hesicplus_b4"] = {"value": round(4 * n / el, 2), "unit": "stereo-pairs/s", "ms_per_step": round(1e3 * el / n, 3), "pairs_per_step": 4,
+                                  "issue": "eager", "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[keep],
+                                  "analysis": Fn.analysis_precision() if keep != torch.float32 else "fp32",
+                                  "model_tflops": round(4 * n * gf / el / 1e3, 2), "gflop_per_pair": gf,
+                                  "roofline": None if not s else {"kernel": s["kernel"], "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                                  "unit": "TFLOP/s", "frac": round(s["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                                  "avg_launch_us": round(s["avg_us"], 2), "launches_per_step": s["launches"] // 3}}
+        del net, xs
+        # ---- one training step (C3's per-GPU share), bf16, HIP-graph replay
+        hesic_amd.set_compute_dtype(torch.bfloat16)
+        tnet = models.HSIC()
+        synthetic.fill_state_dict_(tnet.state_dict())
+        tnet = tnet.to(dev).train()
+        tr = GraphedTrainer(tnet, lr=1e-4, aux_lr=1e-3, lmbda=lmbda)
+        x1, x2, Hm = (t.to(dev) for t in synthetic.stereo_batch(0, 8, size, size))
+        for _ in range(tr.warmup + 3):
+            tr.step(x1, x2, Hm)
+        torch.cuda.synchronize()
+        n, t0 = 12, time.perf_counter()
+        for _ in range(n):
+            crit = tr.step(x1, x2, Hm)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        gf3 = 3 * gflop_per_pair("hsic", size, size)
+        out["train_step_hesic_b8"] = {"ms_per_step": round(1e3 * el / n, 3), "value": round(8 * n / el, 2), "unit": "stereo-pairs/s", "dtype": "bf16",
+                                      "step": "HIP graph replay" if getattr(tr, "capturable", True) else "eager",
+                                      "model_tflops": round(8 * n * gf3 / el / 1e3, 2),
+                                      "mfma_frac_of_step": round(8 * n * gf3 / el / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                      "loss_last_step": round(float(crit["loss"]), 4)}
+        del tr, tnet
+    except Exception as e:          # the headline must not die with the extras
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        hesic_amd.set_compute_dtype(torch.bfloat16 if keep == torch.float32 else keep)
+        hesic_amd.set_compute_dtype(keep)
+    return out
+
+
 def emit_line(obj):
     """The run's ONE JSON line, as the LAST thing on stdout: whatever native libraries have queued on the C stdio buffer (RCCL's
     NCCL_DEBUG=VERSION banner, which this image exports) is flushed first, then the line, flushed."""
@@ -381,6 +460,20 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
     if rank == 0:
         pairs = world * args.batch * args.steps
         per = {lam: {"pairs": v["pairs"], "bpp": round(v["bpp"], 5), "psnr": round(v["psnr"], 4)} for lam, v in sweep.summary(H_img, W_img).items()}
+        # dominant conv kernel of the sweep's steps, measured live after the timed region (single stream: an event pair brackets ONE kernel)
+        from hesic_amd import _lib as L_, models as models_
+        roof = None
+        overlap, models_.OVERLAP_STREAMS = models_.OVERLAP_STREAMS, False
+        with KernelMeter(L_) as km:
+            for k in range(4):
+                step(k, False)
+            s = km.summary()
+        models_.OVERLAP_STREAMS = overlap
+        if s:
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype != "f32" else MFMA_F32_PEAK_TFLOPS
+            roof = {"kernel": s["kernel"], "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
+                    "traffic": None, "mfma_products_per_mac": s["mfma_products_per_mac"], "launches_per_step": s["launches"] // 4, "avg_launch_us": round(s["avg_us"], 2),
+                    "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3), "streaming_kernels": km.streaming}
         emit_line({
             "metric": "stereo-pairs/sec encode+decode @512x512; bpp & PSNR delta vs reference",
             "value": round(pairs / elapsed, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -390,7 +483,8 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
                                    f"{H_img}x{W_img} pairs (zero-padded to {x1p.shape[-2]}x{x1p.shape[-1]}, bpp over the original pixels), batch {args.batch}/GPU",
                        "pairs_per_step": world * args.batch, "sharding": f"one (lambda-model, batch) unit per rank and step over {world} GPU(s), no collective on the path",
                        "lambdas": list(SWEEP_LAMBDAS)},
-            "per_lambda": per, "roofline": None, "cpu_baseline": None})
+            "model_tflops": round(pairs * gflop_per_pair(args.model, x1p.shape[-2], x1p.shape[-1]) / elapsed / 1e3, 2),
+            "per_lambda": per, "roofline": roof, "cpu_baseline": None})
     if world > 1:
         dist.destroy_process_group()
 
@@ -534,6 +628,7 @@ def main():
                          "pairs (about 25 s per set) and compare bf16x3 / bf16 / fp32 against the CPU oracle on the trained weights")
     ap.add_argument("--parity-train-steps", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (HESIC+ B=4 and one training step, ~5 s, after the timed region)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (models.GraphedForward) instead of issuing it eagerly")
     ap.add_argument("--exec", dest="exec_mode", choices=["auto", "eager", "graph"], default="auto",
                     help="inference: how the step is issued.  Same kernels, same results; eager issue costs the host ~1.3-1.5 ms per forward "
@@ -705,7 +800,7 @@ def main():
                        "pairs_per_step": world * args.batch, "sharding": f"pairs over {world} GPU(s), no collective on the path",
                        "analysis": (Fn.analysis_precision() if args.dtype != "f32" else "fp32"),
                        "warp_align_corners": bool(geometry.DEFAULT_ALIGN_CORNERS), "issue": picked},
-            "model_tflops": round(pairs * HESIC_GFLOP_PER_PAIR_512 * (x1p.shape[-2] * x1p.shape[-1] / 512 ** 2) / elapsed / 1e3, 2) if args.model == "hsic" else None,
+            "model_tflops": round(pairs * gflop_per_pair(args.model, x1p.shape[-2], x1p.shape[-1]) / elapsed / 1e3, 2),
             "roofline": roof,
             "gpu_metrics_last_batch": {"bpp": round(m_gpu["bpp"], 5), "psnr": round(m_gpu["psnr"], 4)},
         }
@@ -751,6 +846,9 @@ def main():
                                                           log=lambda t: print(t, file=sys.stderr, flush=True))
         else:
             res["cpu_baseline"] = None
+        default_workload = args.model == "hsic" and args.batch == 8 and not (args.height or args.width) and args.size == 512
+        if world == 1 and default_workload and not args.no_secondary:
+            res["secondary"] = secondary_block(dev, lmbda=args.lmbda)
         emit_line(res)
     if world > 1:
         dist.destroy_process_group()

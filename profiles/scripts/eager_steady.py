@@ -7,7 +7,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hesic_amd
 from hesic_amd import models, synthetic
-hesic_amd.set_compute_dtype(torch.bfloat16)
+hesic_amd.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("HESIC_DTYPE", "f16")])
 net = models.HSIC(); synthetic.fill_state_dict_(net.state_dict()); net = net.cuda().eval(); net.update(force=True)
 x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 8, 512, 512))
 with torch.no_grad():
