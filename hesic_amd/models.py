@@ -632,7 +632,7 @@ class HSIC(StereoCompressionModel):
             channels = [int(c) for c in np.nonzero(flag)[0]]
             for _ch, sym, cdf in self._cdf_chunks(gmm, channels, minmax, gauss._bound(), y_hat):
                 enc.encode(sym, cdf)
-        payload = enc.finish()
+        payload = payload_header() + enc.finish()
         with open(out1, "wb") as f:
             f.write(bytes(head))
         with open(out2, "wb") as f:
@@ -665,7 +665,9 @@ class HSIC(StereoCompressionModel):
         y_shape = x_shape // 16
         z_shape = y_shape // 4
         with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
-            dec = RangeDecoder(f.read())
+            payload = f.read()
+        _, off = check_payload(payload)
+        dec = RangeDecoder(payload[off:])
         start = time.time()
         cdt = Fn.compute_dtype()
         size = (int(x_shape[0]), int(x_shape[1]))
@@ -777,6 +779,44 @@ class HSIC(StereoCompressionModel):
 def _nhwc_rows(t):
     """(1, C, H, W) map -> (H * W, C) rows, one per pixel (a view when the map is channels_last)."""
     return t.permute(0, 2, 3, 1).reshape(t.shape[2] * t.shape[3], t.shape[1])
+
+
+# ---- the .bin payload container (this repository's own file: the reference's third-party `range_coder` is absent, DESIGN.md section 7).
+# A payload can only be decoded by a decoder that forms the SAME cumulative-frequency tables, bit for bit: they come out of the
+# hyper-synthesis (and, for view 2, the decoder1 -> warp -> encoder1 pass) run in the encoder's storage format.  Since round 4 every payload
+# starts with 4 magic bytes + one MODE byte naming what the tables depend on; a decoder in another mode raises instead of desynchronising.
+PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
+TABLE_KERNEL_VERSION = 1                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
+
+
+def payload_mode_byte():
+    """bits 0-1: storage format of the maps (0 fp32, 1 bfloat16, 2 float16); bit 2: error-feedback weight rounding on the single-operand
+    analysis launches (the third analysis pass feeds view 2's tables); bit 3: fp32 latents; bits 4-7: table-kernel version."""
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[Fn.compute_dtype()]
+    return dt | (int(bool(Fn.SHAPED_WEIGHTS) and dt != 0) << 2) | (int(bool(Fn.FP32_LATENTS)) << 3) | (TABLE_KERNEL_VERSION << 4)
+
+
+def describe_mode_byte(b):
+    return (f"{('float32', 'bfloat16', 'float16', '?')[b & 3]} maps, error-feedback analysis weights {'on' if b & 4 else 'off'}, "
+            f"fp32 latents {'on' if b & 8 else 'off'}, table kernels v{b >> 4}")
+
+
+def payload_header(extra=b""):
+    return PAYLOAD_MAGIC + bytes([payload_mode_byte()]) + extra
+
+
+def check_payload(payload, n_extra=0):
+    """Validate the container header; returns (extra bytes, offset of the range-coder stream)."""
+    n = len(PAYLOAD_MAGIC)
+    if len(payload) < n + 1 + n_extra or payload[:n] != PAYLOAD_MAGIC:
+        raise ValueError("decompress: the .bin payload does not start with this coder's format-2 header (a file written by rounds 2-3 of "
+                         "this package, or not one of its payloads): re-encode it -- the header names the mode the tables were formed in")
+    mode, here = payload[n], payload_mode_byte()
+    if mode != here:
+        raise ValueError(f"decompress: the payload was written with [{describe_mode_byte(mode)}] but this process decodes with "
+                         f"[{describe_mode_byte(here)}]; the cumulative-frequency tables would differ in the last count and the range decoder "
+                         "would desynchronise.  Select the writer's mode (hesic_amd.set_compute_dtype, HESIC_SHAPED_WEIGHTS, HESIC_BF16_LATENTS)")
+    return payload[n + 1:n + 1 + n_extra], n + 1 + n_extra
 
 
 def _seq3(seq, x, last_act=NONE):
@@ -1004,6 +1044,7 @@ class HSICJoint(StereoCompressionModel):
         return np.split(order.astype(np.int64), cuts)
 
     ORDER_RASTER, ORDER_WAVEFRONT = 0, 1
+    _TABLE_BYTES = 256 << 20           # bound of one batch of cumulative-frequency tables (device buffer + its host copy)
 
     def compress(self, x1, x2, h_matrix, output_name, output_path="", device=None, order="wavefront"):
         """``order``: the sequence in which the pixels' symbols enter the range coder.  "raster" is the reference's (rows, then
@@ -1051,24 +1092,39 @@ class HSICJoint(StereoCompressionModel):
                 if not channels:
                     continue
                 H, W = y_hat.shape[-2:]
-                rows = max(1, (256 << 20) // (len(channels) * W * (2 * minmax + 2) * 4))
-                tabs, syms = [], []
-                for r0 in range(0, H, rows):                     # row blocks keep the device table buffer bounded
-                    r1 = min(H, r0 + rows)
-                    cdf = Fn.gmm_cdf_tables(sc[:, :, r0:r1], mu[:, :, r0:r1], None, channels, minmax, 1, scale_bound=bound)
-                    cdf = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(-1, len(channels), 2 * minmax + 2)
-                    sym = y_hat[0, channels, r0:r1].float().cpu().numpy().astype(np.int64) + minmax
-                    sym = sym.transpose(1, 2, 0).reshape(-1, len(channels)).astype(np.int32)
-                    if order == "raster":
-                        enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf.reshape(-1, 2 * minmax + 2)))
-                    else:
-                        tabs.append(cdf)
-                        syms.append(sym)
-                if order == "wavefront":                         # pixel-major tables of the whole map, re-ordered group by group
-                    perm = np.concatenate(self._wavefronts(H, W))
-                    cdf, sym = np.concatenate(tabs)[perm], np.concatenate(syms)[perm]
-                    enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf.reshape(-1, 2 * minmax + 2)))
-        payload = bytes([self.ORDER_WAVEFRONT if order == "wavefront" else self.ORDER_RASTER]) + enc.finish()
+                n_tab = 2 * minmax + 2
+                if order == "raster":
+                    rows = max(1, self._TABLE_BYTES // (len(channels) * W * n_tab * 4))
+                    for r0 in range(0, H, rows):                     # row blocks keep the table buffers bounded
+                        r1 = min(H, r0 + rows)
+                        cdf = Fn.gmm_cdf_tables(sc[:, :, r0:r1], mu[:, :, r0:r1], None, channels, minmax, 1, scale_bound=bound)
+                        cdf = cdf.cpu().numpy().view(np.uint32).transpose(1, 2, 0, 3).reshape(-1, len(channels), n_tab)
+                        sym = y_hat[0, channels, r0:r1].float().cpu().numpy().astype(np.int64) + minmax
+                        sym = sym.transpose(1, 2, 0).reshape(-1, len(channels)).astype(np.int32)
+                        enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf.reshape(-1, n_tab)))
+                else:
+                    # wavefront order: the pixels enter the coder group by group of equal t = w + 3 h.  Bands of whole groups, each at most
+                    # _TABLE_BYTES of tables: their (scale, mean) rows are gathered on the device, ONE table launch per band (the table
+                    # kernel is element-wise, so the numbers are those of the whole-map evaluation), one host copy -- host memory is
+                    # bounded by the band, whatever the image size or the latent range (round 3 built the whole map's tables at once)
+                    groups = self._wavefronts(H, W)
+                    cap = max(1, self._TABLE_BYTES // (len(channels) * n_tab * 4))
+                    sc_rows, mu_rows, y_rows = _nhwc_rows(sc), _nhwc_rows(mu), _nhwc_rows(y_hat)
+                    ch_t = torch.as_tensor(channels, device=y_hat.device)
+                    g0 = 0
+                    while g0 < len(groups):
+                        g1, P = g0, 0
+                        while g1 < len(groups) and (P == 0 or P + len(groups[g1]) <= cap):
+                            P += len(groups[g1])
+                            g1 += 1
+                        pix = torch.from_numpy(np.concatenate(groups[g0:g1])).to(y_hat.device)
+                        sc_r, mu_r = (t[pix].contiguous().t().reshape(1, self.M, 1, P) for t in (sc_rows, mu_rows))
+                        cdf = Fn.gmm_cdf_tables(sc_r, mu_r, None, channels, minmax, 1, scale_bound=bound)               # (C, 1, P, n)
+                        cdf = cdf.cpu().numpy().view(np.uint32).reshape(len(channels), P, n_tab).transpose(1, 0, 2)       # pixel-major
+                        sym = (y_rows[pix][:, ch_t].float().cpu().numpy().astype(np.int64) + minmax).astype(np.int32)      # (P, C)
+                        enc.encode(sym.reshape(-1), np.ascontiguousarray(cdf).reshape(-1, n_tab))
+                        g0 = g1
+        payload = payload_header(bytes([self.ORDER_WAVEFRONT if order == "wavefront" else self.ORDER_RASTER])) + enc.finish()
         with open(os.path.join(output_path, str(output_name) + ".npz"), "wb") as f:
             f.write(bytes(head))
         with open(os.path.join(output_path, str(output_name) + ".bin"), "wb") as f:
@@ -1101,10 +1157,11 @@ class HSICJoint(StereoCompressionModel):
         size = (int(x_shape[0]), int(x_shape[1]))
         with open(os.path.join(output_path, str(output_name) + ".bin"), "rb") as f:
             payload = f.read()
-        if not payload or payload[0] not in (self.ORDER_RASTER, self.ORDER_WAVEFRONT):
+        extra, off = check_payload(payload, 1)
+        if extra[0] not in (self.ORDER_RASTER, self.ORDER_WAVEFRONT):
             raise ValueError("decompress: not a HESIC+ payload of this coder (unknown pixel-order byte)")
-        wavefront = payload[0] == self.ORDER_WAVEFRONT
-        dec = RangeDecoder(payload[1:])
+        wavefront = extra[0] == self.ORDER_WAVEFRONT
+        dec = RangeDecoder(payload[off:])
         cdt = Fn.compute_dtype()
         bound = self.gaussian_conditional1._bound()
         start = time.time()

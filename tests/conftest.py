@@ -37,3 +37,16 @@ def warp_golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _default_modes_between_tests():
+    """Every test starts from the package defaults: fp32 compute dtype, the bfloat16 library as the active 16-bit format (tests that
+    hand bf16 tensors straight to an operator rely on it), analysis precision "auto" -- whatever the previous test selected."""
+    yield
+    mod = sys.modules.get("hesic_amd.functional")
+    if mod is not None and os.path.exists(os.path.join(ROOT, "hesic_amd", "libhesic_hip.so")):
+        if mod.L.h16_dtype() != torch.bfloat16:
+            mod.set_compute_dtype(torch.bfloat16)
+        mod.set_compute_dtype(torch.float32)
+        mod.set_analysis_precision("auto")
