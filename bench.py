@@ -269,6 +269,11 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0, parity_pairs=1):
                 break
     m = O.metrics(out, x1, x2)
     m["y_hat"] = {k: out[k].to(torch.int16) for k in ("y1_hat", "y2_hat")}      # rounded latents of the sample: the bit-exactness check
+    if kind == "hsic":
+        # the third analysis pass, round(encoder1(warp(x1_hat))) (newnet1.py:753-757): not transmitted, it conditions view 2's entropy
+        # parameters; the product runs it on single 16-bit operands (error-feedback weights), so its flips are reported separately
+        with torch.no_grad():
+            m["y1_hat_w"] = torch.round(O.g_a(P_cpu, "encoder1.", O.warp_perspective(out["x1_hat"], Hm, x1.shape[-2:], True))).to(torch.int16)
     # the other distinct pairs of the timed batch (it tiles four): the parity block reports the set average the reference's own
     # evaluation reports (test3real.py:110-122) next to every pair
     m["more"] = []
@@ -823,6 +828,12 @@ def main():
             dpsnr = abs(sum(q["dpsnr"] for q in per_pair) / len(per_pair))
             bpp_o = sum(q["bpp"] for q in per_pair) / len(per_pair)
             flips = {k: max(q["flips"][k] for q in per_pair) for k in per_pair[0]["flips"]}
+            cond_flips = None
+            if "y1_hat_w" in m_cpu and square and geometry.DEFAULT_ALIGN_CORNERS:
+                with torch.no_grad():
+                    o0 = net(x1[:1], x2[:1], Hm[:1])
+                    yw = net.encoder1.latent(geometry.warp_perspective(o0["x1_hat"], Hm[:1], tuple(x1.shape[-2:])), want_lo=False)[1]
+                cond_flips = round(float((torch.round(yw.float()).cpu().to(torch.int16) != m_cpu["y1_hat_w"]).float().mean()), 6)
             worst_dbpp, worst_dpsnr = max(abs(q["dbpp"]) for q in per_pair), max(abs(q["dpsnr"]) for q in per_pair)
             res["parity"] = {"abs_dbpp": round(dbpp, 6), "rel_dbpp": round(dbpp / bpp_o, 6), "abs_dpsnr_db": round(dpsnr, 6),
                              "pairs": len(per_pair),
@@ -831,6 +842,7 @@ def main():
                              "per_pair_dbpp": [round(q["dbpp"], 6) for q in per_pair], "per_pair_dpsnr_db": [round(q["dpsnr"], 6) for q in per_pair],
                              "bpp_oracle": round(bpp_o, 5), "psnr_oracle": round(sum(q["psnr"] for q in per_pair) / len(per_pair), 4),
                              "latent_flips": {k: round(v, 6) for k, v in flips.items()},
+                             "conditioning_latent_flips_y1_hat_w": cond_flips,
                              "bars": {"latent_flips": 1e-3, "abs_dpsnr_db": 1e-3, "abs_dbpp": 1e-3, "rel_dbpp": 1e-3},
                              "met": {"latent_flips": bool(max(flips.values()) <= 1e-3), "abs_dpsnr_db": bool(dpsnr < 1e-3),
                                      "abs_dbpp": bool(dbpp < 1e-3), "rel_dbpp": bool(dbpp < 1e-3 * bpp_o),
@@ -840,6 +852,8 @@ def main():
                              "note": f"{args.dtype} GPU path vs fp32 CPU oracle on the {len(per_pair)} distinct pair(s) of the timed workload, random-init-shaped "
                                      "weights (bpp ~5.5: the absolute bpp bar is 1.8e-4 RELATIVE here).  abs_* = |mean over the pairs| (the reference "
                                      "reports set averages), latent_flips = the worst pair; pair0 / worst_pair / per_pair_* give every pair; "
+                                     "conditioning_latent_flips_y1_hat_w = pair 0's round(encoder1(warp(x1_hat))) (not transmitted: it conditions view 2's "
+                                     "entropy parameters; single 16-bit operands, no bar of its own -- its effect is inside dbpp); "
                                      "--parity-trained adds trained operating points"}
             if args.parity_trained > 0:
                 res["parity"]["trained"] = trained_parity(args.model, args.parity_trained, args.parity_train_steps, 512, lmbda=args.lmbda,

@@ -492,7 +492,8 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
     // every block ends in 59 atomics per channel on the gradient row, which serialise per address; fewer pixel slices mean fewer
     // contenders but more serial pixels (~2000 flops each) per thread.  Sweep on the 8 x 8 hyper-latents of a training step (us per
     // launch): 128 slices 111 | 64: 76 | 32: 70 | 16: 89 | 8: 147 | 4: 265
-    static const int max_slices = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
+    static const int max_slices_env = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
+    const int max_slices = max_slices_env < 1 ? 1 : max_slices_env;              // 0 / negative would launch an empty grid
     const int64_t slices = (P + EB_PL - 1) / EB_PL;
     const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + 63) / 64), block(64 * EB_PL);
     if (dtype == HESIC_H16)

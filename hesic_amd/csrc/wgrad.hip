@@ -1712,7 +1712,10 @@ static bool setup_bias_part(const hesic_conv_desc* d, WgArgs& a, void* ws) {
     if (off || !wgrad_tr_path(d, a) || a.ntaps < 1) return false;
     if (!d->transposed) { a.nb_taps = 1; a.b_tap[0] = 0; }
     else {
-        if (d->tap_mask_lo || d->pad + d->stride > d->KH || d->pad + d->stride > d->KW) return false;
+        // the tap set {pad + r : r < stride} covers dY only up to H * stride: other geometries (stride > 2, or an output larger than
+        // H * stride, e.g. k = 4, p = 0, s = 2) take the column-sum blocks -- and b_tap holds stride^2 <= 4 entries
+        if (d->tap_mask_lo || d->stride > 2 || d->stride < 1 || d->pad + d->stride > d->KH || d->pad + d->stride > d->KW ||
+            d->Ho > d->H * d->stride || d->Wo > d->W * d->stride) return false;
         for (int ry = 0; ry < d->stride; ++ry)
             for (int rx = 0; rx < d->stride; ++rx) a.b_tap[a.nb_taps++] = (int8_t)((d->pad + ry) * d->KW + d->pad + rx);
         if (a.nb_taps > 4) { a.nb_taps = 0; return false; }
