@@ -269,6 +269,8 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0, parity_pairs=1):
                 break
     m = O.metrics(out, x1, x2)
     m["y_hat"] = {k: out[k].to(torch.int16) for k in ("y1_hat", "y2_hat")}      # rounded latents of the sample: the bit-exactness check
+    if min(x1.shape[-2:]) > 160:
+        m["ms_ssim"] = float((O.ms_ssim(out["x1_hat"], x1)[0] + O.ms_ssim(out["x2_hat"], x2)[0]) / 2)      # test3real.py:107-109
     if kind == "hsic":
         # the third analysis pass, round(encoder1(warp(x1_hat))) (newnet1.py:753-757): not transmitted, it conditions view 2's entropy
         # parameters; the product runs it on single 16-bit operands (error-feedback weights), so its flips are reported separately
@@ -828,7 +830,12 @@ def main():
             dpsnr = abs(sum(q["dpsnr"] for q in per_pair) / len(per_pair))
             bpp_o = sum(q["bpp"] for q in per_pair) / len(per_pair)
             flips = {k: max(q["flips"][k] for q in per_pair) for k in per_pair[0]["flips"]}
-            cond_flips = None
+            cond_flips, dms = None, None
+            if "ms_ssim" in m_cpu and square:
+                with torch.no_grad():
+                    o0 = net(x1[:1], x2[:1], Hm[:1])
+                    ms_gpu = float((models.ms_ssim(o0["x1_hat"], x1[:1])[0] + models.ms_ssim(o0["x2_hat"], x2[:1])[0]) / 2)
+                dms = {"gpu": round(ms_gpu, 7), "oracle": round(m_cpu["ms_ssim"], 7), "abs_diff": float("%.3g" % abs(ms_gpu - m_cpu["ms_ssim"]))}
             if "y1_hat_w" in m_cpu and square and geometry.DEFAULT_ALIGN_CORNERS:
                 with torch.no_grad():
                     o0 = net(x1[:1], x2[:1], Hm[:1])
@@ -843,6 +850,7 @@ def main():
                              "bpp_oracle": round(bpp_o, 5), "psnr_oracle": round(sum(q["psnr"] for q in per_pair) / len(per_pair), 4),
                              "latent_flips": {k: round(v, 6) for k, v in flips.items()},
                              "conditioning_latent_flips_y1_hat_w": cond_flips,
+                             "ms_ssim_pair0": dms,
                              "bars": {"latent_flips": 1e-3, "abs_dpsnr_db": 1e-3, "abs_dbpp": 1e-3, "rel_dbpp": 1e-3},
                              "met": {"latent_flips": bool(max(flips.values()) <= 1e-3), "abs_dpsnr_db": bool(dpsnr < 1e-3),
                                      "abs_dbpp": bool(dbpp < 1e-3), "rel_dbpp": bool(dbpp < 1e-3 * bpp_o),

@@ -1793,7 +1793,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     // of 64 x 64: 331.2 us; 2 = 256 pixels, 4 waves of 64 couts x 128 pixels (25 % fewer fragment bytes per MFMA, one wave per SIMD):
     // 359.0 us -- fragment-read bandwidth is not what bounds the loop, a lone wave per SIMD just loses its latency cover
     static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 0;      // A/B switch, off
-    if (fast && (hilo ? (big_hl && gdn == 3) : big) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
+    if (fast && (hilo ? (big_hl && gdn == 3) : (big && (big < 3 || gdn == 0))) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
         HESIC_CHECK_ARG(d->Cout % g_groups == 0 && (d->Cout / g_groups) % BN == 0 && g_act_split % BN == 0,
@@ -1878,7 +1878,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
         static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
-        if (bm == 256) {
+        if (bm == 256 && !hilo && big >= 3) {
+            // experiment (round 4): 256 pixels x 128 couts, FOUR waves of 64 couts x 128 pixels (128 accumulator registers), 32-channel stages:
+            // 6 DMA pieces and 12 fragment reads per 16 MFMAs instead of 8 and 16, still two blocks per CU (48 / 72 KB of ring)
+            if (big == 3) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 32, 2, 0, 4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 32, 3, 0, 4>), grid, block, 0, st, a);
+        } else if (bm == 256) {
             const dim3 block2(512);
             if (hilo && big_hl == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 4, 0, 1>), grid, block, 0, st, a);     // 4 waves of 64 couts x 128 pixels
             else if (hilo) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, block2, 0, st, a);

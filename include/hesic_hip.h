@@ -500,6 +500,17 @@ int hesic_perspective_transform(const float* src, const float* dst, float* H, in
 int hesic_h_from_delta(const float* corners, const float* delta, float ratio_a, float ratio_b, int subtract_origin,
                        float* H, int B, void* stream);
 
+/* ------------------------------------------------------------------ MS-SSIM (row M: the second published quality metric)
+ * The reference's evaluation reports pytorch_msssim.ms_ssim(x_hat, x, data_range=1, size_average=False) next to PSNR
+ * (ywz/mywork/test3real.py:107-109; third party, absent: algorithm restated, see oracle/hesic_oracle.py::ms_ssim).
+ * hesic_ssim_scale: ONE scale -- for every (image, channel) the SUMS over the valid positions ((H-10) x (W-10)) of the ssim and cs
+ * maps are ADDED to sums[(b*C + c)*2 + {0,1}] (fp64, zeroed by the caller); x / y are fp32 with element strides (b, c, row, col).
+ * hesic_avgpool2_pad: the 2 x 2 average pool between scales (zero padding of odd sides, divisor 4), contiguous fp32 planar output of
+ * ((H + 2 (H%2) - 2)/2 + 1) x ((W + 2 (W%2) - 2)/2 + 1).  The five-scale combination is host arithmetic on B*C*5*2 numbers.      */
+int hesic_ssim_scale(const float* x, const int64_t x_strides[4], const float* y, const int64_t y_strides[4], int B, int C, int H, int W,
+                     float data_range, double* sums, void* stream);
+int hesic_avgpool2_pad(const float* x, const int64_t x_strides[4], float* y, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,9 @@ container (``tests/golden/make_golden.py``).  One exception, stated in
 DESIGN.md: ``warp_perspective`` comes from the third-party ``kornia`` package,
 which is neither vendored in the reference nor installed; its two historical
 semantics are restated from its published definition -> *parity unpinned* for
-that op only.
+that op only.  Likewise ``ms_ssim`` (round 4): ``pytorch_msssim`` is third party,
+absent and unpinned by the reference; its published algorithm is restated here and
+cross-checked against an independent numpy / scipy route (``make_golden.py msssim``).
 
 Reference files are cited as path:line relative to the reference root.
 """
@@ -534,6 +536,49 @@ def metrics(out, x1, x2):
     bpp_loss = sum(bits.values()) / (n * h * w)
     return {"bits": bits, "bpp_loss": bpp_loss, "bpp": bpp_loss / 2, "mse1": mse1, "mse2": mse2,
             "psnr1": psnr1, "psnr2": psnr2, "psnr": (psnr1 + psnr2) / 2}
+
+
+MS_SSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def ms_ssim(x, y, data_range=1.0, win_size=11, win_sigma=1.5, weights=MS_SSIM_WEIGHTS, K=(0.01, 0.03)):
+    """``pytorch_msssim.ms_ssim(X, Y, data_range, size_average=False)`` as the reference's evaluation calls it
+    (ywz/mywork/test3real.py:107-109): per-image multi-scale SSIM (Wang, Simoncelli, Bovik 2003), (N,) tensor.
+    THIRD PARTY, absent and unpinned -> restated from the published algorithm (parity unpinned for this metric):
+    a normalised 11-tap Gaussian (sigma 1.5) applied separably per channel WITHOUT padding; per scale
+    cs = (2 s_xy + C2) / (s_x^2 + s_y^2 + C2), ssim = (2 mu_x mu_y + C1) / (mu_x^2 + mu_y^2 + C1) * cs, averaged over the
+    valid positions per channel; between scales a 2 x 2 average pool (zero padding of the odd sides, divisor always 4);
+    the first four scales contribute relu(cs)^w, the last relu(ssim)^w; product over scales, mean over channels."""
+    if x.shape != y.shape or x.dim() != 4:
+        raise ValueError("ms_ssim: two (N, C, H, W) tensors of the same shape")
+    if min(x.shape[-2:]) <= (win_size - 1) * 2 ** 4:
+        raise ValueError("ms_ssim: the smaller image side must exceed (win_size - 1) * 2^4 = %d" % ((win_size - 1) * 16))
+    x, y = x.double(), y.double()
+    co = torch.arange(win_size, dtype=torch.float32) - win_size // 2
+    g = torch.exp(-(co ** 2) / (2 * win_sigma ** 2))
+    g = (g / g.sum()).double()
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    ch = x.shape[1]
+    wh, wv = g.reshape(1, 1, 1, -1).repeat(ch, 1, 1, 1), g.reshape(1, 1, -1, 1).repeat(ch, 1, 1, 1)
+
+    def blur(t):
+        return F.conv2d(F.conv2d(t, wh, groups=ch), wv, groups=ch)
+
+    vals = []
+    for i in range(len(weights)):
+        mx, my = blur(x), blur(y)
+        sxx, syy, sxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+        cs_map = (2 * sxy + C2) / (sxx + syy + C2)
+        ssim_map = (2 * mx * my + C1) / (mx * mx + my * my + C1) * cs_map
+        if i < len(weights) - 1:
+            vals.append(torch.relu(cs_map.flatten(2).mean(-1)))
+            pad = [s % 2 for s in x.shape[2:]]
+            x, y = F.avg_pool2d(x, 2, padding=pad), F.avg_pool2d(y, 2, padding=pad)
+        else:
+            vals.append(torch.relu(ssim_map.flatten(2).mean(-1)))
+    v = torch.stack(vals, 0)                                        # (levels, N, C)
+    w = torch.tensor(weights, dtype=torch.float64).reshape(-1, 1, 1)
+    return torch.prod(v ** w, 0).mean(1)
 
 
 def aux_loss(P):

@@ -318,6 +318,52 @@ def fx_warp():
     npz("warp.npz", src=src, H=Hs, g=g, **A)
 
 
+def fx_msssim():
+    """MS-SSIM golden.  ``pytorch_msssim`` (what ywz/mywork/test3real.py:107-109 calls) is third party, absent from the reference tree
+    and the image, and unpinned -- like kornia.  The expected values below come from a route INDEPENDENT of oracle/hesic_oracle.py::ms_ssim:
+    fp64 numpy, scipy.ndimage.correlate1d for the Gaussian (cropped to the valid region), reshape-mean for the 2 x 2 pool.  Two routes
+    to the same published algorithm, not a run of the package itself."""
+    import numpy as np
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(20260930)
+    N, C, H, W = 2, 3, 177, 208                      # odd height: exercises the padded pool
+    base = rng.random((N, C, H // 8 + 2, W // 8 + 2))
+    x = np.clip(np.kron(base, np.ones((8, 8)))[:, :, :H, :W] * 0.8 + 0.1 * rng.random((N, C, H, W)), 0, 1).astype(np.float32)
+    y = np.clip(x + rng.normal(0, [[[[0.02]]], [[[0.08]]]], (N, C, H, W)), 0, 1).astype(np.float32)
+    xq, yq = np.round(x * 255).astype(np.uint8), np.round(y * 255).astype(np.uint8)         # 8-bit images: a small fixture
+    x, y = xq.astype(np.float32) / np.float32(255), yq.astype(np.float32) / np.float32(255)
+    co = np.arange(11, dtype=np.float32) - 5
+    g = np.exp(-(co ** 2) / np.float32(2 * 1.5 ** 2)).astype(np.float32)
+    g = (g / g.sum(dtype=np.float32)).astype(np.float64)
+
+    def blur(t):
+        t = correlate1d(correlate1d(t, g, axis=-1, mode="constant"), g, axis=-2, mode="constant")
+        return t[..., 5:-5, 5:-5]
+
+    def pool(t):
+        h, w = t.shape[-2:]
+        t = np.pad(t, ((0, 0), (0, 0), (h % 2, h % 2), (w % 2, w % 2)))       # F.avg_pool2d(padding = s % 2): zeros on both sides
+        h2, w2 = (t.shape[-2] // 2) * 2, (t.shape[-1] // 2) * 2
+        t = t[..., :h2, :w2]
+        return t.reshape(*t.shape[:2], h2 // 2, 2, w2 // 2, 2).mean((3, 5))
+
+    wts = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    a, b = x.astype(np.float64), y.astype(np.float64)
+    out, per_scale = np.ones((N, C)), []
+    for i, wt in enumerate(wts):
+        mx, my = blur(a), blur(b)
+        sxx, syy, sxy = blur(a * a) - mx * mx, blur(b * b) - my * my, blur(a * b) - mx * my
+        cs = (2 * sxy + C2) / (sxx + syy + C2)
+        ss = (2 * mx * my + C1) / (mx * mx + my * my + C1) * cs
+        v = np.maximum((cs if i < 4 else ss).mean((2, 3)), 0)
+        per_scale.append(np.stack([ss.mean((2, 3)), cs.mean((2, 3))], -1))
+        out *= v ** wt
+        if i < 4:
+            a, b = pool(a), pool(b)
+    npz("msssim.npz", x_u8=xq, y_u8=yq, ms_ssim=out.mean(1), per_scale=np.stack(per_scale))      # x = x_u8 / 255 in float32
+
+
 def _run_model(net, size, batch, training, noise_names, nq, tag):
     x1, x2, Hm = synthetic.stereo_batch(0, batch, size, size)
     noises = {}
@@ -823,6 +869,8 @@ def fx_dataset():
 
 def main():
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["msssim"]:           # needs nothing of the reference
+        return fx_msssim()
     newnet1, newnet1_joint = import_reference()
     which = sys.argv[1:] or ["ops", "warp", "models", "models2", "codec", "codec_model", "codec_model_joint", "dataset", "enhance", "homo", "models3"]
     if "ops" in which:

@@ -356,6 +356,41 @@ def test_graphed_forward_replays_the_eager_result():
 
 
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_segmented_forward_replays_the_eager_result(kind, dtype):
+    """The eval forward as a plan of single-stream HIP graphs (``SegmentedForward``: the eager multi-stream schedule, its events
+    replayed as events, every stretch of a stream in between as one graph): bit-identical to the eager forward, also for new inputs
+    copied into the static buffers, also back to back without a host sync in between."""
+    import hesic_amd
+    from hesic_amd import models
+    hesic_amd.set_compute_dtype(dtype)
+    net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
+    synthetic.fill_state_dict_(net.state_dict())
+    net = net.cuda().eval()
+    a = [t.cuda() for t in synthetic.stereo_batch(0, 2, 128, 192)]
+    b = [t.cuda() for t in synthetic.stereo_batch(7, 2, 128, 192)]
+    g = models.SegmentedForward(net, *a)
+    assert 4 <= g.n_graphs <= 40, g.n_graphs
+    for inp in (a, b, a, b):
+        with torch.no_grad():
+            want = net(*inp)
+        got, _ = g(*inp)
+        for k in ("x1_hat", "x2_hat", "y1_hat", "y2_hat"):
+            assert torch.equal(got[k], want[k]), k
+        for k in want["likelihoods"]:
+            assert torch.equal(got["likelihoods"][k], want["likelihoods"][k]), k
+    outs = []
+    for inp in (a, b, a):                  # no synchronisation between replays: the plan's own events order them
+        got, _ = g(*inp)
+        outs.append({k: got[k].clone() for k in ("x2_hat", "y2_hat")})
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        wa, wb = net(*a), net(*b)
+    for o, w in zip(outs, (wa, wb, wa)):
+        assert torch.equal(o["x2_hat"], w["x2_hat"]) and torch.equal(o["y2_hat"], w["y2_hat"])
+
+
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
 def test_graphed_trainer_follows_the_eager_trace(kind):
     """Whole training step (zero_grad -> forward -> R-D backward -> Adam -> aux backward -> aux Adam) captured into a HIP
     graph: with the same injected noise the replayed steps give the eager Trainer's loss trace and parameters."""
