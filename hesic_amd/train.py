@@ -496,3 +496,37 @@ def init_distributed(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+class Stage2Trainer:
+    """Stage 2 of the reference's schedule (ywz/mywork/newtrain6_real.py:120-167): the compression model is FROZEN in eval mode (rounded
+    latents, no noise), the enhancement net ``Independent_EN`` trains on its reconstructions with
+    ``loss = lambda * 255^2 * (MSE(x1_hat', x1) + MSE(x2_hat', x2))`` (:83-91, ``kind=0``) and one Adam over ITS parameters (:287); the
+    bottlenecks' aux loss is computed there but never stepped (:169-171).  The frozen forward runs under ``no_grad`` in whatever 16-bit /
+    fp32 mode is selected for inference; the enhancement net's forward / backward in ``train_dtype`` (bf16 or fp32)."""
+
+    def __init__(self, model, enhancer, lr=1e-4, lmbda=1e-2, train_dtype=None):
+        self.model, self.enhancer, self.lmbda = model, enhancer, float(lmbda)
+        self.train_dtype = train_dtype
+        self.optimizer = MultiTensorAdam(list(enhancer.parameters()), lr=lr) if next(enhancer.parameters()).is_cuda else \
+            torch.optim.Adam(enhancer.parameters(), lr=lr)
+
+    def step(self, x1, x2, h_matrix):
+        self.model.eval()
+        self.enhancer.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            out = self.model(x1, x2, h_matrix)
+        keep = Fn.compute_dtype()
+        if self.train_dtype is not None and self.train_dtype != keep:
+            Fn.set_compute_dtype(self.train_dtype)
+        try:
+            out2 = self.enhancer(out["x1_hat"].float(), out["x2_hat"].float(), h_matrix)
+            mse = ((out2["x1_hat"].float() - x1) ** 2).mean() + ((out2["x2_hat"].float() - x2) ** 2).mean()
+            loss = self.lmbda * 255 ** 2 * mse
+            loss.backward()
+        finally:
+            if Fn.compute_dtype() != keep:
+                Fn.set_compute_dtype(keep)
+        self.optimizer.step()
+        return {"loss": loss.detach(), "mse_loss": mse.detach()}

@@ -634,6 +634,42 @@ def fx_enhance(newnet1):
     npz("en_64.npz", x1_hat=out["x1_hat"], x2_hat=out["x2_hat"])
 
 
+def fx_stage2(newnet1):
+    """Stage-2 training steps as ywz/mywork/newtrain6_real.py:154-167 runs them, recorded from the reference's own modules: HSIC in eval
+    mode (frozen), Independent_EN in train mode, loss = lambda * 255^2 * (MSE(x1_hat', x1) + MSE(x2_hat', x2)) (:83-91, kind=0), Adam on
+    the enhancement net only.  Two steps on two 128 x 128 pairs: loss / mse per step, every parameter's gradient norm of step 0 and the
+    parameter norms after step 1."""
+    hs = newnet1.HSIC()
+    synthetic.fill_state_dict_(hs.state_dict())
+    hs.eval()
+    en = newnet1.Independent_EN()
+    sd = en.state_dict()
+    for name, t in sd.items():
+        fan = t.shape[1] * 9 if t.dim() == 4 else 1
+        a = (3.0 / fan) ** 0.5 if t.dim() == 4 else 0.05
+        t.copy_(synthetic._uniform("en." + name, t.shape, -a, a))
+    en.train()
+    lam = 0.0067
+    opt = torch.optim.Adam(en.parameters(), lr=1e-4)
+    x1, x2, Hm = synthetic.stereo_batch(11, 2, 128, 128)
+    T = {}
+    for step in range(2):
+        opt.zero_grad()
+        out = hs(x1, x2, Hm)
+        out2 = en(out["x1_hat"], out["x2_hat"], Hm)
+        mse = F.mse_loss(out2["x1_hat"], x1) + F.mse_loss(out2["x2_hat"], x2)
+        loss = lam * 255 ** 2 * mse
+        loss.backward()
+        T[f"loss{step}"], T[f"mse{step}"] = float(loss), float(mse)
+        if step == 0:
+            for n_, p_ in en.named_parameters():
+                T["gn_" + n_] = float(p_.grad.double().norm())
+        opt.step()
+    for n_, p_ in en.named_parameters():
+        T["pn_" + n_] = float(p_.detach().double().norm())
+    npz("stage2_128.npz", **T)
+
+
 def fx_homo():
     """HomographyNet forward (ywz/mywork/model.py:73-101) from the reference's own module.  Weights
     and patches are the name-keyed synthetic ones (regenerated by the tests), so only outputs are stored."""
@@ -881,6 +917,8 @@ def main():
         fx_codec()
     if "enhance" in which:
         fx_enhance(newnet1)
+    if "stage2" in which:
+        fx_stage2(newnet1)
     if "homo" in which:
         fx_homo()
     if "models" in which:

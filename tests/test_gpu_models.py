@@ -843,3 +843,39 @@ def test_independent_en_training_gradients_match_oracle_autograd(dtype, tol):
         if rel > tol:
             bad.append((name, rel))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_gn", [(torch.float32, 2e-3, 2e-2), (torch.bfloat16, 3e-2, 0.15)], ids=["f32", "bf16"])
+def test_stage2_trainer_follows_the_reference_steps(dtype, tol_loss, tol_gn):
+    """``train.Stage2Trainer`` (frozen HSIC in eval mode -> Independent_EN trained on lambda * 255^2 * (MSE1 + MSE2), Adam on the
+    enhancement net: ywz/mywork/newtrain6_real.py:154-167) against two steps RECORDED FROM THE REFERENCE's own modules
+    (tests/golden/stage2_128.npz): loss and mse of both steps, every gradient norm of step 0, every parameter norm after step 1."""
+    import hesic_amd
+    from hesic_amd import models
+    from hesic_amd.train import Stage2Trainer
+    from test_oracle_golden import _en_params
+    g = load_golden("stage2_128.npz")
+    hesic_amd.set_compute_dtype(dtype)
+    hs = models.HSIC()
+    synthetic.fill_state_dict_(hs.state_dict())
+    hs = hs.to(DEV)
+    en = models.Independent_EN()
+    en.load_state_dict(_en_params(), strict=True)
+    en = en.to(DEV)
+    tr = Stage2Trainer(hs, en, lr=1e-4, lmbda=0.0067)
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(11, 2, 128, 128))
+    bad = []
+    for step in range(2):
+        c = tr.step(x1, x2, Hm)
+        assert float(c["loss"]) == pytest.approx(float(g[f"loss{step}"]), rel=tol_loss), step
+        assert float(c["mse_loss"]) == pytest.approx(float(g[f"mse{step}"]), rel=tol_loss), step
+        if step == 0:
+            for name, p in en.named_parameters():
+                gn, ref = float(p.grad.double().norm()), float(g["gn_" + name])
+                if abs(gn - ref) > tol_gn * ref:
+                    bad.append((name, gn, ref))
+    assert not bad, bad[:6]
+    for name, p in en.named_parameters():
+        # Adam's first steps move every element by ~lr whatever the gradient's size: bf16 gradients flip a few update signs
+        assert float(p.detach().double().norm()) == pytest.approx(float(g["pn_" + name]), rel=1e-4 if dtype == torch.float32 else 2e-3), name
+    assert not hs.training and all(p.grad is None for p in hs.parameters())          # the compression model stayed frozen

@@ -8,6 +8,7 @@ import torch
 
 from conftest import T, load_golden
 from hesic_amd import synthetic
+import torch.nn.functional as F
 from oracle import hesic_oracle as O
 
 TOL = dict(rtol=2e-5, atol=2e-6)
@@ -275,3 +276,35 @@ def test_independent_en():
         out = O.independent_en(_en_params(), x1, x2, Hm)
     close(out["x1_hat"], g["x1_hat"], 1e-4, 1e-5)
     close(out["x2_hat"], g["x2_hat"], 1e-4, 1e-5)
+
+
+def test_stage2_training_steps_match_the_reference_run():
+    """Two stage-2 steps (ywz/mywork/newtrain6_real.py:154-167: frozen HSIC in eval mode, Independent_EN trained on
+    lambda * 255^2 * (MSE1 + MSE2) with Adam) recorded from the reference's own modules -- ``stage2_128.npz``, made by
+    ``make_golden.py stage2`` -- replayed through the oracle: loss / mse per step, every gradient norm of step 0, every parameter norm
+    after step 1."""
+    g = load_golden("stage2_128.npz")
+    from hesic_amd import models
+    hs = models.HSIC()
+    synthetic.fill_state_dict_(hs.state_dict())
+    P = {k: v.clone() for k, v in hs.state_dict().items()}
+    E = {k: v.clone().requires_grad_(True) for k, v in _en_params().items()}
+    names = [k for k in E]
+    opt = torch.optim.Adam([E[k] for k in names], lr=1e-4)
+    x1, x2, Hm = synthetic.stereo_batch(11, 2, 128, 128)
+    for step in range(2):
+        opt.zero_grad()
+        with torch.no_grad():
+            out = O.hsic_forward(P, x1, x2, Hm)
+        out2 = O.independent_en(E, out["x1_hat"], out["x2_hat"], Hm)
+        mse = F.mse_loss(out2["x1_hat"], x1) + F.mse_loss(out2["x2_hat"], x2)
+        loss = 0.0067 * 255 ** 2 * mse
+        loss.backward()
+        assert float(loss) == pytest.approx(float(g[f"loss{step}"]), rel=2e-4)
+        assert float(mse) == pytest.approx(float(g[f"mse{step}"]), rel=2e-4)
+        if step == 0:
+            for k in names:
+                assert float(E[k].grad.double().norm()) == pytest.approx(float(g["gn_" + k]), rel=2e-3), k
+        opt.step()
+    for k in names:
+        assert float(E[k].detach().double().norm()) == pytest.approx(float(g["pn_" + k]), rel=1e-5), k
