@@ -1762,7 +1762,11 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int qpix = a.QH * a.QW;
         int bm_s = qpix >= 128 ? 128 : (qpix >= 64 ? 64 : 32);
         if (bm_s == 32 && !(BN == 128 && cin_k % 64 == 0)) bm_s = 64;
-        const int64_t nb = count_blocks(bm_s);
+        // Launches whose output feeds round() or a likelihood (the pair layers and every fp32-latent launch) decide the split PER IMAGE: the
+        // slice count fixes the summation order, and a pair's latents must not depend on what else is in the batch (round 4: pair 7 of 8
+        // and the pair alone differed in the last bit of y -- 2 slices against 8 -- which flips a latent per ~3 pairs)
+        const int per_img = (hilo || g_y32) ? a.B : 1;
+        const int64_t nb = count_blocks(bm_s) / per_img;
         const int bk_ = cin_k % 64 == 0 ? 64 : 32;
         const int min_taps = d->transposed ? (d->KH / s) * (d->KW / s) : a.ntaps_live;
         const int min_steps = min_taps * (cin_k / bk_);
@@ -1776,7 +1780,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // measured on MI355X (B=8): it pays when even 32-pixel tiles leave half the CUs idle, or when K is very long;
         // the short K loops of transposed phases and mid-sized maps lose more to the reduce pass than they gain
         const bool one_phase = !d->transposed || s == 1;      // a stride-1 transposed conv (the data gradient of a stride-1 conv) is one phase with the full K loop
-        const bool starved = one_phase && count_blocks(32) < 128;
+        const bool starved = one_phase && count_blocks(32) / per_img < 128;
         // long K on a small map (>= 64 stages: the 192 -> 128 5x5 layer of encode_hyper at 32x32, 75 stages): four K slices on 128-pixel
         // tiles instead of 256 blocks of 32 pixels, 46.6 -> 27.5 + 5 us (round 2; 100 was the round-1 threshold)
         static const int longk_min = getenv("HESIC_IGEMM_LONGK") ? atoi(getenv("HESIC_IGEMM_LONGK")) : 64;      // A/B switch

@@ -26,7 +26,11 @@ __device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t&
 }
 
 // OUT1 = 1: the output leaves as ONE 16-bit value per channel (128 channels per pixel; half the stores) -- for a consumer that multiplies
-// single operands (the "x3c2" analysis mode: g_a_conv2, 70 % of g_a's MACs, at one product per MAC); everything inside the kernel stays hi/lo.
+// single operands (the "x3c2" analysis mode: g_a_conv2, 70 % of g_a's MACs, at one product per MAC).  Its value is then rounded to 2^-12
+// anyway, so the kernel's own arithmetic only needs ~2^-15: the w_lo and gamma'_lo products are dropped (TWO MFMAs per operand pair, 128
+// instead of 192 per tile) -- x and the squares stay pairs, w is rounded with error feedback over the taps (the image is smooth: the
+// weight-rounding error of the sum cancels, see pack_weight_shaped_kernel), gamma' single.  CPU study (precision_study.py schemes, 512^2,
+// g_a_conv2 single): 3.97e-4 flipped latents with the full pair arithmetic here, 4.09e-4 with this form.
 template <int INV, int OUT1>
 __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     constexpr int KS = 5, R = 15, NW = 8;
@@ -133,9 +137,11 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
             ldh(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
+                if constexpr (!OUT1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    wl[i] = *(const h16x8*)(wl_lo + fa(ks) + i * 8192);
+                    for (int i = 0; i < 4; ++i) {
+                        wl[i] = *(const h16x8*)(wl_lo + fa(ks) + i * 8192);
+                    }
                 }
                 if (ks + 1 < 8) ldh((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -144,8 +150,10 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wh[ks & 1][i], fxh, acc[i], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wh[ks & 1][i], fxl, acc[i], 0, 0, 0);
+                if constexpr (!OUT1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wl[i], fxh, acc[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16_h16(wl[i], fxh, acc[i], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -179,9 +187,11 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
             prep(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
+                if constexpr (!OUT1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    gl[i] = *(const h16x8*)(gl_lo + fa(ks) + i * 8192);
+                    for (int i = 0; i < 4; ++i) {
+                        gl[i] = *(const h16x8*)(gl_lo + fa(ks) + i * 8192);
+                    }
                 }
                 if (ks + 1 < 8) prep((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -189,8 +199,10 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][1], nrm[i], 0, 0, 0);
+                if constexpr (!OUT1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gl[i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gl[i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -251,7 +263,9 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
 //   conv:   row co, slot r = ci*5 + ky (r < 15) at position r ^ (co & 15), 8 values = kx 0..4, 0, 0, 0
 //   gamma': row i (output channel), slot q = 2 ks + h at position q ^ (i & 15), 8 values = gamma'[i][16 ks + 4 h + 0..3],
 //           gamma'[i][16 ks + 8 + 4 h + 0..3] -- the order in which a lane of the GDN contraction holds its squares
-__global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img) {
+// ``shaped``: the hi half of a conv weight is its 16-bit rounding WITH error feedback over the 25 taps of its (cout, cin) pair (serpentine
+// walk, as pack_weight_shaped_kernel) -- for the two-product form of the kernel (OUT1), which multiplies w_hi only.
+__global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img, int shaped) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 4096) return;
     float v[8];
@@ -261,6 +275,19 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
         const int r = idx & 15, ci = r / 5, ky = r % 5;
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((row * 3 + ci) * 5 + ky) * 5 + kx] : 0.f;
+        if (shaped && r < 15) {
+            // replay the walk of this (cout, cin) pair up to row ky: the error carried into it, then this row's five values
+            const float* src = w + (row * 3 + ci) * 25;
+            float e = 0.f;
+            for (int yy = 0; yy <= ky; ++yy)
+                for (int j = 0; j < 5; ++j) {
+                    const int kx = (yy & 1) ? 4 - j : j;
+                    const float tgt = src[yy * 5 + kx] + e;
+                    const float q = h2f(f2h(tgt));
+                    e = tgt - q;
+                    if (yy == ky) v[kx] = q;
+                }
+        }
         pos = r ^ (row & 15);
     } else {
         const int j = idx - 2048, q = j & 15, ks = q >> 1, h = q & 1;
@@ -286,8 +313,14 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
 
 extern "C" int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image, void* stream) {
     HESIC_CHECK_ARG(w && gamma && image, "sconv_pack_weight_image_hilo: null pointer");
-    hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image);
+    hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image, 0);
     HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo");
+}
+
+extern "C" int hesic_sconv_pack_weight_image_hilo_out1(const float* w, const float* gamma, void* image, void* stream) {
+    HESIC_CHECK_ARG(w && gamma && image, "sconv_pack_weight_image_hilo_out1: null pointer");
+    hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image, 1);
+    HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo_out1");
 }
 
 static int n2w_gdn_hilo_launch(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,

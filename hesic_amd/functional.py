@@ -909,15 +909,18 @@ class PackedN2wHiLo:
     """LDS images [w_hi | w_lo | gamma'_hi | gamma'_lo] (128 KB) of the fused hi/lo g_a_conv1 + GDN kernel; inference cache."""
 
     def __init__(self):
-        self._hit = None
+        self._hit = {}
 
-    def get(self, weight, gamma):
+    def get(self, weight, gamma, out1=False):
+        """``out1``: the image of the kernel's single-output form (w rounded with error feedback over the taps, lo halves unused)."""
         tag = (weight.data_ptr(), weight._version, gamma.data_ptr(), gamma._version, _cache_epoch)
-        if self._hit is not None and self._hit[0] == tag:
-            return self._hit[1]
+        hit = self._hit.get(out1)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
         img = torch.empty(128 * 1024, dtype=torch.uint8, device=weight.device)
-        L.call("hesic_sconv_pack_weight_image_hilo", L.ptr(_c(weight)), L.ptr(_c(gamma)), L.ptr(img), L.stream())
-        self._hit = (tag, img)
+        L.call("hesic_sconv_pack_weight_image_hilo_out1" if out1 else "hesic_sconv_pack_weight_image_hilo", L.ptr(_c(weight)), L.ptr(_c(gamma)),
+               L.ptr(img), L.stream())
+        self._hit[out1] = (tag, img)
         return img
 
 

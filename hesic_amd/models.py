@@ -331,7 +331,7 @@ class Encoder1(nn.Module):
         if fused1 and Fn.analysis_conv2_single() and self.g_a_conv2.weight.shape[:2] == (128, 128):
             # "x3c2": conv1 + GDN on pairs inside the kernel, ONE 16-bit value per channel out; g_a_conv2 multiplies single operands,
             # its GDN runs on pairs again and hands pairs to g_a_conv3
-            t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse, out1=True)
+            t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma, out1=True), c1.bias, bp, g1.inverse, out1=True)
             t = self.g_a_conv2.run_gdn_hilo_out(t, self.g_a_gdn2)
             t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3)
             if not want_lo:

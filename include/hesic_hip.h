@@ -220,8 +220,11 @@ typedef struct {
 int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image_hilo, void* stream);
 int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
                                    const float* beta_packed, int inverse, void* y_hilo, void* stream);
-/* Same kernel, same pair arithmetic inside, but y leaves as ONE 16-bit value per channel (128 channels, ys_x >= 128): the input of
- * a one-product layer (hesic_conv2d_gdn_forward_hilo_out).                                                                       */
+/* The same kernel for a one-product consumer (hesic_conv2d_gdn_forward_hilo_out): y leaves as ONE 16-bit value per channel (128
+ * channels, ys_x >= 128).  Its rounding (2^-12) bounds what the arithmetic in front of it must deliver, so this form multiplies two
+ * products per operand pair -- x and the squares as pairs, w and gamma' single -- with w rounded by error feedback over the taps:
+ * image_hilo must come from hesic_sconv_pack_weight_image_hilo_out1 (same 128 KB layout; its lo halves are not read).               */
+int hesic_sconv_pack_weight_image_hilo_out1(const float* w, const float* gamma, void* image_hilo, void* stream);
 int hesic_sconv2d_gdn_forward_hilo_out1(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
                                         const float* beta_packed, int inverse, void* y, void* stream);
 

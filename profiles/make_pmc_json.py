@@ -53,12 +53,15 @@ def main():
             m["launches"] += v["launches"]
             m["bytes"] += v["hbm_bytes_per_launch"] * v["launches"]
             continue
-        name = f"igemm_glds_kernel<{p[0]},{p[1]},{p[2]}{',gdn' if p[4] != '0' else ''}>" + (" hilo" if len(p) > 7 and p[7] == "1" else "")
+        hl = len(p) > 7 and p[7] == "1"
+        name = f"igemm_glds_kernel<{p[0]},{p[1]},{p[2]}{',gdn' if p[4] != '0' else ''}>" + (" hilo" if hl else (" hilo-gdn-out" if p[4] in ("3", "4") else ""))
         m = merged.setdefault(name, {"launches": 0, "bytes": 0.0})
         m["launches"] += v["launches"]
         m["bytes"] += v["hbm_bytes_per_launch"] * v["launches"]
     out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_igemm.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    data["_commit"] = os.environ.get("PMC_COMMIT", data.get("_commit"))
+    data["_collected"] = os.environ.get("PMC_COLLECTED", data.get("_collected"))
     data[key] = {"per_kernel": {k: {"launches": v["launches"], "hbm_bytes_per_launch": round(v["bytes"] / v["launches"])} for k, v in merged.items()},
                  "raw_instantiations": res,
                  "note": "FETCH_SIZE x2 (gfx950 128-B request correction) + WRITE_SIZE, KiB -> bytes; fabric-side, includes Infinity-Cache hits"}
