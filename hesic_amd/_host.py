@@ -166,6 +166,14 @@ class RangeDecoder:
             raise ValueError("RangeDecoder.decode: bad table")
         return out
 
+    def decode_grid_raw(self, cdf_ptr, stride, n_outer, n_inner, row_step_outer, row_step_inner, out_ptr):
+        """``decode_grid`` on raw host addresses (table rows of ``stride`` uint32 at ``cdf_ptr``, int32 symbols to ``out_ptr``): no numpy
+        objects per call -- the HESIC+ wavefront decode calls this once per group."""
+        rc = lib().hesic_rc_decoder_decode_grid(self._h, C.cast(cdf_ptr, C.POINTER(C.c_uint32)), n_outer, n_inner, row_step_outer, row_step_inner,
+                                                stride, C.cast(out_ptr, _pi32))
+        if rc:
+            raise ValueError("RangeDecoder.decode_grid: bad table")
+
     def decode_grid(self, cdf, n_outer, n_inner, row_step_outer, row_step_inner):
         """Symbols (p, q), p outer, under table row ``p * row_step_outer + q * row_step_inner`` of ``cdf`` (rows, n): (n_outer, n_inner) int32."""
         import numpy as np

@@ -73,6 +73,9 @@ _SIGS = {
     "hesic_h16_format": ([], _i32),
     "hesic_last_error": ([], C.c_char_p),
     "hesic_pack_conv_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_joint_step": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp], _i32),
+    "hesic_memcpy_async": ([_vp, _vp, C.c_size_t, _i32, _vp], _i32),
+    "hesic_stream_synchronize": ([_vp], _i32),
     "hesic_ssim_scale": ([_vp, _P(_i64), _vp, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_avgpool2_pad": ([_vp, _P(_i64), _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_shaped": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),

@@ -319,6 +319,18 @@ __device__ float np_pairwise_sum(const float* a, int n) {
     return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
 
+// clipped pmf of symbol s under the row's mixture: ONE definition for both table kernels (their tables must agree bit for bit: an
+// encoder may take one and a decoder the other only if both evaluate the same expression)
+template <int DUMMY = 0>
+__device__ __forceinline__ float cdf_pm(int s, const float* mu, const float* sg, const float* wk, int K) {
+    float pm = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float a = fabsf((float)s - mu[k]);
+        pm += (phi_cdf((0.5f - a) / sg[k]) - phi_cdf((-0.5f - a) / sg[k])) * wk[k];
+    }
+    return fminf(fmaxf(pm, 1.0f / 65536.0f), 1.0f);
+}
+
 template <typename T>
 __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
                                const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
@@ -337,14 +349,7 @@ __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restric
         }
         uint32_t* row = cdf + i * (A + 1);
         float* frow = (float*)(row + 1);
-        for (int s = 0; s < A; ++s) {
-            float pm = 0.f;
-            for (int k = 0; k < d.K; ++k) {
-                const float a = fabsf((float)s - mu[k]);
-                pm += (phi_cdf((0.5f - a) / sg[k]) - phi_cdf((-0.5f - a) / sg[k])) * wk[k];
-            }
-            frow[s] = fminf(fmaxf(pm, 1.0f / 65536.0f), 1.0f);
-        }
+        for (int s = 0; s < A; ++s) frow[s] = cdf_pm(s, mu, sg, wk, d.K);
         const float tot = np_pairwise_sum(frow, A);
         float run = 0.f;
         row[0] = 0u;
@@ -352,6 +357,54 @@ __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restric
             run += rintf(frow[s] / tot * 65536.0f);
             row[s + 1] = (uint32_t)run;
         }
+    }
+}
+
+// The same tables, one WAVE per row (alphabets up to CDF_WAVE_MAX symbols; round 4): the 2 A error-function evaluations of a row -- the
+// whole cost -- spread over the lanes, the clipped pmf staged in LDS, its sum taken by numpy's pairwise order on that array (every lane
+// redundantly: LDS broadcasts), the cumulative counts by a wave scan (integer-valued floats below 2^24: any order is exact).  One thread
+// per row took 15 us for the 2112 rows of a HESIC+ wavefront group (a latency-bound loop of ~40 symbols x 2 erfc); this form ~4 us.
+constexpr int CDF_WAVE_MAX = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void gmm_cdf_wave_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
+                                                           const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
+                                                           uint32_t* __restrict__ cdf) {
+    __shared__ float buf[4][CDF_WAVE_MAX];
+    const int A = 2 * minmax + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* frow = buf[wave];
+    const int64_t total = (int64_t)n_ch * d.HW;
+    for (int64_t i = blockIdx.x * 4ll + wave; i < total; i += (int64_t)gridDim.x * 4) {
+        const int hw = i % d.HW, j = i / d.HW;
+        const int m = channels[j];
+        const int64_t sm = ((int64_t)b * d.HW + hw) * d.sm_pix_stride + m;
+        float mu[GMM_MAXK], sg[GMM_MAXK], wk[GMM_MAXK];
+        for (int k = 0; k < d.K; ++k) {
+            mu[k] = elem<T>::ld(means + sm + d.m_c_off + k * d.M) + (float)minmax;
+            sg[k] = fmaxf(elem<T>::ld(scales + sm + d.s_c_off + k * d.M), d.scale_bound);
+            wk[k] = weights ? weights[(int64_t)b * d.K * d.M + k * d.M + m] : 1.f;
+        }
+        for (int s = lane; s < A; s += 64) frow[s] = cdf_pm(s, mu, sg, wk, d.K);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float tot = np_pairwise_sum(frow, A);
+        uint32_t* row = cdf + i * (A + 1);
+        if (lane == 0) row[0] = 0u;
+        float carry = 0.f;
+        for (int s0 = 0; s0 < A; s0 += 64) {
+            const int s = s0 + lane;
+            float v = s < A ? rintf(frow[s] / tot * 65536.0f) : 0.f;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float u = __shfl_up(v, o, 64);
+                if (lane >= o) v += u;
+            }
+            v += carry;
+            if (s < A) row[s + 1] = (uint32_t)v;
+            carry = __shfl(v, 63, 64);
+        }
+        __builtin_amdgcn_wave_barrier();          // the row buffer is rewritten by the next trip
     }
 }
 
@@ -616,6 +669,17 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
                     "gmm_cdf: bad arguments");
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf: weights required for K > 1");
     const int64_t total = (int64_t)n_channels * d->HW;
+    static const bool thread_rows = getenv("HESIC_CDF_THREAD_ROWS") != nullptr;          // A/B switch: the one-thread-per-row kernel for every alphabet
+    if (2 * minmax + 1 <= CDF_WAVE_MAX && !thread_rows) {
+        const dim3 gw(grid_for(total, 4, 256 * 16));
+        if (d->dtype == HESIC_H16)
+            hipLaunchKernelGGL(gmm_cdf_wave_kernel<h16_t>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales, (const h16_t*)means, weights,
+                               channels, n_channels, minmax, cdf);
+        else
+            hipLaunchKernelGGL(gmm_cdf_wave_kernel<float>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const float*)scales, (const float*)means, weights,
+                               channels, n_channels, minmax, cdf);
+        HESIC_LAUNCH_RETURN("gmm_cdf");
+    }
     const dim3 grid(grid_for(total, 128));
     if (d->dtype == HESIC_H16)
         hipLaunchKernelGGL(gmm_cdf_kernel<h16_t>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales,

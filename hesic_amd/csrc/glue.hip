@@ -740,3 +740,86 @@ extern "C" int hesic_im2col_hilo(const float* x, const int64_t x_strides[4], int
                        x_strides[2], x_strides[3], B, C, H, W, KH, KW, stride, pad, Ho, Wo, KP, (h16_t*)cols);
     HESIC_LAUNCH_RETURN("im2col_hilo");
 }
+
+// ---- HESIC+ wavefront decode (ywz/mywork/newnet1_joint.py:1190-1260 walks the map pixel by pixel; models.HSICJoint.decompress walks it
+// group by group of mutually independent pixels, t = w + 3h).  The device work of one group is a HIP graph replayed per step; this kernel
+// opens it and is what makes the graph step-independent: every per-step quantity (position in the index tables, the previous group's
+// size and rows) lives in device memory.  ONE block (a group is <= ~W/3 pixels: ~100 KB to move), so the phases order themselves with
+// block barriers:
+//   1. the symbols the host decoded for the PREVIOUS group (sym: [nprev][C] int32 pixel-major, copied up in front of the replay) go
+//      into the padded latent map as values sym - minmax in the map's storage type;
+//   2. this group's P pixels at offset *pos of the whole-map tables: their 5 x 5 crops of the padded map -> crops[P][25][M] (the masked
+//      conv's input batch), their hyper-decoder rows par[row] -> feat[p][0, c_par), view 2's extra rows ext[row] -> feat[p][e_off, +M)
+//      (the masked conv writes its own slice of feat in between, the 1x1 entropy-parameter net reads feat);
+//   3. *pos += P, state[0] = P, prev_centre = this group's padded rows.
+// state = {nprev, C, minmax}; channels = the C coded channels (header bitmap); both filled by the host once per view.  P == 0: phase 1 only.
+namespace {
+struct JointStep {
+    unsigned char* y_rows; int es, M, Wp;
+    const int32_t* sym; int64_t* prev_centre; int32_t* state; const int32_t* channels;
+    const int64_t* all_centre; const int64_t* all_rows; int64_t* pos; int P, dtype;
+    unsigned char* crops; const unsigned char* par; int c_par; const unsigned char* ext; int e_off; unsigned char* feat; int c_feat;
+};
+__global__ __launch_bounds__(1024) void joint_step_kernel(const JointStep a) {
+    const int tid = threadIdx.x;
+    const int nprev = a.state[0], C = a.state[1], minmax = a.state[2];
+    const int64_t p0 = *a.pos;
+    for (int i = tid; i < nprev * C; i += 1024) {
+        const int p = i / C, c = i - p * C;
+        st_any(a.y_rows, a.prev_centre[p] * a.M + a.channels[c], a.dtype, (float)(a.sym[i] - minmax));
+    }
+    __threadfence();
+    __syncthreads();
+    const int rch = a.M * a.es / 16;                                  // 16-byte chunks per map row
+    for (int i = tid; i < a.P * 25 * rch; i += 1024) {
+        const int r = i / rch, c = i - r * rch, p = r / 25, t = r - p * 25;
+        const int64_t src = a.all_centre[p0 + p] + (t / 5 - 2) * a.Wp + (t % 5 - 2);
+        ((u32x4*)a.crops)[i] = ((const u32x4*)(a.y_rows + src * a.M * a.es))[c];
+    }
+    const int pch = a.c_par * a.es / 16, fch = a.c_feat * a.es / 16;
+    for (int i = tid; i < a.P * pch; i += 1024) {
+        const int p = i / pch, c = i - p * pch;
+        ((u32x4*)a.feat)[p * fch + c] = ((const u32x4*)(a.par + a.all_rows[p0 + p] * a.c_par * a.es))[c];
+    }
+    if (a.ext)
+        for (int i = tid; i < a.P * rch; i += 1024) {
+            const int p = i / rch, c = i - p * rch;
+            ((u32x4*)a.feat)[p * fch + a.e_off * a.es / 16 + c] = ((const u32x4*)(a.ext + a.all_rows[p0 + p] * a.M * a.es))[c];
+        }
+    __syncthreads();                                                  // every thread has read the previous group's rows and *pos
+    if (tid < a.P) a.prev_centre[tid] = a.all_centre[p0 + tid];
+    if (tid == 0) { *a.pos = p0 + a.P; a.state[0] = a.P; }
+}
+}  // namespace
+
+extern "C" int hesic_joint_step(void* y_rows, int dtype, int M, int Wp, const int32_t* sym, int64_t* prev_centre, int32_t* state,
+                                const int32_t* channels, const int64_t* all_centre, const int64_t* all_rows, int64_t* pos, int P, void* crops,
+                                const void* par, int c_par, const void* ext, int e_off, void* feat, int c_feat, void* stream) {
+    HESIC_CHECK_ARG(y_rows && sym && prev_centre && state && channels && pos && M > 0 && P >= 0 && P <= 1024, "joint_step: bad arguments");
+    HESIC_CHECK_ARG(dtype == HESIC_H16 || dtype == HESIC_F32, "joint_step: bad dtype");
+    const int es = dtype == HESIC_H16 ? 2 : 4;
+    HESIC_CHECK_ARG(P == 0 || (all_centre && all_rows && crops && par && feat && (M * es) % 16 == 0 && (c_par * es) % 16 == 0 && (c_feat * es) % 16 == 0 &&
+                               (e_off * es) % 16 == 0 && c_par <= c_feat && (!ext || e_off + M <= c_feat)),
+                    "joint_step: rows must be whole 16-byte chunks and the feature slices must fit");
+    JointStep a;
+    a.y_rows = (unsigned char*)y_rows; a.es = es; a.M = M; a.Wp = Wp; a.sym = sym; a.prev_centre = prev_centre; a.state = state; a.channels = channels;
+    a.all_centre = all_centre; a.all_rows = all_rows; a.pos = pos; a.P = P; a.dtype = dtype; a.crops = (unsigned char*)crops;
+    a.par = (const unsigned char*)par; a.c_par = c_par; a.ext = (const unsigned char*)ext; a.e_off = e_off; a.feat = (unsigned char*)feat; a.c_feat = c_feat;
+    hipLaunchKernelGGL(joint_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("joint_step");
+}
+
+// Plain copies / a stream wait for host loops that sit between launches (the HESIC+ wavefront decode makes ~750 of them per pair): the
+// torch route costs ~10 us of dispatcher per call.  kind: 1 = host -> device, 2 = device -> host (pinned host memory for async behaviour).
+extern "C" int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream) {
+    HESIC_CHECK_ARG(dst && src && (kind == 1 || kind == 2), "memcpy_async: bad arguments");
+    if (bytes == 0) return 0;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) { hesic_set_error("memcpy_async: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+extern "C" int hesic_stream_synchronize(void* stream) {
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { hesic_set_error("stream_synchronize: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}

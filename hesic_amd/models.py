@@ -859,8 +859,9 @@ def _nhwc_rows(t):
 # A payload can only be decoded by a decoder that forms the SAME cumulative-frequency tables, bit for bit: they come out of the
 # hyper-synthesis (and, for view 2, the decoder1 -> warp -> encoder1 pass) run in the encoder's storage format.  Since round 4 every payload
 # starts with 4 magic bytes + one MODE byte naming what the tables depend on; a decoder in another mode raises instead of desynchronising.
+WAVEFRONT_GRAPHS = _os.environ.get("HESIC_WAVEFRONT_GRAPHS", "1") != "0"      # A/B switch: 0 = round 3's per-group launches from Python
 PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
-TABLE_KERNEL_VERSION = 1                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
+TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
 
 
 def payload_mode_byte():
@@ -1206,6 +1207,124 @@ class HSICJoint(StereoCompressionModel):
         return {"bpp_real": (len(head) + len(payload)) * 8 / num_pixels, "bpp_side": len(head) * 8 / num_pixels,
                 "enctime": time.time() - start, "y1_hat": y1_hat, "y2_hat": y2_hat, "z1_hat": z1_hat, "z2_hat": z2_hat}
 
+    # ---- wavefront decode with the device work of a group as a replayed HIP graph (round 4).  Round 3 issued every group's ~15 device
+    # operations from Python (gathers, masked conv, cat, 1x1 net, layout copies, table kernel: ~270 us per group, 250 groups per 512^2
+    # pair = 0.067 s).  Here the state of the walk lives on the device (csrc/glue.hip: hesic_joint_step -- position in the index tables,
+    # the previous group's symbols and rows, the crop / feature gathers in one block), so ONE five-node graph per group size (joint_step,
+    # masked conv into its slice of the feature rows, three 1x1 layers) serves every step of every image of that size; the host's share of
+    # a step is: copy the previous symbols up, replay, launch the table kernel (its width depends on the image's latent range; it reads
+    # (scale, mean) straight from the net's fp32 output rows), copy the tables down, range-decode.  Graphs and their static buffers are
+    # cached on the module per (view, map size, format, weights).
+    def _wavefront_state(self, which, yh, yw, dev):
+        import numpy as np
+        cdt = Fn.compute_dtype()
+        ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
+        ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
+        tag = (Fn._cache_epoch, cdt) + tuple((p_.data_ptr(), p_._version) for p_ in list(ctx_m.parameters()) + list(ep.parameters()))
+        cache = self.__dict__.setdefault("_wf_cache", {})
+        key = (which, yh, yw, dev.index)
+        st = cache.get(key)
+        if st is not None and st["tag"] == tag:
+            return st
+        if not hasattr(ctx_m, "_packer"):
+            ctx_m._packer = Fn.PackedWeight()
+        M, Wp = self.M, yw + 4
+        groups = self._wavefronts(yh, yw)
+        pmax = max(len(g) for g in groups)
+        all_pix = np.concatenate(groups)
+        centre = (all_pix // yw + 2) * Wp + (all_pix % yw) + 2
+        c_par = (self.h_s1 if which == 1 else self.h_s2)[4].out_channels
+        c_feat = c_par + ctx_m.out_channels + (M if which == 2 else 0)
+        st = {"tag": tag, "groups": [len(g) for g in groups], "pmax": pmax, "ctx_m": ctx_m, "ep": ep, "graphs": {}, "Wp": Wp,
+              "c_par": c_par, "c_feat": c_feat, "e_off": c_par + ctx_m.out_channels,
+              "y_pad": torch.zeros((1, M, yh + 4, Wp), dtype=cdt, device=dev).contiguous(memory_format=torch.channels_last),
+              "par": torch.zeros((yh * yw, c_par), dtype=cdt, device=dev),
+              "ext": torch.zeros((yh * yw, M), dtype=cdt, device=dev) if which == 2 else None,
+              "all_centre": torch.from_numpy(centre.astype(np.int64)).to(dev), "all_rows": torch.from_numpy(all_pix.astype(np.int64)).to(dev),
+              "pos": torch.zeros(1, dtype=torch.int64, device=dev), "state": torch.zeros(3, dtype=torch.int32, device=dev),
+              "channels": torch.zeros(M, dtype=torch.int32, device=dev), "sym": torch.zeros(pmax * M, dtype=torch.int32, device=dev),
+              "prev_centre": torch.zeros(pmax, dtype=torch.int64, device=dev),
+              "crops": torch.zeros((pmax, 5, 5, M), dtype=cdt, device=dev), "feat": torch.zeros((pmax, c_feat), dtype=cdt, device=dev),
+              "sym_pin": torch.zeros(pmax * M, dtype=torch.int32).pin_memory()}
+        st["y_flat"] = st["y_pad"].permute(0, 2, 3, 1).reshape((yh + 4) * Wp, M)
+        cache[key] = st
+        return st
+
+    def _wavefront_kernel(self, st, P):
+        L.call("hesic_joint_step", L.ptr(st["y_flat"]), L.dt(st["y_flat"]), self.M, st["Wp"], L.ptr(st["sym"]), L.ptr(st["prev_centre"]), L.ptr(st["state"]),
+               L.ptr(st["channels"]), L.ptr(st["all_centre"]), L.ptr(st["all_rows"]), L.ptr(st["pos"]), int(P), L.ptr(st["crops"]), L.ptr(st["par"]),
+               st["c_par"], L.ptr(st["ext"]), st["e_off"], L.ptr(st["feat"]), st["c_feat"], L.stream())
+
+    def _wavefront_step_body(self, st, P):
+        """The device work of one group of P pixels up to the fp32 (scale | mean) rows of the entropy-parameter net -- five launches,
+        what a graph of size P replays."""
+        self._wavefront_kernel(st, P)
+        ctx_m = st["ctx_m"]
+        crops = st["crops"][:P].permute(0, 3, 1, 2)                                                        # (P, M, 5, 5), NHWC in memory
+        feat = st["feat"][:P].view(P, st["c_feat"], 1, 1)
+        Fn.conv2d_into(crops, ctx_m.weight, ctx_m.bias, feat, st["c_par"], kernel_size=5, stride=1, padding=0, mask=ctx_m.mask,
+                       tap_mask=ctx_m._tap_mask, packer=ctx_m._packer)
+        return _seq3_hi(st["ep"], feat)                                                                    # (P, 2M, 1, 1) fp32: row p = [scales(M) | means(M)]
+
+    def _wavefront_graph(self, st, P):
+        ent = st["graphs"].get(P)
+        if ent is None:
+            keep = {k: st[k].clone() for k in ("pos", "state", "prev_centre", "y_pad")}
+            side = torch.cuda.Stream(device=st["pos"].device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up off the default stream (packs weights, loads kernels); state restored below
+                for _ in range(2):
+                    self._wavefront_step_body(st, P)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._wavefront_step_body(st, P)
+            for k, v in keep.items():
+                st[k].copy_(v)
+            ent = st["graphs"][P] = (g, out)
+        return ent
+
+    def _decode_view_graphed(self, dec, which, params, minmax, channels, extra, yh, yw, bound):
+        import ctypes as C
+        import numpy as np
+        dev = params.device
+        st = self._wavefront_state(which, yh, yw, dev)
+        M, Cn, n_tab = self.M, len(channels), 2 * minmax + 2
+        for P in sorted(set(st["groups"])):                    # first use of a map size: capture (cached on the module)
+            self._wavefront_graph(st, P)
+        st["y_pad"].zero_()
+        st["par"].copy_(_nhwc_rows(params))
+        if extra is not None:
+            st["ext"].copy_(_nhwc_rows(extra))
+        st["pos"].zero_()
+        st["state"].copy_(torch.tensor([0, Cn, minmax], dtype=torch.int32))
+        st["channels"][:Cn].copy_(torch.tensor(channels, dtype=torch.int32))
+        ch_dev = st["channels"][:Cn]
+        pmax = st["pmax"]
+        tab_dev = torch.empty((Cn * pmax, n_tab), dtype=torch.int32, device=dev)
+        tab_pin = torch.empty((Cn * pmax, n_tab), dtype=torch.int32).pin_memory()
+        descs = {P: L.GmmDesc(1, P, M, 1, L.F32, 0, 2 * M, 0, M, float(bound), 0.0) for P in set(st["groups"])}
+        # raw addresses once; per step: copy the previous symbols up, replay, table launch, copy the tables down, wait, decode
+        stream = L.stream()
+        sym_dev, sym_host = L.ptr(st["sym"]), C.c_void_p(st["sym_pin"].data_ptr())
+        tab_d, tab_h = L.ptr(tab_dev), C.c_void_p(tab_pin.data_ptr())
+        ch_p, call, raw = L.ptr(ch_dev), L.call, dec.decode_grid_raw
+        nprev = 0
+        for P in st["groups"]:
+            if nprev:
+                call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
+            g, sm = st["graphs"][P]
+            g.replay()
+            smp = L.ptr(sm)
+            call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
+            call("hesic_memcpy_async", tab_h, tab_d, Cn * P * n_tab * 4, 2, stream)
+            call("hesic_stream_synchronize", stream)
+            raw(tab_h, n_tab, P, Cn, 1, P, sym_host)                                             # (P, Cn) symbols, pixel-major, into the pinned buffer
+            nprev = P
+        call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
+        self._wavefront_kernel(st, 0)                              # the last group's symbols
+        return st["y_pad"][:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
+
     def decompress(self, x1, x2, h_matrix, output_name, output_path="", device=None):
         """x1 / x2 are unused (the header carries the size); kept for the reference's signature."""
         import os
@@ -1255,6 +1374,8 @@ class HSICJoint(StereoCompressionModel):
                         sym = dec.decode(cdf.cpu().numpy().view(np.uint32).reshape(len(channels), -1))
                         y_pad[0, ch_t, h + 2, w + 2] = torch.from_numpy(sym.astype(np.float32) - minmax).to(dev, cdt)
                 return y_pad[:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
+            if WAVEFRONT_GRAPHS and dev.type == "cuda":
+                return self._decode_view_graphed(dec, which, params, minmax, channels, extra, yh, yw, bound)
             ctx_m = self.context_prediction1 if which == 1 else self.context_prediction2
             ep = self.entropy_parameters1 if which == 1 else self.entropy_parameters2
             if not hasattr(ctx_m, "_packer"):

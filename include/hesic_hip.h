@@ -503,6 +503,25 @@ int hesic_perspective_transform(const float* src, const float* dst, float* H, in
 int hesic_h_from_delta(const float* corners, const float* delta, float ratio_a, float ratio_b, int subtract_origin,
                        float* H, int B, void* stream);
 
+/* ------------------------------------------------------------------ HESIC+ wavefront decode: the first node of a group's graph (row f3)
+ * The reference's decoder walks the latent map pixel by pixel (ywz/mywork/newnet1_joint.py:1190-1260); here the pixels of one
+ * wavefront group t = w + 3h are decoded together and the device work of a group is ONE HIP graph replayed per step.  This launch opens
+ * that graph and keeps every per-step quantity in device memory (one block, phases separated by block barriers):
+ *  1. scatter the previous group's symbols (sym: [nprev][C] int32, pixel-major; value = sym - minmax) into the padded latent map y_rows
+ *     ((Hp*Wp) rows of M values of `dtype`) at rows prev_centre[], channels[];  state = {nprev, C, minmax} (device int32[3]);
+ *  2. gather this group's P pixels (offset *pos in all_centre / all_rows: padded-map row of the pixel, raster row of the pixel): their
+ *     5 x 5 crops -> crops[P][25][M], par[row][0..c_par) -> feat[p][0..c_par), ext[row][0..M) -> feat[p][e_off..e_off+M) (ext may be NULL);
+ *  3. *pos += P; state[0] = P; prev_centre[0..P) = the group's padded rows.
+ * P == 0: step 1 only (after the last group).  Rows must be whole 16-byte chunks.                                                    */
+int hesic_joint_step(void* y_rows, int dtype, int M, int Wp, const int32_t* sym, int64_t* prev_centre, int32_t* state,
+                     const int32_t* channels, const int64_t* all_centre, const int64_t* all_rows, int64_t* pos, int P, void* crops,
+                     const void* par, int c_par, const void* ext, int e_off, void* feat, int c_feat, void* stream);
+
+/* Host-loop helpers of the decode walk: hipMemcpyAsync (kind 1 = host -> device, 2 = device -> host; pinned host memory) and
+ * hipStreamSynchronize behind the same error plumbing.                                                                               */
+int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream);
+int hesic_stream_synchronize(void* stream);
+
 /* ------------------------------------------------------------------ MS-SSIM (row M: the second published quality metric)
  * The reference's evaluation reports pytorch_msssim.ms_ssim(x_hat, x, data_range=1, size_average=False) next to PSNR
  * (ywz/mywork/test3real.py:107-109; third party, absent: algorithm restated, see oracle/hesic_oracle.py::ms_ssim).

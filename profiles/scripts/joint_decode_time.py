@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     import hesic_amd
     from hesic_amd import models, synthetic
-    hesic_amd.set_compute_dtype(torch.bfloat16)
+    hesic_amd.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[os.environ.get("HESIC_DTYPE", "f16")])
     net = models.HSICJoint()
     synthetic.fill_state_dict_(net.state_dict())
     net = net.cuda().eval()
