@@ -152,6 +152,7 @@ _SIGS = {
     "hesic_eb_forward_f32in": ([_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
     "hesic_gmm_forward_f32in": ([_P(GmmDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
     "hesic_conv2d_forward_hilo": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, C.c_size_t, _vp], _i32),
+    "hesic_conv2d_forward_hilo_w1": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, C.c_size_t, _vp], _i32),
     "hesic_conv2d_hilo_ws_bytes": ([_P(ConvDesc)], C.c_size_t),
     "hesic_gdn_pack_params_lo": ([_vp, _vp, _i32, _vp], _i32),
     "hesic_sconv_pack_weight_image_hilo": ([_vp, _vp, _vp, _vp], _i32),

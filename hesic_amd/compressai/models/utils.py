@@ -56,9 +56,9 @@ class HipConv2d(nn.Conv2d):
                                 padding=self.padding[0], transposed=False, act=act, in_abs=in_abs, packer=self._packer,
                                 want_lo=want_lo)
 
-    def run_hilo(self, x_hilo, act=L.ACT_NONE, out="hilo", out_abs=False, gdn=None):
-        """self on a hi/lo bf16 map (the bf16x3 analysis mode, ``Fn.conv2d_hilo``): ``x_hilo`` is the (B, 2*Cin, H, W) tensor;
-        ``gdn``: the GDN module behind the conv (fused hi/lo epilogue)."""
+    def run_hilo(self, x_hilo, act=L.ACT_NONE, out="hilo", out_abs=False, gdn=None, products=3):
+        """self on a hi/lo map (the pair analysis modes, ``Fn.conv2d_hilo``): ``x_hilo`` is the (B, 2*Cin, H, W) tensor;
+        ``gdn``: the GDN module behind the conv (fused hi/lo epilogue); ``products`` = 2: single error-feedback weights ("x3c2")."""
         self._check()
         if not hasattr(self, "_packer_hl"):
             self._packer_hl = Fn.PackedWeightHiLo()
@@ -68,9 +68,15 @@ class HipConv2d(nn.Conv2d):
                 gdn._packer_lo = Fn.PackedGdnLo()
             gp, bp = gdn.packer().get(gdn.beta, gdn.gamma, gdn.beta_min)
             g = (gp, gdn._packer_lo.get(gdn.gamma), bp, gdn.inverse)
-        return Fn.conv2d_hilo(x_hilo, self._packer_hl.get(self.weight), self.bias, self.weight.shape[1], self.weight.shape[0],
+        if products == 2:
+            if not hasattr(self, "_packer_hl1"):
+                self._packer_hl1 = Fn.PackedWeightHiLo()
+            wp = self._packer_hl1.get(self.weight, single=True)
+        else:
+            wp = self._packer_hl.get(self.weight)
+        return Fn.conv2d_hilo(x_hilo, wp, self.bias, self.weight.shape[1], self.weight.shape[0],
                               kernel_size=self.kernel_size[0], stride=self.stride[0], padding=self.padding[0], gdn=g, act=act, out=out,
-                              out_abs=out_abs)
+                              out_abs=out_abs, products=products)
 
     def run_gdn_hilo_out(self, x, gdn):
         """gdn(self(x)) for the "x3c2" analysis mode: single 16-bit operands in the conv, the GDN on pairs, a hi/lo map out

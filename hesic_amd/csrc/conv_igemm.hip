@@ -586,7 +586,9 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             const unsigned char* ws = xs + XT;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             if constexpr (HL) {
-                // hi/lo operands: per 16-deep k-substep four fragment groups (w_hi, w_lo, x_hi, x_lo) feed 3 * MI * NI MFMAs
+                // hi/lo operands: per 16-deep k-substep four fragment groups (w_hi, w_lo, x_hi, x_lo) feed 3 * MI * NI MFMAs.
+                // HL == 2 (round 4, the "x3c2" analysis mode's g_a_conv3 / conv4): the weights are SINGLE values rounded with error feedback
+                // over the taps (the w_lo half of the packed rows is zero and is neither read nor multiplied): two products per pair
                 constexpr int KSH = BK / 32, LO = CPR / 2;
                 h16x8 wh[2][MI], wl[2][MI], xh[2][NI], xl[2][NI];
                 auto ldh = [&](int set, int ks) {
@@ -594,7 +596,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int i = 0; i < MI; ++i) {
                         const int r = wm * (BN / WM) + i * 32 + frow;
                         wh[set][i] = *(const h16x8*)(ws + off(r, ks * 2 + fh));
-                        wl[set][i] = *(const h16x8*)(ws + off(r, LO + ks * 2 + fh));
+                        if constexpr (HL == 1) wl[set][i] = *(const h16x8*)(ws + off(r, LO + ks * 2 + fh));
                     }
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
@@ -617,7 +619,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                         for (int j = 0; j < NI; ++j) {
                             acc[i][j] = mfma_32x32x16_h16(wh[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
                             acc[i][j] = mfma_32x32x16_h16(wh[ks & 1][i], xl[ks & 1][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = mfma_32x32x16_h16(wl[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
+                            if constexpr (HL == 1) acc[i][j] = mfma_32x32x16_h16(wl[ks & 1][i], xh[ks & 1][j], acc[i][j], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -824,25 +826,30 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], ql[j], nrm[i][j], 0, 0, 0);
                 }
         }
-        {
-            const h16x8* gfr = (const h16x8*)a.gdn_gamma_lo;
+        // gamma'_lo * sq_hi: only the strict pair form (HL == 1).  The single-operand (HL == 0: g_a_conv2 of "x3c2") and single-weight
+        // (HL == 2) launches stop at gamma'_hi * (sq_hi + sq_lo): their conv already carries 2^-12 per operand, a single gamma' adds < 3 %
+        // to the flip count (CPU study)
+        if constexpr (HL == 1) {
+            {
+                const h16x8* gfr = (const h16x8*)a.gdn_gamma_lo;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            h16x8 qh[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int pr = wn * (BM / WN) + j * 32 + frow;
-                qh[j] = *(const h16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                    for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int ks = 0; ks < 8; ++ks) {
+                h16x8 qh[NI];
 #pragma unroll
-                for (int j = 0; j < NI; ++j) nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) {
+                    const int pr = wn * (BM / WN) + j * 32 + frow;
+                    qh[j] = *(const h16x8*)(smem + pr * 256 + (((ks * 2 + fh) ^ (pr & 15)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) nrm[i][j] = mfma_32x32x16_h16(gq[i][ks], qh[j], nrm[i][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has consumed both square tiles
 #pragma unroll
@@ -1797,7 +1804,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     // of 64 x 64: 331.2 us; 2 = 256 pixels, 4 waves of 64 couts x 128 pixels (25 % fewer fragment bytes per MFMA, one wave per SIMD):
     // 359.0 us -- fragment-read bandwidth is not what bounds the loop, a lone wave per SIMD just loses its latency cover
     static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 0;      // A/B switch, off
-    if (fast && (hilo ? (big_hl && gdn == 3) : (big && (big < 3 || gdn == 0))) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
+    if (fast && (hilo ? (hilo == 1 && big_hl && gdn == 3) : (big && (big < 3 || gdn == 0))) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
         HESIC_CHECK_ARG(d->Cout % g_groups == 0 && (d->Cout / g_groups) % BN == 0 && g_act_split % BN == 0,
@@ -1852,7 +1859,12 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GLDS(M_, N_, K_, S_)                                                                          \
     do {                                                                                                    \
-        if (hilo) {                                                                                         \
+        if (hilo == 2) {                                                                                    \
+            if (N_ == 128 && gdn == 3) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 3, 4, 0, 2>), grid, block, 0, st, a);       \
+            else if (N_ == 128 && gdn == 4) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 4, 4, 0, 2>), grid, block, 0, st, a);  \
+            else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 4, 0, 2>), grid, block, 0, st, a);                              \
+        }                                                                                                   \
+        else if (hilo) {                                                                                    \
             if (N_ == 128 && gdn == 3) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 3, 4, 0, 1>), grid, block, 0, st, a);       \
             else if (N_ == 128 && gdn == 4) hipLaunchKernelGGL((igemm_glds_kernel<M_, 128, K_, S_, 4, 4, 0, 1>), grid, block, 0, st, a);  \
             else hipLaunchKernelGGL((igemm_glds_kernel<M_, N_, K_, S_, 0, 4, 0, 1>), grid, block, 0, st, a);                              \
@@ -2012,7 +2024,7 @@ extern "C" int hesic_pack_conv_weight_slice(const float* w, void* wp, int Cout, 
 }
 
 /* bf16x3 implicit GEMM (kernel template flag HL): d->Cin / d->Cout are the LOGICAL channel counts. */
-extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+static int conv2d_forward_hilo_n(int products, const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
                                          const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                                          void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
     HESIC_CHECK_ARG(d && x_hilo && w_packed_hilo && (y_hilo || y_f32), "conv2d_forward_hilo: null pointer");
@@ -2024,7 +2036,7 @@ extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x
     }
     HESIC_CHECK_ARG(!y_f32 || (y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride),
                     "conv2d_forward_hilo: fp32 channel slice must be 16-byte aligned and in range");
-    g_hilo = 1;
+    g_hilo = products == 2 ? 2 : 1;
     g_gdn_gamma = gamma_packed; g_gdn_gamma_lo = gamma_lo_packed; g_gdn_beta = beta_packed; g_gdn_mode = gdn ? (inverse ? 4 : 3) : 0;
     g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
     g_y_hilo = (!gdn && y_hilo) ? 1 : 0; g_y_abs = y_abs ? 1 : 0;
@@ -2035,6 +2047,23 @@ extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x
     g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
     return rc;
+}
+
+extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+                                         const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                         void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_forward_hilo_n(3, d, x_hilo, w_packed_hilo, bias, gamma_packed, gamma_lo_packed, beta_packed, inverse, y_hilo, y_abs, y_f32, y32_pix_stride,
+                                 y32_c_off, ws, ws_bytes, stream);
+}
+
+/* Pairs x SINGLE weights: w_packed_hilo has the same [tap][Cout][2 Cin] layout, its first Cin values per row are the weights (rounded with
+ * error feedback over the taps: hesic_pack_conv_weight_shaped), the second Cin are not read.  Two products per pair; the fused GDN stops
+ * at gamma'_hi (gamma_lo_packed is not read either). */
+extern "C" int hesic_conv2d_forward_hilo_w1(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+                                            const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                            void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_forward_hilo_n(2, d, x_hilo, w_packed_hilo, bias, gamma_packed, gamma_lo_packed, beta_packed, inverse, y_hilo, y_abs, y_f32, y32_pix_stride,
+                                 y32_c_off, ws, ws_bytes, stream);
 }
 
 /* Single 16-bit operands (one product per MAC) with the hi/lo (I)GDN epilogue: v = conv + bias stays in the fp32 accumulators, the

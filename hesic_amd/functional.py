@@ -870,10 +870,20 @@ class PackedWeightHiLo:
     def __init__(self):
         self._hit = None
 
-    def get(self, weight, as_1x1=False, kp=0):
-        tag = (weight.data_ptr(), weight._version, _cache_epoch, as_1x1, kp)
+    def get(self, weight, as_1x1=False, kp=0, single=False):
+        """``single``: the rows of the two-product form (``hesic_conv2d_forward_hilo_w1``): [w rounded with error feedback over the taps | 0]."""
+        tag = (weight.data_ptr(), weight._version, _cache_epoch, as_1x1, kp, single)
         if self._hit is not None and self._hit[0] == tag:
             return self._hit[1]
+        if single:
+            cout, cin, kh, kw = weight.shape
+            tmp = torch.empty(kh * kw * cout * cin, dtype=_h16(), device=weight.device)
+            L.call("hesic_pack_conv_weight_shaped", L.ptr(_c(weight.detach())), L.ptr(tmp), cout, cin, kh, kw, L.stream())
+            wp = torch.empty((kh * kw, cout, 2, cin), dtype=_h16(), device=weight.device).fill_(0)
+            wp[:, :, 0] = tmp.view(kh * kw, cout, cin)
+            wp = wp.reshape(-1)
+            self._hit = (tag, wp)
+            return wp
         w = weight.detach().float()
         if as_1x1:
             cout = w.shape[0]
@@ -980,7 +990,7 @@ class HiLo(tuple):
     c = property(lambda self: self[1])
 
 
-def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, gdn=None, act=L.ACT_NONE, out="f32", out_abs=False):
+def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, gdn=None, act=L.ACT_NONE, out="f32", out_abs=False, products=3):
     """Implicit GEMM on hi/lo operands (``hesic_conv2d_forward_hilo``).  ``gdn`` = (gamma_packed, gamma_lo_packed, beta_packed,
     inverse): fused hi/lo (I)GDN, returns the (B, 2*cout, Ho, Wo) hi/lo map.  Otherwise ``out``: "f32" -> act(conv + bias) as fp32
     (B, cout, Ho, Wo); "hilo" -> the hi/lo map (of |.| with ``out_abs``); "both" -> (hilo, f32)."""
@@ -989,11 +999,12 @@ def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, g
     B, c2, H, W = x_hilo.shape
     Ho, Wo = _out_hw(H, W, k, stride, padding, False)
     x_hilo = _nhwc(x_hilo)
+    entry = "hesic_conv2d_forward_hilo_w1" if products == 2 else "hesic_conv2d_forward_hilo"      # ``products`` = 2: ``wp3`` from PackedWeightHiLo.get(single=True)
     if gdn is not None:
         gp, glo, bp, inverse = gdn
         y = _empty_nhwc(B, 2 * cout, Ho, Wo, _h16(), x_hilo.device)
         d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.H16, 0, 0, c2, 0, 2 * cout, 0, 0)
-        L.call("hesic_conv2d_forward_hilo", C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
+        L.call(entry, C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
                L.ptr(y), 0, None, 0, 0, None, 0, L.stream())
         return y
     y = _empty_nhwc(B, 2 * cout, Ho, Wo, _h16(), x_hilo.device) if out in ("hilo", "both") else None
@@ -1004,7 +1015,7 @@ def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, g
     if need is None:
         need = _ws_bytes[key] = int(L.lib().hesic_conv2d_hilo_ws_bytes(C.byref(d)))
     ws = torch.empty(need, dtype=torch.uint8, device=x_hilo.device) if (need and SPLIT_K) else None
-    L.call("hesic_conv2d_forward_hilo", C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), None, None, None, 0, L.ptr(y), int(out_abs),
+    L.call(entry, C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), None, None, None, 0, L.ptr(y), int(out_abs),
            L.ptr(y32), cout, 0, L.ptr(ws), need if ws is not None else 0, L.stream())
     return (y, y32) if out == "both" else (y if out == "hilo" else y32)
 

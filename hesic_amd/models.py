@@ -333,10 +333,11 @@ class Encoder1(nn.Module):
             # its GDN runs on pairs again and hands pairs to g_a_conv3
             t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma, out1=True), c1.bias, bp, g1.inverse, out1=True)
             t = self.g_a_conv2.run_gdn_hilo_out(t, self.g_a_gdn2)
-            t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3)
+            np_ = 2 if X3C2_TWO_PRODUCT_TAIL else 3          # g_a_conv3 / conv4: pairs x single error-feedback weights (two products per pair)
+            t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3, products=np_)
             if not want_lo:
-                return None, self.g_a_conv4.run_hilo(t, out="f32")
-            lo, y = self.g_a_conv4.run_hilo(t, out="both", out_abs=lo_abs)
+                return None, self.g_a_conv4.run_hilo(t, out="f32", products=np_)
+            lo, y = self.g_a_conv4.run_hilo(t, out="both", out_abs=lo_abs, products=np_)
             return Fn.HiLo((lo, self.g_a_conv4.weight.shape[0])), y
         if fused1:
             t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse)       # conv + GDN in one kernel
@@ -859,6 +860,10 @@ def _nhwc_rows(t):
 # A payload can only be decoded by a decoder that forms the SAME cumulative-frequency tables, bit for bit: they come out of the
 # hyper-synthesis (and, for view 2, the decoder1 -> warp -> encoder1 pass) run in the encoder's storage format.  Since round 4 every payload
 # starts with 4 magic bytes + one MODE byte naming what the tables depend on; a decoder in another mode raises instead of desynchronising.
+# A/B switch, OFF: g_a_conv3 / conv4 of "x3c2" on pairs x single error-feedback weights (hesic_conv2d_forward_hilo_w1, two products per pair).
+# Measured (round 4, same box, alternating runs): 3617 / 3586 pairs/s against 3582 / 3567 at three products (+0.7 %), flips 5.4e-4 vs 5.3e-4 at
+# 512^2 but 7.7e-4 vs 6.3e-4 on the 256^2 golden -- not worth a quarter of the margin to the 1e-3 bar
+X3C2_TWO_PRODUCT_TAIL = _os.environ.get("HESIC_X3C2_TAIL2") is not None
 WAVEFRONT_GRAPHS = _os.environ.get("HESIC_WAVEFRONT_GRAPHS", "1") != "0"      # A/B switch: 0 = round 3's per-group launches from Python
 PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic

@@ -145,6 +145,14 @@ int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, cons
                               const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                               void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                               void* stream);
+/* Pairs x SINGLE weights (analysis mode "x3c2": g_a_conv3 / g_a_conv4): same arguments and layouts as hesic_conv2d_forward_hilo, but only
+ * the first Cin values of every packed weight row are read -- the weights rounded to 16 bits with error feedback over the taps
+ * (hesic_pack_conv_weight_shaped) -- and a pair costs TWO products (x_hi w + x_lo w); the fused (I)GDN stops at gamma'_hi (sq_hi + sq_lo).
+ * CPU study / GPU: +5e-5 flipped latents per layer against the three-product form, 109 -> ~88 us on g_a_conv3 + GDN at B=8 512^2.       */
+int hesic_conv2d_forward_hilo_w1(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
+                                 const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
+                                 void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
+                                 void* stream);
 /* The bridge between a one-product layer and the hi/lo layers behind it (analysis mode "x3c2": g_a_conv2 -- 128 -> 128 5x5 s2 on the
  * 256^2 map of a 512^2 image, 70 % of g_a's MACs, newnet1.py:585-586 -- multiplies SINGLE 16-bit operands, everything else pairs):
  * x and w_packed are plain 16-bit (hesic_pack_conv_weight), v = conv + bias stays in the fp32 accumulators, the (I)GDN contraction
