@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);      // <= 128 blocks: same-address atomics serialise
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
 struct SqArgs {
@@ -643,7 +643,10 @@ extern "C" int hesic_softmax_k_backward(const float* weights, const float* g, fl
 
 extern "C" int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream) {
     HESIC_CHECK_ARG(lik && out && n > 0, "sum_log2: bad arguments");
-    hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n / 4 + 1, 256, 128)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
+    // one fp64 atomic per block on ONE address: they serialise in L2.  Measured (round 4, 1.57 M likelihoods, back-to-back launches):
+    // 128 blocks 6.0 us, 512 blocks 8.9 us, 2048 blocks 21.3 us -- so few, fat blocks (HESIC_SUM_LOG2_BLOCKS = A/B switch)
+    static const int max_blocks = getenv("HESIC_SUM_LOG2_BLOCKS") ? atoi(getenv("HESIC_SUM_LOG2_BLOCKS")) : 128;
+    hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n / 4 + 1, 256, max_blocks < 1 ? 1 : max_blocks)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
     HESIC_LAUNCH_RETURN("sum_log2");
 }
 
