@@ -88,6 +88,7 @@ _SIGS = {
     "hesic_perspective_transform": ([_vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_h_from_delta": ([_vp, _vp, _f32, _f32, _i32, _vp, _i32, _vp], _i32),
     "hesic_conv2d_ws_bytes": ([_P(ConvDesc)], C.c_size_t),
+    "hesic_conv2d_f32out_ws_bytes": ([_P(ConvDesc)], C.c_size_t),
     "hesic_conv2d_forward_ws": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp], _i32),
     "hesic_gdn_pack_params": ([_vp, _vp, _f32, _vp, _vp, _i32, _vp], _i32),
     "hesic_conv2d_gdn_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),

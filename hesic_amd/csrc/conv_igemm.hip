@@ -1960,6 +1960,17 @@ extern "C" size_t hesic_conv2d_ws_bytes(const hesic_conv_desc* d) {
     return rc == 0 ? need : 0;
 }
 
+/* The same query for hesic_conv2d_forward_f32out: a launch with an fp32 latent output decides its K split per image (a pair's latents
+ * must not depend on the batch), so its scratch can differ from the plain launch's. */
+extern "C" size_t hesic_conv2d_f32out_ws_bytes(const hesic_conv_desc* d) {
+    size_t need = 0;
+    if (!d) return 0;
+    g_ws_need = &need; g_y32 = (float*)16; g_y32_ps = d->Cout; g_y32_co = 0;
+    const int rc = hesic_conv2d_forward(d, (const void*)16, (const void*)16, nullptr, (void*)16, nullptr);
+    g_ws_need = nullptr; g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
+    return rc == 0 ? need : 0;
+}
+
 extern "C" int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                        void* y, void* ws, size_t ws_bytes, void* stream) {
     g_ws = (float*)ws; g_ws_bytes = ws ? ws_bytes : 0;

@@ -389,10 +389,10 @@ def _wide_conv(x, wp, bias, B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, transpos
     y_ps, y_co = (out.shape[1], out_c_off) if out is not None else (Cout, 0)
     d = L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, int(transposed), L.dt(dtype), act, in_abs,
                    x.shape[1], x_c_off, y_ps, y_co, tap_mask)
-    key = (B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, int(transposed), L.dt(dtype), tap_mask)
+    key = (B, H, W, Cin, Ho, Wo, Cout, k, stride, pad, int(transposed), L.dt(dtype), tap_mask, bool(f32_out))
     need = _ws_bytes.get(key)
-    if need is None:
-        need = _ws_bytes[key] = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    if need is None:      # a launch with an fp32 latent output decides its K split per image: its own query
+        need = _ws_bytes[key] = int((L.lib().hesic_conv2d_f32out_ws_bytes if f32_out else L.lib().hesic_conv2d_ws_bytes)(C.byref(d)))
     ws = None
     if need and SPLIT_K:      # low-resolution layer: split-K launch, fp32 partial tiles in a scratch buffer
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)

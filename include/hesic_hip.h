@@ -116,6 +116,9 @@ int hesic_conv2d_forward_ws(const hesic_conv_desc* d, const void* x, const void*
 int hesic_conv2d_forward_f32out(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                 void* y, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                                 void* stream);
+/* Scratch bytes of hesic_conv2d_forward_f32out for `d` (0: no split; may differ from hesic_conv2d_ws_bytes: launches that feed round() /
+ * a likelihood decide their K split per image so that a pair's latents never depend on the batch it is in). */
+size_t hesic_conv2d_f32out_ws_bytes(const hesic_conv_desc* d);
 
 /* Several convolutions of the same geometry in ONE launch (bf16 storage): the packed weight holds `groups` weights side by side along
  * Cout ([KH*KW][Cout][Cin], d->Cout = total, each slice written by hesic_pack_conv_weight_slice), group g's couts read input

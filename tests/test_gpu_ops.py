@@ -824,8 +824,9 @@ def test_resblock_c32_is_the_two_launch_path_bit_for_bit(hw, skip):
 
 
 # ------------------------------------------------------------------ fp32 latents of the bf16 mode (round 2)
-@pytest.mark.parametrize("shape,split", [((2, 128, 192, 5, 2, 64), False), ((2, 128, 128, 5, 2, 16), True), ((1, 128, 960, 5, 1, 32), False)],
-                         ids=["conv4", "hyper_z_splitk", "sigma960"])
+@pytest.mark.parametrize("shape,split", [((2, 128, 192, 5, 2, 64), True), ((2, 128, 128, 5, 2, 16), True), ((1, 128, 960, 5, 1, 32), False),
+                                         ((4, 128, 128, 5, 2, 128), False)],
+                         ids=["conv4_splitk_per_image", "hyper_z_splitk", "sigma960", "full_size_plain"])
 def test_conv_f32out_is_the_unrounded_accumulator(shape, split):
     """hesic_conv2d_forward_f32out: the fp32 copy equals the oracle on the bf16-rounded operands to fp32 accuracy (not bf16
     accuracy), the bf16 copy is its rounding, `y == NULL` writes only the fp32 tensor; plain and split-K launches."""
@@ -841,8 +842,11 @@ def test_conv_f32out_is_the_unrounded_accumulator(shape, split):
     xd = x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
     wp = Fn.PackedWeight().get(w.to(DEV), None, Cout, Cin, k, k, False, False, torch.bfloat16)
     d = L.ConvDesc(B, H, H, Cin, Ho, Ho, Cout, k, k, s, k // 2, 0, L.BF16, L.ACT_RELU, 0, Cin, 0, Cout, 0, 0)
-    need = int(L.lib().hesic_conv2d_ws_bytes(C.byref(d)))
+    need = int(L.lib().hesic_conv2d_f32out_ws_bytes(C.byref(d)))      # the latent-grade launch's own query: K split decided per image
     assert (need > 0) == split
+    if split:        # ... so the scratch per image does not depend on the batch
+        d1 = L.ConvDesc(1, H, H, Cin, Ho, Ho, Cout, k, k, s, k // 2, 0, L.BF16, L.ACT_RELU, 0, Cin, 0, Cout, 0, 0)
+        assert int(L.lib().hesic_conv2d_f32out_ws_bytes(C.byref(d1))) * B == need
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
     lo = torch.zeros((B, Cout, Ho, Ho), device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     hi = torch.full((B, Cout + 8, Ho, Ho), 7.0, device=DEV).contiguous(memory_format=torch.channels_last)
