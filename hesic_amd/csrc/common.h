@@ -24,12 +24,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 // hesic_gdn_pack_params*): v^2 * 2^-6 stays finite up to |v| = 2047 where fp16 itself ends at 255
 #define H16_SQ_SCALE 0.015625f
 #define H16_SQ_UNSCALE 64.0f
+#define H16_SQ_ROOT 0.125f                /* sqrt(H16_SQ_SCALE) */
 #else
 typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
 #define mfma_32x32x16_h16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define H16_ONE_PAIR 0x3f803f80u
 #define H16_SQ_SCALE 1.0f
 #define H16_SQ_UNSCALE 1.0f
+#define H16_SQ_ROOT 1.0f
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -66,11 +68,24 @@ __device__ __forceinline__ float h2f_lo(uint32_t p) { return (float)__builtin_bi
 __device__ __forceinline__ float h2f_hi(uint32_t p) { return (float)__builtin_bit_cast(hw_h2_t, p)[1]; }
 // two values per instruction, round to nearest even; finite inputs beyond the fp16 range saturate at +-65504 instead of turning into
 // infinities (a too-large activation then costs accuracy at that pixel, not a NaN map)
-__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
-    lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
-    hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+__device__ __forceinline__ float h16_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+// v - (float)half of a packed pair in ONE instruction (v_fma_mix_f32: v * 1.0 + (-h), the 16-bit source converted on the way in; exact like
+// the two-instruction form).  The compiler finds this fusion only in some contexts, the pair-splitting code relies on it everywhere.
+__device__ __forceinline__ float sub_h2_lo(float v, uint32_t p) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(p));
+    return d;
+}
+__device__ __forceinline__ float sub_h2_hi(float v, uint32_t p) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(p));
+    return d;
+}
+// the bare conversion: for values known to be in range (residuals of a clamped value, data bounded by construction)
+__device__ __forceinline__ uint32_t pack_h2_raw(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_h2_t));
 }
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { return pack_h2_raw(h16_clamp(lo), h16_clamp(hi)); }
 #else
 typedef __bf16 hw_h2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float h2f(h16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -80,7 +95,18 @@ __device__ __forceinline__ float h2f_hi(uint32_t p) { return __uint_as_float(p &
 __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(hw_f2_t{lo, hi}, hw_h2_t));
 }
+__device__ __forceinline__ float h16_clamp(float v) { return v; }
+__device__ __forceinline__ uint32_t pack_h2_raw(float lo, float hi) { return pack_h2(lo, hi); }
+__device__ __forceinline__ float sub_h2_lo(float v, uint32_t p) { return v - h2f_lo(p); }
+__device__ __forceinline__ float sub_h2_hi(float v, uint32_t p) { return v - h2f_hi(p); }
 #endif
+// (hi, lo) pairs of two values: hi = the 16-bit rounding (saturating), lo = the rounding of what it left -- one clamp per value, the
+// residual of a clamped value is in range by construction
+__device__ __forceinline__ void split_h2(float p, float q, uint32_t& hi, uint32_t& lo) {
+    p = h16_clamp(p); q = h16_clamp(q);
+    hi = pack_h2_raw(p, q);
+    lo = pack_h2_raw(sub_h2_lo(p, hi), sub_h2_hi(q, hi));
+}
 __device__ __forceinline__ h16_t f2h(float f) { return (h16_t)(pack_h2(f, 0.f) & 0xffffu); }
 // the squares of a fused (I)GDN contraction in 16-bit storage (scaled: see H16_SQ_SCALE; gamma' carries the inverse factor)
 __device__ __forceinline__ uint32_t pack_sq2(float a, float b) { return pack_h2(a * a * H16_SQ_SCALE, b * b * H16_SQ_SCALE); }

@@ -11,6 +11,13 @@
 // splitting, squares, rsqrt, output staging: about as many issue cycles per tile as its 192 MFMAs) run under the other's MFMAs.
 #include "common.h"
 
+#ifdef N2W_DBG
+__device__ long long g_n2w_dbg[2][16];
+#define N2W_T(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && (wave == 0 || wave == 4) && it_dbg == 3 && lane == 0) g_n2w_dbg[wave >> 2][k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define N2W_T(k) do {} while (0)
+#endif
+
 namespace {
 
 struct HArgs {
@@ -20,9 +27,20 @@ struct HArgs {
     FastDiv fd_tx, fd_ty;
 };
 
-__device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t& lo) {
-    hi = pack_h2(p, q);
-    lo = pack_h2(p - h2f_lo(hi), q - h2f_hi(hi));
+__device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t& lo) { split_h2(p, q, hi, lo); }
+// image samples: no saturation step (the binary16 build takes |x| <= 65504 -- an image)
+__device__ __forceinline__ void split2_img(float p, float q, uint32_t& hi, uint32_t& lo) {
+    hi = pack_h2_raw(p, q);
+    lo = pack_h2_raw(sub_h2_lo(p, hi), sub_h2_hi(q, hi));
+}
+// fp32 -> 16-bit terms whose sum is the value to ~2^-22 (binary16: two terms, bfloat16: three)
+constexpr int H16_TERMS = HESIC_H16_IS_F16 ? 2 : 3;
+__device__ __forceinline__ void terms3(float v, uint32_t& t01, uint32_t& t2) {
+    const uint32_t a = pack_h2_raw(h16_clamp(v), 0.f) & 0xffffu;
+    const float r1 = h16_clamp(v) - h2f_lo(a);
+    const uint32_t b = pack_h2_raw(r1, 0.f) & 0xffffu;
+    t01 = a | (b << 16);
+    t2 = H16_TERMS == 3 ? (pack_h2_raw(r1 - h2f_lo(b), 0.f) & 0xffffu) : 0u;
 }
 
 // OUT1 = 1: the output leaves as ONE 16-bit value per channel (128 channels per pixel; half the stores) -- for a consumer that multiplies
@@ -31,9 +49,15 @@ __device__ __forceinline__ void split2(float p, float q, uint32_t& hi, uint32_t&
 // instead of 192 per tile) -- x and the squares stay pairs, w is rounded with error feedback over the taps (the image is smooth: the
 // weight-rounding error of the sum cancels, see pack_weight_shaped_kernel), gamma' single.  CPU study (precision_study.py schemes, 512^2,
 // g_a_conv2 single): 3.97e-4 flipped latents with the full pair arithmetic here, 4.09e-4 with this form.
-template <int INV, int OUT1>
-__global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
-    constexpr int KS = 5, R = 15, NW = 8;
+// PING (8 waves; experimental, HESIC_N2W_PING=1): the two waves of a SIMD alternate roles across block barriers -- one in its matrix phase (conv + GDN contraction, 136
+// MFMAs) while the other is in its VALU / memory phase (rsqrt, output staging and stores, the next tile's rows split into pairs); waves 4..7
+// enter the rotation one barrier late.  Free-running, the two waves drifted into doing the same phase at the same time and the parts of the
+// kernel added up instead of overlapping (two waves per SIMD were only 1.3x one).  A wave that runs out of tiles exits; the barrier then
+// counts the rest.
+template <int INV, int OUT1, int NW = 8, int PING = 0>
+__global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HArgs a) {
+    constexpr int KS = 5, R = 15, NT = NW * 64;
+    constexpr bool EARLY_REQ = OUT1 != 0 && NW == 4;
     constexpr uint32_t POISON = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char* wl_hi = smem;                 // conv weights [128 co][16 slots ^ (co & 15)] of 8 bf16: slot r = ci*5 + ky, values kx 0..4
@@ -85,12 +109,12 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     {
         const u32x4* src = (const u32x4*)a.img;       // 8192 slots of 16 bytes, laid out by n2w_hilo_pack_kernel
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 8192 / (8 * NT); ++r) {
             u32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[tid + (r * 8 + j) * 512];
+            for (int j = 0; j < 8; ++j) v[j] = src[tid + (r * 8 + j) * NT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *(u32x4*)(smem + (tid + (r * 8 + j) * 512) * 16) = v[j];
+            for (int j = 0; j < 8; ++j) *(u32x4*)(smem + (tid + (r * 8 + j) * NT) * 16) = v[j];
         }
     }
     __syncthreads();
@@ -98,16 +122,41 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
     const uint32_t st_lane = (uint32_t)(((lane >> 3) * (int)a.ys_x + (lane & 7) * 8) * 2);       // store lane = (pixel of 8, 16-byte chunk of a 128-byte line)
     const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? 512 : 0, 0x00020000);      // no bias: every load returns zeros
     const __amdgpu_buffer_rsrc_t beta_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.beta, 0, 512, 0x00020000);
+    // OUT1: bias and beta' enter through the matrix cores -- one k-step whose A fragment holds the value as 16-bit terms in k = 0..2 of its
+    // row (lanes of the upper k half: zeros) against a B fragment of ones: 2 x 4 MFMAs per tile start the two accumulator sets instead of 2 x 16
+    // buffer loads whose latency sat in front of each MFMA phase; the terms live in registers for the whole launch
+    uint32_t cb01[4], cb2[4], ce01[4], ce2[4];
+    u32x4 ones_b = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (OUT1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rs, (i * 32 + frow) * 4, 0, 0));
+            const float ev = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(beta_rs, (i * 32 + frow) * 4, 0, 0));
+            terms3(bv * H16_SQ_ROOT, cb01[i], cb2[i]);      // the accumulators hold conv * sqrt(H16_SQ_SCALE), the norms beta' * H16_SQ_SCALE + ...:
+            terms3(ev * H16_SQ_SCALE, ce01[i], ce2[i]);     // the output v * rsqrt(norm) is unchanged, the squares need no scaling multiply
+            if (fh) { cb01[i] = cb2[i] = ce01[i] = ce2[i] = 0u; }
+        }
+        ones_b = u32x4{H16_ONE_PAIR, H16_ONE_PAIR & 0xffffu, 0u, 0u};
+    }
+    if constexpr (PING) {
+#ifdef N2W_STATIC_PRIO
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+        if (wave >= NW / 2) __builtin_amdgcn_s_barrier();
+    }
+    [[maybe_unused]] int it_dbg = -1;
     for (; tile < ntiles; tile += tstride) {
+        ++it_dbg;
+        N2W_T(0);
         const int b = tb, ty = tty, tx = ttx;        // of the tile whose rows are in `raw`
         u32x4 xh[8], xl[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f32x2 p0 = __builtin_bit_cast(f32x2, raw[ks][0]), p1 = __builtin_bit_cast(f32x2, raw[ks][1]), p2 = __builtin_bit_cast(f32x2, raw[ks][2]);
             uint32_t h0, l0, h1, l1, h2, l2;
-            split2(p0.x, p0.y, h0, l0);
-            split2(p1.x, p1.y, h1, l1);
-            split2(p2.x, 0.f, h2, l2);
+            split2_img(p0.x, p0.y, h0, l0);
+            split2_img(p1.x, p1.y, h1, l1);
+            split2_img(p2.x, 0.f, h2, l2);
             xh[ks] = u32x4{h0, h1, h2, 0u};
             xl[ks] = u32x4{l0, l1, l2, 0u};
         }
@@ -116,14 +165,28 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
         // POINTER turned them into flat loads, which also count on lgkmcnt and stalled every LDS wait behind a global round trip.)
         uint32_t pofs = (uint32_t)(fh * 16);
         asm volatile("" : "+v"(pofs));
+        N2W_T(1);
+        if constexpr (PING) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        N2W_T(2);
         f32x16 acc[4];
+        if constexpr (OUT1) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
+                acc[i] = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, u32x4{cb01[i], cb2[i], 0u, 0u}), __builtin_bit_cast(h16x8, ones_b), z, 0, 0, 0);
+        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
-                acc[i][4 * g] = bv.x; acc[i][4 * g + 1] = bv.y; acc[i][4 * g + 2] = bv.z; acc[i][4 * g + 3] = bv.w;
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
+                    acc[i][4 * g] = bv.x; acc[i][4 * g + 1] = bv.y; acc[i][4 * g + 2] = bv.z; acc[i][4 * g + 3] = bv.w;
+                }
+        }
         // conv: the w_hi fragments are double-buffered one k-step ahead; the w_lo fragments of a k-step are requested at its start and
         // used last (behind 8 MFMAs = their LDS latency)
         {
@@ -157,14 +220,29 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        N2W_T(3);
+        if constexpr (EARLY_REQ) {
+            // the next tile's rows are requested in front of the GDN contraction: its 68 MFMAs, the rsqrt pass and the staging passes cover
+            // the round trip (requested behind them, ~half of it was exposed: one wave per SIMD measured 14 k cycles per tile for 8 k of work)
+            __builtin_amdgcn_sched_barrier(0);
+            request(tile + tstride < ntiles ? tile + tstride : tile);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x16 nrm[4];
+        if constexpr (OUT1) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
+                nrm[i] = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, u32x4{ce01[i], ce2[i], 0u, 0u}), __builtin_bit_cast(h16x8, ones_b), z, 0, 0, 0);
+        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 be = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(beta_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
-                nrm[i][4 * g] = be.x; nrm[i][4 * g + 1] = be.y; nrm[i][4 * g + 2] = be.z; nrm[i][4 * g + 3] = be.w;
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 be = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(beta_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
+                    nrm[i][4 * g] = be.x; nrm[i][4 * g + 1] = be.y; nrm[i][4 * g + 2] = be.z; nrm[i][4 * g + 3] = be.w;
+                }
+        }
         // GDN contraction: the squares of k-step ks + 1 (VALU) and its gamma'_hi fragments (LDS) are prepared before the 12 MFMAs of
         // k-step ks are issued; gamma'_lo is requested at the start of its k-step and used last
         {
@@ -178,7 +256,8 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 uint32_t qh[4], ql[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e] * H16_SQ_SCALE, s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1] * H16_SQ_SCALE;
+                    const float sq_scale = OUT1 ? 1.f : H16_SQ_SCALE;
+                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e] * sq_scale, s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1] * sq_scale;
                     split2(s0, s1, qh[e], ql[e]);
                 }
                 fq[set][0] = __builtin_bit_cast(h16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
@@ -206,17 +285,27 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        N2W_T(4);
+        if constexpr (PING) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        N2W_T(5);
         // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] *= INV ? __builtin_amdgcn_sqrtf(nrm[i][r]) : __builtin_amdgcn_rsqf(nrm[i][r]);
-        // the next tile's rows are requested here: `raw` (48 registers) is then not live across the MFMA phases, and the loads have
-        // the staging passes -- and the other wave of the SIMD -- to come back
-        __builtin_amdgcn_sched_barrier(0);
-        request(tile + tstride < ntiles ? tile + tstride : tile);      // unconditional: a conditional update would keep the OLD `raw` live across
-                                                                       // both MFMA phases (48 registers; the allocator spilled them)
-        __builtin_amdgcn_sched_barrier(0);
+        N2W_T(6);
+        if constexpr (!EARLY_REQ) {
+            // the next tile's rows are requested here: `raw` (48 registers) is then not live across the MFMA phases, and the loads have
+            // the staging passes -- and the other wave of the SIMD -- to come back
+            __builtin_amdgcn_sched_barrier(0);
+            request(tile + tstride < ntiles ? tile + tstride : tile);      // unconditional: a conditional update would keep the OLD `raw` live across
+                                                                           // both MFMA phases (48 registers; the allocator spilled them)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (int64_t)b * a.ys_b), 0, (int)POISON, 0x00020000);
         // four passes through the 4 KB of wave-private staging: (hi | lo) x (channels 0..63 | 64..127), all 32 pixels of the tile, 128
         // bytes (one cache line) per pixel and pass.  Every lane takes part in every pass, the hi passes cost one pack per channel
@@ -240,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
             // alias grounds (it did: every other pixel came out with the previous pass's data) -- compiler barriers; the LDS itself
             // executes a wave's accesses in order
             asm volatile("" ::: "memory");
+            N2W_T(8 + pass * 3);
             u32x4 rowv[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -247,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 rowv[it] = *(const u32x4*)(os + pr * 128 + (((lane & 7) ^ (pr & 7)) << 4));
             }
             asm volatile("" ::: "memory");
+            N2W_T(9 + pass * 3);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int y2 = ty * 2 + (it >> 1), x2 = tx * 16 + (it & 1) * 8;
@@ -255,7 +346,9 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
                 // tile offset in the VGPR offset, soffset = 0: see the store-hazard note in sconv_n2w_gdn_fast_kernel
                 __builtin_amdgcn_raw_buffer_store_b128(rowv[it], yr, (int)(ok ? st_lane + (uint32_t)so : POISON), 0, 0);
             }
+            N2W_T(10 + pass * 3);
         }
+        N2W_T(7);
     }
 }
 
@@ -266,6 +359,10 @@ __global__ __launch_bounds__(512, 2) void n2w_gdn_hilo_kernel(const HArgs a) {
 // ``shaped``: the hi half of a conv weight is its 16-bit rounding WITH error feedback over the 25 taps of its (cout, cin) pair (serpentine
 // walk, as pack_weight_shaped_kernel) -- for the two-product form of the kernel (OUT1), which multiplies w_hi only.
 __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img, int shaped) {
+    // the single-output form (shaped != 0) works on conv values scaled by sqrt(H16_SQ_SCALE) (a power of two: exact), so that their squares
+    // are the scaled squares without a multiply per value: conv weights x that factor, gamma' plain (scale and unscale cancel), bias and
+    // beta' scaled inside the kernel
+    const float wsc = shaped ? H16_SQ_ROOT : 1.f, gsc = shaped ? 1.f : H16_SQ_UNSCALE;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 4096) return;
     float v[8];
@@ -274,7 +371,7 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
         row = idx >> 4;
         const int r = idx & 15, ci = r / 5, ky = r % 5;
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((row * 3 + ci) * 5 + ky) * 5 + kx] : 0.f;
+        for (int kx = 0; kx < 8; ++kx) v[kx] = (r < 15 && kx < 5) ? w[((row * 3 + ci) * 5 + ky) * 5 + kx] * wsc : 0.f;
         if (shaped && r < 15) {
             // replay the walk of this (cout, cin) pair up to row ky: the error carried into it, then this row's five values
             const float* src = w + (row * 3 + ci) * 25;
@@ -282,7 +379,7 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
             for (int yy = 0; yy <= ky; ++yy)
                 for (int j = 0; j < 5; ++j) {
                     const int kx = (yy & 1) ? 4 - j : j;
-                    const float tgt = src[yy * 5 + kx] + e;
+                    const float tgt = src[yy * 5 + kx] * wsc + e;
                     const float q = h2f(f2h(tgt));
                     e = tgt - q;
                     if (yy == ky) v[kx] = q;
@@ -297,7 +394,7 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
         for (int e = 0; e < 8; ++e) {
             const int c = 16 * ks + 4 * h + (e & 3) + (e >> 2) * 8;
             const float t = fmaxf(gamma[row * 128 + c], gb);
-            v[e] = (t * t - ped) * H16_SQ_UNSCALE;
+            v[e] = (t * t - ped) * gsc;
         }
         pos = q ^ (row & 15);
     }
@@ -310,6 +407,10 @@ __global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* _
 }
 
 }  // namespace
+
+#ifdef N2W_DBG
+extern "C" int hesic_debug_n2w_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_n2w_dbg), sizeof(long long) * 32); }
+#endif
 
 extern "C" int hesic_sconv_pack_weight_image_hilo(const float* w, const float* gamma, void* image, void* stream) {
     HESIC_CHECK_ARG(w && gamma && image, "sconv_pack_weight_image_hilo: null pointer");
@@ -353,6 +454,26 @@ static int n2w_gdn_hilo_launch(const hesic_sconv_desc* d, const float* x, const 
     }
     const dim3 g(grid), blk(512);
     hipStream_t st = (hipStream_t)stream;
+    static const bool one_wave = getenv("HESIC_N2W_ONE_WAVE") != nullptr;      // experiment: one wave per SIMD (what do the two waves of a SIMD overlap?)
+    // A/B switch, off: back-to-back launches 75.5 vs 81.8 us with the rotation, but the 8-pair step 3620 vs 3638 pairs/s (same box, twice)
+    static const bool ping = getenv("HESIC_N2W_PING") != nullptr;
+    if (ping && out1 && !one_wave) {
+        static bool pattr = false;
+        if (!pattr) {
+            (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 1, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1, 1, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            pattr = true;
+        }
+        if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 1, 8, 1>), g, blk, lds, st, a);
+        else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1, 8, 1>), g, blk, lds, st, a);
+        HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
+    }
+    if (one_wave && out1 && !inverse) {
+        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const unsigned g4 = (unsigned)((tiles + 3) / 4 < 256 ? (tiles + 3) / 4 : 256);
+        hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1, 4>), dim3(g4), dim3(256), lds, st, a);
+        HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
+    }
     if (out1) {
         if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 1>), g, blk, lds, st, a);
         else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1>), g, blk, lds, st, a);
