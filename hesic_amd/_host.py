@@ -174,6 +174,11 @@ class RangeDecoder:
         if rc:
             raise ValueError("RangeDecoder.decode_grid: bad table")
 
+    def grid_callback(self):
+        """(function address, decoder handle) of ``hesic_rc_decoder_decode_grid`` for a C caller that drives the decoder itself
+        (``hesic_joint_decode_groups`` of the HIP library: the HESIC+ wavefront walk without a Python step per group)."""
+        return C.cast(lib().hesic_rc_decoder_decode_grid, C.c_void_p), self._h
+
     def decode_grid(self, cdf, n_outer, n_inner, row_step_outer, row_step_inner):
         """Symbols (p, q), p outer, under table row ``p * row_step_outer + q * row_step_inner`` of ``cdf`` (rows, n): (n_outer, n_inner) int32."""
         import numpy as np

@@ -76,6 +76,7 @@ _SIGS = {
     "hesic_joint_step": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp], _i32),
     "hesic_memcpy_async": ([_vp, _vp, C.c_size_t, _i32, _vp], _i32),
     "hesic_stream_synchronize": ([_vp], _i32),
+    "hesic_joint_decode_groups": ([_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_ssim_scale": ([_vp, _P(_i64), _vp, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_avgpool2_pad": ([_vp, _P(_i64), _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_shaped": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),

@@ -5,6 +5,9 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -821,6 +824,56 @@ extern "C" int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int 
     if (e != hipSuccess) { hesic_set_error("memcpy_async: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+// The whole decode walk of one view behind one call (models.HSICJoint._decode_view_graphed): per group -- previous symbols up, the group's
+// captured device step (hipGraphExec_t of torch's graph), table launch, tables down, wait, range-decode through the caller's decoder
+// (libhesic_host.so: hesic_rc_decoder_decode_grid) into the pinned symbol buffer.  Six Python -> C crossings per group became none; the
+// wait polls hipStreamQuery (a blocked hipStreamSynchronize wakes up through an interrupt).
+extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size, void* const* graph_exec, const hesic_gmm_desc* descs,
+                                         void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
+                                         uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder,
+                                         int spin, void* stream) {
+    HESIC_CHECK_ARG(n_groups >= 0 && group_size && graph_exec && descs && scale_mean && channels && n_channels > 0 && minmax >= 0 && tab_dev &&
+                        tab_host && sym_dev && sym_host && decode && decoder,
+                    "joint_decode_groups: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_tab = 2 * minmax + 2;
+    int nprev = 0;
+    auto fail = [](const char* what, hipError_t e) { hesic_set_error("joint_decode_groups: %s: %s", what, hipGetErrorString(e)); return (int)e; };
+    static const bool timing = getenv("HESIC_JOINT_TIMING") != nullptr;      // stderr: where the wall time of the walk went
+    double t_submit = 0, t_wait = 0, t_decode = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int g = 0; g < n_groups; ++g) {
+        const int P = group_size[g];
+        hipError_t e;
+        const double t0 = timing ? now() : 0;
+        if (nprev && sym_dev != sym_host && (e = hipMemcpyAsync(sym_dev, sym_host, (size_t)nprev * n_channels * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
+            return fail("symbols up", e);
+        if ((e = hipGraphLaunch((hipGraphExec_t)graph_exec[g], st)) != hipSuccess) return fail("graph launch", e);
+        if (int rc = hesic_gmm_cdf(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, tab_dev, stream)) return rc;
+        if (tab_dev != tab_host && (e = hipMemcpyAsync(tab_host, tab_dev, (size_t)n_channels * P * n_tab * 4, hipMemcpyDeviceToHost, st)) != hipSuccess)
+            return fail("tables down", e);
+        const double t1 = timing ? now() : 0;
+        if (spin) {
+            while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+        } else {
+            e = hipStreamSynchronize(st);
+        }
+        if (e != hipSuccess) return fail("wait", e);
+        const double t2 = timing ? now() : 0;
+        if (int rc = decode(decoder, tab_host, P, n_channels, 1, P, n_tab, sym_host)) { hesic_set_error("joint_decode_groups: range decoder failed (%d) in group %d", rc, g); return HESIC_EINVAL; }
+        if (timing) { const double t3 = now(); t_submit += t1 - t0; t_wait += t2 - t1; t_decode += t3 - t2; }
+        nprev = P;
+    }
+    if (nprev && sym_dev != sym_host) {
+        const hipError_t e = hipMemcpyAsync(sym_dev, sym_host, (size_t)nprev * n_channels * 4, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail("symbols up", e);
+    }
+    if (timing)
+        fprintf(stderr, "joint_decode_groups: %d groups, %d channels, tables of %d: submit %.0f us, wait %.0f us, host decode %.0f us\n", n_groups, n_channels,
+                n_tab, t_submit, t_wait, t_decode);
+    return 0;
+}
+
 extern "C" int hesic_stream_synchronize(void* stream) {
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { hesic_set_error("stream_synchronize: %s", hipGetErrorString(e)); return (int)e; }

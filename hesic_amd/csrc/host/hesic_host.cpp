@@ -1,6 +1,7 @@
 // Host-side entropy-coding helpers (see hesic_host.h).  Sequential by nature (rANS is a serial state
 // machine); they sit on the bit-stream path, not on the throughput path.
 #include "hesic_host.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <cstring>
@@ -256,11 +257,12 @@ extern "C" int hesic_rc_decoder_decode_grid(hesic_rc_decoder* d, const uint32_t*
     auto row_of = [&](int64_t p, int64_t q) { return cdf + (p * row_step_outer + q * row_step_inner) * stride; };
     const int64_t n = n_outer * n_inner;
     const int lines = (stride * 4 + 63) / 64;
+    static const int ahead = [] { const char* e = getenv("HESIC_RC_PREFETCH_AHEAD"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t* c = row_of(po, qi);
         {
-            int64_t q2 = qi + 2, p2 = po;
-            if (q2 >= n_inner) { q2 -= n_inner; ++p2; }
+            int64_t q2 = qi + ahead, p2 = po;
+            while (q2 >= n_inner) { q2 -= n_inner; ++p2; }
             if (p2 < n_outer) {
                 const char* nx = (const char*)row_of(p2, q2);
                 for (int l = 0; l < lines; ++l) __builtin_prefetch(nx + 64 * l, 0, 1);

@@ -865,6 +865,9 @@ def _nhwc_rows(t):
 # 512^2 but 7.7e-4 vs 6.3e-4 on the 256^2 golden -- not worth a quarter of the margin to the 1e-3 bar
 X3C2_TWO_PRODUCT_TAIL = _os.environ.get("HESIC_X3C2_TAIL2") is not None
 WAVEFRONT_GRAPHS = _os.environ.get("HESIC_WAVEFRONT_GRAPHS", "1") != "0"      # A/B switch: 0 = round 3's per-group launches from Python
+# A/B switch: 1 = the device reads the decoded symbols from, and writes the tables into, pinned host memory itself (no copy nodes)
+WAVEFRONT_ZEROCOPY = _os.environ.get("HESIC_WAVEFRONT_ZEROCOPY", "1") != "0"
+WAVEFRONT_C_LOOP = _os.environ.get("HESIC_WAVEFRONT_C_LOOP", "1") != "0"      # A/B switch: 0 = the group loop in Python (six C calls per group)
 PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
 
@@ -1246,17 +1249,21 @@ class HSICJoint(StereoCompressionModel):
               "par": torch.zeros((yh * yw, c_par), dtype=cdt, device=dev),
               "ext": torch.zeros((yh * yw, M), dtype=cdt, device=dev) if which == 2 else None,
               "all_centre": torch.from_numpy(centre.astype(np.int64)).to(dev), "all_rows": torch.from_numpy(all_pix.astype(np.int64)).to(dev),
-              "pos": torch.zeros(1, dtype=torch.int64, device=dev), "state": torch.zeros(3, dtype=torch.int32, device=dev),
-              "channels": torch.zeros(M, dtype=torch.int32, device=dev), "sym": torch.zeros(pmax * M, dtype=torch.int32, device=dev),
+              "pos": torch.zeros(1, dtype=torch.int64, device=dev), "cfg": torch.zeros(4 + M, dtype=torch.int32, device=dev),
+              "cfg_pin": torch.zeros(4 + M, dtype=torch.int32).pin_memory(), "tab": None,
+              "sym": torch.zeros(pmax * M, dtype=torch.int32, device=dev),
               "prev_centre": torch.zeros(pmax, dtype=torch.int64, device=dev),
               "crops": torch.zeros((pmax, 5, 5, M), dtype=cdt, device=dev), "feat": torch.zeros((pmax, c_feat), dtype=cdt, device=dev),
               "sym_pin": torch.zeros(pmax * M, dtype=torch.int32).pin_memory()}
         st["y_flat"] = st["y_pad"].permute(0, 2, 3, 1).reshape((yh + 4) * Wp, M)
+        st["state"], st["channels"] = st["cfg"][:3], st["cfg"][4:]          # {nprev, C, minmax} and the coded channels: one upload per view
         cache[key] = st
         return st
 
     def _wavefront_kernel(self, st, P):
-        L.call("hesic_joint_step", L.ptr(st["y_flat"]), L.dt(st["y_flat"]), self.M, st["Wp"], L.ptr(st["sym"]), L.ptr(st["prev_centre"]), L.ptr(st["state"]),
+        import ctypes as C
+        sym = C.c_void_p(st["sym_pin"].data_ptr()) if WAVEFRONT_ZEROCOPY else L.ptr(st["sym"])      # pinned host memory is device-addressable
+        L.call("hesic_joint_step", L.ptr(st["y_flat"]), L.dt(st["y_flat"]), self.M, st["Wp"], sym, L.ptr(st["prev_centre"]), L.ptr(st["state"]),
                L.ptr(st["channels"]), L.ptr(st["all_centre"]), L.ptr(st["all_rows"]), L.ptr(st["pos"]), int(P), L.ptr(st["crops"]), L.ptr(st["par"]),
                st["c_par"], L.ptr(st["ext"]), st["e_off"], L.ptr(st["feat"]), st["c_feat"], L.stream())
 
@@ -1302,31 +1309,58 @@ class HSICJoint(StereoCompressionModel):
         if extra is not None:
             st["ext"].copy_(_nhwc_rows(extra))
         st["pos"].zero_()
-        st["state"].copy_(torch.tensor([0, Cn, minmax], dtype=torch.int32))
-        st["channels"][:Cn].copy_(torch.tensor(channels, dtype=torch.int32))
+        cfg = st["cfg_pin"]
+        cfg[0], cfg[1], cfg[2] = 0, Cn, int(minmax)
+        cfg[4:4 + Cn] = torch.as_tensor(channels, dtype=torch.int32)
+        st["cfg"].copy_(cfg, non_blocking=True)
         ch_dev = st["channels"][:Cn]
         pmax = st["pmax"]
-        tab_dev = torch.empty((Cn * pmax, n_tab), dtype=torch.int32, device=dev)
-        tab_pin = torch.empty((Cn * pmax, n_tab), dtype=torch.int32).pin_memory()
+        if st["tab"] is None or st["tab"][0].shape[1] < n_tab:              # table buffers (device + pinned) kept with the state: pinning costs ~0.1 ms a call
+            st["tab"] = (torch.empty((M * pmax, n_tab), dtype=torch.int32, device=dev), torch.empty((M * pmax, n_tab), dtype=torch.int32).pin_memory())
+        tab_dev, tab_pin = st["tab"]
         descs = {P: L.GmmDesc(1, P, M, 1, L.F32, 0, 2 * M, 0, M, float(bound), 0.0) for P in set(st["groups"])}
-        # raw addresses once; per step: copy the previous symbols up, replay, table launch, copy the tables down, wait, decode
         stream = L.stream()
         sym_dev, sym_host = L.ptr(st["sym"]), C.c_void_p(st["sym_pin"].data_ptr())
         tab_d, tab_h = L.ptr(tab_dev), C.c_void_p(tab_pin.data_ptr())
-        ch_p, call, raw = L.ptr(ch_dev), L.call, dec.decode_grid_raw
-        nprev = 0
-        for P in st["groups"]:
-            if nprev:
+        zc = WAVEFRONT_ZEROCOPY
+        if zc:                                  # same address on both sides: the copies fall away (hesic_joint_decode_groups skips them too)
+            sym_dev, tab_d = sym_host, tab_h
+        ch_p = L.ptr(ch_dev)
+        groups = st["groups"]
+        if WAVEFRONT_C_LOOP:
+            # the whole walk in one C call (hesic_joint_decode_groups): per group the captured device step, the table launch, the two copies,
+            # a polled wait and the host range decoder through its C entry point -- no Python between the groups
+            n = len(groups)
+            fn, handle = dec.grid_callback()
+            execs = (C.c_void_p * n)(*[st["graphs"][P][0].raw_cuda_graph_exec() for P in groups])
+            outs = (C.c_void_p * n)(*[st["graphs"][P][1].data_ptr() for P in groups])
+            dsc = (L.GmmDesc * n)(*[descs[P] for P in groups])
+            sizes = (C.c_int32 * n)(*groups)
+            try:
+                L.call("hesic_joint_decode_groups", n, sizes, execs, dsc, outs, ch_p, Cn, int(minmax), tab_d, tab_h, sym_dev, sym_host, fn, handle,
+                       1, stream)
+            except RuntimeError as e:
+                if "range decoder failed" in str(e):
+                    raise ValueError("RangeDecoder.decode_grid: bad table") from e
+                raise
+        else:
+            # per step: copy the previous symbols up, replay, table launch, copy the tables down, wait, decode
+            call, raw = L.call, dec.decode_grid_raw
+            nprev = 0
+            for P in groups:
+                if nprev and not zc:
+                    call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
+                g, sm = st["graphs"][P]
+                g.replay()
+                smp = L.ptr(sm)
+                call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
+                if not zc:
+                    call("hesic_memcpy_async", tab_h, tab_d, Cn * P * n_tab * 4, 2, stream)
+                call("hesic_stream_synchronize", stream)
+                raw(tab_h, n_tab, P, Cn, 1, P, sym_host)                                             # (P, Cn) symbols, pixel-major, into the pinned buffer
+                nprev = P
+            if not zc:
                 call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
-            g, sm = st["graphs"][P]
-            g.replay()
-            smp = L.ptr(sm)
-            call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
-            call("hesic_memcpy_async", tab_h, tab_d, Cn * P * n_tab * 4, 2, stream)
-            call("hesic_stream_synchronize", stream)
-            raw(tab_h, n_tab, P, Cn, 1, P, sym_host)                                             # (P, Cn) symbols, pixel-major, into the pinned buffer
-            nprev = P
-        call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
         self._wavefront_kernel(st, 0)                              # the last group's symbols
         return st["y_pad"][:, :, 2:-2, 2:-2].contiguous(memory_format=torch.channels_last)
 

@@ -531,6 +531,19 @@ int hesic_joint_step(void* y_rows, int dtype, int M, int Wp, const int32_t* sym,
 /* Host-loop helpers of the decode walk: hipMemcpyAsync (kind 1 = host -> device, 2 = device -> host; pinned host memory) and
  * hipStreamSynchronize behind the same error plumbing.                                                                               */
 int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream);
+/* The decode walk of one view of HESIC+ (newnet1_joint.py:1190-1260 regrouped into wavefronts) as ONE call: for each of the n_groups groups
+ * (group_size[g] pixels) -- copy the previous group's symbols (sym_host, pinned) to sym_dev, launch graph_exec[g] (a hipGraphExec_t: the
+ * group's captured device step, whose output scale_mean[g] is [P][2M] fp32 rows), hesic_gmm_cdf(descs[g]) into tab_dev, copy the tables to
+ * tab_host (pinned), wait (spin != 0: poll hipStreamQuery), and call decode(decoder, tab_host, P, n_channels, 1, P, 2*minmax+2, sym_host)
+ * -- the signature of hesic_rc_decoder_decode_grid (libhesic_host.so).  sym_dev == sym_host / tab_dev == tab_host (pinned, device-addressable
+ * memory used by the kernels directly) skips the respective copies.  The last group's symbols are copied up before returning; the
+ * caller scatters them (hesic_joint_step with P = 0).  A decoder error or a HIP error ends the walk with a non-zero return.              */
+typedef int (*hesic_decode_grid_fn)(void* decoder, const uint32_t* cdf, int64_t n_outer, int64_t n_inner, int64_t row_step_outer,
+                                    int64_t row_step_inner, int32_t stride, int32_t* symbols_out);
+int hesic_joint_decode_groups(int n_groups, const int32_t* group_size, void* const* graph_exec, const hesic_gmm_desc* descs,
+                              void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
+                              uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder, int spin,
+                              void* stream);
 int hesic_stream_synchronize(void* stream);
 
 /* ------------------------------------------------------------------ MS-SSIM (row M: the second published quality metric)
