@@ -733,10 +733,10 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                             v[e] = apply_act(acc[i][j][4 * g + e] + bv[e], act_eff);
                             if (a.y_abs) v[e] = fabsf(v[e]);
                         }
-                        u32x2 o = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
-                        if (half)
-                            o = u32x2{pack_h2(v[0] - h2f_lo(o.x), v[1] - h2f_hi(o.x)),
-                                      pack_h2(v[2] - h2f_lo(o.y), v[3] - h2f_hi(o.y))};
+                        uint32_t h0, l0, h1, l1;
+                        split_h2(v[0], v[1], h0, l0);
+                        split_h2(v[2], v[3], h1, l1);
+                        const u32x2 o = half ? u32x2{l0, l1} : u32x2{h0, h1};
                         *(u32x2*)(smem + pr * OROW + cl * 2) = o;
                     }
                 }
@@ -785,10 +785,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                 for (int ks = 0; ks < 8; ++ks) gq[i][ks] = gfr[((wm * MI + i) * 8 + ks) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
-        auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) {
-            hi = pack_h2(p, q);
-            lo = pack_h2(p - h2f_lo(hi), q - h2f_hi(hi));
-        };
+        auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) { split_h2(p, q, hi, lo); };
         asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
 #pragma unroll
         for (int i = 0; i < MI; ++i)

@@ -20,6 +20,10 @@ def timed(fn, n=60):
 def eager(i):
     with torch.no_grad(): return net(*pool[i % 4])
 res = {"model": kind, "batch": B, "eager_ms": round(timed(eager), 3)}
+torch.cuda.synchronize(); t = time.perf_counter()
+for i in range(8): eager(i)
+res["eager_host_issue_ms"] = round((time.perf_counter() - t) / 8 * 1e3, 3)          # host time to issue a forward (queue not waited for)
+torch.cuda.synchronize()
 g1 = models.GraphedForward(net, *pool[0], with_metrics=False)
 res["graph_ms"] = round(timed(lambda i: g1(*pool[i % 4])), 3)
 del g1
