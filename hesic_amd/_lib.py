@@ -157,6 +157,9 @@ _SIGS = {
     "hesic_conv2d_forward_hilo_w1": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, C.c_size_t, _vp], _i32),
     "hesic_conv2d_hilo_ws_bytes": ([_P(ConvDesc)], C.c_size_t),
     "hesic_gdn_pack_params_lo": ([_vp, _vp, _i32, _vp], _i32),
+    "hesic_gdn_pack_params_batched": ([_vp, _i32, _vp], _i32),
+    "hesic_spatial_max_backward": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_rd_loss_combine": ([_vp, C.c_double, C.c_int64, C.c_int64, _vp, _vp], _i32),
     "hesic_sconv_pack_weight_image_hilo": ([_vp, _vp, _vp, _vp], _i32),
     "hesic_sconv_pack_weight_image_hilo_out1": ([_vp, _vp, _vp, _vp], _i32),
     "hesic_sconv2d_gdn_forward_hilo": ([_P(SConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp], _i32),

@@ -1539,9 +1539,8 @@ int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 // gamma' = max(gamma, 2^-18)^2 - 2^-36 as bf16, twice: [0, 128*128) in the LDS image order of the image-side fused kernel
 // (sconv_n2w_gdn_kernel), [128*128, 2*128*128) in MFMA A-fragment order for igemm_glds_kernel -- fragment (rb, ks) holds,
 // for lane l, gamma'[rb*32 + (l & 31)][ks*16 + (l >> 5)*8 + 0..7].  beta' likewise (fp32).
-__global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
-                                h16_t* __restrict__ gp, float* __restrict__ bp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte slot (8 values) per thread: 128 rows x 16 slots
+__device__ __forceinline__ void gdn_pack_slot(int i, const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
+                                              h16_t* __restrict__ gp, float* __restrict__ bp) {
     if (i >= 128 * 16) return;
     const int row = i >> 4, slot = i & 15;
     const float ped = 1.0f / 68719476736.0f, gb = 1.0f / 262144.0f;
@@ -1556,6 +1555,17 @@ __global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __r
         const float t = fmaxf(beta[i], beta_bound);
         bp[i] = t * t - ped;
     }
+}
+
+__global__ void gdn_pack_kernel(const float* __restrict__ beta, const float* __restrict__ gamma, float beta_bound,
+                                h16_t* __restrict__ gp, float* __restrict__ bp) {
+    gdn_pack_slot(blockIdx.x * blockDim.x + threadIdx.x, beta, gamma, beta_bound, gp, bp);      // one 16-byte slot (8 values) per thread: 128 rows x 16 slots
+}
+
+// every GDN of a model in one launch (the training step's repack behind the optimiser update): 8 blocks per job
+__global__ void gdn_pack_batched_kernel(const hesic_gdn_pack_job* __restrict__ jobs) {
+    const hesic_gdn_pack_job j = jobs[blockIdx.x >> 3];
+    gdn_pack_slot((blockIdx.x & 7) * blockDim.x + threadIdx.x, j.beta, j.gamma, sqrtf(j.beta_min + 1.0f / 68719476736.0f), (h16_t*)j.gamma_packed, j.beta_packed);
 }
 
 // lo half of gamma' for the hi/lo GDN epilogue, MFMA A-fragment order (as the second half of gdn_pack_kernel's buffer):
@@ -1640,6 +1650,12 @@ extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, floa
                        (h16_t*)gamma_packed, beta_packed);
     HESIC_LAUNCH_RETURN("gdn_pack_params");
 }   // when set, hesic_conv2d_forward only reports its tile choice
+
+extern "C" int hesic_gdn_pack_params_batched(const hesic_gdn_pack_job* jobs_device, int n_jobs, void* stream) {
+    HESIC_CHECK_ARG(jobs_device && n_jobs > 0 && n_jobs < (1 << 20), "gdn_pack_params_batched: bad arguments");
+    hipLaunchKernelGGL(gdn_pack_batched_kernel, dim3(8 * n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+    HESIC_LAUNCH_RETURN("gdn_pack_params_batched");
+}
 
 extern "C" int hesic_gdn_pack_params_lo(const float* gamma, void* gamma_lo_packed, int C, void* stream) {
     HESIC_CHECK_ARG(gamma && gamma_lo_packed, "gdn_pack_params_lo: null pointer");

@@ -511,6 +511,35 @@ extern "C" int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int
     HESIC_LAUNCH_RETURN("copy_channels");
 }
 
+// backward of spatial_max: dx[b, p, c] = (p == argmax[b, c]) ? g[b, c] * (leaky && out[b, c] <= 0 ? 0.01 : 1) : 0 -- every element of dx
+// written once, coalesced (the tensor-op form was a fill, a compare, a where, a cast and a scatter: seven launches)
+template <typename T>
+__global__ void spatial_max_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out, const int32_t* __restrict__ arg, T* __restrict__ dx,
+                                       int64_t n, int HW, int C, int leaky) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int p = (int)(r % HW), b = (int)(r / HW);
+        float v = 0.f;
+        if (arg[b * C + c] == p) {
+            const float gv = g[b * C + c];
+            v = (leaky && !(out[b * C + c] > 0.f)) ? 0.01f * gv : gv;
+        }
+        elem<T>::st(dx + i, v);
+    }
+}
+
+extern "C" int hesic_spatial_max_backward(const float* g, const float* out, const int32_t* argmax, void* dx, int B, int HW, int C, int dtype, int leaky,
+                                          void* stream) {
+    HESIC_CHECK_ARG(g && out && argmax && dx && B > 0 && HW > 0 && C > 0 && (dtype == HESIC_H16 || dtype == HESIC_F32), "spatial_max_backward: bad arguments");
+    const int64_t n = (int64_t)B * HW * C;
+    if (dtype == HESIC_H16)
+        hipLaunchKernelGGL(spatial_max_bwd_kernel<h16_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, g, out, argmax, (h16_t*)dx, n, HW, C, leaky);
+    else
+        hipLaunchKernelGGL(spatial_max_bwd_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, g, out, argmax, (float*)dx, n, HW, C, leaky);
+    HESIC_LAUNCH_RETURN("spatial_max_backward");
+}
+
 extern "C" int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW, int C, int dtype, int leaky, void* stream) {
     HESIC_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "spatial_max: bad arguments");
     if (!argmax && HW >= 256) {
@@ -642,6 +671,21 @@ extern "C" int hesic_softmax_k_backward(const float* weights, const float* g, fl
     HESIC_CHECK_ARG(weights && g && dlogits && B > 0 && K > 0 && M > 0, "softmax_k_backward: bad arguments");
     hipLaunchKernelGGL(softmax_k_bwd_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights, g, dlogits, B, K, M);
     HESIC_LAUNCH_RETURN("softmax_k_backward");
+}
+
+// RateDistortionLoss from its three device-side sums (newtrain1.py:37-56): bpp = -acc[0] / npix, mse = (acc[1] + acc[2]) / numel,
+// loss = lambda_255sq * mse + bpp -- one single-thread launch instead of nine one-element tensor ops (each a ~5 us graph node)
+__global__ void rd_loss_combine_kernel(const double* __restrict__ acc, double lambda_255sq, double inv_npix, double inv_numel, float* __restrict__ out) {
+    const double bpp = -acc[0] * inv_npix, mse = (acc[1] + acc[2]) * inv_numel;
+    out[0] = (float)(lambda_255sq * mse + bpp);
+    out[1] = (float)bpp;
+    out[2] = (float)mse;
+}
+
+extern "C" int hesic_rd_loss_combine(const double* acc, double lambda_255sq, int64_t npix, int64_t numel, float* out3, void* stream) {
+    HESIC_CHECK_ARG(acc && out3 && npix > 0 && numel > 0, "rd_loss_combine: bad arguments");
+    hipLaunchKernelGGL(rd_loss_combine_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, lambda_255sq, 1.0 / (double)npix, 1.0 / (double)numel, out3);
+    HESIC_LAUNCH_RETURN("rd_loss_combine");
 }
 
 extern "C" int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream) {

@@ -246,6 +246,8 @@ def invalidate_weight_cache():
 _train_pack_cache = False
 _pack_registry = []            # entries: dict(weight, mask, wp, dims..., owner, key)
 _pack_table = None             # (signature, device job table, n_jobs, total_blocks)
+_gdn_registry = []             # PackedGdn objects holding a persistent training pack
+_gdn_table = None              # (signature, device job table, n_jobs)
 
 
 def train_pack_cache(on):
@@ -254,9 +256,36 @@ def train_pack_cache(on):
     return prev
 
 
+def _repack_gdns():
+    """The registered GDN parameter packs (PackedGdn, Trainer step) refreshed in one launch."""
+    global _gdn_table
+    ents = [g for g in _gdn_registry if g._train is not None and g._train["beta"]() is not None and g._train["gamma"]() is not None]
+    if len(ents) != len(_gdn_registry):
+        _gdn_registry[:] = ents
+    if not ents:
+        return 0
+    import numpy as np
+    sig = tuple((g._train["beta"]().data_ptr(), g._train["gamma"]().data_ptr(), g._train["gp"].data_ptr()) for g in ents)
+    if _gdn_table is None or _gdn_table[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("repack_all: the set of packed GDN parameters changed during HIP-graph capture; run a warm-up step first")
+        jobs = np.zeros(len(ents), dtype=np.dtype([("beta", "<u8"), ("gamma", "<u8"), ("gp", "<u8"), ("bp", "<u8"), ("beta_min", "<f4"), ("pad", "<i4")]))
+        for i, g in enumerate(ents):
+            t = g._train
+            jobs[i] = (t["beta"]().data_ptr(), t["gamma"]().data_ptr(), t["gp"].data_ptr(), t["bp"].data_ptr(), t["beta_min"], 0)
+        _gdn_table = (sig, torch.from_numpy(jobs.view(np.uint8).copy()).to(ents[0]._train["gp"].device), len(ents))
+    _, table, n = _gdn_table
+    L.call("hesic_gdn_pack_params_batched", L.ptr(table), n, L.stream())
+    for g in ents:
+        t = g._train
+        t["tag"] = (t["beta"]().data_ptr(), t["gamma"]().data_ptr(), t["beta"]()._version, t["gamma"]()._version, _cache_epoch)
+    return n
+
+
 def repack_all():
-    """Refresh every registered packed weight from its parameter in one launch and mark it current."""
+    """Refresh every registered packed weight (and GDN parameter pack) from its parameter in one launch each and mark it current."""
     global _pack_table
+    _repack_gdns()
     ents = [e for e in _pack_registry if e["weight"]() is not None]
     if len(ents) != len(_pack_registry):
         _pack_registry[:] = ents
@@ -620,11 +649,27 @@ class PackedGdn:
 
     def __init__(self):
         self._hit = None
+        self._train = None
 
     def get(self, beta, gamma, beta_min):
         tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
         if self._hit is not None and self._hit[0] == tag and not torch.is_grad_enabled():
             return self._hit[1], self._hit[2]
+        if (_train_pack_cache and torch.is_grad_enabled() and isinstance(beta, torch.nn.Parameter) and isinstance(gamma, torch.nn.Parameter)
+                and gamma.dtype == torch.float32 and gamma.is_contiguous() and beta.is_contiguous()):
+            # Trainer step: a persistent pack, refreshed with every other GDN's by ONE launch behind the optimiser update (repack_all) --
+            # 15 pack launches a step otherwise
+            t = self._train
+            if t is not None and t["tag"] == tag and t["gp"].dtype == _h16() and t["gp"].device == gamma.device:
+                return t["gp"], t["bp"]
+            import weakref
+            gp = torch.empty(2 * 128 * 128, dtype=_h16(), device=gamma.device)
+            bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
+            L.call("hesic_gdn_pack_params", L.ptr(beta), L.ptr(gamma), float(beta_min), L.ptr(gp), L.ptr(bp), 128, L.stream())
+            self._train = {"tag": tag, "gp": gp, "bp": bp, "beta": weakref.ref(beta), "gamma": weakref.ref(gamma), "beta_min": float(beta_min)}
+            if self not in _gdn_registry:
+                _gdn_registry.append(self)
+            return gp, bp
         gp = torch.empty(2 * 128 * 128, dtype=_h16(), device=gamma.device)
         bp = torch.empty(128, dtype=torch.float32, device=gamma.device)
         L.call("hesic_gdn_pack_params", L.ptr(_c(beta)), L.ptr(_c(gamma)), float(beta_min), L.ptr(gp),
@@ -1851,11 +1896,11 @@ class _SpatialMaxFn(torch.autograd.Function):
         arg, out = ctx.saved_tensors
         shape, dtype, leaky = ctx.meta
         B, Cc, H, W = shape
-        g = g.reshape(B, Cc).to(torch.float32)
-        if leaky:
-            g = torch.where(out > 0, g, 0.01 * g)
-        dx = _zeros((B, H * W, Cc), dtype, g.device)
-        dx.scatter_(1, arg.long().unsqueeze(1), g.to(dtype).unsqueeze(1))
+        g = g.reshape(B, Cc)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
+        dx = torch.empty((B, H * W, Cc), dtype=dtype, device=g.device)
+        L.call("hesic_spatial_max_backward", L.ptr(g), L.ptr(out), L.ptr(arg), L.ptr(dx), B, H * W, Cc, L.dt(dtype), int(leaky), L.stream())
         return dx.reshape(B, H, W, Cc).permute(0, 3, 1, 2), None
 
 
@@ -1992,14 +2037,19 @@ class _RdLossFn(torch.autograd.Function):
             sum_log2(l, acc[0:1])
         sum_sq_diff(x1_hat, x1, acc[1:2])
         sum_sq_diff(x2_hat, x2, acc[2:3])
-        bpp = -acc[0] / npix
-        mse = (acc[1] + acc[2]) / (B * Cc * H * W)
-        loss = lmbda * 255.0 ** 2 * mse + bpp
+        if x1.is_cuda:
+            out3 = torch.empty(3, dtype=torch.float32, device=x1.device)
+            L.call("hesic_rd_loss_combine", L.ptr(acc), float(lmbda) * 255.0 ** 2, npix, B * Cc * H * W, L.ptr(out3), L.stream())
+            loss, bpp, mse = out3[0], out3[1], out3[2]
+        else:
+            bpp = -acc[0] / npix
+            mse = (acc[1] + acc[2]) / (B * Cc * H * W)
+            loss = (lmbda * 255.0 ** 2 * mse + bpp).float()
+            bpp, mse = bpp.float(), mse.float()
         ctx.save_for_backward(x1, x2, x1_hat, x2_hat, *liks)
         ctx.meta = (float(lmbda), npix, B * Cc * H * W, -1.0 / (math.log(2.0) * npix))
-        bpp, mse = bpp.float(), mse.float()
         ctx.mark_non_differentiable(bpp, mse)        # reported values (the reference logs them); only `loss` carries a gradient
-        return loss.float(), bpp, mse
+        return loss, bpp, mse
 
     @staticmethod
     def backward(ctx, g_loss, g_bpp, g_mse):

@@ -90,6 +90,14 @@ int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, const void* w_
  * (NonNegativeParametrizer applied).                                                                                   */
 int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                           int C, void* stream);
+/* The same for every 128-channel GDN of a model in ONE launch: a table of jobs in device memory (the training step refreshes all its
+ * packed GDN parameters behind the optimiser update, next to hesic_pack_conv_weights_batched).                                      */
+typedef struct {
+    const float* beta; const float* gamma;     /* reparametrised-domain parameters (128, 128 x 128) */
+    void* gamma_packed; float* beta_packed;    /* as hesic_gdn_pack_params */
+    float beta_min; int reserved;
+} hesic_gdn_pack_job;
+int hesic_gdn_pack_params_batched(const hesic_gdn_pack_job* jobs_device, int n_jobs, void* stream);
 int hesic_conv2d_gdn_forward(const hesic_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* gamma_packed, const float* beta_packed, int inverse, void* y, void* stream);
 /* Training form: additionally stores the conv output (conv + bias, bf16, same geometry as y) that GDN's backward needs
@@ -413,6 +421,9 @@ int hesic_copy_channels(const void* x, void* y, int64_t P, int C, int x_pix_stri
  * for the backward.  out fp32 (B,C).                                                                  */
 int hesic_spatial_max(const void* x, float* out, int32_t* argmax, int B, int HW, int C, int dtype, int leaky,
                       void* stream);
+/* Its backward: dx (B,HW,C) of `dtype`, written whole -- g (B,C) fp32 at the arg-max pixel (x 0.01 where leaky and out <= 0), 0 elsewhere. */
+int hesic_spatial_max_backward(const float* g, const float* out, const int32_t* argmax, void* dx, int B, int HW, int C, int dtype, int leaky,
+                               void* stream);
 /* The 1x1 conv + softmax-over-K head (newnet1.py:500,510-512): logits (B,K*M) = W (KM,KM) @ pooled + b;
  * weights[b, k*M+m] = softmax_k.  All fp32.                                                          */
 int hesic_mix_weights_forward(const float* pooled, const float* w, const float* bias, float* logits, float* weights,
@@ -481,6 +492,9 @@ int hesic_softmax_k_backward(const float* weights, const float* g, float* dlogit
 /* -------------------------------------------------------------------------------- reductions (rows T,M)
  * out[0] += sum(log2(lik)) over n fp32 values (bits = -out[0]);  fp64 accumulator on device.          */
 int hesic_sum_log2(const float* lik, int64_t n, double* out, void* stream);
+/* The criterion's three numbers from the sums above (newtrain1.py:37-56): acc = {sum log2 lik, sum sq diff view 1, view 2} (fp64, device);
+ * out3 = {loss, bpp, mse} fp32 with bpp = -acc[0]/npix, mse = (acc[1]+acc[2])/numel, loss = lambda_255sq * mse + bpp.                 */
+int hesic_rd_loss_combine(const double* acc, double lambda_255sq, int64_t npix, int64_t numel, float* out3, void* stream);
 /* out[0] += sum((a-b)^2) with a, b given by element strides over a (B,C,H,W) index space.             */
 int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
                       const int64_t b_strides[4], int B, int C, int H, int W, double* out, void* stream);
