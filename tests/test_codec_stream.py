@@ -459,3 +459,52 @@ def test_gpu_payload_names_its_table_mode_and_a_mismatched_decoder_raises(tmp_pa
     finally:
         hesic_amd.set_compute_dtype(torch.bfloat16)
         hesic_amd.set_compute_dtype(prev)
+
+
+@pytest.mark.gpu
+def test_gpu_joint_decode_walk_variants_agree(tmp_path, monkeypatch):
+    """The HESIC+ wavefront decode walk has four issue forms -- the group loop in C (``hesic_joint_decode_groups``) or in Python, symbols
+    and tables through pinned memory the kernels address directly or through copies: all four decode one payload to the same latents
+    and reconstructions, bit for bit (what they change is who issues the launches, not what is launched)."""
+    import hesic_amd
+    from hesic_amd import models
+    net = models.HSICJoint()
+    synthetic.fill_state_dict_(net.state_dict())
+    net = net.cuda().eval()
+    net.update(force=True)
+    x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(7, 1, 128, 192))
+    enc = net.compress(x1, x2, Hm, "w", str(tmp_path), order="wavefront")
+    ref = None
+    for c_loop in (True, False):
+        for zero_copy in (True, False):
+            monkeypatch.setattr(models, "WAVEFRONT_C_LOOP", c_loop)
+            monkeypatch.setattr(models, "WAVEFRONT_ZEROCOPY", zero_copy)
+            net.__dict__.pop("_wf_cache", None)          # the captured group graphs hold the symbol buffer's address
+            dec = net.decompress(None, None, Hm, "w", str(tmp_path))
+            for k in ("y1_hat", "y2_hat"):
+                assert torch.equal(dec[k].float().cpu(), enc[k].float().cpu()), (c_loop, zero_copy, k)
+            if ref is None:
+                ref = dec
+            for k in ("x1_hat", "x2_hat"):
+                assert torch.equal(dec[k].cpu(), ref[k].cpu()), (c_loop, zero_copy, k)
+    net.__dict__.pop("_wf_cache", None)
+
+
+@pytest.mark.gpu
+def test_gpu_joint_decode_walk_reports_a_corrupt_payload(tmp_path):
+    """A payload cut short desynchronises the range decoder inside the C walk; the walk must end with a Python exception or a wrong
+    latent map, never hang or crash (the decoder reads zeros past the end of its buffer, like the reference's)."""
+    from hesic_amd import models
+    net = models.HSICJoint()
+    synthetic.fill_state_dict_(net.state_dict())
+    net = net.cuda().eval()
+    net.update(force=True)
+    x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(7, 1, 128, 192))
+    enc = net.compress(x1, x2, Hm, "w", str(tmp_path), order="wavefront")
+    blob = (tmp_path / "w.bin").read_bytes()
+    (tmp_path / "w.bin").write_bytes(blob[:len(blob) // 2])
+    try:
+        dec = net.decompress(None, None, Hm, "w", str(tmp_path))
+    except (ValueError, RuntimeError):
+        return
+    assert not torch.equal(dec["y2_hat"].float().cpu(), enc["y2_hat"].float().cpu())

@@ -479,6 +479,17 @@ def test_hyper_glue(ops_golden):
     xo = x.clone().requires_grad_()
     torch.nn.functional.leaky_relu(torch.amax(xo, dim=(2, 3), keepdim=True), 0.01).sum().backward()
     assert rel_err(xd.grad, xo.grad) < 1e-6
+    # all-negative maxima (the leaky slope in the one-launch backward) under a random gradient, 16-bit storage included
+    xn = -x.abs() - 0.1
+    gsm = rnd("hg_gsm", (3, 960, 1, 1), -1, 1)
+    xo = xn.clone().requires_grad_()
+    torch.nn.functional.leaky_relu(torch.amax(xo, dim=(2, 3), keepdim=True), 0.01).backward(gsm)
+    for dt_ in (torch.float32, Fn.compute_dtype()):
+        xd = xn.to(DEV, dt_).detach().requires_grad_()
+        Fn.spatial_max(xd, leaky=True).backward(gsm.to(DEV))
+        xr = xn.to(dt_).float().detach().requires_grad_()
+        torch.nn.functional.leaky_relu(torch.amax(xr, dim=(2, 3), keepdim=True), 0.01).backward(gsm)
+        assert rel_err(xd.grad.float(), xr.grad.to(dt_).float()) < 1e-6, dt_
     K, M = 5, 192
     w = rnd("hg_w", (K * M, K * M, 1, 1)) * 0.05
     b = rnd("hg_b", (K * M,))
@@ -1058,3 +1069,33 @@ def test_hilo_analysis_kernels_are_bit_stable_across_launches():
         assert torch.equal(lo0[:, :192].float() + lo0[:, 192:].float() >= 0, torch.ones_like(y0, dtype=torch.bool))      # |y| pairs
     finally:
         Fn.set_compute_dtype(prev)
+
+
+def test_gdn_packs_of_a_training_step_are_refreshed_in_one_launch():
+    """Under ``train_pack_cache`` (the Trainer's step) every GDN keeps a persistent parameter pack and ``repack_all`` refreshes all of
+    them with ONE launch (``hesic_gdn_pack_params_batched``): after the parameters moved, the refreshed packs equal what the
+    single-GDN launch writes, and a later ``get`` in grad mode returns them without packing again."""
+    Fn, _ = _imp()
+    from compressai.layers import GDN
+    prev_dt = Fn.compute_dtype()
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    prev = Fn.train_pack_cache(True)
+    try:
+        gdns = [GDN(128, inverse=bool(i & 1)).to(DEV) for i in range(3)]
+        with torch.enable_grad():
+            first = [g.packer().get(g.beta, g.gamma, g.beta_min) for g in gdns]
+            with torch.no_grad():                        # an optimiser step that does not bump the version counters
+                for i, g in enumerate(gdns):
+                    g.gamma.data.add_(0.01 * (i + 1) * torch.rand(128, 128, device=DEV))
+                    g.beta.data.add_(0.02 * (i + 1))
+            assert Fn._repack_gdns() >= 3
+            again = [g.packer().get(g.beta, g.gamma, g.beta_min) for g in gdns]
+        for (gp0, bp0), (gp1, bp1), g in zip(first, again, gdns):
+            assert gp0.data_ptr() == gp1.data_ptr() and bp0.data_ptr() == bp1.data_ptr()        # the persistent buffers, refreshed in place
+            with torch.no_grad():
+                gp_ref, bp_ref = Fn.PackedGdn().get(g.beta, g.gamma, g.beta_min)
+            assert torch.equal(gp1.view(torch.int16), gp_ref.view(torch.int16)) and torch.equal(bp1, bp_ref)
+    finally:
+        Fn.train_pack_cache(prev)
+        Fn._gdn_registry[:] = [g for g in Fn._gdn_registry if g not in [x.packer() for x in gdns]]
+        hesic_amd.set_compute_dtype(prev_dt)
