@@ -368,8 +368,12 @@ constexpr int CDF_WAVE_MAX = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void gmm_cdf_wave_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
                                                            const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
-                                                           uint32_t* __restrict__ cdf) {
+                                                           uint32_t* __restrict__ cdf, const int32_t* __restrict__ dyn) {
     __shared__ float buf[4][CDF_WAVE_MAX];
+    if (dyn) {          // channel count and alphabet of THIS image from device memory ({_, n_ch, minmax}): the launch sits in a graph captured for any image
+        n_ch = dyn[1]; minmax = dyn[2];
+        if (n_ch <= 0 || minmax < 1 || 2 * minmax + 1 > CDF_WAVE_MAX) return;
+    }
     const int A = 2 * minmax + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* frow = buf[wave];
@@ -674,10 +678,10 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
         const dim3 gw(grid_for(total, 4, 256 * 16));
         if (d->dtype == HESIC_H16)
             hipLaunchKernelGGL(gmm_cdf_wave_kernel<h16_t>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales, (const h16_t*)means, weights,
-                               channels, n_channels, minmax, cdf);
+                               channels, n_channels, minmax, cdf, nullptr);
         else
             hipLaunchKernelGGL(gmm_cdf_wave_kernel<float>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const float*)scales, (const float*)means, weights,
-                               channels, n_channels, minmax, cdf);
+                               channels, n_channels, minmax, cdf, nullptr);
         HESIC_LAUNCH_RETURN("gmm_cdf");
     }
     const dim3 grid(grid_for(total, 128));
@@ -688,6 +692,24 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
         hipLaunchKernelGGL(gmm_cdf_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const float*)scales,
                            (const float*)means, weights, channels, n_channels, minmax, cdf);
     HESIC_LAUNCH_RETURN("gmm_cdf");
+}
+
+// hesic_gmm_cdf with the channel count and the alphabet read on the device (state = {_, n_channels, minmax}, int32): the launch can then sit
+// in a HIP graph that is replayed for images with other channel lists and alphabets (the HESIC+ wavefront step).  Rows are laid out with
+// the image's own 2 * minmax + 2 stride, as hesic_gmm_cdf writes them; alphabets beyond the wave kernel's 1024 entries write nothing.
+extern "C" int hesic_gmm_cdf_dyn(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                                 const int32_t* channels, int max_channels, const int32_t* state, uint32_t* cdf, void* stream) {
+    if (int e = check_gmm(d, "gmm_cdf_dyn")) return e;
+    HESIC_CHECK_ARG(scales && means && channels && cdf && state && max_channels > 0 && b >= 0 && b < d->B, "gmm_cdf_dyn: bad arguments");
+    HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf_dyn: weights required for K > 1");
+    const dim3 gw(grid_for((int64_t)max_channels * d->HW, 4, 256 * 16));
+    if (d->dtype == HESIC_H16)
+        hipLaunchKernelGGL(gmm_cdf_wave_kernel<h16_t>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales, (const h16_t*)means, weights,
+                           channels, max_channels, 1, cdf, state);
+    else
+        hipLaunchKernelGGL(gmm_cdf_wave_kernel<float>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const float*)scales, (const float*)means, weights,
+                           channels, max_channels, 1, cdf, state);
+    HESIC_LAUNCH_RETURN("gmm_cdf_dyn");
 }
 
 extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,

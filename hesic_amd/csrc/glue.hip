@@ -876,7 +876,7 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
                                          void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
                                          uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder,
                                          int spin, void* stream) {
-    HESIC_CHECK_ARG(n_groups >= 0 && group_size && graph_exec && descs && scale_mean && channels && n_channels > 0 && minmax >= 0 && tab_dev &&
+    HESIC_CHECK_ARG(n_groups >= 0 && group_size && graph_exec && (scale_mean || !descs) && channels && n_channels > 0 && minmax >= 0 && tab_dev &&
                         tab_host && sym_dev && sym_host && decode && decoder,
                     "joint_decode_groups: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -893,7 +893,8 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
         if (nprev && sym_dev != sym_host && (e = hipMemcpyAsync(sym_dev, sym_host, (size_t)nprev * n_channels * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
             return fail("symbols up", e);
         if ((e = hipGraphLaunch((hipGraphExec_t)graph_exec[g], st)) != hipSuccess) return fail("graph launch", e);
-        if (int rc = hesic_gmm_cdf(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, tab_dev, stream)) return rc;
+        if (descs)
+            if (int rc = hesic_gmm_cdf(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, tab_dev, stream)) return rc;
         if (tab_dev != tab_host && (e = hipMemcpyAsync(tab_host, tab_dev, (size_t)n_channels * P * n_tab * 4, hipMemcpyDeviceToHost, st)) != hipSuccess)
             return fail("tables down", e);
         const double t1 = timing ? now() : 0;

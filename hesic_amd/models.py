@@ -867,6 +867,10 @@ X3C2_TWO_PRODUCT_TAIL = _os.environ.get("HESIC_X3C2_TAIL2") is not None
 WAVEFRONT_GRAPHS = _os.environ.get("HESIC_WAVEFRONT_GRAPHS", "1") != "0"      # A/B switch: 0 = round 3's per-group launches from Python
 # A/B switch: 1 = the device reads the decoded symbols from, and writes the tables into, pinned host memory itself (no copy nodes)
 WAVEFRONT_ZEROCOPY = _os.environ.get("HESIC_WAVEFRONT_ZEROCOPY", "1") != "0"
+# A/B switch, off: 1 = the table launch of a group is the sixth node of its captured step (hesic_gmm_cdf_dyn: channel list and alphabet read on
+# the device).  Measured neutral (per view: 1.0 vs 1.6 ms of launch calls, 8.3 vs 7.6 ms of waiting -- a graph node costs what a launch costs)
+WAVEFRONT_TABLE_IN_GRAPH = _os.environ.get("HESIC_WAVEFRONT_TABLE_IN_GRAPH", "0") != "0"
+_CDF_WAVE_MAX = 1024          # csrc/entropy.hip: alphabets the wave-per-row table kernel takes
 WAVEFRONT_C_LOOP = _os.environ.get("HESIC_WAVEFRONT_C_LOOP", "1") != "0"      # A/B switch: 0 = the group loop in Python (six C calls per group)
 PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
@@ -1250,7 +1254,7 @@ class HSICJoint(StereoCompressionModel):
               "ext": torch.zeros((yh * yw, M), dtype=cdt, device=dev) if which == 2 else None,
               "all_centre": torch.from_numpy(centre.astype(np.int64)).to(dev), "all_rows": torch.from_numpy(all_pix.astype(np.int64)).to(dev),
               "pos": torch.zeros(1, dtype=torch.int64, device=dev), "cfg": torch.zeros(4 + M, dtype=torch.int32, device=dev),
-              "cfg_pin": torch.zeros(4 + M, dtype=torch.int32).pin_memory(), "tab": None,
+              "cfg_pin": torch.zeros(4 + M, dtype=torch.int32).pin_memory(), "tab": None, "tab_in_graph": False,
               "sym": torch.zeros(pmax * M, dtype=torch.int32, device=dev),
               "prev_centre": torch.zeros(pmax, dtype=torch.int64, device=dev),
               "crops": torch.zeros((pmax, 5, 5, M), dtype=cdt, device=dev), "feat": torch.zeros((pmax, c_feat), dtype=cdt, device=dev),
@@ -1276,7 +1280,16 @@ class HSICJoint(StereoCompressionModel):
         feat = st["feat"][:P].view(P, st["c_feat"], 1, 1)
         Fn.conv2d_into(crops, ctx_m.weight, ctx_m.bias, feat, st["c_par"], kernel_size=5, stride=1, padding=0, mask=ctx_m.mask,
                        tap_mask=ctx_m._tap_mask, packer=ctx_m._packer)
-        return _seq3_hi(st["ep"], feat)                                                                    # (P, 2M, 1, 1) fp32: row p = [scales(M) | means(M)]
+        sm = _seq3_hi(st["ep"], feat)                                                                      # (P, 2M, 1, 1) fp32: row p = [scales(M) | means(M)]
+        if st["tab_in_graph"]:
+            # sixth node: the group's tables, channel list / alphabet read from the device state (any image replays the same graph)
+            import ctypes as C
+            M = self.M
+            d = L.GmmDesc(1, P, M, 1, L.F32, 0, 2 * M, 0, M, float(st["bound"]), 0.0)
+            tab = st["tab"][1] if WAVEFRONT_ZEROCOPY else st["tab"][0]
+            L.call("hesic_gmm_cdf_dyn", C.byref(d), 0, L.ptr(sm), L.ptr(sm), None, L.ptr(st["channels"]), M, L.ptr(st["state"]),
+                   C.c_void_p(tab.data_ptr()), L.stream())
+        return sm
 
     def _wavefront_graph(self, st, P):
         ent = st["graphs"].get(P)
@@ -1302,6 +1315,12 @@ class HSICJoint(StereoCompressionModel):
         dev = params.device
         st = self._wavefront_state(which, yh, yw, dev)
         M, Cn, n_tab = self.M, len(channels), 2 * minmax + 2
+        if not st["graphs"]:
+            st["tab_in_graph"], st["bound"] = bool(WAVEFRONT_TABLE_IN_GRAPH), float(bound)
+            if st["tab_in_graph"]:                              # the graphs hold the table buffer's address: sized once for the largest alphabet they take
+                rows = M * st["pmax"]
+                st["tab"] = (torch.empty((rows, _CDF_WAVE_MAX + 1), dtype=torch.int32, device=dev),
+                             torch.empty((rows, _CDF_WAVE_MAX + 1), dtype=torch.int32).pin_memory())
         for P in sorted(set(st["groups"])):                    # first use of a map size: capture (cached on the module)
             self._wavefront_graph(st, P)
         st["y_pad"].zero_()
@@ -1315,9 +1334,17 @@ class HSICJoint(StereoCompressionModel):
         st["cfg"].copy_(cfg, non_blocking=True)
         ch_dev = st["channels"][:Cn]
         pmax = st["pmax"]
-        if st["tab"] is None or st["tab"][0].shape[1] < n_tab:              # table buffers (device + pinned) kept with the state: pinning costs ~0.1 ms a call
-            st["tab"] = (torch.empty((M * pmax, n_tab), dtype=torch.int32, device=dev), torch.empty((M * pmax, n_tab), dtype=torch.int32).pin_memory())
-        tab_dev, tab_pin = st["tab"]
+        in_graph = st["tab_in_graph"] and 2 * minmax + 1 <= _CDF_WAVE_MAX and float(bound) == st["bound"]
+        if in_graph:
+            tab_dev, tab_pin = st["tab"]
+        else:
+            # table buffers (device + pinned) kept with the state: pinning costs ~0.1 ms a call.  Not the ones a captured table launch
+            # writes: an alphabet beyond its 1024 entries (random-weight regimes) goes through launches issued per group
+            big = st.get("tab_big")
+            if big is None or big[0].shape[1] < n_tab:
+                big = st["tab_big"] = (torch.empty((M * pmax, n_tab), dtype=torch.int32, device=dev),
+                                       torch.empty((M * pmax, n_tab), dtype=torch.int32).pin_memory())
+            tab_dev, tab_pin = big
         descs = {P: L.GmmDesc(1, P, M, 1, L.F32, 0, 2 * M, 0, M, float(bound), 0.0) for P in set(st["groups"])}
         stream = L.stream()
         sym_dev, sym_host = L.ptr(st["sym"]), C.c_void_p(st["sym_pin"].data_ptr())
@@ -1334,7 +1361,7 @@ class HSICJoint(StereoCompressionModel):
             fn, handle = dec.grid_callback()
             execs = (C.c_void_p * n)(*[st["graphs"][P][0].raw_cuda_graph_exec() for P in groups])
             outs = (C.c_void_p * n)(*[st["graphs"][P][1].data_ptr() for P in groups])
-            dsc = (L.GmmDesc * n)(*[descs[P] for P in groups])
+            dsc = None if in_graph else (L.GmmDesc * n)(*[descs[P] for P in groups])
             sizes = (C.c_int32 * n)(*groups)
             try:
                 L.call("hesic_joint_decode_groups", n, sizes, execs, dsc, outs, ch_p, Cn, int(minmax), tab_d, tab_h, sym_dev, sym_host, fn, handle,
@@ -1353,7 +1380,8 @@ class HSICJoint(StereoCompressionModel):
                 g, sm = st["graphs"][P]
                 g.replay()
                 smp = L.ptr(sm)
-                call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
+                if not in_graph:
+                    call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
                 if not zc:
                     call("hesic_memcpy_async", tab_h, tab_d, Cn * P * n_tab * 4, 2, stream)
                 call("hesic_stream_synchronize", stream)

@@ -401,6 +401,11 @@ int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, const float
  * GaussianMixtureConditional._likelihood -- the reference's Python double loop as one launch.  channels: device int32.  */
 int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
                   const int32_t* channels, int n_channels, int minmax, uint32_t* cdf, void* stream);
+/* The same tables with n_channels and minmax read on the device (state = {unused, n_channels, minmax}, int32; channels sized for
+ * max_channels): a launch that can be captured into a HIP graph and replayed for other images (the HESIC+ wavefront step).  Alphabets
+ * of more than 1024 entries are not written (the caller then uses hesic_gmm_cdf).                                                     */
+int hesic_gmm_cdf_dyn(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                      const int32_t* channels, int max_channels, const int32_t* state, uint32_t* cdf, void* stream);
 /* Gradients: dy (y dtype; only meaningful in noise mode), dscales/dmeans (scales dtype, same layout),
  * dweights (B,K*M) fp32 zero-filled by caller (atomic accumulate).                                   */
 int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
@@ -549,7 +554,8 @@ int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void*
  * (group_size[g] pixels) -- copy the previous group's symbols (sym_host, pinned) to sym_dev, launch graph_exec[g] (a hipGraphExec_t: the
  * group's captured device step, whose output scale_mean[g] is [P][2M] fp32 rows), hesic_gmm_cdf(descs[g]) into tab_dev, copy the tables to
  * tab_host (pinned), wait (spin != 0: poll hipStreamQuery), and call decode(decoder, tab_host, P, n_channels, 1, P, 2*minmax+2, sym_host)
- * -- the signature of hesic_rc_decoder_decode_grid (libhesic_host.so).  sym_dev == sym_host / tab_dev == tab_host (pinned, device-addressable
+ * -- the signature of hesic_rc_decoder_decode_grid (libhesic_host.so).  descs == NULL: the table launch is part of graph_exec[g]
+ * (hesic_gmm_cdf_dyn) and is not issued again.  sym_dev == sym_host / tab_dev == tab_host (pinned, device-addressable
  * memory used by the kernels directly) skips the respective copies.  The last group's symbols are copied up before returning; the
  * caller scatters them (hesic_joint_step with P = 0).  A decoder error or a HIP error ends the walk with a non-zero return.              */
 typedef int (*hesic_decode_grid_fn)(void* decoder, const uint32_t* cdf, int64_t n_outer, int64_t n_inner, int64_t row_step_outer,
