@@ -248,9 +248,17 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
 // layout with global_load_lds_dwordx4 (no register staging, no in-register transposes) and the MFMA operands, which
 // need 8 consecutive PIXELS of one channel per lane, come out of LDS through ds_read_b64_tr_b16: a 16-lane group reads
 // a [4 pixels][16 channels] block and every lane receives one channel's 4 pixels.  The 16-byte slots of a 256-byte
-// pixel row are XOR-ed with ((pixel & 3) << 1) on the DMA source side so the 4 rows of a block hit distinct banks.
+// pixel row are XOR-ed with ((pixel & 3) << 2) on the DMA source side: a transposing read is served 32 lanes (two 16-lane groups = 4
+// pixel rows x 64 bytes) per LDS cycle, and the four rows must land on four different 64-byte bank ranges.  (Rounds 1-3 shifted by 1:
+// rows 0/1 and 2/3 of a half shared their banks -- SQ_LDS_BANK_CONFLICT = 50 % of the kernel's LDS cycles, profiles/r04_e_pmc_sq_train.json.)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+#ifndef WG_SWZ
+#define WG_SWZ 2
+#endif
+#ifndef WGRAD_RING_DEFAULT
+#define WGRAD_RING_DEFAULT 0
+#endif
 
 struct WgTrArgs {
     WgArgs w;
@@ -259,10 +267,15 @@ struct WgTrArgs {
     int fastq;          // QW % 16 == 0 (and chunk % 64 == 0): the 16 pixels a wave stages per step share one image row
 };
 
+// BK pixels per stage, a ring of NST stages: NST - 1 stages are in flight while one is consumed.  <64, 2> (64 KB, two blocks per CU) is the
+// form of rounds 2-4; <32, 5> (80 KB) keeps twice the bytes in flight per CU for the same two blocks (round 4: the kernel sits parked at
+// its vmcnt / barrier half of its cycles with ONE 32 KB stage per block in flight).
+template <int BK, int NST, bool SPREAD = false>
 __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const WgArgs& a = A.w;
-    constexpr int BK = 64, TILE = BK * 256, STAGE = 2 * TILE;       // 64 pixels x 128 channels x 2 B per operand
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int TILE = BK * 256, STAGE = 2 * TILE;       // BK pixels x 128 channels x 2 B per operand
+    constexpr int NI = BK / 16;                            // DMA instructions per wave, operand and stage (4 pixel rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (A.zero_me && blockIdx.x == 0)
         for (int i = tid; i < A.zero_n; i += NT) A.zero_me[i] = 0.f;       // the bias gradient's zero-fill rides on this launch (stream order: done before the next one)
@@ -289,16 +302,16 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)OOB, 0x00020000);
     const int lrow = lane >> 4, pslot = lane & 15;
-    const int ls = pslot ^ ((lrow & 3) << 1);                     // row & 3 == lrow & 3 for all four DMA rows of a lane
+    const int ls = pslot ^ ((lrow & 3) << WG_SWZ);                // row & 3 == lrow & 3 for all four DMA rows of a lane
     const bool d_ch = co0 + ls * 8 < a.Cout, x_ch = ci0 + ls * 8 < a.Cin;
     const uint32_t d_cb = (uint32_t)((a.y_co + co0 + ls * 8) * 2), x_cb = (uint32_t)((a.x_co + ci0 + ls * 8) * 2);
     const int SH = a.transposed ? a.Ho : a.H, SW = a.transposed ? a.Wo : a.W;        // extent of the shifted operand
     const uint32_t lin_ps = (uint32_t)((a.transposed ? a.x_ps : a.y_ps) * 2), sh_ps = (uint32_t)((a.transposed ? a.y_ps : a.x_ps) * 2);
-    uint32_t qi[4], lin_off[4];
-    int qx[4], qy[4], qb[4];
+    uint32_t qi[NI], lin_off[NI];
+    int qx[NI], qy[NI], qb[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t q = (uint32_t)q_begin + (uint32_t)((wave * 4 + i) * 4 + lrow);
+    for (int i = 0; i < NI; ++i) {
+        const uint32_t q = (uint32_t)q_begin + (uint32_t)((wave * NI + i) * 4 + lrow);
         qi[i] = q;
         const uint32_t r1 = fdiv(q, A.dqw);
         qx[i] = (int)(q - r1 * (uint32_t)a.QW);
@@ -307,11 +320,13 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         qb[i] = (int)b;
         lin_off[i] = q * lin_ps;
     }
-    auto issue_slow = [&](int buf) {
+    // i0 .. i1: which of the stage's NI instruction pairs (the spread form issues one pair behind each k-step's MFMAs)
+    auto issue_slow = [&](int buf, int i0, int i1) {
         unsigned char* dt = smem + buf * STAGE;
         unsigned char* xt = dt + TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
+            if (i < i0 || i >= i1) continue;
             const bool inq = qi[i] < (uint32_t)q_end;
             const int sy = qy[i] * a.stride + sh_y, sx = qx[i] * a.stride + sh_x;
             const bool sok = inq && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW;
@@ -319,8 +334,8 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
             uint32_t vd, vx;
             if (a.transposed) { vd = (sok && d_ch) ? s_off + d_cb : OOB; vx = (inq && x_ch) ? lin_off[i] + x_cb : OOB; }
             else { vd = (inq && d_ch) ? lin_off[i] + d_cb : OOB; vx = (sok && x_ch) ? s_off + x_cb : OOB; }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(dt + (wave * 4 + i) * 1024), 16, (int)vd, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xt + (wave * 4 + i) * 1024), 16, (int)vx, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(dt + (wave * NI + i) * 1024), 16, (int)vd, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xt + (wave * NI + i) * 1024), 16, (int)vx, 0, 0, 0);
             qi[i] += BK;
             lin_off[i] += BK * lin_ps;
             qx[i] += BK;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     const uint32_t neg_b = (uint32_t)a.pad * sh_ps;             // the shifted operand's resource starts pad pixels early: soffset >= 0
     const __amdgpu_buffer_rsrc_t lr = a.transposed ? xr : dr;
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)(a.transposed ? a.dy : a.x) - neg_b), 0, (int)OOB, 0x00020000);
-    uint32_t sq_w = (uint32_t)q_begin + (uint32_t)(wave * 16);
+    uint32_t sq_w = (uint32_t)q_begin + (uint32_t)(wave * NI * 4);
     int sqx, sqy, sqb;
     {
         const uint32_t r1 = fdiv(sq_w, A.dqw);
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         sqy = (int)(r1 - b * (uint32_t)a.QH);
         sqb = (int)b;
     }
-    auto issue_fast = [&](int buf) {
+    auto issue_fast = [&](int buf, int i0, int i1) {
         unsigned char* dt = smem + buf * STAGE;
         unsigned char* xt = dt + TILE;
         unsigned char* lt = a.transposed ? xt : dt;
@@ -371,14 +386,16 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         const uint32_t so_s = (uint32_t)(((sqb * SH + sy) * SW + sxw) * (int)sh_ps) + neg_b;
         const uint32_t vl = inq ? v_lin : OOB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
+            if (i < i0 || i >= i1) continue;
             const bool okx = rowok && (unsigned)(sxw + 4 * i * a.stride + lx) < (unsigned)SW;
             const uint32_t vs = okx ? v_sft : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (__attribute__((address_space(3))) void*)(lt + (wave * 4 + i) * 1024), 16, (int)vl,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (__attribute__((address_space(3))) void*)(lt + (wave * NI + i) * 1024), 16, (int)vl,
                                                      (int)(so_l + (uint32_t)(4 * i) * lin_ps), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(stt + (wave * 4 + i) * 1024), 16, (int)vs,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(stt + (wave * NI + i) * 1024), 16, (int)vs,
                                                      (int)(so_s + (uint32_t)(4 * i * a.stride) * sh_ps), 0, 0);
         }
+        if (i1 < NI) return;              // the stage's bookkeeping advances with its last pair
         sq_w += BK;
         sqx += BK;
         if (sqx >= a.QW) {
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
     // byte offset of this lane's 8-byte chunk inside a tile for channel-tile base cb, pixel base pb (multiples of 32 / 16)
     auto tr_off = [&](int cb, int pix) {
         const int ch = cb + (g & 1) * 16 + 4 * (t & 3);
-        return pix * 256 + (((ch >> 3) ^ ((pix & 3) << 1)) << 4) + (ch & 7) * 2;
+        return pix * 256 + (((ch >> 3) ^ ((pix & 3) << WG_SWZ)) << 4) + (ch & 7) * 2;
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -426,14 +443,19 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         constexpr bool ABS = decltype(abs_tag)::value, SQ = decltype(sq_tag)::value, FASTQ = decltype(fast_tag)::value, BIAS = decltype(bias_tag)::value;
         const u32x4 ones_u = {H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR, H16_ONE_PAIR};
         const h16x8 ones = __builtin_bit_cast(h16x8, ones_u);
-        auto issue = [&](int buf) {
-            if constexpr (FASTQ) issue_fast(buf);
-            else issue_slow(buf);
+        auto issue = [&](int buf, int i0, int i1) {
+            if constexpr (FASTQ) issue_fast(buf, i0, i1);
+            else issue_slow(buf, i0, i1);
         };
-        if (nsteps > 0) issue(0);
+        // stages 0 .. NST-2 go out first; every step then issues stage step + NST - 1 (past the end: out-of-range offsets, zeros into a
+        // stage nobody reads -- the count of outstanding DMA instructions stays what the vmcnt below assumes)
+        if (nsteps > 0) {
+#pragma unroll
+            for (int p = 0; p < NST - 1; ++p) issue(p, 0, NI);
+        }
+        int buf = 0;
         for (int64_t step = 0; step < nsteps; ++step) {
-            const int buf = step & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 2 * NI) : "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned char* dt = smem + buf * STAGE;
             const unsigned char* xt = dt + TILE;
@@ -453,7 +475,8 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (step + 1 < nsteps) issue(buf ^ 1);
+            const int nbuf = buf == 0 ? NST - 1 : buf - 1;      // the stage consumed one step ago
+            if constexpr (!SPREAD) issue(nbuf, 0, NI);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16) ldf((ks + 1) & 1, ks + 1);
@@ -488,8 +511,10 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) bacc[i] = mfma_32x32x16_h16(df[i], ones, bacc[i], 0, 0, 0);
                 }
+                if constexpr (SPREAD) issue(nbuf, ks, ks + 1);       // one instruction pair in the shadow of this k-step's MFMAs
                 __builtin_amdgcn_sched_barrier(0);
             }
+            buf = buf + 1 == NST ? 0 : buf + 1;
         }
     };
     if (bslot >= 0) {
@@ -1423,7 +1448,15 @@ __global__ __launch_bounds__(256) void gdn_param_finish_kernel(const float* __re
 // dn (bf16) also goes to a workspace; dgamma' = dn^T x^2 and dbeta' = colsum(dn) are then produced by the 1x1
 // weight-gradient MFMA kernel (x squared on load).  After the tile load every wave owns its 32 pixel rows of both
 // LDS tiles, so no block barrier is needed inside the tile loop.
-__device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (slot ^ (row & 15))) * 16; }   // 256-byte rows
+// 256-byte rows, 16-byte slots XOR-ed with the row's low four bits, the two bit pairs swapped: any 16 consecutive rows put one logical slot
+// on 16 different physical slots (the row-wise ds_read_b128 fragment reads), AND the rows 4k .. 4k+3 put the logical slots c .. c+3 on four
+// different aligned groups of four (the transposing reads of the third GEMM: 4 pixel rows x 64 bytes per LDS cycle).  The plain
+// slot ^ (row & 15) of rounds 2-3 served only the first: 52 % of the kernel's LDS cycles were bank conflicts.
+#ifndef GB_SWZ_PLAIN
+__device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (slot ^ (((row & 3) << 2) | ((row >> 2) & 3)))) * 16; }
+#else
+__device__ __forceinline__ int gb_off(int row, int slot) { return (row * 16 + (slot ^ (row & 15))) * 16; }
+#endif
 
 // PAR = 1 (the default path): the parameter gradients ride on the same pass.  dgamma'[i][j] = sum_p dn[p][i] x[p][j]^2 is a third GEMM
 // with the PIXELS as K: both operands come out of the two LDS tiles through transposing reads
@@ -1652,7 +1685,23 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zer
     A.dqh = make_fastdiv((uint32_t)a.QH);
     static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
     A.fastq = (!slow && a.QW % 16 == 0 && a.chunk % 64 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, A);
+    // A/B switch: the stage ring.  0 = <64, 2> (rounds 2-4), 1 = <32, 5>, 2 = <32, 4>, 3 = <64, 3> (96 KB: one block per CU), 4 = <64, 2> with the
+    // stage's DMA instructions spread behind the k-steps' MFMAs.  Training step, same box, alternating runs (ms): 0: 9.89 / 9.91 | 1: 11.30 |
+    // 2: 11.32 | 3: 12.36 | 4: 10.58 -- more bytes in flight, or cheaper issue slots for the DMA instructions, are not what the loop is short
+    // of: halving the step doubles its barriers, one block per CU loses the other block's cover, late DMA issue shows up as latency.
+    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32 * 512);
+        (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 512);
+        attr = true;
+    }
+    const dim3 g((unsigned)blocks), b(NT);
+    if (ring == 1) hipLaunchKernelGGL((wgrad_tr_kernel<32, 5>), g, b, 5 * 32 * 512, st, A);
+    else if (ring == 2) hipLaunchKernelGGL((wgrad_tr_kernel<32, 4>), g, b, 4 * 32 * 512, st, A);
+    else if (ring == 3) hipLaunchKernelGGL((wgrad_tr_kernel<64, 3>), g, b, 3 * 64 * 512, st, A);
+    else if (ring == 4) hipLaunchKernelGGL((wgrad_tr_kernel<64, 2, true>), g, b, 2 * 64 * 512, st, A);
+    else hipLaunchKernelGGL((wgrad_tr_kernel<64, 2>), g, b, 2 * 64 * 512, st, A);
 }
 
 int pick_splits(int64_t Q, int bk, int tiles) {
