@@ -85,7 +85,8 @@ _SIGS = {
     "hesic_gdn_forward_planar": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp], _i32),
     "hesic_eb_prepare_params": ([_vp, _vp, _i32, _vp], _i32),
     "hesic_gmm_cdf": ([_P(GmmDesc), _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp], _i32),
-    "hesic_gmm_cdf_dyn": ([_P(GmmDesc), _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
+    "hesic_gmm_cdf_rows": ([_P(GmmDesc), _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp], _i32),
+    "hesic_gmm_cdf_dyn": ([_P(GmmDesc), _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
     "hesic_maxpool2_forward": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_perspective_transform": ([_vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_h_from_delta": ([_vp, _vp, _f32, _f32, _i32, _vp, _i32, _vp], _i32),

@@ -334,7 +334,7 @@ __device__ __forceinline__ float cdf_pm(int s, const float* mu, const float* sg,
 template <typename T>
 __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
                                const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
-                               uint32_t* __restrict__ cdf) {
+                               uint32_t* __restrict__ cdf, int pix_major) {
     const int A = 2 * minmax + 1;
     const int64_t total = (int64_t)n_ch * d.HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -347,7 +347,7 @@ __global__ void gmm_cdf_kernel(const hesic_gmm_desc d, int b, const T* __restric
             sg[k] = fmaxf(elem<T>::ld(scales + sm + d.s_c_off + k * d.M), d.scale_bound);
             wk[k] = weights ? weights[(int64_t)b * d.K * d.M + k * d.M + m] : 1.f;
         }
-        uint32_t* row = cdf + i * (A + 1);
+        uint32_t* row = cdf + (pix_major ? (int64_t)hw * n_ch + j : i) * (A + 1);
         float* frow = (float*)(row + 1);
         for (int s = 0; s < A; ++s) frow[s] = cdf_pm(s, mu, sg, wk, d.K);
         const float tot = np_pairwise_sum(frow, A);
@@ -368,7 +368,7 @@ constexpr int CDF_WAVE_MAX = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void gmm_cdf_wave_kernel(const hesic_gmm_desc d, int b, const T* __restrict__ scales, const T* __restrict__ means,
                                                            const float* __restrict__ weights, const int32_t* __restrict__ channels, int n_ch, int minmax,
-                                                           uint32_t* __restrict__ cdf, const int32_t* __restrict__ dyn) {
+                                                           uint32_t* __restrict__ cdf, const int32_t* __restrict__ dyn, int pix_major) {
     __shared__ float buf[4][CDF_WAVE_MAX];
     if (dyn) {          // channel count and alphabet of THIS image from device memory ({_, n_ch, minmax}): the launch sits in a graph captured for any image
         n_ch = dyn[1]; minmax = dyn[2];
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void gmm_cdf_wave_kernel(const hesic_gmm_desc 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float tot = np_pairwise_sum(frow, A);
-        uint32_t* row = cdf + i * (A + 1);
+        uint32_t* row = cdf + (pix_major ? (int64_t)hw * n_ch + j : i) * (A + 1);     // pixel-major: the order a pixel-by-pixel decoder walks them
         if (lane == 0) row[0] = 0u;
         float carry = 0.f;
         for (int s0 = 0; s0 < A; s0 += 64) {
@@ -666,8 +666,17 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
     HESIC_LAUNCH_RETURN("gmm_forward");
 }
 
+extern "C" int hesic_gmm_cdf_rows(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                                  const int32_t* channels, int n_channels, int minmax, int pixel_major, uint32_t* cdf, void* stream);
 extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
                              const int32_t* channels, int n_channels, int minmax, uint32_t* cdf, void* stream) {
+    return hesic_gmm_cdf_rows(d, b, scales, means, weights, channels, n_channels, minmax, 0, cdf, stream);
+}
+
+// pixel_major: row (hw, j) at hw * n_channels + j instead of j * HW + hw -- the order in which the HESIC+ decoder consumes them (the
+// host range decoder then streams through the table instead of striding: ~2x on its 30-40 us per wavefront group)
+extern "C" int hesic_gmm_cdf_rows(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                                  const int32_t* channels, int n_channels, int minmax, int pixel_major, uint32_t* cdf, void* stream) {
     if (int e = check_gmm(d, "gmm_cdf")) return e;
     HESIC_CHECK_ARG(scales && means && channels && cdf && n_channels > 0 && minmax >= 1 && minmax < 32768 && b >= 0 && b < d->B,
                     "gmm_cdf: bad arguments");
@@ -678,19 +687,19 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
         const dim3 gw(grid_for(total, 4, 256 * 16));
         if (d->dtype == HESIC_H16)
             hipLaunchKernelGGL(gmm_cdf_wave_kernel<h16_t>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales, (const h16_t*)means, weights,
-                               channels, n_channels, minmax, cdf, nullptr);
+                               channels, n_channels, minmax, cdf, nullptr, pixel_major);
         else
             hipLaunchKernelGGL(gmm_cdf_wave_kernel<float>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const float*)scales, (const float*)means, weights,
-                               channels, n_channels, minmax, cdf, nullptr);
+                               channels, n_channels, minmax, cdf, nullptr, pixel_major);
         HESIC_LAUNCH_RETURN("gmm_cdf");
     }
     const dim3 grid(grid_for(total, 128));
     if (d->dtype == HESIC_H16)
         hipLaunchKernelGGL(gmm_cdf_kernel<h16_t>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales,
-                           (const h16_t*)means, weights, channels, n_channels, minmax, cdf);
+                           (const h16_t*)means, weights, channels, n_channels, minmax, cdf, pixel_major);
     else
         hipLaunchKernelGGL(gmm_cdf_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, *d, b, (const float*)scales,
-                           (const float*)means, weights, channels, n_channels, minmax, cdf);
+                           (const float*)means, weights, channels, n_channels, minmax, cdf, pixel_major);
     HESIC_LAUNCH_RETURN("gmm_cdf");
 }
 
@@ -698,17 +707,17 @@ extern "C" int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales,
 // in a HIP graph that is replayed for images with other channel lists and alphabets (the HESIC+ wavefront step).  Rows are laid out with
 // the image's own 2 * minmax + 2 stride, as hesic_gmm_cdf writes them; alphabets beyond the wave kernel's 1024 entries write nothing.
 extern "C" int hesic_gmm_cdf_dyn(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
-                                 const int32_t* channels, int max_channels, const int32_t* state, uint32_t* cdf, void* stream) {
+                                 const int32_t* channels, int max_channels, const int32_t* state, int pixel_major, uint32_t* cdf, void* stream) {
     if (int e = check_gmm(d, "gmm_cdf_dyn")) return e;
     HESIC_CHECK_ARG(scales && means && channels && cdf && state && max_channels > 0 && b >= 0 && b < d->B, "gmm_cdf_dyn: bad arguments");
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf_dyn: weights required for K > 1");
     const dim3 gw(grid_for((int64_t)max_channels * d->HW, 4, 256 * 16));
     if (d->dtype == HESIC_H16)
         hipLaunchKernelGGL(gmm_cdf_wave_kernel<h16_t>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const h16_t*)scales, (const h16_t*)means, weights,
-                           channels, max_channels, 1, cdf, state);
+                           channels, max_channels, 1, cdf, state, pixel_major);
     else
         hipLaunchKernelGGL(gmm_cdf_wave_kernel<float>, gw, dim3(256), 0, (hipStream_t)stream, *d, b, (const float*)scales, (const float*)means, weights,
-                           channels, max_channels, 1, cdf, state);
+                           channels, max_channels, 1, cdf, state, pixel_major);
     HESIC_LAUNCH_RETURN("gmm_cdf_dyn");
 }
 

@@ -894,7 +894,7 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
             return fail("symbols up", e);
         if ((e = hipGraphLaunch((hipGraphExec_t)graph_exec[g], st)) != hipSuccess) return fail("graph launch", e);
         if (descs)
-            if (int rc = hesic_gmm_cdf(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, tab_dev, stream)) return rc;
+            if (int rc = hesic_gmm_cdf_rows(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, 1, tab_dev, stream)) return rc;
         if (tab_dev != tab_host && (e = hipMemcpyAsync(tab_host, tab_dev, (size_t)n_channels * P * n_tab * 4, hipMemcpyDeviceToHost, st)) != hipSuccess)
             return fail("tables down", e);
         const double t1 = timing ? now() : 0;
@@ -905,7 +905,7 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
         }
         if (e != hipSuccess) return fail("wait", e);
         const double t2 = timing ? now() : 0;
-        if (int rc = decode(decoder, tab_host, P, n_channels, 1, P, n_tab, sym_host)) { hesic_set_error("joint_decode_groups: range decoder failed (%d) in group %d", rc, g); return HESIC_EINVAL; }
+        if (int rc = decode(decoder, tab_host, P, n_channels, n_channels, 1, n_tab, sym_host)) { hesic_set_error("joint_decode_groups: range decoder failed (%d) in group %d", rc, g); return HESIC_EINVAL; }
         if (timing) { const double t3 = now(); t_submit += t1 - t0; t_wait += t2 - t1; t_decode += t3 - t2; }
         nprev = P;
     }

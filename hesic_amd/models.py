@@ -1287,7 +1287,7 @@ class HSICJoint(StereoCompressionModel):
             M = self.M
             d = L.GmmDesc(1, P, M, 1, L.F32, 0, 2 * M, 0, M, float(st["bound"]), 0.0)
             tab = st["tab"][1] if WAVEFRONT_ZEROCOPY else st["tab"][0]
-            L.call("hesic_gmm_cdf_dyn", C.byref(d), 0, L.ptr(sm), L.ptr(sm), None, L.ptr(st["channels"]), M, L.ptr(st["state"]),
+            L.call("hesic_gmm_cdf_dyn", C.byref(d), 0, L.ptr(sm), L.ptr(sm), None, L.ptr(st["channels"]), M, L.ptr(st["state"]), 1,
                    C.c_void_p(tab.data_ptr()), L.stream())
         return sm
 
@@ -1381,11 +1381,11 @@ class HSICJoint(StereoCompressionModel):
                 g.replay()
                 smp = L.ptr(sm)
                 if not in_graph:
-                    call("hesic_gmm_cdf", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), tab_d, stream)
+                    call("hesic_gmm_cdf_rows", C.byref(descs[P]), 0, smp, smp, None, ch_p, Cn, int(minmax), 1, tab_d, stream)
                 if not zc:
                     call("hesic_memcpy_async", tab_h, tab_d, Cn * P * n_tab * 4, 2, stream)
                 call("hesic_stream_synchronize", stream)
-                raw(tab_h, n_tab, P, Cn, 1, P, sym_host)                                             # (P, Cn) symbols, pixel-major, into the pinned buffer
+                raw(tab_h, n_tab, P, Cn, Cn, 1, sym_host)                                            # pixel-major rows, (P, Cn) symbols into the pinned buffer
                 nprev = P
             if not zc:
                 call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)

@@ -401,11 +401,15 @@ int hesic_gmm_forward_f32in(const hesic_gmm_desc* d, const float* y, const float
  * GaussianMixtureConditional._likelihood -- the reference's Python double loop as one launch.  channels: device int32.  */
 int hesic_gmm_cdf(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
                   const int32_t* channels, int n_channels, int minmax, uint32_t* cdf, void* stream);
+/* The same with a choice of row order: pixel_major != 0 puts row (pixel hw, listed channel j) at hw * n_channels + j (the order a
+ * pixel-by-pixel decoder consumes them) instead of j * HW + hw.                                                                       */
+int hesic_gmm_cdf_rows(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
+                       const int32_t* channels, int n_channels, int minmax, int pixel_major, uint32_t* cdf, void* stream);
 /* The same tables with n_channels and minmax read on the device (state = {unused, n_channels, minmax}, int32; channels sized for
  * max_channels): a launch that can be captured into a HIP graph and replayed for other images (the HESIC+ wavefront step).  Alphabets
  * of more than 1024 entries are not written (the caller then uses hesic_gmm_cdf).                                                     */
 int hesic_gmm_cdf_dyn(const hesic_gmm_desc* d, int b, const void* scales, const void* means, const float* weights,
-                      const int32_t* channels, int max_channels, const int32_t* state, uint32_t* cdf, void* stream);
+                      const int32_t* channels, int max_channels, const int32_t* state, int pixel_major, uint32_t* cdf, void* stream);
 /* Gradients: dy (y dtype; only meaningful in noise mode), dscales/dmeans (scales dtype, same layout),
  * dweights (B,K*M) fp32 zero-filled by caller (atomic accumulate).                                   */
 int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const void* scales, const void* means,
@@ -553,7 +557,8 @@ int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void*
 /* The decode walk of one view of HESIC+ (newnet1_joint.py:1190-1260 regrouped into wavefronts) as ONE call: for each of the n_groups groups
  * (group_size[g] pixels) -- copy the previous group's symbols (sym_host, pinned) to sym_dev, launch graph_exec[g] (a hipGraphExec_t: the
  * group's captured device step, whose output scale_mean[g] is [P][2M] fp32 rows), hesic_gmm_cdf(descs[g]) into tab_dev, copy the tables to
- * tab_host (pinned), wait (spin != 0: poll hipStreamQuery), and call decode(decoder, tab_host, P, n_channels, 1, P, 2*minmax+2, sym_host)
+ * (rows pixel-major: hesic_gmm_cdf_rows) tab_host (pinned), wait (spin != 0: poll hipStreamQuery), and call decode(decoder, tab_host, P,
+ * n_channels, n_channels, 1, 2*minmax+2, sym_host)
  * -- the signature of hesic_rc_decoder_decode_grid (libhesic_host.so).  descs == NULL: the table launch is part of graph_exec[g]
  * (hesic_gmm_cdf_dyn) and is not issued again.  sym_dev == sym_host / tab_dev == tab_host (pinned, device-addressable
  * memory used by the kernels directly) skips the respective copies.  The last group's symbols are copied up before returning; the
