@@ -473,10 +473,11 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
                     xhi[set][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xt + tr_off(wn * 64 + j * 32, pix + 4)));
                 }
             };
+            const int nbuf = buf == 0 ? NST - 1 : buf - 1;      // the stage consumed one step ago
+            if constexpr (!SPREAD) issue(nbuf, 0, NI);           // in front of the first fragment reads (behind them: 9.71 vs 9.675 ms per step, same box)
+            __builtin_amdgcn_sched_barrier(0);
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const int nbuf = buf == 0 ? NST - 1 : buf - 1;      // the stage consumed one step ago
-            if constexpr (!SPREAD) issue(nbuf, 0, NI);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16) ldf((ks + 1) & 1, ks + 1);
