@@ -67,6 +67,40 @@ class GmmDesc(C.Structure):
                                     "s_c_off", "m_c_off")] + [("scale_bound", _f32), ("lik_bound", _f32)]
 
 
+class TapeCall(C.Structure):
+    """hesic_tape_call: a recorded launch (entry point id, its arguments as 64-bit words, the stream argument left out)."""
+    _fields_ = [("fn", _i32), ("nargs", _i32), ("a", C.c_uint64 * 20)]
+
+
+TAPE_IDS = {"hesic_joint_step": 0, "hesic_conv2d_forward": 1, "hesic_conv2d_forward_f32out": 2}
+
+
+def tape_from_calls(calls):
+    """``calls``: [(entry point name, ctypes arguments as passed to ``call``)] -> (TapeCall array, objects to keep alive).  Pointers and
+    integers only; the trailing stream argument is dropped (the replaying C function supplies it)."""
+    arr = (TapeCall * len(calls))()
+    keep = []
+    for t, (name, args) in zip(arr, calls):
+        t.fn, t.nargs = TAPE_IDS[name], len(args) - 1
+        for i, v in enumerate(args[:-1]):
+            if v is None:
+                w = 0
+            elif isinstance(v, int):
+                w = v
+            elif isinstance(v, C.c_void_p):
+                w = v.value or 0
+            elif hasattr(v, "_obj"):                    # byref(struct)
+                keep.append(v._obj)
+                w = C.addressof(v._obj)
+            elif isinstance(v, (C.Array, C.Structure)):
+                keep.append(v)
+                w = C.addressof(v)
+            else:
+                raise TypeError(f"tape_from_calls: {name} argument {i} of type {type(v).__name__}")
+            t.a[i] = w & 0xFFFFFFFFFFFFFFFF
+    return arr, keep
+
+
 _P = C.POINTER
 _SIGS = {
     "hesic_abi_version": ([], _i32),
@@ -77,6 +111,7 @@ _SIGS = {
     "hesic_memcpy_async": ([_vp, _vp, C.c_size_t, _i32, _vp], _i32),
     "hesic_stream_synchronize": ([_vp], _i32),
     "hesic_joint_decode_groups": ([_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
+    "hesic_joint_decode_groups_tape": ([_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_ssim_scale": ([_vp, _P(_i64), _vp, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_avgpool2_pad": ([_vp, _P(_i64), _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_shaped": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),

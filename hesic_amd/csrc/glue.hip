@@ -868,16 +868,45 @@ extern "C" int hesic_memcpy_async(void* dst, const void* src, size_t bytes, int 
     if (e != hipSuccess) { hesic_set_error("memcpy_async: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+// A recorded launch of one of the entry points a HESIC+ group step is made of, replayed by address: the arguments as 64-bit words
+// (pointers and integers only; the trailing stream argument is supplied at replay).
+static int run_tape(const hesic_tape_call* t, int n, void* stream) {
+    for (int i = 0; i < n; ++i) {
+        const uint64_t* a = t[i].a;
+        int rc;
+        switch (t[i].fn) {
+        case HESIC_TAPE_JOINT_STEP:
+            rc = hesic_joint_step((void*)a[0], (int)a[1], (int)a[2], (int)a[3], (const int32_t*)a[4], (int64_t*)a[5], (int32_t*)a[6], (const int32_t*)a[7],
+                                  (const int64_t*)a[8], (const int64_t*)a[9], (int64_t*)a[10], (int)a[11], (void*)a[12], (const void*)a[13], (int)a[14],
+                                  (const void*)a[15], (int)a[16], (void*)a[17], (int)a[18], stream);
+            break;
+        case HESIC_TAPE_CONV2D_FORWARD:
+            rc = hesic_conv2d_forward((const hesic_conv_desc*)a[0], (const void*)a[1], (const void*)a[2], (const float*)a[3], (void*)a[4], stream);
+            break;
+        case HESIC_TAPE_CONV2D_FORWARD_F32OUT:
+            rc = hesic_conv2d_forward_f32out((const hesic_conv_desc*)a[0], (const void*)a[1], (const void*)a[2], (const float*)a[3], (void*)a[4], (float*)a[5],
+                                             (int)a[6], (int)a[7], (void*)a[8], (size_t)a[9], stream);
+            break;
+        default:
+            hesic_set_error("joint_decode_groups: unknown entry point %d on the tape", t[i].fn);
+            return HESIC_EINVAL;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // The whole decode walk of one view behind one call (models.HSICJoint._decode_view_graphed): per group -- previous symbols up, the group's
-// captured device step (hipGraphExec_t of torch's graph), table launch, tables down, wait, range-decode through the caller's decoder
-// (libhesic_host.so: hesic_rc_decoder_decode_grid) into the pinned symbol buffer.  Six Python -> C crossings per group became none; the
-// wait polls hipStreamQuery (a blocked hipStreamSynchronize wakes up through an interrupt).
-extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size, void* const* graph_exec, const hesic_gmm_desc* descs,
-                                         void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
-                                         uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder,
-                                         int spin, void* stream) {
-    HESIC_CHECK_ARG(n_groups >= 0 && group_size && graph_exec && (scale_mean || !descs) && channels && n_channels > 0 && minmax >= 0 && tab_dev &&
-                        tab_host && sym_dev && sym_host && decode && decoder,
+// device step (a captured hipGraphExec_t of torch's, or the recorded launches of the step replayed one by one: back-to-back launches
+// of a dependent chain of small kernels start closer together than the nodes of a graph), table launch, tables down, wait, range-decode
+// through the caller's decoder (libhesic_host.so: hesic_rc_decoder_decode_grid) into the pinned symbol buffer.  Six Python -> C crossings
+// per group became none; the wait polls hipStreamQuery (a blocked hipStreamSynchronize wakes up through an interrupt).
+static int joint_decode_groups(int n_groups, const int32_t* group_size, void* const* graph_exec, const hesic_tape_call* const* tapes, const int32_t* tape_len,
+                               const hesic_gmm_desc* descs, void* const* scale_mean, const int32_t* channels, int n_channels, int minmax,
+                               uint32_t* tab_dev, uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder,
+                               int spin, void* stream) {
+    HESIC_CHECK_ARG(n_groups >= 0 && group_size && (graph_exec || (tapes && tape_len)) && (scale_mean || !descs) && channels && n_channels > 0 && minmax >= 0 &&
+                        tab_dev && tab_host && sym_dev && sym_host && decode && decoder,
                     "joint_decode_groups: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int n_tab = 2 * minmax + 2;
@@ -892,7 +921,11 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
         const double t0 = timing ? now() : 0;
         if (nprev && sym_dev != sym_host && (e = hipMemcpyAsync(sym_dev, sym_host, (size_t)nprev * n_channels * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
             return fail("symbols up", e);
-        if ((e = hipGraphLaunch((hipGraphExec_t)graph_exec[g], st)) != hipSuccess) return fail("graph launch", e);
+        if (graph_exec) {
+            if ((e = hipGraphLaunch((hipGraphExec_t)graph_exec[g], st)) != hipSuccess) return fail("graph launch", e);
+        } else if (int rc = run_tape(tapes[g], tape_len[g], stream)) {
+            return rc;
+        }
         if (descs)
             if (int rc = hesic_gmm_cdf_rows(&descs[g], 0, scale_mean[g], scale_mean[g], nullptr, channels, n_channels, minmax, 1, tab_dev, stream)) return rc;
         if (tab_dev != tab_host && (e = hipMemcpyAsync(tab_host, tab_dev, (size_t)n_channels * P * n_tab * 4, hipMemcpyDeviceToHost, st)) != hipSuccess)
@@ -917,6 +950,24 @@ extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size
         fprintf(stderr, "joint_decode_groups: %d groups, %d channels, tables of %d: submit %.0f us, wait %.0f us, host decode %.0f us\n", n_groups, n_channels,
                 n_tab, t_submit, t_wait, t_decode);
     return 0;
+}
+
+extern "C" int hesic_joint_decode_groups(int n_groups, const int32_t* group_size, void* const* graph_exec, const hesic_gmm_desc* descs,
+                                         void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
+                                         uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder,
+                                         int spin, void* stream) {
+    HESIC_CHECK_ARG(graph_exec, "joint_decode_groups: no graphs");
+    return joint_decode_groups(n_groups, group_size, graph_exec, nullptr, nullptr, descs, scale_mean, channels, n_channels, minmax, tab_dev, tab_host, sym_dev,
+                               sym_host, decode, decoder, spin, stream);
+}
+
+extern "C" int hesic_joint_decode_groups_tape(int n_groups, const int32_t* group_size, const hesic_tape_call* const* tapes, const int32_t* tape_len,
+                                              const hesic_gmm_desc* descs, void* const* scale_mean, const int32_t* channels, int n_channels, int minmax,
+                                              uint32_t* tab_dev, uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode,
+                                              void* decoder, int spin, void* stream) {
+    HESIC_CHECK_ARG(tapes && tape_len, "joint_decode_groups_tape: no tapes");
+    return joint_decode_groups(n_groups, group_size, nullptr, tapes, tape_len, descs, scale_mean, channels, n_channels, minmax, tab_dev, tab_host, sym_dev,
+                               sym_host, decode, decoder, spin, stream);
 }
 
 extern "C" int hesic_stream_synchronize(void* stream) {

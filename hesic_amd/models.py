@@ -871,6 +871,8 @@ WAVEFRONT_ZEROCOPY = _os.environ.get("HESIC_WAVEFRONT_ZEROCOPY", "1") != "0"
 # the device).  Measured neutral (per view: 1.0 vs 1.6 ms of launch calls, 8.3 vs 7.6 ms of waiting -- a graph node costs what a launch costs)
 WAVEFRONT_TABLE_IN_GRAPH = _os.environ.get("HESIC_WAVEFRONT_TABLE_IN_GRAPH", "0") != "0"
 _CDF_WAVE_MAX = 1024          # csrc/entropy.hip: alphabets the wave-per-row table kernel takes
+# A/B switch: 1 = the C loop replays each group's recorded launches one by one instead of launching its graph
+WAVEFRONT_TAPE = _os.environ.get("HESIC_WAVEFRONT_TAPE", "1") != "0"
 WAVEFRONT_C_LOOP = _os.environ.get("HESIC_WAVEFRONT_C_LOOP", "1") != "0"      # A/B switch: 0 = the group loop in Python (six C calls per group)
 PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
@@ -1302,11 +1304,27 @@ class HSICJoint(StereoCompressionModel):
                     self._wavefront_step_body(st, P)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self._wavefront_step_body(st, P)
+            # the launches are also RECORDED while they are captured (entry point + arguments): the graph's private pool keeps every
+            # buffer they name alive, so the same launches can be replayed one by one from C (hesic_joint_decode_groups_tape)
+            rec, orig = [], L.call
+
+            def recording_call(name, *a):
+                rec.append((name, a))
+                return orig(name, *a)
+            L.call = recording_call
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self._wavefront_step_body(st, P)
+            finally:
+                L.call = orig
             for k, v in keep.items():
                 st[k].copy_(v)
-            ent = st["graphs"][P] = (g, out)
+            n_step = len(rec) - (1 if st["tab_in_graph"] else 0)          # the table launch (if captured) is issued by the walk itself on the tape path
+            try:
+                tape = L.tape_from_calls(rec[:n_step])
+            except (KeyError, TypeError):
+                tape = None                                               # an entry point the tape does not know: graph replay only
+            ent = st["graphs"][P] = (g, out, tape)
         return ent
 
     def _decode_view_graphed(self, dec, which, params, minmax, channels, extra, yh, yw, bound):
@@ -1359,13 +1377,22 @@ class HSICJoint(StereoCompressionModel):
             # a polled wait and the host range decoder through its C entry point -- no Python between the groups
             n = len(groups)
             fn, handle = dec.grid_callback()
-            execs = (C.c_void_p * n)(*[st["graphs"][P][0].raw_cuda_graph_exec() for P in groups])
             outs = (C.c_void_p * n)(*[st["graphs"][P][1].data_ptr() for P in groups])
-            dsc = None if in_graph else (L.GmmDesc * n)(*[descs[P] for P in groups])
             sizes = (C.c_int32 * n)(*groups)
+            use_tape = WAVEFRONT_TAPE and all(st["graphs"][P][2] is not None for P in set(groups))
             try:
-                L.call("hesic_joint_decode_groups", n, sizes, execs, dsc, outs, ch_p, Cn, int(minmax), tab_d, tab_h, sym_dev, sym_host, fn, handle,
-                       1, stream)
+                if use_tape:
+                    # recorded launches replayed one by one; the table launch is then always issued by the walk (never the captured one)
+                    tapes = (C.c_void_p * n)(*[C.addressof(st["graphs"][P][2][0]) for P in groups])
+                    lens = (C.c_int32 * n)(*[len(st["graphs"][P][2][0]) for P in groups])
+                    dsc = (L.GmmDesc * n)(*[descs[P] for P in groups])
+                    L.call("hesic_joint_decode_groups_tape", n, sizes, tapes, lens, dsc, outs, ch_p, Cn, int(minmax), tab_d, tab_h, sym_dev, sym_host,
+                           fn, handle, 1, stream)
+                else:
+                    execs = (C.c_void_p * n)(*[st["graphs"][P][0].raw_cuda_graph_exec() for P in groups])
+                    dsc = None if in_graph else (L.GmmDesc * n)(*[descs[P] for P in groups])
+                    L.call("hesic_joint_decode_groups", n, sizes, execs, dsc, outs, ch_p, Cn, int(minmax), tab_d, tab_h, sym_dev, sym_host, fn, handle,
+                           1, stream)
             except RuntimeError as e:
                 if "range decoder failed" in str(e):
                     raise ValueError("RangeDecoder.decode_grid: bad table") from e
@@ -1377,7 +1404,7 @@ class HSICJoint(StereoCompressionModel):
             for P in groups:
                 if nprev and not zc:
                     call("hesic_memcpy_async", sym_dev, sym_host, nprev * Cn * 4, 1, stream)
-                g, sm = st["graphs"][P]
+                g, sm = st["graphs"][P][:2]
                 g.replay()
                 smp = L.ptr(sm)
                 if not in_graph:

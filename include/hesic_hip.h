@@ -569,6 +569,15 @@ int hesic_joint_decode_groups(int n_groups, const int32_t* group_size, void* con
                               void* const* scale_mean, const int32_t* channels, int n_channels, int minmax, uint32_t* tab_dev,
                               uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode, void* decoder, int spin,
                               void* stream);
+/* The same walk with each group's device step given as a TAPE of recorded launches instead of a graph: the entry point (HESIC_TAPE_*) and
+ * its arguments as 64-bit words, the trailing stream argument left out (supplied at replay).  Back-to-back launches of a dependent chain
+ * of small kernels start closer together than the nodes of a captured graph (ROCm 7.2).                                                */
+enum { HESIC_TAPE_JOINT_STEP = 0, HESIC_TAPE_CONV2D_FORWARD = 1, HESIC_TAPE_CONV2D_FORWARD_F32OUT = 2 };
+typedef struct { int32_t fn, nargs; uint64_t a[20]; } hesic_tape_call;
+int hesic_joint_decode_groups_tape(int n_groups, const int32_t* group_size, const hesic_tape_call* const* tapes, const int32_t* tape_len,
+                                   const hesic_gmm_desc* descs, void* const* scale_mean, const int32_t* channels, int n_channels, int minmax,
+                                   uint32_t* tab_dev, uint32_t* tab_host, int32_t* sym_dev, int32_t* sym_host, hesic_decode_grid_fn decode,
+                                   void* decoder, int spin, void* stream);
 int hesic_stream_synchronize(void* stream);
 
 /* ------------------------------------------------------------------ MS-SSIM (row M: the second published quality metric)

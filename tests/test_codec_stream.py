@@ -463,9 +463,9 @@ def test_gpu_payload_names_its_table_mode_and_a_mismatched_decoder_raises(tmp_pa
 
 @pytest.mark.gpu
 def test_gpu_joint_decode_walk_variants_agree(tmp_path, monkeypatch):
-    """The HESIC+ wavefront decode walk has eight issue forms -- the group loop in C (``hesic_joint_decode_groups``) or in Python, symbols
+    """The HESIC+ wavefront decode walk has twelve issue forms -- the group loop in C (``hesic_joint_decode_groups``) or in Python, symbols
     and tables through pinned memory the kernels address directly or through copies, the table launch inside the group's captured step
-    (``hesic_gmm_cdf_dyn``) or issued behind it: all decode one payload to the same latents and reconstructions, bit for bit (what
+    (``hesic_gmm_cdf_dyn``) or issued behind it, the C loop launching each group's graph or replaying its recorded launches one by one: all decode one payload to the same latents and reconstructions, bit for bit (what
     they change is who issues the launches, not what is launched)."""
     import hesic_amd
     from hesic_amd import models
@@ -476,19 +476,21 @@ def test_gpu_joint_decode_walk_variants_agree(tmp_path, monkeypatch):
     x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(7, 1, 128, 192))
     enc = net.compress(x1, x2, Hm, "w", str(tmp_path), order="wavefront")
     ref = None
-    for c_loop, zero_copy, tab_in_graph in [(c, z, t) for c in (True, False) for z in (True, False) for t in (True, False)]:
+    forms = [(c, z, t, tp) for c in (True, False) for z in (True, False) for t in (True, False) for tp in ((True, False) if c else (False,))]
+    for c_loop, zero_copy, tab_in_graph, tape in forms:
         monkeypatch.setattr(models, "WAVEFRONT_C_LOOP", c_loop)
+        monkeypatch.setattr(models, "WAVEFRONT_TAPE", tape)          # the C loop replays the recorded launches of a group step instead of its graph
         monkeypatch.setattr(models, "WAVEFRONT_ZEROCOPY", zero_copy)
         monkeypatch.setattr(models, "WAVEFRONT_TABLE_IN_GRAPH", tab_in_graph)
         net.__dict__.pop("_wf_cache", None)          # the captured group graphs hold the symbol / table buffer addresses
         for rep in range(2):                          # second decode: the cached graphs, another pass over the same state
             dec = net.decompress(None, None, Hm, "w", str(tmp_path))
             for k in ("y1_hat", "y2_hat"):
-                assert torch.equal(dec[k].float().cpu(), enc[k].float().cpu()), (c_loop, zero_copy, tab_in_graph, rep, k)
+                assert torch.equal(dec[k].float().cpu(), enc[k].float().cpu()), (c_loop, zero_copy, tab_in_graph, tape, rep, k)
             if ref is None:
                 ref = dec
             for k in ("x1_hat", "x2_hat"):
-                assert torch.equal(dec[k].cpu(), ref[k].cpu()), (c_loop, zero_copy, tab_in_graph, rep, k)
+                assert torch.equal(dec[k].cpu(), ref[k].cpu()), (c_loop, zero_copy, tab_in_graph, tape, rep, k)
     net.__dict__.pop("_wf_cache", None)
 
 
