@@ -138,3 +138,20 @@ def test_phase_fusion_selection_rule():
         assert l.hesic_conv2d_set_phase_fusion(7) == -1 and b"mode" in l.hesic_last_error()
     finally:
         l.hesic_conv2d_set_phase_fusion(prev if prev in (0, 1, 2) else 1)
+
+
+def test_tape_from_calls_packs_pointers_and_integers():
+    """A recorded launch becomes (entry point id, its arguments as 64-bit words without the trailing stream): byref(struct) -> the struct's
+    address (kept alive), c_void_p -> its value, None -> 0, negative integers two's complement; unknown entry points are refused."""
+    import ctypes as C
+    from hesic_amd import _lib as L
+    d = L.ConvDesc()
+    arr, keep = L.tape_from_calls([("hesic_conv2d_forward", (C.byref(d), C.c_void_p(0x1000), C.c_void_p(None), None, C.c_void_p(0x2000), C.c_void_p(7))),
+                                   ("hesic_joint_step", (C.c_void_p(16), 1, 192, 12, -1) + (0,) * 14 + (C.c_void_p(7),))])
+    assert len(arr) == 2 and arr[0].fn == L.TAPE_IDS["hesic_conv2d_forward"] and arr[0].nargs == 5
+    assert arr[0].a[0] == C.addressof(d) and keep[0] is d and arr[0].a[1] == 0x1000 and arr[0].a[2] == 0 and arr[0].a[3] == 0 and arr[0].a[4] == 0x2000
+    assert arr[1].fn == L.TAPE_IDS["hesic_joint_step"] and arr[1].nargs == 19 and arr[1].a[4] == 0xFFFFFFFFFFFFFFFF
+    with pytest.raises(KeyError):
+        L.tape_from_calls([("hesic_gmm_cdf", (None, None))])
+    with pytest.raises(TypeError):
+        L.tape_from_calls([("hesic_conv2d_forward", (1.5, None))])
