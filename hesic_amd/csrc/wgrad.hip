@@ -39,6 +39,7 @@ struct WgArgs {
     int QH, QW, transposed, stride, pad, KW, in_abs, in_sq;
     int64_t Q, chunk;
     int co_tiles, ci_tiles, ntaps, nsplit;
+    int rowk;                                      // wgrad_row_kernel takes this layer (fill_args): blocks = KH x tiles x nsplit
     int8_t tap_id[25];
     // bias gradient on the matrix cores (wgrad_tr_kernel only): the blocks of the taps listed in b_tap (indices into the live taps)
     // with ci tile 0 also form the column sums of their dY slice -- one more MFMA per cout fragment and k-step against a fragment of
@@ -560,6 +561,216 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
                 if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[i][j][r];
             }
         }
+}
+
+// ---------------------------------------------------------------- one kernel ROW of taps per block (round 5)
+// wgrad_tr_kernel moves 32 KB of operands through L2 -> LDS for every 16 MFMAs of a wave: on the 128 -> 128 5x5 stride-2 layers of the
+// 256^2 maps (conv2 / deconv3, 107 GFLOP each at B = 8) the 25 tap blocks of a pixel range re-read dY 25 times and X 6.25 times --
+// 1.68 GB per launch out of L2 / the Infinity Cache, ~10 TB/s, the matrix pipe 26 % busy and half of the wave cycles parked at vmcnt
+// (profiles/r04_f_pmc_sq_train.json).  Here a block owns the five taps (ky, 0..4) of one kernel row: for 64 consecutive q of ONE image row
+// the linear operand (dY for a conv, X for a transposed conv) is staged once and serves all five taps, and the shifted operand's pixels
+// q * 2 + kx - 2 of the five taps are 131 CONSECUTIVE pixels of one image row -- staged once as an even and an odd plane (tap kx reads
+// plane kx & 1 from row (kx >> 1) on), so neighbouring taps share them too: 50 KB per 40 MFMAs of a wave instead of 32 KB per 16
+// (0.31 GB per launch), 14 transposing LDS reads per 10 MFMAs instead of 16 per 8.  Eight waves (2 per SIMD): wave = 64 channels of the
+// linear operand x 32 of the shifted one x 5 taps = 160 accumulator registers; a ring of three 50 KB stages, one block per CU.
+// The split-K partials keep wgrad_tr_kernel's layout [split][tap][Cout][Cin] (same finishing passes); what grows is their volume:
+// blocks x 5 taps x 64 KB (82 MB for 250 blocks), the price of the larger accumulator tile per CU.  The bias column sums ride on the
+// VALU (the fragments a lane holds are 8 pixels of one channel) in the waves / blocks that see every dY pixel once.
+struct WgRowArgs { WgArgs w; float* zero_me; int zero_n; FastDiv dqw, dqh; };
+
+constexpr int ROW_LINB = 64 * 256, ROW_PLR = 68, ROW_SFTB = 2 * ROW_PLR * 256, ROW_STAGE = ROW_LINB + ROW_SFTB, ROW_NST = 3;
+constexpr int ROW_LDS = ROW_NST * ROW_STAGE;
+
+template <bool TR>
+__global__ __launch_bounds__(512) void wgrad_row_kernel(const WgRowArgs A) {
+    const WgArgs& a = A.w;
+    constexpr int LINB = ROW_LINB, PLR = ROW_PLR, STAGE = ROW_STAGE, NST = ROW_NST;
+    constexpr int NLIN = 16, NSFT = 2 * PLR / 4, NINS = NLIN + NSFT;       // DMA instructions (4 tile rows = 1 KB each) per stage: 16 + 34
+    constexpr int PW = (NINS + 7) / 8;                                      // per wave: 7 (waves 0, 1) or 6
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (A.zero_me && blockIdx.x == 0)
+        for (int i = tid; i < A.zero_n; i += 512) A.zero_me[i] = 0.f;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ky = bid % 5; bid /= 5;
+    const int cit = bid % a.ci_tiles; bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles; bid /= a.co_tiles;
+    const int split = bid;
+    const int co0 = cot * TC, ci0 = cit * TC;
+    const int64_t q_begin = split * a.chunk;
+    const int64_t q_end = (q_begin + a.chunk < a.Q) ? q_begin + a.chunk : a.Q;
+    const int nsteps = (int)((q_end - q_begin) >> 6);          // chunk and Q are multiples of 64 (launcher)
+
+    constexpr uint32_t OOB = 0x80000000u;
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+    const int SH = TR ? a.Ho : a.H, SW = TR ? a.Wo : a.W;
+    const uint32_t lin_ps = (uint32_t)((TR ? a.x_ps : a.y_ps) * 2), sh_ps = (uint32_t)((TR ? a.y_ps : a.x_ps) * 2);
+    const uint32_t neg_b = 2u * sh_ps;                         // the shifted operand's resource starts pad = 2 pixels early: soffset >= 0
+    const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc((void*)(TR ? a.x : a.dy), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)(TR ? a.dy : a.x) - neg_b), 0, (int)OOB, 0x00020000);
+    const int lrow = lane >> 4, pslot = lane & 15;
+    const int ls = pslot ^ ((lrow & 3) << 2);                  // 16-byte slot this lane FETCHES for LDS slot pslot (rows of an instruction are 4-aligned)
+    const int lin_c = (TR ? ci0 : co0) + ls * 8, sft_c = (TR ? co0 : ci0) + ls * 8;
+    const bool lin_ok = lin_c < (TR ? a.Cin : a.Cout), sft_ok = sft_c < (TR ? a.Cout : a.Cin);
+    const uint32_t v_lin = lin_ok ? (uint32_t)lrow * lin_ps + (uint32_t)(((TR ? a.x_co : a.y_co) + lin_c) * 2) : OOB;
+    const uint32_t sft_cb = (uint32_t)(((TR ? a.y_co : a.x_co) + sft_c) * 2);
+    // instruction n = wave + 8 i of a stage: n < 16 -> rows 4n .. 4n+3 of the linear tile; else instruction n - 16 of the shifted tile
+    // (rows 4 (n - 16) .. of plane 0 = even pixels for n - 16 < 17, of plane 1 = odd pixels from 17 on)
+    int sxrel[PW];                                             // pixel (relative to the stage's first = q0 * 2 - 2) of this lane's row
+    uint32_t v_sft[PW];
+#pragma unroll
+    for (int i = 2; i < PW; ++i) {
+        const int mi = wave + 8 * i - NLIN, p = mi >= PLR / 4 ? 1 : 0;
+        const int m = 4 * (mi - p * (PLR / 4)) + lrow;
+        sxrel[i] = 2 * m + p;
+        v_sft[i] = sft_ok ? (uint32_t)sxrel[i] * sh_ps + sft_cb : OOB;
+    }
+    uint32_t sq = (uint32_t)q_begin;                           // first q of the next stage to issue, and its (b, qy, qx)
+    int sqx, sqy, sqb;
+    {
+        const uint32_t r1 = fdiv(sq, A.dqw);
+        sqx = (int)(sq - r1 * (uint32_t)a.QW);
+        const uint32_t b = fdiv(r1, A.dqh);
+        sqy = (int)(r1 - b * (uint32_t)a.QH);
+        sqb = (int)b;
+    }
+    auto issue = [&](int buf) {
+        unsigned char* lt = smem + buf * STAGE;
+        unsigned char* stt = lt + LINB;
+        const bool inq = sq < (uint32_t)q_end;
+        const int sy = sqy * 2 + ky - 2, sxb = sqx * 2 - 2;
+        const bool rowok = inq && (unsigned)sy < (unsigned)SH;
+        const uint32_t so_l = sq * lin_ps;
+        const uint32_t so_s = (uint32_t)(((sqb * SH + sy) * SW + sqx * 2) * (int)sh_ps);
+        const uint32_t vl = inq ? v_lin : OOB;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int n = wave + 8 * i;
+            if (i < 2) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (__attribute__((address_space(3))) void*)(lt + n * 1024), 16, (int)vl,
+                                                         (int)(so_l + (uint32_t)(4 * n) * lin_ps), 0, 0);
+            } else {
+                if (i == PW - 1 && n >= NINS) continue;        // wave-uniform
+                const bool okx = rowok && (unsigned)(sxb + sxrel[i]) < (unsigned)SW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(stt + (n - NLIN) * 1024), 16,
+                                                         (int)(okx ? v_sft[i] : OOB), (int)so_s, 0, 0);
+            }
+        }
+        sq += 64;
+        sqx += 64;
+        if (sqx >= a.QW) {                                     // QW % 64 == 0: a stage never straddles a row
+            sqx = 0;
+            if (++sqy >= a.QH) { sqy = 0; ++sqb; }
+        }
+    };
+
+    const int wl = wave & 1, wsd = wave >> 1;                  // 64-channel half of the linear operand, 32-channel quarter of the shifted one
+    const int frow = lane & 31, fh = lane >> 5, g = lane >> 4, t = lane & 15;
+    const int chs = (g & 1) * 16 + 4 * (t & 3), rsub = fh * 8 + (t >> 2);
+    auto foff = [&](int cb, int rbase) {
+        const int row = rbase + rsub, ch = cb + chs;
+        return row * 256 + (((ch >> 3) ^ ((row & 3) << 2)) << 4) + (ch & 7) * 2;
+    };
+    int lo_off[2], so_off[5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lo_off[i] = foff(wl * 64 + i * 32, 0);
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) so_off[kx] = LINB + foff(wsd * 32, (kx & 1) * PLR + (kx >> 1));
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kx][i][r] = 0.f;
+    // bias column sums: a conv's dY is the linear operand (every block sees all of it: the ky = 0 blocks of ci tile 0 sum it, in the two
+    // waves of shifted-quarter 0); a transposed conv's dY is the shifted one: rows 2 qy + ky - 2 and pixels 2 qx + kx - 2 with ky, kx in
+    // {2, 3} cover every dY pixel exactly once (slots (ky - 2) * 2 + (kx - 2), the order setup_bias_part lists them)
+    const bool bias_blk = a.bias_part && cit == 0 && (TR ? (ky == 2 || ky == 3) : ky == 0);
+    const bool bias_wave = bias_blk && (TR ? wl == 0 : wsd == 0);
+    float bsum[2] = {0.f, 0.f};
+
+    auto sum8 = [](const s16x4 lo, const s16x4 hi) {
+        const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+        return ((h2f_lo(l.x) + h2f_hi(l.x)) + (h2f_lo(l.y) + h2f_hi(l.y))) + ((h2f_lo(h.x) + h2f_hi(h.x)) + (h2f_lo(h.y) + h2f_hi(h.y)));
+    };
+    auto main_loop = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        if (nsteps > 0) {
+#pragma unroll
+            for (int p = 0; p < NST - 1; ++p) issue(p);
+        }
+        int buf = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            if (wave < NINS - 8 * (PW - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (PW - 1)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(buf == 0 ? NST - 1 : buf - 1);                // the stage consumed one step ago
+            const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned char* kb = st + ks * 4096;
+                h16x8 lf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kb + lo_off[i]));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kb + lo_off[i] + 1024));
+                    lf[i] = __builtin_bit_cast(h16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (BIAS && !TR) bsum[i] += sum8(l0, l1);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const s16x4 s0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kb + so_off[kx]));
+                    const s16x4 s1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kb + so_off[kx] + 1024));
+                    const h16x8 sf = __builtin_bit_cast(h16x8, __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (BIAS && TR) {
+                        if (kx == 2) bsum[0] += sum8(s0, s1);
+                        if (kx == 3) bsum[1] += sum8(s0, s1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if constexpr (TR) acc[kx][i] = mfma_32x32x16_h16(sf, lf[i], acc[kx][i], 0, 0, 0);
+                        else acc[kx][i] = mfma_32x32x16_h16(lf[i], sf, acc[kx][i], 0, 0, 0);
+                    }
+                }
+            }
+            buf = buf + 1 == NST ? 0 : buf + 1;
+        }
+    };
+    if (bias_wave) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+
+    if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            if (fh == 0) {
+                if constexpr (TR) {
+                    const int co = co0 + wsd * 32 + frow;
+                    if (co < a.Cout) a.bias_part[((int64_t)split * a.nb_taps + (ky - 2) * 2 + i) * a.Cout + co] = s;
+                } else {
+                    const int co = co0 + wl * 64 + i * 32 + frow;
+                    if (co < a.Cout) a.bias_part[(int64_t)split * a.nb_taps * a.Cout + co] = s;
+                }
+            }
+        }
+    }
+    // C[row = A's channel][col = B's channel]: col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+        float* out = a.out + ((int64_t)split * a.ntaps + ky * 5 + kx) * a.Cout * a.Cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ci = TR ? ci0 + wl * 64 + i * 32 + frow : ci0 + wsd * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int co = TR ? co0 + wsd * 32 + rr : co0 + wl * 64 + i * 32 + rr;
+                if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[kx][i][r];
+            }
+        }
+    }
 }
 
 // dw[tap_id[t]][..] = sum_s ws[s][t][..]; dead taps (masked conv) are zero-filled by the host memset
@@ -1679,6 +1890,21 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const h16_t* __restrict
 }
 
 void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zero_me = nullptr, int zero_n = 0) {
+    if (a.rowk) {
+        WgRowArgs R;
+        R.w = a; R.zero_me = zero_me; R.zero_n = zero_n;
+        R.dqw = make_fastdiv((uint32_t)a.QW); R.dqh = make_fastdiv((uint32_t)a.QH);
+        static bool rattr = false;
+        if (!rattr) {
+            (void)hipFuncSetAttribute((const void*)wgrad_row_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW_LDS);
+            (void)hipFuncSetAttribute((const void*)wgrad_row_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW_LDS);
+            rattr = true;
+        }
+        const dim3 g((unsigned)(5 * a.co_tiles * a.ci_tiles * a.nsplit)), b(512);
+        if (a.transposed) hipLaunchKernelGGL(wgrad_row_kernel<true>, g, b, ROW_LDS, st, R);
+        else hipLaunchKernelGGL(wgrad_row_kernel<false>, g, b, ROW_LDS, st, R);
+        return;
+    }
     WgTrArgs A;
     A.w = a;
     A.zero_me = zero_me; A.zero_n = zero_n;
@@ -1738,6 +1964,28 @@ int fill_args(const hesic_conv_desc* d, WgArgs& a) {
         if (!d->tap_mask_lo || ((d->tap_mask_lo >> t) & 1)) a.tap_id[n++] = (int8_t)t;
     a.ntaps = n;
     const int bk = d->dtype == HESIC_H16 ? WC<h16_t>::BK : WC<float>::BK;
+    // wgrad_row_kernel: 5x5, stride 2, pad 2, every tap live, 64-pixel stages that stay inside one image row, and enough pixels that a
+    // K slice per CU outweighs the 5-tap partial tiles every block leaves (HESIC_WGRAD_ROW=0: off, A/B; HESIC_WGRAD_ROW_MINQ)
+    {
+        const char* e = getenv("HESIC_WGRAD_ROW");
+        const char* mq = getenv("HESIC_WGRAD_ROW_MINQ");
+        const int64_t minq = mq ? atoll(mq) : 100000;
+        const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
+        a.rowk = (!e || atoi(e) != 0) && d->dtype == HESIC_H16 && d->KH == 5 && d->KW == 5 && d->stride == 2 && d->pad == 2 && n == 25 && !d->in_abs &&
+                 a.QW % 64 == 0 && a.Q >= minq && a.Q < (1ll << 31) && off32;
+    }
+    if (a.rowk) {
+        const char* tb = getenv("HESIC_WGRAD_ROW_BLOCKS");
+        const int target = tb ? atoi(tb) : 256;                 // one block per CU (150 KB of LDS)
+        const int64_t stages = a.Q / 64;
+        int64_t s = target / (5 * a.co_tiles * a.ci_tiles);
+        if (s < 1) s = 1;
+        if (s > stages) s = stages;
+        const int64_t per = (stages + s - 1) / s;
+        a.chunk = per * 64;
+        a.nsplit = (int)((stages + per - 1) / per);
+        return 0;
+    }
     a.nsplit = pick_splits(a.Q, bk, n * a.co_tiles * a.ci_tiles);
     a.chunk = ((a.Q + a.nsplit - 1) / a.nsplit + bk - 1) / bk * bk;
     a.nsplit = (int)((a.Q + a.chunk - 1) / a.chunk);
