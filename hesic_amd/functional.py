@@ -865,9 +865,10 @@ def conv2d_latent(x, weight, bias, *, kernel_size, stride, padding, transposed=F
 #   "x3c2"  as "x3", but g_a_conv2 (128 -> 128 5x5 s2 on the largest map: 70 % of g_a's MACs) multiplies SINGLE operands -- one product per
 #           MAC; its input leaves the conv1 + GDN kernel as one 16-bit value per channel, its GDN epilogue runs on pairs and hands pairs on.
 #           Meant for float16 (11-bit significand: ~6e-4 of the latents flip against the fp32 reference; with bfloat16 it is ~5e-3);
+#   "x2"    pairs everywhere, TWO products per MAC: x pairs x single error-feedback weights (no w_lo term; round 5, measured and not the default);
 #   "x1"    single operands everywhere (round 2's path; float16: ~1.3e-3 flips, bfloat16: ~1e-2).
 # "bf16x3" / "bf16" are the round-3 names of "x3" / "x1".
-ANALYSIS_MODES = ("x1", "x3", "x3c2")
+ANALYSIS_MODES = ("x1", "x3", "x3c2", "x2")
 _ANALYSIS_ALIASES = {"bf16": "x1", "bf16x3": "x3"}
 
 
@@ -882,10 +883,12 @@ _analysis_mode = _canon_analysis(_os.environ.get("HESIC_ANALYSIS", "auto"))
 
 
 def set_analysis_precision(mode):
-    """Operand precision of the analysis transforms + hyper-analysis of a 16-bit inference forward: "x3", "x3c2", "x1" (see above) or
-    "auto" (the default: "x3c2" with float16 maps -- measured 4e-4 ... 7e-4 flipped latents, set-average |dbpp| 2e-4, |dPSNR| 2e-5 dB against
-    the fp32 reference at 1.25x the speed of "x3" -- and "x3" with bfloat16 maps, where one product per MAC flips 5e-3).  Returns the
-    previous setting."""
+    """Operand precision of the analysis transforms + hyper-analysis of a 16-bit inference forward: "x3", "x3c2", "x2", "x1" (see above) or
+    "auto" (the default) = "x3" for both 16-bit formats.  Round 4's default for float16 maps was "x3c2" (1.25x the speed of "x3"); round 5
+    measured it at TRAINED operating points (piecewise-smooth pairs, 30 - 33 dB, ``profiles/scripts/parity_smooth.py``): 2.6 - 8e-4 of the
+    latents flip there and every flip moves the reconstruction -- |dPSNR| 2 - 6e-3 dB, outside north_star's 1e-3 -- where "x3" stays at
+    <= 5e-6 flips / 1.6 - 3.6e-4 dB.  "x3c2" (and "x2" = pairs x single error-feedback weights, 1.5 - 2.1e-4 flips, 1.3 - 1.5e-3 dB) stay
+    available as explicit fast modes.  Returns the previous setting."""
     global _analysis_mode
     prev, _analysis_mode = _analysis_mode, _canon_analysis(mode)
     return prev
@@ -894,7 +897,7 @@ def set_analysis_precision(mode):
 def analysis_precision():
     """The mode in effect for the current compute dtype ("auto" resolved)."""
     if _analysis_mode == "auto":
-        return "x3c2" if _compute_dtype == torch.float16 else "x3"
+        return "x3"
     return _analysis_mode
 
 

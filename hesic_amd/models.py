@@ -341,6 +341,15 @@ class Encoder1(nn.Module):
             return Fn.HiLo((lo, self.g_a_conv4.weight.shape[0])), y
         if fused1:
             t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse)       # conv + GDN in one kernel
+            if Fn.analysis_precision() == "x2":
+                # pairs everywhere, TWO products per MAC: x pairs x single error-feedback weights (no w_lo term)
+                p2, p3, p4 = (int(v) for v in _os.environ.get("HESIC_X2_LAYERS", "2,2,2").split(","))
+                t = self.g_a_conv2.run_hilo(t, gdn=self.g_a_gdn2, products=p2)
+                t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3, products=p3)
+                if not want_lo:
+                    return None, self.g_a_conv4.run_hilo(t, out="f32", products=p4)
+                lo, y = self.g_a_conv4.run_hilo(t, out="both", out_abs=lo_abs, products=p4)
+                return Fn.HiLo((lo, self.g_a_conv4.weight.shape[0])), y
         else:
             KP = 96                                        # other layouts: 3 * 25 = 75 im2col columns (padded) -> 1x1 implicit GEMM + GDN
             t = Fn.im2col_hilo(x, 5, 2, 2, KP)

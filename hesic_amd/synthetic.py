@@ -197,6 +197,51 @@ def stereo_pair(seed: int, height: int, width: int):
     return x1.astype(np.float32), x2.astype(np.float32), H.astype(np.float32)
 
 
+def _upsample_linear(grid: np.ndarray, height: int, width: int) -> np.ndarray:
+    """(C, h, w) coarse grid -> (C, height, width), separable linear interpolation with the grid's corners on the image corners."""
+    C, h, w = grid.shape
+    ys, xs = np.linspace(0.0, h - 1.0, height), np.linspace(0.0, w - 1.0, width)
+    y0, x0 = np.minimum(ys.astype(np.int64), h - 2), np.minimum(xs.astype(np.int64), w - 2)
+    fy, fx = (ys - y0)[None, :, None], (xs - x0)[None, None, :]
+    rows = grid[:, y0, :] * (1 - fy) + grid[:, y0 + 1, :] * fy
+    return rows[:, :, x0] * (1 - fx) + rows[:, :, x0 + 1] * fx
+
+
+def smooth_stereo_pair(seed: int, height: int, width: int):
+    """(x1, x2, H) for a PIECEWISE-SMOOTH pair (round 5): the content a trained codec sees on photographs, where ``stereo_pair``'s
+    low-passed noise is close to incompressible (a model trained on it stops near 20 dB).  x1 = a luminance field interpolated from a
+    coarse (one knot per 64 pixels) random grid with a weaker per-channel chroma field, plus four soft-edged regions (discs / half
+    planes) that shift the level by up to 0.2, plus 3x3-boxed texture of amplitude 0.02; x2 = warp(x1, H) + N(0, 0.004).  PCG64 seeded
+    like ``stereo_pair`` (pair i = seed i), same homographies."""
+    r = np.random.Generator(np.random.PCG64(7_000_003 + seed))
+    gh, gw = max(2, height // 64 + 1), max(2, width // 64 + 1)
+    lum = _upsample_linear(r.uniform(0.2, 0.8, size=(1, gh, gw)), height, width)
+    chroma = _upsample_linear(r.uniform(-0.12, 0.12, size=(3, gh, gw)), height, width)
+    img = lum + chroma
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    for _ in range(4):
+        kind, cy, cx = r.integers(0, 2), r.uniform(0, height), r.uniform(0, width)
+        level = r.uniform(-0.2, 0.2, size=(3, 1, 1)) * np.array([1.0, 0.9, 0.8]).reshape(3, 1, 1)
+        if kind == 0:
+            rad = r.uniform(0.08, 0.3) * min(height, width)
+            d = rad - np.sqrt((ys - cy) ** 2 + (xs - cx) ** 2)
+        else:
+            th = r.uniform(0, 2 * np.pi)
+            d = (ys - cy) * np.sin(th) + (xs - cx) * np.cos(th)
+        img = img + level * np.clip(d / 3.0 + 0.5, 0.0, 1.0)[None]          # a 3-pixel ramp: an edge, not a step the warp would alias
+    img = img + 0.02 * _box3(r.uniform(-1.0, 1.0, size=(3, height, width)))
+    x1 = np.clip(img, 0.0, 1.0)
+    H = homography(seed)
+    x2 = np.clip(_warp_np(x1, H) + r.normal(0.0, 0.004, size=x1.shape), 0.0, 1.0)
+    return x1.astype(np.float32), x2.astype(np.float32), H.astype(np.float32)
+
+
+def smooth_stereo_batch(first_seed: int, batch: int, height: int, width: int):
+    xs1, xs2, hs = zip(*(smooth_stereo_pair(first_seed + i, height, width) for i in range(batch)))
+    return (torch.from_numpy(np.stack(xs1)), torch.from_numpy(np.stack(xs2)),
+            torch.from_numpy(np.stack(hs)))
+
+
 def stereo_batch(first_seed: int, batch: int, height: int, width: int):
     xs1, xs2, hs = zip(*(stereo_pair(first_seed + i, height, width) for i in range(batch)))
     return (torch.from_numpy(np.stack(xs1)), torch.from_numpy(np.stack(xs2)),

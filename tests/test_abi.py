@@ -60,16 +60,18 @@ def test_compute_dtype_selects_the_library():
 
 
 def test_analysis_precision_modes():
-    """Host logic of the analysis-precision switch: "auto" resolves per compute dtype, round-3 names stay valid."""
+    """Host logic of the analysis-precision switch: "auto" resolves to the pair mode, the fast modes are explicit, round-3 names stay valid."""
     import torch
     import hesic_amd
     from hesic_amd import functional as Fn
     prev = Fn.set_analysis_precision("auto")
     try:
         hesic_amd.set_compute_dtype(torch.float16)
-        assert Fn.analysis_precision() == "x3c2"
+        assert Fn.analysis_precision() == "x3"          # round 5: the parity-strict pair mode for both 16-bit formats
         hesic_amd.set_compute_dtype(torch.bfloat16)
         assert Fn.analysis_precision() == "x3"
+        Fn.set_analysis_precision("x3c2")
+        assert Fn.analysis_precision() == "x3c2" and Fn.analysis_conv2_single()
         Fn.set_analysis_precision("bf16x3")
         assert Fn.analysis_precision() == "x3"
         Fn.set_analysis_precision("bf16")

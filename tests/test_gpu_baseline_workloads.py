@@ -82,8 +82,8 @@ def check_against(g, out, x1, x2, flips_max, bits_rel, sse_rel, psnr_db, view_ps
 #   sse: per-view squared error, relative;  psnr / view: dB of the two-view mean the reference reports / of each view;
 #   dbpp: |mean over the pairs of (bpp - bpp_ref)|, ABSOLUTE (north_star: bpp within 1e-3)
 MODE_BARS = {
-    ("f16", "x3c2"): dict(flips_max=1e-3, bits_rel=1.5e-3, sse_rel=1e-4, psnr_db=4e-4, view_psnr_db=6e-4, dbpp=1e-3),     # the benchmark's default
-    ("f16", "x3"): dict(flips_max=1e-4, bits_rel=1e-3, sse_rel=5e-5, psnr_db=1e-4, view_psnr_db=2e-4, dbpp=1e-3),
+    ("f16", "x3c2"): dict(flips_max=1e-3, bits_rel=1.5e-3, sse_rel=1e-4, psnr_db=4e-4, view_psnr_db=6e-4, dbpp=1e-3),     # round 4's default; an explicit fast mode now
+    ("f16", "x3"): dict(flips_max=1e-4, bits_rel=1e-3, sse_rel=5e-5, psnr_db=1e-4, view_psnr_db=2e-4, dbpp=1e-3),          # the benchmark's default (round 5)
     ("bf16", "x3"): dict(flips_max=2e-4, bits_rel=1e-3, sse_rel=1e-3, psnr_db=1e-3, view_psnr_db=2e-3, dbpp=1e-3),        # round 3's headline mode
 }
 
@@ -96,7 +96,7 @@ def test_16bit_512_batch_matches_the_reference_pair_by_pair(kind, batch, fmt, an
     from hesic_amd import functional as Fn
     g = load_golden(f"{kind}_512_b{batch}.npz")
     net = build(kind, {"f16": torch.float16, "bf16": torch.bfloat16}[fmt])
-    assert Fn.analysis_precision() == ("x3c2" if fmt == "f16" else "x3")           # "auto"
+    assert Fn.analysis_precision() == "x3"           # "auto": the pair mode for both 16-bit formats (round 5)
     Fn.set_analysis_precision(analysis)
     bars = dict(MODE_BARS[(fmt, analysis)])
     dbpp_bar = bars.pop("dbpp")
@@ -106,6 +106,12 @@ def test_16bit_512_batch_matches_the_reference_pair_by_pair(kind, batch, fmt, an
         meas = check_against(g, out, x1, x2, **bars)
         assert meas["dbpp_abs_set_mean"] < dbpp_bar, meas
         assert meas["dbpp_rel"] < 1e-3, meas
+        if (fmt, analysis, kind) == ("f16", "x3", "hsic"):
+            # the default mode holds north_star's ABSOLUTE 1e-3 bpp bar for EVERY pair of C2, not only for the set average the reference
+            # reports (round 4's x3c2 default missed it on three of eight pairs: +1.2e-3, -0.8e-3, -1.1e-3; measured now: 5.3e-4 worst pair).
+            # C4's random-weight bpp is 12.2: 1e-3 absolute would be 8e-5 RELATIVE there -- its per-pair bar is the relative one above
+            # (measured 1.4e-4 = 1.7e-3 absolute worst pair, 3e-4 set average)
+            assert meas["dbpp_abs"] < 1e-3, meas
         # pairs are independent: the last pair alone reproduces its slice of the batch bit for bit
         one = net(x1[-1:], x2[-1:], Hm[-1:])
     for k in ("y1_hat", "y2_hat", "x1_hat", "x2_hat"):
@@ -139,16 +145,25 @@ def test_fp32_512_batch_matches_the_reference(kind):
     check_against(g2, out, x1, x2, flips_max=2e-4, bits_rel=1e-3, sse_rel=1e-3, psnr_db=1e-3)
 
 
+# C5 bars per mode: (bits of a lambda-model relative, PSNR dB, digest of |y_hat| relative, flipped latents of model 0)
+C5_BARS = {("f16", "x3"): (1e-3, 1e-3, 1e-4, 1e-4), ("f16", "x3c2"): (1.5e-3, 1e-3, 1e-3, 1e-3), ("bf16", "x3"): (1e-3, 1e-3, 2e-4, 1e-3)}
+
+
+@pytest.mark.parametrize("fmt,analysis", list(C5_BARS), ids=["-".join(k) for k in C5_BARS])
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
-def test_c5_lambda_sweep_accumulators_match_the_reference(kind):
+def test_c5_lambda_sweep_accumulators_match_the_reference(kind, fmt, analysis):
     """BASELINE config C5 through ``evaluate.LambdaSweep`` (what ``bench.py --sweep`` times): four lambda-models on an 860 x 1080 pair
     padded to 896 x 1088, bits and squared error accumulated on the device, bpp / PSNR over the original pixels -- against the
-    reference's run of the same four weight sets on the same padded pair."""
+    reference's run of the same four weight sets on the same padded pair.  Every mode ``bench.py --sweep`` can time: float16 maps with
+    the pair analysis (its default), float16 "x3c2" (round 4's timed mode, which had no golden check at this size), bfloat16 pairs."""
     import hesic_amd
-    from hesic_amd import models
+    from hesic_amd import functional as Fn, models
     from hesic_amd.evaluate import SWEEP_LAMBDAS, LambdaSweep
     g = load_golden(f"{kind}_c5.npz")
-    hesic_amd.set_compute_dtype(torch.bfloat16)
+    hesic_amd.set_compute_dtype({"f16": torch.float16, "bf16": torch.bfloat16}[fmt])
+    Fn.set_analysis_precision(analysis)
+    bits_rel, psnr_db, digest_rel, flips_max = C5_BARS[(fmt, analysis)]
+    meas = {}
     sweep = LambdaSweep(kind, torch.device(DEV))
     x1, x2, Hm = synthetic.stereo_batch(0, 1, 860, 1080)
     x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)
@@ -163,13 +178,18 @@ def test_c5_lambda_sweep_accumulators_match_the_reference(kind):
         ref_psnr = (10 * math.log10(npx * 3 / s1) + 10 * math.log10(npx * 3 / s2)) / 2
         got = per[str(lam)]
         assert got["pairs"] == 1
-        assert got["bits"] == pytest.approx(ref_bits, rel=1e-3), (lam, got["bits"], ref_bits)
-        assert abs(got["psnr"] - ref_psnr) < 1e-3, (lam, got["psnr"], ref_psnr)
+        meas[f"bits_rel_{m}"] = abs(got["bits"] / ref_bits - 1)
+        meas[f"dpsnr_db_{m}"] = abs(got["psnr"] - ref_psnr)
+        assert got["bits"] == pytest.approx(ref_bits, rel=bits_rel), (lam, got["bits"], ref_bits)
+        assert abs(got["psnr"] - ref_psnr) < psnr_db, (lam, got["psnr"], ref_psnr)
         for k in ("y1_hat", "y2_hat"):          # digest of every model's latents; the full tensors of model 0
-            assert float(outs[m][k].double().abs().sum()) == pytest.approx(float(g[f"{k}_abs_sum_{m}"]), rel=2e-4), (lam, k)
+            meas[f"digest_rel_{k}_{m}"] = abs(float(outs[m][k].double().abs().sum()) / float(g[f"{k}_abs_sum_{m}"]) - 1)
+            assert meas[f"digest_rel_{k}_{m}"] <= digest_rel, (lam, k, meas)
     for k in ("y1_hat", "y2_hat"):
         assert outs[0][k].shape == (1, 192, 56, 68)
-        assert float((outs[0][k].float().cpu().to(torch.int16) != T(g[k]).to(torch.int16)).float().mean()) <= 1e-3, k
+        meas["flips_" + k] = float((outs[0][k].float().cpu().to(torch.int16) != T(g[k]).to(torch.int16)).float().mean())
+        assert meas["flips_" + k] <= flips_max, (k, meas)
+    print("measured:", {k: float("%.3g" % v) for k, v in meas.items()})
 
 
 def _train_noise(kind, order, B):
@@ -255,7 +275,7 @@ def test_trained_operating_point_parity_at_512():
         ref = O.hsic_forward(P, x1, x2, Hm)
     mr = O.metrics(ref, x1, x2)
     recs = {}
-    for name, dt, an in (("f16-auto", torch.float16, "auto"), ("f16-x3", torch.float16, "x3"), ("bf16-x3", torch.bfloat16, "x3")):
+    for name, dt, an in (("f16-x3c2", torch.float16, "x3c2"), ("f16-x3", torch.float16, "auto"), ("bf16-x3", torch.bfloat16, "x3")):
         hesic_amd.set_compute_dtype(dt)
         Fn.set_analysis_precision(an)
         with torch.no_grad():
@@ -265,9 +285,99 @@ def test_trained_operating_point_parity_at_512():
         recs[name] = {"dbpp": m["bpp"] - mr["bpp"], "dpsnr_db": m["psnr"] - mr["psnr"], "flips": flips, "mode": Fn.analysis_precision()}
     print("trained point: loss %.2f -> %.2f, bpp %.4f, PSNR %.3f dB (oracle);" % (first, last, mr["bpp"], mr["psnr"]),
           {k: {kk: (float("%.3g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in recs.items()})
-    assert recs["f16-auto"]["mode"] == "x3c2"
-    for name in ("f16-auto", "f16-x3"):
+    assert recs["f16-x3"]["mode"] == "x3" and recs["f16-x3c2"]["mode"] == "x3c2"
+    for name in ("f16-x3c2", "f16-x3"):
         r = recs[name]
         assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 1e-3 and r["flips"] <= 1e-3, (name, r)
     r = recs["bf16-x3"]
     assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 2e-3 and r["flips"] <= 1e-3, ("bf16-x3", r)
+
+
+def test_trained_30db_operating_point_parity_at_512():
+    """Parity at an operating point like the published ones (Readme.md:33-46: 33 - 37 dB): graph-replayed training steps (bf16, B=8,
+    256 x 256 PIECEWISE-SMOOTH synthetic pairs, ``synthetic.smooth_stereo_pair``; lambda 0.02, the reference's lr 1e-4, newtrain1.py:180-185)
+    take the deterministic init to >= 30 dB (checked every 500 steps from 1500 on, at most 5000: the loss of this unclipped recipe spikes now
+    and then, as the reference's would); then the 16-bit inference modes against the fp32 CPU oracle run on THOSE weights on a 512 x 512
+    smooth pair.
+    The default mode (float16 maps, pair analysis) must hold north_star's bars there: |dbpp| < 1e-3, |dPSNR| < 1e-3 dB, and -- at an MSE of
+    ~6e-4 every flipped latent is visible in the PSNR -- <= 1e-4 flipped latents.  The explicit fast mode "x3c2" (round 4's default) is
+    measured next to it under the wider bars it actually meets here (<= 1e-3 flips, |dPSNR| < 1e-2 dB: 2 - 6e-3 dB measured, which is why
+    it stopped being the default); bfloat16 pairs likewise (storage noise of the synthesis maps: 4e-3 dB measured, bar 1e-2)."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, models
+    from hesic_amd.train import GraphedTrainer
+    from oracle import hesic_oracle as O
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    net = models.HSIC()
+    synthetic.fill_state_dict_(net.state_dict())
+    net = net.to(DEV)
+    torch.manual_seed(5)
+    tr = GraphedTrainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.02)
+    pool = [tuple(t.to(DEV) for t in synthetic.smooth_stereo_batch(100 + 8 * i, 8, 256, 256)) for i in range(8)]
+    x1, x2, Hm = synthetic.smooth_stereo_batch(0, 1, 512, 512)
+    xd = tuple(t.to(DEV) for t in (x1, x2, Hm))
+    steps, psnr_now = 0, 0.0
+    while steps < 5000 and psnr_now < 30.3:
+        for st in range(500):
+            tr.step(*pool[(steps + st) % len(pool)])
+        steps += 500
+        if steps >= 1500:
+            net.eval()
+            Fn.invalidate_weight_cache()
+            with torch.no_grad():
+                o = net(*xd)
+                psnr_now = models.metrics_from(models.rate_distortion(o, xd[0], xd[1]))["psnr"]
+            net.train()
+    torch.cuda.synchronize()
+    del tr
+    net.eval()
+    net.update(force=True)
+    Fn.invalidate_weight_cache()
+    P = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.hsic_forward(P, x1, x2, Hm)
+    mr = O.metrics(ref, x1, x2)
+    assert mr["psnr"] >= 30.0, mr            # the point of this test
+    recs = {}
+    for name, dt, an in (("f16-x3", torch.float16, "auto"), ("f16-x3c2", torch.float16, "x3c2"), ("bf16-x3", torch.bfloat16, "x3")):
+        hesic_amd.set_compute_dtype(dt)
+        Fn.set_analysis_precision(an)
+        with torch.no_grad():
+            out = net(x1.to(DEV), x2.to(DEV), Hm.to(DEV))
+            m = models.metrics_from(models.rate_distortion(out, x1.to(DEV), x2.to(DEV)))
+        flips = max(float((out[k].float().cpu() != ref[k]).float().mean()) for k in ("y1_hat", "y2_hat"))
+        recs[name] = {"dbpp": m["bpp"] - mr["bpp"], "dpsnr_db": m["psnr"] - mr["psnr"], "flips": flips, "mode": Fn.analysis_precision()}
+    print("trained smooth point after %d steps: bpp %.4f, PSNR %.3f dB (oracle);" % (steps, mr["bpp"], mr["psnr"]),
+          {k: {kk: (float("%.3g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in recs.items()})
+    r = recs["f16-x3"]
+    assert r["mode"] == "x3"
+    assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 1e-3 and r["flips"] <= 1e-4, ("f16-x3 (default)", r)
+    for name in ("f16-x3c2", "bf16-x3"):
+        r = recs[name]
+        assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 1e-2 and r["flips"] <= 1e-3, (name, r)
+
+
+def test_conditioning_latents_of_the_third_analysis_pass_stay_under_their_bar():
+    """``round(encoder1(warp(x1_hat)))`` is not transmitted -- it conditions view 2's entropy parameters (newnet1.py:753-757) -- and runs on
+    single 16-bit operands in every analysis mode.  Its flips against the oracle had no bar in round 4 (0.88 % in "x3c2", where x1_hat itself
+    differs around every flipped latent); pair 0 of the C2 workload: <= 3e-3 in the default mode (measured 1e-3), <= 1e-2 in "x3c2"."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, geometry
+    from oracle import hesic_oracle as O
+    net = build("hsic", torch.float16)
+    P = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
+    x1, x2, Hm = synthetic.stereo_batch(0, 1, 512, 512)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.hsic_forward(P, x1, x2, Hm)
+        want = torch.round(O.g_a(P, "encoder1.", O.warp_perspective(ref["x1_hat"], Hm, x1.shape[-2:], True))).to(torch.int16)
+    meas = {}
+    for an, bar in (("auto", 3e-3), ("x3c2", 1e-2)):
+        Fn.set_analysis_precision(an)
+        with torch.no_grad():
+            o = net(x1.to(DEV), x2.to(DEV), Hm.to(DEV))
+            yw = net.encoder1.latent(geometry.warp_perspective(o["x1_hat"], Hm.to(DEV), tuple(x1.shape[-2:])), want_lo=False)[1]
+        meas[Fn.analysis_precision()] = float((torch.round(yw.float()).cpu().to(torch.int16) != want).float().mean())
+        assert meas[Fn.analysis_precision()] <= bar, meas
+    print("measured:", meas)
