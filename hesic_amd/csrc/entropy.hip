@@ -50,6 +50,40 @@ __device__ __forceinline__ void eb_load(const float* p, EBParams& q) {
     for (int i = 0; i < 12; ++i) q.tf[i] = tanhf(p[EB_F0 + i]);
 }
 
+// The parameter rows of a block's EB_CL channels in LDS, transformed ONCE per block (round 5).  Rounds 1-4 had every thread fetch its
+// channel's 60 values with 60 strided loads (64 cache lines per wave instruction) and run the 45 softplus / tanh itself -- for ONE pixel per
+// thread on the 8 x 8 hyper-latents of a training step: eb_fwd 26 us, eb_bwd 67 us for 65 536 elements.  Rows are padded to 65 floats
+// (a wave reads 16 different rows: 16 different banks).  prep: softplus / tanh applied (slot layout of the raw row); sg: sigmoid of the raw
+// matrix entries = d softplus / d raw, what the backward multiplies with (null: forward only).
+constexpr int EB_CL = 16, EB_PL = 16, EB_ROW = HESIC_EB_PARAM_STRIDE + 1;
+__device__ __forceinline__ void eb_stage(const float* __restrict__ params, int c0, int C, float (*prep)[EB_ROW], float (*sg)[EB_ROW]) {
+    // EB_CL * 64 floats = 256 threads x one float4, coalesced
+    const int e = threadIdx.x * 4, ch = e >> 6, slot = e & 63;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + ch < C) v = *(const f32x4*)(params + (int64_t)(c0 + ch) * HESIC_EB_PARAM_STRIDE + slot);
+    const float ready = (c0 + ch < C) ? params[(int64_t)(c0 + ch) * HESIC_EB_PARAM_STRIDE + EB_READY] : 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sl = slot + k;
+        const float r = v[k];
+        float o = r;
+        if (ready == 0.f) {
+            if (sl < 33) o = softplusf(r);
+            else if (sl >= EB_F0 && sl < EB_F0 + 12) o = tanhf(r);
+        }
+        prep[ch][sl] = o;
+        if (sg) sg[ch][sl] = sl < 33 ? sigmoidf(r) : 0.f;
+    }
+}
+__device__ __forceinline__ void eb_load_prepared(const float* p, EBParams& q) {
+#pragma unroll
+    for (int i = 0; i < 33; ++i) q.sp[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) q.b[i] = p[EB_B0 + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q.tf[i] = p[EB_F0 + i];
+}
+
 // forward of the 1-3-3-3-3-1 cumulative; keeps pre-activations when `pre` != nullptr (backward)
 __device__ __forceinline__ float eb_logits(const EBParams& q, float v, float (*pre)[3], float (*hin)[3]) {
     float h[3], t[3];
@@ -75,16 +109,20 @@ __device__ __forceinline__ float eb_logits(const EBParams& q, float v, float (*p
     return q.sp[EB_M4] * h[0] + q.sp[EB_M4 + 1] * h[1] + q.sp[EB_M4 + 2] * h[2] + q.b[12];
 }
 
+// block = EB_CL channels x EB_PL pixel lanes; the block's parameter rows are staged (and transformed) once in LDS (eb_stage)
 template <typename T, typename TO = T>
-__global__ void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+__global__ __launch_bounds__(EB_CL * EB_PL) void eb_fwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
                               TO* __restrict__ zhat, float* __restrict__ lik, int32_t* __restrict__ sym, int64_t P, int C) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    __shared__ float prep[EB_CL][EB_ROW];
+    const int cl = threadIdx.x & (EB_CL - 1), pl = threadIdx.x / EB_CL;
+    const int c0 = blockIdx.y * EB_CL, c = c0 + cl;
+    eb_stage(params, c0, C, prep, nullptr);
+    __syncthreads();
     if (c >= C) return;
     EBParams q;
-    eb_load(params + (int64_t)c * HESIC_EB_PARAM_STRIDE, q);
-    const float med = params[(int64_t)c * HESIC_EB_PARAM_STRIDE + EB_MED];
-    const float bound = params[(int64_t)c * HESIC_EB_PARAM_STRIDE + EB_BOUND];
-    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+    eb_load_prepared(prep[cl], q);
+    const float med = prep[cl][EB_MED], bound = prep[cl][EB_BOUND];
+    for (int64_t p = (int64_t)blockIdx.x * EB_PL + pl; p < P; p += (int64_t)gridDim.x * EB_PL) {
         const int64_t i = p * C + c;
         const float zv = elem<T>::ld(z + i);
         float v;
@@ -118,7 +156,7 @@ __global__ void eb_prepare_kernel(const float* __restrict__ raw, float* __restri
 }
 
 // backward through one logits evaluation: accumulates d(params) into gp[58] and returns d/dv
-__device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* raw, float v, float gout, float* gp) {
+__device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* sg, float v, float gout, float* gp) {
     float pre[4][3], hin[5][3];
     eb_logits(q, v, pre, hin);
     // layer 4: out = sp4 . h3 + b4
@@ -126,7 +164,7 @@ __device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* r
     gp[EB_B4] += gout;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        gp[EB_M4 + j] += gout * hin[4][j] * sigmoidf(raw[EB_M4 + j]);
+        gp[EB_M4 + j] += gout * hin[4][j] * sg[EB_M4 + j];
         dh[j] = gout * q.sp[EB_M4 + j];
     }
 #pragma unroll
@@ -146,7 +184,7 @@ __device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* r
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int k = EB_M1 + (l - 1) * 9 + r * 3 + j;
-                gp[k] += dpre[r] * hin[l][j] * sigmoidf(raw[k]);
+                gp[k] += dpre[r] * hin[l][j] * sg[k];
                 nh[j] += q.sp[k] * dpre[r];
             }
         dh[0] = nh[0]; dh[1] = nh[1]; dh[2] = nh[2];
@@ -159,27 +197,31 @@ __device__ __forceinline__ float eb_logits_bwd(const EBParams& q, const float* r
         gp[EB_F0 + r] += dh[r] * th * (1.f - tf * tf);
         const float dpre = dh[r] * (1.f + tf * (1.f - th * th));
         gp[EB_B0 + r] += dpre;
-        gp[EB_M0 + r] += dpre * v * sigmoidf(raw[EB_M0 + r]);
+        gp[EB_M0 + r] += dpre * v * sg[EB_M0 + r];
         dv += dpre * q.sp[EB_M0 + r];
     }
     return dv;
 }
 
-// block = 64 channels x EB_PL pixel lanes: the lanes of a channel walk different pixels and meet in LDS before the block's
-// 59 atomics per channel (round 1 ran one pixel lane: 8 serial pixels of ~1000 flops each per thread on the 8 x 8 maps)
-constexpr int EB_PL = 4;
+// block = EB_CL channels x EB_PL pixel lanes (round 5: 16 x 16; rounds 1-4 ran 64 x 4 on at most 64 blocks -- 70 us on the 8 x 8 hyper-latents of
+// a training step, ~6000 dependent VALU instructions per pixel and four serial pixels per thread on a quarter of the CUs).  The pixel lanes
+// of a channel meet through two shuffles (a wave = 16 channels x 4 pixel lanes) and LDS before the block's 59 atomics per channel.
 template <typename T>
-__global__ __launch_bounds__(64 * EB_PL) void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
+__global__ __launch_bounds__(EB_CL * EB_PL) void eb_bwd_kernel(const T* __restrict__ z, const float* __restrict__ params, const T* __restrict__ noise,
                               const float* __restrict__ glik, const T* __restrict__ gzhat, T* __restrict__ dz,
                               float* __restrict__ dparams, int64_t P, int C) {
-    __shared__ float red[EB_PL - 1][64][EB_NP + 1];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    constexpr int NW = EB_CL * EB_PL / 64;
+    __shared__ float red[NW - 1][EB_CL][EB_NP + 1];
+    const int cl = threadIdx.x & (EB_CL - 1), pl = threadIdx.x / EB_CL, wv = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * EB_CL, c = c0 + cl;
     const bool live = c < C;
-    const float* raw = params + (int64_t)(live ? c : 0) * HESIC_EB_PARAM_STRIDE;
+    __shared__ float prep[EB_CL][EB_ROW], sgs[EB_CL][EB_ROW];
+    eb_stage(params, c0, C, prep, sgs);
+    __syncthreads();
     EBParams q;
-    eb_load(raw, q);
-    const float med = raw[EB_MED], bound = raw[EB_BOUND];
+    eb_load_prepared(prep[cl], q);
+    const float* sgt = sgs[cl];
+    const float med = prep[cl][EB_MED], bound = prep[cl][EB_BOUND];
     float gp[EB_NP + 1];
 #pragma unroll
     for (int i = 0; i <= EB_NP; ++i) gp[i] = 0.f;
@@ -195,7 +237,7 @@ __global__ __launch_bounds__(64 * EB_PL) void eb_bwd_kernel(const T* __restrict_
             if (!(fabsf(dlt) >= bound || g < 0.f)) g = 0.f;           // LowerBound rule (bound_ops.py:28-31)
             const float sg = signf(dlt) * g;
             const float gU = sg * A * (1.f - A) * s, gL = -sg * Bv * (1.f - Bv) * s;
-            float dv = eb_logits_bwd(q, raw, v + 0.5f, gU, gp) + eb_logits_bwd(q, raw, v - 0.5f, gL, gp);
+            float dv = eb_logits_bwd(q, sgt, v + 0.5f, gU, gp) + eb_logits_bwd(q, sgt, v - 0.5f, gL, gp);
             if (gzhat) dv += elem<T>::ld(gzhat + i);
             if (noise) {
                 elem<T>::st(dz + i, dv);
@@ -205,18 +247,25 @@ __global__ __launch_bounds__(64 * EB_PL) void eb_bwd_kernel(const T* __restrict_
             }
         }
     }
-    if (pl > 0) {
+    // a wave holds 4 pixel lanes (lane >> 4) of its 16 channels: fold them, then the waves through LDS
 #pragma unroll
-        for (int i = 0; i <= EB_NP; ++i) red[pl - 1][cl][i] = gp[i];
+    for (int i = 0; i <= EB_NP; ++i) {
+        gp[i] += __shfl_xor(gp[i], 16, 64);
+        gp[i] += __shfl_xor(gp[i], 32, 64);
+    }
+    const bool lead = (threadIdx.x & 63) < EB_CL;
+    if (wv > 0 && lead) {
+#pragma unroll
+        for (int i = 0; i <= EB_NP; ++i) red[wv - 1][cl][i] = gp[i];
     }
     __syncthreads();
-    if (pl == 0 && live) {
+    if (wv == 0 && lead && live) {
         float* out = dparams + (int64_t)c * HESIC_EB_PARAM_STRIDE;
 #pragma unroll
         for (int i = 0; i <= EB_NP; ++i) {
             float v = gp[i];
 #pragma unroll
-            for (int l = 0; l < EB_PL - 1; ++l) v += red[l][cl][i];
+            for (int l = 0; l < NW - 1; ++l) v += red[l][cl][i];
             atomicAdd(out + i, v);
         }
     }
@@ -526,8 +575,9 @@ int check_gmm(const hesic_gmm_desc* d, const char* who) {
 extern "C" int hesic_eb_forward(const void* z, const float* params, const void* noise, void* z_hat, float* lik, int32_t* symbols,
                                 int64_t P, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward: bad arguments");
-    const int bx = C >= 128 ? 128 : 64;
-    const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
+    const int64_t slices = (P + EB_PL - 1) / EB_PL;
+    const int bx = EB_CL * EB_PL;
+    const dim3 grid((unsigned)(slices < 256 ? slices : 256), (C + EB_CL - 1) / EB_CL);
     if (dtype == HESIC_H16)
         hipLaunchKernelGGL(eb_fwd_kernel<h16_t>, grid, dim3(bx), 0, (hipStream_t)stream, (const h16_t*)z, params,
                            (const h16_t*)noise, (h16_t*)z_hat, lik, symbols, P, C);
@@ -547,12 +597,13 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
                                  void* dz, float* dparams, int64_t P, int C, int dtype, void* stream) {
     HESIC_CHECK_ARG(z && params && g_lik && dz && dparams && P > 0 && C > 0, "eb_backward: bad arguments");
     // every block ends in 59 atomics per channel on the gradient row, which serialise per address; fewer pixel slices mean fewer
-    // contenders but more serial pixels (~2000 flops each) per thread.  Sweep on the 8 x 8 hyper-latents of a training step (us per
-    // launch): 128 slices 111 | 64: 76 | 32: 70 | 16: 89 | 8: 147 | 4: 265
+    // contenders but more serial pixels (~6000 VALU instructions each) per thread.  Rounds 1-4 (64 channels x 4 pixel lanes per block), us per
+    // launch on the 8 x 8 hyper-latents of a training step: 128 slices 111 | 64: 76 | 32: 70 | 16: 89 | 8: 147 | 4: 265; round 5 (16 x 16 per
+    // block, C / 16 channel groups): 32 slices = one pixel per thread there, 256 blocks
     static const int max_slices_env = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
     const int max_slices = max_slices_env < 1 ? 1 : max_slices_env;              // 0 / negative would launch an empty grid
     const int64_t slices = (P + EB_PL - 1) / EB_PL;
-    const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + 63) / 64), block(64 * EB_PL);
+    const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + EB_CL - 1) / EB_CL), block(EB_CL * EB_PL);
     if (dtype == HESIC_H16)
         hipLaunchKernelGGL(eb_bwd_kernel<h16_t>, grid, block, 0, (hipStream_t)stream, (const h16_t*)z, params,
                            (const h16_t*)noise, g_lik, (const h16_t*)g_zhat, (h16_t*)dz, dparams, P, C);
@@ -824,8 +875,9 @@ extern "C" int hesic_eb_forward_f32in(const float* z, const float* params, void*
                                       int64_t P, int C, void* stream) {
     HESIC_CHECK_ARG(z && params && z_hat && lik && P > 0 && C > 0, "eb_forward_f32in: bad arguments");
     HESIC_CHECK_ARG(out_dtype == HESIC_H16 || out_dtype == HESIC_F32, "eb_forward_f32in: bad dtype");
-    const int bx = C >= 128 ? 128 : 64;
-    const dim3 grid((unsigned)(P < 1024 ? P : 1024), (C + bx - 1) / bx);
+    const int64_t slices = (P + EB_PL - 1) / EB_PL;
+    const int bx = EB_CL * EB_PL;
+    const dim3 grid((unsigned)(slices < 256 ? slices : 256), (C + EB_CL - 1) / EB_CL);
     if (out_dtype == HESIC_H16)
         hipLaunchKernelGGL((eb_fwd_kernel<float, h16_t>), grid, dim3(bx), 0, (hipStream_t)stream, z, params, (const float*)nullptr,
                            (h16_t*)z_hat, lik, symbols, P, C);

@@ -1258,6 +1258,168 @@ __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restri
     if (lane == 0) dw[i] = s;
 }
 
+// ---- narrow <-> wide, 5x5 stride 2 (g_a_conv1 3 -> 128, g_s_conv4 128 -> 3 transposed): one launch, no im2col matrix (round 5).
+//   dW[wc][n = c * 25 + ky * 5 + kx] = sum_q WIDE[q][wc] * NARROW[c][2 qy + ky - 2][2 qx + kx - 2]
+// Rounds 2-4 wrote the (Q x 96) 16-bit im2col matrix of the narrow image (84 MB at B = 8, 512^2), ran wgrad_tr_kernel on it as a one-tap
+// GEMM (reading it and the 134 MB wide map), and summed the slices: 33 + 60 + 16 us per layer, five layers per step, for 0.63 GMAC each.
+// Here a block walks 64-pixel row segments of the wide grid: the wide tile (64 px x 128 ch) arrives by LDS-DMA as in wgrad_row_kernel; the
+// narrow WINDOW the segment's 75 patch columns are made of -- 3 channels x 5 rows x 131 consecutive pixels, fp32 -- arrives by 4-byte LDS-DMA
+// as an even and an odd pixel plane per (channel, row) (tap kx = plane kx & 1 from element kx >> 1 on: unit-stride, conflict-free reads);
+// the four waves turn it into the segment's (64 px x 96 col) 16-bit patch tile in LDS (24 columns per wave, lane = pixel), and both operands
+// reach the matrix cores through transposing reads.  The launch is bound by the wide map's HBM read (134 MB) instead of three passes.
+struct NwArgs {
+    const void* wide; const float* narrow; float* part; float* bias_part;        // part [nsplit][128][96], bias_part [nsplit][128] or null
+    int64_t ns_b, ns_c, ns_y, ns_x;                                              // narrow strides in elements
+    int QH, QW, NH, NW;
+    int64_t Q, chunk;
+};
+constexpr int NWF_WIDE = 64 * 256, NWF_WIN = 8192, NWF_STAGE = NWF_WIDE + NWF_WIN, NWF_NST = 3, NWF_PATCH = 64 * 256;
+constexpr int NWF_LDS = NWF_NST * NWF_STAGE + NWF_PATCH;
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void wgrad_nw_fused_kernel(const NwArgs a) {
+    constexpr int STAGE = NWF_STAGE, NST = NWF_NST, PLW = 68;                    // 68 elements per (channel, row, parity) plane of the window
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem + NST * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t q_begin = split * a.chunk;
+    const int64_t q_end = (q_begin + a.chunk < a.Q) ? q_begin + a.chunk : a.Q;
+    const int nsteps = (int)((q_end - q_begin) >> 6);
+    constexpr uint32_t OOB = 0x80000000u;
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)smem) : "memory");
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wide, 0, (int)OOB, 0x00020000);
+    const int64_t neg = (2 * a.ns_y + 2 * a.ns_x) * 4;                            // the window starts two rows / two pixels before (2 qy, 2 qx)
+    const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.narrow - neg), 0, (int)OOB, 0x00020000);
+    const int lrow = lane >> 4, pslot = lane & 15;
+    const uint32_t v_w = (uint32_t)(lrow * 256 + ((pslot ^ ((lrow & 3) << 2)) << 4));
+    // window element e = (wave * 8 + i) * 64 + lane of the stage -> plane row r = e / 68 = (c * 5 + ky) * 2 + parity, element m = e % 68
+    int wky[8], wx[8];
+    uint32_t v_n[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = (wave * 8 + i) * 64 + lane;
+        const int r = e / PLW, m = e - r * PLW;
+        const int c = r / 10, rr = r - c * 10;
+        wky[i] = rr >> 1;
+        wx[i] = 2 * m + (rr & 1);
+        v_n[i] = r < 30 ? (uint32_t)((c * a.ns_c + wky[i] * a.ns_y + wx[i] * a.ns_x) * 4) : OOB;
+    }
+    uint32_t sq = (uint32_t)q_begin;
+    int sqx, sqy, sqb;
+    {
+        const uint32_t r1 = sq / (uint32_t)a.QW;
+        sqx = (int)(sq - r1 * (uint32_t)a.QW);
+        sqb = (int)(r1 / (uint32_t)a.QH);
+        sqy = (int)(r1 - (uint32_t)sqb * (uint32_t)a.QH);
+    }
+    auto issue = [&](int buf) {
+        unsigned char* wt = smem + buf * STAGE;
+        unsigned char* nt = wt + NWF_WIDE;
+        const bool inq = sq < (uint32_t)q_end;
+        const uint32_t vw = inq ? v_w : OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(wt + n * 1024), 16, (int)vw,
+                                                     (int)((sq + (uint32_t)(4 * n)) * 256u), 0, 0);
+        }
+        const uint32_t so = (uint32_t)((sqb * a.ns_b + 2 * sqy * a.ns_y + 2 * sqx * a.ns_x) * 4);
+        const int y0 = 2 * sqy - 2, x0 = 2 * sqx - 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = inq && (unsigned)(y0 + wky[i]) < (unsigned)a.NH && (unsigned)(x0 + wx[i]) < (unsigned)a.NW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(nr, (__attribute__((address_space(3))) void*)(nt + (wave * 8 + i) * 256), 4,
+                                                     (int)(ok ? v_n[i] : OOB), (int)so, 0, 0);
+        }
+        sq += 64;
+        sqx += 64;
+        if (sqx >= a.QW) {
+            sqx = 0;
+            if (++sqy >= a.QH) { sqy = 0; ++sqb; }
+        }
+    };
+    const int frow = lane & 31, fh = lane >> 5, g = lane >> 4, t = lane & 15;
+    const int chs = (g & 1) * 16 + 4 * (t & 3), rsub = fh * 8 + (t >> 2);
+    auto foff = [&](int cb) {
+        const int ch = cb + chs;
+        return rsub * 256 + (((ch >> 3) ^ ((rsub & 3) << 2)) << 4) + (ch & 7) * 2;
+    };
+    const int a_off = foff(wave * 32);
+    int b_off[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) b_off[n] = foff(n * 32);
+    f32x16 acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    float bsum = 0.f;
+    if (nsteps > 0) {
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p) issue(p);
+    }
+    int buf = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 12) : "memory");
+        __builtin_amdgcn_s_barrier();                       // the stage has landed for every wave; the patch tile of the last step is read out
+        issue(buf == 0 ? NST - 1 : buf - 1);
+        const unsigned char* st = smem + buf * STAGE;
+        {
+            // patch tile: lane = pixel, this wave's 24 columns (three 16-byte slots of the pixel's row); columns >= 75 are zero
+            const float* win = (const float*)(st + NWF_WIDE);
+            uint32_t w[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                float v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int col = wave * 24 + 2 * j + h;                    // wave-uniform
+                    const int c = col / 25, r = col - c * 25, ky = r / 5, kx = r - ky * 5;
+                    const float x = win[((c * 5 + ky) * 2 + (kx & 1)) * PLW + (kx >> 1) + lane];
+                    v[h] = col < 75 ? x : 0.f;
+                }
+                w[j] = pack_h2(v[0], v[1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int slot = wave * 3 + k;
+                *(u32x4*)(patch + lane * 256 + ((slot ^ ((lane & 3) << 2)) << 4)) = u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned char* kw = st + ks * 4096;
+            const unsigned char* kp = patch + ks * 4096;
+            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kw + a_off));
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kw + a_off + 1024));
+            const h16x8 af = __builtin_bit_cast(h16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            if constexpr (BIAS) {
+                const u32x2 lo = __builtin_bit_cast(u32x2, l0), hi = __builtin_bit_cast(u32x2, l1);
+                bsum += ((h2f_lo(lo.x) + h2f_hi(lo.x)) + (h2f_lo(lo.y) + h2f_hi(lo.y))) + ((h2f_lo(hi.x) + h2f_hi(hi.x)) + (h2f_lo(hi.y) + h2f_hi(hi.y)));
+            }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const s16x4 s0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kp + b_off[n]));
+                const s16x4 s1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(kp + b_off[n] + 1024));
+                const h16x8 bf = __builtin_bit_cast(h16x8, __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[n] = mfma_32x32x16_h16(af, bf, acc[n], 0, 0, 0);
+            }
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    if constexpr (BIAS) {
+        const float sb = bsum + __shfl_xor(bsum, 32, 64);
+        if (fh == 0) a.bias_part[(int64_t)split * 128 + wave * 32 + frow] = sb;
+    }
+    float* out = a.part + (int64_t)split * 128 * 96;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 96 + n * 32 + frow] = acc[n][r];
+}
+
 // ---- narrow x narrow, stride 1 (pre_conv 6 -> 3, after_conv 6 -> 3 transposed), 5x5 pad 2.
 //   conv:        dW[co][ci][ky][kx] = sum_p dy[co][p] * x[ci][p + k - 2]
 //   transposed:  dW[ci][co][ky][kx] = sum_i x[ci][i]  * dy[co][i + k - 2]
@@ -2212,6 +2374,50 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         const int QH = conv1 ? d->Ho : d->H, QW = conv1 ? d->Wo : d->W, NH = conv1 ? d->H : d->Ho, NW = conv1 ? d->W : d->Wo;
         h16_t* P = (h16_t*)ws;
         float* part = (float*)((unsigned char*)ws + (Q * 96 * 2 + 255) / 256 * 256);
+        bool fused_done = false;
+        {
+            // round 5: one fused launch (wgrad_nw_fused_kernel) when the narrow image is fp32 and a 64-pixel stage stays inside one row of the
+            // wide grid; HESIC_NW_FUSED=0 is the A/B switch back to im2col + one-tap GEMM
+            const char* e = getenv("HESIC_NW_FUSED");
+            const int ndt0 = conv1 ? d->x_dtype : d->y_dtype;
+            const int64_t nsb0 = conv1 ? d->xs_b : d->ys_b, nsc0 = conv1 ? d->xs_c : d->ys_c, nsy0 = conv1 ? d->xs_y : d->ys_y, nsx0 = conv1 ? d->xs_x : d->ys_x;
+            const int64_t span = ((int64_t)(d->B - 1) * nsb0 + 2 * nsc0 + (int64_t)(NH + 2) * nsy0 + (int64_t)(NW + 140) * nsx0) * 4;
+            if ((!e || atoi(e) != 0) && ndt0 == HESIC_F32 && QW % 64 == 0 && Q < (1ll << 23) && nsb0 >= 0 && nsc0 >= 0 && nsy0 >= 0 && nsx0 >= 0 &&
+                span < (1ll << 31)) {
+                hesic_conv_desc g0;
+                nw_gemm_desc(Q, g0);
+                WgArgs a0;
+                fill_args(&g0, a0);                                   // the slice count the workspace was sized for
+                NwArgs n;
+                n.wide = conv1 ? dy : x; n.narrow = (const float*)(conv1 ? x : dy); n.part = part;
+                n.ns_b = nsb0; n.ns_c = nsc0; n.ns_y = nsy0; n.ns_x = nsx0;
+                n.QH = QH; n.QW = QW; n.NH = NH; n.NW = NW; n.Q = Q;
+                const int64_t stages = Q / 64;
+                int64_t ns = a0.nsplit < 256 ? a0.nsplit : 256;
+                if (ns > stages) ns = stages;
+                const int64_t per = (stages + ns - 1) / ns;
+                n.chunk = per * 64;
+                ns = (stages + per - 1) / per;
+                float* bpart = part + ns * 128 * 96;
+                const bool with_bias = conv1 && dbias;
+                n.bias_part = with_bias ? bpart : nullptr;
+                static bool nattr = false;
+                if (!nattr) {
+                    (void)hipFuncSetAttribute((const void*)wgrad_nw_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NWF_LDS);
+                    (void)hipFuncSetAttribute((const void*)wgrad_nw_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NWF_LDS);
+                    nattr = true;
+                }
+                if (with_bias) hipLaunchKernelGGL(wgrad_nw_fused_kernel<true>, dim3((unsigned)ns), dim3(256), NWF_LDS, st, n);
+                else hipLaunchKernelGGL(wgrad_nw_fused_kernel<false>, dim3((unsigned)ns), dim3(256), NWF_LDS, st, n);
+                hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, (int)ns, 75);
+                if (with_bias) {
+                    hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)bpart, dbias, (int)ns);
+                    dbias = nullptr;
+                }
+                fused_done = true;
+            }
+        }
+        if (!fused_done) {
         static const bool chunk_form = getenv("HESIC_IM2COL_CHUNKS") != nullptr;      // A/B switch: the thread-per-chunk kernel of rounds 1-3
         const void* nimg = conv1 ? x : dy;
         const int ndt = conv1 ? d->x_dtype : d->y_dtype;
@@ -2240,6 +2446,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         if (a2.bias_part) {
             hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)bpart, dbias, a2.nsplit);
             dbias = nullptr;                          // done: skip the column-sum pass below
+        }
         }
     } else if (!legacy && k5 && d->stride == 2 && !d->transposed && d->Cin == 3 && d->Cout == 128 && d->ys_c == 1 && d->y_dtype == HESIC_H16 &&
         d->H == 2 * d->Ho && d->W == 2 * d->Wo) {

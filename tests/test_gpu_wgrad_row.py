@@ -85,3 +85,63 @@ def test_row_kernel_is_deterministic():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     finally:
         hesic_amd.set_compute_dtype(torch.float32)
+
+
+# ---- wgrad_nw_fused_kernel: g_a_conv1 (3 -> 128) / g_s_conv4 (128 -> 3 transposed) weight gradients in one launch
+NW_CASES = [
+    # transposed, (B, H, W) of the NARROW (image-side) grid
+    (0, (2, 128, 128)),
+    (0, (1, 96, 256)),
+    (1, (2, 128, 128)),
+    (1, (3, 64, 256)),
+]
+
+
+def _run_nw(L, d, x, gy, wshape, Cout, fused):
+    os.environ["HESIC_NW_FUSED"] = "1" if fused else "0"
+    try:
+        nws = int(L.lib().hesic_sconv2d_wgrad_ws_bytes(C.byref(d)))
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+        dw = torch.full(wshape, 7.0, dtype=torch.float32, device=DEV)          # the call overwrites
+        db = torch.full((Cout,), 7.0, dtype=torch.float32, device=DEV)
+        L.call("hesic_sconv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(db), L.ptr(ws), nws, L.stream())
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("HESIC_NW_FUSED", None)
+    return dw, db
+
+
+@pytest.mark.parametrize("case", range(len(NW_CASES)))
+def test_fused_narrow_wide_wgrad_matches_torch_and_the_im2col_route(case):
+    import hesic_amd
+    from hesic_amd import _lib as L
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        tr, (B, H, W) = NW_CASES[case]
+        if not tr:        # conv1: x = image (fp32 planar), gy = wide map on the half grid
+            x = synthetic._uniform(f"nw.x{case}", (B, 3, H, W), 0, 1).to(DEV)
+            gy = synthetic._uniform(f"nw.g{case}", (B, 128, H // 2, W // 2), -1, 1).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            Cin, Cout, wshape = 3, 128, (128, 3, 5, 5)
+            xs, ys = x.stride(), gy.stride()
+            d = L.SConvDesc(B, H, W, Cin, H // 2, W // 2, Cout, 5, 5, 2, 2, 0, L.F32, L.BF16, 0, 0, xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3])
+        else:             # deconv4: x = wide map on the half grid, gy = image-side gradient (fp32 planar)
+            x = synthetic._uniform(f"nw.x{case}", (B, 128, H // 2, W // 2), -2, 2).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gy = synthetic._uniform(f"nw.g{case}", (B, 3, H, W), -1, 1).to(DEV)
+            Cin, Cout, wshape = 128, 3, (128, 3, 5, 5)
+            xs, ys = x.stride(), gy.stride()
+            d = L.SConvDesc(B, H // 2, W // 2, Cin, H, W, Cout, 5, 5, 2, 2, 1, L.BF16, L.F32, 0, 0, xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3])
+        dw1, db1 = _run_nw(L, d, x, gy, wshape, Cout, True)
+        dw0, db0 = _run_nw(L, d, x, gy, wshape, Cout, False)
+        w = torch.zeros(wshape, device=DEV, requires_grad=True)
+        b = torch.zeros(Cout, device=DEV, requires_grad=True)
+        y = (F.conv_transpose2d(x.float(), w, b, stride=2, padding=2, output_padding=1) if tr else F.conv2d(x.float(), w, b, stride=2, padding=2))
+        y.backward(gy.float())
+        scale = float(w.grad.abs().max())
+        # the narrow operand enters the matrix cores as bf16 in both routes (the im2col matrix / the patch tile): 2^-9 per element, random sign
+        assert float((dw1 - w.grad).abs().max()) <= 3e-3 * scale, "fused vs torch fp32"
+        assert float((dw1 - dw0).abs().max()) <= 2e-5 * scale, "fused vs im2col route (same bf16 operands, other summation order)"
+        bs = float(b.grad.abs().max()) + 1.0
+        assert float((db1 - b.grad).abs().max()) <= 2e-5 * bs
+        assert float((db1 - db0).abs().max()) <= 2e-5 * bs
+    finally:
+        hesic_amd.set_compute_dtype(torch.float32)
