@@ -1247,6 +1247,45 @@ __global__ __launch_bounds__(1024) void nw_bias_reduce_kernel(const float* __res
         db[co] = t;
     }
 }
+// The slices of the fused narrow <-> wide weight gradient summed in ONE launch (round 5): block = 32 consecutive patch columns of one wide
+// channel (128-byte runs of a slice row) x 8 slice groups that meet in LDS, fixed order; blocks [384, 388) sum the bias column sums the same way.
+// (nw_reduce_kernel below reads one value per lane from rows 49 KB apart -- 16 us for 12.6 MB -- and the bias took a second, one-block launch.)
+__global__ __launch_bounds__(256) void nw_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
+                                                        const float* __restrict__ bpart, float* __restrict__ db) {
+    __shared__ float red[8][32];
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int b = blockIdx.x;
+    float s0 = 0.f, s1 = 0.f;
+    if (b < 384) {
+        const int wc = b / 3, n = (b - wc * 3) * 32 + j;
+        const float* src = part + (int64_t)wc * 96 + n;
+        int k = grp;
+        for (; k + 8 < nsplit; k += 16) { s0 += src[(int64_t)k * 128 * 96]; s1 += src[(int64_t)(k + 8) * 128 * 96]; }
+        if (k < nsplit) s0 += src[(int64_t)k * 128 * 96];
+        red[grp][j] = s0 + s1;
+        __syncthreads();
+        if (grp == 0 && n < 75) {
+            float t = red[0][j];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += red[g][j];
+            dw[wc * 75 + n] = t;
+        }
+        return;
+    }
+    if (!bpart) return;
+    const int co = (b - 384) * 32 + j;
+    int k = grp;
+    for (; k + 8 < nsplit; k += 16) { s0 += bpart[k * 128 + co]; s1 += bpart[(k + 8) * 128 + co]; }
+    if (k < nsplit) s0 += bpart[k * 128 + co];
+    red[grp][j] = s0 + s1;
+    __syncthreads();
+    if (grp == 0) {
+        float t = red[0][j];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][j];
+        db[co] = t;
+    }
+}
 __global__ void nw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int NCT) {
     // one wave per output value (the K split of this route is up to 256 deep: a serial sum per thread was 74 us)
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2363,12 +2402,13 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nw = (int64_t)d->Cout * d->Cin * d->KH * d->KW;
-    zero_async(dw, nw, st);
     static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2;
     bool conv1 = false;
     const int64_t need = hesic_sconv2d_wgrad_ws_bytes(d);
-    if (!legacy && need > 0 && ws && ws_bytes >= need && nw_fast_case(d, conv1)) {
+    const bool mfma_route = !legacy && need > 0 && ws && ws_bytes >= need && nw_fast_case(d, conv1);
+    if (!mfma_route) zero_async(dw, nw, st);          // the routes below accumulate with atomics; the MFMA route's finishing pass writes every element
+    if (mfma_route) {
         // MFMA route: im2col of the 3-channel side, then the 1x1 weight-gradient kernel with WIDE as "dY"
         const int64_t Q = conv1 ? (int64_t)d->B * d->Ho * d->Wo : (int64_t)d->B * d->H * d->W;
         const int QH = conv1 ? d->Ho : d->H, QW = conv1 ? d->Wo : d->W, NH = conv1 ? d->H : d->Ho, NW = conv1 ? d->W : d->Wo;
@@ -2409,11 +2449,9 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
                 }
                 if (with_bias) hipLaunchKernelGGL(wgrad_nw_fused_kernel<true>, dim3((unsigned)ns), dim3(256), NWF_LDS, st, n);
                 else hipLaunchKernelGGL(wgrad_nw_fused_kernel<false>, dim3((unsigned)ns), dim3(256), NWF_LDS, st, n);
-                hipLaunchKernelGGL(nw_reduce_kernel, dim3((128 * 75 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, (int)ns, 75);
-                if (with_bias) {
-                    hipLaunchKernelGGL(nw_bias_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)bpart, dbias, (int)ns);
-                    dbias = nullptr;
-                }
+                hipLaunchKernelGGL(nw_finish_kernel, dim3(with_bias ? 388 : 384), dim3(256), 0, st, (const float*)part, dw, (int)ns,
+                                   (const float*)(with_bias ? bpart : nullptr), dbias);
+                if (with_bias) dbias = nullptr;
                 fused_done = true;
             }
         }

@@ -655,7 +655,9 @@ class PackedGdn:
         tag = (beta.data_ptr(), gamma.data_ptr(), beta._version, gamma._version, _cache_epoch)
         if self._hit is not None and self._hit[0] == tag and not torch.is_grad_enabled():
             return self._hit[1], self._hit[2]
-        if (_train_pack_cache and torch.is_grad_enabled() and isinstance(beta, torch.nn.Parameter) and isinstance(gamma, torch.nn.Parameter)
+        # (grad mode is OFF inside an autograd.Function.forward -- where the fused conv + GDN stages call this: rounds 3-4 therefore re-packed 12
+        # of the 15 GDNs one by one every step on top of the batched launch; the Trainer's step flag alone decides)
+        if (_train_pack_cache and isinstance(beta, torch.nn.Parameter) and isinstance(gamma, torch.nn.Parameter)
                 and gamma.dtype == torch.float32 and gamma.is_contiguous() and beta.is_contiguous()):
             # Trainer step: a persistent pack, refreshed with every other GDN's by ONE launch behind the optimiser update (repack_all) --
             # 15 pack launches a step otherwise
