@@ -346,6 +346,139 @@ def trained_parity(kind="hsic", sets=4, steps=3000, size=512, lr=1e-4, aux_lr=1e
 
 
 
+def _timed_loop(fn, warm, n):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def secondary_modes(dev, oracle_pairs, size=512):
+    """BASELINE config C2 (HESIC, 8 x 512^2) in the modes the headline is NOT run in, each with pairs/s and its parity triple against the
+    same fp32 CPU oracle results the headline's ``parity`` block uses: bfloat16 maps with pair analysis (the dtype BASELINE.json names
+    literally) and float16 "x3c2" (round 4's default, now an explicit fast mode -- its trained-point PSNR deviation is why)."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, models, synthetic
+    out = {}
+    keep_dt, keep_an = Fn.compute_dtype(), Fn.set_analysis_precision("auto")
+    try:
+        npar = len(oracle_pairs)
+        base = [synthetic.stereo_batch(j, 1, size, size) for j in range(npar)]
+        x1, x2, Hm = (torch.cat([b[i] for b in base] * (8 // npar), 0).to(dev) for i in range(3))
+        for name, dt, an in (("bf16_x3", torch.bfloat16, "x3"), ("f16_x3c2", torch.float16, "x3c2")):
+            hesic_amd.set_compute_dtype(dt)
+            Fn.set_analysis_precision(an)
+            net = models.HSIC()
+            synthetic.fill_state_dict_(net.state_dict())
+            net = net.to(dev).eval()
+
+            def fwd(i):
+                with torch.no_grad():
+                    return models.rate_distortion(net(x1, x2, Hm), x1, x2)
+            ms = 1e3 * _timed_loop(fwd, 12, 30)
+            per = []
+            for j, mc in enumerate(oracle_pairs):
+                with torch.no_grad():
+                    oj = net(x1[j:j + 1], x2[j:j + 1], Hm[j:j + 1])
+                    mj = models.metrics_from(models.rate_distortion(oj, x1[j:j + 1], x2[j:j + 1]))
+                fl = max(float((oj[k].float().cpu().to(torch.int16) != v).float().mean()) for k, v in mc["y_hat"].items())
+                per.append((mj["bpp"] - mc["bpp"], mj["psnr"] - mc["psnr"], fl))
+            out[name] = {"value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "issue": "eager",
+                         "parity": {"abs_dbpp": float("%.3g" % abs(sum(q[0] for q in per) / npar)), "abs_dpsnr_db": float("%.3g" % abs(sum(q[1] for q in per) / npar)),
+                                    "latent_flips_worst_pair": float("%.3g" % max(q[2] for q in per)),
+                                    "worst_pair_abs_dbpp": float("%.3g" % max(abs(q[0]) for q in per)), "pairs": npar}}
+            del net
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        hesic_amd.set_compute_dtype(keep_dt)
+        Fn.set_analysis_precision(keep_an)
+    return out
+
+
+def secondary_sweep_and_path_a(dev, size=512):
+    """BASELINE config C5 through ``evaluate.LambdaSweep`` (four lambda-models on 860 x 1080 pairs padded to 896 x 1088, B = 4 per step) for
+    HESIC and HESIC+, and INTEGRATION.md path A -- the reference's own call order over the drop-in modules (``hesic_amd.path_a``), plain NCHW
+    tensors between modules, no fused schedule -- for HESIC at 8 x 512^2: pairs/s each, in the headline's dtype."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, models, path_a, synthetic
+    from hesic_amd.evaluate import LambdaSweep
+    out = {}
+    try:
+        x1, x2, Hm = (t.to(dev) for t in synthetic.stereo_batch(0, 4, 860, 1080))
+        x1p, x2p = models.pad_to_multiple(x1), models.pad_to_multiple(x2)
+        for kind in ("hsic", "joint"):
+            sweep = LambdaSweep(kind, dev)
+            ms = 1e3 * _timed_loop(lambda i: sweep.step(i % 4, x1, x2, x1p, x2p, Hm, True), 12, 16)
+            gf = gflop_per_pair(kind, x1p.shape[-2], x1p.shape[-1])
+            out["c5_sweep_" + ("hesic" if kind == "hsic" else "hesicplus")] = {
+                "value": round(4e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "pairs_per_step": 4, "padded": [int(x1p.shape[-2]), int(x1p.shape[-1])],
+                "model_tflops": round(4 * gf / ms, 2), "mfma_frac_of_step": round(4 * gf / ms / MFMA_BF16_PEAK_TFLOPS, 4), "analysis": Fn.analysis_precision()}
+            del sweep
+        del x1, x2, x1p, x2p
+        net = models.HSIC()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.to(dev).eval()
+        a, b, h = (t.to(dev) for t in synthetic.stereo_batch(0, 8, size, size))
+
+        def fwd_a(i):
+            with torch.no_grad():
+                return path_a.hsic_forward(net, a, b, h)
+        ms = 1e3 * _timed_loop(fwd_a, 6, 15)
+        out["path_a_hesic_b8"] = {"value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3),
+                                  "note": "the reference's call order (newnet1.py:724-783) over the drop-in compressai modules, one C-ABI call per module, "
+                                          "single 16-bit operands and 16-bit latents at every module boundary; parity: tests/test_gpu_path_a.py"}
+        del net
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def secondary_train_rccl(dev, size=512, lmbda=0.0067):
+    """The graph-replayed training step with a ONE-RANK RCCL process group in the graph (the bucketed all-reduces of config C3 run for real,
+    over no link): what the collectives cost a step before any xGMI hop."""
+    import torch.distributed as dist
+    import hesic_amd
+    from hesic_amd import functional as Fn, models, synthetic
+    from hesic_amd.train import GraphedTrainer
+    out = {}
+    keep = Fn.compute_dtype()
+    made = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            made = True
+        hesic_amd.set_compute_dtype(torch.bfloat16)
+        tnet = models.HSIC()
+        synthetic.fill_state_dict_(tnet.state_dict())
+        tnet = tnet.to(dev).train()
+        tr = GraphedTrainer(tnet, lr=1e-4, aux_lr=1e-3, lmbda=lmbda, force_collectives=True)
+        x1, x2, Hm = (t.to(dev) for t in synthetic.stereo_batch(0, 8, size, size))
+        ms = 1e3 * _timed_loop(lambda i: tr.step(x1, x2, Hm), tr.warmup + 3, 12)
+        out = {"ms_per_step": round(ms, 3), "value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "dtype": "bf16", "world_size": 1,
+               "buckets": len(getattr(tr.main_reducer, "buckets", []) or []), "step": "HIP graph replay with the RCCL all-reduces inside"}
+        tr.main_reducer.close()
+        tr.aux_reducer.close()
+        del tr, tnet
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        hesic_amd.set_compute_dtype(torch.bfloat16 if keep == torch.float32 else keep)
+        hesic_amd.set_compute_dtype(keep)
+    return out
+
+
 def secondary_block(dev, size=512, lmbda=0.0067):
     """Two more driver-visible numbers, measured AFTER the headline's timed region (rank 0 of a 1-GPU run, a few seconds):
     BASELINE config C4 (HESIC+, 4 pairs of 512 x 512, the headline's dtype / analysis mode, eager issue) with its dominant conv kernel's
@@ -887,6 +1020,11 @@ def main():
         default_workload = args.model == "hsic" and args.batch == 8 and not (args.height or args.width) and args.size == 512
         if world == 1 and default_workload and not args.no_secondary:
             res["secondary"] = secondary_block(dev, lmbda=args.lmbda)
+            # round 5: the other modes of C2 with their parity, the C5 sweep, path A and the training step with RCCL in the graph (~15 s)
+            if not args.no_cpu_baseline and args.dtype != "f32":
+                res["secondary"]["c2_other_modes"] = secondary_modes(dev, [m_cpu] + m_cpu["more"])
+            res["secondary"].update(secondary_sweep_and_path_a(dev))
+            res["secondary"]["train_step_hesic_b8_rccl_1rank"] = secondary_train_rccl(dev, lmbda=args.lmbda)
         emit_line(res)
     if world > 1:
         dist.destroy_process_group()

@@ -20,6 +20,7 @@ LIB_PATH_F16 = os.path.join(_HERE, "libhesic_hip_f16.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hesic_hip.h")
 
 F32, H16 = 0, 1
+ABI_VERSION = 2      # include/hesic_hip.h HESIC_ABI_VERSION
 BF16 = H16       # historical name: the library's 16-bit format (hesic_h16_format())
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 EB_PARAM_STRIDE = 64
@@ -228,11 +229,22 @@ def _load(h16):
                 f"hesic_amd: {path} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C hesic_amd/csrc`. There is no CPU fallback.")
         l = C.CDLL(path)
+        # the version check comes BEFORE the signatures are bound: a stale build then fails with the rebuild hint instead of an AttributeError
+        # on the first entry point it lacks
+        rebuild = "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C hesic_amd/csrc`"
+        try:
+            l.hesic_abi_version.argtypes, l.hesic_abi_version.restype = [], _i32
+            ver = l.hesic_abi_version()
+        except AttributeError:
+            raise RuntimeError(f"hesic_amd: {os.path.basename(path)} exports no hesic_abi_version -- not this package's library; {rebuild}") from None
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"hesic_amd: {os.path.basename(path)} ABI version mismatch (library {ver}, package {ABI_VERSION}): {rebuild}")
         for name, (args, res) in _SIGS.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                raise RuntimeError(f"hesic_amd: {os.path.basename(path)} lacks the entry point {name} although it reports ABI {ver}: {rebuild}") from None
             fn.argtypes, fn.restype = args, res
-        if l.hesic_abi_version() != 1:
-            raise RuntimeError(f"hesic_amd: {os.path.basename(path)} ABI version mismatch")
         if l.hesic_h16_format() != (1 if h16 == torch.float16 else 0):
             raise RuntimeError(f"hesic_amd: {os.path.basename(path)} was built for the other 16-bit format")
         _libs[h16] = l

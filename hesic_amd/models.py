@@ -883,38 +883,57 @@ _CDF_WAVE_MAX = 1024          # csrc/entropy.hip: alphabets the wave-per-row tab
 # A/B switch: 1 = the C loop replays each group's recorded launches one by one instead of launching its graph
 WAVEFRONT_TAPE = _os.environ.get("HESIC_WAVEFRONT_TAPE", "1") != "0"
 WAVEFRONT_C_LOOP = _os.environ.get("HESIC_WAVEFRONT_C_LOOP", "1") != "0"      # A/B switch: 0 = the group loop in Python (six C calls per group)
-PAYLOAD_MAGIC = b"HSC\x02"               # format 2 (round 4).  Format 1 (rounds 2-3) had no header: HESIC raw, HESIC+ one pixel-order byte
+PAYLOAD_MAGIC = b"HSC\x03"               # format 3 (round 5: two mode bytes).  Format 2 (round 4) had one; format 1 (rounds 2-3) no header
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
+_MODE_BYTES = 2
+
+
+def payload_mode_bytes():
+    """Everything the cumulative-frequency tables depend on besides the weights (round 4's single byte left out the warp convention
+    and the summation-order switches, so a decoder differing in one of them passed the check and desynchronised on view 2).
+    byte 0 -- bits 0-1: storage format of the maps (0 fp32, 1 bfloat16, 2 float16); bit 2: error-feedback weight rounding on the
+    single-operand analysis launches (the third analysis pass feeds view 2's tables); bit 3: fp32 latents; bits 4-7: table-kernel version.
+    byte 1 -- bit 0: warp convention (``geometry.DEFAULT_ALIGN_CORNERS``: x1_hat_warp, hence round(encoder1(warp(x1_hat))), hence view 2's
+    tables); bit 1: split-K launches allowed (``Fn.SPLIT_K``); bit 2: grouped hyper-synthesis launches (``Fn.GROUP_HYPER``) -- both reorder
+    the fp32 sums of the hyper-synthesis; bits 3-4: analysis precision of the third pass' producer chain (0 x3, 1 x3c2, 2 x1, 3 x2: x1_hat is
+    decoded from y1_hat alone, but the mode is recorded so that a mismatch is reported rather than argued about)."""
+    from . import geometry as _geo
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[Fn.compute_dtype()]
+    b0 = dt | (int(bool(Fn.SHAPED_WEIGHTS) and dt != 0) << 2) | (int(bool(Fn.FP32_LATENTS)) << 3) | (TABLE_KERNEL_VERSION << 4)
+    an = 0 if dt == 0 else {"x3": 0, "x3c2": 1, "x1": 2, "x2": 3}[Fn.analysis_precision()]
+    b1 = int(bool(_geo.DEFAULT_ALIGN_CORNERS)) | (int(bool(Fn.SPLIT_K)) << 1) | (int(bool(Fn.GROUP_HYPER)) << 2) | (an << 3)
+    return bytes([b0, b1])
 
 
 def payload_mode_byte():
-    """bits 0-1: storage format of the maps (0 fp32, 1 bfloat16, 2 float16); bit 2: error-feedback weight rounding on the single-operand
-    analysis launches (the third analysis pass feeds view 2's tables); bit 3: fp32 latents; bits 4-7: table-kernel version."""
-    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[Fn.compute_dtype()]
-    return dt | (int(bool(Fn.SHAPED_WEIGHTS) and dt != 0) << 2) | (int(bool(Fn.FP32_LATENTS)) << 3) | (TABLE_KERNEL_VERSION << 4)
+    """Byte 0 of ``payload_mode_bytes()`` (the round-4 name; tests and tools that look at the storage format use it)."""
+    return payload_mode_bytes()[0]
 
 
-def describe_mode_byte(b):
-    return (f"{('float32', 'bfloat16', 'float16', '?')[b & 3]} maps, error-feedback analysis weights {'on' if b & 4 else 'off'}, "
-            f"fp32 latents {'on' if b & 8 else 'off'}, table kernels v{b >> 4}")
+def describe_mode_bytes(b):
+    b0, b1 = b[0], b[1]
+    return (f"{('float32', 'bfloat16', 'float16', '?')[b0 & 3]} maps, error-feedback analysis weights {'on' if b0 & 4 else 'off'}, "
+            f"fp32 latents {'on' if b0 & 8 else 'off'}, table kernels v{b0 >> 4}, warp align_corners={'True' if b1 & 1 else 'False'}, "
+            f"split-K {'on' if b1 & 2 else 'off'}, grouped hyper-synthesis {'on' if b1 & 4 else 'off'}, analysis {('x3', 'x3c2', 'x1', 'x2')[(b1 >> 3) & 3]}")
 
 
 def payload_header(extra=b""):
-    return PAYLOAD_MAGIC + bytes([payload_mode_byte()]) + extra
+    return PAYLOAD_MAGIC + payload_mode_bytes() + extra
 
 
 def check_payload(payload, n_extra=0):
     """Validate the container header; returns (extra bytes, offset of the range-coder stream)."""
     n = len(PAYLOAD_MAGIC)
-    if len(payload) < n + 1 + n_extra or payload[:n] != PAYLOAD_MAGIC:
-        raise ValueError("decompress: the .bin payload does not start with this coder's format-2 header (a file written by rounds 2-3 of "
+    if len(payload) < n + _MODE_BYTES + n_extra or payload[:n] != PAYLOAD_MAGIC:
+        raise ValueError("decompress: the .bin payload does not start with this coder's format-3 header (a file written by rounds 2-4 of "
                          "this package, or not one of its payloads): re-encode it -- the header names the mode the tables were formed in")
-    mode, here = payload[n], payload_mode_byte()
+    mode, here = bytes(payload[n:n + _MODE_BYTES]), payload_mode_bytes()
     if mode != here:
-        raise ValueError(f"decompress: the payload was written with [{describe_mode_byte(mode)}] but this process decodes with "
-                         f"[{describe_mode_byte(here)}]; the cumulative-frequency tables would differ in the last count and the range decoder "
-                         "would desynchronise.  Select the writer's mode (hesic_amd.set_compute_dtype, HESIC_SHAPED_WEIGHTS, HESIC_BF16_LATENTS)")
-    return payload[n + 1:n + 1 + n_extra], n + 1 + n_extra
+        raise ValueError(f"decompress: the payload was written with [{describe_mode_bytes(mode)}] but this process decodes with "
+                         f"[{describe_mode_bytes(here)}]; the cumulative-frequency tables would differ in the last count and the range decoder "
+                         "would desynchronise.  Select the writer's mode (hesic_amd.set_compute_dtype, set_analysis_precision, "
+                         "geometry.use_reference_era_warp / HESIC_WARP_ALIGN_CORNERS, HESIC_SHAPED_WEIGHTS, HESIC_BF16_LATENTS, HESIC_NO_GROUP_HYPER)")
+    return payload[n + _MODE_BYTES:n + _MODE_BYTES + n_extra], n + _MODE_BYTES + n_extra
 
 
 def _seq3(seq, x, last_act=NONE):
@@ -1766,7 +1785,7 @@ class AutoForward:
         if net.training:
             raise RuntimeError("AutoForward wraps the inference schedule: call net.eval() first")
         self.net, self.static_outputs = net, static_outputs
-        self._tensors, self._calls = None, 0
+        self._slots, self._calls = None, 0
         self._graph = GraphedForward(net, x1, x2, h_matrix, with_metrics=False)
         self._tag = self._weights_tag()
 
@@ -1791,14 +1810,20 @@ class AutoForward:
             self._graph = None                     # frees the captured graph and its private memory pool
 
     def _weights_tag(self):
-        """(cache epoch, storage format, analysis mode, (storage, version) of every parameter / buffer).  The tensor LIST is cached: rebuilding
-        ``state_dict(keep_vars=True)`` cost ~0.3 ms per call on the path chosen for having no host cost; the list is refreshed every 256
-        calls (``load_state_dict`` and optimisers update the registered tensors in place; a replaced Parameter object is caught then)."""
+        """(cache epoch, storage format, analysis mode, (identity, storage, version) of every parameter / buffer).  What is cached is the list of
+        SLOTS -- (a module's ``_parameters`` / ``_buffers`` dict, name) -- not the tensors: every call looks the current tensor up, so a replaced
+        Parameter object (``load_state_dict(assign=True)``, ``mod.weight = nn.Parameter(...)``) is seen on the very next call and no old
+        parameter is kept alive (the round-4 cache of the tensor list replayed stale packed weights for up to 255 calls).  The slot
+        list itself (modules added or removed) is rebuilt every 256 calls; rebuilding ``state_dict`` per call cost ~0.3 ms."""
         self._calls += 1
-        if self._tensors is None or self._calls % 256 == 0:
-            self._tensors = list(self.net.state_dict(keep_vars=True).values())
-        ts = self._tensors
-        return (Fn._cache_epoch, Fn.compute_dtype(), Fn.analysis_precision()) + tuple((t.data_ptr(), t._version) for t in ts)
+        if self._slots is None or self._calls % 256 == 0:
+            self._slots = [(d, n) for m in self.net.modules() for d in (m._parameters, m._buffers) for n in d]
+        tag = []
+        for d, n in self._slots:
+            t = d.get(n)
+            if t is not None:
+                tag.append((id(t), t.data_ptr(), t._version))
+        return (Fn._cache_epoch, Fn.compute_dtype(), Fn.analysis_precision(), tuple(tag))
 
     def __call__(self, x1, x2, h_matrix):
         if self.mode == "graph" and (tuple(x1.shape), tuple(x2.shape), tuple(h_matrix.shape)) == self._shape:

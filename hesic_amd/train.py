@@ -17,6 +17,7 @@ bucket's last gradient has been written, so it overlaps the rest of the backward
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 
 import torch
 import torch.distributed as dist
@@ -186,10 +187,20 @@ class FlatReducer:
     through a post-accumulate hook -- so the collective runs under the rest of the backward pass.  How many writes complete
     a parameter (encoder1's weights receive two per step) is learned in the first step, which reduces everything at
     ``finish()``.  ``finish()`` launches what is left (parameters without gradient on this rank still take part: ranks stay
-    in step), waits and -- for backends without an averaging reduction (gloo) -- divides.  world_size 1: all no-ops."""
+    in step), waits and -- for backends without an averaging reduction (gloo) -- divides.  world_size 1: all no-ops.
 
-    def __init__(self, group: FlatGroup, bucket_mb: float = 25.0, process_group=None, overlap=True, force=False):
+    ``collective`` (round 5; environment default ``HESIC_DP_COLLECTIVE``): "allreduce" -- one in-place all-reduce per bucket (a ring on
+    RCCL: 2 (N-1)/N of the bucket over ONE xGMI link per hop, ~1.6 ms for the 140 MB of HESIC at N = 8) -- or "rsag": the same
+    sum as a reduce-scatter into this rank's 1/N of the bucket followed by an all-gather of the shards, both in place on the flat buffer;
+    on a fully connected xGMI node every rank then exchanges 1/N of the bucket with each of its 7 peers at once (~0.23 ms).  The part of a
+    bucket beyond a multiple of N elements (< N values) goes through a small all-reduce.  Values are equal to "allreduce" up to the
+    summation order (``tests/test_dp_gloo.py``); unmeasured on hardware until an 8-GPU node exists."""
+
+    def __init__(self, group: FlatGroup, bucket_mb: float = 25.0, process_group=None, overlap=True, force=False, collective=None):
         self.group, self.pg, self.overlap = group, process_group, overlap
+        self.collective = collective or _os.environ.get("HESIC_DP_COLLECTIVE", "allreduce")
+        if self.collective not in ("allreduce", "rsag"):
+            raise ValueError("FlatReducer: collective must be 'allreduce' or 'rsag'")
         up = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if up else 1
         self.buckets, self._work, self._expected, self._events = [], [], None, [0] * len(group.params)
@@ -279,11 +290,34 @@ class FlatReducer:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(self._comm):
                 e0.record()
-                dist.all_reduce(buf, op=op, group=self.pg)          # synchronous on the communication stream: e1 is its completion
+                for w in self._collect(buf, op, False):              # synchronous on the communication stream: e1 is its completion
+                    pass
                 e1.record()
             self._timed.append((b["hi"] - b["lo"], e0, e1))
             return
-        self._work.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
+        self._work.extend(self._collect(buf, op, True))
+
+    def _collect(self, buf, op, async_op):
+        """The bucket's sum over the ranks, in place: one all-reduce, or reduce-scatter + all-gather (see the class docstring)."""
+        if self.collective == "allreduce" or self.world < 2:
+            return [dist.all_reduce(buf, op=op, group=self.pg, async_op=async_op)]
+        n, W = buf.numel(), self.world
+        main = n - n % W
+        works = []
+        if main:
+            rank = dist.get_rank(self.pg)
+            shard = buf[rank * (main // W):(rank + 1) * (main // W)]
+            # the all-gather reads the shard the reduce-scatter wrote: the two are issued in order on the backend's stream; with async_op the
+            # first is waited for before the second is issued only on backends that run collectives on the caller's thread (gloo)
+            w1 = dist.reduce_scatter_tensor(shard, buf[:main], op=op, group=self.pg, async_op=async_op)
+            if async_op and not self.avg_op:
+                w1.wait()
+                w1 = None
+            w2 = dist.all_gather_into_tensor(buf[:main], shard, group=self.pg, async_op=async_op)
+            works += [w for w in (w1, w2) if w is not None]
+        if main < n:
+            works.append(dist.all_reduce(buf[main:], op=op, group=self.pg, async_op=async_op))
+        return [w for w in works if w is not None]
 
     def finish(self):
         """Call once after the backward pass: launches the remaining buckets, waits, averages."""
@@ -307,7 +341,6 @@ class FlatReducer:
             self._expected = [e if e > 0 else -1 for e in self._events]
 
 
-import os as _os
 WGRAD_STREAM = _os.environ.get("HESIC_WGRAD_STREAM") is not None      # A/B switch (off): weight gradients on a stream of their own -- measured 12.34 vs 12.28 ms at B=8 512^2: the step is not gap-bound
 
 
@@ -315,7 +348,7 @@ class Trainer:
     """Holds the model, ``Adam(parameters, lr)`` + ``Adam(aux_parameters, aux_lr)`` (newtrain1.py:294-295) over flat
     parameter / gradient buffers and, when a process group is up, one in-place reducer per optimiser group."""
 
-    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, overlap=True, force_collectives=False):
+    def __init__(self, model, lr=1e-4, aux_lr=1e-3, lmbda=1e-2, bucket_mb=25.0, overlap=True, force_collectives=False, collective=None):
         self.model, self.lmbda = model, float(lmbda)
         main, aux = list(model.parameters()), list(model.aux_parameters())
         self.main_group, self.aux_group = FlatGroup(main), FlatGroup(aux)
@@ -329,8 +362,8 @@ class Trainer:
         # EB matrices/biases/factors get their gradient from the main backward but are stepped by the aux
         # optimiser after the aux backward adds the quantile gradient: both groups are reduced,
         # the aux group only after the aux backward.
-        self.main_reducer = FlatReducer(self.main_group, bucket_mb, overlap=overlap, force=force_collectives)
-        self.aux_reducer = FlatReducer(self.aux_group, bucket_mb, overlap=False, force=force_collectives)
+        self.main_reducer = FlatReducer(self.main_group, bucket_mb, overlap=overlap, force=force_collectives, collective=collective)
+        self.aux_reducer = FlatReducer(self.aux_group, bucket_mb, overlap=False, force=force_collectives, collective=collective)
         self.world = self.main_reducer.world
 
     def _forward_loss(self, x1, x2, h_matrix, noise):

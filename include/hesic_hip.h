@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HESIC_ABI_VERSION 1
+#define HESIC_ABI_VERSION 2   /* round 5: bumped (entry points added since v1: the tape calls, *_hilo_out, msssim, joint decode) */
 #define HESIC_EINVAL (-1)
 
 enum { HESIC_F32 = 0, HESIC_H16 = 1, HESIC_BF16 = 1 /* historical name of HESIC_H16 */ };

@@ -405,7 +405,7 @@ def test_gpu_joint_wavefront_and_raster_payloads_decode_to_the_same_latents(tmp_
             times[order] = time.perf_counter() - t0
             sizes[order] = len((tmp_path / (order + ".bin")).read_bytes())
             blob = (tmp_path / (order + ".bin")).read_bytes()
-            assert blob[:4] == models.PAYLOAD_MAGIC and blob[4] == models.payload_mode_byte() and blob[5] == (1 if order == "wavefront" else 0)
+            assert blob[:4] == models.PAYLOAD_MAGIC and blob[4:6] == models.payload_mode_bytes() and blob[6] == (1 if order == "wavefront" else 0)
             for k in ("y1_hat", "y2_hat"):
                 assert torch.equal(dec[k].float().cpu(), enc[k].float().cpu()), (order, k)
             outs[order] = dec
@@ -429,8 +429,8 @@ def test_gpu_joint_wavefront_and_raster_payloads_decode_to_the_same_latents(tmp_
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["hsic", "joint"])
 def test_gpu_payload_names_its_table_mode_and_a_mismatched_decoder_raises(tmp_path, kind):
-    """The .bin container starts with the format magic and a MODE byte (storage format of the maps, error-feedback weights, fp32
-    latents, table-kernel version).  A decoder in another mode -- whose tables would differ in the last count and silently desynchronise
+    """The .bin container starts with the format magic and two MODE bytes (storage format of the maps, error-feedback weights, fp32
+    latents, table-kernel version; round 5: warp convention, split-K / grouped hyper-synthesis launches, analysis precision).  A decoder in another mode -- whose tables would differ in the last count and silently desynchronise
     the range decoder -- raises a ValueError that names both modes; so does a headerless (round 2-3) payload."""
     import hesic_amd
     from hesic_amd import functional as Fn, models
@@ -452,9 +452,26 @@ def test_gpu_payload_names_its_table_mode_and_a_mismatched_decoder_raises(tmp_pa
         with pytest.raises(ValueError, match="float16 maps.*bfloat16 maps"):
             net.decompress(None, None, Hm, "p", str(tmp_path))
         hesic_amd.set_compute_dtype(torch.float16)
+        # the OTHER warp convention (kornia <= 0.4): x1_hat_warp, hence view 2's tables, would differ -- round 4's header did not name it
+        from hesic_amd import geometry
+        keep_ac = geometry.use_reference_era_warp(True)
+        try:
+            with pytest.raises(ValueError, match="align_corners=True.*align_corners=False"):
+                net.decompress(None, None, Hm, "p", str(tmp_path))
+        finally:
+            geometry.use_reference_era_warp(not keep_ac)
+        # the summation-order switches of the hyper-synthesis are in the header too
+        keep_sk, Fn.SPLIT_K = Fn.SPLIT_K, not Fn.SPLIT_K
+        try:
+            with pytest.raises(ValueError, match="split-K"):
+                net.decompress(None, None, Hm, "p", str(tmp_path))
+        finally:
+            Fn.SPLIT_K = keep_sk
+        dec = net.decompress(None, None, Hm, "p", str(tmp_path))      # and back in the writer's mode it decodes again
+        assert torch.equal(dec["y2_hat"].float().cpu(), enc["y2_hat"].float().cpu())
         (tmp_path / "old.npz").write_bytes((tmp_path / "p.npz").read_bytes())
-        (tmp_path / "old.bin").write_bytes(blob[5:])                 # what rounds 2-3 wrote: no header
-        with pytest.raises(ValueError, match="format-2 header"):
+        (tmp_path / "old.bin").write_bytes(blob[6:])                 # what rounds 2-3 wrote: no header
+        with pytest.raises(ValueError, match="format-3 header"):
             net.decompress(None, None, Hm, "old", str(tmp_path))
     finally:
         hesic_amd.set_compute_dtype(torch.bfloat16)
