@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(fmt):
     h16 = torch.float16 if fmt == "f16" else torch.bfloat16
     path = L.LIB_PATH_F16 if fmt == "f16" else L.LIB_PATH
     l = L.lib(h16)
-    assert l.hesic_abi_version() == 1
+    assert l.hesic_abi_version() == L.ABI_VERSION == 2            # include/hesic_hip.h HESIC_ABI_VERSION
     assert l.hesic_h16_format() == (1 if fmt == "f16" else 0)
     declared = L.declared_symbols()
     assert len(declared) >= 30
