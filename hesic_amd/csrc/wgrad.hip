@@ -40,6 +40,11 @@ struct WgArgs {
     int64_t Q, chunk;
     int co_tiles, ci_tiles, ntaps, nsplit;
     int rowk;                                      // wgrad_row_kernel takes this layer (fill_args): blocks = KH x tiles x nsplit
+    // split-K workspace layout: 0 = [split][tap][Cout][Cin] (rounds 1-4; the reduce kernels of the packed-layout API and the 1x1 GEMM users
+    // read it), 1 = [tap][Cout][split][Cin] (round 5, the direct / partial / finish_batched route): the slices of one (tap, cout) row are
+    // ADJACENT 512-byte rows, so the finishing pass streams nsplit * Cin * 4 contiguous bytes per row instead of nsplit 128-byte runs that
+    // lie ntaps * Cout * Cin * 4 = 1.6 MB apart (365 us per step for ~1 GB of partials = 2.9 TB/s, profiles/r05_d_train_step_timeline.txt)
+    int ws_layout;
     int8_t tap_id[25];
     // bias gradient on the matrix cores (wgrad_tr_kernel only): the blocks of the taps listed in b_tap (indices into the live taps)
     // with ci tile 0 also form the column sums of their dY slice -- one more MFMA per cout fragment and k-step against a fragment of
@@ -47,6 +52,11 @@ struct WgArgs {
     // transposed conv reads dY at q * stride + k - pad: the stride^2 taps with k - pad in [0, stride) cover every pixel exactly once.
     float* bias_part; int nb_taps; int8_t b_tap[4];
 };
+
+// element offset of row (split, live tap index, cout) of the split-K workspace
+__device__ __host__ __forceinline__ int64_t ws_row(const WgArgs& a, int split, int tapi, int co) {
+    return a.ws_layout ? (((int64_t)tapi * a.Cout + co) * a.nsplit + split) * a.Cin : (((int64_t)split * a.ntaps + tapi) * a.Cout + co) * a.Cin;
+}
 
 template <typename T> struct WC;
 template <> struct WC<h16_t> { static constexpr int BK = 64, PB = 8, CB = 8; };
@@ -230,7 +240,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
         __syncthreads();
     }
     // C[i = co][j = ci]: col = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[i][j][r];
+                if (co < a.Cout && ci < a.Cin) a.out[ws_row(a, split, tapi, co) + ci] = acc[i][j][r];
             }
         }
 }
@@ -549,7 +558,6 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
         else main_loop(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
     }
 
-    float* out = a.out + ((int64_t)split * a.ntaps + tapi) * a.Cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[i][j][r];
+                if (co < a.Cout && ci < a.Cin) a.out[ws_row(a, split, tapi, co) + ci] = acc[i][j][r];
             }
         }
 }
@@ -759,7 +767,6 @@ __global__ __launch_bounds__(512) void wgrad_row_kernel(const WgRowArgs A) {
     // C[row = A's channel][col = B's channel]: col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int kx = 0; kx < 5; ++kx) {
-        float* out = a.out + ((int64_t)split * a.ntaps + ky * 5 + kx) * a.Cout * a.Cin;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ci = TR ? ci0 + wl * 64 + i * 32 + frow : ci0 + wsd * 32 + frow;
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(512) void wgrad_row_kernel(const WgRowArgs A) {
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int co = TR ? co0 + wsd * 32 + rr : co0 + wl * 64 + i * 32 + rr;
-                if (co < a.Cout && ci < a.Cin) out[(int64_t)co * a.Cin + ci] = acc[kx][i][r];
+                if (co < a.Cout && ci < a.Cin) a.out[ws_row(a, split, ky * 5 + kx, co) + ci] = acc[kx][i][r];
             }
         }
     }
@@ -924,6 +931,7 @@ struct FinishArgs {
     int tiles_ci, tiles_co, tap_groups, taps_per_group, n_red;
     int8_t tap_id[25];
     const float* bias_part; int nb_parts, accumulate_bias;      // bias column sums left by wgrad_tr_kernel: [nb_parts][Cout], summed in order by ONE block
+    int ws_layout;                                              // WgArgs::ws_layout of the launch that wrote ws
 };
 
 template <typename T>
@@ -949,7 +957,11 @@ __device__ __forceinline__ void finish_body(const FinishArgs& f, const T* __rest
     const int tg = bid / f.tiles_co;
     const int t0 = tg * f.taps_per_group;
     const int tn = (t0 + f.taps_per_group <= f.ntaps ? f.taps_per_group : f.ntaps - t0);
-    const int64_t per_tap = (int64_t)f.Cout * f.Cin, n = (int64_t)f.ntaps * per_tap;
+    const int64_t per_tap = (int64_t)f.Cout * f.Cin;
+    // slice stride and row stride (elements) of the workspace layout (WgArgs::ws_layout)
+    const int64_t n = f.ws_layout ? f.Cin : (int64_t)f.ntaps * per_tap;
+    const int64_t rowst = f.ws_layout ? (int64_t)f.nsplit * f.Cin : f.Cin;
+    const int64_t tapst = f.ws_layout ? (int64_t)f.Cout * f.nsplit * f.Cin : per_tap;
     if ((f.Cin & 3) == 0) {
         // 16-byte lanes: thread = (tap lane tq of 4, cout cl of 8, 4 consecutive cins), the K slices of its value all in flight at once --
         // a quarter of the load instructions of the 4-byte form below for the same 128-byte row segments
@@ -959,7 +971,7 @@ __device__ __forceinline__ void finish_body(const FinishArgs& f, const T* __rest
         for (int tl = tq; tl < tn; tl += 4) {
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
             if (in4) {
-                const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co4 * f.Cin + ci4;
+                const float* src = f.ws + (int64_t)(t0 + tl) * tapst + (int64_t)co4 * rowst + ci4;
                 int k = 0;
                 for (; k + 7 < f.nsplit; k += 8) {
                     const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * n), a1 = *(const f32x4*)(src + (int64_t)(k + 1) * n);
@@ -981,7 +993,7 @@ __device__ __forceinline__ void finish_body(const FinishArgs& f, const T* __rest
     for (int tl = 0; tl < ((f.Cin & 3) == 0 ? 0 : tn); ++tl) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (in) {
-            const float* src = f.ws + (int64_t)(t0 + tl) * per_tap + (int64_t)co * f.Cin + ci;
+            const float* src = f.ws + (int64_t)(t0 + tl) * tapst + (int64_t)co * rowst + ci;
             int k = 0;
             for (; k + 7 < f.nsplit; k += 8) {           // eight loads in flight per lane; fixed order: deterministic
                 const float a0 = src[(int64_t)k * n], a1 = src[(int64_t)(k + 1) * n], a2 = src[(int64_t)(k + 2) * n], a3 = src[(int64_t)(k + 3) * n];
@@ -2298,6 +2310,7 @@ static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws
     memset(&f, 0, sizeof(f));
     f.ws = (const float*)ws; f.dw = dw; f.nsplit = a.nsplit; f.ntaps = a.ntaps; f.T_all = T_all; f.Cout = d->Cout; f.Cin = d->Cin;
     f.transposed = d->transposed; f.accumulate = (accumulate || a.ntaps < T_all) ? 1 : 0;
+    f.ws_layout = a.ws_layout;
     memcpy(f.tap_id, a.tap_id, sizeof(f.tap_id));
     f.tiles_ci = (d->Cin + 31) / 32; f.tiles_co = (d->Cout + 7) / 8;
     const int tiles = f.tiles_ci * f.tiles_co;
@@ -2317,6 +2330,14 @@ static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws
 }
 
 static thread_local int g_wgrad_partial_only = 0;      // set by hesic_conv2d_wgrad_partial: stop after the split-K MFMA launch
+// workspace layout of the direct / partial / finish_batched route (WgArgs::ws_layout).  A/B switch, OFF: HESIC_WGRAD_WS_LAYOUT=1 puts the
+// slices of a (tap, cout) row next to each other.  Measured neutral on the training step (same box, alternating runs: 9.579 / 9.583 ms
+// with it, 9.586 / 9.596 without): the finishing pass still reads 128-byte pieces (its 8 cout x 32 cin tiles) -- contiguity across
+// slices alone does not raise its 2.9 TB/s; a 512-byte-wide tile would be the next step.
+static int direct_ws_layout() {
+    const char* e = getenv("HESIC_WGRAD_WS_LAYOUT");
+    return (e && atoi(e) == 1) ? 1 : 0;
+}
 
 extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                          int accumulate, void* ws, int64_t ws_bytes, void* stream) {
@@ -2328,6 +2349,7 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     HESIC_CHECK_ARG(d->KH * d->KW <= 25, "conv2d_wgrad_direct: at most 25 taps");
     WgArgs a;
     fill_args(d, a);
+    a.ws_layout = direct_ws_layout();
     const int64_t need = (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
     HESIC_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad_direct: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     hipStream_t st = (hipStream_t)stream;
@@ -2715,6 +2737,7 @@ extern "C" int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* d
                 HESIC_CHECK_ARG(dw[i] != dw[j0 + j] || i < j0, "conv2d_wgrad_finish_batched: jobs %d and %d add into the same gradient in one launch", i, j0 + j);
             WgArgs a;
             fill_args(d, a);
+            a.ws_layout = direct_ws_layout();
             FinishExtra& e = fb.e[j];
             const bool bias_in_tr = setup_bias_part(d, a, (void*)ws[j0 + j]);      // the same decision hesic_conv2d_wgrad_partial took
             const int n_col = make_finish(d, a, ws[j0 + j], dw[j0 + j], accumulate, dbias[j0 + j] != nullptr, fb.f[j], e.P, e.rpb, accumulate);
