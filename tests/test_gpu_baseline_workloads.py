@@ -293,12 +293,13 @@ def test_trained_operating_point_parity_at_512():
     assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 2e-3 and r["flips"] <= 1e-3, ("bf16-x3", r)
 
 
-def test_trained_30db_operating_point_parity_at_512():
+@pytest.mark.parametrize("kind", ["hsic", "joint"])
+def test_trained_30db_operating_point_parity_at_512(kind):
     """Parity at an operating point like the published ones (Readme.md:33-46: 33 - 37 dB): graph-replayed training steps (bf16, B=8,
     256 x 256 PIECEWISE-SMOOTH synthetic pairs, ``synthetic.smooth_stereo_pair``; lambda 0.02, the reference's lr 1e-4, newtrain1.py:180-185)
     take the deterministic init to >= 30 dB (checked every 500 steps from 1500 on, at most 5000: the loss of this unclipped recipe spikes now
-    and then, as the reference's would); then the 16-bit inference modes against the fp32 CPU oracle run on THOSE weights on a 512 x 512
-    smooth pair.
+    and then, as the reference's would); then the 16-bit inference modes against the fp32 CPU oracle run on THOSE weights on a SET of two
+    512 x 512 smooth pairs (set averages of bpp and PSNR, as the reference's evaluation reports them; flips = the worst pair).
     The default mode (float16 maps, pair analysis) must hold north_star's bars there: |dbpp| < 1e-3, |dPSNR| < 1e-3 dB, and -- at an MSE of
     ~6e-4 every flipped latent is visible in the PSNR -- <= 1e-4 flipped latents.  The explicit fast mode "x3c2" (round 4's default) is
     measured next to it under the wider bars it actually meets here (<= 1e-3 flips, |dPSNR| < 1e-2 dB: 2 - 6e-3 dB measured, which is why
@@ -308,13 +309,13 @@ def test_trained_30db_operating_point_parity_at_512():
     from hesic_amd.train import GraphedTrainer
     from oracle import hesic_oracle as O
     hesic_amd.set_compute_dtype(torch.bfloat16)
-    net = models.HSIC()
+    net = (models.HSIC if kind == "hsic" else models.HSICJoint)()
     synthetic.fill_state_dict_(net.state_dict())
     net = net.to(DEV)
     torch.manual_seed(5)
     tr = GraphedTrainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.02)
     pool = [tuple(t.to(DEV) for t in synthetic.smooth_stereo_batch(100 + 8 * i, 8, 256, 256)) for i in range(8)]
-    x1, x2, Hm = synthetic.smooth_stereo_batch(0, 1, 512, 512)
+    x1, x2, Hm = synthetic.smooth_stereo_batch(0, 2, 512, 512)          # a SET of two pairs: the reference reports set averages (test3real.py:110-122)
     xd = tuple(t.to(DEV) for t in (x1, x2, Hm))
     steps, psnr_now = 0, 0.0
     while steps < 5000 and psnr_now < 30.3:
@@ -335,20 +336,25 @@ def test_trained_30db_operating_point_parity_at_512():
     Fn.invalidate_weight_cache()
     P = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
     torch.set_num_threads(min(16, torch.get_num_threads()))
+    fwd_o = O.hsic_forward if kind == "hsic" else O.hsic_joint_forward
     with torch.no_grad():
-        ref = O.hsic_forward(P, x1, x2, Hm)
-    mr = O.metrics(ref, x1, x2)
-    assert mr["psnr"] >= 30.0, mr            # the point of this test
+        refs = [fwd_o(P, x1[j:j + 1], x2[j:j + 1], Hm[j:j + 1]) for j in range(2)]
+    mrs = [O.metrics(r, x1[j:j + 1], x2[j:j + 1]) for j, r in enumerate(refs)]
+    mr = {"bpp": (mrs[0]["bpp"] + mrs[1]["bpp"]) / 2, "psnr": (mrs[0]["psnr"] + mrs[1]["psnr"]) / 2}
+    assert mr["psnr"] >= 30.0, mrs            # the point of this test
     recs = {}
     for name, dt, an in (("f16-x3", torch.float16, "auto"), ("f16-x3c2", torch.float16, "x3c2"), ("bf16-x3", torch.bfloat16, "x3")):
         hesic_amd.set_compute_dtype(dt)
         Fn.set_analysis_precision(an)
-        with torch.no_grad():
-            out = net(x1.to(DEV), x2.to(DEV), Hm.to(DEV))
-            m = models.metrics_from(models.rate_distortion(out, x1.to(DEV), x2.to(DEV)))
-        flips = max(float((out[k].float().cpu() != ref[k]).float().mean()) for k in ("y1_hat", "y2_hat"))
-        recs[name] = {"dbpp": m["bpp"] - mr["bpp"], "dpsnr_db": m["psnr"] - mr["psnr"], "flips": flips, "mode": Fn.analysis_precision()}
-    print("trained smooth point after %d steps: bpp %.4f, PSNR %.3f dB (oracle);" % (steps, mr["bpp"], mr["psnr"]),
+        ms, flips = [], 0.0
+        for j in range(2):
+            with torch.no_grad():
+                out = net(xd[0][j:j + 1], xd[1][j:j + 1], xd[2][j:j + 1])
+                ms.append(models.metrics_from(models.rate_distortion(out, xd[0][j:j + 1], xd[1][j:j + 1])))
+            flips = max(flips, max(float((out[k].float().cpu() != refs[j][k]).float().mean()) for k in ("y1_hat", "y2_hat")))
+        recs[name] = {"dbpp": (ms[0]["bpp"] + ms[1]["bpp"]) / 2 - mr["bpp"], "dpsnr_db": (ms[0]["psnr"] + ms[1]["psnr"]) / 2 - mr["psnr"],
+                      "dpsnr_db_worst_pair": max(abs(ms[j]["psnr"] - mrs[j]["psnr"]) for j in range(2)), "flips": flips, "mode": Fn.analysis_precision()}
+    print("%s trained smooth point after %d steps: bpp %.4f, PSNR %.3f dB (oracle);" % (kind, steps, mr["bpp"], mr["psnr"]),
           {k: {kk: (float("%.3g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in recs.items()})
     r = recs["f16-x3"]
     assert r["mode"] == "x3"
