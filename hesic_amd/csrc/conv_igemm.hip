@@ -1816,7 +1816,10 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     // hi/lo GDN form, same box back to back (conv 128->128 s2 @256^2 B=8, graph replay): 128-pixel tile 339.8 us; 1 = 256 pixels, 8 waves
     // of 64 x 64: 331.2 us; 2 = 256 pixels, 4 waves of 64 couts x 128 pixels (25 % fewer fragment bytes per MFMA, one wave per SIMD):
     // 359.0 us -- fragment-read bandwidth is not what bounds the loop, a lone wave per SIMD just loses its latency cover
-    static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 0;      // A/B switch, off
+    // Round 5: ON (1) -- with "x3" the default analysis mode this launch is the forward's largest (2 x 336 us); same box, graph replay,
+    // alternating: 345.8 / 344.0 us (0) vs 332.6 / 331.8 (1) vs 332.2 / 337.9 (3 = the 8-wave form on a ring of three 48 KB stages);
+    // 8-pair step 2.763 -> 2.741 ms.  The K walk of an output is the same in every tile: results are bit-identical.
+    static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 1;      // A/B switch
     if (fast && (hilo ? (hilo == 1 && big_hl && gdn == 3) : (big && (big < 3 || gdn == 0))) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
@@ -1915,6 +1918,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         } else if (bm == 256) {
             const dim3 block2(512);
             if (hilo && big_hl == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 4, 0, 1>), grid, block, 0, st, a);     // 4 waves of 64 couts x 128 pixels
+            else if (hilo && big_hl == 3) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 3, 3, 8, 0, 1>), grid, block2, 0, st, a);   // round 5: 8 waves, THREE 48 KB stages
             else if (hilo) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, block2, 0, st, a);
             else if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 1, 8>), grid, block2, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 2, 8>), grid, block2, 0, st, a);
