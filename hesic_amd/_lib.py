@@ -184,6 +184,9 @@ _SIGS = {
     "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
     "hesic_conv2d_wgrad_finish_batched": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i32, _vp], _i32),
     "hesic_gdn_backward_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
+    "hesic_gdn_backward_partial_ok": ([_i64, _i32, _i32], _i32),
+    "hesic_gdn_backward_partial": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
+    "hesic_gdn_param_finish_batched": ([_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_gdn_backward_planar_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
     "hesic_eb_pack_table": ([_P(EbLayout), _vp, _i32, _vp], _i32),
     "hesic_eb_scatter_grads": ([_P(EbLayout), _vp, _i32, _i32, _vp], _i32),

@@ -2583,15 +2583,63 @@ extern "C" int64_t hesic_gdn_backward_ws_bytes(int64_t P, int C) {
 extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const void* dy, float* dw_packed, float* dbias,
                                   void* ws, int64_t ws_bytes, void* stream);
 
+// ---- the parameter-gradient finishing passes of SEVERAL fused GDN backwards in one launch (round 5): a training step ran 15 of them, 6 us
+// each, one behind every gdn128_bwd_kernel.  hesic_gdn_backward_partial leaves the block partials in the caller's workspace;
+// hesic_gdn_param_finish_batched sums them (the order of gdn_param_finish_kernel: bit-identical) for up to GDN_FIN_NB layers per launch.
+constexpr int GDN_FIN_NB = 16;
+struct GdnFinJob { const float* part; const float* beta; const float* gamma; float* dgamma; float* dbeta; int nb; float bound; };
+struct GdnFinBatch { int n, accumulate; GdnFinJob j[GDN_FIN_NB]; };
+namespace {
+__global__ __launch_bounds__(256) void gdn_param_finish_batched_kernel(const GdnFinBatch fb) {
+    constexpr int NP = 128 * 128 + 128, BPJ = NP / 64;
+    const int job = blockIdx.x / BPJ, blk = blockIdx.x - job * BPJ;
+    const GdnFinJob& J = fb.j[job];
+    __shared__ f32x4 red[16][16];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = (blk * 16 + el) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int k = grp;
+    for (; k + 16 < J.nb; k += 32) {
+        s0 += *(const f32x4*)(J.part + (int64_t)k * NP + i);
+        s1 += *(const f32x4*)(J.part + (int64_t)(k + 16) * NP + i);
+    }
+    if (k < J.nb) s0 += *(const f32x4*)(J.part + (int64_t)k * NP + i);
+    red[grp][el] = s0 + s1;
+    __syncthreads();
+    if (grp == 0) {
+        f32x4 sum = red[0][el];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) sum += red[g][el];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = i + e;
+            if (idx < 128 * 128) {
+                const float th = J.gamma[idx], g = sum[e] * 2.f * fmaxf(th, kGammaBound);
+                const float v = (th >= kGammaBound || g < 0.f) ? g : 0.f;
+                J.dgamma[idx] = fb.accumulate ? J.dgamma[idx] + v : v;
+            } else {
+                const int c = idx - 128 * 128;
+                const float th = J.beta[c], g = sum[e] * 2.f * fmaxf(th, J.bound);
+                const float v = (th >= J.bound || g < 0.f) ? g : 0.f;
+                J.dbeta[c] = fb.accumulate ? J.dbeta[c] + v : v;
+            }
+        }
+    }
+}
+}  // namespace
+
+static thread_local int g_gdn_partial_only = 0;    // set by hesic_gdn_backward_partial: stop behind gdn128_bwd_kernel
+extern "C" int hesic_gdn_backward_partial_ok(int64_t P, int C, int dtype);
 static thread_local int g_gdn_accumulate = 0;      // set by hesic_gdn_backward_acc around its call
 
 extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,
                                   float* dgamma, void* ws, int64_t P, int C, int inverse, float beta_min, int dtype, void* stream) {
     const int accumulate = g_gdn_accumulate;
-    HESIC_CHECK_ARG(x && dy && beta && gamma && dx && dbeta && dgamma && ws && P > 0 && C > 0, "gdn_backward: bad arguments");
+    HESIC_CHECK_ARG(x && dy && beta && gamma && dx && (g_gdn_partial_only || (dbeta && dgamma)) && ws && P > 0 && C > 0, "gdn_backward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
     static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr;
+    HESIC_CHECK_ARG(!g_gdn_partial_only || hesic_gdn_backward_partial_ok(P, C, dtype), "gdn_backward_partial: only the fused 128-channel 16-bit form leaves block partials");
     if (!legacy && C == 128 && dtype == HESIC_H16 && P < (1ll << 22)) {
         hesic_conv_desc d;
         gdn_fast_desc(P, d);
@@ -2628,6 +2676,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { hesic_set_error("gdn_backward: %s", hipGetErrorString(e)); return (int)e; }
             }
+            if (g_gdn_partial_only) HESIC_LAUNCH_RETURN("gdn_backward_partial");
             hipLaunchKernelGGL(gdn_param_finish_kernel, dim3((unsigned)(NP / 64)), dim3(256), 0, st, (const float*)part, nb, beta, gamma, dgamma, dbeta, bound, accumulate);
             HESIC_LAUNCH_RETURN("gdn_backward");
         }
@@ -2690,6 +2739,43 @@ extern "C" int hesic_gdn_backward_acc(const void* x, const void* dy, const float
     const int rc = hesic_gdn_backward(x, dy, beta, gamma, dx, dbeta, dgamma, ws, P, C, inverse, beta_min, dtype, stream);
     g_gdn_accumulate = 0;
     return rc;
+}
+
+extern "C" int hesic_gdn_backward_partial_ok(int64_t P, int C, int dtype) {
+    static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr, split_params = getenv("HESIC_GDN_BWD_SPLIT") != nullptr;
+    return (!legacy && !split_params && C == 128 && dtype == HESIC_H16 && P > 0 && P < (1ll << 22)) ? 1 : 0;
+}
+
+extern "C" int hesic_gdn_backward_partial(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, void* ws, int64_t P,
+                                          int C, int inverse, float beta_min, int dtype, void* stream) {
+    g_gdn_partial_only = 1;
+    const int rc = hesic_gdn_backward(x, dy, beta, gamma, dx, nullptr, nullptr, ws, P, C, inverse, beta_min, dtype, stream);
+    g_gdn_partial_only = 0;
+    return rc;
+}
+
+extern "C" int hesic_gdn_param_finish_batched(int n, const void* const* ws, const int64_t* P, const float* const* beta, const float* const* gamma,
+                                              float* const* dgamma, float* const* dbeta, const float* beta_min, int accumulate, void* stream) {
+    HESIC_CHECK_ARG(n >= 0 && (n == 0 || (ws && P && beta && gamma && dgamma && dbeta && beta_min)), "gdn_param_finish_batched: null pointer");
+    constexpr int NP = 128 * 128 + 128;
+    for (int j0 = 0; j0 < n; j0 += GDN_FIN_NB) {
+        GdnFinBatch fb;
+        memset(&fb, 0, sizeof(fb));
+        fb.n = n - j0 < GDN_FIN_NB ? n - j0 : GDN_FIN_NB;
+        fb.accumulate = accumulate ? 1 : 0;
+        for (int j = 0; j < fb.n; ++j) {
+            const int q = j0 + j;
+            HESIC_CHECK_ARG(ws[q] && beta[q] && gamma[q] && dgamma[q] && dbeta[q] && P[q] > 0, "gdn_param_finish_batched: job %d: bad arguments", q);
+            for (int i = j0; i < q; ++i)
+                HESIC_CHECK_ARG(dgamma[i] != dgamma[q], "gdn_param_finish_batched: jobs %d and %d add into the same gradient in one launch", i, q);
+            const int64_t tiles = (P[q] + 127) / 128;
+            fb.j[j].part = (const float*)ws[q]; fb.j[j].beta = beta[q]; fb.j[j].gamma = gamma[q]; fb.j[j].dgamma = dgamma[q]; fb.j[j].dbeta = dbeta[q];
+            fb.j[j].nb = (int)(tiles < 256 ? tiles : 256);
+            fb.j[j].bound = sqrtf(beta_min[q] + kPedestal);
+        }
+        hipLaunchKernelGGL(gdn_param_finish_batched_kernel, dim3((unsigned)(fb.n * (NP / 64))), dim3(256), 0, (hipStream_t)stream, fb);
+    }
+    HESIC_LAUNCH_RETURN("gdn_param_finish_batched");
 }
 
 extern "C" int hesic_gdn_backward_planar_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, float* dbeta,

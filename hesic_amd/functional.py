@@ -161,6 +161,7 @@ def set_wgrad_stream(stream):
 
 # Deferred finishing passes of the wide weight gradients (see _wide_conv_grads): a list while train.Trainer.step collects them
 _finish_queue = None
+GDN_FINISH_BATCH = _os.environ.get("HESIC_GDN_FINISH_BATCH", "1") != "0"      # A/B switch: 0 = one parameter finish per GDN backward (rounds 2-4)
 WGRAD_FINISH_BATCH = int(_os.environ.get("HESIC_WGRAD_FINISH_BATCH", "8"))     # A/B switch: 0 = one finishing launch per layer (rounds 2-3)
 
 
@@ -176,9 +177,30 @@ def defer_wgrad_finish(on):
     return prev
 
 
+_gdn_finish_queue = []        # (ws, P, beta, gamma, slot_beta, slot_gamma, beta_min): fused GDN backwards whose parameter finish is pending
+
+
+def flush_gdn_finish():
+    """One ``hesic_gdn_param_finish_batched`` call for the queued GDN backwards (round 5: 15 six-microsecond launches per step before)."""
+    q = _gdn_finish_queue
+    if not q:
+        return
+    n = len(q)
+    vp, i64, f32 = C.c_void_p * n, C.c_int64 * n, C.c_float * n
+    L.call("hesic_gdn_param_finish_batched", n, vp(*[j[0].data_ptr() for j in q]), i64(*[j[1] for j in q]), vp(*[j[2].data_ptr() for j in q]),
+           vp(*[j[3].data_ptr() for j in q]), vp(*[j[5].grad.data_ptr() for j in q]), vp(*[j[4].grad.data_ptr() for j in q]),
+           f32(*[j[6] for j in q]), 1, L.stream())
+    jobs = list(q)
+    q.clear()
+    for j in jobs:
+        _slot_done(j[4])
+        _slot_done(j[5])
+
+
 def flush_wgrad_finish():
     """One ``hesic_conv2d_wgrad_finish_batched`` call for the queued layers, on the current stream (the stream their split-K launches
     went to); the gradient slots report afterwards, so a bucket's all-reduce is still issued behind its last finishing launch."""
+    flush_gdn_finish()
     q = _finish_queue
     if not q:
         return
@@ -712,6 +734,16 @@ def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
     dbeta = sb.grad if direct else torch.empty_like(beta, dtype=torch.float32)
     dgamma = sg.grad if direct else torch.empty_like(gamma, dtype=torch.float32)
     ws = torch.empty(max(1, L.lib().hesic_gdn_backward_ws_bytes(P, Cc)), dtype=torch.uint8, device=v.device)
+    if (direct and _finish_queue is not None and GDN_FINISH_BATCH and beta.is_contiguous() and gamma.is_contiguous()
+            and L.lib().hesic_gdn_backward_partial_ok(P, Cc, L.dt(v))):
+        # Trainer step: dx now, the parameter-gradient finish with the other GDNs' in one launch (flush_gdn_finish); a module used twice in a
+        # step (encoder1) must not have two jobs in one launch
+        if any(j[5] is sg for j in _gdn_finish_queue) or len(_gdn_finish_queue) >= 16:
+            flush_gdn_finish()
+        L.call("hesic_gdn_backward_partial", L.ptr(v), L.ptr(gy), L.ptr(beta), L.ptr(gamma), L.ptr(gv), L.ptr(ws), P, Cc, int(inverse),
+               float(beta_min), L.dt(v), L.stream())
+        _gdn_finish_queue.append((ws, P, beta, gamma, sb, sg, float(beta_min)))
+        return gv, None, None
     L.call("hesic_gdn_backward_acc", L.ptr(v), L.ptr(gy), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(gv), L.ptr(dbeta),
            L.ptr(dgamma), int(direct), L.ptr(ws), P, Cc, int(inverse), float(beta_min), L.dt(v), L.stream())
     if direct:

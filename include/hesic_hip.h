@@ -311,6 +311,17 @@ int hesic_gdn_backward(const void* x, const void* dy, const float* beta, const f
 int hesic_gdn_backward_acc(const void* x, const void* dy, const float* beta, const float* gamma, void* dx,
                            float* dbeta, float* dgamma, int accumulate, void* ws, int64_t P, int C, int inverse,
                            float beta_min, int dtype, void* stream);
+/* Round 5: the parameter-gradient finishing passes of several fused GDN backwards (compressai/layers/gdn.py:55-70 under autograd, the
+ * backward of newtrain1.py:85-96) in ONE launch.  hesic_gdn_backward_partial = hesic_gdn_backward stopped behind its main kernel: dx is
+ * complete, the per-block (dgamma' | dbeta') partials stay in ws (which the caller keeps alive); hesic_gdn_backward_partial_ok says
+ * whether (P, C, dtype) has that form (C == 128, 16-bit storage).  hesic_gdn_param_finish_batched sums the partials of n such calls in
+ * the order hesic_gdn_backward would (bit-identical), applies the reparametrisation chain and writes / adds (accumulate) dgamma, dbeta;
+ * two jobs of one call must not share a gradient.                                                                               */
+int hesic_gdn_backward_partial_ok(int64_t P, int C, int dtype);
+int hesic_gdn_backward_partial(const void* x, const void* dy, const float* beta, const float* gamma, void* dx, void* ws, int64_t P,
+                               int C, int inverse, float beta_min, int dtype, void* stream);
+int hesic_gdn_param_finish_batched(int n, const void* const* ws, const int64_t* P, const float* const* beta, const float* const* gamma,
+                                   float* const* dgamma, float* const* dbeta, const float* beta_min, int accumulate, void* stream);
 /* The 3-channel image-side GDNs (pre_gdn / after_gdn, newnet1.py:630,669) under autograd on PLANAR (B, 3, HW) tensors, as
  * hesic_gdn_forward_planar: dx and the parameter gradients from one pass over x and dy (no NHWC copies on either side, so the conv
  * behind pre_gdn keeps its planar-input kernel).  ws: at least 64 bytes.  accumulate as hesic_gdn_backward_acc.                    */
