@@ -213,3 +213,27 @@ def test_loading_a_checkpoint_mentions_the_warp_convention_once():
         assert not any("warp convention" in str(x.message) for x in w)
     finally:
         geometry.DEFAULT_ALIGN_CORNERS, geometry._CONVENTION_CHOSEN, models.StereoCompressionModel._warned_warp = keep
+
+
+def test_smooth_synthetic_pairs_are_deterministic_smooth_and_warp_consistent():
+    """``synthetic.smooth_stereo_pair`` (round 5: the content the >= 30 dB trained-point parity test trains on): seeded (same pair twice, other
+    seed differs), inside [0, 1], far smoother than ``stereo_pair``'s low-passed noise (mean |horizontal difference| 10x smaller), and view 2
+    is view 1 warped by the pair's homography (the oracle's warp of x1 reproduces x2 up to its N(0, 0.004) noise where the warp is inside)."""
+    import numpy as np
+    import torch
+    from hesic_amd import synthetic
+    from oracle import hesic_oracle as O
+    a = synthetic.smooth_stereo_pair(3, 96, 128)
+    b = synthetic.smooth_stereo_pair(3, 96, 128)
+    c = synthetic.smooth_stereo_pair(4, 96, 128)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b)) and not np.array_equal(a[0], c[0])
+    x1, x2, H = a
+    assert x1.dtype == np.float32 and x1.shape == (3, 96, 128) and 0.0 <= x1.min() and x1.max() <= 1.0 and 0.0 <= x2.min() and x2.max() <= 1.0
+    n1 = synthetic.stereo_pair(3, 96, 128)[0]
+    assert np.abs(np.diff(x1, axis=2)).mean() < 0.1 * np.abs(np.diff(n1, axis=2)).mean()
+    w = O.warp_perspective(torch.from_numpy(x1)[None], torch.from_numpy(H)[None], (96, 128), True)[0].numpy()
+    inside = w.sum(0) > 0
+    assert inside.mean() > 0.7
+    assert np.abs(w - x2)[:, inside].mean() < 0.01
+    xb = synthetic.smooth_stereo_batch(3, 2, 96, 128)
+    assert tuple(xb[0].shape) == (2, 3, 96, 128) and np.array_equal(xb[0][0].numpy(), x1) and tuple(xb[2].shape) == (2, 3, 3)
