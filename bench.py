@@ -170,7 +170,7 @@ class WgradMeter:
                 self.orig("hesic_conv2d_wgrad_partial", args[0], args[1], args[2], args[6], args[7], args[8])
                 e1.record()
                 ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
-                self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)))
+                self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps), self.kernel_of(d)))
             if name == "hesic_conv2d_wgrad_partial":          # Trainer.step with the batched finishing pass: the MFMA launch is its own call
                 d = args[0]._obj
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -178,7 +178,7 @@ class WgradMeter:
                 rc = self.orig(name, *args)
                 e1.record()
                 ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
-                self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)))
+                self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps), self.kernel_of(d)))
                 return rc
             return self.orig(name, *args)
         self.L.call = call
@@ -187,14 +187,29 @@ class WgradMeter:
     def __exit__(self, *exc):
         self.L.call = self.orig
 
+    @staticmethod
+    def kernel_of(d):
+        """Which kernel csrc/wgrad.hip's fill_args gives this layer (round 5): the row kernel takes the 5x5 stride-2 layers whose pixel grid
+        has rows of a multiple of 64 and >= 100 000 pixels (and HESIC_WGRAD_ROW != 0); everything else one tap per block."""
+        qh, qw = (d.H, d.W) if d.transposed else (d.Ho, d.Wo)
+        row = (os.environ.get("HESIC_WGRAD_ROW", "1") != "0" and d.KH == 5 and d.KW == 5 and d.stride == 2 and d.pad == 2 and not d.tap_mask_lo
+               and not d.in_abs and qw % 64 == 0 and d.B * qh * qw >= int(os.environ.get("HESIC_WGRAD_ROW_MINQ", "100000")))
+        return "wgrad_row_kernel" if row else "wgrad_tr_kernel"
+
     def summary(self):
         torch.cuda.synchronize()
         n = len(self.rec)
         if not n:
             return None
-        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec) * 1e-3
+        t = sum(e0.elapsed_time(e1) for e0, e1, *_ in self.rec) * 1e-3
         f = sum(r[2] for r in self.rec)
-        return {"launches": n, "avg_us": 1e6 * t / n, "tflops": f / t / 1e12, "flops_per_launch": f / n}
+        by = {}
+        for e0, e1, fl, k in self.rec:
+            b = by.setdefault(k, [0, 0.0, 0.0])
+            b[0] += 1; b[1] += e0.elapsed_time(e1) * 1e-3; b[2] += fl
+        return {"launches": n, "avg_us": 1e6 * t / n, "tflops": f / t / 1e12, "flops_per_launch": f / n,
+                "by_kernel": {k: {"launches": v[0], "avg_us": round(1e6 * v[1] / v[0], 2), "tflops": round(v[2] / v[1] / 1e12, 2),
+                                  "gflop_per_launch": round(v[2] / v[0] / 1e9, 3), "share_of_wgrad_time": round(v[1] / t, 4)} for k, v in by.items()}}
 
 
 def cpu_train_baseline(kind, P_cpu, param_names, size, lmbda, budget_s=15.0):
@@ -701,9 +716,16 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
         s = wm.summary()
     if s and rank == 0:
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype != "f32" else MFMA_F32_PEAK_TFLOPS
-        roof = {"kernel": "wgrad_tr_kernel", "bound": "mfma", "achieved": round(s["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(s["tflops"] / peak, 4), "traffic": None, "launches_per_step": s["launches"] // 2,
-                "avg_launch_us": round(s["avg_us"], 2), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3)}
+        # the dominant kernel of the step by time is the weight-gradient family; since round 5 it has two members -- the line's figure is
+        # the one with the larger share of the family's time, `wgrad_kernels` gives both (launch counts are per metering pass of 2 steps)
+        byk = s["by_kernel"]
+        top = max(byk, key=lambda k: byk[k]["share_of_wgrad_time"])
+        roof = {"kernel": top, "bound": "mfma", "achieved": byk[top]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": round(byk[top]["tflops"] / peak, 4), "traffic": None, "launches_per_step": byk[top]["launches"] // 2,
+                "avg_launch_us": byk[top]["avg_us"], "gflop_per_launch": byk[top]["gflop_per_launch"],
+                "wgrad_kernels": {k: dict(v, frac=round(v["tflops"] / peak, 4)) for k, v in byk.items()},
+                "wgrad_family": {"achieved": round(s["tflops"], 2), "frac": round(s["tflops"] / peak, 4), "launches_per_step": s["launches"] // 2,
+                                 "avg_launch_us": round(s["avg_us"], 2)}}
     # gradient all-reduce, self-diagnosing (N > 1 on RCCL): ONE eager step whose buckets run synchronously on a communication stream
     # between events -- per-bucket duration, bus bandwidth and the share of the communication hidden under the backward pass
     comm = None
