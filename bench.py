@@ -455,43 +455,28 @@ def secondary_sweep_and_path_a(dev, size=512):
 
 def secondary_train_rccl(dev, size=512, lmbda=0.0067):
     """The graph-replayed training step with a ONE-RANK RCCL process group in the graph (the bucketed all-reduces of config C3 run for real,
-    over no link): what the collectives cost a step before any xGMI hop."""
-    import torch.distributed as dist
-    import hesic_amd
-    from hesic_amd import functional as Fn, models, synthetic
-    from hesic_amd.train import GraphedTrainer
-    out = {}
-    keep = Fn.compute_dtype()
-    made = False
+    over no link): what the collectives cost a step before any xGMI hop.  Runs as a CHILD process with a time limit (``bench.py --mode train``
+    with HESIC_FORCE_COLLECTIVES=1): a collective library that fails to come up on some box must not take the headline line with it."""
+    import subprocess
+    env = dict(os.environ, HESIC_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "12", "--warmup", "6", "--no-cpu-baseline", "--lmbda", str(lmbda), "--size", str(size)]
     try:
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=0, world_size=1)
-            made = True
-        hesic_amd.set_compute_dtype(torch.bfloat16)
-        tnet = models.HSIC()
-        synthetic.fill_state_dict_(tnet.state_dict())
-        tnet = tnet.to(dev).train()
-        tr = GraphedTrainer(tnet, lr=1e-4, aux_lr=1e-3, lmbda=lmbda, force_collectives=True)
-        x1, x2, Hm = (t.to(dev) for t in synthetic.stereo_batch(0, 8, size, size))
-        ms = 1e3 * _timed_loop(lambda i: tr.step(x1, x2, Hm), tr.warmup + 3, 12)
-        out = {"ms_per_step": round(ms, 3), "value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "dtype": "bf16", "world_size": 1,
-               "buckets": len(getattr(tr.main_reducer, "buckets", []) or []), "step": "HIP graph replay with the RCCL all-reduces inside"}
-        tr.main_reducer.close()
-        tr.aux_reducer.close()
-        del tr, tnet
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child exited with {r.returncode}: {(r.stderr or '').strip()[-300:]}"}
+        d = json.loads(lines[-1])
+        comm = d.get("comm") or {}
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "dtype": d.get("dtype", "bf16"), "world_size": 1,
+                "buckets": len(comm.get("buckets", []) or []), "comm_total_ms": comm.get("allreduce_total_ms"), "comm_hidden_frac": comm.get("hidden_under_backward_frac"),
+                "per_bucket": [{"mb": b.get("mb"), "ms": b.get("ms")} for b in (comm.get("buckets") or [])],
+                "step": "HIP graph replay with the RCCL all-reduces inside (child process)"}
+    except subprocess.TimeoutExpired:
+        return {"error": "child process exceeded 240 s"}
     except Exception as e:
-        out["error"] = f"{type(e).__name__}: {e}"
-    finally:
-        if made:
-            try:
-                dist.destroy_process_group()
-            except Exception:
-                pass
-        hesic_amd.set_compute_dtype(torch.bfloat16 if keep == torch.float32 else keep)
-        hesic_amd.set_compute_dtype(keep)
-    return out
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def secondary_block(dev, size=512, lmbda=0.0067):

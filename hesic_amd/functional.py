@@ -174,6 +174,7 @@ def defer_wgrad_finish(on):
         _finish_queue = None
     elif _finish_queue is None and WGRAD_FINISH_BATCH > 0:
         _finish_queue = []
+        _gdn_finish_queue.clear()          # jobs a failed step left behind must not be finished into this one
     return prev
 
 
