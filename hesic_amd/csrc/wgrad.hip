@@ -932,6 +932,7 @@ struct FinishArgs {
     int8_t tap_id[25];
     const float* bias_part; int nb_parts, accumulate_bias;      // bias column sums left by wgrad_tr_kernel: [nb_parts][Cout], summed in order by ONE block
     int ws_layout;                                              // WgArgs::ws_layout of the launch that wrote ws
+    int wide;                                                   // round 5: block = 8 couts x 128 cins x ONE tap, 512-byte row reads (finish_body)
 };
 
 template <typename T>
@@ -950,6 +951,38 @@ __device__ __forceinline__ void finish_body(const FinishArgs& f, const T* __rest
             return;
         }
         colsum_body<T>(dy, db, P, f.Cout, y_ps, y_co, rows_per_block, bid - f.n_red, scratch);
+        return;
+    }
+    if (f.wide) {
+        // One tap, 8 couts, 128 cins per block: a wave instruction reads two whole 512-byte rows of a slice (the narrow form below reads 128-byte
+        // quarters of eight rows: 1 GB of partials per training step at 2.9 TB/s).  The slices are summed in the narrow form's order (two
+        // alternating accumulators over groups of eight) -- the same bits; the four sums of a lane go straight to the PyTorch layout.
+        const int tci = bid % f.tiles_ci; bid /= f.tiles_ci;
+        const int tco = bid % f.tiles_co;
+        const int tl = bid / f.tiles_co;                        // live tap index
+        const int co = tco * 8 + (threadIdx.x >> 5), ci = tci * 128 + (threadIdx.x & 31) * 4;
+        if (co >= f.Cout || ci >= f.Cin) return;
+        const int64_t per_tap = (int64_t)f.Cout * f.Cin;
+        const int64_t n = f.ws_layout ? f.Cin : (int64_t)f.ntaps * per_tap;
+        const float* src = f.ws + (f.ws_layout ? ((int64_t)tl * f.Cout + co) * f.nsplit * f.Cin : (int64_t)tl * per_tap + (int64_t)co * f.Cin) + ci;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        int k = 0;
+        for (; k + 7 < f.nsplit; k += 8) {
+            const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * n), a1 = *(const f32x4*)(src + (int64_t)(k + 1) * n);
+            const f32x4 a2 = *(const f32x4*)(src + (int64_t)(k + 2) * n), a3 = *(const f32x4*)(src + (int64_t)(k + 3) * n);
+            const f32x4 a4 = *(const f32x4*)(src + (int64_t)(k + 4) * n), a5 = *(const f32x4*)(src + (int64_t)(k + 5) * n);
+            const f32x4 a6 = *(const f32x4*)(src + (int64_t)(k + 6) * n), a7 = *(const f32x4*)(src + (int64_t)(k + 7) * n);
+            s0 += a0; s1 += a1; s0 += a2; s1 += a3; s0 += a4; s1 += a5; s0 += a6; s1 += a7;
+        }
+        for (; k < f.nsplit; ++k) s0 += *(const f32x4*)(src + (int64_t)k * n);
+        const f32x4 sv = s0 + s1;
+        const int t = f.tap_id[tl];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ci + e >= f.Cin) break;
+            const int64_t dst = f.transposed ? ((int64_t)(ci + e) * f.Cout + co) * f.T_all + t : ((int64_t)co * f.Cin + ci + e) * f.T_all + t;
+            f.dw[dst] = f.accumulate ? f.dw[dst] + sv[e] : sv[e];
+        }
         return;
     }
     const int tci = bid % f.tiles_ci; bid /= f.tiles_ci;
@@ -2312,6 +2345,24 @@ static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws
     f.transposed = d->transposed; f.accumulate = (accumulate || a.ntaps < T_all) ? 1 : 0;
     f.ws_layout = a.ws_layout;
     memcpy(f.tap_id, a.tap_id, sizeof(f.tap_id));
+    // A/B switch, OFF: HESIC_WGRAD_FINISH_WIDE=1 = blocks of 8 couts x 128 cins x one tap that read whole 512-byte rows and write their four
+    // sums straight to the PyTorch layout.  Measured SLOWER on the training step (same box, alternating: 9.534 / 9.539 ms with it, 9.350 /
+    // 9.352 without): the tap-strided 4-byte writes cost more than the wider reads save -- the 8 x 32 x taps tiles turn a tile round in LDS
+    // and write runs along the destination's fastest index.
+    static const bool wide_on = getenv("HESIC_WGRAD_FINISH_WIDE") && atoi(getenv("HESIC_WGRAD_FINISH_WIDE")) == 1;
+    if (wide_on && (d->Cin & 3) == 0) {
+        f.wide = 1;
+        f.tiles_ci = (d->Cin + 127) / 128; f.tiles_co = (d->Cout + 7) / 8;
+        f.taps_per_group = 1; f.tap_groups = a.ntaps;
+        f.n_red = f.tiles_ci * f.tiles_co * a.ntaps;
+        P = (int64_t)d->B * d->Ho * d->Wo;
+        rpb = P / 256 > 0 ? (P + 255) / 256 : 1;
+        if (with_bias && a.bias_part) {
+            f.bias_part = a.bias_part; f.nb_parts = a.nsplit * a.nb_taps; f.accumulate_bias = accumulate_bias;
+            return 1;
+        }
+        return with_bias ? (int)((P + rpb - 1) / rpb) : 0;
+    }
     f.tiles_ci = (d->Cin + 31) / 32; f.tiles_co = (d->Cout + 7) / 8;
     const int tiles = f.tiles_ci * f.tiles_co;
     int groups = (512 + tiles - 1) / tiles;                      // enough blocks to cover the chip twice
