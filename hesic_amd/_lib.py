@@ -116,6 +116,7 @@ _SIGS = {
     "hesic_ssim_scale": ([_vp, _P(_i64), _vp, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_avgpool2_pad": ([_vp, _P(_i64), _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_shaped": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
+    "hesic_pack_conv_weight_shaped_tr": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weights_batched": ([_vp, _i32, _i32, _vp], _i32),
     "hesic_conv2d_forward": ([_P(ConvDesc), _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_gdn_forward_planar": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp], _i32),

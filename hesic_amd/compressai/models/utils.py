@@ -126,21 +126,21 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def run(self, x, act=L.ACT_NONE):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False), tr_stride=self.stride[0])
         return Fn.conv2d(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                          padding=self.padding[0], transposed=True, act=act, packer=self._packer)
 
     def run_slice(self, x, c_off, act=L.ACT_NONE):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False), tr_stride=self.stride[0])
         return Fn.conv2d_slice(x, c_off, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                padding=self.padding[0], transposed=True, act=act, packer=self._packer)
 
     def run_latent(self, x, act=L.ACT_NONE, want_lo=True):
         self._check()
         if not hasattr(self, "_packer"):
-            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
+            self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False), tr_stride=self.stride[0])
         return Fn.conv2d_latent(x, self.weight, self.bias, kernel_size=self.kernel_size[0], stride=self.stride[0],
                                 padding=self.padding[0], transposed=True, act=act, packer=self._packer, want_lo=want_lo)
 
@@ -148,7 +148,7 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         if Fn.conv2d_gdn_fusable(x, self.weight, gdn.beta.numel(), True):
             self._check()
             if not hasattr(self, "_packer"):
-                self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False))
+                self._packer = Fn.PackedWeight(shaped=getattr(self, "shaped_weights", False), tr_stride=self.stride[0])
             return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
                                  stride=self.stride[0], padding=self.padding[0], transposed=True, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())

@@ -1418,6 +1418,32 @@ __global__ void pack_weight_shaped_kernel(const float* __restrict__ w, h16_t* __
         }
 }
 
+// The same for a ConvTranspose2d weight (Cin, Cout, KH, KW) of stride s (round 5: the synthesis stacks): an output pixel of phase (py, px)
+// sums only the taps with (ky % s, kx % s) = phase over neighbouring INPUT pixels, so the error is fed back inside each phase's tap
+// class (9 / 6 / 6 / 4 taps for 5 x 5, stride 2), serpentine inside the class.  Measured at a trained 31 dB operating point
+// (profiles/scripts/synthesis_precision.py): plain rounding of the four synthesis layers' weights moves the PSNR by +-(2 - 9)e-4 dB per
+// layer -- all of the default mode's residual deviation, against a 1e-3 bar.
+__global__ void pack_weight_shaped_tr_kernel(const float* __restrict__ w, h16_t* __restrict__ wp, int Cout, int Cin, int KH, int KW, int s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (co, ci), ci fastest: coalesced 2-byte stores per tap
+    if (i >= Cout * Cin) return;
+    const int ci = i % Cin, co = i / Cin;
+    const float* src = w + ((int64_t)ci * Cout + co) * KH * KW;
+    for (int cy = 0; cy < s; ++cy)
+        for (int cx = 0; cx < s; ++cx) {
+            const int nx = (KW - cx + s - 1) / s;
+            float e = 0.f;
+            int row = 0;
+            for (int ky = cy; ky < KH; ky += s, ++row)
+                for (int j = 0; j < nx; ++j) {
+                    const int kx = cx + s * ((row & 1) ? nx - 1 - j : j);
+                    const float tgt = src[ky * KW + kx] + e;
+                    const h16_t q = f2h(tgt);
+                    e = tgt - h2f(q);
+                    wp[((int64_t)(ky * KW + kx) * Cout + co) * Cin + ci] = q;
+                }
+        }
+}
+
 // All weight repacks of a training step in ONE launch (an eager step issued 68 of them, ~7 us each).  Block -> job by a
 // search over the jobs' first-block table; a block moves a tile of 8 couts x 32 cins x all taps through LDS so that both
 // sides are wide: the source is read in runs of 32*taps (conv) or 8*taps (transposed conv) consecutive floats, the
@@ -1605,6 +1631,12 @@ extern "C" int hesic_pack_conv_weight_shaped(const float* w, void* wp, int Cout,
     HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (int64_t)Cout * Cin < (1ll << 31), "pack_conv_weight_shaped: bad arguments");
     hipLaunchKernelGGL(pack_weight_shaped_kernel, dim3((unsigned)((Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (h16_t*)wp, Cout, Cin, KH, KW);
     HESIC_LAUNCH_RETURN("pack_conv_weight_shaped");
+}
+
+extern "C" int hesic_pack_conv_weight_shaped_tr(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int stride, void* stream) {
+    HESIC_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && stride >= 1 && (int64_t)Cout * Cin < (1ll << 31), "pack_conv_weight_shaped_tr: bad arguments");
+    hipLaunchKernelGGL(pack_weight_shaped_tr_kernel, dim3((unsigned)((Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (h16_t*)wp, Cout, Cin, KH, KW, stride);
+    HESIC_LAUNCH_RETURN("pack_conv_weight_shaped_tr");
 }
 
 extern "C" int hesic_pack_conv_weights_batched(const hesic_pack_job* jobs_device, int n_jobs, int total_blocks, void* stream) {

@@ -348,11 +348,12 @@ class PackedWeight:
     ``train_pack_cache(True)`` (the Trainer's step) the packed buffer is persistent, registered for ``repack_all()`` and
     reused while its (storage, version, epoch) tag is current."""
 
-    def __init__(self, shaped=False):
+    def __init__(self, shaped=False, tr_stride=0):
         self._cache = {}
         # ``shaped``: at 16-bit INFERENCE a Conv2d weight is rounded with error feedback over the taps of each (cout, cin) pair
-        # (``hesic_pack_conv_weight_shaped``) -- for layers whose input is a spatially smooth feature map (g_a_conv2..4)
-        self.shaped = shaped
+        # (``hesic_pack_conv_weight_shaped``) -- for layers whose input is a spatially smooth feature map (g_a_conv2..4); a ConvTranspose2d
+        # weight (``tr_stride`` = its stride; round 5: the synthesis stacks) inside each output phase's tap class
+        self.shaped, self.tr_stride = shaped, int(tr_stride)
 
     def get(self, weight, mask, cout, cin, kh, kw, transposed, flip, dtype):
         # autograd.Function bodies run with grad mode off, so a training step also takes the cached branch (one repack
@@ -398,6 +399,9 @@ class PackedWeight:
         if (self.shaped and SHAPED_WEIGHTS and caching and not _train_pack_cache and dtype != torch.float32 and mask is None and not transposed
                 and not flip and kh * kw > 1 and weight.dtype == torch.float32 and weight.is_contiguous()):
             L.call("hesic_pack_conv_weight_shaped", L.ptr(weight.detach()), L.ptr(wp), cout, cin, kh, kw, L.stream())
+        elif (self.shaped and self.tr_stride and SHAPED_WEIGHTS and caching and not _train_pack_cache and dtype != torch.float32 and mask is None
+                and transposed and not flip and kh * kw > 1 and weight.dtype == torch.float32 and weight.is_contiguous()):
+            L.call("hesic_pack_conv_weight_shaped_tr", L.ptr(weight.detach()), L.ptr(wp), cout, cin, kh, kw, self.tr_stride, L.stream())
         else:
             L.call("hesic_pack_conv_weight", L.ptr(weight.detach()), L.ptr(mask), L.ptr(wp), cout, cin, kh, kw,
                    int(transposed), int(flip), L.dt(dtype), L.stream())
@@ -419,6 +423,12 @@ def _weight_image(kind, weight, gp=None, gtag=None):
     hit = _img_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is weight:
         return hit[1]
+    if kind == 1 and SHAPED_WEIGHTS and not torch.is_grad_enabled() and not _train_pack_cache:
+        kind = 2          # inference: g_s_conv4's panel rounded with error feedback per output phase (csrc/sconv.hip, round 5)
+        key = (kind, weight.data_ptr())
+        hit = _img_cache.get(key)
+        if hit is not None and hit[0] == tag and hit[2]() is weight:
+            return hit[1]
     img = torch.empty(65536 if kind == 0 else 24576, dtype=torch.uint8, device=weight.device)
     L.call("hesic_sconv_pack_weight_image", kind, L.ptr(_c(weight)), L.ptr(gp), L.ptr(img), L.stream())
     if len(_img_cache) > 64:

@@ -396,6 +396,12 @@ class Decoder1(nn.Module):
         self.g_s_conv2, self.g_s_gdn2 = deconv(N, N), GDN(N, inverse=True)
         self.g_s_conv3, self.g_s_gdn3 = deconv(N, N), GDN(N, inverse=True)
         self.g_s_conv4 = deconv(N, 3)
+        # round 5: at 16-bit inference the weights of the layers whose input is a spatially smooth IGDN output are rounded with error feedback
+        # inside each output phase's tap class (Fn.PackedWeight(shaped=True, tr_stride=2); g_s_conv4's LDS panel likewise, Fn._weight_image) --
+        # their plain rounding was the default mode's whole residual PSNR deviation at a trained point.  g_s_conv1 reads the integer latents
+        # (not smooth: error feedback would cost sqrt(2) there) and keeps plain rounding.
+        for c in (self.g_s_conv2, self.g_s_conv3):
+            c.shaped_weights = True
 
     def stack(self, y):
         y = self.g_s_conv1.run_gdn(y, self.g_s_gdn1)        # deconv + IGDN in one kernel at inference

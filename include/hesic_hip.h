@@ -68,6 +68,10 @@ int hesic_pack_conv_weight(const float* w, const float* mask, void* w_packed, in
  * weights' sum within half an ulp, so on spatially smooth feature maps the weight-rounding error of the layer's output cancels
  * ("x3c2").  A drop-in for hesic_pack_conv_weight(w, NULL, wp, ..., 0, 0, HESIC_H16): same buffer, same consumers.        */
 int hesic_pack_conv_weight_shaped(const float* w, void* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+/* Round 5: the same for a ConvTranspose2d weight (Cin, Cout, KH, KW) of the given stride: the error is fed back inside each output
+ * phase's tap class ((ky % stride, kx % stride)), the taps one output pixel actually sums (the synthesis stacks, deconv() of
+ * compressai/models/utils.py:112-118, at 16-bit inference).  Same [tap][Cout][Cin] layout as hesic_pack_conv_weight(transposed = 1). */
+int hesic_pack_conv_weight_shaped_tr(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int stride, void* stream);
 
 /* Many repacks in one launch (a training step repacks every conv weight after the optimiser update): `jobs_device` is a
  * DEVICE array of n_jobs descriptors, job i owns blocks [block0_i, block0_{i+1}), one per tile of 8 couts x 32 cins
@@ -276,6 +280,7 @@ int hesic_sconv2d_gdn_forward_train(const hesic_sconv_desc* d, const void* x, co
  * hesic_sconv_pack_weight_image builds it ONCE per weight update and the *_prepacked forms start with a straight copy.
  *   kind 0: g_a_conv1 + GDN (3 -> 128, 5x5 s2): image = 65536 bytes, needs gamma_packed (hesic_gdn_pack_params)
  *   kind 1: g_s_conv4 (128 -> 3 transposed, 5x5 s2): image = 24576 bytes, gamma_packed ignored
+ *   kind 2: as kind 1 with error-feedback rounding over the taps of each output phase (16-bit inference; round 5)
  * w is still passed (other geometries fall back to the ordinary kernels, which read it).                              */
 int hesic_sconv_pack_weight_image(int kind, const float* w, const void* gamma_packed, void* image, void* stream);
 int hesic_sconv2d_forward_prepacked(const hesic_sconv_desc* d, const void* x, const float* w, const void* w_image, const float* bias,

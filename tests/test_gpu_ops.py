@@ -291,7 +291,11 @@ def test_image_side_convs(dtype):
         wt = rnd("ic_wt", (128, 3, 5, 5)) * 0.05
         bt = rnd("ic_bt", (3,), -0.1, 0.1)
         fi = bf(f) if dtype == torch.bfloat16 else f
-        yt = Fn.conv2d(fi.to(DEV, dtype), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        keep_sh, Fn.SHAPED_WEIGHTS = Fn.SHAPED_WEIGHTS, False      # the kernel's arithmetic against round-to-nearest weights (the error-feedback panel: test below)
+        try:
+            yt = Fn.conv2d(fi.to(DEV, dtype), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        finally:
+            Fn.SHAPED_WEIGHTS = keep_sh
         assert yt.dtype == torch.float32 and yt.shape == (2, 3, 32, 48)
         assert rel_err(yt, O.deconv(fi, r(wt), bt, 2)) < 1e-4
         x6 = rnd("ic_x6", (2, 6, 16, 16), 0, 1)
@@ -696,8 +700,12 @@ def test_wide_to_narrow_deconv_shapes(hw):
         f = bf(rnd(f"w2n_f{hw}", (2, 128) + hw))
         wt = rnd("w2n_w", (128, 3, 5, 5)) * 0.05
         bt = rnd("w2n_b", (3,), -0.1, 0.1)
-        with torch.no_grad():
-            y = Fn.conv2d(f.to(DEV, torch.bfloat16), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        keep_sh, Fn.SHAPED_WEIGHTS = Fn.SHAPED_WEIGHTS, False      # round-to-nearest weights, like the oracle call below
+        try:
+            with torch.no_grad():
+                y = Fn.conv2d(f.to(DEV, torch.bfloat16), wt.to(DEV), bt.to(DEV), kernel_size=5, stride=2, padding=2, transposed=True)
+        finally:
+            Fn.SHAPED_WEIGHTS = keep_sh
         ref = O.deconv(f, bf(wt), bt, 2)
         assert y.shape == ref.shape and y.dtype == torch.float32
         # the MFMA kernel multiplies bf16-rounded weights exactly like the oracle call; a 1x1 map (ambiguous NHWC strides) takes
@@ -1099,3 +1107,44 @@ def test_gdn_packs_of_a_training_step_are_refreshed_in_one_launch():
         Fn.train_pack_cache(prev)
         Fn._gdn_registry[:] = [g for g in Fn._gdn_registry if g not in [x.packer() for x in gdns]]
         hesic_amd.set_compute_dtype(prev_dt)
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_synthesis_weights_rounded_with_error_feedback_per_output_phase(fmt):
+    """Round 5: at 16-bit inference the weights of g_s_conv2 / g_s_conv3 (``hesic_pack_conv_weight_shaped_tr``) and g_s_conv4's LDS panel
+    (``hesic_sconv_pack_weight_image`` kind 2) are rounded with error feedback inside each output phase's tap class.  On a spatially SMOOTH
+    input (what an IGDN output is) the result is closer to the transposed conv with the fp32 weights than with round-to-nearest weights, by
+    at least 2x in rms; with the switch off the kernels reproduce the round-to-nearest oracle call as before."""
+    Fn, O = _imp()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[fmt]
+    Fn.set_compute_dtype(dt)
+    try:
+        g = torch.Generator().manual_seed(7)
+        coarse = torch.randn(2, 128, 5, 7, generator=g)
+        f = torch.nn.functional.interpolate(coarse, size=(40, 56), mode="bicubic", align_corners=True)     # smooth over a 5 x 5 window
+        f16 = f.to(dt).float()
+        for cout, name in ((3, "g_s_conv4"), (128, "g_s_conv3")):
+            wt = rnd(f"ef_w{cout}", (128, cout, 5, 5)) * 0.05
+            exact = O.deconv(f16, wt, None, 2)
+            outs = {}
+            for sh in (True, False):
+                keep_sh, Fn.SHAPED_WEIGHTS = Fn.SHAPED_WEIGHTS, sh
+                try:
+                    with torch.no_grad():
+                        if cout == 3:
+                            y = Fn.conv2d(f16.to(DEV, dt), wt.to(DEV), None, kernel_size=5, stride=2, padding=2, transposed=True)
+                        else:
+                            y = Fn.conv2d(f16.to(DEV, dt), wt.to(DEV), None, kernel_size=5, stride=2, padding=2, transposed=True,
+                                          packer=Fn.PackedWeight(shaped=True, tr_stride=2))
+                finally:
+                    Fn.SHAPED_WEIGHTS = keep_sh
+                outs[sh] = (y.float().cpu() - exact).double()
+            # interior pixels (the border sees fewer taps of a class); the 128-channel output is itself stored in 16 bits: compare in fp64 rms
+            e_ef, e_rn = (float(outs[k][..., 4:-4, 4:-4].pow(2).mean().sqrt()) for k in (True, False))
+            print(name, fmt, "rms error vs fp32 weights: error feedback %.3g, round to nearest %.3g" % (e_ef, e_rn))
+            if cout == 3:
+                assert e_ef < 0.5 * e_rn, (name, e_ef, e_rn)
+            else:
+                assert e_ef < e_rn, (name, e_ef, e_rn)          # the 16-bit output rounding is a floor under both
+    finally:
+        Fn.set_compute_dtype(torch.float32)
