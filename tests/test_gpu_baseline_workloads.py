@@ -298,7 +298,7 @@ def test_trained_30db_operating_point_parity_at_512(kind):
     """Parity at an operating point like the published ones (Readme.md:33-46: 33 - 37 dB): graph-replayed training steps (bf16, B=8,
     256 x 256 PIECEWISE-SMOOTH synthetic pairs, ``synthetic.smooth_stereo_pair``; lambda 0.02, the reference's lr 1e-4, newtrain1.py:180-185)
     take the deterministic init to >= 30 dB (checked every 500 steps from 1500 on, at most 5000: the loss of this unclipped recipe spikes now
-    and then, as the reference's would); then the 16-bit inference modes against the fp32 CPU oracle run on THOSE weights on a SET of two
+    and then, as the reference's would); then the 16-bit inference modes against the fp32 CPU oracle run on THOSE weights on a SET of four
     512 x 512 smooth pairs (set averages of bpp and PSNR, as the reference's evaluation reports them; flips = the worst pair).
     The default mode (float16 maps, pair analysis) must hold north_star's bars there: |dbpp| < 1e-3, |dPSNR| < 1e-3 dB, and -- at an MSE of
     ~6e-4 every flipped latent is visible in the PSNR -- <= 1e-4 flipped latents.  The explicit fast mode "x3c2" (round 4's default) is
@@ -315,7 +315,8 @@ def test_trained_30db_operating_point_parity_at_512(kind):
     torch.manual_seed(5)
     tr = GraphedTrainer(net, lr=1e-4, aux_lr=1e-3, lmbda=0.02)
     pool = [tuple(t.to(DEV) for t in synthetic.smooth_stereo_batch(100 + 8 * i, 8, 256, 256)) for i in range(8)]
-    x1, x2, Hm = synthetic.smooth_stereo_batch(0, 2, 512, 512)          # a SET of two pairs: the reference reports set averages (test3real.py:110-122)
+    NP = 4
+    x1, x2, Hm = synthetic.smooth_stereo_batch(0, NP, 512, 512)          # a SET of pairs: the reference reports set averages (test3real.py:110-122)
     xd = tuple(t.to(DEV) for t in (x1, x2, Hm))
     steps, psnr_now = 0, 0.0
     while steps < 5000 and psnr_now < 30.3:
@@ -338,22 +339,23 @@ def test_trained_30db_operating_point_parity_at_512(kind):
     torch.set_num_threads(min(16, torch.get_num_threads()))
     fwd_o = O.hsic_forward if kind == "hsic" else O.hsic_joint_forward
     with torch.no_grad():
-        refs = [fwd_o(P, x1[j:j + 1], x2[j:j + 1], Hm[j:j + 1]) for j in range(2)]
+        refs = [fwd_o(P, x1[j:j + 1], x2[j:j + 1], Hm[j:j + 1]) for j in range(NP)]
     mrs = [O.metrics(r, x1[j:j + 1], x2[j:j + 1]) for j, r in enumerate(refs)]
-    mr = {"bpp": (mrs[0]["bpp"] + mrs[1]["bpp"]) / 2, "psnr": (mrs[0]["psnr"] + mrs[1]["psnr"]) / 2}
+    mr = {"bpp": sum(m["bpp"] for m in mrs) / NP, "psnr": sum(m["psnr"] for m in mrs) / NP}
     assert mr["psnr"] >= 30.0, mrs            # the point of this test
     recs = {}
-    for name, dt, an in (("f16-x3", torch.float16, "auto"), ("f16-x3c2", torch.float16, "x3c2"), ("bf16-x3", torch.bfloat16, "x3")):
+    for name, dt, an in (("f16-x3", torch.float16, "auto"), ("f16-x3c2", torch.float16, "x3c2"), ("bf16-x3", torch.bfloat16, "x3"), ("f32", torch.float32, "auto")):
         hesic_amd.set_compute_dtype(dt)
         Fn.set_analysis_precision(an)
         ms, flips = [], 0.0
-        for j in range(2):
+        for j in range(NP):
             with torch.no_grad():
                 out = net(xd[0][j:j + 1], xd[1][j:j + 1], xd[2][j:j + 1])
                 ms.append(models.metrics_from(models.rate_distortion(out, xd[0][j:j + 1], xd[1][j:j + 1])))
             flips = max(flips, max(float((out[k].float().cpu() != refs[j][k]).float().mean()) for k in ("y1_hat", "y2_hat")))
-        recs[name] = {"dbpp": (ms[0]["bpp"] + ms[1]["bpp"]) / 2 - mr["bpp"], "dpsnr_db": (ms[0]["psnr"] + ms[1]["psnr"]) / 2 - mr["psnr"],
-                      "dpsnr_db_worst_pair": max(abs(ms[j]["psnr"] - mrs[j]["psnr"]) for j in range(2)), "flips": flips, "mode": Fn.analysis_precision()}
+        recs[name] = {"dbpp": sum(m["bpp"] for m in ms) / NP - mr["bpp"], "dpsnr_db": sum(m["psnr"] for m in ms) / NP - mr["psnr"],
+                      "dpsnr_db_worst_pair": max(abs(ms[j]["psnr"] - mrs[j]["psnr"]) for j in range(NP)), "flips": flips,
+                      "mode": Fn.analysis_precision() if dt != torch.float32 else "fp32"}
     print("%s trained smooth point after %d steps: bpp %.4f, PSNR %.3f dB (oracle);" % (kind, steps, mr["bpp"], mr["psnr"]),
           {k: {kk: (float("%.3g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in recs.items()})
     r = recs["f16-x3"]
@@ -361,6 +363,10 @@ def test_trained_30db_operating_point_parity_at_512(kind):
     assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 1e-3 and r["flips"] <= 1e-4, ("f16-x3 (default)", r)
     # the non-default modes are MEASURED here (the printed record is the point); their bars only catch a broken path: training is not
     # bit-reproducible, and over the round's runs x3c2 showed 2.6 - 8.1e-4 flips / up to 6.3e-3 dB, bf16 pairs up to 6.6e-4 bpp / 8e-3 dB
+    # fp32 storage (exact-fp32 MFMA): what is left there is the summation order alone -- a handful of latents at a rounding tie; each of
+    # them moves a pair's PSNR by ~1e-4 dB at this MSE, the floor under every 16-bit figure above
+    r = recs["f32"]
+    assert abs(r["dbpp"]) < 1e-3 and abs(r["dpsnr_db"]) < 1e-3 and r["flips"] <= 1e-4, ("f32", r)
     for name in ("f16-x3c2", "bf16-x3"):
         r = recs[name]
         assert abs(r["dbpp"]) < 2e-3 and abs(r["dpsnr_db"]) < 2e-2 and r["flips"] <= 2e-3, (name, r)
