@@ -122,3 +122,53 @@ def test_trainer_step_is_the_same_with_and_without_the_batched_finish():
     # parameters after the first Adam step move by lr * g / (|g| + eps): compared where the gradient is not within rounding of zero
     big = g1.abs() > 1e-4 * float(g1.abs().max())
     assert float((p0 - p1)[big].abs().max()) <= 1e-5 * float(p1.abs().max())
+
+
+def test_batched_gdn_param_finish_equals_the_per_layer_backward():
+    """hesic_gdn_backward_partial + ONE hesic_gdn_param_finish_batched call for several GDN / IGDN backwards (round 5: what a Trainer step
+    issues) against hesic_gdn_backward_acc per layer: dx, dgamma and dbeta bit for bit (the block partials are summed in the same order),
+    accumulating into slots that already hold a value; two jobs on one gradient in one call are refused."""
+    import hesic_amd
+    from hesic_amd import _lib as L
+    hesic_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        st = L.stream()
+        cases = [(2, 24, 40, False), (1, 64, 64, True), (3, 16, 16, False)]
+        ref, bat, keep = [], [], []
+        for i, (B, H, W, inv) in enumerate(cases):
+            P = B * H * W
+            x = rnd(f"gx{i}", (B, 128, H, W), -2, 2).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gy = rnd(f"gg{i}", (B, 128, H, W)).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            beta = rnd(f"gb{i}", (128,), 0.5, 1.5).to(DEV)
+            gamma = (rnd(f"gm{i}", (128, 128), 0.0, 0.02) + 0.1 * torch.eye(128)).to(DEV)
+            assert L.lib().hesic_gdn_backward_partial_ok(P, 128, L.BF16) == 1
+            nws = int(L.lib().hesic_gdn_backward_ws_bytes(P, 128))
+            out = []
+            for mode in ("ref", "bat"):
+                ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+                dx = torch.empty_like(x)
+                dg = torch.full((128, 128), 0.25, device=DEV)
+                db = torch.full((128,), -0.5, device=DEV)
+                if mode == "ref":
+                    L.call("hesic_gdn_backward_acc", L.ptr(x), L.ptr(gy), L.ptr(beta), L.ptr(gamma), L.ptr(dx), L.ptr(db), L.ptr(dg), 1, L.ptr(ws), P, 128,
+                           int(inv), 1e-6, L.BF16, st)
+                else:
+                    L.call("hesic_gdn_backward_partial", L.ptr(x), L.ptr(gy), L.ptr(beta), L.ptr(gamma), L.ptr(dx), L.ptr(ws), P, 128, int(inv), 1e-6, L.BF16, st)
+                out.append((dx, dg, db, ws, beta, gamma, P))
+            ref.append(out[0]); bat.append(out[1])
+        n = len(cases)
+        vp, i64, f32 = C.c_void_p * n, C.c_int64 * n, C.c_float * n
+        L.call("hesic_gdn_param_finish_batched", n, vp(*[b[3].data_ptr() for b in bat]), i64(*[b[6] for b in bat]), vp(*[b[4].data_ptr() for b in bat]),
+               vp(*[b[5].data_ptr() for b in bat]), vp(*[b[1].data_ptr() for b in bat]), vp(*[b[2].data_ptr() for b in bat]), f32(*[1e-6] * n), 1, st)
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert torch.equal(ref[i][0], bat[i][0]), f"case {i}: dx"
+            assert torch.equal(ref[i][1], bat[i][1]), f"case {i}: dgamma"
+            assert torch.equal(ref[i][2], bat[i][2]), f"case {i}: dbeta"
+            assert float((ref[i][1] - 0.25).abs().max()) > 1e-4
+        with pytest.raises(RuntimeError, match="same gradient"):
+            L.call("hesic_gdn_param_finish_batched", 2, vp(bat[0][3].data_ptr(), bat[0][3].data_ptr(), None), i64(bat[0][6], bat[0][6], 0),
+                   vp(bat[0][4].data_ptr(), bat[0][4].data_ptr(), None), vp(bat[0][5].data_ptr(), bat[0][5].data_ptr(), None),
+                   vp(bat[0][1].data_ptr(), bat[0][1].data_ptr(), None), vp(bat[0][2].data_ptr(), bat[0][2].data_ptr(), None), f32(1e-6, 1e-6, 0), 1, st)
+    finally:
+        hesic_amd.set_compute_dtype(torch.float32)
