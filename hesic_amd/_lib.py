@@ -174,6 +174,7 @@ _SIGS = {
     "hesic_softmax_k_backward": ([_vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_sum_log2": ([_vp, _i64, _vp, _vp], _i32),
     "hesic_sum_sq_diff": ([_vp, _i32, _P(_i64), _vp, _i32, _P(_i64), _i32, _i32, _i32, _i32, _vp, _vp], _i32),
+    "hesic_rd_sums": ([_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
     "hesic_log_backward": ([_vp, _f32, _vp, _i64, _vp], _i32),
     "hesic_sq_diff_backward": ([_vp, _i32, _P(_i64), _vp, _i32, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "hesic_act_backward": ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),

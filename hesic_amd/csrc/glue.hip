@@ -312,10 +312,9 @@ __global__ void softmax_k_bwd_kernel(const float* __restrict__ w, const float* _
     for (int k = 0; k < K; ++k) dl[o + k * M] = w[o + k * M] * (g[o + k * M] - dot);
 }
 
-__global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__ lik, int64_t n, double* __restrict__ out) {
-    __shared__ double red[4];
+__device__ __forceinline__ void sum_log2_body(const float* __restrict__ lik, int64_t n, double* __restrict__ out, int bid, int nb, double* red) {
     double acc = 0.0;
-    const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gt = bid * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)nb * blockDim.x;
     const int64_t n4 = (((uintptr_t)lik & 15) == 0) ? (n >> 2) : 0;           // 16-byte lanes when the tensor allows it
     for (int64_t i = gt; i < n4; i += stride) {
         const f32x4 v = ((const f32x4*)lik)[i];
@@ -327,14 +326,17 @@ __global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
+__global__ __launch_bounds__(256) void sum_log2_kernel(const float* __restrict__ lik, int64_t n, double* __restrict__ out) {
+    __shared__ double red[4];
+    sum_log2_body(lik, n, out, (int)blockIdx.x, (int)gridDim.x, red);
+}
 
 struct SqArgs {
     const void* a; const void* b; int a_dt, b_dt; int64_t as[4], bs[4]; int B, C, H, W; double* out;
 };
-__global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
+__device__ __forceinline__ void sum_sq_diff_body(const SqArgs& q, int bid, int nb, double* red) {
     // one pixel per thread and iteration (all C channels of it): the index split is 32-bit and done once per pixel, and
     // both an NCHW and an NHWC operand are read with at most a C-element stride between neighbouring lanes
-    __shared__ double red[4];
     const int64_t npix = (int64_t)q.B * q.H * q.W;
     double acc = 0.0;
     auto offsets = [&](int64_t p, int64_t& oa, int64_t& ob) {
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
         oa = b * q.as[0] + y * q.as[2] + x * q.as[3];
         ob = b * q.bs[0] + y * q.bs[2] + x * q.bs[3];
     };
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)nb * blockDim.x;
+    int64_t p = bid * (int64_t)blockDim.x + threadIdx.x;
     if (q.C == 3) {
         // the image case: 4 pixels x 3 channels x 2 operands = 24 independent loads in flight per lane
         for (; p + 3 * stride < npix; p += 4 * stride) {
@@ -388,6 +390,28 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(q.out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
+    __shared__ double red[4];
+    sum_sq_diff_body(q, (int)blockIdx.x, (int)gridDim.x, red);
+}
+
+// The bits / squared-error reductions of one forward in ONE launch (round 5: four sum_log2 + two sum_sq_diff launches before, 66 us per step
+// on the metrics stream): block -> job by a scan of <= 8 first-block indices; the bodies are the single-job kernels' (same sums, same order
+// per job for a given block count).  *first zero: block 0 of every job does NOT clear its accumulator -- the caller's zero-fill stays.
+struct RdBatch {
+    int n; int start[9];
+    const float* lik[8]; int64_t numel[8]; double* lik_out[8];
+    int nsq; SqArgs sq[2];
+};
+__global__ __launch_bounds__(256) void rd_sums_kernel(const RdBatch b) {
+    __shared__ double red[4];
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
+    const int bid = (int)blockIdx.x - b.start[j], nb = b.start[j + 1] - b.start[j];
+    const int nl = b.n - b.nsq;
+    if (j < nl) sum_log2_body(b.lik[j], b.numel[j], b.lik_out[j], bid, nb, red);
+    else sum_sq_diff_body(b.sq[j - nl], bid, nb, red);
 }
 
 __global__ void log_bwd_kernel(const float* __restrict__ lik, float scale, float* __restrict__ g, int64_t n) {
@@ -706,6 +730,36 @@ extern "C" int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_str
     // few blocks: every block ends in one fp64 atomic on the same address, and those serialise in L2
     hipLaunchKernelGGL(sum_sq_diff_kernel, dim3(grid_for((int64_t)B * H * W, 256 * 4, 512)), dim3(256), 0, (hipStream_t)stream, q);
     HESIC_LAUNCH_RETURN("sum_sq_diff");
+}
+
+extern "C" int hesic_rd_sums(int n_lik, const float* const* lik, const int64_t* numel, double* const* lik_out, int n_sq, const void* const* a,
+                             const int* a_dtype, const int64_t* a_strides, const void* const* b, const int* b_dtype, const int64_t* b_strides,
+                             const int* dims, double* const* sq_out, void* stream) {
+    HESIC_CHECK_ARG(n_lik >= 0 && n_lik <= 8 && n_sq >= 0 && n_sq <= 2 && n_lik + n_sq > 0, "rd_sums: at most 8 likelihood maps and 2 image pairs");
+    HESIC_CHECK_ARG((n_lik == 0 || (lik && numel && lik_out)) && (n_sq == 0 || (a && b && a_dtype && b_dtype && a_strides && b_strides && dims && sq_out)), "rd_sums: null pointer");
+    RdBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    static const int max_blocks = getenv("HESIC_SUM_LOG2_BLOCKS") ? atoi(getenv("HESIC_SUM_LOG2_BLOCKS")) : 128;
+    int blk = 0;
+    for (int i = 0; i < n_lik; ++i) {
+        HESIC_CHECK_ARG(lik[i] && lik_out[i] && numel[i] > 0, "rd_sums: likelihood map %d: bad arguments", i);
+        rb.lik[i] = lik[i]; rb.numel[i] = numel[i]; rb.lik_out[i] = lik_out[i];
+        rb.start[i] = blk;
+        blk += grid_for(numel[i] / 4 + 1, 256, max_blocks < 1 ? 1 : max_blocks);
+    }
+    for (int i = 0; i < n_sq; ++i) {
+        HESIC_CHECK_ARG(a[i] && b[i] && sq_out[i] && dims[4 * i] > 0 && dims[4 * i + 1] > 0 && dims[4 * i + 2] > 0 && dims[4 * i + 3] > 0, "rd_sums: image pair %d: bad arguments", i);
+        SqArgs& q = rb.sq[i];
+        q.a = a[i]; q.b = b[i]; q.a_dt = a_dtype[i]; q.b_dt = b_dtype[i]; q.B = dims[4 * i]; q.C = dims[4 * i + 1]; q.H = dims[4 * i + 2]; q.W = dims[4 * i + 3];
+        q.out = sq_out[i];
+        for (int k = 0; k < 4; ++k) { q.as[k] = a_strides[4 * i + k]; q.bs[k] = b_strides[4 * i + k]; }
+        rb.start[n_lik + i] = blk;
+        blk += grid_for((int64_t)q.B * q.H * q.W, 256 * 4, 512);
+    }
+    rb.n = n_lik + n_sq; rb.nsq = n_sq;
+    rb.start[rb.n] = blk;
+    hipLaunchKernelGGL(rd_sums_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, rb);
+    HESIC_LAUNCH_RETURN("rd_sums");
 }
 
 extern "C" int hesic_log_backward(const float* lik, float scale, float* g_lik, int64_t n, void* stream) {

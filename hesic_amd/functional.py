@@ -2049,6 +2049,9 @@ def mix_weights(pooled, weight, bias, K, M):
 
 
 # ----------------------------------------------------------------------------- reductions
+RD_SUMS_FUSED = _os.environ.get("HESIC_RD_SUMS_FUSED", "1") != "0"       # A/B switch: 0 = one launch per likelihood map / image pair (rounds 1-4)
+
+
 def sum_log2(lik, out=None):
     """sum(log2(lik)) as an fp64 device scalar (bits = -sum)."""
     L.require_cuda(lik)
@@ -2070,6 +2073,22 @@ def sum_sq_diff(a, b, out=None):
     return out
 
 
+def rd_sums(liks, lik_outs, pairs, sq_outs):
+    """sum(log2(lik_i)) into ``lik_outs[i]`` and sum((a - b)^2) of the image pairs into ``sq_outs[i]`` -- every reduction behind one forward's
+    bpp / PSNR in ONE launch (``hesic_rd_sums``; four + two launches before).  The accumulators are added to (zero-fill them first)."""
+    L.require_cuda(*liks, *[t for p in pairs for t in p])
+    liks = [l if (l.is_contiguous() or l.is_contiguous(memory_format=_CL)) else l.contiguous() for l in liks]
+    nl, ns = len(liks), len(pairs)
+    vpl, i64l = C.c_void_p * max(nl, 1), C.c_int64 * max(nl, 1)
+    vps, i32s, i64s, i32d = C.c_void_p * max(ns, 1), C.c_int32 * max(ns, 1), C.c_int64 * (4 * max(ns, 1)), C.c_int32 * (4 * max(ns, 1))
+    sa, sb, dims = [], [], []
+    for a, b in pairs:
+        sa += list(a.stride()); sb += list(b.stride()); dims += list(a.shape)
+    L.call("hesic_rd_sums", nl, vpl(*[l.data_ptr() for l in liks]), i64l(*[l.numel() for l in liks]), vpl(*[o.data_ptr() for o in lik_outs]),
+           ns, vps(*[a.data_ptr() for a, _ in pairs]), i32s(*[L.dt(a) for a, _ in pairs]), i64s(*sa), vps(*[b.data_ptr() for _, b in pairs]),
+           i32s(*[L.dt(b) for _, b in pairs]), i64s(*sb), i32d(*dims), vps(*[o.data_ptr() for o in sq_outs]), L.stream())
+
+
 class _RdLossFn(torch.autograd.Function):
     """RateDistortionLoss (ywz/mywork/newtrain1.py:37-56) as two kinds of HIP reductions:
     loss = lmbda*255^2*(MSE1+MSE2) + sum_t sum(log lik_t)/(-ln2 * B*H*W).  Returns (loss, bpp, mse)."""
@@ -2081,10 +2100,13 @@ class _RdLossFn(torch.autograd.Function):
         npix = B * H * W
         acc = _zeros(3, torch.float64, x1.device)
         liks = tuple(l if (l.is_contiguous() or l.is_contiguous(memory_format=_CL)) else l.contiguous() for l in liks)
-        for l in liks:
-            sum_log2(l, acc[0:1])
-        sum_sq_diff(x1_hat, x1, acc[1:2])
-        sum_sq_diff(x2_hat, x2, acc[2:3])
+        if x1.is_cuda and RD_SUMS_FUSED and len(liks) <= 8:
+            rd_sums(liks, [acc[0:1]] * len(liks), [(x1_hat, x1), (x2_hat, x2)], [acc[1:2], acc[2:3]])
+        else:
+            for l in liks:
+                sum_log2(l, acc[0:1])
+            sum_sq_diff(x1_hat, x1, acc[1:2])
+            sum_sq_diff(x2_hat, x2, acc[2:3])
         if x1.is_cuda:
             out3 = torch.empty(3, dtype=torch.float32, device=x1.device)
             L.call("hesic_rd_loss_combine", L.ptr(acc), float(lmbda) * 255.0 ** 2, npix, B * Cc * H * W, L.ptr(out3), L.stream())

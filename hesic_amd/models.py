@@ -1901,7 +1901,12 @@ def rate_distortion(out, x1, x2):
         Fn.sum_sq_diff(out["x2_hat"][..., :h, :w], x2, out=acc[n + 1:n + 2])
         return acc
 
-    _branches(x1, bits_sums, sq_sums)         # six small-grid reductions: the two families side by side (disjoint accumulators)
+    if x1.is_cuda and Fn.RD_SUMS_FUSED and n <= 8:
+        # round 5: all six reductions in ONE launch (hesic_rd_sums)
+        Fn.rd_sums([out["likelihoods"][k] for k in keys], [acc[i:i + 1] for i in range(n)],
+                   [(out["x1_hat"][..., :h, :w], x1), (out["x2_hat"][..., :h, :w], x2)], [acc[n:n + 1], acc[n + 1:n + 2]])
+    else:
+        _branches(x1, bits_sums, sq_sums)         # six small-grid reductions: the two families side by side (disjoint accumulators)
     bits = -acc[:n]
     res = {"bits_" + k: bits[i:i + 1] for i, k in enumerate(keys)}
     res["sse1"], res["sse2"] = acc[n:n + 1], acc[n + 1:n + 2]

@@ -523,6 +523,13 @@ int hesic_rd_loss_combine(const double* acc, double lambda_255sq, int64_t npix, 
 /* out[0] += sum((a-b)^2) with a, b given by element strides over a (B,C,H,W) index space.             */
 int hesic_sum_sq_diff(const void* a, int a_dtype, const int64_t a_strides[4], const void* b, int b_dtype,
                       const int64_t b_strides[4], int B, int C, int H, int W, double* out, void* stream);
+/* Round 5: the reductions behind one forward's bpp / PSNR (newtrain1.py:44-56, test3real.py:69-72) in ONE launch: n_lik <= 8 likelihood
+ * maps (sum log2 into lik_out[i]) and n_sq <= 2 image pairs (sum of squared differences into sq_out[i]; strides / dims as four values per
+ * pair: a_strides[4 i ..], dims = B, C, H, W).  The accumulators are ADDED to (the caller zero-fills them), as by hesic_sum_log2 /
+ * hesic_sum_sq_diff, whose per-job sums this reproduces.                                                                          */
+int hesic_rd_sums(int n_lik, const float* const* lik, const int64_t* numel, double* const* lik_out, int n_sq, const void* const* a,
+                  const int* a_dtype, const int64_t* a_strides, const void* const* b, const int* b_dtype, const int64_t* b_strides,
+                  const int* dims, double* const* sq_out, void* stream);
 
 /* Backward of the two reductions inside the R-D loss (newtrain1.py:44-56):
  *   g_lik[i] = scale / lik[i]                      (d/dlik of scale * sum(ln lik))
