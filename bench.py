@@ -106,7 +106,7 @@ class KernelMeter:
                 import copy
                 dv = copy.copy(d)
                 dv.Cin, dv.x_pix_stride = 2 * d.Cin, max(d.x_pix_stride, 2 * d.Cin)
-            self.rec.append((e0, e1, fl, self.variant(dv, fused) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else "") + (" hilo-gdn-out" if name.endswith("hilo_out") else ""),
+            self.rec.append((e0, e1, fl, self.variant(dv, fused, hilo and not name.endswith("hilo_out")) + (" grouped" if name.endswith("grouped") else "") + (" hilo" if hilo else "") + (" hilo-gdn-out" if name.endswith("hilo_out") else ""),
                              3.0 if hilo else 1.0))
             return rc
         self.L.call = call
@@ -115,10 +115,15 @@ class KernelMeter:
     def __exit__(self, *exc):
         self.L.call = self.orig
 
-    def variant(self, d, fused):
+    def variant(self, d, fused, hilo_pairs=False):
         import ctypes as C
         v = (C.c_int32 * 4)()
         self.orig("hesic_conv2d_variant", C.byref(d), v)
+        # the plan query runs the single-operand tile choice; the pair + GDN launch is promoted to the 256-pixel 8-wave tile when the grid is
+        # large enough (csrc/conv_igemm.hip, HESIC_IGEMM_BM256_HILO, default on since round 5) -- name what actually runs
+        if (hilo_pairs and fused and tuple(v[:3]) == (128, 128, 64) and v[3] == 1 and os.environ.get("HESIC_IGEMM_BM256_HILO", "1") != "0"
+                and not d.transposed and d.B * ((d.Ho * d.Wo + 255) // 256) >= 384):
+            v[0] = 256
         if v[3] == 2:
             return f"igemm_tr4_kernel<{'gdn' if fused else 'plain'}>"
         if v[3]:
