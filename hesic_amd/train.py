@@ -540,6 +540,12 @@ class Stage2Trainer:
 
     def __init__(self, model, enhancer, lr=1e-4, lmbda=1e-2, train_dtype=None):
         self.model, self.enhancer, self.lmbda = model, enhancer, float(lmbda)
+        # training runs in bfloat16 (fp32 exponent range) or fp32: with float16 inference selected the enhancer needs an explicit training
+        # format (with train_dtype=None the first step failed inside an operator instead of here)
+        if train_dtype is None and Fn.compute_dtype() == torch.float16:
+            train_dtype = torch.bfloat16
+        if train_dtype not in (None, torch.bfloat16, torch.float32):
+            raise ValueError("Stage2Trainer: train_dtype is None, torch.bfloat16 or torch.float32 (float16 is an inference format)")
         self.train_dtype = train_dtype
         self.optimizer = MultiTensorAdam(list(enhancer.parameters()), lr=lr) if next(enhancer.parameters()).is_cuda else \
             torch.optim.Adam(enhancer.parameters(), lr=lr)
