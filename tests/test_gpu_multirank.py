@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(port, *flags):
-    env = dict(os.environ, HESIC_DIST_BACKEND="gloo", HESIC_SINGLE_DEVICE="1")
+def _run(port, *flags, env_extra=None):
+    env = dict(os.environ, HESIC_DIST_BACKEND="gloo", HESIC_SINGLE_DEVICE="1", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *flags]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
@@ -29,3 +29,14 @@ def test_two_rank_inference_and_training_bench_lines():
     t = _run(29542, "--mode", "train", "--batch", "2", "--size", "256")
     assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 4 and t["value"] > 0 and t["roofline"]["kernel"] == "wgrad_tr_kernel"
     assert all(v == v for v in t["losses_last_step"].values())    # finite
+
+
+def test_two_rank_training_with_reduce_scatter_all_gather_matches_the_all_reduce():
+    """The same two-rank training run with the gradient buckets summed as reduce-scatter + all-gather (``HESIC_DP_COLLECTIVE=rsag``, round 5):
+    the step's losses equal the all-reduce run's (the first steps see identical parameters; the averaged gradients differ in summation
+    order only)."""
+    a = _run(29543, "--mode", "train", "--batch", "2", "--size", "256", "--eager")
+    b = _run(29544, "--mode", "train", "--batch", "2", "--size", "256", "--eager", env_extra={"HESIC_DP_COLLECTIVE": "rsag"})
+    for k in ("bpp_loss", "mse_loss", "aux_loss"):
+        va, vb = a["losses_last_step"][k], b["losses_last_step"][k]
+        assert va == va and vb == vb and abs(va - vb) <= 2e-3 * abs(va) + 1e-6, (k, va, vb)
