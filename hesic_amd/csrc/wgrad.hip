@@ -1581,24 +1581,35 @@ __global__ __launch_bounds__(256, 2) void sconv_wgrad_nn_kernel(const void* __re
         if (a_dtype == HESIC_H16) stage_a(h16_t{}); else stage_a(float{});
         if (s_dtype == HESIC_H16) stage_s(h16_t{}); else stage_s(float{});
         __syncthreads();
-#pragma unroll 2
-        for (int r = 0; r < TH; ++r) {
-            float av[NA];
+        // Round 5: a lane owns FOUR consecutive pixels of a row (a wave = 4 rows x 64 columns per pass, four passes per tile): the eight S values
+        // its four pixels share across the five kx shifts arrive as two 16-byte reads and feed 20 NA FMAs, where one pixel per lane read five
+        // 4-byte values for 5 NA FMAs -- the loop was bound by LDS instructions (109 / 76 us per launch for 12 us of FMA issue).  The sums
+        // are the same 450; only their association over pixels changes.
+#pragma unroll 1
+        for (int rg = 0; rg < TH / 4; ++rg) {
+            const int r = rg * 4 + (lane >> 4), x0 = (lane & 15) * 4;
+            f32x4 av[NA];
 #pragma unroll
-            for (int a = 0; a < NA; ++a) av[a] = at[(a * TH + r) * TW + lane];
+            for (int a = 0; a < NA; ++a) av[a] = *(const f32x4*)(at + (a * TH + r) * TW + x0);
 #pragma unroll
             for (int i = 0; i < NPW; ++i) {
                 const int p = wave + 4 * i;                       // wave-uniform
                 if (p < NP) {
                     const int is = p / 5, ky = p - is * 5;
-                    const float* sr = st + (is * PH + r + ky) * PW + lane;
-                    float sv[5];
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) sv[k] = sr[k];
+                    const float* sr = st + (is * PH + r + ky) * PW + x0;
+                    const f32x4 s0 = *(const f32x4*)sr, s1 = *(const f32x4*)(sr + 4);
+                    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
 #pragma unroll
-                        for (int k = 0; k < 5; ++k) acc[i][a][k] = fmaf(av[a], sv[k], acc[i][a][k]);
+                        for (int k = 0; k < 5; ++k) {
+                            float t = acc[i][a][k];
+                            t = fmaf(av[a].x, sv[k], t);
+                            t = fmaf(av[a].y, sv[k + 1], t);
+                            t = fmaf(av[a].z, sv[k + 2], t);
+                            t = fmaf(av[a].w, sv[k + 3], t);
+                            acc[i][a][k] = t;
+                        }
                 }
             }
         }
@@ -2406,6 +2417,11 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     hipStream_t st = (hipStream_t)stream;
     a.x = x; a.dy = dy; a.out = (float*)ws;
     const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
+    static const bool wlog = getenv("HESIC_WGRAD_LOG") != nullptr;     // diagnostic: one line per weight-gradient launch (geometry, K slices)
+    if (wlog)
+        fprintf(stderr, "[hesic] wgrad %s B=%d %dx%d Cin=%d -> %dx%d Cout=%d k=%d s=%d taps=%d Q=%lld nsplit=%d chunk=%lld blocks=%lld row=%d\n",
+                d->transposed ? "deconv" : "conv", d->B, d->H, d->W, d->Cin, d->Ho, d->Wo, d->Cout, d->KH, d->stride, a.ntaps, (long long)a.Q, a.nsplit,
+                (long long)a.chunk, (long long)(a.rowk ? 5 * a.co_tiles * a.ci_tiles * a.nsplit : blocks), a.rowk);
     const bool bias_in_tr = setup_bias_part(d, a, ws);               // always (the partial-only call has no dbias, its finishing call does)
     float* zero_me = (dbias && !accumulate && !bias_in_tr) ? dbias : nullptr;       // accumulate: the caller's buffer already holds a value
     bool db_zeroed = false;
