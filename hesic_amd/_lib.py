@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import re
 
 import torch
@@ -281,7 +282,34 @@ def h16_dtype():
     return _h16
 
 
+_tls = threading.local()
+
+
+class call_hook:
+    """``with call_hook(fn):`` -- ``fn(name, args)`` sees every ``call`` the CURRENT THREAD makes inside the block (launch tapes, the
+    segment recorder).  Thread-local: a launch from another thread (a second model, a prefetch or metrics thread) during a recording
+    neither lands on the tape nor marks a segment.  Hooks nest (the inner one runs first)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        hooks = getattr(_tls, "hooks", None)
+        if hooks is None:
+            hooks = _tls.hooks = []
+        hooks.append(self.fn)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.hooks.remove(self.fn)
+        return False
+
+
 def call(name, *args):
+    hooks = getattr(_tls, "hooks", None)
+    if hooks:
+        for h in reversed(hooks):
+            h(name, args)
     rc = getattr(_lib or lib(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib().hesic_last_error().decode()}")

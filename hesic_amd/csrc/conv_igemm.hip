@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
 //     first stage of the next phase waits with a COUNTED vmcnt: the stores drain under the next K loop, not in front of it;
 //   * the per-row DMA offsets do not depend on the phase (same q-tile), only the tap displacement does.
 // Summation order per output value is the one of igemm_glds_kernel (taps in raster order, channel chunk innermost): bit-identical.
+// Ablation builds (profiles/scripts/tr4_ablation.sh; never in the shipped libraries): -DTR4_ABL=<bits>  1: no LDS-DMA instructions, 2: no MFMAs in
+// the K loop (the fragment reads stay), 4: no fragment reads (MFMAs on whatever the registers hold), 8: no epilogue (accumulators kept alive, nothing
+// squared / contracted / stored).  Compile-time, so the K loop stays one basic block in every variant.
+#ifndef TR4_ABL
+#define TR4_ABL 0
+#endif
 template <int GDN>
 __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
     using T = h16_t;
@@ -1117,12 +1123,19 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
+        if constexpr (!(TR4_ABL & 1)) {
 #pragma unroll
-        for (int i = 0; i < XI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, (int)xv[i], (int)sx, 0, 0);
+            for (int i = 0; i < XI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, (int)xv[i], (int)sx, 0, 0);
 #pragma unroll
-        for (int i = 0; i < WI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, (int)wv[i], (int)sw, 0, 0);
+            for (int i = 0; i < WI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, (int)wv[i], (int)sw, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) asm volatile("" ::"v"(xv[i]), "s"(sx), "v"(xs));
+#pragma unroll
+            for (int i = 0; i < WI; ++i) asm volatile("" ::"v"(wv[i]), "s"(sw), "v"(ws));
+        }
         if (++cur_chunk == kchunks) {
             cur_chunk = 0;
             dx -= 1;
@@ -1182,6 +1195,13 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             gbuf ^= 1;
             h16x8 wf[2][MI], xf[2][NI];
             auto ldf = [&](int set, int ks) {
+                if constexpr (TR4_ABL & 4) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(wf[set][i]) : "v"(ws));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) asm volatile("" : "=v"(xf[set][j]) : "v"(xs));
+                    return;
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) wf[set][i] = *(const h16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
 #pragma unroll
@@ -1194,11 +1214,18 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (TR4_ABL & 2) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(wf[ks & 1][i]));
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = mfma_32x32x16_h16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(xf[ks & 1][j]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = mfma_32x32x16_h16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1226,7 +1253,19 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         // ---- epilogue in the buffer of the stage just computed
         unsigned char* eb = smem + (gbuf ^ 1) * STAGE;
         const int ry = ph >> 1, rx = ph & 1;
-        if constexpr (GDN == 0) {
+        if constexpr ((TR4_ABL & 8) != 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+            if constexpr (GDN != 0) asm volatile("" ::"v"(gq[0][0]), "v"(gq[0][7]));
+#pragma unroll
+            for (int k = 0; k < NST; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, yr, (int)OOB, 0, 0);      // keeps the counted vmcnt of the next phase right
+            if (GDN && a.y_pre)
+#pragma unroll
+                for (int k = 0; k < NST; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, yr, (int)OOB, 0, 0);
+            (void)eb; (void)ry; (void)rx;
+        } else if constexpr (GDN == 0) {
             const int act_eff = a.act;
             int fr_ = frow, fh_ = fh;
             asm volatile("" : "+v"(fr_), "+v"(fh_));

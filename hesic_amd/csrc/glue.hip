@@ -928,6 +928,12 @@ static int run_tape(const hesic_tape_call* t, int n, void* stream) {
     for (int i = 0; i < n; ++i) {
         const uint64_t* a = t[i].a;
         int rc;
+        // argument counts of the three entry points (stream left out): a tape packed against another revision of a signature is refused
+        const int want = t[i].fn == HESIC_TAPE_JOINT_STEP ? 19 : t[i].fn == HESIC_TAPE_CONV2D_FORWARD ? 5 : t[i].fn == HESIC_TAPE_CONV2D_FORWARD_F32OUT ? 10 : -1;
+        if (want >= 0 && t[i].nargs != want) {
+            hesic_set_error("joint_decode_groups: tape entry %d (entry point %d) carries %d arguments, %d expected", i, t[i].fn, t[i].nargs, want);
+            return HESIC_EINVAL;
+        }
         switch (t[i].fn) {
         case HESIC_TAPE_JOINT_STEP:
             rc = hesic_joint_step((void*)a[0], (int)a[1], (int)a[2], (int)a[3], (const int32_t*)a[4], (int64_t*)a[5], (int32_t*)a[6], (const int32_t*)a[7],

@@ -23,12 +23,16 @@ def set_compute_dtype(dtype):
     accumulate: training and inference) or torch.float16 (IEEE half operands on the matrix cores at the same rate, 11-bit
     significand: INFERENCE -- the default of ``bench.py``).  A 16-bit choice also selects the library built for that format
     (``_lib.use_h16``); packed-weight caches are dropped when the format changes."""
-    global _compute_dtype
+    global _compute_dtype, _cache_epoch
     if dtype not in (torch.float32, torch.bfloat16, torch.float16):
         raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
     if dtype != torch.float32 and dtype != L.h16_dtype():
         L.use_h16(dtype)
-        invalidate_weight_cache()
+        # A pure library switch moves the FORMAT half of the epoch only: packs whose cache key carries the 16-bit dtype (every conv weight:
+        # PackedWeight) keep one entry per format and hit again when the format comes back -- Stage2Trainer alternates f16 inference with a
+        # bf16 enhancer step and used to repack all frozen HSIC weights twice per step (ADVICE r4).  Caches keyed without the dtype see a
+        # different tag and rebuild, as before.
+        _cache_epoch = (str(dtype), _epoch_n)
     _compute_dtype = dtype
 
 
@@ -251,15 +255,17 @@ def _slot_done(slot):
 
 
 # ------------------------------------------------------------------------------ packing cache
-_cache_epoch = 0
+_epoch_n = 0
+_cache_epoch = (str(L.h16_dtype()), 0)       # (active 16-bit format, invalidation count): compared for equality inside the cache tags
 SHAPED_WEIGHTS = _os.environ.get("HESIC_SHAPED_WEIGHTS", "1") != "0"      # A/B switch for PackedWeight(shaped=True)
 
 
 def invalidate_weight_cache():
     """Forget every packed inference weight (call after changing parameters through an API that does not bump
     the tensor version counter, e.g. a fused optimiser step issued under ``torch.no_grad()`` outside training)."""
-    global _cache_epoch
-    _cache_epoch += 1
+    global _cache_epoch, _epoch_n
+    _epoch_n += 1
+    _cache_epoch = (_cache_epoch[0], _epoch_n)
 
 
 # Training-step pack registry (used by train.Trainer): with ``train_pack_cache(True)`` the packers keep one persistent

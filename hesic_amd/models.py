@@ -24,6 +24,7 @@ RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
 
 # inference runs the two views' independent front ends on two HIP streams (set False for a single-stream schedule)
 import os as _os
+import threading as _threading
 OVERLAP_STREAMS = _os.environ.get("HESIC_NO_OVERLAP") is None
 CAT_FREE_EP = _os.environ.get("HESIC_CAT_EP") is None          # A/B switch (HESIC+): set to go back to torch.cat in front of entropy_parameters
 _side_streams = {}
@@ -73,26 +74,33 @@ def hand_over(tensors, stream):
 # ---- cross-stream synchronisation of the inference schedule.  Every event record / wait of the schedule goes through these three
 # helpers: issued eagerly they are the torch calls; while a ``SegmentedForward`` is being built they cut the streams' work into
 # single-stream SEGMENTS (one HIP graph each) and write the events into its replay plan (see SegmentedForward).
-_seg_rec = None
+_seg_tls = _threading.local()         # .rec: the recorder of a SegmentedForward build on THIS thread (another thread's forward stays eager)
+
+
+def _seg_rec_get():
+    return getattr(_seg_tls, "rec", None)
 
 
 def _ev_record(stream):
-    if _seg_rec is not None:
-        return _seg_rec.record(stream)
+    rec = _seg_rec_get()
+    if rec is not None:
+        return rec.record(stream)
     ev = torch.cuda.Event()
     ev.record(stream)
     return ev
 
 
 def _wait_event(stream, ev):
-    if _seg_rec is not None:
-        return _seg_rec.wait(stream, ev)
+    rec = _seg_rec_get()
+    if rec is not None:
+        return rec.wait(stream, ev)
     stream.wait_event(ev)
 
 
 def _wait_stream(stream, other):
-    if _seg_rec is not None:
-        return _seg_rec.wait(stream, _seg_rec.record(other))
+    rec = _seg_rec_get()
+    if rec is not None:
+        return rec.wait(stream, rec.record(other))
     stream.wait_stream(other)
 
 
@@ -109,9 +117,17 @@ class _SegmentRecorder:
         ent = self.open.pop(st.cuda_stream, None)
         if ent is not None:
             _, g, holder = ent
-            with torch.cuda.stream(st):
+            import warnings
+            with torch.cuda.stream(st), warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
                 g.capture_end()
-            if st.cuda_stream in self.touched:          # an empty capture has no executable graph: its launch entry is dropped
+            # Whether the segment holds work is read off the capture itself: torch warns "The CUDA Graph is empty" when capture_end found no
+            # node (and builds no executable graph).  The count of ``L.call`` launches (``touched``) alone would drop a segment made only of
+            # torch-native kernels (copy_, cat, .float()) and leave its outputs uninitialised; it stays as a cross-check.
+            empty = any("Graph is empty" in str(w.message) for w in caught)
+            if empty and st.cuda_stream in self.touched:
+                raise RuntimeError("SegmentedForward: a segment with recorded launches captured as an empty graph")
+            if not empty:
                 holder.append(g)
             else:
                 self.empty.append(g)                    # destroyed after the build: a graph must not be released while another stream captures
@@ -1340,17 +1356,9 @@ class HSICJoint(StereoCompressionModel):
             g = torch.cuda.CUDAGraph()
             # the launches are also RECORDED while they are captured (entry point + arguments): the graph's private pool keeps every
             # buffer they name alive, so the same launches can be replayed one by one from C (hesic_joint_decode_groups_tape)
-            rec, orig = [], L.call
-
-            def recording_call(name, *a):
-                rec.append((name, a))
-                return orig(name, *a)
-            L.call = recording_call
-            try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    out = self._wavefront_step_body(st, P)
-            finally:
-                L.call = orig
+            rec = []
+            with L.call_hook(lambda name, a: rec.append((name, a))), torch.cuda.graph(g, capture_error_mode="thread_local"):     # this thread's launches only
+                out = self._wavefront_step_body(st, P)
             for k, v in keep.items():
                 st[k].copy_(v)
             n_step = len(rec) - (1 if st["tab_in_graph"] else 0)          # the table launch (if captured) is issued by the walk itself on the tape path
@@ -1698,13 +1706,12 @@ class SegmentedForward:
     buffers, static outputs (overwritten by the next call), bit-identical to the eager forward (tested)."""
 
     def __init__(self, net, x1, x2, h_matrix, with_metrics=False, warmup=3):
-        global _seg_rec
         if net.training:
             raise RuntimeError("SegmentedForward captures the inference schedule: call net.eval() first")
         if with_metrics:
             raise ValueError("SegmentedForward: reduce the metrics behind the replay (models.rate_distortion on the static outputs)")
-        if _seg_rec is not None:
-            raise RuntimeError("SegmentedForward: another build is in progress")
+        if _seg_rec_get() is not None:
+            raise RuntimeError("SegmentedForward: another build is in progress on this thread")
         self.net = net
         self.x1, self.x2, self.h = x1.clone(), x2.clone(), h_matrix.clone()
         dev = x1.device
@@ -1716,17 +1723,9 @@ class SegmentedForward:
                 net(self.x1, self.x2, self.h)
         torch.cuda.synchronize(dev)
         rec = _SegmentRecorder()
-        orig_call = L.call
-
-        def counting_call(name, *args):
-            rec.touch()
-            return orig_call(name, *args)
-        L.call = counting_call
-        _seg_rec = rec
-        import warnings
+        _seg_tls.rec = rec
         try:
-            with torch.no_grad(), torch.cuda.stream(self.main), warnings.catch_warnings():
-                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")       # a stretch with no launches: dropped from the plan
+            with torch.no_grad(), torch.cuda.stream(self.main), L.call_hook(lambda name, a: rec.touch()):      # thread-local: see _lib.call_hook
                 rec._open(self.main)
                 self.out = net(self.x1, self.x2, self.h)
                 self.plan = rec.finish()
@@ -1739,8 +1738,7 @@ class SegmentedForward:
                     pass
             raise
         finally:
-            _seg_rec = None
-            L.call = orig_call
+            _seg_tls.rec = None
         cur.wait_stream(self.main)
         self.n_graphs = sum(1 for e in self.plan if e[0] == "launch")
 

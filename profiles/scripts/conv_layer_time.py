@@ -24,16 +24,18 @@ def main():
     ap.add_argument("--cin", type=int, default=128, help="--layer plain / deconv_plain: input channels")
     ap.add_argument("--cout", type=int, default=128, help="--layer plain / deconv_plain: output channels")
     ap.add_argument("--stride", type=int, default=2, help="--layer plain: stride (kernel 5x5)")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16", help="16-bit storage format = which library is bound")
     ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph (no host launch cost in the figure)")
     args = ap.parse_args()
     import hesic_amd
     from compressai.layers import GDN
     from compressai.models.utils import conv, deconv
-    hesic_amd.set_compute_dtype(torch.bfloat16)
+    h16 = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    hesic_amd.set_compute_dtype(h16)
     torch.manual_seed(0)
     B, S = args.batch, args.size
     ci, co = (args.cin, args.cout) if args.layer in ("plain", "deconv_plain") else (128, 128)
-    x = (torch.randn(B, ci, S, S, device="cuda") * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = (torch.randn(B, ci, S, S, device="cuda") * 0.5).to(h16).contiguous(memory_format=torch.channels_last)
     if args.layer in ("conv2", "conv3", "plain"):
         st = args.stride if args.layer == "plain" else 2
         layer, g = conv(ci, co, stride=st).cuda(), GDN(128).cuda()

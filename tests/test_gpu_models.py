@@ -879,3 +879,32 @@ def test_stage2_trainer_follows_the_reference_steps(dtype, tol_loss, tol_gn):
         # Adam's first steps move every element by ~lr whatever the gradient's size: bf16 gradients flip a few update signs
         assert float(p.detach().double().norm()) == pytest.approx(float(g["pn_" + name]), rel=1e-4 if dtype == torch.float32 else 2e-3), name
     assert not hs.training and all(p.grad is None for p in hs.parameters())          # the compression model stayed frozen
+
+
+def test_stage2_trainer_under_f16_inference_keeps_both_formats_packs():
+    """f16 inference library + bf16 enhancer training (the documented combination): ``Stage2Trainer`` switches the 16-bit format twice per
+    step.  A pure library switch moves only the format half of the pack-cache epoch, so the frozen HSIC weights are packed once per
+    format -- not on every step -- and ``invalidate_weight_cache()`` still drops both."""
+    import hesic_amd
+    from hesic_amd import functional as Fn, models
+    from hesic_amd.train import Stage2Trainer
+    hesic_amd.set_compute_dtype(torch.float16)
+    hs = models.HSIC()
+    synthetic.fill_state_dict_(hs.state_dict())
+    hs = hs.to(DEV)
+    en = models.Independent_EN().to(DEV)
+    tr = Stage2Trainer(hs, en, lr=1e-4, lmbda=0.0067)
+    assert tr.train_dtype == torch.bfloat16
+    x1, x2, Hm = (t.to(DEV) for t in synthetic.stereo_batch(11, 2, 128, 128))
+    c0 = tr.step(x1, x2, Hm)
+    assert Fn.compute_dtype() == torch.float16 and math.isfinite(float(c0["loss"]))
+    packs = {id(v[1]) for m in hs.modules() for v in getattr(getattr(m, "_packer", None), "_cache", {}).values()}
+    assert packs, "no packed conv weights cached after a step"
+    epoch = Fn._cache_epoch
+    c1 = tr.step(x1, x2, Hm)
+    assert Fn._cache_epoch == epoch and Fn.compute_dtype() == torch.float16
+    packs1 = {id(v[1]) for m in hs.modules() for v in getattr(getattr(m, "_packer", None), "_cache", {}).values()}
+    assert packs <= packs1, "a frozen weight was repacked by the format switch"
+    assert float(c1["loss"]) < float(c0["loss"]) * 1.5
+    Fn.invalidate_weight_cache()
+    assert Fn._cache_epoch != epoch and Fn._cache_epoch[0] == epoch[0]

@@ -237,3 +237,36 @@ def test_smooth_synthetic_pairs_are_deterministic_smooth_and_warp_consistent():
     assert np.abs(w - x2)[:, inside].mean() < 0.01
     xb = synthetic.smooth_stereo_batch(3, 2, 96, 128)
     assert tuple(xb[0].shape) == (2, 3, 96, 128) and np.array_equal(xb[0][0].numpy(), x1) and tuple(xb[2].shape) == (2, 3, 3)
+
+
+def test_call_hook_sees_only_the_recording_threads_launches(monkeypatch):
+    """Launch tapes and the segment recorder listen through ``_lib.call_hook``: thread-local, so a launch another thread makes while
+    a recording is open neither lands on the tape nor marks a segment; hooks nest and are removed on exit."""
+    import threading
+    from hesic_amd import _lib as L
+
+    class Stub:
+        def __getattr__(self, name):
+            return lambda *a: 0
+    monkeypatch.setattr(L, "_lib", Stub())
+    seen, inner = [], []
+    started, done = threading.Event(), threading.Event()
+
+    def other():
+        started.wait(5)
+        L.call("from_other_thread", 1)
+        done.set()
+    th = threading.Thread(target=other)
+    th.start()
+    with L.call_hook(lambda name, args: seen.append((name, args))):
+        L.call("a", 1, 2)
+        started.set()
+        assert done.wait(5)
+        with L.call_hook(lambda name, args: inner.append(name)):
+            L.call("b")
+        L.call("c")
+    th.join()
+    L.call("after")
+    assert [n for n, _ in seen] == ["a", "b", "c"] and seen[0][1] == (1, 2)
+    assert inner == ["b"]
+    assert not getattr(L._tls, "hooks")
