@@ -185,6 +185,37 @@ class WgradMeter:
                 ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
                 self.rec.append((e0, e1, conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps), self.kernel_of(d)))
                 return rc
+            if name == "hesic_conv2d_wgrad_partial_batched":
+                # round 5: the split-K launches of a few queued layers in one call.  Row-kernel layers are launched one by one inside it: the
+                # meter issues those itself (one event pair each, as above); the one-tap-per-block layers go down as ONE batched call -- the
+                # shared grid is what the step runs -- under one event pair carrying the sum of their flops ("wgrad_tr_batched_kernel").
+                import ctypes as C
+                m, descs, xs, dys, wss, nbytes, nsp, st = args
+                tr = []
+                for i in range(m):
+                    d = descs[i]
+                    ntaps = bin(d.tap_mask_lo).count("1") if d.tap_mask_lo else None
+                    fl = conv_flops(d.B, d.Ho, d.Wo, d.H, d.W, d.Cin, d.Cout, d.KH, d.transposed, ntaps)
+                    if self.kernel_of(d) == "wgrad_row_kernel":
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        self.orig("hesic_conv2d_wgrad_partial", C.byref(d), C.c_void_p(xs[i]), C.c_void_p(dys[i]), C.c_void_p(wss[i]), nbytes[i], st)
+                        e1.record()
+                        self.rec.append((e0, e1, fl, "wgrad_row_kernel"))
+                    else:
+                        tr.append((i, fl))
+                if tr:
+                    k = len(tr)
+                    vp = C.c_void_p * k
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self.orig(name, k, (type(descs[0]) * k)(*[descs[i] for i, _ in tr]), vp(*[xs[i] for i, _ in tr]), vp(*[dys[i] for i, _ in tr]),
+                              vp(*[wss[i] for i, _ in tr]), (C.c_int64 * k)(*[nbytes[i] for i, _ in tr]),
+                              (C.c_int32 * k)(*[nsp[i] for i, _ in tr]) if nsp is not None else None, st)
+                    e1.record()
+                    self.rec.append((e0, e1, sum(f for _, f in tr), "wgrad_tr_batched_kernel"))
+                    self.batched_layers = getattr(self, "batched_layers", 0) + k
+                return None
             return self.orig(name, *args)
         self.L.call = call
         return self
@@ -716,6 +747,9 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
                 "wgrad_kernels": {k: dict(v, frac=round(v["tflops"] / peak, 4)) for k, v in byk.items()},
                 "wgrad_family": {"achieved": round(s["tflops"], 2), "frac": round(s["tflops"] / peak, 4), "launches_per_step": s["launches"] // 2,
                                  "avg_launch_us": round(s["avg_us"], 2)}}
+        if getattr(wm, "batched_layers", 0) and "wgrad_tr_batched_kernel" in roof["wgrad_kernels"]:
+            # one "launch" of this entry = one hesic_conv2d_wgrad_partial_batched call = the shared grid(s) of several layers
+            roof["wgrad_kernels"]["wgrad_tr_batched_kernel"]["layers_per_step"] = wm.batched_layers // 2
     # gradient all-reduce, self-diagnosing (N > 1 on RCCL): ONE eager step whose buckets run synchronously on a communication stream
     # between events -- per-bucket duration, bus bandwidth and the share of the communication hidden under the backward pass
     comm = None

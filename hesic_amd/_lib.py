@@ -185,6 +185,10 @@ _SIGS = {
     "hesic_conv2d_forward_grouped": ([_P(ConvDesc), _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_slice": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
+    "hesic_conv2d_wgrad_partial_batched": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_i64), _P(_i32), _vp], _i32),
+    "hesic_conv2d_wgrad_nsplit": ([_P(ConvDesc), _i32], _i32),
+    "hesic_conv2d_wgrad_ws_bytes_n": ([_P(ConvDesc), _i32], _i64),
+    "hesic_conv2d_wgrad_finish_batched_n": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i32, _P(_i32), _vp], _i32),
     "hesic_conv2d_wgrad_finish_batched": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i32, _vp], _i32),
     "hesic_gdn_backward_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp], _i32),
     "hesic_gdn_backward_partial_ok": ([_i64, _i32, _i32], _i32),

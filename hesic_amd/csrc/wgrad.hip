@@ -13,6 +13,8 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 
 #include "common.h"
 
@@ -280,18 +282,20 @@ struct WgTrArgs {
 // BK pixels per stage, a ring of NST stages: NST - 1 stages are in flight while one is consumed.  <64, 2> (64 KB, two blocks per CU) is the
 // form of rounds 2-4; <32, 5> (80 KB) keeps twice the bytes in flight per CU for the same two blocks (round 4: the kernel sits parked at
 // its vmcnt / barrier half of its cycles with ONE 32 KB stage per block in flight).
+// hw_bid / nb: this block's hardware id inside its job and the job's block count (the launch's own blockIdx / gridDim for the one-job form;
+// its 8-aligned range of a batched launch, whose surplus ids the caller has already sent home)
 template <int BK, int NST, bool SPREAD = false>
-__global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
+__device__ __forceinline__ void wgrad_tr_body(const WgTrArgs& A, const int hw_bid, const int nb) {
     const WgArgs& a = A.w;
     constexpr int TILE = BK * 256, STAGE = 2 * TILE;       // BK pixels x 128 channels x 2 B per operand
     constexpr int NI = BK / 16;                            // DMA instructions per wave, operand and stage (4 pixel rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (A.zero_me && blockIdx.x == 0)
+    if (A.zero_me && hw_bid == 0)
         for (int i = tid; i < A.zero_n; i += NT) A.zero_me[i] = 0.f;       // the bias gradient's zero-fill rides on this launch (stream order: done before the next one)
     // logical block order: tap fastest, then channel tiles, K slice (pixel range) slowest, on XCD-contiguous ids -- the
     // 25 tap blocks of a pixel range read the same dY rows and overlapping X rows, so they should meet in one L2
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(hw_bid, nb);
     const int tapi = bid % a.ntaps; bid /= a.ntaps;
     const int cit = bid % a.ci_tiles; bid /= a.ci_tiles;
     const int cot = bid % a.co_tiles; bid /= a.co_tiles;
@@ -570,6 +574,36 @@ __global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
             }
         }
 }
+template <int BK, int NST, bool SPREAD = false>
+__global__ __launch_bounds__(NT) void wgrad_tr_kernel(const WgTrArgs A) {
+    wgrad_tr_body<BK, NST, SPREAD>(A, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several layers' split-K launches in ONE grid (hesic_conv2d_wgrad_partial_batched; round 5).  One launch per layer costs each of the ~30
+// 128-channel weight gradients of a training step its own ramp (every block waits for its first stage at the same moment), its own tail (every
+// block writes its 64 KB partial at the same moment) and the idle slots of a 400- or 450-block grid on 512; a layer with 16 stages per
+// block spends ~40 % of its launch there (10 GF in 28 us against 50 GF in 76 us for 64 stages per block).  Here the jobs' block ranges follow
+// each other (8-aligned, so a job's XCD remap sees its own range), longest K slices first: a slot that finishes a block takes the next one,
+// whatever layer it belongs to.  Results are bit-identical to the one-launch-per-layer form (same blocks, same order inside each block).
+constexpr int WB_MAX = 14;                                  // jobs per launch: the argument block stays under the 4 KB of a kernel's arguments
+struct WgTrBatch {
+    int n;
+    int start[WB_MAX + 1];                                  // multiples of 8
+    int blocks[WB_MAX];                                     // real block count of the job (the rest of its range exits)
+    WgTrArgs job[WB_MAX];
+};
+static_assert(sizeof(WgTrBatch) <= 4096, "kernel arguments: 4 KB");
+
+template <int BK, int NST>
+__global__ __launch_bounds__(NT) void wgrad_tr_batched_kernel(const WgTrBatch B) {
+    int j = 0;
+    while (j + 1 < B.n && (int)blockIdx.x >= B.start[j + 1]) ++j;       // uniform: scalar loop over <= 14 entries
+    const int local = (int)blockIdx.x - B.start[j], nb8 = B.start[j + 1] - B.start[j];
+    if (xcd_remap(local, nb8) >= B.blocks[j]) return;
+    // the body reads its job through scalar loads of the argument block; the logical id is recomputed inside from the same (local, nb8)
+    wgrad_tr_body<BK, NST, false>(B.job[j], local, nb8);
+}
+
 
 // ---------------------------------------------------------------- one kernel ROW of taps per block (round 5)
 // wgrad_tr_kernel moves 32 KB of operands through L2 -> LDS for every 16 MFMAs of a wave: on the 128 -> 128 5x5 stride-2 layers of the
@@ -2146,6 +2180,17 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const h16_t* __restrict
     }
 }
 
+static WgTrArgs make_tr_args(const WgArgs& a, float* zero_me, int zero_n) {
+    WgTrArgs A;
+    A.w = a;
+    A.zero_me = zero_me; A.zero_n = zero_n;
+    A.dqw = make_fastdiv((uint32_t)a.QW);
+    A.dqh = make_fastdiv((uint32_t)a.QH);
+    static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
+    A.fastq = (!slow && a.QW % 16 == 0 && a.chunk % 64 == 0) ? 1 : 0;
+    return A;
+}
+
 void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zero_me = nullptr, int zero_n = 0) {
     if (a.rowk) {
         WgRowArgs R;
@@ -2162,13 +2207,7 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zer
         else hipLaunchKernelGGL(wgrad_row_kernel<false>, g, b, ROW_LDS, st, R);
         return;
     }
-    WgTrArgs A;
-    A.w = a;
-    A.zero_me = zero_me; A.zero_n = zero_n;
-    A.dqw = make_fastdiv((uint32_t)a.QW);
-    A.dqh = make_fastdiv((uint32_t)a.QH);
-    static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
-    A.fastq = (!slow && a.QW % 16 == 0 && a.chunk % 64 == 0) ? 1 : 0;
+    const WgTrArgs A = make_tr_args(a, zero_me, zero_n);
     // A/B switch: the stage ring.  0 = <64, 2> (rounds 2-4), 1 = <32, 5>, 2 = <32, 4>, 3 = <64, 3> (96 KB: one block per CU), 4 = <64, 2> with the
     // stage's DMA instructions spread behind the k-steps' MFMAs.  Training step, same box, alternating runs (ms): 0: 9.89 / 9.91 | 1: 11.30 |
     // 2: 11.32 | 3: 12.36 | 4: 10.58 -- more bytes in flight, or cheaper issue slots for the DMA instructions, are not what the loop is short
@@ -2188,7 +2227,7 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zer
     else hipLaunchKernelGGL((wgrad_tr_kernel<64, 2>), g, b, 2 * 64 * 512, st, A);
 }
 
-int pick_splits(int64_t Q, int bk, int tiles) {
+int pick_splits(int64_t Q, int bk, int tiles, bool batched = false) {
     // aim at ~384 blocks (measured best on MI355X for the step as a whole: every extra slice is another fp32 partial tile
     // to write and reduce), at least 4 K-steps per block
     static const int target0 = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
@@ -2199,7 +2238,12 @@ int pick_splits(int64_t Q, int bk, int tiles) {
     static const int big_target = getenv("HESIC_WGRAD_BLOCKS_BIG") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG")) : 500;
     // from which pixel count on (same box, alternating runs, ms): 100000: 10.62 / 10.61 | 30000 (adds the 128 -> 128 layers on 128^2 inputs): 10.57 / 10.59 | 8000: 10.71
     static const int64_t big_q = getenv("HESIC_WGRAD_BIG_Q") ? atoll(getenv("HESIC_WGRAD_BIG_Q")) : 30000;      // A/B switch
-    const int target = (big_target && Q >= big_q) ? big_target : target0;
+    // batched route (hesic_conv2d_wgrad_nsplit(d, 1)): the grid is shared with the other queued layers, so a layer need not fill the 512 block
+    // slots by itself -- fewer slices = fewer fp32 partial tiles to write and reduce.  Training step, same box, alternating runs (ms), small /
+    // large-layer targets: 384 / 500: 9.187 / 9.189 | 256 / 500: 9.140 | 200 / 250: 9.077 / 9.074 | 128 / 250: 9.076 | 100 / 125: 9.308
+    static const int bt_small = getenv("HESIC_WGRAD_BLOCKS_BATCHED") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BATCHED")) : 200;
+    static const int bt_big = getenv("HESIC_WGRAD_BLOCKS_BIG_BATCHED") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG_BATCHED")) : 250;
+    const int target = batched ? (Q >= big_q ? bt_big : bt_small) : ((big_target && Q >= big_q) ? big_target : target0);
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
     if (s > maxs) s = maxs;
@@ -2208,7 +2252,9 @@ int pick_splits(int64_t Q, int bk, int tiles) {
     return (int)s;
 }
 
-int fill_args(const hesic_conv_desc* d, WgArgs& a) {
+// nsplit_override > 0: the caller names the K-slice count of a one-tap-per-block layer (the batched route, whose shared grids want fewer,
+// longer slices than a launch that has to fill the machine by itself); the row kernel keeps its own count
+int fill_args(const hesic_conv_desc* d, WgArgs& a, int nsplit_override = 0) {
     memset(&a, 0, sizeof(a));
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ps = d->y_pix_stride; a.y_co = d->y_c_off;
@@ -2243,7 +2289,7 @@ int fill_args(const hesic_conv_desc* d, WgArgs& a) {
         a.nsplit = (int)((stages + per - 1) / per);
         return 0;
     }
-    a.nsplit = pick_splits(a.Q, bk, n * a.co_tiles * a.ci_tiles);
+    a.nsplit = nsplit_override > 0 ? nsplit_override : pick_splits(a.Q, bk, n * a.co_tiles * a.ci_tiles);
     a.chunk = ((a.Q + a.nsplit - 1) / a.nsplit + bk - 1) / bk * bk;
     a.nsplit = (int)((a.Q + a.chunk - 1) / a.chunk);
     return 0;
@@ -2260,6 +2306,17 @@ static bool wgrad_tr_path(const hesic_conv_desc* d, const WgArgs& a) {
     const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
     return d->dtype == HESIC_H16 && prefix && a.Q < (1ll << 31) && off32;
 }
+extern "C" int hesic_conv2d_wgrad_nsplit(const hesic_conv_desc* d, int batched) {
+    if (!d || d->KH * d->KW > 25) return 0;
+    WgArgs a;
+    fill_args(d, a);
+    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
+    if (a.rowk || !batched || ring != 0 || !wgrad_tr_path(d, a)) return a.nsplit;      // only the shared-grid kernel's layers take another count
+    const int bk = d->dtype == HESIC_H16 ? WC<h16_t>::BK : WC<float>::BK;
+    fill_args(d, a, pick_splits(a.Q, bk, a.ntaps * a.co_tiles * a.ci_tiles, true));
+    return a.nsplit;
+}
+
 // point a.bias_part behind the weight partials in ws and list the taps whose blocks sum dY's columns; false: no such tap set
 static bool setup_bias_part(const hesic_conv_desc* d, WgArgs& a, void* ws) {
     static const bool off = getenv("HESIC_WGRAD_BIAS_COLSUM") != nullptr;      // A/B switch: the separate column-sum blocks of rounds 1-3
@@ -2283,6 +2340,13 @@ extern "C" int64_t hesic_conv2d_wgrad_ws_bytes(const hesic_conv_desc* d) {
     if (!d || d->KH * d->KW > 25) return 0;
     WgArgs a;
     fill_args(d, a);
+    return (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
+}
+
+extern "C" int64_t hesic_conv2d_wgrad_ws_bytes_n(const hesic_conv_desc* d, int nsplit) {
+    if (!d || d->KH * d->KW > 25) return 0;
+    WgArgs a;
+    fill_args(d, a, nsplit);
     return (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
 }
 
@@ -2874,8 +2938,72 @@ extern "C" int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* 
     return rc;
 }
 
+// The split-K launches of n layers (what hesic_conv2d_wgrad_partial does for one), the 128-channel-tile MFMA ones among them sharing grids of
+// up to WB_MAX jobs (wgrad_tr_batched_kernel); layers on another kernel (wgrad_row_kernel, the VALU fallback) are launched one by one.  The
+// partials land in each job's own workspace exactly as hesic_conv2d_wgrad_partial leaves them: hesic_conv2d_wgrad_finish_batched follows.
+extern "C" int hesic_conv2d_wgrad_partial_batched(int n, const hesic_conv_desc* descs, const void* const* x, const void* const* dy, void* const* ws,
+                                                  const int64_t* ws_bytes, const int32_t* nsplit, void* stream) {
+    HESIC_CHECK_ARG(n >= 0 && (n == 0 || (descs && x && dy && ws && ws_bytes)), "conv2d_wgrad_partial_batched: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
+    struct Job { WgArgs a; int64_t blocks; };
+    std::vector<Job> jobs;
+    for (int i = 0; i < n; ++i) {
+        const hesic_conv_desc* d = descs + i;
+        HESIC_CHECK_ARG(x[i] && dy[i] && ws[i], "conv2d_wgrad_partial_batched: job %d: null pointer", i);
+        WgArgs a;
+        bool batched = d->KH * d->KW <= 25 && ring == 0;
+        if (batched) {
+            fill_args(d, a, nsplit ? nsplit[i] : 0);
+            a.ws_layout = direct_ws_layout();
+            batched = wgrad_tr_path(d, a) && !a.rowk;
+        }
+        if (!batched) {
+            // another kernel takes this layer: it picks its own K-slice count, which a caller-named count has to agree with
+            if (nsplit && nsplit[i] > 0) {
+                WgArgs a0;
+                fill_args(d, a0);
+                HESIC_CHECK_ARG(a0.nsplit == nsplit[i], "conv2d_wgrad_partial_batched: job %d: %d K slices named, this layer's kernel takes %d", i, nsplit[i], a0.nsplit);
+            }
+            if (int rc = hesic_conv2d_wgrad_partial(d, x[i], dy[i], ws[i], ws_bytes[i], stream)) return rc;
+            continue;
+        }
+        const int ce = 8;
+        HESIC_CHECK_ARG(d->Cin % ce == 0 && d->Cout % ce == 0 && d->x_pix_stride % ce == 0 && d->y_pix_stride % ce == 0 && d->x_c_off % ce == 0 &&
+                            d->y_c_off % ce == 0, "conv2d_wgrad_partial_batched: job %d: channels must be multiples of %d", i, ce);
+        const int64_t need = (int64_t)a.nsplit * a.ntaps * d->Cout * d->Cin * 4 + bias_part_bytes(d, a);
+        HESIC_CHECK_ARG(ws_bytes[i] >= need, "conv2d_wgrad_partial_batched: job %d: workspace too small (%lld < %lld)", i, (long long)ws_bytes[i], (long long)need);
+        a.x = x[i]; a.dy = dy[i]; a.out = (float*)ws[i];
+        setup_bias_part(d, a, ws[i]);
+        jobs.push_back(Job{a, (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit});
+    }
+    // longest K slices first: the launch ends on its shortest blocks
+    std::stable_sort(jobs.begin(), jobs.end(), [](const Job& p, const Job& q) { return p.a.chunk > q.a.chunk; });
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += WB_MAX) {
+        WgTrBatch B;
+        memset(&B, 0, sizeof(B));
+        B.n = (int)(jobs.size() - j0 < (size_t)WB_MAX ? jobs.size() - j0 : WB_MAX);
+        for (int j = 0; j < B.n; ++j) {
+            const Job& J = jobs[j0 + j];
+            B.job[j] = make_tr_args(J.a, nullptr, 0);
+            B.blocks[j] = (int)J.blocks;
+            B.start[j + 1] = B.start[j] + (int)((J.blocks + 7) / 8 * 8);
+        }
+        if (B.n == 1) { launch_wgrad_tr(jobs[j0].a, jobs[j0].blocks, st); continue; }
+        hipLaunchKernelGGL((wgrad_tr_batched_kernel<64, 2>), dim3((unsigned)B.start[B.n]), dim3(NT), 2 * 64 * 512, st, B);
+    }
+    HESIC_LAUNCH_RETURN("conv2d_wgrad_partial_batched");
+}
+
+extern "C" int hesic_conv2d_wgrad_finish_batched_n(int n, const hesic_conv_desc* descs, const void* const* ws, const void* const* dy, float* const* dw,
+                                                   float* const* dbias, int accumulate, const int32_t* nsplit, void* stream);
 extern "C" int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* descs, const void* const* ws, const void* const* dy, float* const* dw,
                                                  float* const* dbias, int accumulate, void* stream) {
+    return hesic_conv2d_wgrad_finish_batched_n(n, descs, ws, dy, dw, dbias, accumulate, nullptr, stream);
+}
+
+extern "C" int hesic_conv2d_wgrad_finish_batched_n(int n, const hesic_conv_desc* descs, const void* const* ws, const void* const* dy, float* const* dw,
+                                                   float* const* dbias, int accumulate, const int32_t* nsplit, void* stream) {
     HESIC_CHECK_ARG(n >= 0 && (n == 0 || (descs && ws && dy && dw && dbias)), "conv2d_wgrad_finish_batched: null pointer");
     hipStream_t st = (hipStream_t)stream;
     for (int j0 = 0; j0 < n; j0 += FIN_NB) {
@@ -2889,7 +3017,7 @@ extern "C" int hesic_conv2d_wgrad_finish_batched(int n, const hesic_conv_desc* d
             for (int i = 0; i < j0 + j; ++i)
                 HESIC_CHECK_ARG(dw[i] != dw[j0 + j] || i < j0, "conv2d_wgrad_finish_batched: jobs %d and %d add into the same gradient in one launch", i, j0 + j);
             WgArgs a;
-            fill_args(d, a);
+            fill_args(d, a, nsplit ? nsplit[j0 + j] : 0);
             a.ws_layout = direct_ws_layout();
             FinishExtra& e = fb.e[j];
             const bool bias_in_tr = setup_bias_part(d, a, (void*)ws[j0 + j]);      // the same decision hesic_conv2d_wgrad_partial took

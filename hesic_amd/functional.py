@@ -167,6 +167,9 @@ def set_wgrad_stream(stream):
 _finish_queue = None
 GDN_FINISH_BATCH = _os.environ.get("HESIC_GDN_FINISH_BATCH", "1") != "0"      # A/B switch: 0 = one parameter finish per GDN backward (rounds 2-4)
 WGRAD_FINISH_BATCH = int(_os.environ.get("HESIC_WGRAD_FINISH_BATCH", "8"))     # A/B switch: 0 = one finishing launch per layer (rounds 2-3)
+# round 5: the split-K launches of the queued layers are deferred too and share grids (hesic_conv2d_wgrad_partial_batched); 0 = each layer's
+# split-K launch where its backward runs, only the finishing pass batched (A/B)
+WGRAD_PARTIAL_BATCH = _os.environ.get("HESIC_WGRAD_PARTIAL_BATCH", "1") != "0"
 
 
 def defer_wgrad_finish(on):
@@ -214,9 +217,16 @@ def flush_wgrad_finish():
     vp = C.c_void_p * n
     ws = vp(*[j[1].data_ptr() for j in q])
     dy = vp(*[j[2].data_ptr() for j in q])
+    pend = [j for j in q if j[6] is not None]
+    if pend:          # jobs whose split-K launch was deferred: (x, workspace bytes, K slices) ride in the job
+        m = len(pend)
+        vm = C.c_void_p * m
+        L.call("hesic_conv2d_wgrad_partial_batched", m, (L.ConvDesc * m)(*[j[0] for j in pend]), vm(*[j[6].data_ptr() for j in pend]),
+               vm(*[j[2].data_ptr() for j in pend]), vm(*[j[1].data_ptr() for j in pend]), (C.c_int64 * m)(*[j[7] for j in pend]),
+               (C.c_int32 * m)(*[j[8] for j in pend]), L.stream())
     dw = vp(*[j[3].grad.data_ptr() for j in q])
     db = vp(*[(j[4].grad.data_ptr() if j[4] is not None else None) for j in q])
-    L.call("hesic_conv2d_wgrad_finish_batched", n, descs, ws, dy, dw, db, 1, L.stream())
+    L.call("hesic_conv2d_wgrad_finish_batched_n", n, descs, ws, dy, dw, db, 1, (C.c_int32 * n)(*[j[8] for j in q]), L.stream())
     jobs = list(q)
     q.clear()
     for j in jobs:
@@ -595,6 +605,11 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=
                     if has_bias:
                         _slot_done(bs_)
                 return dx, None, None
+            nsp = 0
+            if _finish_queue is not None and WGRAD_PARTIAL_BATCH:
+                # the shared-grid route: its own (smaller) K-slice count, named to both batched calls; the workspace is sized for it
+                nsp = L.lib().hesic_conv2d_wgrad_nsplit(C.byref(d), 1)
+                nws = L.lib().hesic_conv2d_wgrad_ws_bytes_n(C.byref(d), nsp)
             ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
             if _finish_queue is not None:
                 # deferred finishing pass (train.Trainer.step): only the split-K MFMA launch now; the K-slice reduce + layout change +
@@ -602,8 +617,11 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=
                 dwp = ws_.grad.data_ptr()
                 if len(_finish_queue) >= WGRAD_FINISH_BATCH or any(j[5] == dwp for j in _finish_queue) or (_finish_queue and _finish_queue[0][0].dtype != d.dtype):
                     flush_wgrad_finish()
-                L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws), nws, L.stream())
-                _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp))
+                if WGRAD_PARTIAL_BATCH:
+                    _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp, x, nws, nsp))      # x stays alive until the flush
+                else:
+                    L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws), nws, L.stream())
+                    _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp, None, nws, 0))
                 return dx, None, None
             L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
                    L.ptr(ws), nws, L.stream())

@@ -217,6 +217,21 @@ int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const voi
 /* Only the first of its two launches -- the split-K MFMA kernel that leaves the fp32 partial tiles in ws -- for profiling
  * (bench.py brackets it with HIP events to price the weight-gradient kernel against the MFMA roofline).               */
 int hesic_conv2d_wgrad_partial(const hesic_conv_desc* d, const void* x, const void* dy, void* ws, int64_t ws_bytes, void* stream);
+/* hesic_conv2d_wgrad_partial for n layers in one call: the split-K launches of the 128-channel-tile MFMA layers share grids of up to 14 jobs
+ * (block ranges back to back, longest K slices first), so a layer with few K stages per block no longer pays its own launch ramp and tail;
+ * the other layers are launched one by one.  Each job's partials land in its own ws[j] (hesic_conv2d_wgrad_ws_bytes(descs + j) bytes),
+ * bit-identical to the one-by-one calls; hesic_conv2d_wgrad_finish_batched follows.  x[j] and dy[j] must stay valid until then -- the
+ * backward pass of a training step (newtrain1.py:85-96) queues its layers and issues both calls every few layers.            */
+int hesic_conv2d_wgrad_partial_batched(int n, const hesic_conv_desc* descs, const void* const* x, const void* const* dy, void* const* ws,
+                                       const int64_t* ws_bytes, const int32_t* nsplit, void* stream);
+/* K-slice counts named by the caller (nsplit[j]; NULL or 0 = the library's choice for a launch of its own).  A shared grid is kept full by
+ * the other jobs' blocks, so a layer wants fewer and longer slices there -- fewer fp32 partial tiles to write and reduce:
+ * hesic_conv2d_wgrad_nsplit(d, 1) is the count for that route (0: the one-launch-per-layer count; the row kernel's layers always keep
+ * theirs), hesic_conv2d_wgrad_ws_bytes_n(d, nsplit) the workspace for it, and the finishing call must be given the same counts.          */
+int hesic_conv2d_wgrad_nsplit(const hesic_conv_desc* d, int batched);
+int64_t hesic_conv2d_wgrad_ws_bytes_n(const hesic_conv_desc* d, int nsplit);
+int hesic_conv2d_wgrad_finish_batched_n(int n, const hesic_conv_desc* descs, const void* const* ws, const void* const* dy, float* const* dw,
+                                        float* const* dbias, int accumulate, const int32_t* nsplit, void* stream);
 /* The second launch of hesic_conv2d_wgrad_direct for n layers at once: job j reduces the K slices hesic_conv2d_wgrad_partial(descs + j,
  * ..) left in ws[j] into dw[j] (PyTorch layout) and sums dy[j]'s columns into dbias[j] (NULL: no bias), `accumulate` as above.  The
  * backward pass of a training step (newtrain1.py:85-96) has one such pass per conv layer -- 37 launches of ~17 us on small grids;

@@ -172,3 +172,86 @@ def test_batched_gdn_param_finish_equals_the_per_layer_backward():
                    vp(bat[0][1].data_ptr(), bat[0][1].data_ptr(), None), vp(bat[0][2].data_ptr(), bat[0][2].data_ptr(), None), f32(1e-6, 1e-6, 0), 1, st)
     finally:
         hesic_amd.set_compute_dtype(torch.float32)
+
+
+def test_batched_split_k_launch_leaves_the_same_partials_as_the_per_layer_launches():
+    """hesic_conv2d_wgrad_partial_batched (round 5: the split-K launches of several layers in shared grids, longest K slices first) against one
+    hesic_conv2d_wgrad_partial per layer: the same blocks do the same work in the same order, so every workspace -- K-slice partial tiles
+    and the per-slice bias column sums behind them -- is compared bit for bit.  Sixteen jobs: two shared grids (14 + 2) inside one call,
+    with a non-multiple-of-8 block count per job (the 8-aligned ranges' surplus ids exit) and a large layer that goes to the row kernel."""
+    from hesic_amd import _lib as L
+    st = L.stream()
+    idx = list(range(len(LAYERS))) + [0, 3, 5, 7, 1, 8]
+    jobs = [_layer(i, L) for i in idx]
+    # one layer the row kernel takes (5x5 stride 2, rows of 64 pixels, >= 100 000 pixels): launched on its own inside the batched call
+    B, H, W = 8, 256, 256
+    xb = rnd("xrow", (B, 128, H, W), -2, 2).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = rnd("grow", (B, 128, H // 2, W // 2)).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    jobs.append((L.ConvDesc(B, H, W, 128, H // 2, W // 2, 128, 5, 5, 2, 2, 0, L.BF16, 0, 0, 128, 0, 128, 0, 0), xb, gb, None, 128, True))
+    n = len(jobs)
+    ref, bat, nbytes = [], [], []
+    for d, x, gy, *_ in jobs:
+        nws = int(L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d)))
+        a = torch.full((max(nws, 16),), 0x5a, dtype=torch.uint8, device=DEV)
+        L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(a), nws, st)
+        ref.append(a)
+        bat.append(torch.full((max(nws, 16),), 0x5a, dtype=torch.uint8, device=DEV))
+        nbytes.append(nws)
+    vp = C.c_void_p * n
+    L.call("hesic_conv2d_wgrad_partial_batched", n, (L.ConvDesc * n)(*[j[0] for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
+           vp(*[j[2].data_ptr() for j in jobs]), vp(*[b.data_ptr() for b in bat]), (C.c_int64 * n)(*nbytes), None, st)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(bat[i], ref[i]), f"job {i}: workspace differs"
+    # a workspace that is too small is refused, naming the job
+    short = list(nbytes)
+    short[2] -= 4
+    with pytest.raises(RuntimeError, match="job 2"):
+        L.call("hesic_conv2d_wgrad_partial_batched", n, (L.ConvDesc * n)(*[j[0] for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
+               vp(*[j[2].data_ptr() for j in jobs]), vp(*[b.data_ptr() for b in bat]), (C.c_int64 * n)(*short), None, st)
+    L.call("hesic_conv2d_wgrad_partial_batched", 0, None, None, None, None, None, None, st)       # an empty queue is a no-op
+
+
+def test_batched_route_with_its_own_k_slice_counts_matches_the_direct_gradients():
+    """The Trainer's route: hesic_conv2d_wgrad_nsplit(d, 1) K slices per layer (fewer than a launch of its own takes), workspaces from
+    hesic_conv2d_wgrad_ws_bytes_n, hesic_conv2d_wgrad_partial_batched + hesic_conv2d_wgrad_finish_batched_n with the same counts.  Another slice
+    count is another summation order: dW / dbias against hesic_conv2d_wgrad_direct within fp32 rounding of the sums, and a count the finishing
+    call is not told about must not be silently accepted for a layer another kernel takes."""
+    from hesic_amd import _lib as L
+    st = L.stream()
+    idx = list(range(len(LAYERS)))
+    jobs = [_layer(i, L) for i in idx]
+    # a layer of the training step's size (128 -> 128 5x5 on 32^2 maps, B = 8: 8192 pixels), where the two policies differ
+    xb = rnd("xb8", (8, 128, 32, 32), -2, 2).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = rnd("gb8", (8, 128, 32, 32)).to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    jobs.append((L.ConvDesc(8, 32, 32, 128, 32, 32, 128, 5, 5, 1, 2, 0, L.BF16, 0, 0, 128, 0, 128, 0, 0), xb, gb, (128, 128, 5, 5), 128, True))
+    n = len(jobs)
+    nsp = [int(L.lib().hesic_conv2d_wgrad_nsplit(C.byref(j[0]), 1)) for j in jobs]
+    nsp0 = [int(L.lib().hesic_conv2d_wgrad_nsplit(C.byref(j[0]), 0)) for j in jobs]
+    assert all(a >= 1 and a <= b for a, b in zip(nsp, nsp0)) and nsp[-1] < nsp0[-1], (nsp, nsp0)
+    # a layer another kernel takes keeps its count (fp32 storage: the VALU fallback)
+    df = L.ConvDesc(2, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1, 0, L.F32, 0, 0, 64, 0, 64, 0, 0)
+    assert L.lib().hesic_conv2d_wgrad_nsplit(C.byref(df), 1) == L.lib().hesic_conv2d_wgrad_nsplit(C.byref(df), 0)
+    nbytes = [int(L.lib().hesic_conv2d_wgrad_ws_bytes_n(C.byref(j[0]), k)) for j, k in zip(jobs, nsp)]
+    assert all(int(L.lib().hesic_conv2d_wgrad_ws_bytes_n(C.byref(j[0]), k)) == int(L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(j[0])))
+               for j, k in zip(jobs, nsp0))
+    ws = [torch.empty(max(b, 16), dtype=torch.uint8, device=DEV) for b in nbytes]
+    dw = [torch.full(j[3], 0.25, dtype=torch.float32, device=DEV) for j in jobs]
+    db = [torch.full((j[4],), -0.5, dtype=torch.float32, device=DEV) if j[5] else None for j in jobs]
+    vp, i32 = C.c_void_p * n, C.c_int32 * n
+    descs = (L.ConvDesc * n)(*[j[0] for j in jobs])
+    L.call("hesic_conv2d_wgrad_partial_batched", n, descs, vp(*[j[1].data_ptr() for j in jobs]), vp(*[j[2].data_ptr() for j in jobs]),
+           vp(*[w.data_ptr() for w in ws]), (C.c_int64 * n)(*nbytes), i32(*nsp), st)
+    L.call("hesic_conv2d_wgrad_finish_batched_n", n, descs, vp(*[w.data_ptr() for w in ws]), vp(*[j[2].data_ptr() for j in jobs]),
+           vp(*[w.data_ptr() for w in dw]), vp(*[(b.data_ptr() if b is not None else None) for b in db]), 1, i32(*nsp), st)
+    for i, (d, x, gy, wshape, Cout, has_b) in enumerate(jobs):
+        nws = int(L.lib().hesic_conv2d_wgrad_ws_bytes(C.byref(d)))
+        w0 = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+        rdw = torch.full(wshape, 0.25, dtype=torch.float32, device=DEV)
+        rdb = torch.full((Cout,), -0.5, dtype=torch.float32, device=DEV) if has_b else None
+        L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(rdw), L.ptr(rdb), 1, L.ptr(w0), nws, st)
+        torch.cuda.synchronize()
+        scale = float((rdw - 0.25).abs().max())
+        assert float((dw[i] - rdw).abs().max()) <= 2e-5 * scale + 1e-6, f"layer {i}: dW"
+        if has_b:
+            assert float((db[i] - rdb).abs().max()) <= 2e-5 * float(rdb.abs().max() + 1.0), f"layer {i}: dbias"
