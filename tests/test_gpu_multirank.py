@@ -27,7 +27,7 @@ def test_two_rank_inference_and_training_bench_lines():
     d = _run(29541, "--batch", "2", "--size", "256")
     assert d["n_gpus"] == 2 and d["config"]["pairs_per_step"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     t = _run(29542, "--mode", "train", "--batch", "2", "--size", "256")
-    assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 4 and t["value"] > 0 and t["roofline"]["kernel"] == "wgrad_tr_kernel"
+    assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 4 and t["value"] > 0 and t["roofline"]["kernel"].startswith("wgrad_")
     assert all(v == v for v in t["losses_last_step"].values())    # finite
 
 
