@@ -2180,6 +2180,250 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const h16_t* __restrict
     }
 }
 
+// ---- Round 5: the same pass as TWO tile pipelines per CU (training form: the parameter gradients ride along).
+// One block of four waves (one per SIMD, 128 KB of LDS) left every phase of a tile exposed: per tile and wave ~1500 VALU instructions (6 k
+// cycles), 96 MFMAs (3 k), ~300 LDS instructions and two block barriers run one after the other -- 16 k cycles per tile where the HBM
+// traffic of the tile (98 KB) needs 8 k at 6.4 TB/s (profiles/r05_g_pmc_sq_train.json: MFMA pipe 16 % busy, 40 % of the wave cycles parked).
+// Here a block is EIGHT waves = two groups of four, each group with its own (x, gy) tile pair; gamma' is held once (row-major only: the
+// second GEMM reads its transposed fragments with ds_read_b64_tr_b16 as the third one does) -- 32 + 2 x 64 KB = all 160 KB.  The groups run
+// the same loop one segment apart: the block barriers a group needs anyway (dn complete / x tile free) are the hand-over points, so while
+// one group is in its matrix segment (GEMM2 + GEMM3) the other is in its memory / VALU segment (dx out, next tile in, GEMM1, epilogue) on
+// the same SIMDs.  256 registers per wave instead of 512: the next tile is not prefetched into registers but requested as LDS-DMA right
+// after the copy-out (wave-private rows; its latency is covered by the other group's segment), beta' comes in as the initial value of the
+// first GEMM's accumulators (from a 512-byte scratch in the block's own partial slot) instead of an add per value.
+// Same arithmetic per value as gdn128_bwd_kernel<true, INV> except that n = beta' + sum starts from beta' (one rounding earlier).
+// RESULT (why it is not the default): correct (the GDN and training-trace tests pass with HESIC_GDN_BWD2=1) and 12 - 20 % SLOWER.  The block barrier
+// is the only cheap synchronisation, so the groups move in lockstep and a tile's segments pair one to one with the partner's -- but the
+// dependences leave no balanced cut: everything except the third GEMM (final epilogue, tile exchange, GEMM1, the 64-value rsqrt epilogue, GEMM2)
+// has to sit between "x tile free" and "dn complete", ~85 % of a tile's cycles, and that segment of one group only ever runs against the
+// short one of the other; the next tile's request, which the one-group form issues a whole tile ahead into 64 spare registers, is
+// exposed here (no registers, no LDS left to prefetch into).  ~22 k cycles per tile against 17.8 k.  What would help is LDS for a second
+// tile pair per group (another 64 KB per group), which the CU does not have.
+template <bool INV>
+__global__ __launch_bounds__(512) void gdn128_bwd2_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gy, const float* __restrict__ beta,
+                                                          const float* __restrict__ gamma, h16_t* __restrict__ dx, float* __restrict__ part, int64_t P,
+                                                          float beta_bound) {
+    constexpr bool inverse = INV;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* gs = smem;                                           // gamma' [i][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    unsigned char* xs = smem + 32768 + grp * 65536;                    // this group's x tile [128 px][128 ch] (becomes dx)
+    unsigned char* ds = xs + 32768;                                     // and its gy tile (becomes dn)
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int c = tid; c < 128 * 16; c += 512) {
+        const int row = c >> 4, slot = c & 15;
+        const f32x4 a0 = *(const f32x4*)(gamma + row * 128 + slot * 8), a1 = *(const f32x4*)(gamma + row * 128 + slot * 8 + 4);
+        *(u32x4*)(gs + gb_off(row, slot)) =
+            u32x4{pack_h2(reparam(a0.x, kGammaBound), reparam(a0.y, kGammaBound)), pack_h2(reparam(a0.z, kGammaBound), reparam(a0.w, kGammaBound)),
+                  pack_h2(reparam(a1.x, kGammaBound), reparam(a1.y, kGammaBound)), pack_h2(reparam(a1.z, kGammaBound), reparam(a1.w, kGammaBound))};
+    }
+    float* out = part + (int64_t)blockIdx.x * (128 * 128 + 128);
+    float* scratch = out + 128 * 128;                                   // beta' until the block's dbeta' partial is written there
+    if (tid < 128) scratch[tid] = reparam(beta[tid], beta_bound);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int64_t ntiles = (P + 127) / 128;
+    const int G = (int)gridDim.x;
+    const int64_t mine = ntiles > (int64_t)blockIdx.x ? (ntiles - blockIdx.x + G - 1) / G : 0;      // tiles blockIdx.x, + G, ...: the groups alternate
+    const int iters = (int)((mine + 1) / 2);                            // the same for both groups: a tile past the end reads zeros, its stores are dropped
+    const int r0 = wq * 32;
+    const int nbytes = (int)(P * 256);                                  // P < 2^22 (host)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)scratch, 0, 512, 0x00020000);
+    const int lofs = (r0 + (lane >> 4)) * 256 + (lane & 15) * 16;     // copy-out: this lane's first row / LOGICAL slot
+    // LDS-DMA: instruction `it` fills rows r0 + 4 it .. + 3 linearly (lane = row in four, PHYSICAL slot); the lane fetches the logical slot
+    // that gb_off puts there: (row & 3) = lane >> 4, (row >> 2) & 3 = it & 3 (r0 is a multiple of 32)
+    int dofs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dofs[k] = (r0 + (lane >> 4)) * 256 + (((lane & 15) ^ (((lane >> 4) << 2) | k)) << 4);
+    f32x16 acc[4];
+    auto load_tile = [&](int64_t t) {
+        const int base = t < ntiles ? (int)t * 32768 : nbytes;           // past the end: every offset out of range
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            // the tile offset rides in the VGPR offset: that is the part the buffer unit range-checks
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (r0 + it * 4) * 256), 16, dofs[it & 3] + it * 1024 + base, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (__attribute__((address_space(3))) void*)(ds + (r0 + it * 4) * 256), 16, dofs[it & 3] + it * 1024 + base, 0, 0, 0);
+        }
+        // beta' -> the first GEMM's accumulators (lane: channels i*32 + 8g + 4fh + e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, (i * 32 + 8 * g + 4 * fh) * 4, 0, 0));
+                acc[i][4 * g] = bq.x; acc[i][4 * g + 1] = bq.y; acc[i][4 * g + 2] = bq.z; acc[i][4 * g + 3] = bq.w;
+            }
+    };
+    f32x16 g3[4];
+    float cs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g3[j][r] = 0.f;
+    // lane ids as opaque copies, re-laundered at the top of every segment of the tile loop: the swizzled LDS addresses built from them are
+    // then recomputed there (a few VALU operations each) instead of being hoisted out of the loop into ~150 long-lived registers -- a wave has 256
+    int frq = frow, fhq = fh, tgq = lane >> 4, ttq = lane & 15;
+    auto tr = [&](const unsigned char* tile_, int cb, int px_) {
+        const int ch = cb + (tgq & 1) * 16 + 4 * (ttq & 3);
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile_ + gb_off(px_, ch >> 3) + (ch & 7) * 2));
+    };
+
+    int64_t tile = (int64_t)blockIdx.x + (int64_t)grp * G;
+    load_tile(tile);
+    // eight stores the range check drops: the loop is entered with the queue of memory operations its back edge carries (32 loads, then 8 stores)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, dxr, nbytes, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();                        // one segment behind group 0
+    for (int itn = 0; itn < iters; ++itn, tile += 2 * (int64_t)G) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // the tile and beta' are in; the previous tile's stores may still be on their way
+        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
+        // ---- GEMM1: n = beta' + gamma' x^2 (this wave's 32 pixel rows)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 raw = *(const u32x4*)(xs + gb_off(r0 + frq, ks * 2 + fhq));
+            const float f0 = h2f_lo(raw.x), f1 = h2f_hi(raw.x), f2 = h2f_lo(raw.y), f3 = h2f_hi(raw.y);
+            const float f4 = h2f_lo(raw.z), f5 = h2f_hi(raw.z), f6 = h2f_lo(raw.w), f7 = h2f_hi(raw.w);
+            const h16x8 xf = __builtin_bit_cast(h16x8, u32x4{pack_h2(f0 * f0, f1 * f1), pack_h2(f2 * f2, f3 * f3), pack_h2(f4 * f4, f5 * f5), pack_h2(f6 * f6, f7 * f7)});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const h16x8 gf = *(const h16x8*)(gs + gb_off(i * 32 + frq, ks * 2 + fhq));
+                acc[i] = mfma_32x32x16_h16(gf, xf, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // 256 registers per wave: the fragment reads of one k-step at a time
+        }
+        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * fhq;
+                const int off = gb_off(r0 + frq, ch >> 3) + (ch & 7) * 2;
+                const u32x2 xq = *(const u32x2*)(xs + off), gq = *(const u32x2*)(ds + off);
+                const float xv[4] = {h2f_lo(xq.x), h2f_hi(xq.x), h2f_lo(xq.y), h2f_hi(xq.y)};
+                const float gv[4] = {h2f_lo(gq.x), h2f_hi(gq.x), h2f_lo(gq.y), h2f_hi(gq.y)};
+                float dn[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = acc[i][4 * g + e];
+                    const float rs = __builtin_amdgcn_rsqf(n);
+                    if (inverse) {
+                        dn[e] = 0.5f * gv[e] * xv[e] * rs;
+                        acc[i][4 * g + e] = gv[e] * (n * rs);
+                    } else {
+                        dn[e] = -0.5f * gv[e] * xv[e] * rs * rs * rs;
+                        acc[i][4 * g + e] = gv[e] * rs;
+                    }
+                }
+                *(u32x2*)(ds + off) = u32x2{pack_h2(dn[0], dn[1]), pack_h2(dn[2], dn[3])};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // B1: the group's dn tile is complete
+        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
+        // ---- GEMM3: dgamma'[i][j] += sum_p dn[p][i] x[p][j]^2 over the group's 128 pixels; wave wq owns columns 32 wq .. + 31
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int pix = ks * 16 + (tgq >> 1) * 8 + (ttq >> 2);
+            const s16x8 vx = __builtin_shufflevector(tr(xs, wq * 32, pix), tr(xs, wq * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+            u32x4 ux = __builtin_bit_cast(u32x4, vx);
+            uint32_t* w4 = (uint32_t*)&ux;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float l2 = h2f_lo(w4[q]), h2 = h2f_hi(w4[q]);
+                w4[q] = pack_h2(l2 * l2, h2 * h2);
+            }
+            const h16x8 xf = __builtin_bit_cast(h16x8, ux);
+            {
+                const s16x8 vc = __builtin_shufflevector(tr(ds, wq * 32, pix), tr(ds, wq * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                const u32x4 ua = __builtin_bit_cast(u32x4, vc);
+                cs += ((h2f_lo(ua.x) + h2f_hi(ua.x)) + (h2f_lo(ua.y) + h2f_hi(ua.y))) + ((h2f_lo(ua.z) + h2f_hi(ua.z)) + (h2f_lo(ua.w) + h2f_hi(ua.w)));
+            }
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const s16x8 va = __builtin_shufflevector(tr(ds, ib * 32, pix), tr(ds, ib * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                g3[ib] = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, va), xf, g3[ib], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // B2: every wave of the group is done with the x and dn tiles
+        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
+        // ---- GEMM2 + dx, one 32-channel block at a time (16 live registers of s instead of 64): s[j][p] = sum_i gamma'[i][j] dn[p][i] with the
+        // gamma'^T fragments through transposing reads of gs and this wave's own dn rows; dx = t1 + 2 x s goes into the x tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const h16x8 df = *(const h16x8*)(ds + gb_off(r0 + frq, ks * 2 + fhq));
+                const int kr = ks * 16 + (tgq >> 1) * 8 + (ttq >> 2);
+                const s16x8 va = __builtin_shufflevector(tr(gs, i * 32, kr), tr(gs, i * 32, kr + 4), 0, 1, 2, 3, 4, 5, 6, 7);
+                s2 = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, va), df, s2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * fhq;
+                const int off = gb_off(r0 + frq, ch >> 3) + (ch & 7) * 2;
+                const u32x2 xq = *(const u32x2*)(xs + off);
+                const float xv[4] = {h2f_lo(xq.x), h2f_hi(xq.x), h2f_lo(xq.y), h2f_hi(xq.y)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[i][4 * g + e] + 2.f * xv[e] * s2[4 * g + e];
+                *(u32x2*)(xs + off) = u32x2{pack_h2(o[0], o[1]), pack_h2(o[2], o[3])};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // copy-out: the rows go to registers, the NEXT tile is requested, THEN the stores are issued -- the wait at the loop top is "all but the
+        // newest eight" = the loads only (the counter is in order: loads requested behind the stores would wait for a store round trip each tile)
+        const int so = tile < ntiles ? (int)tile * 32768 + lofs : nbytes;
+        u32x4 ob[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
+            ob[it] = *(const u32x4*)(xs + gb_off(r0 + row, slot));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the rows are in registers: the DMA may overwrite them
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(tile + 2 * (int64_t)G);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(ob[it], dxr, so + (tile < ntiles ? it * 1024 : 0), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                        // the barrier group 1 started with
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // the trailing (out-of-range) tile request has landed: the tiles are free
+    __syncthreads();
+    // the two groups' partials: group 1 hands its own over through its tile area, group 0 adds and writes the block's partial
+    float* xg = (float*)(smem + 32768 + 65536);                         // 64 KB: [wq][ib][r][lane], then [wq][lane] column sums behind it (group 0's area)
+    float* xc = (float*)(smem + 32768);
+    cs += __shfl_xor(cs, 32);
+    if (grp == 1) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xg[((wq * 4 + ib) * 16 + r) * 64 + lane] = g3[ib][r];
+        xc[wq * 64 + lane] = cs;
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 128 + wq * 32 + frow] = g3[ib][r] + xg[((wq * 4 + ib) * 16 + r) * 64 + lane];
+        if (fh == 0) out[128 * 128 + wq * 32 + frow] = cs + xc[wq * 64 + lane];
+    }
+}
+
 static WgTrArgs make_tr_args(const WgArgs& a, float* zero_me, int zero_n) {
     WgTrArgs A;
     A.w = a;
@@ -2799,7 +3043,21 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
             // one pass: dx + a (128 x 128 + 128) parameter-gradient partial per block, then the block partials summed in a fixed order
             constexpr int NP = 128 * 128 + 128;
             float* part = (float*)base;
-            if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+            // round 5 experiment, OFF by default: two tile pipelines per CU (gdn128_bwd2_kernel; HESIC_GDN_BWD2=N: from N tiles on).  Measured SLOWER:
+            // 4096 tiles 172 - 194 us against 150 - 162 us, 1024 tiles 49 - 53 against 40 (same box), training step 9.19 / 9.20 against 8.94 / 8.97 ms.
+            static const int64_t two_from = getenv("HESIC_GDN_BWD2") ? atoll(getenv("HESIC_GDN_BWD2")) : 0;
+            if (two_from > 0 && tiles >= two_from) {
+                static bool attr2 = false;
+                if (!attr2) {
+                    (void)hipFuncSetAttribute((const void*)gdn128_bwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    (void)hipFuncSetAttribute((const void*)gdn128_bwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    attr2 = true;
+                }
+                if (inverse) hipLaunchKernelGGL((gdn128_bwd2_kernel<true>), dim3((unsigned)nb), dim3(512), 163840, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+                                                (h16_t*)dx, part, P, bound);
+                else hipLaunchKernelGGL((gdn128_bwd2_kernel<false>), dim3((unsigned)nb), dim3(512), 163840, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+                                        (h16_t*)dx, part, P, bound);
+            } else if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
                                             (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
             else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
                                     (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
