@@ -24,7 +24,7 @@ i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   HESIC_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc $set --kernel-include-regex "$RX|sconv_n2w|sconv_w2n|warp_fwd|sconv_6to3" --output-format csv -d $O/pmcsq/p$i -- python $GRAFT_REPO_ROOT/profiles/scripts/forward_n.py hsic 3 > /dev/null 2>&1
-  timeout 400 rocprofv3 --pmc $set --kernel-include-regex "wgrad_tr_kernel|wgrad_row_kernel|wgrad_nw_fused|gdn128_bwd_kernel|wgrad_finish" --output-format csv -d $O/pmctr/p$i -- python $GRAFT_REPO_ROOT/profiles/scripts/train_step.py --size 512 --only e --steps 2 > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc $set --kernel-include-regex "wgrad_tr_|wgrad_row_kernel|wgrad_nw_fused|gdn128_bwd_kernel|wgrad_finish" --output-format csv -d $O/pmctr/p$i -- python $GRAFT_REPO_ROOT/profiles/scripts/train_step.py --size 512 --only e --steps 2 > /dev/null 2>&1
 done
 python $GRAFT_REPO_ROOT/profiles/make_pmc_sq_json.py $O/pmcsq $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
 python $GRAFT_REPO_ROOT/profiles/make_pmc_sq_json.py $O/pmctr $O/pmc_sq_train.json > $O/pmc_sq_train.txt 2>&1
