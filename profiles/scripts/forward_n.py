@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N eval forwards of HESIC / HESIC+ (B=8, 512x512, bf16, single stream) -- the workload behind the rocprofv3 --pmc passes
+"""N eval forwards of HESIC / HESIC+ (B=8 or HESIC_BATCH, 512x512, f16 or HESIC_DTYPE, single stream) -- the workload behind the rocprofv3 --pmc passes
 (profiles/make_pmc_json.py) and the kernel traces:  python profiles/scripts/forward_n.py [hsic|joint] [n]"""
 import os
 import sys
@@ -17,7 +17,7 @@ net = models.HSIC() if which == "hsic" else models.HSICJoint()
 synthetic.fill_state_dict_(net.state_dict())
 net = net.cuda().eval()
 net.update(force=True)
-x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, 8, 512, 512))
+x1, x2, Hm = (t.cuda() for t in synthetic.stereo_batch(0, int(os.environ.get("HESIC_BATCH", "8")), 512, 512))
 with torch.no_grad():
     for _ in range(n):
         out = net(x1, x2, Hm)

@@ -16,7 +16,7 @@ def main():
     f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "sum_sq_diff_kernel" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "sum_sq_diff_kernel" in r["Kernel_Name"] or "rd_sums_kernel" in r["Kernel_Name"]]
     # the metrics reductions close a step (one or two launches per step): take the launches of the last step
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 6
     per = max(1, len(marks) // nsteps)
