@@ -2,7 +2,7 @@
 # Ablations of igemm_tr4_kernel<IGDN> (g_s deconv3 + IGDN, 128 -> 128 5x5 s2 on 128^2 inputs, B = 8, f16): the f16 library rebuilt with
 # -DTR4_ABL=<bits> (conv_igemm.hip: 1 no LDS-DMA, 2 no K-loop MFMAs, 4 no fragment reads, 8 no epilogue), each variant swapped in for
 # hesic_amd/libhesic_hip_f16.so on the (scratch) GPU box and timed with profiles/scripts/conv_layer_time.py from a HIP graph.
-# Build the variants first (CPU container):  see the recipe in DESIGN_APPENDIX.md, round 5, "tr4 ablations"; they live in
+# Build the variants first (CPU container): profiles/scripts/tr4_ablation_build.sh; they live in
 # profiles/abl_build/ (git-ignored, travels to the box).  Output: gpurun_out/tr4_ablation.txt
 set -u
 cd "$GRAFT_REPO_ROOT"
