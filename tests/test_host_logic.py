@@ -270,3 +270,49 @@ def test_call_hook_sees_only_the_recording_threads_launches(monkeypatch):
     assert [n for n, _ in seen] == ["a", "b", "c"] and seen[0][1] == (1, 2)
     assert inner == ["b"]
     assert not getattr(L._tls, "hooks")
+
+
+def test_wgrad_flush_empties_its_queues_before_the_calls(monkeypatch):
+    """``flush_wgrad_finish`` / ``flush_gdn_finish``: the queued jobs are taken off the queue BEFORE the C calls, so a call that fails (a bad
+    launch, an out-of-memory workspace) cannot leave its jobs behind for the next step; deferred split-K launches (jobs that carry their conv
+    input) go down as ONE ``hesic_conv2d_wgrad_partial_batched`` call ahead of the finishing call, with the same K-slice counts."""
+    import types
+    from hesic_amd import _lib as L
+    from hesic_amd import functional as Fn
+    calls = []
+
+    def fake_call(name, *args):
+        calls.append((name, args[0]))
+        if name == "hesic_conv2d_wgrad_finish_batched_n" and fail["on"]:
+            raise RuntimeError("boom")
+    monkeypatch.setattr(L, "call", fake_call)
+    monkeypatch.setattr(L, "stream", lambda: None)
+    fail = {"on": False}
+    done = []
+    monkeypatch.setattr(Fn, "_slot_done", lambda s: done.append(s))
+    slot = lambda: types.SimpleNamespace(grad=torch.zeros(4))
+    t = lambda: torch.zeros(16)
+    d = L.ConvDesc()
+    prev = Fn.defer_wgrad_finish(True)
+    try:
+        q = Fn._finish_queue
+        assert q == []
+        w1, w2, b2 = slot(), slot(), slot()
+        q.append(Fn._WgJob(d, t(), t(), w1, None, 1, t(), 64, 3))          # split-K launch deferred (carries x)
+        q.append(Fn._WgJob(d, t(), t(), w2, b2, 2, None, 64, 0))            # split-K launch already issued
+        Fn.flush_wgrad_finish()
+        assert [c for c in calls] == [("hesic_conv2d_wgrad_partial_batched", 1), ("hesic_conv2d_wgrad_finish_batched_n", 2)]
+        assert done == [w1, w2, b2] and Fn._finish_queue == []
+        calls.clear(); done.clear()
+        fail["on"] = True
+        q.append(Fn._WgJob(d, t(), t(), w1, None, 1, t(), 64, 3))
+        with pytest.raises(RuntimeError, match="boom"):
+            Fn.flush_wgrad_finish()
+        assert Fn._finish_queue == [] and done == []           # nothing left behind, no slot reported as written
+        fail["on"] = False
+        Fn.flush_wgrad_finish()
+        assert len(calls) == 2                                    # the failed flush's two calls; the empty one made none
+    finally:
+        Fn._finish_queue.clear()
+        Fn._gdn_finish_queue.clear()
+        monkeypatch.setattr(Fn, "_finish_queue", None if not prev else [])
