@@ -1549,7 +1549,11 @@ __global__ __launch_bounds__(256) void wgrad_nw_fused_kernel(const NwArgs a) {
 // the NS*5 (s, ky) pairs are dealt to the 4 waves, a wave keeps NA*5 accumulators per pair (<= 120 per lane) and walks all
 // 16 rows of the 16x64 LDS tile: per row and pair 5 shifted reads of S feed NA*5 FMAs.  Persistent blocks: the cross-lane
 // reduction and the atomics happen once per block.
-template <int NA, int NS_>
+// DMA (round 5): both tensors fp32 with 32-bit offsets inside one image -- the tile rows go global -> LDS as 4-byte LDS-DMA, one instruction
+// per (channel, row) of 64 pixels (+ one masked to four lanes for the halo columns 64 .. 67 of the shifted operand), addresses from scalar row
+// arithmetic: no registers, no per-element div / mod, every row of the tile in flight at once.  The register-staged form (40 loads per thread
+// and tile in rounds of 4 - 8, each element's (c, y, x) from two divisions) stays for the other storage types.
+template <int NA, int NS_, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void sconv_wgrad_nn_kernel(const void* __restrict__ A, int a_dtype, int64_t as_b, int64_t as_c,
                                                              int64_t as_y, int64_t as_x, const void* __restrict__ S, int s_dtype,
                                                              int64_t ss_b, int64_t ss_c, int64_t ss_y, int64_t ss_x,
@@ -1612,8 +1616,33 @@ __global__ __launch_bounds__(256, 2) void sconv_wgrad_nn_kernel(const void* __re
                     if (i0 + tid + 256 * u < NS_ * PH * PW) st[i0 + tid + 256 * u] = v[u];
             }
         };
-        if (a_dtype == HESIC_H16) stage_a(h16_t{}); else stage_a(float{});
-        if (s_dtype == HESIC_H16) stage_s(h16_t{}); else stage_s(float{});
+        if constexpr (DMA) {
+            constexpr uint32_t POISON = 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)A + b * as_b), 0, (int)POISON, 0x00020000);
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)S + b * ss_b), 0, (int)POISON, 0x00020000);
+            const int xa = tx * TW + lane, xs0 = tx * TW - 2 + lane, xs1 = xs0 + 64;
+            const bool xa_ok = xa < W, xs0_ok = (unsigned)xs0 < (unsigned)W, xs1_ok = (unsigned)xs1 < (unsigned)W;
+            for (int idx = wave; idx < NA * TH; idx += 4) {                       // wave-uniform: scalar row arithmetic
+                const int c = idx / TH, r = idx - c * TH, y = ty * TH + r;
+                const uint32_t vo = (y < H && xa_ok) ? (uint32_t)((c * (int)as_c + y * (int)as_y + xa * (int)as_x) * 4) : POISON;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (__attribute__((address_space(3))) void*)(at + idx * TW), 4, (int)vo, 0, 0, 0);
+            }
+            for (int idx = wave; idx < NS_ * PH; idx += 4) {
+                const int c = idx / PH, r = idx - c * PH, y = ty * TH - 2 + r;
+                const bool yok = (unsigned)y < (unsigned)H;
+                const int rb = (c * (int)ss_c + y * (int)ss_y) * 4;
+                const uint32_t v0 = (yok && xs0_ok) ? (uint32_t)(rb + xs0 * (int)ss_x * 4) : POISON;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(st + idx * PW), 4, (int)v0, 0, 0, 0);
+                if (lane < 4) {                                                   // halo columns 64 .. 67: only these four lanes write
+                    const uint32_t v1 = (yok && xs1_ok) ? (uint32_t)(rb + xs1 * (int)ss_x * 4) : POISON;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(st + idx * PW + 64), 4, (int)v1, 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (a_dtype == HESIC_H16) stage_a(h16_t{}); else stage_a(float{});
+            if (s_dtype == HESIC_H16) stage_s(h16_t{}); else stage_s(float{});
+        }
         __syncthreads();
         // Round 5: a lane owns FOUR consecutive pixels of a row (a wave = 4 rows x 64 columns per pass, four passes per tile): the eight S values
         // its four pixels share across the five kx shifts arrive as two 16-byte reads and feed 20 NA FMAs, where one pixel per lane read five
@@ -2899,12 +2928,22 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         const int64_t tiles = (int64_t)((d->W + 63) / 64) * ((d->H + 15) / 16) * d->B;
         const unsigned g = (unsigned)(tiles < NN_BLOCKS ? tiles : NN_BLOCKS);       // persistent blocks
         float* part = (ws && ws_bytes >= (int64_t)NN_BLOCKS * 450 * 4) ? (float*)ws : nullptr;
-        if (!d->transposed)   // A = dy (co), S = x (ci); dW[co][ci][k]
-            hipLaunchKernelGGL((sconv_wgrad_nn_kernel<3, 6>), dim3(g), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, x,
-                               d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, part, 1, d->B, d->H, d->W);
-        else                  // A = x (ci), S = dy (co); dW[ci][co][k]
-            hipLaunchKernelGGL((sconv_wgrad_nn_kernel<6, 3>), dim3(g), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dy,
-                               d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, part, 1, d->B, d->H, d->W);
+        // LDS-DMA staging: fp32 on both sides, non-negative strides, 32-bit byte offsets inside one image (HESIC_NN_DMA=0: register staging, A/B)
+        static const bool dma_off = getenv("HESIC_NN_DMA") && atoi(getenv("HESIC_NN_DMA")) == 0;
+        auto span = [&](int64_t sc, int64_t sy, int64_t sx, int C_) { return (C_ * sc + (int64_t)(d->H + 4) * sy + (int64_t)(d->W + 4) * sx) * 4; };
+        const bool dma = !dma_off && d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_F32 && d->xs_c >= 0 && d->xs_y >= 0 && d->xs_x >= 0 && d->ys_c >= 0 &&
+                         d->ys_y >= 0 && d->ys_x >= 0 && span(d->xs_c, d->xs_y, d->xs_x, 6) < (1ll << 31) && span(d->ys_c, d->ys_y, d->ys_x, 3) < (1ll << 31);
+        if (!d->transposed) {   // A = dy (co), S = x (ci); dW[co][ci][k]
+            if (dma) hipLaunchKernelGGL((sconv_wgrad_nn_kernel<3, 6, true>), dim3(g), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, x,
+                                        d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, part, 1, d->B, d->H, d->W);
+            else hipLaunchKernelGGL((sconv_wgrad_nn_kernel<3, 6>), dim3(g), dim3(256), 0, st, dy, d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, x,
+                                    d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dw, part, 1, d->B, d->H, d->W);
+        } else {                // A = x (ci), S = dy (co); dW[ci][co][k]
+            if (dma) hipLaunchKernelGGL((sconv_wgrad_nn_kernel<6, 3, true>), dim3(g), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dy,
+                                        d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, part, 1, d->B, d->H, d->W);
+            else hipLaunchKernelGGL((sconv_wgrad_nn_kernel<6, 3>), dim3(g), dim3(256), 0, st, x, d->x_dtype, d->xs_b, d->xs_c, d->xs_y, d->xs_x, dy,
+                                    d->y_dtype, d->ys_b, d->ys_c, d->ys_y, d->ys_x, dw, part, 1, d->B, d->H, d->W);
+        }
         if (part) hipLaunchKernelGGL(nn_partial_reduce_kernel, dim3((450 + 3) / 4), dim3(256), 0, st, (const float*)part, dw, (int)g, 450);
     } else {
         const int64_t Q = (int64_t)d->B * (d->transposed ? d->H * d->W : d->Ho * d->Wo);
