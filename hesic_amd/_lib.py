@@ -185,6 +185,8 @@ _SIGS = {
     "hesic_conv2d_forward_grouped": ([_P(ConvDesc), _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "hesic_pack_conv_weight_slice": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv2d_wgrad_partial": ([_P(ConvDesc), _vp, _vp, _vp, _i64, _vp], _i32),
+    "hesic_conv2d_hilo_set_acc_scale": ([_f32], _i32),
+    "hesic_sconv_pack_weight_image_hilo_scaled": ([_vp, _vp, _f32, _vp, _vp], _i32),
     "hesic_conv2d_wgrad_partial_batched": ([_i32, _P(ConvDesc), _P(_vp), _P(_vp), _P(_vp), _P(_i64), _P(_i32), _vp], _i32),
     "hesic_conv2d_wgrad_nsplit": ([_P(ConvDesc), _i32], _i32),
     "hesic_conv2d_wgrad_ws_bytes_n": ([_P(ConvDesc), _i32], _i64),

@@ -43,6 +43,7 @@ struct IgemmArgs {
     int KH, KW, stride, pad, transposed, ntaps_live;   // taps are derived arithmetically (no table loads in the K loop)
     const void* gdn_gamma;     // fused GDN epilogue: packed gamma' (hesic_gdn_pack_params); the fragment-order half is used here
     const float* gdn_beta;     // beta' fp32 [128]
+    float acc_scale;           // hi/lo launches whose packed weights carry a power-of-two factor: the accumulators are multiplied by this (its inverse) once, behind the K loop
     void* y_pre;               // fused GDN, training: also store the conv output v = conv + bias (bf16, y's geometry) for GDN's backward
     FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
@@ -384,7 +385,10 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     constexpr int YOFF = BM * 256;                            // fused GDN: squared tile at 0, output tile behind it
     constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
     constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    // binary16 build, pair (I)GDN: the squares are scaled PER PIXEL (see the epilogue); the wave slices of a pixel exchange their maxima here
+    constexpr bool DYN_SQ = HESIC_H16_IS_F16 && GDN >= 3;
+    constexpr int XMAX_BYTES = DYN_SQ ? WM * BM * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + XMAX_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA bases go to M0
     const bool loader = WS && wave >= NW;      // wave-uniform
@@ -661,6 +665,19 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     };
     if (a.in_abs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (HL != 0) {
+        // pair weights packed as (w * 2^s)_hi | (w * 2^s)_lo (binary16: the lo half of an unscaled 0.02 is a subnormal half, the pair then
+        // carries 2^-20 instead of 2^-22): the sums come out times 2^s, exactly; one multiply per value here, in front of every epilogue
+        // (a K slice's partial tile is scaled the same way: the reduce adds scaled partials)
+        if (a.acc_scale != 1.f) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= a.acc_scale;
+        }
+    }
     if constexpr (GDN == 0) {
         if (a.ksplit > 1) {
             // K slice: raw fp32 partial sums straight from the accumulators (16 bytes per lane and channel quad)
@@ -762,19 +779,42 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         // gamma_hi sq_hi + gamma_hi sq_lo + gamma_lo sq_hi on top of beta' (fp32 accumulators), the product v * rsqrt(nrm) stays
         // fp32 and leaves as [hi(128) | lo(128)] per pixel -- 2^-17 relative instead of 2^-9 at every layer boundary.
         constexpr bool INV = GDN == 4;
+        // Binary16 build (DYN_SQ): a square v^2 * 2^-6 of |v| < 0.0625 is a SUBNORMAL half (absolute step 6e-8, its lo partner carries nothing):
+        // with beta' = 1e-2 and activations of 0.1 the norm comes out 4e-6 relative wrong, with beta' = 1e-4 up to 1e-3
+        // (profiles/scripts/gdn_pair_precision.py) -- worse than bfloat16 pairs (1.4e-6), and far from the 2^-22 the pair carries elsewhere.
+        // So a pixel's squares are formed from u = v * 2^k with k chosen from the pixel's own largest |v| over all 128 channels (|u| in
+        // [2^6, 2^7): u^2 <= 2^14 fits, the largest square keeps all 22 bits, a channel 2^-13 below it is still normal); the contraction then
+        // holds 64 * 4^k * sum(gamma' v^2) (gamma' is packed times 64), beta' is added AFTER it in fp32: n = beta' + nrm * 2^(-6 - 2k).
+        // Powers of two throughout: no rounding of its own.  bfloat16 build: its range needs none of this (k = -3, as before).
         f32x16 nrm[MI][NI];
+        [[maybe_unused]] float sq_c[NI], sq_inv[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
                 const f32x4 t = a.bias ? *(const f32x4*)(a.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 be = *(const f32x4*)(a.gdn_beta + cl);
+                [[maybe_unused]] f32x4 be = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!DYN_SQ) be = *(const f32x4*)(a.gdn_beta + cl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) { acc[i][j][4 * g + e] += t[e]; nrm[i][j][4 * g + e] = be[e]; }
             }
+        if constexpr (DYN_SQ) {
+            float* xmax = (float*)(smem + LDS_BYTES);                     // [WM][BM]: outside the ring, which slower waves may still be reading
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[i][j][r]));
+                m = fmaxf(m, __shfl_xor(m, 32));                          // the other 4-channel halves of the same pixel
+                sq_c[j] = m;
+                if (WM > 1 && fh == 0) xmax[wm * BM + wn * (BM / WN) + j * 32 + frow] = m;
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         h16x8 gq[MI][8];
         {
@@ -786,7 +826,25 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         }
         __builtin_amdgcn_sched_barrier(0);
         auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) { split_h2(p, q, hi, lo); };
-        asm volatile("s_barrier" ::: "memory");                        // every wave is done reading the ring
+        if constexpr (DYN_SQ) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... and the pixel maxima are visible
+        else asm volatile("s_barrier" ::: "memory");                   // every wave is done reading the ring
+        if constexpr (DYN_SQ) {
+            const float* xmax = (const float*)(smem + LDS_BYTES);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                float m = sq_c[j];
+                if (WM > 1) {
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) m = fmaxf(m, xmax[w * BM + wn * (BM / WN) + j * 32 + frow]);
+                }
+                int ex = 0;
+                (void)frexpf(m, &ex);                                      // m in [2^(ex-1), 2^ex); 0 -> ex = 0
+                int k = 7 - ex;
+                k = k > 40 ? 40 : (k < -24 ? -24 : k);                     // inf / NaN / denormal maxima: stay finite
+                sq_c[j] = ldexpf(1.f, k);
+                sq_inv[j] = ldexpf(1.f, -6 - 2 * k);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -795,10 +853,16 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int pr = wn * (BM / WN) + j * 32 + frow;
-                    const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                    float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
                     uint32_t h0, l0, h1, l1;
+                    if constexpr (DYN_SQ) {
+                        v0 *= sq_c[j]; v1 *= sq_c[j]; v2 *= sq_c[j]; v3 *= sq_c[j];
+                        split2(v0 * v0, v1 * v1, h0, l0);
+                        split2(v2 * v2, v3 * v3, h1, l1);
+                    } else {
                     split2(v0 * v0 * H16_SQ_SCALE, v1 * v1 * H16_SQ_SCALE, h0, l0);
                     split2(v2 * v2 * H16_SQ_SCALE, v3 * v3 * H16_SQ_SCALE, h1, l1);
+                    }
                     const u32x2 h = u32x2{h0, h1}, l = u32x2{l0, l1};
                     const int o = pr * 256 + (((cl >> 3) ^ (pr & 15)) << 4) + (cl & 7) * 2;
                     *(u32x2*)(smem + o) = h;
@@ -858,9 +922,11 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                 for (int j = 0; j < NI; ++j) {
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     float v[4];
+                    [[maybe_unused]] f32x4 be = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (DYN_SQ) be = *(const f32x4*)(a.gdn_beta + cl);      // L1 hits: 512 bytes per block
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float n = nrm[i][j][4 * g + e];
+                        const float n = DYN_SQ ? fmaf(nrm[i][j][4 * g + e], sq_inv[j], be[e]) : nrm[i][j][4 * g + e];
                         v[e] = acc[i][j][4 * g + e] * (INV ? sqrtf(n) : rsqrtf(n));
                     }
                     uint32_t h0, l0, h1, l1;
@@ -1712,6 +1778,7 @@ static thread_local int g_y32_ps = 0, g_y32_co = 0;
 static thread_local int g_hilo = 0;                      // set by hesic_conv2d_forward_hilo: bf16x3 operands
 static thread_local const void* g_gdn_gamma_lo = nullptr;
 static thread_local int g_y_hilo = 0, g_y_abs = 0;
+static thread_local float g_hilo_acc_scale = 1.f;      // hesic_conv2d_hilo_set_acc_scale: consumed by the next hi/lo launch of this thread
 
 extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                                      int C, void* stream) {
@@ -1790,6 +1857,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre; a.gdn_gamma_lo = g_gdn_gamma_lo; a.y_hilo = g_y_hilo; a.y_abs = g_y_abs;
+    a.acc_scale = hilo ? g_hilo_acc_scale : 1.f;
     a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = cin_k; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
@@ -2145,7 +2213,14 @@ static int conv2d_forward_hilo_n(int products, const hesic_conv_desc* d, const v
     g_hilo = 0; g_y_hilo = g_y_abs = 0;
     g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
+    g_hilo_acc_scale = 1.f;                               // one launch only
     return rc;
+}
+
+extern "C" int hesic_conv2d_hilo_set_acc_scale(float scale) {
+    HESIC_CHECK_ARG(scale > 0.f && scale == scale && scale < 3.0e38f, "conv2d_hilo_set_acc_scale: a positive finite factor (a power of two) expected");
+    g_hilo_acc_scale = scale;
+    return 0;
 }
 
 extern "C" int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,

@@ -228,8 +228,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
             request(tile + tstride < ntiles ? tile + tstride : tile);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // binary16 build, pair output: the squares of this pixel are formed from v * 2^k, k from the pixel's largest |v| over its 128 channels
+        // (this lane's 64 and lane ^ 32's), beta' is added behind the contraction -- see the hi/lo (I)GDN epilogue of igemm_glds_kernel
+        // (conv_igemm.hip) for the why: fixed-scale squares of small activations are subnormal halves
+        constexpr bool DYN_SQ = HESIC_H16_IS_F16 && !OUT1;
+        [[maybe_unused]] float sq_c = 1.f, sq_inv = 1.f;
+        if constexpr (DYN_SQ) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[i][r]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            int ex = 0;
+            (void)frexpf(m, &ex);
+            int k = 7 - ex;
+            k = k > 40 ? 40 : (k < -24 ? -24 : k);
+            sq_c = ldexpf(1.f, k);
+            sq_inv = ldexpf(1.f, -6 - 2 * k);                   // gamma' is packed times 64 (H16_SQ_UNSCALE)
+        }
         f32x16 nrm[4];
-        if constexpr (OUT1) {
+        if constexpr (DYN_SQ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[i][r] = 0.f;
+        } else if constexpr (OUT1) {
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -257,7 +281,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sq_scale = OUT1 ? 1.f : H16_SQ_SCALE;
-                    const float s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e] * sq_scale, s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1] * sq_scale;
+                    float s0, s1;
+                    if constexpr (DYN_SQ) {
+                        const float u0 = acc[si][so + 2 * e] * sq_c, u1 = acc[si][so + 2 * e + 1] * sq_c;
+                        s0 = u0 * u0; s1 = u1 * u1;
+                    } else {
+                        s0 = acc[si][so + 2 * e] * acc[si][so + 2 * e] * sq_scale; s1 = acc[si][so + 2 * e + 1] * acc[si][so + 2 * e + 1] * sq_scale;
+                    }
                     split2(s0, s1, qh[e], ql[e]);
                 }
                 fq[set][0] = __builtin_bit_cast(h16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
@@ -293,6 +323,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
         }
         N2W_T(5);
         // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc
+        if constexpr (DYN_SQ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 be = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(beta_rs, (int)(pofs + (uint32_t)((i * 32 + 8 * g) * 4)), 0, 0));
+                    nrm[i][4 * g] = fmaf(nrm[i][4 * g], sq_inv, be.x); nrm[i][4 * g + 1] = fmaf(nrm[i][4 * g + 1], sq_inv, be.y);
+                    nrm[i][4 * g + 2] = fmaf(nrm[i][4 * g + 2], sq_inv, be.z); nrm[i][4 * g + 3] = fmaf(nrm[i][4 * g + 3], sq_inv, be.w);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -358,11 +398,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
 //           gamma'[i][16 ks + 8 + 4 h + 0..3] -- the order in which a lane of the GDN contraction holds its squares
 // ``shaped``: the hi half of a conv weight is its 16-bit rounding WITH error feedback over the 25 taps of its (cout, cin) pair (serpentine
 // walk, as pack_weight_shaped_kernel) -- for the two-product form of the kernel (OUT1), which multiplies w_hi only.
-__global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img, int shaped) {
+__global__ void n2w_hilo_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, unsigned char* __restrict__ img, int shaped,
+                                     float wscale = 1.f) {
     // the single-output form (shaped != 0) works on conv values scaled by sqrt(H16_SQ_SCALE) (a power of two: exact), so that their squares
     // are the scaled squares without a multiply per value: conv weights x that factor, gamma' plain (scale and unscale cancel), bias and
     // beta' scaled inside the kernel
-    const float wsc = shaped ? H16_SQ_ROOT : 1.f, gsc = shaped ? 1.f : H16_SQ_UNSCALE;
+    // wscale (a power of two; pair form only): the conv weights go in as (w * wscale)_hi | (w * wscale)_lo so that the lo half of a small weight
+    // is a normal half; the caller passes bias * wscale and beta' * wscale^2 -- GDN's output v / sqrt(beta' + sum gamma' v^2) does not change
+    const float wsc = shaped ? H16_SQ_ROOT : wscale, gsc = shaped ? 1.f : H16_SQ_UNSCALE;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 4096) return;
     float v[8];
@@ -416,6 +459,12 @@ extern "C" int hesic_sconv_pack_weight_image_hilo(const float* w, const float* g
     HESIC_CHECK_ARG(w && gamma && image, "sconv_pack_weight_image_hilo: null pointer");
     hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image, 0);
     HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo");
+}
+
+extern "C" int hesic_sconv_pack_weight_image_hilo_scaled(const float* w, const float* gamma, float wscale, void* image, void* stream) {
+    HESIC_CHECK_ARG(w && gamma && image && wscale > 0.f && wscale < 3.0e38f, "sconv_pack_weight_image_hilo_scaled: null pointer or bad scale");
+    hipLaunchKernelGGL(n2w_hilo_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, gamma, (unsigned char*)image, 0, wscale);
+    HESIC_LAUNCH_RETURN("sconv_pack_weight_image_hilo_scaled");
 }
 
 extern "C" int hesic_sconv_pack_weight_image_hilo_out1(const float* w, const float* gamma, void* image, void* stream) {

@@ -983,6 +983,24 @@ def analysis_conv2_single():
     return analysis_precision() == "x3c2"
 
 
+PAIR_WEIGHT_SCALING = _os.environ.get("HESIC_PAIR_WEIGHT_SCALING", "1") != "0"      # A/B switch (round 5)
+
+
+def _pair_weight_shift(w):
+    """Power-of-two exponent s for packing a weight as the pair (w 2^s)_hi | (w 2^s)_lo.  binary16 only: the lo half of an unscaled weight of
+    0.02 is 5e-6 -- a SUBNORMAL half (step 6e-8), so the pair carries 2^-20 instead of 2^-22 and a 128 -> 128 5x5 layer's output is
+    ~1e-6 relative off, the largest single term of the pair mode's flipped latents (profiles/scripts/gdn_pair_precision.py).  With the
+    largest |w| brought to [2^13, 2^14) every weight down to 2^-17 of it keeps a normal lo half; the kernel multiplies its accumulators by
+    2^-s once (exact).  bfloat16 has fp32's range: s = 0.  One device -> host sync per repack (inference packs are cached)."""
+    if not PAIR_WEIGHT_SCALING or _h16() != torch.float16 or not w.is_cuda:
+        return 0
+    m = float(w.abs().max())
+    if not (m > 0.0) or m != m or m == float("inf"):
+        return 0
+    import math
+    return max(0, min(24, 13 - math.frexp(m)[1] + 1))
+
+
 class PackedWeightHiLo:
     """[w_hi | w_lo] (bf16, the kernels' [tap][Cout][2 Cin] layout) of a conv weight; inference cache keyed like ``PackedWeight``.
     ``as_1x1``: flatten (Cout, Cin, k, k) to a 1x1 weight over the im2col columns, zero-padded to ``kp`` columns."""
@@ -1009,12 +1027,16 @@ class PackedWeightHiLo:
             cout = w.shape[0]
             flat = w.reshape(cout, -1)
             w = torch.cat([flat, flat.new_zeros(cout, kp - flat.shape[1])], 1).reshape(cout, kp, 1, 1)
+        sh = _pair_weight_shift(w)
+        if sh:
+            w = w * float(2 ** sh)
         hi = w.to(_h16()).float()
         lo = (w - hi).to(_h16()).float()
         w2 = torch.cat([hi, lo], 1).contiguous()
         cout, cin2, kh, kw = w2.shape
         wp = torch.empty(kh * kw * cout * cin2, dtype=_h16(), device=w2.device)
         L.call("hesic_pack_conv_weight", L.ptr(w2), None, L.ptr(wp), cout, cin2, kh, kw, 0, 0, L.H16, L.stream())
+        wp.hesic_acc_scale = float(2.0 ** -sh)          # conv2d_hilo hands it to the launch (hesic_conv2d_hilo_set_acc_scale)
         self._hit = (tag, wp)
         return wp
 
@@ -1048,8 +1070,15 @@ class PackedN2wHiLo:
         if hit is not None and hit[0] == tag:
             return hit[1]
         img = torch.empty(128 * 1024, dtype=torch.uint8, device=weight.device)
-        L.call("hesic_sconv_pack_weight_image_hilo_out1" if out1 else "hesic_sconv_pack_weight_image_hilo", L.ptr(_c(weight)), L.ptr(_c(gamma)),
-               L.ptr(img), L.stream())
+        sh = 0 if out1 else _pair_weight_shift(weight.detach().float())
+        if sh:
+            # pair form, binary16: weights times 2^s in the image (normal lo halves); sconv_gdn_hilo then passes bias 2^s and beta' 4^s
+            L.call("hesic_sconv_pack_weight_image_hilo_scaled", L.ptr(_c(weight)), L.ptr(_c(gamma)), float(2 ** sh), L.ptr(img), L.stream())
+        else:
+            L.call("hesic_sconv_pack_weight_image_hilo_out1" if out1 else "hesic_sconv_pack_weight_image_hilo", L.ptr(_c(weight)), L.ptr(_c(gamma)),
+                   L.ptr(img), L.stream())
+        img.hesic_wscale = float(2 ** sh)
+        img.hesic_scaled = {}                              # (tensor address, version) -> the scaled copy of bias / beta'
         self._hit[out1] = (tag, img)
         return img
 
@@ -1064,6 +1093,19 @@ def sconv_gdn_hilo(x, image, bias, beta_packed, inverse, out1=False):
     """GDN(conv(x)) of the 3 -> 128 5x5 stride-2 stage on hi/lo pairs in one kernel: (B, 256, H/2, W/2) [hi | lo] 16-bit NHWC;
     ``out1``: the same arithmetic, but the output is ONE 16-bit value per channel, (B, 128, H/2, W/2)."""
     L.require_cuda(x)
+    wsc = getattr(image, "hesic_wscale", 1.0)
+    if wsc != 1.0:
+        def scaled(t, f):
+            if t is None:
+                return None
+            key = (t.data_ptr(), t._version, f)
+            hit = image.hesic_scaled.get(key)
+            if hit is None:
+                if len(image.hesic_scaled) > 8:
+                    image.hesic_scaled.clear()
+                hit = image.hesic_scaled[key] = (t.detach().float() * f).contiguous()
+            return hit
+        bias, beta_packed = scaled(bias, wsc), scaled(beta_packed, wsc * wsc)
     B, Cc, H, W = x.shape
     Ho, Wo = _out_hw(H, W, 5, 2, 2, False)
     y = _empty_nhwc(B, 128 if out1 else 256, Ho, Wo, _h16(), x.device)
@@ -1120,10 +1162,13 @@ def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, g
     Ho, Wo = _out_hw(H, W, k, stride, padding, False)
     x_hilo = _nhwc(x_hilo)
     entry = "hesic_conv2d_forward_hilo_w1" if products == 2 else "hesic_conv2d_forward_hilo"      # ``products`` = 2: ``wp3`` from PackedWeightHiLo.get(single=True)
+    acc_scale = getattr(wp3, "hesic_acc_scale", 1.0)            # weights packed times 2^s (PackedWeightHiLo): the launch unscales its sums
     if gdn is not None:
         gp, glo, bp, inverse = gdn
         y = _empty_nhwc(B, 2 * cout, Ho, Wo, _h16(), x_hilo.device)
         d = L.ConvDesc(B, H, W, cin, Ho, Wo, cout, k, k, stride, padding, 0, L.H16, 0, 0, c2, 0, 2 * cout, 0, 0)
+        if acc_scale != 1.0:
+            L.call("hesic_conv2d_hilo_set_acc_scale", acc_scale)
         L.call(entry, C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), L.ptr(gp), L.ptr(glo), L.ptr(bp), int(inverse),
                L.ptr(y), 0, None, 0, 0, None, 0, L.stream())
         return y
@@ -1135,6 +1180,8 @@ def conv2d_hilo(x_hilo, wp3, bias, cin, cout, *, kernel_size, stride, padding, g
     if need is None:
         need = _ws_bytes[key] = int(L.lib().hesic_conv2d_hilo_ws_bytes(C.byref(d)))
     ws = torch.empty(need, dtype=torch.uint8, device=x_hilo.device) if (need and SPLIT_K) else None
+    if acc_scale != 1.0:
+        L.call("hesic_conv2d_hilo_set_acc_scale", acc_scale)
     L.call(entry, C.byref(d), L.ptr(x_hilo), L.ptr(wp3), L.ptr(bias), None, None, None, 0, L.ptr(y), int(out_abs),
            L.ptr(y32), cout, 0, L.ptr(ws), need if ws is not None else 0, L.stream())
     return (y, y32) if out == "both" else (y if out == "hilo" else y32)

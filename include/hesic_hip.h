@@ -160,6 +160,9 @@ int hesic_conv2d_forward_hilo(const hesic_conv_desc* d, const void* x_hilo, cons
                               const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                               void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes,
                               void* stream);
+/* Pair weights packed times 2^s (see above; any of the hi/lo conv entry points): the NEXT hi/lo launch of the calling thread multiplies its
+ * accumulators by `scale` (= 2^-s) once, behind the K loop -- in front of bias, activation, the fused (I)GDN and the K-slice partials alike.  */
+int hesic_conv2d_hilo_set_acc_scale(float scale);
 /* Pairs x SINGLE weights (analysis mode "x3c2": g_a_conv3 / g_a_conv4): same arguments and layouts as hesic_conv2d_forward_hilo, but only
  * the first Cin values of every packed weight row are read -- the weights rounded to 16 bits with error feedback over the taps
  * (hesic_pack_conv_weight_shaped) -- and a pair costs TWO products (x_hi w + x_lo w); the fused (I)GDN stops at gamma'_hi (sq_hi + sq_lo).
@@ -262,6 +265,10 @@ int hesic_sconv2d_gdn_forward_hilo(const hesic_sconv_desc* d, const float* x, co
  * channels, ys_x >= 128).  Its rounding (2^-12) bounds what the arithmetic in front of it must deliver, so this form multiplies two
  * products per operand pair -- x and the squares as pairs, w and gamma' single -- with w rounded by error feedback over the taps:
  * image_hilo must come from hesic_sconv_pack_weight_image_hilo_out1 (same 128 KB layout; its lo halves are not read).               */
+/* Pair form with the conv weights packed times `wscale` (a power of two): in the binary16 build the lo half of a weight of 0.02 is a subnormal
+ * half (the pair then carries 2^-20 instead of 2^-22); with wscale = 2^s the caller hands hesic_sconv2d_gdn_forward_hilo bias * 2^s and
+ * beta_packed * 4^s -- GDN's output is unchanged (v / sqrt(beta' + sum gamma' v^2) is invariant under v -> 2^s v, beta' -> 4^s beta').        */
+int hesic_sconv_pack_weight_image_hilo_scaled(const float* w, const float* gamma, float wscale, void* image, void* stream);
 int hesic_sconv_pack_weight_image_hilo_out1(const float* w, const float* gamma, void* image_hilo, void* stream);
 int hesic_sconv2d_gdn_forward_hilo_out1(const hesic_sconv_desc* d, const float* x, const void* image_hilo, const float* bias,
                                         const float* beta_packed, int inverse, void* y, void* stream);

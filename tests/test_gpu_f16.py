@@ -222,3 +222,71 @@ def test_f16_pairs_do_not_depend_on_the_batch(kind):
         one = net(x1[-1:], x2[-1:], Hm[-1:])
     for k in ("y1_hat", "y2_hat", "x1_hat", "x2_hat"):
         assert torch.equal(out[k][-1:], one[k]), k
+
+
+@pytest.mark.parametrize("beta_v,sigma", [(1e-4, 0.03), (1e-2, 0.1), (1.0, 1.0)])
+def test_pair_gdn_keeps_its_precision_for_small_activations_and_small_beta(beta_v, sigma):
+    """binary16 pair GDN (the fused epilogue of the pair convs): the squares are scaled per PIXEL by a power of two chosen from the pixel's
+    largest |v| and beta' joins behind the contraction (round 5).  With the fixed 2^-6 of rounds 3-4 the squares of |v| < 0.0625 were
+    subnormal halves: beta' = 1e-4 with activations of 0.03 came out 1e-4 .. 1e-3 relative wrong, beta' = 1e-2 / 0.1 at 4e-6
+    (profiles/scripts/gdn_pair_precision.py).  Bar: the pair level, 1e-6 at the 99th percentile, in every regime."""
+    from compressai.layers import GDN
+    from compressai.models.utils import conv
+    from hesic_amd import functional as Fn
+    hesic_amd.set_compute_dtype(torch.float16)
+    Fn.set_analysis_precision("x3")
+    try:
+        torch.manual_seed(0)
+        C, S = 128, 64
+        layer = conv(C, C, stride=2).to(DEV)
+        g = GDN(C).to(DEV)
+        ped = 2.0 ** -36
+        with torch.no_grad():
+            layer.weight.zero_(); layer.bias.zero_()
+            for c in range(C):
+                layer.weight[c, c, 2, 2] = 1.0                                     # identity at the centre tap: the layer is a stride-2 pick
+            gam = torch.rand(C, C, device=DEV) * 2e-3 + torch.eye(C, device=DEV) * 0.1
+            g.beta.copy_(torch.full((C,), beta_v + ped, device=DEV).sqrt())
+            g.gamma.copy_((gam + ped).sqrt())
+            x = torch.randn(2, C, S, S, device=DEV) * sigma
+            hi = x.to(torch.float16)
+            lo = (x - hi.float()).to(torch.float16)
+            xh = torch.cat((hi, lo), 1).contiguous(memory_format=torch.channels_last)
+            y = layer.run_hilo(xh, gdn=g)
+            got = (y[:, :C].float() + y[:, C:].float()).double()
+            v = (hi.float() + lo.float())[:, :, ::2, ::2].double()
+            ref = v / ((g.beta.double() ** 2 - ped).view(1, C, 1, 1) + torch.einsum("ij,bjhw->bihw", g.gamma.double() ** 2 - ped, v * v)).sqrt()
+        rel = (got - ref).abs() / ref.abs().clamp_min(1e-30)
+        sel = ref.abs() > ref.abs().median()                                       # the larger half: a tiny output's own lo half is subnormal storage
+        assert float(rel[sel].quantile(0.99)) < 1e-6, (beta_v, sigma, float(rel[sel].median()), float(rel[sel].quantile(0.99)))
+    finally:
+        Fn.set_analysis_precision("auto")
+
+
+def test_pair_conv_keeps_its_precision_for_small_weights():
+    """binary16 pair weights are packed as (w 2^s)_hi | (w 2^s)_lo with the largest |w| in [2^13, 2^14) and the launch multiplies its sums
+    by 2^-s (round 5): the lo half of an unscaled 0.002 is a subnormal half and the pair carried 3e-5 relative (a 128 -> 128 5x5 layer
+    ~1e-6 off on weights of 0.02).  fp32 latent of a pair conv with weights of ~0.002 against fp64, relative to the output scale: 3e-7
+    measured (8.5e-6 with ``HESIC_PAIR_WEIGHT_SCALING=0``); bar 6e-7."""
+    from compressai.models.utils import conv
+    from hesic_amd import functional as Fn
+    hesic_amd.set_compute_dtype(torch.float16)
+    Fn.set_analysis_precision("x3")
+    try:
+        torch.manual_seed(1)
+        layer = conv(128, 192, stride=2).to(DEV)
+        with torch.no_grad():
+            layer.weight.copy_(torch.randn_like(layer.weight) * 0.002)
+            layer.bias.copy_(torch.randn_like(layer.bias) * 0.01)
+            x = torch.randn(2, 128, 32, 32, device=DEV) * 0.5
+            hi = x.to(torch.float16)
+            lo = (x - hi.float()).to(torch.float16)
+            xh = torch.cat((hi, lo), 1).contiguous(memory_format=torch.channels_last)
+            y32 = layer.run_hilo(xh, out="f32")
+            ref = torch.nn.functional.conv2d((hi.float() + lo.float()).double(), layer.weight.double(), layer.bias.double(), stride=2, padding=2)
+        err = float((y32.double() - ref).abs().max() / ref.abs().max())
+        assert err < 6e-7, err
+        wp = layer._packer_hl.get(layer.weight)
+        assert wp.hesic_acc_scale < 1.0 and wp.hesic_acc_scale == 2.0 ** round(__import__("math").log2(wp.hesic_acc_scale))       # a power of two, weights scaled up
+    finally:
+        Fn.set_analysis_precision("auto")
