@@ -15,6 +15,9 @@
 #ifndef HESIC_H16_IS_F16
 #define HESIC_H16_IS_F16 0
 #endif
+#ifndef HESIC_NO_DYN_SQ
+#define HESIC_NO_DYN_SQ 0     /* A/B builds only (-DHESIC_NO_DYN_SQ=1): the fixed 2^-6 scale of the pair (I)GDN squares of rounds 3-4 */
+#endif
 typedef uint16_t h16_t;   // raw bits of a 16-bit float (format: see above)
 #if HESIC_H16_IS_F16
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;

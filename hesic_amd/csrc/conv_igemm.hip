@@ -386,8 +386,12 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
     constexpr int LDS_BYTES = NS * STAGE > EPI_ALL ? NS * STAGE : EPI_ALL;
     // binary16 build, pair (I)GDN: the squares are scaled PER PIXEL (see the epilogue); the wave slices of a pixel exchange their maxima here
-    constexpr bool DYN_SQ = HESIC_H16_IS_F16 && GDN >= 3;
-    constexpr int XMAX_BYTES = DYN_SQ ? WM * BM * 4 : 0;
+    constexpr bool DYN_SQ = HESIC_H16_IS_F16 && !HESIC_NO_DYN_SQ && GDN >= 3;
+    // ... in the ring's spare room behind the two epilogue tiles when there is some (one more barrier, no more LDS: the <32,128,128> tile's ring
+    // is exactly 80 KB = two blocks per CU, 512 bytes on top halved its occupancy, 62.8 -> 97.8 us), else in 1 - 2 KB of their own
+    constexpr bool XMAX_IN_RING = DYN_SQ && (EPI_ALL + WM * BM * 4 <= NS * STAGE);
+    constexpr int XMAX_BYTES = (DYN_SQ && !XMAX_IN_RING) ? WM * BM * 4 : 0;
+    constexpr int XMAX_OFF = XMAX_IN_RING ? EPI_ALL : LDS_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + XMAX_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA bases go to M0
@@ -788,21 +792,26 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         // Powers of two throughout: no rounding of its own.  bfloat16 build: its range needs none of this (k = -3, as before).
         f32x16 nrm[MI][NI];
         [[maybe_unused]] float sq_c[NI], sq_inv[NI];
+        // beta' of this lane's channels is used behind the contraction: small tiles (registers to spare, one tile per block: the L2 round trip
+        // would sit in front of the output) request it here, the 128- / 256-pixel tiles (252+ registers) re-read it there
+        constexpr bool EARLY_BE = DYN_SQ && BM <= 64;
+        [[maybe_unused]] f32x4 beq[EARLY_BE ? MI : 1][4];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh;
                 const f32x4 t = a.bias ? *(const f32x4*)(a.bias + cl) : f32x4{0.f, 0.f, 0.f, 0.f};
-                [[maybe_unused]] f32x4 be = {0.f, 0.f, 0.f, 0.f};
+                f32x4 be = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (!DYN_SQ) be = *(const f32x4*)(a.gdn_beta + cl);
+                else if constexpr (EARLY_BE) beq[i][g] = *(const f32x4*)(a.gdn_beta + cl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) { acc[i][j][4 * g + e] += t[e]; nrm[i][j][4 * g + e] = be[e]; }
             }
         if constexpr (DYN_SQ) {
-            float* xmax = (float*)(smem + LDS_BYTES);                     // [WM][BM]: outside the ring, which slower waves may still be reading
+            float* xmax = (float*)(smem + XMAX_OFF);                      // [WM][BM]
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 float m = 0.f;
@@ -812,7 +821,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[i][j][r]));
                 m = fmaxf(m, __shfl_xor(m, 32));                          // the other 4-channel halves of the same pixel
                 sq_c[j] = m;
-                if (WM > 1 && fh == 0) xmax[wm * BM + wn * (BM / WN) + j * 32 + frow] = m;
+                // outside the ring it can be written now (slower waves may still be reading the ring); inside it, behind the barrier below
+                if (!XMAX_IN_RING && WM > 1 && fh == 0) xmax[wm * BM + wn * (BM / WN) + j * 32 + frow] = m;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -826,10 +836,17 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         }
         __builtin_amdgcn_sched_barrier(0);
         auto split2 = [](float p, float q, uint32_t& hi, uint32_t& lo) { split_h2(p, q, hi, lo); };
-        if constexpr (DYN_SQ) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... and the pixel maxima are visible
+        if constexpr (DYN_SQ && !XMAX_IN_RING) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... and the pixel maxima are visible
         else asm volatile("s_barrier" ::: "memory");                   // every wave is done reading the ring
+        if constexpr (XMAX_IN_RING && WM > 1) {
+            float* xmax = (float*)(smem + XMAX_OFF);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (fh == 0) xmax[wm * BM + wn * (BM / WN) + j * 32 + frow] = sq_c[j];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if constexpr (DYN_SQ) {
-            const float* xmax = (const float*)(smem + LDS_BYTES);
+            const float* xmax = (const float*)(smem + XMAX_OFF);
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 float m = sq_c[j];
@@ -923,7 +940,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
                     const int pr = wn * (BM / WN) + j * 32 + frow;
                     float v[4];
                     [[maybe_unused]] f32x4 be = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (DYN_SQ) be = *(const f32x4*)(a.gdn_beta + cl);      // L1 hits: 512 bytes per block
+                    if constexpr (EARLY_BE) be = beq[i][g];
+                    else if constexpr (DYN_SQ) be = *(const f32x4*)(a.gdn_beta + cl);      // L1 / L2 hits: 512 bytes per layer
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float n = DYN_SQ ? fmaf(nrm[i][j][4 * g + e], sq_inv[j], be[e]) : nrm[i][j][4 * g + e];

@@ -231,14 +231,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
         // binary16 build, pair output: the squares of this pixel are formed from v * 2^k, k from the pixel's largest |v| over its 128 channels
         // (this lane's 64 and lane ^ 32's), beta' is added behind the contraction -- see the hi/lo (I)GDN epilogue of igemm_glds_kernel
         // (conv_igemm.hip) for the why: fixed-scale squares of small activations are subnormal halves
-        constexpr bool DYN_SQ = HESIC_H16_IS_F16 && !OUT1;
+        constexpr bool DYN_SQ = HESIC_H16_IS_F16 && !HESIC_NO_DYN_SQ && !OUT1;
         [[maybe_unused]] float sq_c = 1.f, sq_inv = 1.f;
         if constexpr (DYN_SQ) {
             float m = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[i][r]));
+                for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(acc[i][r])), fabsf(acc[i][r + 1]));     // v_max3_f32 with |.| modifiers
             m = fmaxf(m, __shfl_xor(m, 32));
             int ex = 0;
             (void)frexpf(m, &ex);
@@ -249,10 +249,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
         }
         f32x16 nrm[4];
         if constexpr (DYN_SQ) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) nrm[i][r] = 0.f;
+            // started by the first k-step's MFMAs (zero C operand)
         } else if constexpr (OUT1) {
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -305,7 +302,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
                 if (ks + 1 < 8) prep((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (DYN_SQ && ks == 0) {      // the accumulators start at zero: an inline-constant C operand, no 64 moves per tile
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][0], z, 0, 0, 0);
+                    } else nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][0], nrm[i], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) nrm[i] = mfma_32x32x16_h16(gh[ks & 1][i], fq[ks & 1][1], nrm[i], 0, 0, 0);
                 if constexpr (!OUT1) {
