@@ -989,6 +989,26 @@ def main():
                 "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3), "other_conv_kernels": s["all"],
                 # the HBM-bound kernels of the path against the 8 TB/s peak (north_star: "achieved HBM GB/s for the warp")
                 "streaming_kernels": km.streaming}
+        # the warp alone, 20 launches back to back between ONE pair of HIP events: the single-launch bracket above carries ~4 us of launch
+        # latency on a ~12 us kernel (profiles/scripts/warp_time.py: 11.7 us from a graph)
+        try:
+            wk = next((k for k in km.streaming if k.startswith("warp_perspective")), None)
+            if wk is not None:
+                from hesic_amd import functional as Fn_
+                hw = x1.shape[-2:]
+                for _ in range(3):
+                    Fn_.warp_perspective(x1, Hm, tuple(hw))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    Fn_.warp_perspective(x1, Hm, tuple(hw))
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 20
+                by = km.streaming[wk]["bytes_per_launch"]
+                km.streaming[wk]["back_to_back"] = {"launches": 20, "avg_launch_us": round(us, 2), "achieved": round(by / us / 1e3, 1), "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4)}
+        except Exception as e:                     # a report line, never the reason a bench run fails
+            print(f"# warp back-to-back timing skipped: {e}", file=sys.stderr)
 
     if rank == 0:
         pairs = world * args.batch * args.steps
