@@ -1797,6 +1797,7 @@ static thread_local int g_hilo = 0;                      // set by hesic_conv2d_
 static thread_local const void* g_gdn_gamma_lo = nullptr;
 static thread_local int g_y_hilo = 0, g_y_abs = 0;
 static thread_local float g_hilo_acc_scale = 1.f;      // hesic_conv2d_hilo_set_acc_scale: consumed by the next hi/lo launch of this thread
+static thread_local float g_hilo_acc_scale_active = 1.f;      // ... the value that launch runs with (set and cleared by conv2d_forward_hilo_n)
 
 extern "C" int hesic_gdn_pack_params(const float* beta, const float* gamma, float beta_min, void* gamma_packed, float* beta_packed,
                                      int C, void* stream) {
@@ -1875,7 +1876,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.gdn_gamma = g_gdn_gamma; a.gdn_beta = g_gdn_beta; a.y_pre = g_y_pre; a.gdn_gamma_lo = g_gdn_gamma_lo; a.y_hilo = g_y_hilo; a.y_abs = g_y_abs;
-    a.acc_scale = hilo ? g_hilo_acc_scale : 1.f;
+    a.acc_scale = hilo ? g_hilo_acc_scale_active : 1.f;
     a.y32 = g_y32; a.y32_ps = g_y32_ps; a.y32_co = g_y32_co;
     const int gdn = g_gdn_mode;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = cin_k; a.x_ps = d->x_pix_stride; a.x_co = d->x_c_off;
@@ -2212,6 +2213,10 @@ extern "C" int hesic_pack_conv_weight_slice(const float* w, void* wp, int Cout, 
 static int conv2d_forward_hilo_n(int products, const hesic_conv_desc* d, const void* x_hilo, const void* w_packed_hilo, const float* bias,
                                          const void* gamma_packed, const void* gamma_lo_packed, const float* beta_packed, int inverse,
                                          void* y_hilo, int y_abs, float* y_f32, int y32_pix_stride, int y32_c_off, void* ws, size_t ws_bytes, void* stream) {
+    // the accumulator scale named for THIS launch (hesic_conv2d_hilo_set_acc_scale) is taken and cleared first: a call refused by one of the
+    // checks below must not leave it behind for an unrelated later launch
+    const float acc_scale_now = g_hilo_acc_scale;
+    g_hilo_acc_scale = 1.f;
     HESIC_CHECK_ARG(d && x_hilo && w_packed_hilo && (y_hilo || y_f32), "conv2d_forward_hilo: null pointer");
     HESIC_CHECK_ARG(d->dtype == HESIC_H16 && !d->in_abs, "conv2d_forward_hilo: bf16 storage, no |x| on load (use y_abs on the producer)");
     const bool gdn = gamma_packed != nullptr;
@@ -2222,6 +2227,7 @@ static int conv2d_forward_hilo_n(int products, const hesic_conv_desc* d, const v
     HESIC_CHECK_ARG(!y_f32 || (y32_c_off % 4 == 0 && y32_pix_stride % 4 == 0 && y32_c_off + d->Cout <= y32_pix_stride),
                     "conv2d_forward_hilo: fp32 channel slice must be 16-byte aligned and in range");
     g_hilo = products == 2 ? 2 : 1;
+    g_hilo_acc_scale_active = acc_scale_now;
     g_gdn_gamma = gamma_packed; g_gdn_gamma_lo = gamma_lo_packed; g_gdn_beta = beta_packed; g_gdn_mode = gdn ? (inverse ? 4 : 3) : 0;
     g_y32 = y_f32; g_y32_ps = y32_pix_stride; g_y32_co = y32_c_off;
     g_y_hilo = (!gdn && y_hilo) ? 1 : 0; g_y_abs = y_abs ? 1 : 0;
@@ -2231,7 +2237,7 @@ static int conv2d_forward_hilo_n(int products, const hesic_conv_desc* d, const v
     g_hilo = 0; g_y_hilo = g_y_abs = 0;
     g_gdn_gamma = nullptr; g_gdn_gamma_lo = nullptr; g_gdn_beta = nullptr; g_gdn_mode = 0;
     g_y32 = nullptr; g_y32_ps = g_y32_co = 0;
-    g_hilo_acc_scale = 1.f;                               // one launch only
+    g_hilo_acc_scale_active = 1.f;                        // one launch only
     return rc;
 }
 

@@ -290,3 +290,33 @@ def test_pair_conv_keeps_its_precision_for_small_weights():
         assert wp.hesic_acc_scale < 1.0 and wp.hesic_acc_scale == 2.0 ** round(__import__("math").log2(wp.hesic_acc_scale))       # a power of two, weights scaled up
     finally:
         Fn.set_analysis_precision("auto")
+
+
+def test_accumulator_scale_of_a_refused_pair_launch_does_not_leak_into_the_next_one():
+    """``hesic_conv2d_hilo_set_acc_scale`` names the factor for the NEXT hi/lo launch of the thread.  A launch the argument checks refuse must
+    still consume it: the following, unrelated launch runs unscaled."""
+    import ctypes as C
+    from compressai.models.utils import conv
+    from hesic_amd import _lib as L
+    from hesic_amd import functional as Fn
+    hesic_amd.set_compute_dtype(torch.float16)
+    Fn.set_analysis_precision("x3")
+    try:
+        torch.manual_seed(2)
+        layer = conv(128, 128, stride=2).to(DEV)
+        x = torch.randn(1, 128, 16, 16, device=DEV) * 0.5
+        hi = x.to(torch.float16)
+        xh = torch.cat((hi, (x - hi.float()).to(torch.float16)), 1).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            want = layer.run_hilo(xh, out="f32").clone()
+        L.call("hesic_conv2d_hilo_set_acc_scale", 0.25)
+        d = L.ConvDesc(1, 16, 16, 128, 8, 8, 128, 5, 5, 2, 2, 0, L.H16, 0, 0, 256, 0, 128, 0, 0)
+        with pytest.raises(RuntimeError, match="null pointer"):
+            L.call("hesic_conv2d_forward_hilo", C.byref(d), None, None, None, None, None, None, 0, None, 0, None, 0, 0, None, 0, L.stream())
+        with torch.no_grad():
+            got = layer.run_hilo(xh, out="f32")
+        assert torch.equal(got, want)
+        with pytest.raises(RuntimeError, match="positive finite"):
+            L.call("hesic_conv2d_hilo_set_acc_scale", 0.0)
+    finally:
+        Fn.set_analysis_precision("auto")
