@@ -90,8 +90,10 @@ def test_batched_finish_rejects_two_jobs_on_one_gradient():
 
 
 def test_trainer_step_is_the_same_with_and_without_the_batched_finish():
-    """One Trainer.step from the same state with the finishing passes batched (default) and one per layer: identical weight
-    gradients up to the bias atomics, i.e. parameters after Adam agree to 1e-6 relative."""
+    """One Trainer.step from the same state through the queued route (default: split-K launches in shared grids with their own K-slice
+    counts, batched finishing passes) and with one launch pair per layer: the same weight gradients up to the summation order of the K
+    slices and the scatter-adds of the warp's backward (run to run ~5e-7 of the largest gradient, profiles/scripts/train_determinism.py;
+    between the routes up to ~1e-5 was seen once in a dozen runs): 5e-5 of the largest gradient, parameters after Adam likewise."""
     import hesic_amd
     from hesic_amd import functional as Fn, models, train
     hesic_amd.set_compute_dtype(torch.bfloat16)
@@ -118,10 +120,10 @@ def test_trainer_step_is_the_same_with_and_without_the_batched_finish():
     (l0, g0, p0), (l1, g1, p1) = outs
     assert l0 == l1
     assert float(g1.abs().max()) > 0
-    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float((g0 - g1).abs().max()) <= 5e-5 * float(g1.abs().max())
     # parameters after the first Adam step move by lr * g / (|g| + eps): compared where the gradient is not within rounding of zero
     big = g1.abs() > 1e-4 * float(g1.abs().max())
-    assert float((p0 - p1)[big].abs().max()) <= 1e-5 * float(p1.abs().max())
+    assert float((p0 - p1)[big].abs().max()) <= 5e-5 * float(p1.abs().max())
 
 
 def test_batched_gdn_param_finish_equals_the_per_layer_backward():
