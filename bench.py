@@ -327,7 +327,7 @@ def cpu_baseline(kind, P_cpu, size, budget_s=12.0, parity_pairs=1):
         # parameters; the product runs it on single 16-bit operands (error-feedback weights), so its flips are reported separately
         with torch.no_grad():
             m["y1_hat_w"] = torch.round(O.g_a(P_cpu, "encoder1.", O.warp_perspective(out["x1_hat"], Hm, x1.shape[-2:], True))).to(torch.int16)
-    # the other distinct pairs of the timed batch (it tiles four): the parity block reports the set average the reference's own
+    # the other distinct pairs of the timed batch: the parity block reports the set average the reference's own
     # evaluation reports (test3real.py:110-122) next to every pair
     m["more"] = []
     for j in range(1, parity_pairs):
@@ -644,10 +644,8 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed, ranks_info = job_time(elapsed, world, dev, args.batch * args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
         dist.all_reduce(acc)
     if rank == 0:
         pairs = world * args.batch * args.steps
@@ -676,7 +674,7 @@ def sweep_main(args, batch, rank, world, dev, H_img, W_img):
                        "pairs_per_step": world * args.batch, "sharding": f"one (lambda-model, batch) unit per rank and step over {world} GPU(s), no collective on the path",
                        "lambdas": list(SWEEP_LAMBDAS)},
             "model_tflops": round(pairs * gflop_per_pair(args.model, x1p.shape[-2], x1p.shape[-1]) / elapsed / 1e3, 2),
-            "per_lambda": per, "roofline": roof, "cpu_baseline": None})
+            "per_lambda": per, "roofline": roof, "cpu_baseline": None, **({"ranks": ranks_info} if ranks_info else {})})
     if world > 1:
         dist.destroy_process_group()
 
@@ -710,10 +708,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, ranks_info = job_time(elapsed, world, dev, args.batch * args.steps)
     losses = {k: float(v) for k, v in crit.items()}
 
     # roofline of the weight-gradient MFMA kernel, measured live (eager steps, events on the launch stream); launch census.
@@ -796,16 +791,48 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
             res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
         else:
             res["cpu_baseline"] = None
+        if ranks_info is not None:
+            res["ranks"] = ranks_info
         emit_line(res)
     if world > 1 or force:
         dist.destroy_process_group()
 
 
+def job_time(elapsed, world, dev, units_per_rank, unit="pairs_per_s"):
+    """(the job's time = the slowest rank's, a `ranks` block for the JSON line): every rank's own wall time of the timed region is gathered,
+    and the communicator says what it is (backend `nccl` = RCCL on ROCm) and how many ranks it holds."""
+    if world == 1:
+        return elapsed, None
+    import torch.distributed as dist
+    mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per_rank = [float(v) for v in every]
+    return max(per_rank), {"backend": dist.get_backend(), "nranks": dist.get_world_size(),
+                           "per_rank_" + unit: [round(units_per_rank / v, 1) for v in per_rank]}
+
+
+def self_launch(n, argv=None):
+    """Re-run this command line as ``n`` ranks of ONE node: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <same flags>``.  Returns the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *(sys.argv[1:] if argv is None else argv)]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)      # >= 0.5 s of timed region at the default workload
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU per step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--height", type=int, default=None, help="non-square workloads (e.g. 860x1080, zero-padded to x64)")
@@ -837,6 +864,11 @@ def main():
                          "(Python + ctypes per launch), a HIP-graph replay none but the runtime orders parallel branches its own way. "
                          "auto = time a few steps of both during warm-up and keep the faster")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start N ranks of this same command under torch.distributed.run (one process per GPU,
+        # RCCL over xGMI; 127.0.0.1 rendezvous -- the container hostname may not resolve) and hand their exit code on.  Rank 0 of
+        # the child job prints the ONE JSON line.
+        raise SystemExit(self_launch(args.gpus))
 
     import hesic_amd
     from hesic_amd import functional as Fn, geometry, models, synthetic
@@ -869,7 +901,7 @@ def main():
     net = net.to(dev).eval()
 
     # synthetic pairs: rank r gets pairs [r*B, (r+1)*B); one generated pair set is tiled if B is large
-    uniq = min(args.batch, 4)
+    uniq = min(args.batch, 8)          # round 6: every pair of the timed C2 batch is a distinct pair (rounds 1-5 tiled four)
     H_img, W_img = args.height or args.size, args.width or args.size
     x1, x2, Hm = synthetic.stereo_batch(rank * uniq, uniq, H_img, W_img)
     reps = -(-args.batch // uniq)
@@ -950,10 +982,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, ranks_info = job_time(elapsed, world, dev, args.batch * args.steps)
     m_gpu = models.metrics_from(rd)
 
     # roofline of the dominant kernel, measured live with HIP events on the launch stream
@@ -1026,9 +1055,11 @@ def main():
             "roofline": roof,
             "gpu_metrics_last_batch": {"bpp": round(m_gpu["bpp"], 5), "psnr": round(m_gpu["psnr"], 4)},
         }
+        if ranks_info is not None:
+            res["ranks"] = ranks_info
         if world == 1 and not args.no_cpu_baseline:
             square = not (args.height or args.width)
-            npar = min(4, args.batch) if square else 1          # the timed batch tiles min(batch, 4) distinct pairs
+            npar = min(8, args.batch) if square else 1          # every distinct pair of the timed batch
             base, m_cpu = cpu_baseline(args.model, P_cpu, args.size if square else 512, parity_pairs=npar)
             res["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in base.items()}
             per_pair = []

@@ -43,3 +43,26 @@ def test_two_rank_training_with_reduce_scatter_all_gather_matches_the_all_reduce
         # run to run (profiles/scripts/train_determinism.py), and three Adam steps at random-init weights amplify that to a few 1e-3 of the
         # rate term -- the exact value equality of the two collectives is the gloo test's job (tests/test_dp_gloo.py); here: same trajectory
         assert va == va and vb == vb and abs(va - vb) <= 1e-2 * abs(va) + 1e-6, (k, va, vb)
+
+
+def _run_self(*flags, env_extra=None):
+    """``python bench.py --gpus 2 ...`` with NO launcher around it (the driver's command shape): bench.py starts its own ranks."""
+    env = dict(os.environ, HESIC_DIST_BACKEND="gloo", HESIC_SINGLE_DEVICE="1", **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *flags]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    d = _run_self("--batch", "2", "--size", "256")
+    assert d["n_gpus"] == 2 and d["config"]["pairs_per_step"] == 4 and d["value"] > 0
+    assert d["ranks"]["nranks"] == 2 and len(d["ranks"]["per_rank_pairs_per_s"]) == 2 and d["ranks"]["backend"] == "gloo"
+    t = _run_self("--mode", "train", "--batch", "2", "--size", "256")
+    assert t["n_gpus"] == 2 and t["config"]["global_batch"] == 4 and t["ranks"]["nranks"] == 2 and t["comm"] is not None
+    s = _run_self("--sweep", "--batch", "1", "--height", "128", "--width", "192")
+    assert s["n_gpus"] == 2 and s["ranks"]["nranks"] == 2 and len(s["per_lambda"]) == 4
