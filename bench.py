@@ -451,7 +451,7 @@ def secondary_modes(dev, oracle_pairs, size=512):
     return out
 
 
-def secondary_sweep_and_path_a(dev, size=512):
+def secondary_sweep_and_path_a(dev, size=512, oracle_pairs=None):
     """BASELINE config C5 through ``evaluate.LambdaSweep`` (four lambda-models on 860 x 1080 pairs padded to 896 x 1088, B = 4 per step) for
     HESIC and HESIC+, and INTEGRATION.md path A -- the reference's own call order over the drop-in modules (``hesic_amd.path_a``), plain NCHW
     tensors between modules, no fused schedule -- for HESIC at 8 x 512^2: pairs/s each, in the headline's dtype."""
@@ -478,11 +478,27 @@ def secondary_sweep_and_path_a(dev, size=512):
 
         def fwd_a(i):
             with torch.no_grad():
-                return path_a.hsic_forward(net, a, b, h)
-        ms = 1e3 * _timed_loop(fwd_a, 6, 15)
-        out["path_a_hesic_b8"] = {"value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3),
-                                  "note": "the reference's call order (newnet1.py:724-783) over the drop-in compressai modules, one C-ABI call per module, "
-                                          "single 16-bit operands and 16-bit latents at every module boundary; parity: tests/test_gpu_path_a.py"}
+                return models.rate_distortion(path_a.hsic_forward(net, a, b, h), a, b)        # the same step as the headline: forward + bits / squared error
+        ms = 1e3 * _timed_loop(fwd_a, 8, 20)
+        rec = {"value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "issue": "eager, one stream",
+               "analysis": Fn.analysis_precision(),
+               "note": "the reference's call order (newnet1.py:724-783) over the drop-in compressai modules, every module's output handed to the next "
+                       "as it is; round 6: the modules hand over among themselves at inference (hesic_amd/handover.py: deferred conv -> GDN fusion, "
+                       "hi/lo pairs and fp32 latents between consecutive modules), HESIC_NO_HANDOVER=1 = round 5's literal launches; "
+                       "parity bars: tests/test_gpu_path_a.py"}
+        if oracle_pairs:
+            per = []
+            for j, mc in enumerate(oracle_pairs):
+                with torch.no_grad():
+                    oj = path_a.hsic_forward(net, a[j:j + 1], b[j:j + 1], h[j:j + 1])
+                    mj = models.metrics_from(models.rate_distortion(oj, a[j:j + 1], b[j:j + 1]))
+                fl = max(float((oj[k].float().cpu().to(torch.int16) != v).float().mean()) for k, v in mc["y_hat"].items())
+                per.append((mj["bpp"] - mc["bpp"], mj["psnr"] - mc["psnr"], fl))
+            npar = len(per)
+            rec["parity"] = {"abs_dbpp": float("%.3g" % abs(sum(q[0] for q in per) / npar)), "abs_dpsnr_db": float("%.3g" % abs(sum(q[1] for q in per) / npar)),
+                             "latent_flips_worst_pair": float("%.3g" % max(q[2] for q in per)),
+                             "worst_pair_abs_dbpp": float("%.3g" % max(abs(q[0]) for q in per)), "pairs": npar}
+        out["path_a_hesic_b8"] = rec
         del net
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
@@ -1120,7 +1136,7 @@ def main():
             # round 5: the other modes of C2 with their parity, the C5 sweep, path A and the training step with RCCL in the graph (~15 s)
             if not args.no_cpu_baseline and args.dtype != "f32":
                 res["secondary"]["c2_other_modes"] = secondary_modes(dev, [m_cpu] + m_cpu["more"])
-            res["secondary"].update(secondary_sweep_and_path_a(dev))
+            res["secondary"].update(secondary_sweep_and_path_a(dev, oracle_pairs=None if args.no_cpu_baseline or args.dtype == "f32" else [m_cpu] + m_cpu["more"]))
             res["secondary"]["train_step_hesic_b8_rccl_1rank"] = secondary_train_rccl(dev, lmbda=args.lmbda)
         emit_line(res)
     if world > 1:

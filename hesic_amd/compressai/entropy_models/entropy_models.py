@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from compressai._CXX import pmf_to_quantized_cdf as _pmf_to_quantized_cdf
 from compressai.ops import LowerBound
 from hesic_amd import functional as Fn
+from hesic_amd import handover as _ho
 
 
 class _EntropyCoder:
@@ -82,6 +83,13 @@ class EntropyModel(nn.Module):
         """'noise': x + U(-1/2,1/2); 'dequantize': round(x-mu)+mu; 'symbols': int32 round(x-mu)."""
         if mode not in ("noise", "dequantize", "symbols"):
             raise ValueError(f'Invalid quantization mode: "{mode}"')
+        if _ho.is_carrier(inputs):
+            # inference hand-over (hesic_amd/handover.py): the latent comes from the conv's fp32 accumulators and is rounded in fp32, its
+            # integer values stored in the 16-bit format for the convs that read them (models._round_latent)
+            if mode == "dequantize" and means is None and Fn.fp32_latents():
+                return Fn.round_to(inputs.f32(), Fn.compute_dtype())
+            inputs = inputs.plain()
+        means = _ho.plain(means) if means is not None else None
         if mode == "noise":
             return inputs + self._noise_like(inputs)
         if inputs.is_cuda and inputs.dim() == 4 and inputs.dtype in (torch.float32, torch.bfloat16, torch.float16):
@@ -272,6 +280,14 @@ class EntropyBottleneck(EntropyModel):
     def forward(self, x):
         if len(self.filters) != 4 or any(f != 3 for f in self.filters):
             raise NotImplementedError("hesic_amd EntropyBottleneck kernel is specialised for filters=(3,3,3,3)")
+        if _ho.active(x) and not self.training:
+            # inference hand-over: z from the producing conv's fp32 accumulators; z_hat goes on as a Carrier so that the bilinear
+            # up-sampling + cat in front of gmm_hyper_y2 (newnet1.py:556-557) can be recorded
+            z = _ho.f32_of(x) if Fn.fp32_latents() else _ho.plain(x)
+            od = Fn.compute_dtype() if (z.dtype == torch.float32 and Fn.fp32_latents()) else None
+            z_hat, lik = self.forward_with_noise(z, None, out_dtype=od)
+            return _ho.value(z_hat), lik
+        x = _ho.plain(x)
         noise = self._noise_like(x) if self.training else None
         return self.forward_with_noise(x, noise)
 
@@ -359,6 +375,20 @@ class _GaussianBase(EntropyModel):
         return self.lower_bound_scale.value()
 
 
+def _handed_over(model, inputs, scales, means, out_dtype):
+    """Inference hand-over (hesic_amd/handover.py): latents and parameter maps that arrive as Carriers are taken from their producers' fp32
+    accumulators, and y_hat is stored in the 16-bit format (``out_dtype``) -- what ``models.HSIC._forward_eval`` asks for explicitly."""
+    if not any(_ho.is_carrier(t) for t in (inputs, scales, means)):
+        return inputs, scales, means, out_dtype
+    if not model.training and Fn.fp32_latents():
+        inputs, scales = _ho.f32_of(inputs), _ho.f32_of(scales)
+        means = _ho.f32_of(means) if means is not None else None
+        if out_dtype is None and inputs.dtype == torch.float32:
+            out_dtype = Fn.compute_dtype()
+        return inputs, scales, means, out_dtype
+    return _ho.plain(inputs), _ho.plain(scales), (_ho.plain(means) if means is not None else None), out_dtype
+
+
 class GaussianConditional(_GaussianBase):
     r"""Gaussian conditional layer (reference :433-562): y_hat = round(y-mu)+mu (eval) or y+U (train),
     likelihood = Phi((1/2-|y_hat-mu|)/s) - Phi((-1/2-|y_hat-mu|)/s), s = max(scale, bound)."""
@@ -378,6 +408,7 @@ class GaussianConditional(_GaussianBase):
         return self._standardized_cumulative((.5 - values) / scales) - self._standardized_cumulative((-.5 - values) / scales)
 
     def forward(self, inputs, scales, means=None, noise=None, out_dtype=None):
+        inputs, scales, means, out_dtype = _handed_over(self, inputs, scales, means, out_dtype)
         if self.training and noise is None:
             noise = self._noise_like(inputs)
         lb = self.likelihood_bound if self.use_likelihood_bound else 0.0
@@ -408,6 +439,8 @@ class GaussianMixtureConditional(_GaussianBase):
         return likelihood
 
     def forward(self, inputs, scales, means=None, weights=None, noise=None, out_dtype=None):
+        inputs, scales, means, out_dtype = _handed_over(self, inputs, scales, means, out_dtype)
+        weights = _ho.plain(weights) if weights is not None else None
         if self.training and noise is None:
             noise = self._noise_like(inputs)
         lb = self.likelihood_bound if self.use_likelihood_bound else 0.0

@@ -5,6 +5,7 @@ import torch.nn as nn
 from compressai.models.utils import HipConv2d
 from hesic_amd import _lib as L
 from hesic_amd import functional as Fn
+from hesic_amd import handover as _ho
 
 from .gdn import GDN
 
@@ -36,6 +37,8 @@ class MaskedConv2d(HipConv2d):
 
     def forward(self, x):
         self._fold_mask()
+        if _ho.active(x):
+            return _ho.conv(self, x)
         return self.run(x, mask=self.mask, tap_mask=self._tap_mask)
 
     def forward_into(self, x, out, c_off):
@@ -72,6 +75,7 @@ class ResidualBlock(nn.Module):
     def forward(self, x, outer_skip=None):
         """``outer_skip``: an extra tensor added to the result (the Enhancement_Block's ``+ x``, newnet1.py:286), fused
         into the last conv's epilogue on the 32-channel inference path."""
+        x = _ho.plain(x)
         if self.skip is None and Fn.conv3x3_c32_ok(x, self.conv1.weight) and Fn.conv3x3_c32_ok(x, self.conv2.weight):
             if Fn.RESBLOCK_FUSED:       # both convs, the identity and the outer skip in one launch: the intermediate map stays on the CU
                 return Fn.resblock_c32(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, act=L.ACT_LEAKY, res2=outer_skip)

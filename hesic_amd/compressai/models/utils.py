@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from hesic_amd import functional as Fn
+from hesic_amd import handover as _ho
 from hesic_amd import _lib as L
 
 
@@ -101,7 +102,7 @@ class HipConv2d(nn.Conv2d):
             return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
                                  stride=self.stride[0], padding=self.padding[0], transposed=False, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
-        return gdn(self.run(x))
+        return Fn.gdn(self.run(x), gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min)
 
     def run_cat(self, xa, xb, gdn=None, gdn_on_input=False):
         """self(torch.cat((xa, xb), 1)) without materialising the cat where the kernels allow it (inference); ``gdn``: the
@@ -111,6 +112,8 @@ class HipConv2d(nn.Conv2d):
                              padding=self.padding[0], transposed=False, gdn=gdn, gdn_on_input=gdn_on_input)
 
     def forward(self, x):
+        if _ho.active(x):
+            return _ho.conv(self, x)          # inference: deferred until the next module of the package sees it (hesic_amd/handover.py)
         return self.run(x)
 
 
@@ -152,7 +155,7 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
             return Fn.conv2d_gdn(x, self.weight, self.bias, gdn.beta, gdn.gamma, kernel_size=self.kernel_size[0],
                                  stride=self.stride[0], padding=self.padding[0], transposed=True, inverse=gdn.inverse,
                                  beta_min=gdn.beta_min, packer=self._packer, gdn_packer=gdn.packer())
-        return gdn(self.run(x))
+        return Fn.gdn(self.run(x), gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min)
 
     def run_cat(self, xa, xb, gdn=None, gdn_on_input=False):
         self._check()
@@ -162,7 +165,28 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
         if output_size is not None:
             raise NotImplementedError("hesic_amd deconv: output_size is fixed by output_padding = stride-1")
+        if _ho.active(x):
+            return _ho.conv(self, x, transposed=True)
         return self.run(x)
+
+
+def _plain_inputs(fn):
+    """The ``run*`` entry points launch at once; a Carrier among their tensor arguments (a deferred output of another module of the package,
+    hesic_amd/handover.py) is produced first."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if any(type(a) is _ho.Carrier for a in args):
+            args = tuple(_ho.plain(a) for a in args)
+        return fn(self, *args, **kwargs)
+    return wrapped
+
+
+for _cls in (HipConv2d, HipConvTranspose2d):
+    for _name in ("run", "run_into", "run_slice", "run_latent", "run_gdn", "run_cat", "run_gdn_hilo_out"):
+        if _name in _cls.__dict__:
+            setattr(_cls, _name, _plain_inputs(_cls.__dict__[_name]))
 
 
 def conv(in_channels, out_channels, kernel_size=5, stride=2):

@@ -397,10 +397,10 @@ __global__ __launch_bounds__(256) void sum_sq_diff_kernel(const SqArgs q) {
 }
 
 // The bits / squared-error reductions of one forward in ONE launch (round 5: four sum_log2 + two sum_sq_diff launches before, 66 us per step
-// on the metrics stream): block -> job by a scan of <= 8 first-block indices; the bodies are the single-job kernels' (same sums, same order
+// on the metrics stream): block -> job by a scan of <= 10 first-block indices; the bodies are the single-job kernels' (same sums, same order
 // per job for a given block count).  *first zero: block 0 of every job does NOT clear its accumulator -- the caller's zero-fill stays.
 struct RdBatch {
-    int n; int start[9];
+    int n; int start[11];          // 8 likelihood maps + 2 image pairs + the end marker (9 let start[9..10] run into lik[0])
     const float* lik[8]; int64_t numel[8]; double* lik_out[8];
     int nsq; SqArgs sq[2];
 };

@@ -1497,14 +1497,15 @@ def conv2d_cat(xa, xb, weight, bias, *, kernel_size, stride, padding, transposed
           and xa.shape[2:] == xb.shape[2:] and xa.dtype in (torch.float32, _h16()) and xb.dtype in (torch.float32, _h16()))
     fuse = ok and gdn is not None and FUSE_GDN3 and (not gdn_on_input or xa.shape[1] == 3)
     if not ok or (gdn is not None and not fuse):
+        gdn_now = None if gdn is None else (lambda t: _gdn_op(t, gdn.beta, gdn.gamma, gdn.inverse, gdn.beta_min))      # the operator, not the module's (deferring) __call__
         if gdn is not None and gdn_on_input:
-            xa = gdn(xa)
+            xa = gdn_now(xa)
         if ok:
             y = conv2d_cat(xa, xb, weight, bias, kernel_size=kernel_size, stride=stride, padding=padding, transposed=transposed, packer=packer)
         else:
             y = conv2d(torch.cat((xa.float(), xb.float()), 1), weight, bias, kernel_size=kernel_size, stride=stride,
                        padding=padding, transposed=transposed, packer=packer)
-        return gdn(y) if (gdn is not None and not gdn_on_input) else y
+        return gdn_now(y) if (gdn is not None and not gdn_on_input) else y
     B, _, H, W = xa.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=xa.device)
     d = _sdesc(xa, y, cin, cout, kernel_size, stride, padding, transposed)
@@ -1591,6 +1592,9 @@ def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
             and beta.dtype == torch.float32 and gamma.dtype == torch.float32):
         return _apply(_Gdn3PlanarFn, x, beta, gamma, inverse, beta_min)
     return _apply(_GdnFn, x, beta, gamma, inverse, beta_min)
+
+
+_gdn_op = gdn          # conv2d_cat's parameter ``gdn`` is the MODULE
 
 
 # ----------------------------------------------------------------------------------- warp

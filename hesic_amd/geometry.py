@@ -45,7 +45,10 @@ def warp_perspective(src, M, dsize, flags="bilinear", border_mode=None, align_co
     ac = DEFAULT_ALIGN_CORNERS if align_corners is None else bool(align_corners)
     if M.shape[0] != src.shape[0]:
         M = M.expand(src.shape[0], 3, 3)
-    return Fn.warp_perspective(src, M, dsize, ac, inverse_map)
+    from . import handover as _ho
+    src = _ho.plain(src)
+    # a warped reconstruction is still a reconstruction: the analysis stack that reads it runs on single operands (handover.py)
+    return _ho.inherit_tags(Fn.warp_perspective(src, M, dsize, ac, inverse_map), src)
 
 
 def get_perspective_transform(src, dst):

@@ -18,6 +18,7 @@ from compressai.models.utils import HipConv2d, conv, deconv
 
 from . import _lib as L
 from . import functional as Fn
+from . import handover as _ho
 from .geometry import warp_perspective
 
 RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
@@ -473,7 +474,7 @@ class spatial_pool2d(nn.Module):
     """Global spatial max per (sample, channel) (newnet1.py:441-453) as one reduction kernel."""
 
     def forward(self, X):
-        return Fn.spatial_max(X, leaky=False)
+        return Fn.spatial_max(_ho.plain(X), leaky=False)
 
 
 def _mixture_weights(head, feat, K, M):
@@ -1607,7 +1608,7 @@ class Enhancement(nn.Module):
             # weight is zero-padded inside the op, its gradient comes back for the six real channels
             t = Fn.conv3x3_c32_train(Fn.pack_images_c32(x, x_another_warp), self.conv1.weight, self.conv1.bias)
         else:
-            t = self.conv1(torch.cat((x.float(), x_another_warp.float()), 1))
+            t = _ho.plain(self.conv1(torch.cat((x.float(), x_another_warp.float()), 1)))
         t = self.EB3(self.EB2(self.EB1(t)))
         if Fn.conv3x3_c32_ok(t, self.conv2.weight):          # 32 -> 3 output conv + the image it refines, fp32 planar out
             return Fn.conv3x3_c32(t, self.conv2.weight, self.conv2.bias, res1=x)

@@ -3,27 +3,23 @@ drop-in package (``hesic_amd/compressai``: ``conv()`` / ``deconv()`` modules, ``
 ``nn.Sequential`` / ``nn.ReLU`` / ``nn.LeakyReLU`` / ``nn.UpsamplingBilinear2d``, ``torch.cat`` / ``torch.abs`` / ``softmax`` and the
 kornia-shaped ``warp_perspective`` -- what the reference's own ``newnet1{,_joint}.py`` executes after ``import hesic_amd``
 (ywz/mywork/newnet1.py:590-601, :615-624, :641-655, :676-692, :433-437, :441-453, :496-512, :562-577, :724-783;
-newnet1_joint.py:675-753).  NCHW-contiguous tensors in and out of every module; no fused ``run_*`` entry point, no ``_forward_eval``
-schedule.  The reference .py files do not travel to the GPU box, so the call order is restated here: ``tests/test_gpu_path_a.py`` checks
+newnet1_joint.py:675-753).  Every module's output goes to the next module as it is, like in the reference; no fused ``run_*`` entry point, no
+``_forward_eval`` schedule.  At inference the modules hand over among themselves (``hesic_amd/handover.py``: deferred conv -> GDN fusion,
+hi/lo pairs and fp32 latents between consecutive modules of the package); ``HESIC_NO_HANDOVER=1`` gives round 5's literal launches.  The reference .py files do not travel to the GPU box, so the call order is restated here: ``tests/test_gpu_path_a.py`` checks
 it against the reference-recorded goldens and ``bench.py`` times it (``secondary.path_a``); the container-only
 ``tests/test_dropin_reference_model.py`` loads the real files against the same package."""
 import torch
 import torch.nn.functional as F
 
 
-def _nchw(t):
-    """What a caller that knows nothing about layouts hands over: a plain contiguous NCHW tensor."""
-    return t.contiguous()
-
-
 def encoder1(m, x):
-    t = m.g_a_conv1(_nchw(x))
-    t = m.g_a_gdn1(_nchw(t))
-    t = m.g_a_conv2(_nchw(t))
-    t = m.g_a_gdn2(_nchw(t))
-    t = m.g_a_conv3(_nchw(t))
-    t = m.g_a_gdn3(_nchw(t))
-    return m.g_a_conv4(_nchw(t))
+    t = m.g_a_conv1(x)                    # newnet1.py:590-600: one module call after the other, each output handed to the next as it is
+    t = m.g_a_gdn1(t)
+    t = m.g_a_conv2(t)
+    t = m.g_a_gdn2(t)
+    t = m.g_a_conv3(t)
+    t = m.g_a_gdn3(t)
+    return m.g_a_conv4(t)
 
 
 def encoder2(m, x1_warp, x2):
@@ -32,13 +28,13 @@ def encoder2(m, x1_warp, x2):
 
 
 def decoder1(m, y_hat):
-    t = m.g_s_conv1(_nchw(y_hat))
-    t = m.g_s_gdn1(_nchw(t))
-    t = m.g_s_conv2(_nchw(t))
-    t = m.g_s_gdn2(_nchw(t))
-    t = m.g_s_conv3(_nchw(t))
-    t = m.g_s_gdn3(_nchw(t))
-    return m.g_s_conv4(_nchw(t))
+    t = m.g_s_conv1(y_hat)
+    t = m.g_s_gdn1(t)
+    t = m.g_s_conv2(t)
+    t = m.g_s_gdn2(t)
+    t = m.g_s_conv3(t)
+    t = m.g_s_gdn3(t)
+    return m.g_s_conv4(t)
 
 
 def decoder2(m, y_hat, x1_hat_warp):

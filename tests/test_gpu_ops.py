@@ -521,6 +521,24 @@ def test_reductions():
     assert abs(got - ref) < 1e-5 * ref
 
 
+def test_rd_sums_takes_its_maximum_of_eight_maps_and_two_pairs():
+    """``hesic_rd_sums`` at its declared limit -- 8 likelihood maps + 2 image pairs = 10 jobs + the end marker (the job table held
+    9 first-block indices and the last two ran into the first map's pointer)."""
+    Fn, _ = _imp()
+    liks = [rnd(f"rd8_l{i}", (1, 16 + 8 * i, 8, 8 + i), 1e-9, 1.0) for i in range(8)]
+    pairs = [(rnd(f"rd8_a{i}", (2, 3, 32, 48)), rnd(f"rd8_b{i}", (2, 3, 32, 48))) for i in range(2)]
+    lik_acc = torch.zeros(8, dtype=torch.float64, device=DEV)
+    sq_acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    Fn.rd_sums([l.to(DEV) for l in liks], [lik_acc[i:i + 1] for i in range(8)], [(a.to(DEV), b.to(DEV)) for a, b in pairs],
+               [sq_acc[i:i + 1] for i in range(2)])
+    for i, l in enumerate(liks):
+        ref = float(torch.log2(l.double()).sum())
+        assert abs(float(lik_acc[i]) - ref) < 1e-6 * abs(ref) + 1e-2, i
+    for i, (a, b) in enumerate(pairs):
+        ref = float(((a.double() - b.double()) ** 2).sum())
+        assert abs(float(sq_acc[i]) - ref) < 1e-5 * ref, i
+
+
 @pytest.mark.parametrize("tr,inv", [(0, False), (1, True)], ids=["conv+gdn", "deconv+igdn"])
 def test_fused_conv_gdn_matches_the_two_ops(tr, inv):
     """The inference-only fused epilogue equals conv() followed by GDN.forward (bf16 storage) and the fp32 oracle."""
