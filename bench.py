@@ -505,6 +505,81 @@ def secondary_sweep_and_path_a(dev, size=512, oracle_pairs=None):
     return out
 
 
+EN_GFLOP_PER_PAIR_512 = 176.7          # Independent_EN: 2 views x (6*32*9 + 18*32*32*9 + 32*3*9) MAC per pixel x 512^2 x 2 (newnet1.py:272-311)
+
+
+def secondary_hesic_en(dev, size=512):
+    """What the published evaluation runs (ywz/mywork/test3real.py:186): HSIC followed by Independent_EN (newnet1.py:1278-1321) on 8 x 512^2
+    pairs in the headline's mode -- pairs/s of the whole pipeline, the enhancement stage alone, and its dominant kernel (one ResidualBlock
+    per launch, csrc/enh.hip) against the MFMA roofline by HIP events on the launch stream."""
+    import hesic_amd
+    from hesic_amd import _lib as L_, functional as Fn, models, synthetic
+    out = {}
+    try:
+        net = models.GMM_together()
+        synthetic.fill_state_dict_(net.state_dict())
+        net = net.to(dev).eval()
+        a, b, h = (t.to(dev) for t in synthetic.stereo_batch(0, 8, size, size))
+
+        def fwd(i):
+            with torch.no_grad():
+                return models.rate_distortion(net(a, b, h), a, b)
+        ms = 1e3 * _timed_loop(fwd, 8, 20)
+        with torch.no_grad():
+            o1 = net.m1(a, b, h)
+            x1h, x2h = o1["x1_hat"].float(), o1["x2_hat"].float()
+
+            def en(i):
+                return net.m2(x1h, x2h, h)
+            ms_en = 1e3 * _timed_loop(en, 5, 20)
+            # the ResidualBlock launches between HIP events on their stream (9 per view)
+            orig, recs = L_.call, []
+
+            def call(name, *args):
+                if name not in ("hesic_resblock_c32_forward", "hesic_conv3x3_c32_forward"):
+                    return orig(name, *args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(name, *args)
+                e1.record()
+                recs.append((name, e0, e1))
+                return rc
+            L_.call = call
+            try:
+                for _ in range(3):
+                    net.m2(x1h, x2h, h)
+            finally:
+                L_.call = orig
+            torch.cuda.synchronize()
+        px = 8 * size * size
+        per = {}
+        for name, e0, e1 in recs:
+            per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e-3)
+        gf_en = EN_GFLOP_PER_PAIR_512 * (size * size / 512 ** 2)
+        gf_all = gf_en + gflop_per_pair("hsic", size, size)
+        out = {"value": round(8e3 / ms, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "pairs_per_step": 8,
+               "workload": "HSIC -> Independent_EN (GMM_together, newnet1.py:1304-1321) + bpp / PSNR of the enhanced reconstructions, 8 x 512^2, "
+                           "headline dtype / analysis mode", "gflop_per_pair": round(gf_all, 1), "model_tflops": round(8 * gf_all / ms, 2),
+               "mfma_frac_of_step": round(8 * gf_all / ms / MFMA_BF16_PEAK_TFLOPS, 4),
+               "independent_en_alone": {"ms": round(ms_en, 3), "gflop_per_pair": round(gf_en, 1), "tflops": round(8 * gf_en / ms_en, 1),
+                                        "frac": round(8 * gf_en / ms_en / MFMA_BF16_PEAK_TFLOPS, 4)}}
+        rb = per.get("hesic_resblock_c32_forward")
+        if rb:
+            fl = 2.0 * px * 2 * 32 * 32 * 9          # two 32 -> 32 3x3 convs per launch
+            t = sum(rb) / len(rb)
+            out["roofline"] = {"kernel": "c32_resblock_kernel", "bound": "mfma", "achieved": round(fl / t / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": len(rb) // 3,
+                               "avg_launch_us": round(1e6 * t, 2), "gflop_per_launch": round(fl / 1e9, 2),
+                               "hbm_bytes_algorithmic": 2 * px * 64 + (px * 64), "traffic": None}
+        cv = per.get("hesic_conv3x3_c32_forward")
+        if cv:
+            out["conv3x3_c32_avg_us"] = round(1e6 * sum(cv) / len(cv), 2)
+        del net
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def secondary_train_rccl(dev, size=512, lmbda=0.0067):
     """The graph-replayed training step with a ONE-RANK RCCL process group in the graph (the bucketed all-reduces of config C3 run for real,
     over no link): what the collectives cost a step before any xGMI hop.  Runs as a CHILD process with a time limit (``bench.py --mode train``
@@ -808,6 +883,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
         else:
             res["cpu_baseline"] = None
         if ranks_info is not None:
+            ranks_info["gradient_collective"] = getattr(tr.main_reducer, "collective", "allreduce")
             res["ranks"] = ranks_info
         emit_line(res)
     if world > 1 or force:
@@ -1137,6 +1213,7 @@ def main():
             if not args.no_cpu_baseline and args.dtype != "f32":
                 res["secondary"]["c2_other_modes"] = secondary_modes(dev, [m_cpu] + m_cpu["more"])
             res["secondary"].update(secondary_sweep_and_path_a(dev, oracle_pairs=None if args.no_cpu_baseline or args.dtype == "f32" else [m_cpu] + m_cpu["more"]))
+            res["secondary"]["hesic_en_b8"] = secondary_hesic_en(dev)
             res["secondary"]["train_step_hesic_b8_rccl_1rank"] = secondary_train_rccl(dev, lmbda=args.lmbda)
         emit_line(res)
     if world > 1:

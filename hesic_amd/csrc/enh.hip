@@ -223,6 +223,28 @@ constexpr int RB_NPC = (RB_IPIX * 4 + 511) / 512;                            // 
 constexpr int RB_MCH = (HPIX + 31) / 32;                                     // 32-pixel groups of the 18 x 34 intermediate region: 20
 constexpr int RB_LDS = RB_IPIX * 64 + 2 * HPIX * 64 + 4 * 32 * OPITCH * 4;
 
+// Ablation builds (profiles/scripts/en_ablation.sh; never in the shipped libraries): -DRB_ABL=<bits>  1: no MFMAs (fragment reads stay), 2: no fragment
+// reads, 4: the consumers' identity / outer-skip loads and the output stores dropped, 8: no producer work at all, 16: no consumer work at all.
+// Measured (round 6, B=8 512^2, random data, profiles/r06_en_ablation.txt): full 157 us; no MFMAs 107; no fragment reads 115; neither 92; no identity
+// loads / stores 121; all three gone ("skeleton": halo staging, both epilogues' LDS + VALU, barriers) 40; no producer work 95; no consumer work 111.
+// I.e. the parts ADD (40 + 50 + 42 + 36 = 168 ~ 157) and so do the roles (111 + 46): the LDS carries, per 16 x 32 tile, 663 KB of fragment reads
+// (2600 cycles at 256 B/clk), ~150 KB of slow writes (halo staging, intermediate halo, the consumers' fp32 turn-round: ~1900 cycles at ~80 B/clk)
+// and 64 KB of turn-round reads -- as busy as the matrix pipe (5184 cycles per SIMD and tile), so neither role finds a free unit while the other runs.
+// Tried and dropped (round 6): rotating both loops so that the MFMAs of group g + 1 stand in one basic block with the epilogue of group g -- the
+// second accumulator set, the staged sums, the fragment double buffer and the residuals need 26 (producer only) to 66 registers more than the 256 of a
+// two-waves-per-SIMD block and spill to scratch.
+#ifndef RB_ABL
+#define RB_ABL 0
+#endif
+__device__ __forceinline__ f32x16 rb_no_mfma(const h16x8& a_, const h16x8& b_, const f32x16& c_) {
+    asm volatile("" ::"v"(a_), "v"(b_));          // the operands stay live (their loads are not optimised away), nothing is multiplied
+    return c_;
+}
+#if RB_ABL & 1
+#define RB_MFMA(A_, B_, C_) rb_no_mfma(A_, B_, C_)
+#else
+#define RB_MFMA(A_, B_, C_) mfma_32x32x16_h16(A_, B_, C_, 0, 0, 0)
+#endif
 template <bool RES2>
 __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
             request(nt);
         }
         if (role == 0) {
-            if (s < n_my) {
+            if (s < n_my && !(RB_ABL & 8)) {
                 unsigned char* hmid = hmid0 + (s & 1) * (HPIX * 64);
 #pragma unroll 1
                 for (int cc = 0; cc < RB_MCH / 4; ++cc) {
@@ -320,9 +342,14 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                         const int hp = (mr + t / 3) * RB_IW + mc + t % 3;
                         const unsigned char* row = hin + hp * 64;
                         const int sw = (hp >> 2) & 3;
+#if RB_ABL & 2
+                        const h16x8 xf0 = wf[(t + 1) % 9][0], xf1 = wf[(t + 2) % 9][1];
+                        (void)row; (void)sw;
+#else
                         const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
-                        acc = mfma_32x32x16_h16(wf[t][0], xf0, acc, 0, 0, 0);
-                        acc1 = mfma_32x32x16_h16(wf[t][1], xf1, acc1, 0, 0, 0);
+#endif
+                        acc = RB_MFMA(wf[t][0], xf0, acc);
+                        acc1 = RB_MFMA(wf[t][1], xf1, acc1);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     }
                 }
             }
-        } else if (s >= 1) {
+        } else if (s >= 1 && !(RB_ABL & 16)) {
             const unsigned char* hmid = hmid0 + ((s - 1) & 1) * (HPIX * 64);
 #pragma unroll 1
             for (int rq = 0; rq < TH / 4; ++rq) {
@@ -358,8 +385,12 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const int xx = ptx * TW + rpx + 16 * it;
                     const bool lv = y < a.H && xx < a.W;
                     const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8;
+#if RB_ABL & 4
+                    r1v[it] = r2v[it] = u32x4{(uint32_t)o, 0u, 0u, 0u}; (void)lv;
+#else
                     r1v[it] = lv ? *(const u32x4*)(a.x + o) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
                     r2v[it] = (RES2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+#endif
                 }
                 f32x16 acc, acc1;
 #pragma unroll
@@ -369,9 +400,14 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const int hp = (yl + t / 3) * HW_ + p + t % 3;
                     const unsigned char* row = hmid + hp * 64;
                     const int sw = (hp >> 2) & 3;
+#if RB_ABL & 2
+                    const h16x8 xf0 = wf[(t + 1) % 9][0], xf1 = wf[(t + 2) % 9][1];
+                    (void)row; (void)sw;
+#else
                     const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
-                    acc = mfma_32x32x16_h16(wf[t][0], xf0, acc, 0, 0, 0);
-                    acc1 = mfma_32x32x16_h16(wf[t][1], xf1, acc1, 0, 0, 0);
+#endif
+                    acc = RB_MFMA(wf[t][0], xf0, acc);
+                    acc1 = RB_MFMA(wf[t][1], xf1, acc1);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -395,7 +431,11 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                         v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
                         v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
                     }
+#if RB_ABL & 4
+                    if (y < a.H && xx < a.W && v[0] == 1.2345e-30f)
+#else
                     if (y < a.H && xx < a.W)
+#endif
                         *(u32x4*)((h16_t*)a.y + (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8) =
                             u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
                 }
