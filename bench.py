@@ -120,8 +120,8 @@ class KernelMeter:
         v = (C.c_int32 * 4)()
         self.orig("hesic_conv2d_variant", C.byref(d), v)
         # the plan query runs the single-operand tile choice; the pair + GDN launch is promoted to the 256-pixel 8-wave tile when the grid is
-        # large enough (csrc/conv_igemm.hip, HESIC_IGEMM_BM256_HILO, default on since round 5) -- name what actually runs
-        if (hilo_pairs and fused and tuple(v[:3]) == (128, 128, 64) and v[3] == 1 and os.environ.get("HESIC_IGEMM_BM256_HILO", "1") != "0"
+        # large enough (csrc/conv_igemm.hip) -- name what actually runs
+        if (hilo_pairs and fused and tuple(v[:3]) == (128, 128, 64) and v[3] == 1
                 and not d.transposed and d.B * ((d.Ho * d.Wo + 255) // 256) >= 384):
             v[0] = 256
         if v[3] == 2:

@@ -47,7 +47,6 @@ struct IgemmArgs {
     void* y_pre;               // fused GDN, training: also store the conv output v = conv + bias (bf16, y's geometry) for GDN's backward
     FastDiv fd_nt, fd_tx, fd_ty, fd_b, fd_ph;                 // block-id decode without integer divisions
     int tap_parity;            // stride-2 conv: walk the taps parity class by parity class (see the K-loop cursor)
-    int chunk_major;           // with tap_parity: class -> channel chunk -> tap instead of class -> tap -> chunk (hi/lo operands)
     int ksplit;                // > 1: the K loop (taps x channel chunks) is cut into ksplit slices, one block each, that
     float* ws;                 //      leave fp32 partial tiles in ws[slice][B][Ho][Wo][Cout] for splitk_reduce_kernel
     int x_group_step, tiles_per_group;   // grouped launch: cout tile nt reads input channels [x_co + (nt / tiles_per_group) * x_group_step, + Cin)
@@ -352,19 +351,14 @@ constexpr int igemm_waves_per_eu(int bm, int bn, int bk, int ns, int nw) { retur
 // NW = waves per block: 4 (2x2 wave grid, 64x64 wave tiles).  NW = 8 (4x2 grid, 32 couts x 64 pixels per wave: twice the
 // waves per SIMD, 1.5 fragment reads per MFMA) compiles and is correct but measured EQUAL on every layer (the loop is not
 // limited by per-wave latency), so only NW = 4 is instantiated.
-// WS = 1 ("wave-specialised", A/B switch HESIC_IGEMM_WS=1, NOT the default): the block carries NW extra LOADER waves (one per
-// SIMD, next to a compute wave).  The compute waves run nothing but fragment reads + MFMAs + one barrier per stage; all
-// LDS-DMA issue, its address bookkeeping and the vmcnt waits live in the loaders (one block per CU, NS = 3 stages of 32 KB).
-// This is the per-SIMD ping-pong pairing of MI355X_MICROARCH.md ("two waves per SIMD") in its cleanest form.  Measured
-// (round 2, conv 128 -> 128 5x5 s2 @256^2 B=8 + GDN, same box, back to back): 144.0 us against 143.8 us for the self-loading
-// form at two blocks per CU -- no gain, and the ablations (run-time HESIC_IGEMM_DBG switches, removed in round 3: their branches cut the K loop into basic blocks) say why: with the DMA removed the self-loading
-// form runs at 84 us, with the MFMAs removed at 86 us, with both removed at 33 us (loop + barriers + GDN epilogue): the
-// matrix phase (~58 us) and the LDS-fill phase (~60 us) ADD instead of overlapping, and the fill alone costs 39 us even from
-// an L1-resident source (DBG=14 vs 6: 53 us from L2) -- 1.64 GB through the ~64 B/clk/CU global->LDS path, which a 128 x 128
-// tile needs at 62.5 B/clk/CU to feed the matrix cores at peak.  The bound is the tile's arithmetic intensity against that
-// path (and against L2: 33 TB/s), not issue scheduling; only a larger (cout x pixel) tile moves it.
-template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS = 0, int HL = 0>
-__global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
+// (Rounds 2 - 5 carried a "wave-specialised" form -- NW extra LOADER waves per block issuing all LDS-DMA, the compute waves nothing but fragment
+// reads + MFMAs + one barrier per stage.  Measured, conv 128 -> 128 5x5 s2 @256^2 B=8 + GDN, same box, back to back: 144.0 us against 143.8 us for
+// this self-loading form at two blocks per CU; the ablations said why: without the DMA the self-loading form runs 84 us, without the MFMAs 86 us,
+// without both 33 us -- the matrix phase (~58 us) and the LDS-fill phase (~60 us) ADD instead of overlapping, and the fill alone costs 39 us even
+// from an L1-resident source: 1.64 GB through the ~64 B/clk/CU global -> LDS path, which a 128 x 128 tile needs at 62.5 B/clk/CU to feed the
+// matrix cores at peak.  The bound is the tile's arithmetic intensity against that path, not issue scheduling.  Removed in round 6.)
+template <int BMP, int BN, int BK, int NS, int GDN = 0, int NW = 4, int WS_UNUSED = 0, int HL = 0>
+__global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) void igemm_glds_kernel(const IgemmArgs a) {
     constexpr int NTHREADS = NW * 64;          // COMPUTE threads (the epilogue's copy loops stride by this)
     using T = h16_t;
     constexpr int BM = BMP;                   // pixels per block: 128, 64 or 32 (small layers need more blocks)
@@ -378,9 +372,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     constexpr int OROW = BN * 2 + 16;
     constexpr int EPI = BM * OROW;
     static_assert(NS >= 2 && NS <= 4 && (XI + WI) * 3 <= 63, "ring depth / vmcnt range");
-    static_assert(!WS || (BMP == 128 && BN == 128 && NW == 4), "the wave-specialised form is built for the 128 x 128 tile");
+    static_assert(WS_UNUSED == 0, "the loader-wave form was removed in round 6");
     static_assert(GDN == 0 || BN == 128, "fused GDN needs every channel of a pixel in the block");
-    static_assert(!HL || !WS, "hi/lo operands: self-loading form only");
     constexpr int BKH = HL ? BK / 2 : BK;     // channels a stage advances by (HL: a row holds BK/2 hi channels and their BK/2 lo partners)
     constexpr int YOFF = BM * 256;                            // fused GDN: squared tile at 0, output tile behind it
     constexpr int EPI_ALL = GDN ? 2 * YOFF : EPI;
@@ -395,8 +388,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + XMAX_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA bases go to M0
-    const bool loader = WS && wave >= NW;      // wave-uniform
-    const int lw = WS ? (wave >= NW ? wave - NW : wave) : wave;     // index among the waves that issue the DMA
+    const int lw = wave;     // index among the waves that issue the DMA
     int bid;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -526,26 +518,7 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
         for (int i = 0; i < WI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(ws + (lw * WI + i) * 1024),
                                                      16, (int)wv[i], (int)sw, 0, 0);
-        if (a.chunk_major) {
-            // parity walk, class -> channel chunk -> tap: the taps of a class re-read the same quarter of the input pixels, and with
-            // the chunk OUTSIDE the taps only 1/kchunks of every pixel row is live at a time -- the hi/lo operand maps are twice as
-            // wide, and with the chunk innermost the co-resident blocks of an XCD (~5.9 MB per class) cycled their input through
-            // the 4 MB L2 (PMC: 867 MB fetched per launch for 336 MB of operands on the 128 -> 128 layer at 256^2)
-            dx += 2;
-            if (++cur_c == nkx_e) {
-                cur_c = 0; dx = dx_row; ++cur_j; dy += 2;
-                if (cur_j == nky_e) {
-                    if (++cur_chunk == kchunks) {
-                        cur_chunk = 0;
-                        ++cls;
-                        ky0_e = cls >> 1; kx0_e = cls & 1;
-                        nkx_e = (a.KW - kx0_e + 1) >> 1; nky_e = (a.KH - ky0_e + 1) >> 1;
-                    }
-                    cur_j = 0; dy = ky0_e - a.pad; dx_row = kx0_e - a.pad; dx = dx_row;
-                }
-            }
-            set_tap();
-        } else if (++cur_chunk == kchunks) {
+        if (++cur_chunk == kchunks) {
             cur_chunk = 0;
             next_tap();
         }
@@ -554,41 +527,17 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
     // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
     // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
     // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
-    if constexpr (WS) {
-        if (loader) {
-            // ---- loader wave: stage s+NS-1 is requested right behind the barrier that opens stage s (every compute wave has then
-            // finished reading the buffer it goes to: stage s-1's fragments were consumed by MFMAs issued before that barrier); a
-            // stage is announced (barrier) only after this wave's pieces of it have landed (counted vmcnt, never a drain)
-            static_assert(!WS || NS >= 3, "the loaders need a stage in flight beside the one being computed");
-#pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
-                if (s < nsteps) issue(s);
-            int nxt = NS - 1;
-            for (int step = 0; step < nsteps; ++step) {
-                const int rem = nsteps - 1 - step;
-                wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
-                __builtin_amdgcn_s_barrier();
-                if (step + NS - 1 < nsteps) issue(nxt);
-                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-            }
-            return;           // the epilogue's barriers only count the waves that are still alive
-        }
-    }
     auto main_loop = [&](auto abs_tag) {
         constexpr bool ABS = decltype(abs_tag)::value;
         constexpr int KS = BK / 16;
-        if constexpr (!WS) {
 #pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
-                if (s < nsteps) issue(s);
-        }
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nsteps) issue(s);
         int buf = 0, nxt = NS - 1;
         for (int step = 0; step < nsteps; ++step) {
             const int rem = nsteps - 1 - step;
-            if constexpr (!WS) {
-                if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
-                else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
-            }
+            if constexpr (NS == 2) wait_dma_groups<XI + WI>(0);
+            else wait_dma_groups<XI + WI>(rem < NS - 2 ? rem : NS - 2);
             __builtin_amdgcn_s_barrier();
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XT;
@@ -642,10 +591,8 @@ __global__ __launch_bounds__((WS ? 2 * NW : NW) * 64, WS ? 2 : igemm_waves_per_e
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!WS) {
-                if (step + NS - 1 < nsteps) issue(nxt);
-                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-            }
+            if (step + NS - 1 < nsteps) issue(nxt);
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
@@ -1908,8 +1855,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     const int pad128 = ((d->Cout + 127) / 128) * 128, pad64 = ((d->Cout + 63) / 64) * 64;
     const int BN = (pad128 - pad64) * 8 > pad128 ? 64 : 128;
     a.n_tiles = (d->Cout + BN - 1) / BN;
-    static const bool legacy = getenv("HESIC_IGEMM_LEGACY") != nullptr;   // A/B switch for profiling
-    const bool fast = d->dtype == HESIC_H16 && (!legacy || gdn || g_y32);
+    const bool fast = d->dtype == HESIC_H16;
     HESIC_CHECK_ARG(!g_y32 || (fast && !gdn), "conv2d_forward_f32out: bf16 storage without the fused GDN epilogue only");
     // pixel tile: 128, shrunk to 64 / 32 (fast path only) until the grid has ~1.5 blocks per CU
     int bm = 128;
@@ -1927,16 +1873,13 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
     if (fast && !tr4_forced) {
         if (count_blocks(128) < 384) bm = 64;
         if (bm == 64 && count_blocks(64) < 384 && BN == 128 && cin_k % 64 == 0) bm = 32;
-        static const int force_bm = getenv("HESIC_IGEMM_BM") ? atoi(getenv("HESIC_IGEMM_BM")) : 0;      // A/B switch
-        if (force_bm == 128 || force_bm == 64 || (force_bm == 32 && BN == 128 && cin_k % 64 == 0)) bm = force_bm;
     }
     // Split-K for the low-resolution layers (hyper path: 8x8 .. 32x32 maps): with so few pixels a full-K block per tile
     // leaves most CUs idle and makes every block stream the whole weight tensor.  Given a workspace, the K loop is cut
     // into up to 8 slices (>= 4 stages each) on the largest pixel tile the map fills, partial tiles go to the workspace
     // in fp32 and splitk_reduce_kernel applies bias / activation / bf16 rounding.
     int ksplit = 1;
-    static const bool nosplit = getenv("HESIC_IGEMM_NOSPLIT") != nullptr;    // A/B switch for profiling
-    if (fast && !gdn && !nosplit && (g_ws || g_ws_need)) {
+    if (fast && !gdn && (g_ws || g_ws_need)) {
         const int qpix = a.QH * a.QW;
         int bm_s = qpix >= 128 ? 128 : (qpix >= 64 ? 64 : 32);
         if (bm_s == 32 && !(BN == 128 && cin_k % 64 == 0)) bm_s = 64;
@@ -1950,8 +1893,7 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int min_steps = min_taps * (cin_k / bk_);
         // one block per CU is the target; a very long K loop (>= 200 stages: the 960-channel data gradients) is cut further, to two
         // co-resident blocks per CU (183 us unsplit -> 108 us at 4 slices -> measured below at 8)
-        static const int split_target_long = getenv("HESIC_IGEMM_SPLIT_LONG") ? atoi(getenv("HESIC_IGEMM_SPLIT_LONG")) : 512;   // A/B switch
-        const int target = min_steps >= 200 ? split_target_long : 256;
+        const int target = min_steps >= 200 ? 512 : 256;
         int S = (int)((target + nb - 1) / nb);
         if (S > 8) S = 8;
         if (S > min_steps / 4) S = min_steps / 4;
@@ -1961,24 +1903,16 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const bool starved = one_phase && count_blocks(32) / per_img < 128;
         // long K on a small map (>= 64 stages: the 192 -> 128 5x5 layer of encode_hyper at 32x32, 75 stages): four K slices on 128-pixel
         // tiles instead of 256 blocks of 32 pixels, 46.6 -> 27.5 + 5 us (round 2; 100 was the round-1 threshold)
-        static const int longk_min = getenv("HESIC_IGEMM_LONGK") ? atoi(getenv("HESIC_IGEMM_LONGK")) : 64;      // A/B switch
-        const bool long_k = one_phase && min_steps >= longk_min;
+        const bool long_k = one_phase && min_steps >= 64;
         if (nb < 256 && S >= 2 && (starved || long_k)) { ksplit = S; bm = bm_s; }
     }
-    // 256-pixel tile, 8 waves of 64 x 64 (2 cout x 4 pixel slices), one block per CU: the weight tile is shared by twice the
-    // pixels, i.e. 25 % fewer bytes through the global -> LDS path per MFMA (that path bounds the kernel)
-    // Measured (round 2, same box, back to back): conv 128->128 s2 @256^2 146 vs 153 us, the transposed layer 223 vs 216 us, the
-    // step's 7 fused launches 132 vs 124 us -- no gain (one 8-wave block per CU marches through its barriers in lockstep and loses
-    // the overlap two independent 4-wave blocks give), so it stays an A/B switch, off by default.
-    static const int big = getenv("HESIC_IGEMM_BM256") ? atoi(getenv("HESIC_IGEMM_BM256")) : 0;      // A/B switch
-    // hi/lo GDN form, same box back to back (conv 128->128 s2 @256^2 B=8, graph replay): 128-pixel tile 339.8 us; 1 = 256 pixels, 8 waves
-    // of 64 x 64: 331.2 us; 2 = 256 pixels, 4 waves of 64 couts x 128 pixels (25 % fewer fragment bytes per MFMA, one wave per SIMD):
-    // 359.0 us -- fragment-read bandwidth is not what bounds the loop, a lone wave per SIMD just loses its latency cover
-    // Round 5: ON (1) -- with "x3" the default analysis mode this launch is the forward's largest (2 x 336 us); same box, graph replay,
-    // alternating: 345.8 / 344.0 us (0) vs 332.6 / 331.8 (1) vs 332.2 / 337.9 (3 = the 8-wave form on a ring of three 48 KB stages);
-    // 8-pair step 2.763 -> 2.741 ms.  The K walk of an output is the same in every tile: results are bit-identical.
-    static const int big_hl = getenv("HESIC_IGEMM_BM256_HILO") ? atoi(getenv("HESIC_IGEMM_BM256_HILO")) : 1;      // A/B switch
-    if (fast && (hilo ? (hilo == 1 && big_hl && gdn == 3) : (big && (big < 3 || gdn == 0))) && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
+    // 256-pixel tile, 8 waves of 64 x 64 (2 cout x 4 pixel slices), one block per CU, for the pair conv + GDN launch (the forward's largest:
+    // g_a_conv2 + GDN on pairs, twice per forward): the weight tile is shared by twice the pixels.  Same box, graph replay, alternating (round 5):
+    // 128-pixel tile 345.8 / 344.0 us, this one 332.6 / 331.8.  The K walk of an output is the same in every tile: bit-identical results.
+    // Measured and dropped (kept out of the library since round 6): the same tile for single-operand layers (146 vs 153 us conv, 223 vs 216 us
+    // transposed: no gain, one 8-wave block per CU marches through its barriers in lockstep), 4 waves of 64 couts x 128 pixels (359 us: a lone wave
+    // per SIMD loses its latency cover), a ring of three 48 KB stages (332.2 / 337.9 us), loader waves next to the compute waves (144.0 vs 143.8 us).
+    if (fast && hilo == 1 && gdn == 3 && bm == 128 && BN == 128 && cin_k % 64 == 0 && ksplit == 1 && count_blocks(256) >= 384) bm = 256;
     if (g_groups > 1 || g_act_split) {
         HESIC_CHECK_ARG(fast && !gdn, "conv2d_forward_grouped: bf16 storage, no fused GDN");
         HESIC_CHECK_ARG(d->Cout % g_groups == 0 && (d->Cout / g_groups) % BN == 0 && g_act_split % BN == 0,
@@ -2013,20 +1947,16 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         const int mode = g_phase4_mode.load(std::memory_order_relaxed);
         const int64_t nb4 = nblocks / 4, rounds = (nb4 + 511) / 512;
         const bool fills = mode >= 2 || (nb4 >= 384 && nb4 * 10 >= rounds * 512 * 7);
-        static const bool force_bk32_ = getenv("HESIC_IGEMM_BK32") != nullptr;
-        use_tr4 = fast && mode && fills && bm == 128 && tr4_shape && !force_bk32_ && ksplit == 1 && (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31);
+        use_tr4 = fast && mode && fills && bm == 128 && tr4_shape && ksplit == 1 && (int64_t)d->Ho * d->Wo * a.y_ps * 2 < (1ll << 31);
     }
     if (g_plan_out) {
         if (use_tr4) { g_plan_out[0] = 128; g_plan_out[1] = 128; g_plan_out[2] = 64; g_plan_out[3] = 2; return 0; }
         g_plan_out[0] = bm; g_plan_out[1] = BN; g_plan_out[2] = fast ? (((bm == 32) || (bm == 64 && BN == 64)) && cin_k % 128 == 0 ? 128 : (cin_k % 64 == 0 ? 64 : 32)) : BK; g_plan_out[3] = fast ? 1 : 0;
         return 0;
     }
-    a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1 && !getenv("HESIC_IGEMM_RASTER_TAPS")) ? 1 : 0;
-    // A/B switch, OFF: 1 = the hi/lo parity walks, 2 = all parity walks.  It cuts the hi/lo launch's fetch traffic (800 -> 655 MB on the big
-    // layer) at equal time (343 vs 346 us), but the summation order then depends on the K step of the tile variant, and with it the last
-    // bit of y on the batch size (the tile choice follows the grid): pairs must not depend on what else is in the batch
-    static const int chunk_major_env = getenv("HESIC_IGEMM_CHUNK_MAJOR") ? atoi(getenv("HESIC_IGEMM_CHUNK_MAJOR")) : 0;
-    a.chunk_major = a.tap_parity && (chunk_major_env == 2 || (chunk_major_env == 1 && hilo));
+    a.tap_parity = (!d->transposed && s == 2 && d->KH >= 2 && d->KW >= 2 && a.ntaps_live == d->KH * d->KW && ksplit == 1) ? 1 : 0;
+    // (a class -> channel chunk -> tap walk of the parity classes cut the pair launch's fetch traffic 800 -> 655 MB at equal time, 343 vs 346 us, but
+    // the summation order then depends on the K step of the tile variant, and with it the last bit of y on the batch size: removed in round 6)
     a.fd_nt = make_fastdiv((uint32_t)a.n_tiles); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     a.fd_b = make_fastdiv((uint32_t)a.B); a.fd_ph = make_fastdiv((uint32_t)a.nphase);
     const dim3 grid((unsigned)nblocks), block(NTHREADS);
@@ -2058,34 +1988,17 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         // ring depth: a 2-deep ring relies on 2-3 co-resident blocks per CU to hide the L2 latency; layers whose grid
         // is too small for that (low resolutions) get a 4-deep ring instead, as long as every block of the grid still
         // fits in LDS at once (160 KB per CU)
-        static const bool force_bk32 = getenv("HESIC_IGEMM_BK32") != nullptr;    // A/B switch for profiling
         // the buffer-addressed DMA keeps 32-bit offsets relative to the tile's first input row and the packed weights
         HESIC_CHECK_ARG(((int64_t)(TH * a.in_step + 2 * d->KH) * a.W + 2 * d->KW) * a.x_ps * 2 < (1ll << 31) &&
                             (int64_t)d->KH * d->KW * d->Cout * cin_k * 2 < (1ll << 31),
                         "conv2d_forward: image rows / weights too large for 32-bit tile offsets");
-        const int bk = (cin_k % 64 == 0 && !force_bk32) ? 64 : 32;
+        const int bk = cin_k % 64 == 0 ? 64 : 32;
         const int stage = (bm + BN) * bk * 2;
         const int64_t per_cu = (nblocks + 255) / 256;
         const bool deep = bm < 128 ? per_cu * 4 * stage <= 160 * 1024 : (bk == 32 && per_cu * 4 * stage <= 160 * 1024);
-        static const int ws_mode = getenv("HESIC_IGEMM_WS") ? atoi(getenv("HESIC_IGEMM_WS")) : 0;      // A/B switch: 1 = loader waves (measured slower)
-        if (bm == 256 && !hilo && big >= 3) {
-            // experiment (round 4): 256 pixels x 128 couts, FOUR waves of 64 couts x 128 pixels (128 accumulator registers), 32-channel stages:
-            // 6 DMA pieces and 12 fragment reads per 16 MFMAs instead of 8 and 16, still two blocks per CU (48 / 72 KB of ring)
-            if (big == 3) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 32, 2, 0, 4>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 32, 3, 0, 4>), grid, block, 0, st, a);
-        } else if (bm == 256) {
-            const dim3 block2(512);
-            if (hilo && big_hl == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 4, 0, 1>), grid, block, 0, st, a);     // 4 waves of 64 couts x 128 pixels
-            else if (hilo && big_hl == 3) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 3, 3, 8, 0, 1>), grid, block2, 0, st, a);   // round 5: 8 waves, THREE 48 KB stages
-            else if (hilo) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, block2, 0, st, a);
-            else if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 1, 8>), grid, block2, 0, st, a);
-            else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 2, 8>), grid, block2, 0, st, a);
-            else hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 0, 8>), grid, block2, 0, st, a);
-        } else if (bm == 128 && bk == 64 && BN == 128 && ws_mode && !hilo && ksplit == 1) {
-            const dim3 block_ws(2 * NTHREADS);
-            if (gdn == 1) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 1, 4, 1>), grid, block_ws, 0, st, a);
-            else if (gdn == 2) hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 2, 4, 1>), grid, block_ws, 0, st, a);
-            else hipLaunchKernelGGL((igemm_glds_kernel<128, 128, 64, 3, 0, 4, 1>), grid, block_ws, 0, st, a);
+        if (bm == 256) {
+            // pair conv + GDN on 256 pixels x 128 couts: 8 waves of 64 x 64, one block per CU (see the tile choice above)
+            hipLaunchKernelGGL((igemm_glds_kernel<256, 128, 64, 2, 3, 8, 0, 1>), grid, dim3(512), 0, st, a);
         } else if (use_tr4) {
             // the four output phases of a tile in one block (igemm_tr4_kernel): a quarter of the blocks, one 50-stage pipeline each
             const dim3 grid4((unsigned)(nblocks / 4));
@@ -2098,22 +2011,16 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         } else if (bm == 64) {
             // same lever as for the 32-pixel tile: BK = 128 where two 2-stage blocks still fit a CU (64 x 64 tiles: 64 KB; 128 ->
             // 192 5x5 s2 @64x64 B=8: 28.4 -> 22.3 us) or where the grid is one block per CU anyway (64 x 128 tiles, 96 KB)
-            static const int bk128m = getenv("HESIC_IGEMM_BK128M") ? atoi(getenv("HESIC_IGEMM_BK128M")) : 1;       // A/B switch: 0 off, 2 = also 64x128
-            if (bk == 64 && BN == 64 && bk128m && cin_k % 128 == 0) LAUNCH_GLDS(64, 64, 128, 2);
-            else if (bk == 64 && BN == 128 && bk128m == 2 && cin_k % 128 == 0 && nblocks <= 256) LAUNCH_GLDS(64, 128, 128, 2);
+            if (bk == 64 && BN == 64 && cin_k % 128 == 0) LAUNCH_GLDS(64, 64, 128, 2);
             else if (bk == 64) { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 64); else LAUNCH_GLDS_NS(64, 64, 64); }
             else { if (BN == 128) LAUNCH_GLDS_NS(64, 128, 32); else LAUNCH_GLDS_NS(64, 64, 32); }
         } else {
             // 32-pixel tiles are bound by per-stage bookkeeping and barrier waits (PMC: ~95 scalar/vector instructions per 4
             // MFMAs): BK = 128 halves the stage count (8 MFMAs per wave and stage, 2-deep ring of 40 KB stages) --
-            // 128 -> 128 5x5 s1 @32x32 B=8: 23.4 -> 18.8 us; a 3-deep ring was slower (20.7).  HESIC_IGEMM_BK128=0 = A/B switch.
-            static const bool bk128 = !(getenv("HESIC_IGEMM_BK128") && atoi(getenv("HESIC_IGEMM_BK128")) == 0);
-            if (bk128 && cin_k % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
+            // 128 -> 128 5x5 s1 @32x32 B=8: 23.4 -> 18.8 us; a 3-deep ring was slower (20.7).
+            if (cin_k % 128 == 0) LAUNCH_GLDS(32, 128, 128, 2);
             else LAUNCH_GLDS_NS(32, 128, 64);
         }
-    } else if (d->dtype == HESIC_H16) {
-        if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<h16_t, 128>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((igemm_conv_kernel<h16_t, 64>), grid, block, 0, st, a);
     } else {
         if (BN == 128) hipLaunchKernelGGL((igemm_conv_kernel<float, 128>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((igemm_conv_kernel<float, 64>), grid, block, 0, st, a);

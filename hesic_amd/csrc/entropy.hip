@@ -600,7 +600,7 @@ extern "C" int hesic_eb_backward(const void* z, const float* params, const void*
     // contenders but more serial pixels (~6000 VALU instructions each) per thread.  Rounds 1-4 (64 channels x 4 pixel lanes per block), us per
     // launch on the 8 x 8 hyper-latents of a training step: 128 slices 111 | 64: 76 | 32: 70 | 16: 89 | 8: 147 | 4: 265; round 5 (16 x 16 per
     // block, C / 16 channel groups): 32 slices = one pixel per thread there, 256 blocks
-    static const int max_slices_env = getenv("HESIC_EB_BWD_SLICES") ? atoi(getenv("HESIC_EB_BWD_SLICES")) : 32;
+    constexpr int max_slices_env = 32;
     const int max_slices = max_slices_env < 1 ? 1 : max_slices_env;              // 0 / negative would launch an empty grid
     const int64_t slices = (P + EB_PL - 1) / EB_PL;
     const dim3 grid((unsigned)(slices < max_slices ? slices : max_slices), (C + EB_CL - 1) / EB_CL), block(EB_CL * EB_PL);
@@ -694,7 +694,7 @@ extern "C" int hesic_gmm_forward(const hesic_gmm_desc* d, const void* y, const v
     const int64_t total = (int64_t)d->B * d->HW * d->M;
     const dim3 grid(grid_for(total, 256));
     // pair form: even channel geometry (4-byte bf16 pairs, 8-byte fp32 pairs), 32-bit pair index
-    static const bool no_pair = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
+    constexpr bool no_pair = false;                  // A/B switch for profiling
     const bool pair = !no_pair && d->dtype == HESIC_H16 && (d->K == 5 || d->K == 1) && d->M % 2 == 0 && d->sm_pix_stride % 2 == 0 &&
                       d->s_c_off % 2 == 0 && d->m_c_off % 2 == 0 && total / 2 < (1ll << 31) && !((uintptr_t)y & 3) &&
                       !((uintptr_t)scales & 3) && !((uintptr_t)means & 3) && !((uintptr_t)noise & 3) && !((uintptr_t)y_hat & 3) &&
@@ -733,7 +733,7 @@ extern "C" int hesic_gmm_cdf_rows(const hesic_gmm_desc* d, int b, const void* sc
                     "gmm_cdf: bad arguments");
     HESIC_CHECK_ARG(weights || d->K == 1, "gmm_cdf: weights required for K > 1");
     const int64_t total = (int64_t)n_channels * d->HW;
-    static const bool thread_rows = getenv("HESIC_CDF_THREAD_ROWS") != nullptr;          // A/B switch: the one-thread-per-row kernel for every alphabet
+    constexpr bool thread_rows = false;          // A/B switch: the one-thread-per-row kernel for every alphabet
     if (2 * minmax + 1 <= CDF_WAVE_MAX && !thread_rows) {
         const dim3 gw(grid_for(total, 4, 256 * 16));
         if (d->dtype == HESIC_H16)
@@ -787,7 +787,7 @@ extern "C" int hesic_gmm_backward(const hesic_gmm_desc* d, const void* y, const 
     if (ppb < 4) ppb = 4;
     if (ppb > 64) ppb = 64;
     const dim3 grid((d->M + 63) / 64, (d->HW + ppb - 1) / ppb, d->B);
-    static const bool slow_bwd = getenv("HESIC_GMM_GENERIC") != nullptr;                  // A/B switch for profiling
+    constexpr bool slow_bwd = false;                  // A/B switch for profiling
     if (d->dtype == HESIC_H16 && !slow_bwd && (d->K == 5 || d->K == 1)) {
         if (d->K == 5)
             hipLaunchKernelGGL((gmm_bwd_kernel<h16_t, 5>), grid, dim3(256), 0, (hipStream_t)stream, *d, (const h16_t*)y,

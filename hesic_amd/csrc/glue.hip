@@ -716,7 +716,7 @@ extern "C" int hesic_sum_log2(const float* lik, int64_t n, double* out, void* st
     HESIC_CHECK_ARG(lik && out && n > 0, "sum_log2: bad arguments");
     // one fp64 atomic per block on ONE address: they serialise in L2.  Measured (round 4, 1.57 M likelihoods, back-to-back launches):
     // 128 blocks 6.0 us, 512 blocks 8.9 us, 2048 blocks 21.3 us -- so few, fat blocks (HESIC_SUM_LOG2_BLOCKS = A/B switch)
-    static const int max_blocks = getenv("HESIC_SUM_LOG2_BLOCKS") ? atoi(getenv("HESIC_SUM_LOG2_BLOCKS")) : 128;
+    constexpr int max_blocks = 128;
     hipLaunchKernelGGL(sum_log2_kernel, dim3(grid_for(n / 4 + 1, 256, max_blocks < 1 ? 1 : max_blocks)), dim3(256), 0, (hipStream_t)stream, lik, n, out);
     HESIC_LAUNCH_RETURN("sum_log2");
 }
@@ -739,7 +739,7 @@ extern "C" int hesic_rd_sums(int n_lik, const float* const* lik, const int64_t* 
     HESIC_CHECK_ARG((n_lik == 0 || (lik && numel && lik_out)) && (n_sq == 0 || (a && b && a_dtype && b_dtype && a_strides && b_strides && dims && sq_out)), "rd_sums: null pointer");
     RdBatch rb;
     memset(&rb, 0, sizeof(rb));
-    static const int max_blocks = getenv("HESIC_SUM_LOG2_BLOCKS") ? atoi(getenv("HESIC_SUM_LOG2_BLOCKS")) : 128;
+    constexpr int max_blocks = 128;
     int blk = 0;
     for (int i = 0; i < n_lik; ++i) {
         HESIC_CHECK_ARG(lik[i] && lik_out[i] && numel[i] > 0, "rd_sums: likelihood map %d: bad arguments", i);

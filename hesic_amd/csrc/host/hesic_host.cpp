@@ -257,7 +257,7 @@ extern "C" int hesic_rc_decoder_decode_grid(hesic_rc_decoder* d, const uint32_t*
     auto row_of = [&](int64_t p, int64_t q) { return cdf + (p * row_step_outer + q * row_step_inner) * stride; };
     const int64_t n = n_outer * n_inner;
     const int lines = (stride * 4 + 63) / 64;
-    static const int ahead = [] { const char* e = getenv("HESIC_RC_PREFETCH_AHEAD"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    constexpr int ahead = 4;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t* c = row_of(po, qi);
         {

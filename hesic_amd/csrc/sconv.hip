@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void sconv_small_s1_kernel(const SArgs a) {
 }
 
 int launch_forward(const SArgs& a, hipStream_t st) {
-    static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;   // A/B switch for profiling
+    constexpr bool legacy = false;   // A/B switch for profiling
     if (!legacy && !a.transposed && a.y_dtype == HESIC_H16 && a.Cin == 3 && a.KH == 5 && a.KW == 5 && a.stride == 2 && a.pad == 2 &&
         a.Cout % 8 == 0 && a.ys_c == 1 && (a.ys_x % 8) == 0 && (a.ys_y % 8) == 0 && (a.ys_b % 8) == 0) {
         const int64_t tiles = (int64_t)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * a.B;
@@ -1167,7 +1167,7 @@ int launch_forward(const SArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(sconv_wide_to_narrow_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), lds, st, a);
     } else if (!legacy && a.stride == 1 && a.Cin == 6 && a.Cout == 3 && a.KH == 5 && a.KW == 5 && a.pad == 2 && a.Ho == a.H &&
                a.Wo == a.W && a.Wo >= 128) {
-        static const int px = getenv("HESIC_6TO3_PX") ? atoi(getenv("HESIC_6TO3_PX")) : 4;       // A/B switch
+        constexpr int px = 4;       // A/B switch
         if (px == 8) {
             const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
             hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 8>), dim3(tiles), dim3(256), 0, st, a);
@@ -1252,7 +1252,7 @@ extern "C" int hesic_sconv2d_forward_cat(const hesic_sconv_desc* d, const void* 
     a.x2 = xb; a.x2s_b = xb_strides[0]; a.x2s_c = xb_strides[1]; a.x2s_y = xb_strides[2]; a.x2s_x = xb_strides[3];
     a.x2_dtype = xb_dtype; a.c_split = ca;
     a.gdn_beta = g_cat_beta; a.gdn_gamma = g_cat_gamma; a.gdn_bound = g_cat_bound; a.gdn_mode = g_cat_mode; a.gdn_inverse = g_cat_inverse;
-    static const int px = getenv("HESIC_6TO3_PX") ? atoi(getenv("HESIC_6TO3_PX")) : 4;           // A/B switch
+    constexpr int px = 4;           // A/B switch
     if (px == 8) {
         const int tiles = ((a.Wo + 127) / 128) * ((a.Ho + 15) / 16) * a.B;
         hipLaunchKernelGGL((sconv_6to3_s1_kernel<5, 8>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
@@ -1368,7 +1368,7 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
                     "sconv2d_gdn_forward: built for the 3 -> 128 5x5 stride-2 stage with bf16 NHWC output");
     SArgs a = make_args(d);
     a.x = x; a.w = w; a.bias = bias; a.y = y;
-    static const int n2w_dbg = getenv("HESIC_N2W_DBG") ? atoi(getenv("HESIC_N2W_DBG")) : 0;
+    constexpr int n2w_dbg = 0;
     a.dbg = n2w_dbg;
     a.w_img = g_w_img;
     const size_t lds = 65536 + 1024 + 8 * 32 * (128 * 2 + 16);
@@ -1381,7 +1381,7 @@ static int sconv_gdn_launch(const hesic_sconv_desc* d, const void* x, const floa
         attr = true;
     }
     // fp32 planes, unit pixel stride, even width, everything addressable with 32-bit byte offsets inside one image
-    static const bool no_fast = getenv("HESIC_N2W_GENERIC") != nullptr;              // A/B switch for profiling
+    constexpr bool no_fast = false;              // A/B switch for profiling
     const bool fastx = !no_fast && d->x_dtype == HESIC_F32 && d->xs_x == 1 && d->W % 2 == 0 && tiles < (1ll << 30) &&
                        (2 * d->xs_c + (int64_t)(d->H + 4) * d->xs_y + d->W) * 4 < (1ll << 31) &&
                        ((int64_t)d->Ho * d->ys_y + (int64_t)d->Wo * d->ys_x) * 2 < (1ll << 31) && d->xs_c >= 0 && d->xs_y >= 0;

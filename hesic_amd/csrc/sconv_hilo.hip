@@ -505,9 +505,9 @@ static int n2w_gdn_hilo_launch(const hesic_sconv_desc* d, const float* x, const 
     }
     const dim3 g(grid), blk(512);
     hipStream_t st = (hipStream_t)stream;
-    static const bool one_wave = getenv("HESIC_N2W_ONE_WAVE") != nullptr;      // experiment: one wave per SIMD (what do the two waves of a SIMD overlap?)
+    constexpr bool one_wave = false;      // experiment: one wave per SIMD (what do the two waves of a SIMD overlap?)
     // A/B switch, off: back-to-back launches 75.5 vs 81.8 us with the rotation, but the 8-pair step 3620 vs 3638 pairs/s (same box, twice)
-    static const bool ping = getenv("HESIC_N2W_PING") != nullptr;
+    constexpr bool ping = false;
     if (ping && out1 && !one_wave) {
         static bool pattr = false;
         if (!pattr) {

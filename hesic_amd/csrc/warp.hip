@@ -129,68 +129,8 @@ __global__ __launch_bounds__(256) void warp_fwd_f32c3_kernel(const WArgs a) {
     }
 }
 
-// Round 5 variant ("two output rows per wave + 16-byte stores"): a lane owns FOUR consecutive output pixels of V4_ROWS rows -- 16-byte
-// stores (3 per row instead of 12 four-byte ones), a quarter of the threads, 48 V4_ROWS taps in flight per lane.  Same arithmetic per pixel
-// as warp_fwd_f32c3_kernel (bit-identical; HESIC_WARP_V4=1 selects it -- measured in DESIGN_APPENDIX, round 5).
-constexpr int V4_ROWS = 2;
-__global__ __launch_bounds__(128) void warp_fwd_f32c3_v4_kernel(const WArgs a) {
-    const hesic_warp_desc& d = a.d;
-    __shared__ double iv[9];
-    const int b = blockIdx.z;
-    if (threadIdx.x == 0) invert_h(a.M, b, iv, a.d.m_is_dst_to_src);
-    __syncthreads();
-    const int ox0 = (blockIdx.x * 128 + threadIdx.x) * 4;
-    if (ox0 >= d.Wo) return;
-    constexpr uint32_t POISON = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)a.src + (int64_t)b * d.ss_b), 0, (int)POISON, 0x00020000);
-    const int sy_ = (int)d.ss_y, sc_ = (int)d.ss_c;
-    float t[V4_ROWS][4][3][4], wt[V4_ROWS][4][4];
-    bool ok[V4_ROWS][4][4];
-#pragma unroll
-    for (int r = 0; r < V4_ROWS; ++r) {
-        const int oy = blockIdx.y * V4_ROWS + r;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int ox = ox0 + p;
-            float sx, sy;
-            const bool fin = src_coords(d, iv, ox, oy, sx, sy) && oy < d.Ho && ox < d.Wo;
-            const float fx0 = floorf(sx), fy0 = floorf(sy);
-            const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-            const bool big = !fin || fabsf(fx0) > 1e8f || fabsf(fy0) > 1e8f;
-            const int x0 = big ? -10 : (int)fx0, y0 = big ? -10 : (int)fy0;
-            const bool vx0 = x0 >= 0 && x0 < d.W, vx1 = x0 + 1 >= 0 && x0 + 1 < d.W;
-            const bool vy0 = y0 >= 0 && y0 < d.H, vy1 = y0 + 1 >= 0 && y0 + 1 < d.H;
-            const uint32_t o00 = (uint32_t)((y0 * sy_ + x0) * 4);
-            ok[r][p][0] = vy0 && vx0; ok[r][p][1] = vy0 && vx1; ok[r][p][2] = vy1 && vx0; ok[r][p][3] = vy1 && vx1;
-            const uint32_t off[4] = {ok[r][p][0] ? o00 : POISON, ok[r][p][1] ? o00 + 4u : POISON, ok[r][p][2] ? o00 + (uint32_t)(sy_ * 4) : POISON,
-                                     ok[r][p][3] ? o00 + (uint32_t)(sy_ * 4) + 4u : POISON};
-            wt[r][p][0] = ok[r][p][0] ? wx0 * wy0 : 0.f; wt[r][p][1] = ok[r][p][1] ? wx1 * wy0 : 0.f;
-            wt[r][p][2] = ok[r][p][2] ? wx0 * wy1 : 0.f; wt[r][p][3] = ok[r][p][3] ? wx1 * wy1 : 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[r][p][c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)off[k], c * sc_ * 4, 0));
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < V4_ROWS; ++r) {
-        const int oy = blockIdx.y * V4_ROWS + r;
-        if (oy >= d.Ho) break;
-        float* dp = (float*)a.dst + (int64_t)b * d.ds_b + (int64_t)oy * d.ds_y + ox0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                v[p] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (ok[r][p][k]) v[p] += t[r][p][c][k] * wt[r][p][k];
-            }
-            *(f32x4*)(dp + (int64_t)c * d.ds_c) = f32x4{v[0], v[1], v[2], v[3]};
-        }
-    }
-}
+// (Round 5 built the variant asked for twice -- a lane owns FOUR consecutive output pixels of two rows, 16-byte stores: bit-identical and 2x SLOWER,
+// 25.1 vs 11.7 us back to back, the gathers lose their coalescing.  Removed from the library in round 6: profiles/experiments/r05_warp_v4_four_pixels_per_lane.patch.)
 
 // transpose of the gather: scatter-add of the same four weights into d_src (fp32)
 __global__ void warp_bwd_kernel(const WArgs a) {
@@ -235,14 +175,10 @@ extern "C" int hesic_warp_perspective_forward(const hesic_warp_desc* d, const vo
     if (int e = check(d, "warp_perspective_forward")) return e;
     HESIC_CHECK_ARG(src && M && dst, "warp_perspective_forward: null pointer");
     WArgs a; a.d = *d; a.src = src; a.M = M; a.dst = dst; a.dsrc = nullptr;
-    static const bool generic = getenv("HESIC_WARP_GENERIC") != nullptr;              // A/B switch for profiling
-    const bool fast = !generic && d->C == 3 && d->src_dtype == HESIC_F32 && d->dst_dtype == HESIC_F32 && d->ss_x == 1 && d->ds_x == 1 &&
+    const bool fast = d->C == 3 && d->src_dtype == HESIC_F32 && d->dst_dtype == HESIC_F32 && d->ss_x == 1 && d->ds_x == 1 &&
                       d->ss_y > 0 && d->ss_c > 0 && (2 * d->ss_c + (int64_t)(d->H + 1) * d->ss_y + d->W + 2) * 4 < (1ll << 31) &&
                       d->Ho < 65536 && d->B < 65536;
-    static const bool v4 = getenv("HESIC_WARP_V4") != nullptr;      // A/B switch: four pixels per lane, 16-byte stores
-    if (fast && v4 && d->Wo % 4 == 0 && d->ds_y % 4 == 0 && d->ds_c % 4 == 0 && d->ds_b % 4 == 0 && ((uintptr_t)dst & 15) == 0)
-        hipLaunchKernelGGL(warp_fwd_f32c3_v4_kernel, dim3((d->Wo + 511) / 512, (d->Ho + V4_ROWS - 1) / V4_ROWS, d->B), dim3(128), 0, (hipStream_t)stream, a);
-    else if (fast)
+    if (fast)
         hipLaunchKernelGGL(warp_fwd_f32c3_kernel, dim3((d->Wo + 255) / 256, (d->Ho + WARP_ROWS - 1) / WARP_ROWS, d->B), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)d->Ho * d->Wo, 256), d->B), dim3(256), 0, (hipStream_t)stream, a);

@@ -2209,249 +2209,9 @@ __global__ __launch_bounds__(256) void gdn128_bwd_kernel(const h16_t* __restrict
     }
 }
 
-// ---- Round 5: the same pass as TWO tile pipelines per CU (training form: the parameter gradients ride along).
-// One block of four waves (one per SIMD, 128 KB of LDS) left every phase of a tile exposed: per tile and wave ~1500 VALU instructions (6 k
-// cycles), 96 MFMAs (3 k), ~300 LDS instructions and two block barriers run one after the other -- 16 k cycles per tile where the HBM
-// traffic of the tile (98 KB) needs 8 k at 6.4 TB/s (profiles/r05_g_pmc_sq_train.json: MFMA pipe 16 % busy, 40 % of the wave cycles parked).
-// Here a block is EIGHT waves = two groups of four, each group with its own (x, gy) tile pair; gamma' is held once (row-major only: the
-// second GEMM reads its transposed fragments with ds_read_b64_tr_b16 as the third one does) -- 32 + 2 x 64 KB = all 160 KB.  The groups run
-// the same loop one segment apart: the block barriers a group needs anyway (dn complete / x tile free) are the hand-over points, so while
-// one group is in its matrix segment (GEMM2 + GEMM3) the other is in its memory / VALU segment (dx out, next tile in, GEMM1, epilogue) on
-// the same SIMDs.  256 registers per wave instead of 512: the next tile is not prefetched into registers but requested as LDS-DMA right
-// after the copy-out (wave-private rows; its latency is covered by the other group's segment), beta' comes in as the initial value of the
-// first GEMM's accumulators (from a 512-byte scratch in the block's own partial slot) instead of an add per value.
-// Same arithmetic per value as gdn128_bwd_kernel<true, INV> except that n = beta' + sum starts from beta' (one rounding earlier).
-// RESULT (why it is not the default): correct (the GDN and training-trace tests pass with HESIC_GDN_BWD2=1) and 12 - 20 % SLOWER.  The block barrier
-// is the only cheap synchronisation, so the groups move in lockstep and a tile's segments pair one to one with the partner's -- but the
-// dependences leave no balanced cut: everything except the third GEMM (final epilogue, tile exchange, GEMM1, the 64-value rsqrt epilogue, GEMM2)
-// has to sit between "x tile free" and "dn complete", ~85 % of a tile's cycles, and that segment of one group only ever runs against the
-// short one of the other; the next tile's request, which the one-group form issues a whole tile ahead into 64 spare registers, is
-// exposed here (no registers, no LDS left to prefetch into).  ~22 k cycles per tile against 17.8 k.  What would help is LDS for a second
-// tile pair per group (another 64 KB per group), which the CU does not have.
-template <bool INV>
-__global__ __launch_bounds__(512) void gdn128_bwd2_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gy, const float* __restrict__ beta,
-                                                          const float* __restrict__ gamma, h16_t* __restrict__ dx, float* __restrict__ part, int64_t P,
-                                                          float beta_bound) {
-    constexpr bool inverse = INV;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* gs = smem;                                           // gamma' [i][j]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wq = wave & 3;
-    unsigned char* xs = smem + 32768 + grp * 65536;                    // this group's x tile [128 px][128 ch] (becomes dx)
-    unsigned char* ds = xs + 32768;                                     // and its gy tile (becomes dn)
-    const int frow = lane & 31, fh = lane >> 5;
-    for (int c = tid; c < 128 * 16; c += 512) {
-        const int row = c >> 4, slot = c & 15;
-        const f32x4 a0 = *(const f32x4*)(gamma + row * 128 + slot * 8), a1 = *(const f32x4*)(gamma + row * 128 + slot * 8 + 4);
-        *(u32x4*)(gs + gb_off(row, slot)) =
-            u32x4{pack_h2(reparam(a0.x, kGammaBound), reparam(a0.y, kGammaBound)), pack_h2(reparam(a0.z, kGammaBound), reparam(a0.w, kGammaBound)),
-                  pack_h2(reparam(a1.x, kGammaBound), reparam(a1.y, kGammaBound)), pack_h2(reparam(a1.z, kGammaBound), reparam(a1.w, kGammaBound))};
-    }
-    float* out = part + (int64_t)blockIdx.x * (128 * 128 + 128);
-    float* scratch = out + 128 * 128;                                   // beta' until the block's dbeta' partial is written there
-    if (tid < 128) scratch[tid] = reparam(beta[tid], beta_bound);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int64_t ntiles = (P + 127) / 128;
-    const int G = (int)gridDim.x;
-    const int64_t mine = ntiles > (int64_t)blockIdx.x ? (ntiles - blockIdx.x + G - 1) / G : 0;      // tiles blockIdx.x, + G, ...: the groups alternate
-    const int iters = (int)((mine + 1) / 2);                            // the same for both groups: a tile past the end reads zeros, its stores are dropped
-    const int r0 = wq * 32;
-    const int nbytes = (int)(P * 256);                                  // P < 2^22 (host)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)scratch, 0, 512, 0x00020000);
-    const int lofs = (r0 + (lane >> 4)) * 256 + (lane & 15) * 16;     // copy-out: this lane's first row / LOGICAL slot
-    // LDS-DMA: instruction `it` fills rows r0 + 4 it .. + 3 linearly (lane = row in four, PHYSICAL slot); the lane fetches the logical slot
-    // that gb_off puts there: (row & 3) = lane >> 4, (row >> 2) & 3 = it & 3 (r0 is a multiple of 32)
-    int dofs[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dofs[k] = (r0 + (lane >> 4)) * 256 + (((lane & 15) ^ (((lane >> 4) << 2) | k)) << 4);
-    f32x16 acc[4];
-    auto load_tile = [&](int64_t t) {
-        const int base = t < ntiles ? (int)t * 32768 : nbytes;           // past the end: every offset out of range
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            // the tile offset rides in the VGPR offset: that is the part the buffer unit range-checks
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(xs + (r0 + it * 4) * 256), 16, dofs[it & 3] + it * 1024 + base, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (__attribute__((address_space(3))) void*)(ds + (r0 + it * 4) * 256), 16, dofs[it & 3] + it * 1024 + base, 0, 0, 0);
-        }
-        // beta' -> the first GEMM's accumulators (lane: channels i*32 + 8g + 4fh + e)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, (i * 32 + 8 * g + 4 * fh) * 4, 0, 0));
-                acc[i][4 * g] = bq.x; acc[i][4 * g + 1] = bq.y; acc[i][4 * g + 2] = bq.z; acc[i][4 * g + 3] = bq.w;
-            }
-    };
-    f32x16 g3[4];
-    float cs = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g3[j][r] = 0.f;
-    // lane ids as opaque copies, re-laundered at the top of every segment of the tile loop: the swizzled LDS addresses built from them are
-    // then recomputed there (a few VALU operations each) instead of being hoisted out of the loop into ~150 long-lived registers -- a wave has 256
-    int frq = frow, fhq = fh, tgq = lane >> 4, ttq = lane & 15;
-    auto tr = [&](const unsigned char* tile_, int cb, int px_) {
-        const int ch = cb + (tgq & 1) * 16 + 4 * (ttq & 3);
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile_ + gb_off(px_, ch >> 3) + (ch & 7) * 2));
-    };
-
-    int64_t tile = (int64_t)blockIdx.x + (int64_t)grp * G;
-    load_tile(tile);
-    // eight stores the range check drops: the loop is entered with the queue of memory operations its back edge carries (32 loads, then 8 stores)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, dxr, nbytes, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) __builtin_amdgcn_s_barrier();                        // one segment behind group 0
-    for (int itn = 0; itn < iters; ++itn, tile += 2 * (int64_t)G) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // the tile and beta' are in; the previous tile's stores may still be on their way
-        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
-        // ---- GEMM1: n = beta' + gamma' x^2 (this wave's 32 pixel rows)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const u32x4 raw = *(const u32x4*)(xs + gb_off(r0 + frq, ks * 2 + fhq));
-            const float f0 = h2f_lo(raw.x), f1 = h2f_hi(raw.x), f2 = h2f_lo(raw.y), f3 = h2f_hi(raw.y);
-            const float f4 = h2f_lo(raw.z), f5 = h2f_hi(raw.z), f6 = h2f_lo(raw.w), f7 = h2f_hi(raw.w);
-            const h16x8 xf = __builtin_bit_cast(h16x8, u32x4{pack_h2(f0 * f0, f1 * f1), pack_h2(f2 * f2, f3 * f3), pack_h2(f4 * f4, f5 * f5), pack_h2(f6 * f6, f7 * f7)});
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const h16x8 gf = *(const h16x8*)(gs + gb_off(i * 32 + frq, ks * 2 + fhq));
-                acc[i] = mfma_32x32x16_h16(gf, xf, acc[i], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);          // 256 registers per wave: the fragment reads of one k-step at a time
-        }
-        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = i * 32 + 8 * g + 4 * fhq;
-                const int off = gb_off(r0 + frq, ch >> 3) + (ch & 7) * 2;
-                const u32x2 xq = *(const u32x2*)(xs + off), gq = *(const u32x2*)(ds + off);
-                const float xv[4] = {h2f_lo(xq.x), h2f_hi(xq.x), h2f_lo(xq.y), h2f_hi(xq.y)};
-                const float gv[4] = {h2f_lo(gq.x), h2f_hi(gq.x), h2f_lo(gq.y), h2f_hi(gq.y)};
-                float dn[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float n = acc[i][4 * g + e];
-                    const float rs = __builtin_amdgcn_rsqf(n);
-                    if (inverse) {
-                        dn[e] = 0.5f * gv[e] * xv[e] * rs;
-                        acc[i][4 * g + e] = gv[e] * (n * rs);
-                    } else {
-                        dn[e] = -0.5f * gv[e] * xv[e] * rs * rs * rs;
-                        acc[i][4 * g + e] = gv[e] * rs;
-                    }
-                }
-                *(u32x2*)(ds + off) = u32x2{pack_h2(dn[0], dn[1]), pack_h2(dn[2], dn[3])};
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // B1: the group's dn tile is complete
-        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
-        // ---- GEMM3: dgamma'[i][j] += sum_p dn[p][i] x[p][j]^2 over the group's 128 pixels; wave wq owns columns 32 wq .. + 31
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int pix = ks * 16 + (tgq >> 1) * 8 + (ttq >> 2);
-            const s16x8 vx = __builtin_shufflevector(tr(xs, wq * 32, pix), tr(xs, wq * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-            u32x4 ux = __builtin_bit_cast(u32x4, vx);
-            uint32_t* w4 = (uint32_t*)&ux;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float l2 = h2f_lo(w4[q]), h2 = h2f_hi(w4[q]);
-                w4[q] = pack_h2(l2 * l2, h2 * h2);
-            }
-            const h16x8 xf = __builtin_bit_cast(h16x8, ux);
-            {
-                const s16x8 vc = __builtin_shufflevector(tr(ds, wq * 32, pix), tr(ds, wq * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-                const u32x4 ua = __builtin_bit_cast(u32x4, vc);
-                cs += ((h2f_lo(ua.x) + h2f_hi(ua.x)) + (h2f_lo(ua.y) + h2f_hi(ua.y))) + ((h2f_lo(ua.z) + h2f_hi(ua.z)) + (h2f_lo(ua.w) + h2f_hi(ua.w)));
-            }
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const s16x8 va = __builtin_shufflevector(tr(ds, ib * 32, pix), tr(ds, ib * 32, pix + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-                g3[ib] = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, va), xf, g3[ib], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // B2: every wave of the group is done with the x and dn tiles
-        asm volatile("" : "+v"(frq), "+v"(fhq), "+v"(tgq), "+v"(ttq));
-        // ---- GEMM2 + dx, one 32-channel block at a time (16 live registers of s instead of 64): s[j][p] = sum_i gamma'[i][j] dn[p][i] with the
-        // gamma'^T fragments through transposing reads of gs and this wave's own dn rows; dx = t1 + 2 x s goes into the x tile
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 s2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s2[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const h16x8 df = *(const h16x8*)(ds + gb_off(r0 + frq, ks * 2 + fhq));
-                const int kr = ks * 16 + (tgq >> 1) * 8 + (ttq >> 2);
-                const s16x8 va = __builtin_shufflevector(tr(gs, i * 32, kr), tr(gs, i * 32, kr + 4), 0, 1, 2, 3, 4, 5, 6, 7);
-                s2 = mfma_32x32x16_h16(__builtin_bit_cast(h16x8, va), df, s2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = i * 32 + 8 * g + 4 * fhq;
-                const int off = gb_off(r0 + frq, ch >> 3) + (ch & 7) * 2;
-                const u32x2 xq = *(const u32x2*)(xs + off);
-                const float xv[4] = {h2f_lo(xq.x), h2f_hi(xq.x), h2f_lo(xq.y), h2f_hi(xq.y)};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[i][4 * g + e] + 2.f * xv[e] * s2[4 * g + e];
-                *(u32x2*)(xs + off) = u32x2{pack_h2(o[0], o[1]), pack_h2(o[2], o[3])};
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // copy-out: the rows go to registers, the NEXT tile is requested, THEN the stores are issued -- the wait at the loop top is "all but the
-        // newest eight" = the loads only (the counter is in order: loads requested behind the stores would wait for a store round trip each tile)
-        const int so = tile < ntiles ? (int)tile * 32768 + lofs : nbytes;
-        u32x4 ob[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int c = it * 64 + lane, row = c >> 4, slot = c & 15;
-            ob[it] = *(const u32x4*)(xs + gb_off(r0 + row, slot));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the rows are in registers: the DMA may overwrite them
-        __builtin_amdgcn_sched_barrier(0);
-        load_tile(tile + 2 * (int64_t)G);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(ob[it], dxr, so + (tile < ntiles ? it * 1024 : 0), 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();                        // the barrier group 1 started with
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // the trailing (out-of-range) tile request has landed: the tiles are free
-    __syncthreads();
-    // the two groups' partials: group 1 hands its own over through its tile area, group 0 adds and writes the block's partial
-    float* xg = (float*)(smem + 32768 + 65536);                         // 64 KB: [wq][ib][r][lane], then [wq][lane] column sums behind it (group 0's area)
-    float* xc = (float*)(smem + 32768);
-    cs += __shfl_xor(cs, 32);
-    if (grp == 1) {
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xg[((wq * 4 + ib) * 16 + r) * 64 + lane] = g3[ib][r];
-        xc[wq * 64 + lane] = cs;
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                out[(ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 128 + wq * 32 + frow] = g3[ib][r] + xg[((wq * 4 + ib) * 16 + r) * 64 + lane];
-        if (fh == 0) out[128 * 128 + wq * 32 + frow] = cs + xc[wq * 64 + lane];
-    }
-}
+// (Round 5 built a two-pipelines-per-CU form of this pass, gdn128_bwd2_kernel: correct, 12 - 20 % slower -- the block barrier is the only cheap
+// synchronisation and the dependences leave no balanced cut for two groups in lockstep.  Removed from the library in round 6; the kernel, its
+// launch and the measurements are kept as profiles/experiments/r05_gdn128_bwd2_two_pipelines.patch.)
 
 static WgTrArgs make_tr_args(const WgArgs& a, float* zero_me, int zero_n) {
     WgTrArgs A;
@@ -2459,7 +2219,7 @@ static WgTrArgs make_tr_args(const WgArgs& a, float* zero_me, int zero_n) {
     A.zero_me = zero_me; A.zero_n = zero_n;
     A.dqw = make_fastdiv((uint32_t)a.QW);
     A.dqh = make_fastdiv((uint32_t)a.QH);
-    static const bool slow = getenv("HESIC_WGRAD_SLOWQ") != nullptr;          // A/B switch for profiling
+    constexpr bool slow = false;          // A/B switch for profiling
     A.fastq = (!slow && a.QW % 16 == 0 && a.chunk % 64 == 0) ? 1 : 0;
     return A;
 }
@@ -2481,41 +2241,29 @@ void launch_wgrad_tr(const WgArgs& a, int64_t blocks, hipStream_t st, float* zer
         return;
     }
     const WgTrArgs A = make_tr_args(a, zero_me, zero_n);
-    // A/B switch: the stage ring.  0 = <64, 2> (rounds 2-4), 1 = <32, 5>, 2 = <32, 4>, 3 = <64, 3> (96 KB: one block per CU), 4 = <64, 2> with the
-    // stage's DMA instructions spread behind the k-steps' MFMAs.  Training step, same box, alternating runs (ms): 0: 9.89 / 9.91 | 1: 11.30 |
-    // 2: 11.32 | 3: 12.36 | 4: 10.58 -- more bytes in flight, or cheaper issue slots for the DMA instructions, are not what the loop is short
-    // of: halving the step doubles its barriers, one block per CU loses the other block's cover, late DMA issue shows up as latency.
-    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32 * 512);
-        (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 512);
-        attr = true;
-    }
+    // the stage ring is <64, 2>.  Measured and dropped (training step, same box, ms; round 5): <64, 2> 9.89 / 9.91 | <32, 5> 11.30 | <32, 4> 11.32 | <64, 3>
+    // (96 KB: one block per CU) 12.36 | <64, 2> with the stage's DMA instructions spread behind the k-steps' MFMAs 10.58 -- more bytes in flight, or
+    // cheaper issue slots for the DMA instructions, are not what the loop is short of.
     const dim3 g((unsigned)blocks), b(NT);
-    if (ring == 1) hipLaunchKernelGGL((wgrad_tr_kernel<32, 5>), g, b, 5 * 32 * 512, st, A);
-    else if (ring == 2) hipLaunchKernelGGL((wgrad_tr_kernel<32, 4>), g, b, 4 * 32 * 512, st, A);
-    else if (ring == 3) hipLaunchKernelGGL((wgrad_tr_kernel<64, 3>), g, b, 3 * 64 * 512, st, A);
-    else if (ring == 4) hipLaunchKernelGGL((wgrad_tr_kernel<64, 2, true>), g, b, 2 * 64 * 512, st, A);
-    else hipLaunchKernelGGL((wgrad_tr_kernel<64, 2>), g, b, 2 * 64 * 512, st, A);
+    hipLaunchKernelGGL((wgrad_tr_kernel<64, 2>), g, b, 2 * 64 * 512, st, A);
 }
 
 int pick_splits(int64_t Q, int bk, int tiles, bool batched = false) {
     // aim at ~384 blocks (measured best on MI355X for the step as a whole: every extra slice is another fp32 partial tile
     // to write and reduce), at least 4 K-steps per block
-    static const int target0 = getenv("HESIC_WGRAD_BLOCKS") ? atoi(getenv("HESIC_WGRAD_BLOCKS")) : 384;   // A/B switch
+    constexpr int target0 = 384;   // A/B switch
     // The layers with many pixels (first measured from Q >= 100000 on: 128 -> 128 5x5 on 256^2 inputs at B=8, 25 tap blocks per slice): 16 slices = 400 blocks leave 22 % of
     // the 512 block slots (256 CUs x 2) empty for the whole launch, 21 slices = 525 blocks run a second round for 13 of them; 20 slices = 500
     // blocks fill one round.  Training step, same box, alternating runs (ms): 384: 10.65 / 10.66 / 10.48 | 448: 10.70 (earlier box) | 475: 10.57 |
     // 500: 10.53 / 10.53 / 10.33 / 10.33 | 512: 11.01 (earlier box) | 1000: 10.64; 500 for EVERY layer: 10.48 (no gain).  0 = off (A/B).
-    static const int big_target = getenv("HESIC_WGRAD_BLOCKS_BIG") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG")) : 500;
+    constexpr int big_target = 500;
     // from which pixel count on (same box, alternating runs, ms): 100000: 10.62 / 10.61 | 30000 (adds the 128 -> 128 layers on 128^2 inputs): 10.57 / 10.59 | 8000: 10.71
-    static const int64_t big_q = getenv("HESIC_WGRAD_BIG_Q") ? atoll(getenv("HESIC_WGRAD_BIG_Q")) : 30000;      // A/B switch
+    constexpr int64_t big_q = 30000;      // A/B switch
     // batched route (hesic_conv2d_wgrad_nsplit(d, 1)): the grid is shared with the other queued layers, so a layer need not fill the 512 block
     // slots by itself -- fewer slices = fewer fp32 partial tiles to write and reduce.  Training step, same box, alternating runs (ms), small /
     // large-layer targets: 384 / 500: 9.187 / 9.189 | 256 / 500: 9.140 | 200 / 250: 9.077 / 9.074 | 128 / 250: 9.076 | 100 / 125: 9.308
-    static const int bt_small = getenv("HESIC_WGRAD_BLOCKS_BATCHED") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BATCHED")) : 200;
-    static const int bt_big = getenv("HESIC_WGRAD_BLOCKS_BIG_BATCHED") ? atoi(getenv("HESIC_WGRAD_BLOCKS_BIG_BATCHED")) : 250;
+    constexpr int bt_small = 200;
+    constexpr int bt_big = 250;
     const int target = batched ? (Q >= big_q ? bt_big : bt_small) : ((big_target && Q >= big_q) ? big_target : target0);
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t maxs = Q / (4 * bk) > 0 ? Q / (4 * bk) : 1;
@@ -2551,8 +2299,7 @@ int fill_args(const hesic_conv_desc* d, WgArgs& a, int nsplit_override = 0) {
                  a.QW % 64 == 0 && a.Q >= minq && a.Q < (1ll << 31) && off32;
     }
     if (a.rowk) {
-        const char* tb = getenv("HESIC_WGRAD_ROW_BLOCKS");
-        const int target = tb ? atoi(tb) : 256;                 // one block per CU (150 KB of LDS)
+        const int target = 256;                 // one block per CU (150 KB of LDS)
         const int64_t stages = a.Q / 64;
         int64_t s = target / (5 * a.co_tiles * a.ci_tiles);
         if (s < 1) s = 1;
@@ -2583,7 +2330,7 @@ extern "C" int hesic_conv2d_wgrad_nsplit(const hesic_conv_desc* d, int batched) 
     if (!d || d->KH * d->KW > 25) return 0;
     WgArgs a;
     fill_args(d, a);
-    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
+    constexpr int ring = WGRAD_RING_DEFAULT;
     if (a.rowk || !batched || ring != 0 || !wgrad_tr_path(d, a)) return a.nsplit;      // only the shared-grid kernel's layers take another count
     const int bk = d->dtype == HESIC_H16 ? WC<h16_t>::BK : WC<float>::BK;
     fill_args(d, a, pick_splits(a.Q, bk, a.ntaps * a.co_tiles * a.ci_tiles, true));
@@ -2592,7 +2339,7 @@ extern "C" int hesic_conv2d_wgrad_nsplit(const hesic_conv_desc* d, int batched) 
 
 // point a.bias_part behind the weight partials in ws and list the taps whose blocks sum dY's columns; false: no such tap set
 static bool setup_bias_part(const hesic_conv_desc* d, WgArgs& a, void* ws) {
-    static const bool off = getenv("HESIC_WGRAD_BIAS_COLSUM") != nullptr;      // A/B switch: the separate column-sum blocks of rounds 1-3
+    constexpr bool off = false;      // A/B switch: the separate column-sum blocks of rounds 1-3
     a.bias_part = nullptr; a.nb_taps = 0;
     if (off || !wgrad_tr_path(d, a) || a.ntaps < 1) return false;
     if (!d->transposed) { a.nb_taps = 1; a.b_tap[0] = 0; }
@@ -2638,7 +2385,7 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     hipStream_t st = (hipStream_t)stream;
     a.x = x; a.dy = dy; a.out = (float*)ws;
     const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-    static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
+    constexpr bool wg_legacy = false;
     bool prefix = true;                               // live taps must be tap_id[0] + 0,1,2,... for the fast kernel
     for (int i = 0; i < a.ntaps; ++i) prefix = prefix && a.tap_id[i] == a.tap_id[0] + i;
     const bool off32 = ((int64_t)a.B * a.H * a.W + 64) * a.x_ps * 2 < (1ll << 31) && ((int64_t)a.B * a.Ho * a.Wo + 64) * a.y_ps * 2 < (1ll << 31);
@@ -2651,7 +2398,7 @@ extern "C" int hesic_conv2d_wgrad(const hesic_conv_desc* d, const void* x, const
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
     const int64_t per_tap = (int64_t)d->Cout * d->Cin;
     if (a.ntaps < d->KH * d->KW) zero_async(dw_packed, (int64_t)d->KH * d->KW * per_tap, st);
-    static const bool split_launch = getenv("HESIC_WGRAD_SPLIT_FINISH") != nullptr;     // A/B switch for profiling
+    constexpr bool split_launch = false;     // A/B switch for profiling
     if (dbias && !split_launch) {
         if (!db_zeroed) zero_async(dbias, d->Cout, st);
         const int64_t P = (int64_t)d->B * d->Ho * d->Wo;
@@ -2697,7 +2444,7 @@ static int make_finish(const hesic_conv_desc* d, const WgArgs& a, const void* ws
     // sums straight to the PyTorch layout.  Measured SLOWER on the training step (same box, alternating: 9.534 / 9.539 ms with it, 9.350 /
     // 9.352 without): the tap-strided 4-byte writes cost more than the wider reads save -- the 8 x 32 x taps tiles turn a tile round in LDS
     // and write runs along the destination's fastest index.
-    static const bool wide_on = getenv("HESIC_WGRAD_FINISH_WIDE") && atoi(getenv("HESIC_WGRAD_FINISH_WIDE")) == 1;
+    constexpr bool wide_on = false;
     if (wide_on && (d->Cin & 3) == 0) {
         f.wide = 1;
         f.tiles_ci = (d->Cin + 127) / 128; f.tiles_co = (d->Cout + 7) / 8;
@@ -2733,10 +2480,7 @@ static thread_local int g_wgrad_partial_only = 0;      // set by hesic_conv2d_wg
 // slices of a (tap, cout) row next to each other.  Measured neutral on the training step (same box, alternating runs: 9.579 / 9.583 ms
 // with it, 9.586 / 9.596 without): the finishing pass still reads 128-byte pieces (its 8 cout x 32 cin tiles) -- contiguity across
 // slices alone does not raise its 2.9 TB/s; a 512-byte-wide tile would be the next step.
-static int direct_ws_layout() {
-    const char* e = getenv("HESIC_WGRAD_WS_LAYOUT");
-    return (e && atoi(e) == 1) ? 1 : 0;
-}
+static int direct_ws_layout() { return 0; }
 
 extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                          int accumulate, void* ws, int64_t ws_bytes, void* stream) {
@@ -2754,7 +2498,7 @@ extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x
     hipStream_t st = (hipStream_t)stream;
     a.x = x; a.dy = dy; a.out = (float*)ws;
     const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-    static const bool wlog = getenv("HESIC_WGRAD_LOG") != nullptr;     // diagnostic: one line per weight-gradient launch (geometry, K slices)
+    constexpr bool wlog = false;     // diagnostic: one line per weight-gradient launch (geometry, K slices)
     if (wlog)
         fprintf(stderr, "[hesic] wgrad %s B=%d %dx%d Cin=%d -> %dx%d Cout=%d k=%d s=%d taps=%d Q=%lld nsplit=%d chunk=%lld blocks=%lld row=%d\n",
                 d->transposed ? "deconv" : "conv", d->B, d->H, d->W, d->Cin, d->Ho, d->Wo, d->Cout, d->KH, d->stride, a.ntaps, (long long)a.Q, a.nsplit,
@@ -2828,7 +2572,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
     a.ys_b = d->ys_b; a.ys_c = d->ys_c; a.ys_y = d->ys_y; a.ys_x = d->ys_x;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nw = (int64_t)d->Cout * d->Cin * d->KH * d->KW;
-    static const bool legacy = getenv("HESIC_SCONV_LEGACY") != nullptr;
+    constexpr bool legacy = false;
     const bool k5 = d->KH == 5 && d->KW == 5 && d->pad == 2;
     bool conv1 = false;
     const int64_t need = hesic_sconv2d_wgrad_ws_bytes(d);
@@ -2882,7 +2626,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
             }
         }
         if (!fused_done) {
-        static const bool chunk_form = getenv("HESIC_IM2COL_CHUNKS") != nullptr;      // A/B switch: the thread-per-chunk kernel of rounds 1-3
+        constexpr bool chunk_form = false;      // A/B switch: the thread-per-chunk kernel of rounds 1-3
         const void* nimg = conv1 ? x : dy;
         const int ndt = conv1 ? d->x_dtype : d->y_dtype;
         const int64_t nsb = conv1 ? d->xs_b : d->ys_b, nsc = conv1 ? d->xs_c : d->ys_c, nsy = conv1 ? d->xs_y : d->ys_y, nsx = conv1 ? d->xs_x : d->ys_x;
@@ -2902,7 +2646,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         a2.x = P; a2.dy = conv1 ? dy : x; a2.out = part;
         // conv1: the GEMM's "dY" operand IS dy (128 channels, 134 MB at B=8 512^2) -- its column sums (the bias gradient) come out of the same
         // launch (WgArgs::bias_part) instead of a second pass over it
-        static const bool bias_colsum = getenv("HESIC_WGRAD_BIAS_COLSUM") != nullptr;      // A/B switch
+        constexpr bool bias_colsum = false;      // A/B switch
         float* bpart = part + (int64_t)a2.nsplit * 128 * 96;
         if (conv1 && dbias && !bias_colsum) { a2.bias_part = bpart; a2.nb_taps = 1; a2.b_tap[0] = 0; }
         launch_wgrad_tr(a2, (int64_t)a2.ntaps * a2.co_tiles * a2.ci_tiles * a2.nsplit, st);
@@ -2929,7 +2673,7 @@ extern "C" int hesic_sconv2d_wgrad(const hesic_sconv_desc* d, const void* x, con
         const unsigned g = (unsigned)(tiles < NN_BLOCKS ? tiles : NN_BLOCKS);       // persistent blocks
         float* part = (ws && ws_bytes >= (int64_t)NN_BLOCKS * 450 * 4) ? (float*)ws : nullptr;
         // LDS-DMA staging: fp32 on both sides, non-negative strides, 32-bit byte offsets inside one image (HESIC_NN_DMA=0: register staging, A/B)
-        static const bool dma_off = getenv("HESIC_NN_DMA") && atoi(getenv("HESIC_NN_DMA")) == 0;
+        constexpr bool dma_off = false;
         auto span = [&](int64_t sc, int64_t sy, int64_t sx, int C_) { return (C_ * sc + (int64_t)(d->H + 4) * sy + (int64_t)(d->W + 4) * sx) * 4; };
         const bool dma = !dma_off && d->x_dtype == HESIC_F32 && d->y_dtype == HESIC_F32 && d->xs_c >= 0 && d->xs_y >= 0 && d->xs_x >= 0 && d->ys_c >= 0 &&
                          d->ys_y >= 0 && d->ys_x >= 0 && span(d->xs_c, d->xs_y, d->xs_x, 6) < (1ll << 31) && span(d->ys_c, d->ys_y, d->ys_x, 3) < (1ll << 31);
@@ -3052,7 +2796,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     HESIC_CHECK_ARG(x && dy && beta && gamma && dx && (g_gdn_partial_only || (dbeta && dgamma)) && ws && P > 0 && C > 0, "gdn_backward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float bound = sqrtf(beta_min + kPedestal);
-    static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr;
+    constexpr bool legacy = false;
     HESIC_CHECK_ARG(!g_gdn_partial_only || hesic_gdn_backward_partial_ok(P, C, dtype), "gdn_backward_partial: only the fused 128-channel 16-bit form leaves block partials");
     if (!legacy && C == 128 && dtype == HESIC_H16 && P < (1ll << 22)) {
         hesic_conv_desc d;
@@ -3077,26 +2821,12 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         }
         const int64_t tiles = (P + 127) / 128;
         const int nb = (int)(tiles < 256 ? tiles : 256);
-        static const bool split_params = getenv("HESIC_GDN_BWD_SPLIT") != nullptr;      // A/B switch: the three-launch form of round 2
+        constexpr bool split_params = false;      // A/B switch: the three-launch form of round 2
         if (!split_params) {
             // one pass: dx + a (128 x 128 + 128) parameter-gradient partial per block, then the block partials summed in a fixed order
             constexpr int NP = 128 * 128 + 128;
             float* part = (float*)base;
-            // round 5 experiment, OFF by default: two tile pipelines per CU (gdn128_bwd2_kernel; HESIC_GDN_BWD2=N: from N tiles on).  Measured SLOWER:
-            // 4096 tiles 172 - 194 us against 150 - 162 us, 1024 tiles 49 - 53 against 40 (same box), training step 9.19 / 9.20 against 8.94 / 8.97 ms.
-            static const int64_t two_from = getenv("HESIC_GDN_BWD2") ? atoll(getenv("HESIC_GDN_BWD2")) : 0;
-            if (two_from > 0 && tiles >= two_from) {
-                static bool attr2 = false;
-                if (!attr2) {
-                    (void)hipFuncSetAttribute((const void*)gdn128_bwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    (void)hipFuncSetAttribute((const void*)gdn128_bwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    attr2 = true;
-                }
-                if (inverse) hipLaunchKernelGGL((gdn128_bwd2_kernel<true>), dim3((unsigned)nb), dim3(512), 163840, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
-                                                (h16_t*)dx, part, P, bound);
-                else hipLaunchKernelGGL((gdn128_bwd2_kernel<false>), dim3((unsigned)nb), dim3(512), 163840, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
-                                        (h16_t*)dx, part, P, bound);
-            } else if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
+            if (inverse) hipLaunchKernelGGL((gdn128_bwd_kernel<true, true>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
                                             (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
             else hipLaunchKernelGGL((gdn128_bwd_kernel<true, false>), dim3((unsigned)nb), dim3(256), 131072 + 512, st, (const h16_t*)x, (const h16_t*)dy, beta, gamma,
                                     (h16_t*)dx, (h16_t*)nullptr, part, P, bound);
@@ -3120,7 +2850,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
         // (same kernels as hesic_conv2d_wgrad, with the X operand squared on load)
         a.x = x; a.dy = dn; a.out = (float*)wws; a.in_sq = 1;
         const int64_t blocks = (int64_t)a.ntaps * a.co_tiles * a.ci_tiles * a.nsplit;
-        static const bool wg_legacy = getenv("HESIC_WGRAD_LEGACY") != nullptr;
+        constexpr bool wg_legacy = false;
         if (wg_legacy) hipLaunchKernelGGL(wgrad_kernel<h16_t>, dim3((unsigned)blocks), dim3(NT), 0, st, a);
         else launch_wgrad_tr(a, blocks, st, dbp, 128);
         if (wg_legacy) zero_async(dbp, 128, st);
@@ -3137,7 +2867,7 @@ extern "C" int hesic_gdn_backward(const void* x, const void* dy, const float* be
     float* dgp = dx0 + P * C;
     float* dbp = dgp + (int64_t)C * C;
     zero_async(dgp, (int64_t)C * C + C, st);
-    static const bool small_split = getenv("HESIC_GDN3_BWD_SPLIT") != nullptr;      // A/B switch: the three passes
+    constexpr bool small_split = false;      // A/B switch: the three passes
     if (C == 3 && !small_split) {
         const dim3 g3(grid_for(P, 256 * 2, 1024));      // 128 blocks (the parameter pass's grid: few atomics) left half the CUs idle: 57.9 us
         if (dtype == HESIC_H16)
@@ -3170,7 +2900,7 @@ extern "C" int hesic_gdn_backward_acc(const void* x, const void* dy, const float
 }
 
 extern "C" int hesic_gdn_backward_partial_ok(int64_t P, int C, int dtype) {
-    static const bool legacy = getenv("HESIC_GDN_BWD_LEGACY") != nullptr, split_params = getenv("HESIC_GDN_BWD_SPLIT") != nullptr;
+    constexpr bool legacy = false, split_params = false;
     return (!legacy && !split_params && C == 128 && dtype == HESIC_H16 && P > 0 && P < (1ll << 22)) ? 1 : 0;
 }
 
@@ -3242,7 +2972,7 @@ extern "C" int hesic_conv2d_wgrad_partial_batched(int n, const hesic_conv_desc* 
                                                   const int64_t* ws_bytes, const int32_t* nsplit, void* stream) {
     HESIC_CHECK_ARG(n >= 0 && (n == 0 || (descs && x && dy && ws && ws_bytes)), "conv2d_wgrad_partial_batched: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    static const int ring = getenv("HESIC_WGRAD_RING") ? atoi(getenv("HESIC_WGRAD_RING")) : WGRAD_RING_DEFAULT;
+    constexpr int ring = WGRAD_RING_DEFAULT;
     struct Job { WgArgs a; int64_t blocks; };
     std::vector<Job> jobs;
     for (int i = 0; i < n; ++i) {

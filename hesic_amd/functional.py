@@ -94,7 +94,7 @@ def _apply(fn, *args):
     return fn.forward(_NoCtx(), *args)
 
 
-FUSE_GDN3 = __import__("os").environ.get("HESIC_NO_FUSE_GDN3") is None      # A/B switch: 3-channel (I)GDN inside the 6 -> 3 cat-conv launch
+FUSE_GDN3 = True      # module switch (tests / profiling): 3-channel (I)GDN inside the 6 -> 3 cat-conv launch
 
 
 def _c(t):
@@ -165,11 +165,11 @@ def set_wgrad_stream(stream):
 
 # Deferred finishing passes of the wide weight gradients (see _wide_conv_grads): a list while train.Trainer.step collects them
 _finish_queue = None
-GDN_FINISH_BATCH = _os.environ.get("HESIC_GDN_FINISH_BATCH", "1") != "0"      # A/B switch: 0 = one parameter finish per GDN backward (rounds 2-4)
-WGRAD_FINISH_BATCH = int(_os.environ.get("HESIC_WGRAD_FINISH_BATCH", "8"))     # A/B switch: 0 = one finishing launch per layer (rounds 2-3)
+GDN_FINISH_BATCH = True      # module switch: False = one parameter finish per GDN backward (rounds 2-4)
+WGRAD_FINISH_BATCH = 8     # module switch: 0 = one finishing launch per layer (rounds 2-3)
 # round 5: the split-K launches of the queued layers are deferred too and share grids (hesic_conv2d_wgrad_partial_batched); 0 = each layer's
 # split-K launch where its backward runs, only the finishing pass batched (A/B)
-WGRAD_PARTIAL_BATCH = _os.environ.get("HESIC_WGRAD_PARTIAL_BATCH", "1") != "0"
+WGRAD_PARTIAL_BATCH = True
 
 
 def defer_wgrad_finish(on):
@@ -701,7 +701,7 @@ class _ConvFn(torch.autograd.Function):
 
 
 import os as _os
-FUSE_CONV_GDN = _os.environ.get("HESIC_NO_FUSE") is None      # A/B switch for profiling
+FUSE_CONV_GDN = True      # module switch for profiling
 
 
 class PackedGdn:
@@ -740,7 +740,7 @@ class PackedGdn:
         return gp, bp
 
 
-FUSE_CONV_GDN_TRAIN = _os.environ.get("HESIC_NO_FUSE_TRAIN") is None      # A/B switch for profiling
+FUSE_CONV_GDN_TRAIN = True      # module switch for profiling
 
 
 def conv2d_gdn_fusable(x, weight, gdn_channels, transposed):
@@ -983,7 +983,7 @@ def analysis_conv2_single():
     return analysis_precision() == "x3c2"
 
 
-PAIR_WEIGHT_SCALING = _os.environ.get("HESIC_PAIR_WEIGHT_SCALING", "1") != "0"      # A/B switch (round 5)
+PAIR_WEIGHT_SCALING = True      # part of the pair arithmetic since round 5 (no run-time switch: it changes the last bit of y)
 
 
 def _pair_weight_shift(w):
@@ -1356,7 +1356,7 @@ def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     return y
 
 
-RESBLOCK_FUSED = _os.environ.get("HESIC_EN_TWO_LAUNCH") is None      # A/B switch: unset = a ResidualBlock is ONE launch at inference
+RESBLOCK_FUSED = True      # module switch: a ResidualBlock is ONE launch at inference
 
 
 def resblock_c32(x, w1, b1, w2, b2, act=L.ACT_LEAKY, res2=None):
@@ -1373,7 +1373,7 @@ def resblock_c32(x, w1, b1, w2, b2, act=L.ACT_LEAKY, res2=None):
     return y
 
 
-EN_TRAIN_FAST = _os.environ.get("HESIC_EN_GENERIC") is None      # A/B switch
+EN_TRAIN_FAST = True      # module switch
 
 
 def conv3x3_c32_train_ok(x, weight):
@@ -1577,7 +1577,7 @@ class _Gdn3PlanarFn(torch.autograd.Function):
         return dx, dbeta, dgamma, None, None
 
 
-GDN3_PLANAR_TRAIN = _os.environ.get("HESIC_GDN3_NHWC_TRAIN") is None      # A/B switch: the NHWC route of rounds 1-3 under autograd
+GDN3_PLANAR_TRAIN = True      # module switch: False = the NHWC route of rounds 1-3 under autograd
 
 
 def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
@@ -2127,7 +2127,7 @@ def mix_weights(pooled, weight, bias, K, M):
 
 
 # ----------------------------------------------------------------------------- reductions
-RD_SUMS_FUSED = _os.environ.get("HESIC_RD_SUMS_FUSED", "1") != "0"       # A/B switch: 0 = one launch per likelihood map / image pair (rounds 1-4)
+RD_SUMS_FUSED = True       # module switch: False = one launch per likelihood map / image pair (rounds 1-4)
 
 
 def sum_log2(lik, out=None):

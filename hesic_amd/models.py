@@ -27,11 +27,11 @@ RELU, LEAKY, NONE = L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE
 import os as _os
 import threading as _threading
 OVERLAP_STREAMS = _os.environ.get("HESIC_NO_OVERLAP") is None
-CAT_FREE_EP = _os.environ.get("HESIC_CAT_EP") is None          # A/B switch (HESIC+): set to go back to torch.cat in front of entropy_parameters
+CAT_FREE_EP = True          # module switch (HESIC+): False = torch.cat in front of entropy_parameters
 _side_streams = {}
 
 
-_RECORD = _os.environ.get("HESIC_NO_RECORD_STREAM") is None
+_RECORD = True
 
 
 def _rec(t, stream):
@@ -344,7 +344,7 @@ class Encoder1(nn.Module):
         if not hasattr(self, "_hl1"):
             self._hl1 = Fn.PackedWeightHiLo(), Fn.PackedGdnLo(), Fn.PackedN2wHiLo()
         gp, bp = g1.packer().get(g1.beta, g1.gamma, g1.beta_min)
-        fused1 = Fn.sconv_gdn_hilo_ok(x, c1.weight) and not _os.environ.get("HESIC_N2W_HILO_IM2COL")
+        fused1 = Fn.sconv_gdn_hilo_ok(x, c1.weight)
         if fused1 and Fn.analysis_conv2_single() and self.g_a_conv2.weight.shape[:2] == (128, 128):
             # "x3c2": conv1 + GDN on pairs inside the kernel, ONE 16-bit value per channel out; g_a_conv2 multiplies single operands,
             # its GDN runs on pairs again and hands pairs to g_a_conv3
@@ -360,7 +360,7 @@ class Encoder1(nn.Module):
             t = Fn.sconv_gdn_hilo(x, self._hl1[2].get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse)       # conv + GDN in one kernel
             if Fn.analysis_precision() == "x2":
                 # pairs everywhere, TWO products per MAC: x pairs x single error-feedback weights (no w_lo term)
-                p2, p3, p4 = (int(v) for v in _os.environ.get("HESIC_X2_LAYERS", "2,2,2").split(","))
+                p2, p3, p4 = X2_LAYERS
                 t = self.g_a_conv2.run_hilo(t, gdn=self.g_a_gdn2, products=p2)
                 t = self.g_a_conv3.run_hilo(t, gdn=self.g_a_gdn3, products=p3)
                 if not want_lo:
@@ -895,17 +895,18 @@ def _nhwc_rows(t):
 # A/B switch, OFF: g_a_conv3 / conv4 of "x3c2" on pairs x single error-feedback weights (hesic_conv2d_forward_hilo_w1, two products per pair).
 # Measured (round 4, same box, alternating runs): 3617 / 3586 pairs/s against 3582 / 3567 at three products (+0.7 %), flips 5.4e-4 vs 5.3e-4 at
 # 512^2 but 7.7e-4 vs 6.3e-4 on the 256^2 golden -- not worth a quarter of the margin to the 1e-3 bar
-X3C2_TWO_PRODUCT_TAIL = _os.environ.get("HESIC_X3C2_TAIL2") is not None
-WAVEFRONT_GRAPHS = _os.environ.get("HESIC_WAVEFRONT_GRAPHS", "1") != "0"      # A/B switch: 0 = round 3's per-group launches from Python
+X3C2_TWO_PRODUCT_TAIL = False
+X2_LAYERS = (2, 2, 2)          # "x2" mode (measured and not the default): products per MAC of g_a_conv2 / conv3 / conv4
+WAVEFRONT_GRAPHS = True      # module switch: False = round 3's per-group launches from Python
 # A/B switch: 1 = the device reads the decoded symbols from, and writes the tables into, pinned host memory itself (no copy nodes)
-WAVEFRONT_ZEROCOPY = _os.environ.get("HESIC_WAVEFRONT_ZEROCOPY", "1") != "0"
+WAVEFRONT_ZEROCOPY = True
 # A/B switch, off: 1 = the table launch of a group is the sixth node of its captured step (hesic_gmm_cdf_dyn: channel list and alphabet read on
 # the device).  Measured neutral (per view: 1.0 vs 1.6 ms of launch calls, 8.3 vs 7.6 ms of waiting -- a graph node costs what a launch costs)
-WAVEFRONT_TABLE_IN_GRAPH = _os.environ.get("HESIC_WAVEFRONT_TABLE_IN_GRAPH", "0") != "0"
+WAVEFRONT_TABLE_IN_GRAPH = False
 _CDF_WAVE_MAX = 1024          # csrc/entropy.hip: alphabets the wave-per-row table kernel takes
 # A/B switch: 1 = the C loop replays each group's recorded launches one by one instead of launching its graph
-WAVEFRONT_TAPE = _os.environ.get("HESIC_WAVEFRONT_TAPE", "1") != "0"
-WAVEFRONT_C_LOOP = _os.environ.get("HESIC_WAVEFRONT_C_LOOP", "1") != "0"      # A/B switch: 0 = the group loop in Python (six C calls per group)
+WAVEFRONT_TAPE = True
+WAVEFRONT_C_LOOP = True      # module switch: False = the group loop in Python (six C calls per group)
 PAYLOAD_MAGIC = b"HSC\x03"               # format 3 (round 5: two mode bytes).  Format 2 (round 4) had one; format 1 (rounds 2-3) no header
 TABLE_KERNEL_VERSION = 2                  # bump when hesic_gmm_cdf / the table-producing launches change their arithmetic
 _MODE_BYTES = 2

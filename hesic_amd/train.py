@@ -341,7 +341,7 @@ class FlatReducer:
             self._expected = [e if e > 0 else -1 for e in self._events]
 
 
-WGRAD_STREAM = _os.environ.get("HESIC_WGRAD_STREAM") is not None      # A/B switch (off): weight gradients on a stream of their own -- measured 12.34 vs 12.28 ms at B=8 512^2: the step is not gap-bound
+WGRAD_STREAM = False      # module switch (off): weight gradients on a stream of their own -- measured 12.34 vs 12.28 ms at B=8 512^2: the step is not gap-bound
 
 
 class Trainer:
