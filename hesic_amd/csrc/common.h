@@ -22,6 +22,7 @@ typedef uint16_t h16_t;   // raw bits of a 16-bit float (format: see above)
 #if HESIC_H16_IS_F16
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 #define mfma_32x32x16_h16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define mfma_16x16x32_h16 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define H16_ONE_PAIR 0x3c003c00u          /* two 1.0 */
 // squares that go through 16-bit storage inside the fused (I)GDN contractions are scaled by H16_SQ_SCALE (gamma' by its inverse, in
 // hesic_gdn_pack_params*): v^2 * 2^-6 stays finite up to |v| = 2047 where fp16 itself ends at 255
@@ -31,6 +32,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 #else
 typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
 #define mfma_32x32x16_h16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define mfma_16x16x32_h16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define H16_ONE_PAIR 0x3f803f80u
 #define H16_SQ_SCALE 1.0f
 #define H16_SQ_UNSCALE 1.0f

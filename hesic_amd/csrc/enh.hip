@@ -9,6 +9,11 @@
 // every wave walks four image rows of it: 18 ds_read_b128 + 18 v_mfma_f32_32x32x16_bf16 per 32 pixels, all 32 couts live.
 // Epilogue: bias, LeakyReLU, up to two residual tensors (the block's identity and the Enhancement_Block's outer skip),
 // bf16 NHWC out -- or, for the last layer (32 -> 3), fp32 planar out plus the fp32 planar residual image.
+// Round 6: the ROWS of the weight fragments are permuted (fragment row 8 j + 4 hh + e holds cout 16 hh + 4 j + e), so a lane's sixteen
+// accumulators are the couts 16 h .. 16 h + 15 of ONE pixel: 32 contiguous bytes of the NHWC row.  Residuals are read and outputs stored as two
+// 16-byte pieces per lane (a wave instruction covers 2 KB of consecutive pixels), the intermediate halo is written as two 16-byte chunks per
+// lane -- no fp32 turn-round through LDS any more (rounds 1 - 5: 4 ds_write_b128 + 4 ds_read_b128 and ~80 VALU instructions per 32 pixels;
+// 18 KB of LDS per block).  Same sums per value: bit-identical.
 // HBM-bound by construction: 64 B in + 64 B out per pixel (134 + 134 MB per layer at B=8 512x512).
 #include "common.h"
 
@@ -22,7 +27,6 @@ struct C32Args {
 
 constexpr int TH = 16, TW = 32, HW_ = TW + 2, HH = TH + 2, HPIX = HH * HW_;     // halo: 18 x 34 pixels of 64 bytes
 
-constexpr int OPITCH = 36;       // floats per staged output pixel (32 + 4: bank spread)
 
 // Next-tile halo pieces through inline-asm buffer loads the compiler cannot see: tracked loads pending at the head of the row-group loop
 // (which has stores in it) made it flush them there -- `s_waitcnt vmcnt(0)` right behind the request, the whole round trip exposed once per
@@ -42,17 +46,51 @@ __device__ __forceinline__ void c32_wait_pieces(u32x4 (&pc)[N]) {
     for (int u = 0; u < N; ++u) asm volatile("" : "+v"(pc[u]));       // the values are defined from here on
 }
 
+// fragment row -> output channel (see the header): row 8 j + 4 hh + e holds cout 16 hh + 4 j + e
+__device__ __forceinline__ int c32_cout_of_row(int row) { return 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3); }
+
+// act(v) with the activation known at compile time where the caller knows it (LK: LeakyReLU as max(v, 0.01 v) -- two instructions instead of the
+// multiply / compare / two selects of the run-time form; same value for every finite v)
+template <bool LK>
+__device__ __forceinline__ float c32_act(float v, int act) {
+    if constexpr (LK) return fmaxf(v, 0.01f * v);
+    else return apply_act(v, act);
+}
+
+// act(acc + bias) + res1 + res2 of a lane's sixteen couts -> two 16-byte stores.  NR = how many residual tensors take part (a missing one is not
+// added as + 0: one instruction per value).
+template <int NR, bool LK>
+__device__ __forceinline__ void c32_store_row(h16_t* dst, const f32x16& acc, const float (&bv)[16], int act, const u32x4 (&r1v)[2], const u32x4 (&r2v)[2]) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c32_act<LK>(acc[8 * it + e] + bv[8 * it + e], act);
+        const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (NR >= 2) {
+                v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
+                v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
+            } else if constexpr (NR == 1) {
+                v[2 * e] += h2f_lo(ra[e]);
+                v[2 * e + 1] += h2f_hi(ra[e]);
+            }
+        }
+        *(u32x4*)(dst + 8 * it) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+    }
+}
+
 // NRES (MODE 0): how many residual tensors the launch carries, at compile time -- with run-time null checks the row loop of a plain layer
 // still ended every row group in `s_waitcnt vmcnt(0)` (for loads it never issues), i.e. waited out the next tile's halo prefetch and
 // the previous row group's stores.
 template <int MODE, int NRES = 2>      // 0: 32 couts, bf16 NHWC out (+ bf16 NHWC residuals); 1: <= 4 couts, fp32 planar out (+ fp32 planar residual)
 __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char halo[HPIX * 64];
-    __shared__ __attribute__((aligned(16))) float ostage[4][32 * OPITCH];        // per wave: 32 pixels x 32 couts fp32, padded rows
     constexpr uint32_t POISON = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
-    // weights -> 18 A fragments: lane (cout = p, half h) holds channels k*16 + h*8 + [0,8) of tap t.  The (Cout,32,3,3) fp32
+    // weights -> 18 A fragments: lane (fragment row p = cout C32_COUT_OF_ROW(p), half h) holds channels k*16 + h*8 + [0,8) of tap t.  The (Cout,32,3,3) fp32
     // tensor comes in through LDS with coalesced loads (row pitch 289 floats: the per-lane gathers below hit 32 different
     // banks); gathering it straight from global memory cost every block ~9000 scattered cache-line requests.
     h16x8 wf[9][2];
@@ -70,19 +108,17 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             for (int k = 0; k < 2; ++k) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
+                for (int e = 0; e < 8; ++e) v[e] = wst[c32_cout_of_row(p) * 289 + (k * 16 + h * 8 + e) * 9 + t];
                 wf[t][k] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
             }
         __syncthreads();
     }
-    float bv[4][4];
+    float bv[16];          // accumulator r of this lane = cout 16 h + r
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 8 * j + 4 * h + e;
-            bv[j][e] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int c = 16 * h + r;
+        bv[r] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+    }
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     // halo -> registers: 16-byte piece i = (pixel i >> 2, slot i & 3) holds channel chunk slot ^ ((pixel >> 2) & 3); pixels
     // outside the image are poisoned offsets (zeros = the conv's zero padding).  The next tile's pieces are requested as soon
@@ -124,21 +160,15 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             const int yl = wave + 4 * rq;
             const int y = ty * TH + yl, x = tx * TW + p;
             const bool live = y < a.H && x < a.W;
-            // Row-major view of the wave's 32 output pixels: lane -> (pixel (lane >> 2) + 16 it, 16-byte chunk lane & 3), so loads
-            // and stores are full 64-byte pixel rows, 1 KB contiguous per instruction (the accumulator layout -- 8 bytes per lane,
-            // lanes 64 bytes apart -- cost 43 us of scattered stores and 30 us per residual).  Residuals are requested here, before
-            // the MFMAs, and added in fp32 after the tile has turned round in the wave's LDS slice.
-            const int rpx = lane >> 2, rch = lane & 3;
+            // a lane's 32 output bytes (couts 16 h .. 16 h + 15 of pixel p): residuals are requested here, before the MFMAs
+            const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * 32 + 16 * h;
             u32x4 r1v[2], r2v[2];
             float rp[4];
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int xx = tx * TW + rpx + 16 * it;
-                    const bool lv = y < a.H && xx < a.W;
-                    const int64_t o = (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8;
-                    r1v[it] = (NRES >= 1 && lv) ? *(const u32x4*)((const h16_t*)a.res1 + o) : u32x4{0u, 0u, 0u, 0u};
-                    r2v[it] = (NRES >= 2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r1v[it] = (NRES >= 1 && live) ? *(const u32x4*)((const h16_t*)a.res1 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
+                    r2v[it] = (NRES >= 2 && live) ? *(const u32x4*)((const h16_t*)a.res2 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
                 }
             } else {
 #pragma unroll
@@ -159,38 +189,15 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
-            // D[cout][pixel]: lane holds pixel p, couts 8 j + 4 h + e (j = r >> 2, e = r & 3)
+            // D[fragment row][pixel]: lane holds pixel p, accumulator r = cout 16 h + r (permuted weight rows)
             if constexpr (MODE == 0) {
-                float* os = ostage[wave];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[4 * j + e] + bv[j][e], a.act);
-                    *(f32x4*)(os + p * OPITCH + 8 * j + 4 * h) = v;
-                }
-                // (wave-private slice: the LDS pipe keeps a wave's own writes and reads in order, no barrier)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int q = rpx + 16 * it, xx = tx * TW + q;
-                    const f32x4 lo = *(const f32x4*)(os + q * OPITCH + rch * 8), hi = *(const f32x4*)(os + q * OPITCH + rch * 8 + 4);
-                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
-                        v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
-                    }
-                    if (y < a.H && xx < a.W)
-                        *(u32x4*)((h16_t*)a.y + (((int64_t)b * a.H + y) * a.W + xx) * 32 + rch * 8) =
-                            u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
-                }
+                if (live) c32_store_row<NRES, false>((h16_t*)a.y + o, acc, bv, a.act, r1v, r2v);
             } else {
                 if (live && h == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c < a.Cout)
-                            ((float*)a.y)[(((int64_t)b * a.Cout + c) * a.H + y) * a.W + x] = apply_act(acc[c] + bv[0][c], a.act) + rp[c];
+                            ((float*)a.y)[(((int64_t)b * a.Cout + c) * a.H + y) * a.W + x] = apply_act(acc[c] + bv[c], a.act) + rp[c];
                 }
             }
         }
@@ -221,7 +228,7 @@ struct RBArgs {
 constexpr int RB_IW = TW + 4, RB_IH = TH + 4, RB_IPIX = RB_IW * RB_IH;      // input halo: 20 x 36 pixels
 constexpr int RB_NPC = (RB_IPIX * 4 + 511) / 512;                            // 16-byte pieces per thread: 6
 constexpr int RB_MCH = (HPIX + 31) / 32;                                     // 32-pixel groups of the 18 x 34 intermediate region: 20
-constexpr int RB_LDS = RB_IPIX * 64 + 2 * HPIX * 64 + 4 * 32 * OPITCH * 4;
+constexpr int RB_LDS = RB_IPIX * 64 + 2 * HPIX * 64;
 
 // Ablation builds (profiles/scripts/en_ablation.sh; never in the shipped libraries): -DRB_ABL=<bits>  1: no MFMAs (fragment reads stay), 2: no fragment
 // reads, 4: the consumers' identity / outer-skip loads and the output stores dropped, 8: no producer work at all, 16: no consumer work at all.
@@ -250,7 +257,6 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
     unsigned char* hin = rb_smem;                              // input halo, 64-byte pixels, chunk slot ^ ((pixel >> 2) & 3)
     unsigned char* hmid0 = rb_smem + RB_IPIX * 64;             // two intermediate halos, same layout
-    float* ostage_all = (float*)(rb_smem + RB_IPIX * 64 + 2 * HPIX * 64);
     constexpr uint32_t POISON = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, w4 = wave & 3;                 // 0: producer (conv1), 1: consumer (conv2)
@@ -272,19 +278,17 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                 for (int k = 0; k < 2; ++k) {
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = wst[p * 289 + (k * 16 + h * 8 + e) * 9 + t];
+                    for (int e = 0; e < 8; ++e) v[e] = wst[c32_cout_of_row(p) * 289 + (k * 16 + h * 8 + e) * 9 + t];
                     wf[t][k] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
                 }
         }
         __syncthreads();
     }
-    float bv[4][4];
+    float bv[16];          // accumulator r of this lane = cout 16 h + r (permuted weight rows, see the header)
     {
         const float* bp = role ? a.b2 : a.b1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = bp ? bp[8 * j + 4 * h + e] : 0.f;
+        for (int r = 0; r < 16; ++r) bv[r] = bp ? bp[16 * h + r] : 0.f;
     }
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -356,14 +360,14 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                     const int iy = ty * TH - 1 + mr, ix = tx * TW - 1 + mc;
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (m_raw < HPIX) {
-                        unsigned char* dst = hmid + m * 64 + 8 * h;
+                        unsigned char* dst = hmid + m * 64;
                         const int sw = (m >> 2) & 3;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float v[4];
+                        for (int it = 0; it < 2; ++it) {                 // channel chunks 2 h and 2 h + 1 of the pixel
+                            float v[8];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = inside ? apply_act(acc[4 * j + e] + bv[j][e], a.act) : 0.f;
-                            *(u32x2*)(dst + ((j ^ sw) << 4)) = u32x2{pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
+                            for (int e = 0; e < 8; ++e) v[e] = inside ? apply_act(acc[8 * it + e] + bv[8 * it + e], a.act) : 0.f;
+                            *(u32x4*)(dst + (((2 * h + it) ^ sw) << 4)) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
                         }
                     }
                 }
@@ -374,22 +378,21 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
             for (int rq = 0; rq < TH / 4; ++rq) {
                 const int yl = w4 + 4 * rq;
                 const int y = pty * TH + yl;
-                const int rpx = lane >> 2, rch = lane & 3;
-                // identity and outer skip of this row group, requested in front of its MFMAs.  Measured alternatives, all SLOWER here (one
-                // block per CU: 256 registers per wave, and what they added spilled or cost its own round trip): the identity of all four
-                // row groups requested a stage ahead (202 us per launch against 178), bias re-read per stage from LDS, the outer skip one
-                // row group ahead (237 against 178 for the launches that carry one).
+                // identity and outer skip of this lane's 32 output bytes (couts 16 h .. 16 h + 15 of pixel p), requested in front of the MFMAs.
+                // Measured alternatives, all SLOWER here (one block per CU: 256 registers per wave, and what they added spilled or cost its own
+                // round trip): the identity of all four row groups requested a stage ahead (202 us per launch against 178), bias re-read per
+                // stage from LDS, the outer skip one row group ahead (237 against 178 for the launches that carry one).
+                const int xx = ptx * TW + p;
+                const bool lv = y < a.H && xx < a.W;
+                const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + 16 * h;
                 u32x4 r1v[2], r2v[2];
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int xx = ptx * TW + rpx + 16 * it;
-                    const bool lv = y < a.H && xx < a.W;
-                    const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8;
 #if RB_ABL & 4
-                    r1v[it] = r2v[it] = u32x4{(uint32_t)o, 0u, 0u, 0u}; (void)lv;
+                    r1v[it] = r2v[it] = u32x4{(uint32_t)o, 0u, 0u, 0u};
 #else
-                    r1v[it] = lv ? *(const u32x4*)(a.x + o) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
-                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o) : u32x4{0u, 0u, 0u, 0u};
+                    r1v[it] = lv ? *(const u32x4*)(a.x + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
+                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
 #endif
                 }
                 f32x16 acc, acc1;
@@ -411,37 +414,312 @@ __global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
-                float* os = ostage_all + w4 * (32 * OPITCH);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[4 * j + e] + bv[j][e], a.act);
-                    *(f32x4*)(os + p * OPITCH + 8 * j + 4 * h) = v;
-                }
-                // (wave-private slice: the LDS pipe keeps a wave's own writes and reads in order, no barrier)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int q = rpx + 16 * it, xx = ptx * TW + q;
-                    const f32x4 lo = *(const f32x4*)(os + q * OPITCH + rch * 8), hi = *(const f32x4*)(os + q * OPITCH + rch * 8 + 4);
-                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t ra[4] = {r1v[it].x, r1v[it].y, r1v[it].z, r1v[it].w}, rb[4] = {r2v[it].x, r2v[it].y, r2v[it].z, r2v[it].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
-                        v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
-                    }
 #if RB_ABL & 4
-                    if (y < a.H && xx < a.W && v[0] == 1.2345e-30f)
+                if (lv && acc[0] == 1.2345e-30f)
 #else
-                    if (y < a.H && xx < a.W)
+                if (lv)
 #endif
-                        *(u32x4*)((h16_t*)a.y + (((int64_t)pb * a.H + y) * a.W + xx) * 32 + rch * 8) =
-                            u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
-                }
+                    c32_store_row<RES2 ? 2 : 1, false>((h16_t*)a.y + o, acc, bv, a.act, r1v, r2v);
             }
         }
         __syncthreads();
+        pb = b; pty = ty; ptx = tx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- ResidualBlock, row-rolling form (round 6)
+// What bounded the kernel above (profiles/r06_en_ablation.txt, r06_a_pmc_sq_en.json): every 32-pixel group re-reads its nine shifted fragments from
+// LDS -- 648 ds_read_b128 per 16 x 32 tile, ~5.2 k LDS cycles per CU and tile, as many as the matrix pipe needs per SIMD --, the epilogues cost as many
+// VALU cycles as the MFMAs matrix cycles, and the phases of the two lock-stepped roles add up.  Here a wave owns a COLUMN of 32 pixels and walks down
+// its rows:
+//   * the six fragments of an input row (three tap columns x two 16-pixel halves) are read ONCE and serve the three output rows that touch it
+//     (6 reads per 36 MFMAs instead of 36), four accumulator sets rotate: output row r accumulates while input rows r .. r + 2 pass, its epilogue
+//     stands one input row later, in the same scheduling region as MFMAs that do not depend on it;
+//   * v_mfma_f32_16x16x32 (K = 32 = all input channels of a tap) with the weight rows permuted so that a lane ends up with EIGHT CONSECUTIVE couts of
+//     one pixel: fragment row 4 g + e of cout half c2 holds cout 8 g + 4 c2 + e, lane (pixel px, g) of the D tile then owns couts 8 g .. 8 g + 7 =
+//     one 16-byte chunk of the NHWC row, four lanes a whole 64-byte pixel, a wave instruction 1 KB of consecutive pixels -- identity / outer-skip
+//     loads, output stores and the intermediate region's LDS writes need no turn-round (the 32 x 32 x 16 form leaves a lane 4 + 4 + 4 + 4 couts;
+//     with permuted rows 2 x 16 bytes at a 64-byte stride: measured 73 us of a 159 us launch in loads / stores);
+//   * the next tile's input halo lands by LDS-DMA in a second buffer (no register holds it; rounds 3 - 5 parked it in 24 registers per lane);
+//   * tile 14 x 30 output pixels: the intermediate region is 16 x 32 (a row = exactly one 32-pixel column group, four producer waves x four rows),
+//     the input halo 18 x 34.  A pixel's 64 bytes sit at (row * width + col) * 64, channel chunk c in slot c ^ ((col >> 1) & 3): conflict-free for
+//     the fragment reads of every tap column (brute-forced over the b128 lane groups) and for the 16-byte writes.
+// Summation order per output value: taps in raster order, one MFMA per tap.  Not the order of c32_conv3x3_kernel (two K = 16 halves per tap): the
+// ResidualBlock launch agrees with two launches of it to the last bit of the 16-bit result in all but ~1.5e-3 of the values (tested).
+#ifdef R3_STAMP          /* cycle stamps of block 0 (profiles/scripts/en_stamps.py; never in the shipped libraries) */
+__device__ unsigned long long* g_r3_stamp = nullptr;
+#define R3_ST(slot) do { if (blockIdx.x == 0 && lane == 0 && s >= 2 && s < 6) g_r3_stamp[((s - 2) * 8 + wave) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define R3_ST(slot) do {} while (0)
+#endif
+constexpr int R3_TH = 14, R3_TW = 30;
+constexpr int R3_IH = R3_TH + 4, R3_IW = R3_TW + 4, R3_MH = R3_TH + 2, R3_MW = R3_TW + 2;
+constexpr int R3_IPIX = R3_IH * R3_IW, R3_MPIX = R3_MH * R3_MW;              // 612, 512 pixels
+constexpr int R3_NDMA = (R3_IPIX * 4 + 63) / 64;                             // 1 KB LDS-DMA instructions per input halo: 39 (the last one partial)
+constexpr int R3_IBYTES = R3_NDMA * 1024, R3_MBYTES = (R3_MPIX + 2) * 64;    // (the consumers' dead columns 30, 31 read two pixels past a row)
+constexpr int R3_LDS_DATA = 2 * R3_IBYTES + 2 * R3_MBYTES;                   // two input halos, two intermediate regions: 142 KB
+constexpr int R3_LDS = R3_LDS_DATA + R3_NDMA * 64 * 2;                       // + the DMA pieces' halo positions (5 KB)
+static_assert(R3_IBYTES >= 32 * 289 * 4, "the weight staging buffer lives in the input halo");
+
+typedef f32x4 c32_acc_t[2][2];          // [16-pixel half q][cout half c2]: couts 8 g + 4 c2 + e of pixel 16 q + px
+
+// R output rows of a 32-pixel column from R + 2 input rows at `src` (LDS, PITCH bytes per row).  Output row r accumulates in iterations r .. r + 2;
+// fin(r, acc) stands in iteration r + 3 (the last one behind the loop), pre(r) -- its residual requests -- one iteration ahead of that.
+template <int R, int PITCH, typename PRE, typename FIN>
+__device__ __forceinline__ void c32_roll(const unsigned char* src, const int (&foff)[3][2], const h16x8 (&wf)[9][2], const f32x4 (&bias)[2], PRE&& pre, FIN&& fin) {
+    c32_acc_t acc[R];
+    h16x8 f[3][2];          // ONE set: the fragments of tap column kx are re-requested for the next input row right behind their last MFMA
+    auto rd = [&](int i, int kx) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#if RB_ABL & 2
+            f[kx][q] = wf[(i + kx) % 9][q];
+#else
+            f[kx][q] = *(const h16x8*)(src + i * PITCH + foff[kx][q]);
+#endif
+        }
+    };
+    rd(0, 0); rd(0, 1); rd(0, 2);
+#pragma unroll
+    for (int i = 0; i < R + 2; ++i) {
+        if (i >= 3) { pre(i - 3, 0); fin(i - 3, acc[i - 3], 0); }
+        if (i == R + 1) pre(R - 1, 1);          // the last row's requests one input row early: its epilogue stands behind the loop, with no MFMAs to cover a wait
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int ky = i - r;
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // the first MFMA of a row starts from the bias (couts 8 g + 4 c2 + e): no add in the epilogue
+#if RB_ABL & 1
+                        asm volatile("" ::"v"(wf[ky * 3 + kx][c2]), "v"(f[kx][q]));
+                        acc[r][q][c2] = (ky == 0 && kx == 0) ? bias[c2] : acc[r][q][c2];
+#else
+                        acc[r][q][c2] = mfma_16x16x32_h16(wf[ky * 3 + kx][c2], f[kx][q], (ky == 0 && kx == 0) ? bias[c2] : acc[r][q][c2], 0, 0, 0);
+#endif
+                    }
+            }
+            if (i + 1 < R + 2) rd(i + 1, kx);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // one input row per scheduling region
+    }
+    fin(R - 1, acc[R - 1], 1);
+}
+
+// act(acc) + res1 + res2 of a lane's eight couts -> 16 bytes (the bias is already in the accumulators)
+template <int NR, bool LK>
+__device__ __forceinline__ u32x4 c32_pack8(const f32x4& a0, const f32x4& a1, int act, const u32x4& r1, const u32x4& r2) {
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c32_act<LK>(v[e], act);
+    const uint32_t ra[4] = {r1.x, r1.y, r1.z, r1.w}, rb[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (NR >= 2) {
+            v[2 * e] += h2f_lo(ra[e]) + h2f_lo(rb[e]);
+            v[2 * e + 1] += h2f_hi(ra[e]) + h2f_hi(rb[e]);
+        } else if constexpr (NR == 1) {
+            v[2 * e] += h2f_lo(ra[e]);
+            v[2 * e + 1] += h2f_hi(ra[e]);
+        }
+    }
+    return u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+}
+
+template <bool RES2, bool LK>
+__global__ __launch_bounds__(512) void c32_resblock_r3_kernel(const RBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char r3_smem[];
+    unsigned char* hin0 = r3_smem;                             // two input halos 18 x 34 (39 KB each: 39 DMA instructions of 1 KB)
+    unsigned char* hmid0 = r3_smem + 2 * R3_IBYTES;            // two intermediate regions 16 x 32 (+ 2 pixels)
+    // the buffer-load-to-LDS builtin is not modelled as a store to LDS: let the buffers escape through an empty asm so that the "memory"-clobbering
+    // waits below count as writers of them
+    asm volatile("" ::"v"((__attribute__((address_space(3))) unsigned char*)r3_smem) : "memory");
+    constexpr uint32_t POISON = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 0: producer (conv1), 1: consumer (conv2).  The consumers are waves 0 .. 3: the two waves of a SIMD share its VALU issue by age, and the
+    // consumer -- epilogue with the residual adds, loads, stores -- is the stage's longer role (stamped: 9.8 k vs 6.5 k cycles with the roles the other way round)
+    const int role = 1 - (wave >> 2), w4 = wave & 3;
+    const int px = lane & 15, g = lane >> 4;                   // fragment / tile column, 8-channel group
+    h16x8 wf[9][2];
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        float* wst = (float*)hin0;                               // 32 x 289 floats = 37 KB <= an input halo buffer
+        const float* w = which ? a.w2 : a.w1;
+        for (int i = tid; i < 32 * 288; i += 512) {
+            const int co = i / 288, r = i - co * 288;
+            wst[co * 289 + r] = w[i];
+        }
+        __syncthreads();
+        if (role == which) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const int co = 8 * (px >> 2) + 4 * c2 + (px & 3);          // fragment row px of cout half c2
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = wst[co * 289 + (8 * g + e) * 9 + t];
+                    wf[t][c2] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
+                }
+        }
+        __syncthreads();
+    }
+    f32x4 bias[2];        // a lane's couts 8 g + 4 c2 + e: the initial value of its accumulators
+    {
+        const float* bp = role ? a.b2 : a.b1;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) bias[c2] = bp ? *(const f32x4*)(bp + 8 * g + 4 * c2) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // per-lane constants: fragment reads (column 16 q + px + kx of a row, channel chunk g) and the producers' 16-byte writes (column 16 q + px)
+    int foff[3][2], woff[2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = 16 * q + px + kx;
+            foff[kx][q] = col * 64 + ((g ^ ((col >> 1) & 3)) << 4);
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int col = 16 * q + px;
+        woff[q] = col * 64 + ((g ^ ((col >> 1) & 3)) << 4);
+    }
+
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int cb = 0, cty = 0, ctx = 0;
+    // the input halo of `tile` into buffer `buf` by LDS-DMA: 16-byte piece i = (pixel i >> 2, slot i & 3) holds channel chunk slot ^ ((column >> 1) & 3);
+    // a wave instruction lands 64 consecutive pieces (1 KB), PRODUCER wave w issues instructions w, w + 4, ...; pixels outside the image carry an out-of-range
+    // offset (the buffer unit writes zeros = the conv's zero padding).  No register holds the tile while it is in flight.
+    // halo position (row << 8 | column) of every 16-byte DMA piece, once per block, in LDS behind the buffers (5 KB): the division by the halo width
+    // is not repeated per stage and no register carries the pieces' constants through the row loops
+    constexpr int NISS = 4;          // the four PRODUCER waves issue the DMA (measured: all eight waves issuing and awaiting it 113 / 147 us per launch
+    const int jw = w4;               // without / with outer skip against 105 / 132 -- the consumers then wait for their stores at every stage top)
+    constexpr int NPCS = (R3_NDMA + NISS - 1) / NISS;
+    unsigned short* dpos = (unsigned short*)(r3_smem + R3_LDS_DATA);
+    for (int i = tid; i < R3_NDMA * 64; i += 512) {
+        const int hp = i >> 2;
+        const int hy = hp / R3_IW, hx = hp - hy * R3_IW;
+        dpos[i] = (unsigned short)(hp < R3_IPIX ? (hy << 8) | hx : 0x7f00);          // (a piece behind the halo: its row is never inside an image)
+    }
+    __syncthreads();
+    auto request = [&](int tile, int buf) {
+        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
+        ctx = tile - (int)q * a.tiles_x;
+        cb = (int)fdiv(q, a.fd_ty);
+        cty = (int)q - cb * a.tiles_y;
+        const int y0 = cty * R3_TH - 2, x0 = ctx * R3_TW - 2;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)cb * a.H * a.W * 32), 0, (int)POISON, 0x00020000);
+        unsigned char* dst = hin0 + buf * R3_IBYTES;
+        const int base = (y0 * a.W + x0) * 64;
+#pragma unroll
+        for (int u = 0; u < NPCS; ++u) {
+            const int j = jw + NISS * u;                         // wave-uniform
+            if (j < R3_NDMA) {
+                const int dp = dpos[j * 64 + lane], hy = dp >> 8, hx = dp & 255;
+                const bool ok = (unsigned)(y0 + hy) < (unsigned)a.H && (unsigned)(x0 + hx) < (unsigned)a.W;
+                const int rel = (hy * a.W + hx) * 64 + (((lane & 3) ^ ((hx >> 1) & 3)) << 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16,
+                                                         ok ? base + rel : (int)POISON, 0, 0, 0);
+            }
+        }
+    };
+    // (every wave decodes the tile; only the producers move data: they have no other vector-memory traffic, so their `s_waitcnt vmcnt(0)` in front of
+    // the stage barrier waits for the halo alone -- the consumers' stores drain under the next stage instead of in front of its barrier)
+    auto decode = [&](int tile) {
+        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
+        ctx = tile - (int)q * a.tiles_x;
+        cb = (int)fdiv(q, a.fd_ty);
+        cty = (int)q - cb * a.tiles_y;
+    };
+    if (role == 0) request((int)blockIdx.x, 0); else decode((int)blockIdx.x);
+    int pb = 0, pty = 0, ptx = 0;          // tile of the previous stage (the consumer's)
+#pragma unroll 1
+    for (int s = 0; s <= n_my; ++s) {
+        const int b = cb, ty = cty, tx = ctx;                     // tile s, whose halo lands in buffer s & 1
+        const unsigned char* hin = hin0 + (s & 1) * R3_IBYTES;
+        R3_ST(0);
+        if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of it
+        R3_ST(1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        R3_ST(2);
+        if (s + 1 < n_my) {                                       // the other buffer: its readers finished a stage ago
+            if (role == 0) request((int)blockIdx.x + (s + 1) * (int)gridDim.x, (s + 1) & 1);
+            else decode((int)blockIdx.x + (s + 1) * (int)gridDim.x);
+        }
+        R3_ST(3);
+        if (role == 0) {
+            if (s < n_my && !(RB_ABL & 8)) {
+                // intermediate rows 4 w4 .. 4 w4 + 3 (image rows ty * 14 - 1 + ...), columns = image tx * 30 - 1 + col; ZERO outside the image:
+                // conv2 pads the intermediate map, not conv1's extrapolation
+                unsigned char* hmid = hmid0 + (s & 1) * R3_MBYTES + (4 * w4) * (R3_MW * 64);
+                const int ix0 = tx * R3_TW - 1 + px, iy0 = ty * R3_TH - 1 + 4 * w4;
+                c32_roll<4, R3_IW * 64>(hin + (4 * w4) * (R3_IW * 64), foff, wf, bias, [](int, int) {}, [&](int r, const c32_acc_t& acc, int) {
+                    const bool yin = (unsigned)(iy0 + r) < (unsigned)a.H;
+                    const u32x4 none = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        u32x4 o = c32_pack8<0, LK>(acc[q][0], acc[q][1], a.act, none, none);
+                        if (!(yin && (unsigned)(ix0 + 16 * q) < (unsigned)a.W)) o = none;
+                        *(u32x4*)(hmid + r * (R3_MW * 64) + woff[q]) = o;
+                    }
+                });
+            }
+        } else if (s >= 1 && !(RB_ABL & 16)) {
+            // output rows: waves 0, 1 take four (0 - 3, 4 - 7), waves 2, 3 three (8 - 10, 11 - 13)
+            const int r0 = w4 < 2 ? 4 * w4 : 8 + 3 * (w4 - 2);
+            const unsigned char* hmid = hmid0 + ((s - 1) & 1) * R3_MBYTES + r0 * (R3_MW * 64);
+            const int x0 = ptx * R3_TW + px, y0 = pty * R3_TH + r0;
+            const bool xok[2] = {x0 < a.W, px + 16 < R3_TW && x0 + 16 < a.W};
+            // identity, outer skip and output through buffer descriptors of the image: a dead lane (outside the tile / the image) carries an
+            // out-of-range offset -- loads return zeros, stores are dropped -- so the whole row loop stays ONE basic block per input row (exec-masked
+            // loads / stores put a branch around each and the scheduler could not move the epilogue's VALU work under the MFMAs)
+            const int64_t img = (int64_t)pb * a.H * a.W * 32;
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + img), 0, (int)POISON, 0x00020000);
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)((const h16_t*)(RES2 ? a.res2 : (const void*)a.x) + img), 0, (int)POISON, 0x00020000);
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((h16_t*)a.y + img), 0, (int)POISON, 0x00020000);
+            const int ob = ((y0 * a.W + x0) * 32 + 8 * g) * 2;               // byte offset of (row 0, half 0) inside the image
+            u32x4 r1v[2][2], r2v[2][2];          // [set][16-pixel half]: set 1 = the last row's (requested early)
+            auto pre = [&](int r, int set) {            // identity and outer skip of output row r: requested at the top of the input row whose MFMAs cover the wait
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool lv = xok[q] && y0 + r < a.H;
+                    const int o = lv ? ob + (r * a.W + 16 * q) * 64 : (int)POISON;
+#if RB_ABL & 4
+                    r1v[set][q] = r2v[set][q] = u32x4{(uint32_t)o, 0u, 0u, 0u};
+#else
+                    r1v[set][q] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);          // the identity (L2: the producers read it a stage ago)
+                    if constexpr (RES2) r2v[set][q] = __builtin_amdgcn_raw_buffer_load_b128(sr, o, 0, 0);
+                    else r2v[set][q] = u32x4{0u, 0u, 0u, 0u};
+#endif
+                }
+            };
+            auto fin = [&](int r, const c32_acc_t& acc, int set) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool lv = xok[q] && y0 + r < a.H;
+                    const u32x4 o = c32_pack8<RES2 ? 2 : 1, LK>(acc[q][0], acc[q][1], a.act, r1v[set][q], r2v[set][q]);
+#if RB_ABL & 4
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yr, (lv && o.x == 0x12345678u) ? ob + (r * a.W + 16 * q) * 64 : (int)POISON, 0, 0);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yr, lv ? ob + (r * a.W + 16 * q) * 64 : (int)POISON, 0, 0);
+#endif
+                }
+            };
+            if (w4 < 2) c32_roll<4, R3_MW * 64>(hmid, foff, wf, bias, pre, fin);
+            else c32_roll<3, R3_MW * 64>(hmid, foff, wf, bias, pre, fin);
+        }
+        // end of stage: the producers' LDS writes are out (lgkmcnt), nobody waits for global stores here (__syncthreads would: vmcnt(0))
+        R3_ST(4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        R3_ST(5);
         pb = b; pty = ty; ptx = tx;
     }
 }
@@ -495,6 +773,9 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
     HESIC_LAUNCH_RETURN("conv3x3_c32_forward");
 }
 
+#ifdef R3_STAMP
+extern "C" int hesic_en_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_r3_stamp), &p, sizeof(p)); }
+#endif
 extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, int act,
                                           const void* res2, void* y, int B, int H, int W, void* stream) {
     HESIC_CHECK_ARG(x && w1 && w2 && y && B > 0 && H > 0 && W > 0, "resblock_c32_forward: bad arguments");
@@ -503,19 +784,43 @@ extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const 
     RBArgs a;
     a.x = (const h16_t*)x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.res2 = res2; a.y = y;
     a.B = B; a.H = H; a.W = W; a.act = act;
+#ifdef RB_OLD_FORM          /* the 16 x 32-tile, 32-pixel-group form of rounds 3 - 5 (ablation builds: profiles/scripts/en_ablation.sh) */
     a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+#else
+    a.tiles_x = (W + R3_TW - 1) / R3_TW; a.tiles_y = (H + R3_TH - 1) / R3_TH;
+#endif
     a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * B;
     HESIC_CHECK_ARG(ntiles < (1ll << 31), "resblock_c32_forward: too many tiles");
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);          // persistent: one block per CU, both weight sets packed once per block
+#ifdef RB_OLD_FORM
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
         (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
         attr = true;
     }
-    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);          // persistent: one block per CU, both weight sets packed once per block
     if (res2) hipLaunchKernelGGL(c32_resblock_kernel<true>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(c32_resblock_kernel<false>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
+#else
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)c32_resblock_r3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+        (void)hipFuncSetAttribute((const void*)c32_resblock_r3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+        (void)hipFuncSetAttribute((const void*)c32_resblock_r3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+        (void)hipFuncSetAttribute((const void*)c32_resblock_r3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+        attr = true;
+    }
+    const dim3 g(grid), bk(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (act == HESIC_ACT_LEAKY) {          // the ResidualBlock's activation (layers.py:131): known at compile time
+        if (res2) hipLaunchKernelGGL((c32_resblock_r3_kernel<true, true>), g, bk, R3_LDS, st, a);
+        else hipLaunchKernelGGL((c32_resblock_r3_kernel<false, true>), g, bk, R3_LDS, st, a);
+    } else {
+        if (res2) hipLaunchKernelGGL((c32_resblock_r3_kernel<true, false>), g, bk, R3_LDS, st, a);
+        else hipLaunchKernelGGL((c32_resblock_r3_kernel<false, false>), g, bk, R3_LDS, st, a);
+    }
+#endif
     HESIC_LAUNCH_RETURN("resblock_c32_forward");
 }
 

@@ -830,11 +830,14 @@ def test_conv3x3_c32_enhancement_kernel(hw):
 
 @pytest.mark.parametrize("hw", [(64, 64), (37, 45), (16, 32), (5, 3), (50, 130), (96, 160)])
 @pytest.mark.parametrize("skip", [False, True])
-def test_resblock_c32_is_the_two_launch_path_bit_for_bit(hw, skip):
-    """hesic_resblock_c32_forward (a whole ResidualBlock of the enhancement stage per launch, layers.py:125-147): bit-identical to two
-    hesic_conv3x3_c32_forward launches (same rounding points: bf16 intermediate, fp32 accumulation in the same tap order) on sizes that
-    end in partial tiles and on single-tile images (every intermediate pixel of the ring outside the image must be ZERO, not conv1
-    evaluated there), and close to the oracle composition."""
+def test_resblock_c32_agrees_with_the_two_launch_path(hw, skip):
+    """hesic_resblock_c32_forward (a whole ResidualBlock of the enhancement stage per launch, layers.py:125-147) against two
+    hesic_conv3x3_c32_forward launches: same rounding points (16-bit intermediate, fp32 accumulation), on sizes that end in partial tiles and on
+    single-tile images (every intermediate pixel of the ring outside the image must be ZERO, not conv1 evaluated there), and close to the oracle
+    composition.  Rounds 3 - 5: bit-identical.  Round 6: the one-launch kernel sums a tap's 32 channels in ONE 16 x 16 x 32 MFMA, the single-conv kernel
+    in two K = 16 halves on two chains -- another fp32 summation order, so a few of the 16-bit results land on the neighbouring value (and an
+    intermediate value that rounds the other way moves the outputs around it).  Bars: every value within ONE bf16 ulp of the tensor's largest value
+    (2^-8 of it; measured <= 3.4e-3), fewer than 2e-3 of the values different at all (measured <= 7.3e-4)."""
     Fn, O = _imp()
     H, W = hw
     x = bf(rnd(f"rb_x{hw}", (2, 32, H, W), -2, 2))
@@ -855,7 +858,13 @@ def test_resblock_c32_is_the_two_launch_path_bit_for_bit(hw, skip):
     finally:
         Fn.set_compute_dtype(torch.float32)
     assert one.dtype == torch.bfloat16 and one.shape == two.shape
-    assert torch.equal(one, two) and torch.equal(nob, two_nob)
+    for got, want in ((one, two), (nob, two_nob)):
+        d = (got.float() - want.float()).abs()
+        scale = float(want.float().abs().max())
+        meas = {"max_abs_over_scale": float(d.max()) / scale, "share_different": float((d > 0).float().mean()),
+                "share_beyond_one_ulp_of_scale": float((d > scale * 2.0 ** -8).float().mean())}
+        print("measured:", {k: float("%.3g" % v) for k, v in meas.items()})
+        assert meas["max_abs_over_scale"] <= 2.0 ** -8 and meas["share_different"] < 2e-3, meas          # measured: <= 3.4e-3, <= 7.3e-4
     ref = leaky(O.conv(bf(leaky(O.conv(x, bf(w1), b1, 1), 0.01)), bf(w2), b2, 1), 0.01) + x + (0 if r2 is None else r2)
     assert rel_err(one, ref) < 1e-2
 
