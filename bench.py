@@ -567,7 +567,7 @@ def secondary_hesic_en(dev, size=512):
         if rb:
             fl = 2.0 * px * 2 * 32 * 32 * 9          # two 32 -> 32 3x3 convs per launch
             t = sum(rb) / len(rb)
-            out["roofline"] = {"kernel": "c32_resblock_kernel", "bound": "mfma", "achieved": round(fl / t / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+            out["roofline"] = {"kernel": "c32_resblock_r3_kernel", "bound": "mfma", "achieved": round(fl / t / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": len(rb) // 3,
                                "avg_launch_us": round(1e6 * t, 2), "gflop_per_launch": round(fl / 1e9, 2),
                                "hbm_bytes_algorithmic": 2 * px * 64 + (px * 64), "traffic": None}

@@ -206,226 +206,26 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------- a whole ResidualBlock per launch
-// leaky(conv2(leaky(conv1(x)))) + x (+ the Enhancement_Block's outer skip), compressai/layers/layers.py:125-147: the two launches of the
-// kernel above move 64 B in + 64 B out per pixel TWICE; here the intermediate map never leaves the CU.  One block of EIGHT waves per CU,
-// two roles, software-pipelined over the block's tiles:
-//   producer waves 0..3 (conv1 weights in registers): stage s evaluates conv1 on the (16+2) x (32+2) intermediate pixels of tile s from
-//     the (16+4) x (32+4)-pixel input halo in LDS -- 20 groups of 32 consecutive pixels of that region, 5 per wave; +20 % MFMAs for the
-//     ring that neighbouring tiles also compute -- and writes them (bias, LeakyReLU, bf16, ZERO outside the image: conv2 pads the
-//     intermediate map, not conv1's extrapolation) into intermediate halo s & 1, in the layout conv2's fragment reads expect;
-//   consumer waves 4..7 (conv2 weights): stage s runs conv2 of tile s - 1 from the other intermediate halo exactly like the single-layer
-//     kernel (output staging, identity and outer skip in the row-major view, 1 KB stores).
-// Every SIMD hosts one producer and one consumer wave, i.e. two different phases at any time (a first form with four waves doing both
-// convs in turn, one wave per SIMD, ran 270 us per block against 2 x 90 for the two launches; this one 178 us -- the same kernel time,
-// but half the launches: an eager Independent_EN forward at B=8 512x512 3.56 ms against 4.02).  Two block barriers per stage; 139.5 KB of
-// LDS.  Rounding points are those of the two-launch path (bf16 intermediate, fp32 accumulation in the same tap order): bit-identical.
+// leaky(conv2(leaky(conv1(x)))) + x (+ the Enhancement_Block's outer skip), compressai/layers/layers.py:125-147: two launches of the kernel above move
+// 64 B in + 64 B out per pixel TWICE; here the intermediate map never leaves the CU.  One block of EIGHT waves per CU, two roles, software-pipelined over
+// the block's tiles: producer waves run conv1 of tile s into an intermediate region in LDS (bias, LeakyReLU, 16-bit, ZERO outside the image: conv2 pads
+// the intermediate map, not conv1's extrapolation), consumer waves conv2 of tile s - 1 from the other region + identity + outer skip.
+// (Rounds 3 - 5 ran this on 16 x 32 tiles in 32-pixel groups with the 32 x 32 x 16 MFMA and an fp32 turn-round of the output through LDS: 129 / 144 us
+// per launch without / with outer skip at B=8 512^2.  Ablations of that kernel -- profiles/r06_en_ablation.txt: full 157 us on random data, no MFMAs 107,
+// no fragment reads 115, neither 92, no identity loads / stores 121, skeleton 40, no producer 95, no consumer 111: phases and roles ADD -- and its counters
+// (r06_a_pmc_sq_en.json: MFMA pipe 30 % busy, 14 VALU per MFMA, 27 % of LDS cycles conflicts) led to the form below; the old kernel is kept as
+// profiles/experiments/r05_c32_resblock_tile16x32.patch.)
 struct RBArgs {
     const h16_t* x; const float* w1; const float* b1; const float* w2; const float* b2; const void* res2; void* y;
     int B, H, W, act, tiles_x, tiles_y;
     FastDiv fd_tx, fd_ty;
 };
 
-constexpr int RB_IW = TW + 4, RB_IH = TH + 4, RB_IPIX = RB_IW * RB_IH;      // input halo: 20 x 36 pixels
-constexpr int RB_NPC = (RB_IPIX * 4 + 511) / 512;                            // 16-byte pieces per thread: 6
-constexpr int RB_MCH = (HPIX + 31) / 32;                                     // 32-pixel groups of the 18 x 34 intermediate region: 20
-constexpr int RB_LDS = RB_IPIX * 64 + 2 * HPIX * 64;
-
 // Ablation builds (profiles/scripts/en_ablation.sh; never in the shipped libraries): -DRB_ABL=<bits>  1: no MFMAs (fragment reads stay), 2: no fragment
 // reads, 4: the consumers' identity / outer-skip loads and the output stores dropped, 8: no producer work at all, 16: no consumer work at all.
-// Measured (round 6, B=8 512^2, random data, profiles/r06_en_ablation.txt): full 157 us; no MFMAs 107; no fragment reads 115; neither 92; no identity
-// loads / stores 121; all three gone ("skeleton": halo staging, both epilogues' LDS + VALU, barriers) 40; no producer work 95; no consumer work 111.
-// I.e. the parts ADD (40 + 50 + 42 + 36 = 168 ~ 157) and so do the roles (111 + 46): the LDS carries, per 16 x 32 tile, 663 KB of fragment reads
-// (2600 cycles at 256 B/clk), ~150 KB of slow writes (halo staging, intermediate halo, the consumers' fp32 turn-round: ~1900 cycles at ~80 B/clk)
-// and 64 KB of turn-round reads -- as busy as the matrix pipe (5184 cycles per SIMD and tile), so neither role finds a free unit while the other runs.
-// Tried and dropped (round 6): rotating both loops so that the MFMAs of group g + 1 stand in one basic block with the epilogue of group g -- the
-// second accumulator set, the staged sums, the fragment double buffer and the residuals need 26 (producer only) to 66 registers more than the 256 of a
-// two-waves-per-SIMD block and spill to scratch.
 #ifndef RB_ABL
 #define RB_ABL 0
 #endif
-__device__ __forceinline__ f32x16 rb_no_mfma(const h16x8& a_, const h16x8& b_, const f32x16& c_) {
-    asm volatile("" ::"v"(a_), "v"(b_));          // the operands stay live (their loads are not optimised away), nothing is multiplied
-    return c_;
-}
-#if RB_ABL & 1
-#define RB_MFMA(A_, B_, C_) rb_no_mfma(A_, B_, C_)
-#else
-#define RB_MFMA(A_, B_, C_) mfma_32x32x16_h16(A_, B_, C_, 0, 0, 0)
-#endif
-template <bool RES2>
-__global__ __launch_bounds__(512) void c32_resblock_kernel(const RBArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
-    unsigned char* hin = rb_smem;                              // input halo, 64-byte pixels, chunk slot ^ ((pixel >> 2) & 3)
-    unsigned char* hmid0 = rb_smem + RB_IPIX * 64;             // two intermediate halos, same layout
-    constexpr uint32_t POISON = 0x80000000u;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wave >> 2, w4 = wave & 3;                 // 0: producer (conv1), 1: consumer (conv2)
-    const int p = lane & 31, h = lane >> 5;
-    h16x8 wf[9][2];
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        float* wst = (float*)hin;                                // 32 x 289 floats = 37 KB <= the input halo buffer
-        const float* w = which ? a.w2 : a.w1;
-        for (int i = tid; i < 32 * 288; i += 512) {
-            const int co = i / 288, r = i - co * 288;
-            wst[co * 289 + r] = w[i];
-        }
-        __syncthreads();
-        if (role == which) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = wst[c32_cout_of_row(p) * 289 + (k * 16 + h * 8 + e) * 9 + t];
-                    wf[t][k] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
-                }
-        }
-        __syncthreads();
-    }
-    float bv[16];          // accumulator r of this lane = cout 16 h + r (permuted weight rows, see the header)
-    {
-        const float* bp = role ? a.b2 : a.b1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = bp ? bp[16 * h + r] : 0.f;
-    }
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    u32x4 pc[RB_NPC];
-    int cb = 0, cty = 0, ctx = 0;
-    auto request = [&](int tile) {
-        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
-        ctx = tile - (int)q * a.tiles_x;
-        cb = (int)fdiv(q, a.fd_ty);
-        cty = (int)q - cb * a.tiles_y;
-        const int y0 = cty * TH - 2, x0 = ctx * TW - 2;
-        const u32x4 xr = c32_rsrc(a.x + (int64_t)cb * a.H * a.W * 32);
-#pragma unroll
-        for (int u = 0; u < RB_NPC; ++u) {
-            const int i = tid + 512 * u;
-            const int hp = i >> 2, slot = i & 3;
-            const int hy = hp / RB_IW, hx = hp - hy * RB_IW;
-            const int iy = y0 + hy, ix = x0 + hx;
-            const bool ok = hp < RB_IPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int chunk = slot ^ ((hp >> 2) & 3);
-            c32_load_piece(pc[u], ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, xr);
-        }
-    };
-    request((int)blockIdx.x);
-    int pb = 0, pty = 0, ptx = 0;          // tile of the previous stage (the consumer's)
-#pragma unroll 1
-    for (int s = 0; s <= n_my; ++s) {
-        const int b = cb, ty = cty, tx = ctx;                     // tile s, whose halo is in `pc`
-        c32_wait_pieces(pc);
-        if (s < n_my) {
-#pragma unroll
-            for (int u = 0; u < RB_NPC; ++u) {
-                const int i = tid + 512 * u;
-                if (i < RB_IPIX * 4) *(u32x4*)(hin + i * 16) = pc[u];
-            }
-        }
-        __syncthreads();
-        {   // unconditional (the old pieces are dead here); past the last tile the request repeats the last one
-            const int nt = (int)blockIdx.x + (s + 1 < n_my ? s + 1 : (n_my > 0 ? n_my - 1 : 0)) * (int)gridDim.x;
-            request(nt);
-        }
-        if (role == 0) {
-            if (s < n_my && !(RB_ABL & 8)) {
-                unsigned char* hmid = hmid0 + (s & 1) * (HPIX * 64);
-#pragma unroll 1
-                for (int cc = 0; cc < RB_MCH / 4; ++cc) {
-                    const int m_raw = (w4 + 4 * cc) * 32 + p;
-                    const int m = m_raw < HPIX ? m_raw : HPIX - 1;
-                    const int mr = m / HW_, mc = m - mr * HW_;
-                    f32x16 acc, acc1;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int hp = (mr + t / 3) * RB_IW + mc + t % 3;
-                        const unsigned char* row = hin + hp * 64;
-                        const int sw = (hp >> 2) & 3;
-#if RB_ABL & 2
-                        const h16x8 xf0 = wf[(t + 1) % 9][0], xf1 = wf[(t + 2) % 9][1];
-                        (void)row; (void)sw;
-#else
-                        const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
-#endif
-                        acc = RB_MFMA(wf[t][0], xf0, acc);
-                        acc1 = RB_MFMA(wf[t][1], xf1, acc1);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
-                    const int iy = ty * TH - 1 + mr, ix = tx * TW - 1 + mc;
-                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                    if (m_raw < HPIX) {
-                        unsigned char* dst = hmid + m * 64;
-                        const int sw = (m >> 2) & 3;
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) {                 // channel chunks 2 h and 2 h + 1 of the pixel
-                            float v[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = inside ? apply_act(acc[8 * it + e] + bv[8 * it + e], a.act) : 0.f;
-                            *(u32x4*)(dst + (((2 * h + it) ^ sw) << 4)) = u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
-                        }
-                    }
-                }
-            }
-        } else if (s >= 1 && !(RB_ABL & 16)) {
-            const unsigned char* hmid = hmid0 + ((s - 1) & 1) * (HPIX * 64);
-#pragma unroll 1
-            for (int rq = 0; rq < TH / 4; ++rq) {
-                const int yl = w4 + 4 * rq;
-                const int y = pty * TH + yl;
-                // identity and outer skip of this lane's 32 output bytes (couts 16 h .. 16 h + 15 of pixel p), requested in front of the MFMAs.
-                // Measured alternatives, all SLOWER here (one block per CU: 256 registers per wave, and what they added spilled or cost its own
-                // round trip): the identity of all four row groups requested a stage ahead (202 us per launch against 178), bias re-read per
-                // stage from LDS, the outer skip one row group ahead (237 against 178 for the launches that carry one).
-                const int xx = ptx * TW + p;
-                const bool lv = y < a.H && xx < a.W;
-                const int64_t o = (((int64_t)pb * a.H + y) * a.W + xx) * 32 + 16 * h;
-                u32x4 r1v[2], r2v[2];
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-#if RB_ABL & 4
-                    r1v[it] = r2v[it] = u32x4{(uint32_t)o, 0u, 0u, 0u};
-#else
-                    r1v[it] = lv ? *(const u32x4*)(a.x + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};          // the identity (L2: the producers read it a stage ago)
-                    r2v[it] = (RES2 && lv) ? *(const u32x4*)((const h16_t*)a.res2 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
-#endif
-                }
-                f32x16 acc, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int hp = (yl + t / 3) * HW_ + p + t % 3;
-                    const unsigned char* row = hmid + hp * 64;
-                    const int sw = (hp >> 2) & 3;
-#if RB_ABL & 2
-                    const h16x8 xf0 = wf[(t + 1) % 9][0], xf1 = wf[(t + 2) % 9][1];
-                    (void)row; (void)sw;
-#else
-                    const h16x8 xf0 = *(const h16x8*)(row + ((h ^ sw) << 4)), xf1 = *(const h16x8*)(row + (((2 + h) ^ sw) << 4));
-#endif
-                    acc = RB_MFMA(wf[t][0], xf0, acc);
-                    acc1 = RB_MFMA(wf[t][1], xf1, acc1);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
-#if RB_ABL & 4
-                if (lv && acc[0] == 1.2345e-30f)
-#else
-                if (lv)
-#endif
-                    c32_store_row<RES2 ? 2 : 1, false>((h16_t*)a.y + o, acc, bv, a.act, r1v, r2v);
-            }
-        }
-        __syncthreads();
-        pb = b; pty = ty; ptx = tx;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- ResidualBlock, row-rolling form (round 6)
 // What bounded the kernel above (profiles/r06_en_ablation.txt, r06_a_pmc_sq_en.json): every 32-pixel group re-reads its nine shifted fragments from
@@ -784,25 +584,11 @@ extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const 
     RBArgs a;
     a.x = (const h16_t*)x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.res2 = res2; a.y = y;
     a.B = B; a.H = H; a.W = W; a.act = act;
-#ifdef RB_OLD_FORM          /* the 16 x 32-tile, 32-pixel-group form of rounds 3 - 5 (ablation builds: profiles/scripts/en_ablation.sh) */
-    a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
-#else
     a.tiles_x = (W + R3_TW - 1) / R3_TW; a.tiles_y = (H + R3_TH - 1) / R3_TH;
-#endif
     a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
     const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * B;
     HESIC_CHECK_ARG(ntiles < (1ll << 31), "resblock_c32_forward: too many tiles");
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);          // persistent: one block per CU, both weight sets packed once per block
-#ifdef RB_OLD_FORM
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
-        (void)hipFuncSetAttribute((const void*)c32_resblock_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
-        attr = true;
-    }
-    if (res2) hipLaunchKernelGGL(c32_resblock_kernel<true>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(c32_resblock_kernel<false>, dim3(grid), dim3(512), RB_LDS, (hipStream_t)stream, a);
-#else
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)c32_resblock_r3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
@@ -820,7 +606,6 @@ extern "C" int hesic_resblock_c32_forward(const void* x, const float* w1, const 
         if (res2) hipLaunchKernelGGL((c32_resblock_r3_kernel<true, false>), g, bk, R3_LDS, st, a);
         else hipLaunchKernelGGL((c32_resblock_r3_kernel<false, false>), g, bk, R3_LDS, st, a);
     }
-#endif
     HESIC_LAUNCH_RETURN("resblock_c32_forward");
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the time of the one-launch ResidualBlock (csrc/enh.hip: c32_resblock_kernel) goes: compile-time ablations (-DRB_ABL=<bits>) of the kernel,
+# Where the time of the one-launch ResidualBlock (csrc/enh.hip: c32_resblock_r3_kernel; rounds 3 - 5: c32_resblock_kernel, profiles/experiments/) goes: compile-time ablations (-DRB_ABL=<bits>) of the kernel,
 # each built into its own small library next to a stub of the error plumbing, timed back to back at B=8 512^2.  Never in the shipped libraries.
 # Build (in the build container, hipcc cross-compiles; the .so files travel with the snapshot):
 #   for abl in 0 1 2 3 4 8 16 7; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHESIC_H16_IS_F16=1 -DRB_ABL=$abl -Ihesic_amd/csrc -c hesic_amd/csrc/enh.hip -o /tmp/e.o
