@@ -305,7 +305,8 @@ __device__ __forceinline__ void c32_roll(const unsigned char* src, const int (&f
             }
             if (i + 1 < R + 2) rd(i + 1, kx);
         }
-        __builtin_amdgcn_sched_barrier(0);       // one input row per scheduling region
+        __builtin_amdgcn_iglp_opt(0);            // (measured: 103.6 / 131.6 us per launch without / with outer skip against 108.5 / 135.1 without the hint)
+        __builtin_amdgcn_sched_barrier(0);       // one input row per scheduling region (without it: 109.6 / 161.8 us)
     }
     fin(R - 1, acc[R - 1], 1);
 }
@@ -397,7 +398,8 @@ __global__ __launch_bounds__(512) void c32_resblock_r3_kernel(const RBArgs a) {
     // offset (the buffer unit writes zeros = the conv's zero padding).  No register holds the tile while it is in flight.
     // halo position (row << 8 | column) of every 16-byte DMA piece, once per block, in LDS behind the buffers (5 KB): the division by the halo width
     // is not repeated per stage and no register carries the pieces' constants through the row loops
-    constexpr int NISS = 4;          // the four PRODUCER waves issue the DMA (measured: all eight waves issuing and awaiting it 113 / 147 us per launch
+    constexpr int NISS = 4;          // the four PRODUCER waves issue the DMA in one burst at the stage top (measured: the pieces spread two per input row
+                                     // over the producers' row loop 121 / 136 us against 114 / 137 on the same box; all eight waves issuing and awaiting it 113 / 147 us per launch
     const int jw = w4;               // without / with outer skip against 105 / 132 -- the consumers then wait for their stores at every stage top)
     constexpr int NPCS = (R3_NDMA + NISS - 1) / NISS;
     unsigned short* dpos = (unsigned short*)(r3_smem + R3_LDS_DATA);
