@@ -167,6 +167,7 @@ _SIGS = {
     "hesic_mix_weights_forward": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_conv3x3_c32_forward": ([_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_pack_images_c32": ([_vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "hesic_conv3x3_c32_forward_img6": ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_resblock_c32_forward": ([_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "hesic_adam_step": ([_vp, _vp], _i32),
     "hesic_pooled_linear_forward": ([_vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),

@@ -205,6 +205,104 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- the 6 -> 32 input conv, straight from the two images
+// Enhancement.conv1 on torch.cat((x, x_another_warp), 1) (newnet1.py:300-301).  Rounds 3 - 5: pack_images_c32 wrote the two planar fp32 images as
+// channels 0..5 of a zero-padded 32-channel map (50 us, 134 MB out) and c32_conv3x3_kernel read it back with a zero-padded weight (72 us, 134 MB in,
+// 18 MFMAs per 32 pixels of which 9 multiplied zeros).  Here the halo is built from the six image planes directly (fp32 -> 16-bit, 32 bytes per pixel:
+// chunk 0 = the six channels + two zeros, chunk 1 = zeros; chunk c in slot c ^ ((pixel >> 3) & 1)), nine K = 16 MFMAs per group: 50 MB in, 134 MB out.
+// Same products and the same order of the non-zero ones: bit-identical to the two-launch route.
+struct C6Args {
+    const float* xa; const float* xb; const float* w; const float* bias; void* y;
+    int B, H, W, act, tiles_x, tiles_y;
+    FastDiv fd_tx, fd_ty;
+};
+
+__global__ __launch_bounds__(256, 2) void c32_conv6_kernel(const C6Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char halo[HPIX * 32];
+    __shared__ float wst[32 * 55];
+    constexpr uint32_t POISON = 0x80000000u;
+    constexpr int NPX = (HPIX + 255) / 256;              // halo pixels per thread: 3
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    h16x8 wf[9];
+    {
+        for (int i = tid; i < 32 * 54; i += 256) wst[(i / 54) * 55 + i % 54] = a.w[i];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (h == 0 && e < 6) ? wst[c32_cout_of_row(p) * 55 + e * 9 + t] : 0.f;
+            wf[t] = __builtin_bit_cast(h16x8, u32x4{pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])});
+        }
+    }
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[16 * h + r] : 0.f;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int64_t plane = (int64_t)a.H * a.W;
+    float pv[NPX][6];
+    int cb = 0, cty = 0, ctx = 0;
+    auto request = [&](int tile) {
+        const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
+        ctx = tile - (int)q * a.tiles_x;
+        cb = (int)fdiv(q, a.fd_ty);
+        cty = (int)q - cb * a.tiles_y;
+        const int y0 = cty * TH - 1, x0 = ctx * TW - 1;
+        const u32x4 ra = c32_rsrc(a.xa + (int64_t)cb * 3 * plane), rb = c32_rsrc(a.xb + (int64_t)cb * 3 * plane);
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const int hp = tid + 256 * u;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = y0 + hy, ix = x0 + hx;
+            const bool ok = hp < HPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int o = (iy * a.W + ix) * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(pv[u][c]) : "v"(ok ? o + (int)(c * plane * 4) : (int)POISON), "s"(ra) : "memory");
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(pv[u][3 + c]) : "v"(ok ? o + (int)(c * plane * 4) : (int)POISON), "s"(rb) : "memory");
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    request(tile < ntiles ? tile : 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = cb, ty = cty, tx = ctx;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(pv[u][c]));
+            const int hp = tid + 256 * u;
+            if (hp < HPIX) {
+                const int sw = (hp >> 3) & 1;
+                *(u32x4*)(halo + hp * 32 + (sw << 4)) = u32x4{pack_h2(pv[u][0], pv[u][1]), pack_h2(pv[u][2], pv[u][3]), pack_h2(pv[u][4], pv[u][5]), 0u};
+                *(u32x4*)(halo + hp * 32 + ((1 ^ sw) << 4)) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        __syncthreads();
+        request(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile);
+#pragma unroll 1
+        for (int rq = 0; rq < TH / 4; ++rq) {
+            const int yl = wave + 4 * rq;
+            const int y = ty * TH + yl, x = tx * TW + p;
+            const bool live = y < a.H && x < a.W;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hp = (yl + t / 3) * HW_ + p + t % 3;
+                const h16x8 xf = *(const h16x8*)(halo + hp * 32 + ((h ^ ((hp >> 3) & 1)) << 4));
+                acc = mfma_32x32x16_h16(wf[t], xf, acc, 0, 0, 0);
+            }
+            const u32x4 none[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (live) c32_store_row<0, false>((h16_t*)a.y + (((int64_t)b * a.H + y) * a.W + x) * 32 + 16 * h, acc, bv, a.act, none, none);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- a whole ResidualBlock per launch
 // leaky(conv2(leaky(conv1(x)))) + x (+ the Enhancement_Block's outer skip), compressai/layers/layers.py:125-147: two launches of the kernel above move
 // 64 B in + 64 B out per pixel TWICE; here the intermediate map never leaves the CU.  One block of EIGHT waves per CU, two roles, software-pipelined over
@@ -550,6 +648,20 @@ extern "C" int hesic_pack_images_c32(const float* xa, const float* xb, void* out
     const int64_t total = (int64_t)B * H * W;
     hipLaunchKernelGGL(pack_images_c32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, xa, xb, (h16_t*)out, B, (int64_t)H * W);
     HESIC_LAUNCH_RETURN("pack_images_c32");
+}
+
+extern "C" int hesic_conv3x3_c32_forward_img6(const float* xa, const float* xb, const float* w, const float* bias, int act, void* y, int B, int H, int W,
+                                              void* stream) {
+    HESIC_CHECK_ARG(xa && xb && w && y && B > 0 && H > 0 && W > 0, "conv3x3_c32_forward_img6: bad arguments");
+    HESIC_CHECK_ARG((int64_t)H * W * 64 < (1ll << 31) && (int64_t)3 * H * W * 4 < (1ll << 31), "conv3x3_c32_forward_img6: image too large for 32-bit offsets");
+    C6Args a;
+    a.xa = xa; a.xb = xb; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.act = act;
+    a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+    a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_ty = make_fastdiv((uint32_t)a.tiles_y);
+    const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * B;
+    HESIC_CHECK_ARG(ntiles < (1ll << 31), "conv3x3_c32_forward_img6: too many tiles");
+    hipLaunchKernelGGL(c32_conv6_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, (hipStream_t)stream, a);
+    HESIC_LAUNCH_RETURN("conv3x3_c32_forward_img6");
 }
 
 extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, int Cout, int act, const void* res1,

@@ -1333,6 +1333,18 @@ def pack_images_c32(xa, xb):
     return out
 
 
+def conv3x3_c32_img6(xa, xb, weight, bias, act=L.ACT_NONE):
+    """act(conv3x3(cat((xa, xb), 1)) + bias) of the enhancement net's input layer (newnet1.py:300-301) in ONE launch (round 6,
+    ``hesic_conv3x3_c32_forward_img6``): the two fp32 planar (B,3,H,W) images are read as they are, (B,32,H,W) 16-bit NHWC out; bit-identical to
+    ``pack_images_c32`` + ``conv3x3_c32`` with the weight zero-padded along Cin."""
+    L.require_cuda(xa, xb, weight)
+    B, _, H, W = xa.shape
+    y = _empty_nhwc(B, 32, H, W, _h16(), xa.device)
+    L.call("hesic_conv3x3_c32_forward_img6", L.ptr(xa.float().contiguous()), L.ptr(xb.float().contiguous()), L.ptr(weight.detach().float().contiguous()),
+           L.ptr(None if bias is None else bias.detach().float()), int(act), L.ptr(y), B, H, W, L.stream())
+    return y
+
+
 def conv3x3_c32(x, weight, bias, act=L.ACT_NONE, res1=None, res2=None):
     """act(conv3x3(x) + bias) + res1 + res2 in one launch: x (B,32,H,W) bf16 (any layout, made NHWC); 32 couts -> bf16 NHWC
     with bf16 residuals, <= 4 couts -> fp32 planar with one fp32 planar residual (the 32 -> 3 output conv + the image)."""

@@ -1592,17 +1592,9 @@ class Enhancement(nn.Module):
     def forward(self, x, x_another_warp):
         if (Fn.conv3x3_c32_ok(x.new_empty((1, 32, 1, 1), dtype=Fn._h16()), self.EB1.RB1.conv1.weight) and x.is_cuda
                 and tuple(self.conv1.weight.shape) == (32, 6, 3, 3)):
-            # inference: the 6 -> 32 input conv runs on the 32-channel kernel too -- the two images go into channels 0..5 of a
-            # zero-padded NHWC bf16 map, the weight is zero-padded along Cin (cached)
-            B, _, H, W = x.shape
-            xin = Fn.pack_images_c32(x, x_another_warp)
-            w6 = self.conv1.weight
-            tag = (w6.data_ptr(), w6._version)
-            if getattr(self, "_w32", None) is None or self._w32[0] != tag:
-                wp = torch.zeros((32, 32, 3, 3), dtype=torch.float32, device=w6.device)
-                wp[:, :6] = w6.detach()
-                self._w32 = (tag, wp)
-            t = Fn.conv3x3_c32(xin, self._w32[1], self.conv1.bias)
+            # inference: the 6 -> 32 input conv reads the two planar images directly (round 6: one launch instead of pack_images_c32 + the
+            # 32-channel kernel on a zero-padded map and weight; same numbers)
+            t = Fn.conv3x3_c32_img6(x, x_another_warp, self.conv1.weight, self.conv1.bias)
         elif (x.is_cuda and not x.requires_grad and not x_another_warp.requires_grad and tuple(self.conv1.weight.shape) == (32, 6, 3, 3)
               and Fn.conv3x3_c32_train_ok(x.new_empty((1, 32, 1, 1), dtype=Fn._h16()), self.conv1.weight)):
             # stage-2 training (HSIC frozen, so the images carry no gradient): the same packed 32-channel input map; the 6-input-channel

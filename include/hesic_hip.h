@@ -516,6 +516,12 @@ int hesic_conv3x3_c32_wgrad(const void* x, const void* g, float* dw, float* dbia
  * zero-padded along Cin.                                                                                  */
 int hesic_pack_images_c32(const float* xa, const float* xb, void* out_nhwc32_bf16, int B, int H, int W, void* stream);
 
+/* conv3x3(torch.cat((xa, xb), 1)) of Enhancement.forward (ywz/mywork/newnet1.py:300-301; compressai/layers/layers.py conv3x3) in ONE launch (round 6):
+ * xa, xb fp32 planar (B,3,H,W) contiguous, w fp32 (32,6,3,3), bias fp32 (32) or NULL, y (B,H,W,32) 16-bit NHWC.  Bit-identical to
+ * hesic_pack_images_c32 + hesic_conv3x3_c32_forward with the weight zero-padded along Cin, without the 32-channel round trip through HBM. */
+int hesic_conv3x3_c32_forward_img6(const float* xa, const float* xb, const float* w, const float* bias, int act, void* y, int B, int H, int W,
+                                   void* stream);
+
 /* torch.optim.Adam(params, lr) update (ywz/mywork/newtrain1.py:294-295; no amsgrad, no weight decay) for up to
  * HESIC_ADAM_MAX_TENSORS fp32 tensors per call: p, g, m (exp_avg), v (exp_avg_sq) dense arrays of numel elements in the
  * same element order, step = the tensor's own fp32 step counter (device scalar, incremented by the call).  The struct is

@@ -828,6 +828,28 @@ def test_conv3x3_c32_enhancement_kernel(hw):
     assert rel_err(y6, O.conv(bf(torch.cat((a6, b6), 1)), bf(w6), b, 1)) < 1e-2
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (37, 45), (5, 3), (50, 130)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_conv3x3_c32_img6_is_pack_plus_conv_bit_for_bit(hw, dtype):
+    """hesic_conv3x3_c32_forward_img6 (round 6: Enhancement.conv1 on the two planar images in one launch, newnet1.py:300-301) against the two-launch
+    route of rounds 3 - 5 (pack_images_c32 + the 32-channel kernel on a weight zero-padded along Cin): the same products in the same order."""
+    Fn, O = _imp()
+    H, W = hw
+    xa, xb = rnd(f"i6_a{hw}", (2, 3, H, W)), rnd(f"i6_b{hw}", (2, 3, H, W))
+    w, b = rnd("i6_w", (32, 6, 3, 3)) * 0.2, rnd("i6_bias", (32,), -0.2, 0.2)
+    Fn.set_compute_dtype(dtype)
+    try:
+        with torch.no_grad():
+            one = Fn.conv3x3_c32_img6(xa.to(DEV), xb.to(DEV), w.to(DEV), b.to(DEV))
+            w32 = torch.zeros(32, 32, 3, 3)
+            w32[:, :6] = w
+            two = Fn.conv3x3_c32(Fn.pack_images_c32(xa.to(DEV), xb.to(DEV)), w32.to(DEV), b.to(DEV))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    assert one.dtype == dtype and one.shape == (2, 32, H, W) and torch.equal(one, two)
+    assert rel_err(one, O.conv(torch.cat((xa, xb), 1), w, b, 1)) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
 @pytest.mark.parametrize("hw", [(64, 64), (37, 45), (16, 32), (5, 3), (50, 130), (96, 160)])
 @pytest.mark.parametrize("skip", [False, True])
 def test_resblock_c32_agrees_with_the_two_launch_path(hw, skip):
