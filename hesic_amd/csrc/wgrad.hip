@@ -2480,6 +2480,8 @@ static thread_local int g_wgrad_partial_only = 0;      // set by hesic_conv2d_wg
 // slices of a (tap, cout) row next to each other.  Measured neutral on the training step (same box, alternating runs: 9.579 / 9.583 ms
 // with it, 9.586 / 9.596 without): the finishing pass still reads 128-byte pieces (its 8 cout x 32 cin tiles) -- contiguity across
 // slices alone does not raise its 2.9 TB/s; a 512-byte-wide tile would be the next step.
+// (round 6, same box, two alternating runs each, ms per training step: this layout + the narrow finishing pass 8.887 / 8.897; slices of a (tap, cout) row
+// adjacent 8.895 / 8.892; the 512-byte-wide finishing pass 9.037 / 9.049; both 9.027 / 9.042 -- the finishing pass's layout is not a lever)
 static int direct_ws_layout() { return 0; }
 
 extern "C" int hesic_conv2d_wgrad_direct(const hesic_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
