@@ -1127,7 +1127,10 @@ def main():
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 20
                 by = km.streaming[wk]["bytes_per_launch"]
-                km.streaming[wk]["back_to_back"] = {"launches": 20, "avg_launch_us": round(us, 2), "achieved": round(by / us / 1e3, 1), "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4)}
+                km.streaming[wk]["back_to_back"] = {"launches": 20, "avg_launch_us": round(us, 2), "achieved": round(by / us / 1e3, 1), "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4),
+                                                    "note": "the SAME 25 MB source and destination 20 times between one event pair: they stay in the 256 MB Infinity Cache, so this is "
+                                                            "cache-assisted bandwidth (the kernel without its launch latency), not HBM bandwidth; the single-launch figure above is the "
+                                                            "roofline entry (ADVICE r5)"}
         except Exception as e:                     # a report line, never the reason a bench run fails
             print(f"# warp back-to-back timing skipped: {e}", file=sys.stderr)
 

@@ -85,13 +85,28 @@ class _NoCtx:
         pass
 
 
+_autograd_depth = 0          # > 0 while an autograd.Function of this module runs its forward on behalf of a grad-enabled call
+
+
 def _apply(fn, *args):
+    global _autograd_depth
     if torch.is_grad_enabled():
         if _compute_dtype == torch.float16 and any(torch.is_tensor(a) and a.requires_grad for a in args):
             raise RuntimeError("hesic_amd: float16 is an inference format here (gradients need the fp32 exponent range): train with "
                                "set_compute_dtype(torch.bfloat16) or torch.float32, or run the forward under torch.no_grad()")
-        return fn.apply(*args)
+        _autograd_depth += 1
+        try:
+            return fn.apply(*args)
+        finally:
+            _autograd_depth -= 1
     return fn.forward(_NoCtx(), *args)
+
+
+def inference_call():
+    """True when the current operator call is a plain inference call: grad mode off, NOT the forward of an autograd.Function reached from a
+    grad-enabled call (grad mode is off inside ``Function.forward`` too) and not a backward pass.  The error-feedback ("shaped") weight packs are
+    inference-only: a training forward outside ``Trainer.step`` must multiply the plainly rounded weights its backward differentiates."""
+    return not torch.is_grad_enabled() and _autograd_depth == 0 and torch._C._current_graph_task_id() < 0
 
 
 FUSE_GDN3 = True      # module switch (tests / profiling): 3-channel (I)GDN inside the 6 -> 3 cat-conv launch
@@ -378,7 +393,8 @@ class PackedWeight:
         # autograd.Function bodies run with grad mode off, so a training step also takes the cached branch (one repack
         # per layout and step, when the version tag moves)
         caching = not torch.is_grad_enabled()
-        key = (transposed, flip, dtype, cout, cin)
+        # an inference pack with error-feedback rounding and the plain pack of a training forward / backward are different images of one weight
+        key = (transposed, flip, dtype, cout, cin, bool(self.shaped and SHAPED_WEIGHTS and inference_call() and not _train_pack_cache))
         tag = (weight.data_ptr(), weight._version, None if mask is None else mask._version, _cache_epoch)
         hit = None
         if caching:
@@ -415,10 +431,10 @@ class PackedWeight:
             self._cache[key] = (tag, wp)
             return wp
         wp = torch.empty(kh * kw * cout * cin, dtype=dtype, device=weight.device)
-        if (self.shaped and SHAPED_WEIGHTS and caching and not _train_pack_cache and dtype != torch.float32 and mask is None and not transposed
+        if (self.shaped and SHAPED_WEIGHTS and caching and inference_call() and not _train_pack_cache and dtype != torch.float32 and mask is None and not transposed
                 and not flip and kh * kw > 1 and weight.dtype == torch.float32 and weight.is_contiguous()):
             L.call("hesic_pack_conv_weight_shaped", L.ptr(weight.detach()), L.ptr(wp), cout, cin, kh, kw, L.stream())
-        elif (self.shaped and self.tr_stride and SHAPED_WEIGHTS and caching and not _train_pack_cache and dtype != torch.float32 and mask is None
+        elif (self.shaped and self.tr_stride and SHAPED_WEIGHTS and caching and inference_call() and not _train_pack_cache and dtype != torch.float32 and mask is None
                 and transposed and not flip and kh * kw > 1 and weight.dtype == torch.float32 and weight.is_contiguous()):
             L.call("hesic_pack_conv_weight_shaped_tr", L.ptr(weight.detach()), L.ptr(wp), cout, cin, kh, kw, self.tr_stride, L.stream())
         else:
@@ -442,7 +458,7 @@ def _weight_image(kind, weight, gp=None, gtag=None):
     hit = _img_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is weight:
         return hit[1]
-    if kind == 1 and SHAPED_WEIGHTS and not torch.is_grad_enabled() and not _train_pack_cache:
+    if kind == 1 and SHAPED_WEIGHTS and inference_call() and not _train_pack_cache:
         kind = 2          # inference: g_s_conv4's panel rounded with error feedback per output phase (csrc/sconv.hip, round 5)
         key = (kind, weight.data_ptr())
         hit = _img_cache.get(key)

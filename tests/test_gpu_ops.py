@@ -1158,6 +1158,49 @@ def test_gdn_packs_of_a_training_step_are_refreshed_in_one_launch():
         hesic_amd.set_compute_dtype(prev_dt)
 
 
+def test_error_feedback_packs_are_for_plain_inference_calls_only():
+    """grad mode is off inside an autograd.Function's forward and backward as well as under ``torch.no_grad()``.  A grad-enabled
+    call (a training forward outside ``Trainer.step``) and its backward use the plainly rounded weights -- the forward output equals the
+    SHAPED_WEIGHTS-off result bit for bit, through one packer that has already cached its error-feedback pack from an inference call -- and
+    the inference call after it gets the error-feedback pack back."""
+    Fn, O = _imp()
+    dt = torch.bfloat16          # float16 is an inference-only format here
+    Fn.set_compute_dtype(dt)
+    try:
+        x = rnd("efi_x", (2, 128, 24, 40)).to(DEV, dt)
+        w = (rnd("efi_w", (128, 128, 5, 5)) * 0.05).to(DEV).requires_grad_(True)
+        pk = Fn.PackedWeight(shaped=True)
+        kw = dict(kernel_size=5, stride=2, padding=2, packer=pk)
+        with torch.no_grad():
+            y_inf = Fn.conv2d(x, w, None, **kw).clone()
+            keep, Fn.SHAPED_WEIGHTS = Fn.SHAPED_WEIGHTS, False
+            try:
+                y_plain = Fn.conv2d(x, w, None, packer=Fn.PackedWeight(shaped=True), kernel_size=5, stride=2, padding=2).clone()
+            finally:
+                Fn.SHAPED_WEIGHTS = keep
+        assert not torch.equal(y_inf, y_plain)                      # the two packs differ
+        seen = []
+        class Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                seen.append(("forward", Fn.inference_call()))
+                return t.clone()
+            @staticmethod
+            def backward(ctx, g):
+                seen.append(("backward", Fn.inference_call()))
+                return g
+        y_tr = Fn.conv2d(x, w, None, **kw)                          # grad-enabled call through the SAME packer
+        assert y_tr.requires_grad and torch.equal(y_tr.detach(), y_plain)
+        Probe.apply(y_tr).float().sum().backward()
+        assert w.grad is not None and bool(torch.isfinite(w.grad).all())
+        assert ("backward", False) in seen
+        with torch.no_grad():
+            assert Fn.inference_call()
+            assert torch.equal(Fn.conv2d(x, w, None, **kw), y_inf)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("fmt", ["bf16", "f16"])
 def test_synthesis_weights_rounded_with_error_feedback_per_output_phase(fmt):
     """Round 5: at 16-bit inference the weights of g_s_conv2 / g_s_conv3 (``hesic_pack_conv_weight_shaped_tr``) and g_s_conv4's LDS panel
