@@ -696,6 +696,91 @@ def secondary_block(dev, size=512, lmbda=0.0067):
     return out
 
 
+def _smi_sample():
+    """Shader clock (MHz) and socket power (W) of the visible GPU from rocm-smi (the hwmon nodes inside the container belong to other cards)."""
+    import subprocess
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out).values()))
+    except Exception:
+        return None
+    r = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if "sclk" in kl and "(" in str(v):
+            try:
+                r["sclk_mhz"] = float(str(v).split("(")[1].lower().split("mhz")[0])
+            except ValueError:
+                pass
+        elif "power" in kl and "max" not in kl and "cap" not in kl:
+            try:
+                r["power_w"] = float(v)
+            except (TypeError, ValueError):
+                pass
+    return r or None
+
+
+def under_load(fn, seconds=2.0):
+    """Run fn() back to back for `seconds` while a thread samples rocm-smi: the clock and socket power the chip settles at under that load
+    (first half of the samples dropped).  Returns (calls made, wall seconds, {"sclk_mhz", "power_w", "samples"} or None)."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            r = _smi_sample()
+            if r:
+                samples.append(r)
+            time.sleep(0.02)
+    th = threading.Thread(target=poll, daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        n += 4
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stop.set()
+    th.join(timeout=15)
+    tail = samples[len(samples) // 2:]
+    st = None
+    if tail:
+        st = {"samples": len(tail)}
+        for k in ("sclk_mhz", "power_w"):
+            v = [x[k] for x in tail if k in x]
+            if v:
+                st[k] = round(sum(v) / len(v), 1)
+    return n, wall, st
+
+
+def power_state(step_fn, dtype, dev):
+    """`roofline.power_state`: what the board's power management does to the peak the roofline is priced against.  (a) the timed step replayed
+    for 2 s, (b) a register-only MFMA loop (hesic_probe_mfma_loop: no LDS, no memory) on random and on all-zero operands, each with the clock and
+    socket power rocm-smi reports meanwhile.  Measured AFTER the timed region; a report block, never the reason a run fails."""
+    import ctypes as C
+    from hesic_amd import _lib as L
+    out = {"power_cap_w": 1400.0, "nominal_sclk_mhz": 2400.0, "how": "rocm-smi --showclocks --showpower polled from a thread while the load repeats for 2 s"}
+    n, wall, st = under_load(step_fn)
+    out["timed_step"] = dict(st or {}, ms_per_step=round(1e3 * wall / n, 3))
+    h16 = torch.float16 if dtype == "f16" else torch.bfloat16
+    sink = torch.zeros(1024, device=dev)
+    for kind in ("random", "zeros"):
+        src = ((torch.rand(32768, device=dev) - 0.5) * 0.25 if kind == "random" else torch.zeros(32768, device=dev)).to(h16)
+        fl = C.c_double(0.0)
+
+        def loop():
+            L.call("hesic_probe_mfma_loop", L.ptr(src), L.ptr(sink), 2048, C.byref(fl), L.stream())
+        loop()
+        n, wall, st = under_load(loop, 1.5)
+        out[f"mfma_loop_{kind}_operands"] = dict(st or {}, tflops=round(fl.value * n / wall / 1e12, 1))
+    out["note"] = ("`peak` above is the nominal dense rate at 2.4 GHz; on random operands the matrix pipe alone holds mfma_loop_random_operands.tflops because the chip "
+                   "leaves its nominal clock at the power cap, and the timed step runs at timed_step.sclk_mhz / power_w (profiles/r06_power_probe.txt: the dominant "
+                   "launch alone sits AT the cap)")
+    return out
+
+
 def emit_line(obj):
     """The run's ONE JSON line, as the LAST thing on stdout: whatever native libraries have queued on the C stdio buffer (RCCL's
     NCCL_DEBUG=VERSION banner, which this image exports) is flushed first, then the line, flushed."""
@@ -949,6 +1034,7 @@ def main():
                          "pairs (about 25 s per set) and compare bf16x3 / bf16 / fp32 against the CPU oracle on the trained weights")
     ap.add_argument("--parity-train-steps", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-state", action="store_true", help="skip roofline.power_state (clock / socket power under the timed step and under a matrix-only loop, ~6 s)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (HESIC+ B=4 and one training step, ~5 s, after the timed region)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (models.GraphedForward) instead of issuing it eagerly")
     ap.add_argument("--exec", dest="exec_mode", choices=["auto", "eager", "graph"], default="auto",
@@ -1133,6 +1219,19 @@ def main():
                                                             "roofline entry (ADVICE r5)"}
         except Exception as e:                     # a report line, never the reason a bench run fails
             print(f"# warp back-to-back timing skipped: {e}", file=sys.stderr)
+        if rank == 0 and world == 1 and args.dtype != "f32" and not args.no_power_state:
+            try:
+                _i = [0]
+
+                def _one():
+                    _i[0] += 1
+                    step(_i[0])
+                roof["power_state"] = power_state(_one, args.dtype, dev)
+                pl = roof["power_state"].get("mfma_loop_random_operands", {}).get("tflops")
+                if pl:
+                    roof["executed_frac_of_mfma_loop_at_power_cap"] = round(s["executed_tflops"] / pl, 4)
+            except Exception as e:
+                print(f"# power_state skipped: {e}", file=sys.stderr)
 
     if rank == 0:
         pairs = world * args.batch * args.steps

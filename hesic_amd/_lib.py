@@ -112,6 +112,7 @@ _SIGS = {
     "hesic_joint_step": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp], _i32),
     "hesic_memcpy_async": ([_vp, _vp, C.c_size_t, _i32, _vp], _i32),
     "hesic_stream_synchronize": ([_vp], _i32),
+    "hesic_probe_mfma_loop": ([_vp, _vp, _i32, _P(C.c_double), _vp], _i32),
     "hesic_joint_decode_groups": ([_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_joint_decode_groups_tape": ([_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
     "hesic_ssim_scale": ([_vp, _P(_i64), _vp, _P(_i64), _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),

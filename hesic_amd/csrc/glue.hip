@@ -1035,3 +1035,42 @@ extern "C" int hesic_stream_synchronize(void* stream) {
     if (e != hipSuccess) { hesic_set_error("stream_synchronize: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+
+// ---- measurement aid (bench.py `roofline.power_state`; no product path calls it): a register-only loop of independent
+// v_mfma_f32_32x32x16 on 16-bit operands, every SIMD of the chip busy, no LDS and no memory traffic -- what the matrix pipe sustains under the
+// board's power management on operands of the given kind.  `src` holds >= 64 KB of 16-bit values (random, or zeros); `sink` takes nothing unless
+// the sums hit a magic value (keeps the loop alive).  2048 blocks x 4 waves x iters x 16 MFMAs of 32768 flops.
+namespace {
+__global__ __launch_bounds__(256, 2) void probe_mfma_loop_kernel(const h16x8* __restrict__ src, float* __restrict__ sink, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const h16x8 a0 = src[t & 4095], a1 = src[(t + 64) & 4095], b0 = src[(t + 128) & 4095], b1 = src[(t + 192) & 4095];
+    f32x16 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[u][r] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[0] = mfma_32x32x16_h16(a0, b0, c[0], 0, 0, 0);
+            c[1] = mfma_32x32x16_h16(a0, b1, c[1], 0, 0, 0);
+            c[2] = mfma_32x32x16_h16(a1, b0, c[2], 0, 0, 0);
+            c[3] = mfma_32x32x16_h16(a1, b1, c[3], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += c[u][r];
+    if (s == 12345.678f) sink[t & 1023] = s;
+}
+}  // namespace
+
+extern "C" int hesic_probe_mfma_loop(const void* src_64k, float* sink_4k, int iters, double* flops_out, void* stream) {
+    HESIC_CHECK_ARG(src_64k && sink_4k && iters > 0, "probe_mfma_loop: null pointer or no iterations");
+    constexpr int BLOCKS = 2048;
+    hipLaunchKernelGGL(probe_mfma_loop_kernel, dim3(BLOCKS), dim3(256), 0, (hipStream_t)stream, (const h16x8*)src_64k, sink_4k, iters);
+    if (flops_out) *flops_out = (double)BLOCKS * 4 * iters * 16 * 32768.0;
+    HESIC_LAUNCH_RETURN("probe_mfma_loop");
+}

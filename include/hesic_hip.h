@@ -631,6 +631,11 @@ int hesic_joint_decode_groups_tape(int n_groups, const int32_t* group_size, cons
                                    void* decoder, int spin, void* stream);
 int hesic_stream_synchronize(void* stream);
 
+/* Measurement aid, not part of the path (bench.py `roofline.power_state`): a register-only loop of independent 32x32x16 MFMAs on the library's
+ * 16-bit format over the whole chip -- the rate the matrix pipe sustains under the board's power management for operands of the kind `src_64k`
+ * holds (>= 64 KB of 16-bit values: random, or zeros).  `sink_4k`: 4 KB the kernel never really writes.  *flops_out = flops of the launch. */
+int hesic_probe_mfma_loop(const void* src_64k, float* sink_4k, int iters, double* flops_out, void* stream);
+
 /* ------------------------------------------------------------------ MS-SSIM (row M: the second published quality metric)
  * The reference's evaluation reports pytorch_msssim.ms_ssim(x_hat, x, data_range=1, size_average=False) next to PSNR
  * (ywz/mywork/test3real.py:107-109; third party, absent: algorithm restated, see oracle/hesic_oracle.py::ms_ssim).

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-python profiles/scripts/aten_ops_in_forward.py > gpurun_out/r06_aten.log 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-secondary > gpurun_out/r06_bench_ps.json 2> gpurun_out/r06_bench_ps.err
