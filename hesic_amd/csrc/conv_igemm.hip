@@ -1071,20 +1071,32 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
 #ifndef TR4_ABL
 #define TR4_ABL 0
 #endif
-template <int GDN>
+#ifndef TR4_HALO
+#define TR4_HALO 1
+#endif
+// HALO = 1 (round 6; Cin = 128, 5 x 5, pad 2, q-tile 8 x 16): the X operand is not staged per (tap, channel chunk) -- 25 taps x 2 chunks x 16 KB
+// per block, 9 distinct shifts of ONE 10 x 18 input patch -- but ONCE per block, as that patch with all 128 channels (180 pixels x 256 B = 45 KB,
+// through registers), and the fragment reads of a tap address it at the tap's shift; the ring then carries weight tiles only (2 x 16 KB),
+// so a block moves 0.85 MB through the global -> LDS path instead of 1.6 MB.  LDS per block 45 + 32 KB (+ beta'): still two blocks per CU, and the
+// epilogue tile (32 KB) takes BOTH ring buffers -- the next phase's first weight tile is requested behind the epilogue's last LDS read instead
+// of under it.  16-byte slot s of halo pixel (hy, hx) sits at position s ^ (hx & 15): a b128 fragment read's 16-lane groups ({0-3, 12-15} of one
+// tile row + {4-11} of the next) then cover the 64 banks exactly once at every shift.  Same taps, same order, same chunks: bit-identical.
+template <int GDN, int HALO = 0>
 __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
     using T = h16_t;
     constexpr int BM = 128, BN = 128, BK = 64, NW = 4, NT = NW * 64;
     constexpr int CPR = BK * 2 / 16, RPB = 256 / (BK * 2);
-    constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
-    constexpr int XI = BM * CPR / 64 / NW, WI = BN * CPR / 64 / NW;
+    constexpr int XT = HALO ? 0 : BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
+    constexpr int XI = HALO ? 0 : BM * CPR / 64 / NW, WI = BN * CPR / 64 / NW;
+    constexpr int HW_ = 18, HPIX = 10 * HW_, XH_OFF = 2 * WT, XH_BYTES = HALO ? HPIX * 256 : 0;      // halo: 10 rows x 18 pixels x 128 channels
     constexpr int WM = 2, MI = BN / WM / 32, NI = BM / 2 / 32;
     constexpr int NST = BM * 16 / NT;                         // 16-byte stores per lane and output tile
-    static_assert(STAGE == BM * 256 && NST == 8, "the epilogue tile takes exactly one stage buffer");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + (GDN ? 512 : 0)];   // ring + beta' (fp32 [128])
+    static_assert((HALO ? 2 * STAGE : STAGE) == BM * 256 && NST == 8, "the epilogue tile takes exactly one stage buffer (HALO: both weight buffers)");
+    constexpr int BETA_OFF = 2 * STAGE + XH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BETA_OFF + (GDN ? 512 : 0)];   // ring + (halo) + beta' (fp32 [128])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (GDN && tid < 128) *(float*)(smem + 2 * STAGE + tid * 4) = a.gdn_beta[tid];     // read behind the K loop's barriers
+    if (GDN && tid < 128) *(float*)(smem + BETA_OFF + tid * 4) = a.gdn_beta[tid];     // read behind the K loop's barriers
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     uint32_t rest = fdiv((uint32_t)bid, a.fd_nt);
     const int nt = bid - (int)rest * a.n_tiles;
@@ -1110,8 +1122,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         (void*)(xg + ((int64_t)b * a.H + row0) * a.W * a.x_ps - neg), 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)OOB, 0x00020000);
     const int prow = lane / CPR, pslot = lane % CPR;
-    uint32_t xoff[XI], xv[XI], wv[WI];
-    int iy0[XI], ix0[XI];
+    uint32_t xoff[XI ? XI : 1], xv[XI ? XI : 1], wv[WI];
+    int iy0[XI ? XI : 1], ix0[XI ? XI : 1];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int row = (wave * XI + i) * (64 / CPR) + prow;
@@ -1127,6 +1139,38 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         const int row = (wave * WI + i) * (64 / CPR) + prow;
         const int ls = pslot ^ ((row / RPB) & (CPR - 1));
         wv[i] = (uint32_t)(((n0 + row) * a.Cin + ls * 8) * 2);
+    }
+    if constexpr (HALO != 0) {
+        // the input patch of the tile, once, through registers (16 bytes per lane and step: slot e & 15 of halo pixel e >> 4): 12 loads per lane
+        // in flight together, then 12 LDS writes -- once per block, so the LDS-DMA form (45 instructions per block, measured 1 - 2 % faster
+        // per launch) is not worth its open question: no kernel of this library has LDS-DMA destinations beyond the first 128 KB of a CU's
+        // LDS yet, and the second co-resident block's patch would lie there
+        constexpr int HSTEPS = (HPIX * 16 + NT - 1) / NT;
+        u32x4 hv[HSTEPS];
+#pragma unroll
+        for (int i = 0; i < HSTEPS; ++i) {
+            const int e = i * NT + tid, hp = e >> 4, hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = row0 - 1 + hy, ix = tx * a.TW - 1 + hx;
+            const int ls = (e & 15) ^ (hx & 15);
+            const bool ok = hp < HPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t vo = ok ? (uint32_t)(((((hy - 1) * a.W + ix) * a.x_ps + a.x_co + ls * 8) + neg) * 2) : OOB;
+            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vo, 0, 0);          // out of range: zeros
+        }
+#pragma unroll
+        for (int i = 0; i < HSTEPS; ++i) {
+            const int e = i * NT + tid;
+            if (e < HPIX * 16) *(u32x4*)(smem + XH_OFF + e * 16) = hv[i];
+        }
+    }
+    // consumer side of the halo: this lane's pixels of the tile (q-tile 8 x 16: pixel p = (p >> 4, p & 15)) as halo addresses at shift (0, 0)
+    [[maybe_unused]] int hbase[BM / 2 / 32], hsw[BM / 2 / 32];
+    if constexpr (HALO != 0) {
+#pragma unroll
+        for (int j = 0; j < BM / 2 / 32; ++j) {
+            const int pq = (wave / 2) * (BM / 2) + j * 32 + (lane & 31);
+            hbase[j] = XH_OFF + (((pq >> 4) + 1) * HW_ + (pq & 15) + 1) * 256;
+            hsw[j] = (pq & 15) + 1;
+        }
     }
     // phase (ry, rx) = (ph >> 1, ph & 1): taps k = k0 + 2 j with k0 = (r + pad) & 1, input displacement (r + pad - k) / 2 = d0 - j
     auto phase_geo = [&](int ph, int& ky0, int& kx0, int& nky, int& nkx, int& dyb, int& dxb) {
@@ -1154,6 +1198,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         const uint32_t sx = s_x + (uint32_t)(cur_chunk * BK * 2), sw = s_w + (uint32_t)(cur_chunk * BK * 2);
         unsigned char* xs = smem + buf * STAGE;
         unsigned char* ws = xs + XT;
+        (void)sx;
         if constexpr (!(TR4_ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < XI; ++i)
@@ -1198,13 +1243,41 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         for (int k = 0; k < NST; ++k) {
             const int pr = (t >> 4) + k * (NT / 16), cc = t & 15;
             const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
-            const uint32_t vo = (qy < a.QH && qx < a.QW) ? (uint32_t)(((2 * qy * Wo + 2 * qx) * a.y_ps + a.y_co + n0 + cc * 8) * 2) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(eb + pr * 256 + ((cc ^ (pr & 15)) << 4)), rs, (int)vo, (int)so, 0);
+            // phase offset in the VGPR offset, soffset = 0: see the store-hazard note in store_tile_then_issue below
+            const uint32_t vo = (qy < a.QH && qx < a.QW) ? (uint32_t)(((2 * qy * Wo + 2 * qx) * a.y_ps + a.y_co + n0 + cc * 8) * 2) + so : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(eb + pr * 256 + ((cc ^ (pr & 15)) << 4)), rs, (int)vo, 0, 0);
         }
     };
 
+    // HALO: the phase's last store -- tile rows into registers, barrier (every wave is done with the tile = with both weight buffers), the next
+    // phase's first weight tile requested, then the stores: request and stores travel together, the next phase waits for both (vmcnt(0))
     f32x16 acc[MI][NI];
     int gbuf = 0;
+    auto store_tile_then_issue = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned char* eb, int ry, int rx, bool more) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const uint32_t so = (uint32_t)((ry * Wo + rx) * a.y_ps * 2);
+        u32x4 rows[NST];
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int pr = (t >> 4) + k * (NT / 16), cc = t & 15;
+            rows[k] = *(const u32x4*)(eb + pr * 256 + ((cc ^ (pr & 15)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) issue(gbuf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int pr = (t >> 4) + k * (NT / 16), cc = t & 15;
+            const int qy = ty * a.TH + (pr >> a.tw_shift), qx = tx * a.TW + (pr & (a.TW - 1));
+            // the phase offset goes INTO the VGPR offset (soffset = 0): with a register soffset the compiler's hazard recognizer lets a VALU
+            // write into a 16-byte store's data registers follow the store directly (here: the next store's address, computed into a
+            // register of the previous store's data), and under memory-pipe back-pressure -- two blocks per CU -- gfx950 then stores the
+            // NEW contents: 4 - 17 % wrong pixels, different on every launch, never in the last store of a lane (see also sconv.hip)
+            const uint32_t vo = (qy < a.QH && qx < a.QW) ? (uint32_t)(((2 * qy * Wo + 2 * qx) * a.y_ps + a.y_co + n0 + cc * 8) * 2) + so : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(rows[k], rs, (int)vo, 0, 0);
+        }
+    };
     issue(0);
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
@@ -1217,7 +1290,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        auto stage = [&](auto last_tag) {
+        auto stage = [&](auto last_tag, int step) {
             constexpr bool LAST = decltype(last_tag)::value;
             constexpr int KS = BK / 16;
             __builtin_amdgcn_s_barrier();
@@ -1225,7 +1298,24 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             const unsigned char* ws = xs + XT;
             gbuf ^= 1;
             h16x8 wf[2][MI], xf[2][NI];
+            [[maybe_unused]] int hx_[NI];
+            [[maybe_unused]] int hchunk = 0;
+            if constexpr (HALO != 0) {
+                // tap of this stage (two channel chunks per tap): its shift moves the lane's halo address and the slot rotation
+                const int tap = step >> 1, tj = (tap >= c_nkx) + (tap >= 2 * c_nkx), tc = tap - tj * c_nkx;
+                const int dy_ = c_dyb - tj, dx_ = c_dxb - tc;
+                hchunk = (step & 1) * 128;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) hx_[j] = (hbase[j] + (dy_ * HW_ + dx_) * 256) | (((fh ^ (hsw[j] + dx_)) & 15) << 4);
+            }
             auto ldf = [&](int set, int ks) {
+                if constexpr (HALO != 0) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) wf[set][i] = *(const h16x8*)(ws + off(wm * (BN / WM) + i * 32 + frow, ks * 2 + fh));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) xf[set][j] = *(const h16x8*)(smem + (hx_[j] ^ (hchunk + ks * 32)));
+                    return;
+                }
                 if constexpr (TR4_ABL & 4) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(wf[set][i]) : "v"(ws));
@@ -1240,7 +1330,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             };
             ldf(0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!LAST || ph < 3) issue(gbuf);                      // LAST: stage 0 of the next phase, into the buffer the epilogue does not use
+            if (!LAST || (ph < 3 && !HALO)) issue(gbuf);           // LAST: stage 0 of the next phase, into the buffer the epilogue does not use
+                                                                   // (HALO: the epilogue takes both weight buffers -- requested behind it)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) ldf((ks + 1) & 1, ks + 1);
@@ -1262,11 +1353,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         };
         // first stage of a later phase: everything but the previous epilogue's stores (the newest vector-memory operations of this wave)
         // has to be back; the lgkmcnt part covers that epilogue's last LDS reads before the barrier hands its buffer to the DMA
-        if (ph == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ph == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: HALO's patch, written by ds_write)
+        // HALO: the weight tile was requested just in front of the phase's last stores.  A COUNTED wait is not safe here: loads and stores
+        // retire out of order with respect to each other, so vmcnt(NST) can be reached by the stores alone while the tile is still in flight
+        // (measured: 4 - 17 % wrong pixels, different on every launch).  The unfused form's counted wait works because its request is a
+        // whole epilogue older than its stores.
+        else if constexpr (HALO != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (GDN && a.y_pre) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
         for (int step = 0; step < nsteps - 1; ++step) {
-            stage(std::false_type{});
+            stage(std::false_type{}, step);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // (I)GDN: the gamma' fragments of the epilogue are requested in front of the phase's last stage -- an L2 round trip that would
@@ -1279,10 +1375,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             for (int ks = 0; ks < 8; ++ks)
                 gq[0][ks] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, ((wm * MI + 0) * 8 + ks) * 1024, 0));
         }
-        stage(std::true_type{});
+        stage(std::true_type{}, nsteps - 1);
 
-        // ---- epilogue in the buffer of the stage just computed
-        unsigned char* eb = smem + (gbuf ^ 1) * STAGE;
+        // ---- epilogue in the buffer of the stage just computed (HALO: in both weight buffers)
+        unsigned char* eb = HALO ? smem : smem + (gbuf ^ 1) * STAGE;
         const int ry = ph >> 1, rx = ph & 1;
         if constexpr ((TR4_ABL & 8) != 0) {
 #pragma unroll
@@ -1317,7 +1413,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
                     }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            store_tile(yr, eb, ry, rx);
+            if constexpr (HALO != 0) store_tile_then_issue(yr, eb, ry, rx, ph < 3);
+            else store_tile(yr, eb, ry, rx);
         } else {
             // fused (I)GDN (compressai/layers/gdn.py:55-70), the data flow of igemm_glds_kernel's epilogue in ONE 32 KB tile: squares in,
             // contraction on the matrix cores one cout half at a time (32 norm registers live instead of 64: the DMA cursor's state
@@ -1376,7 +1473,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = wm * (BN / WM) + i * 32 + 8 * g + 4 * fh2;
-                    const f32x4 be = *(const f32x4*)(smem + 2 * STAGE + cl * 4);
+                    const f32x4 be = *(const f32x4*)(smem + BETA_OFF + cl * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1401,7 +1498,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has its square fragments: the tile may be overwritten
             put_tile(std::false_type{});
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            store_tile(yr, eb, ry, rx);
+            if constexpr (HALO != 0) store_tile_then_issue(yr, eb, ry, rx, ph < 3);
+            else store_tile(yr, eb, ry, rx);
         }
     }
 }
@@ -2002,7 +2100,14 @@ extern "C" int hesic_conv2d_forward(const hesic_conv_desc* d, const void* x, con
         } else if (use_tr4) {
             // the four output phases of a tile in one block (igemm_tr4_kernel): a quarter of the blocks, one 50-stage pipeline each
             const dim3 grid4((unsigned)(nblocks / 4));
-            if (gdn == 1) hipLaunchKernelGGL((igemm_tr4_kernel<1>), grid4, block, 0, st, a);
+            // the input patch staged once per block (HALO): 128 input channels, 5 x 5 taps at pad 2 (shifts -1 .. 1), the 8 x 16 q-tile
+            const bool halo = TR4_HALO && cin_k == 128 && d->KH == 5 && d->KW == 5 && d->pad == 2 && a.TW == 16 && a.TH == 8;
+            if (halo) {
+                if (gdn == 1) hipLaunchKernelGGL((igemm_tr4_kernel<1, 1>), grid4, block, 0, st, a);
+                else if (gdn == 2) hipLaunchKernelGGL((igemm_tr4_kernel<2, 1>), grid4, block, 0, st, a);
+                else hipLaunchKernelGGL((igemm_tr4_kernel<0, 1>), grid4, block, 0, st, a);
+            }
+            else if (gdn == 1) hipLaunchKernelGGL((igemm_tr4_kernel<1>), grid4, block, 0, st, a);
             else if (gdn == 2) hipLaunchKernelGGL((igemm_tr4_kernel<2>), grid4, block, 0, st, a);
             else hipLaunchKernelGGL((igemm_tr4_kernel<0>), grid4, block, 0, st, a);
         } else if (bm == 128) {

@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 : > gpurun_out/r6_pw.log
 poll() { for i in $(seq 1 $1); do /opt/rocm/bin/rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket" | tr '\n' ' ' ; echo; done; }
-for mode in "" zeros; do
-  ( sleep 2; poll 4 ) >> gpurun_out/r6_pw.log &
-  profiles/scripts/micro/mfma_peak 6 $mode >> gpurun_out/r6_pw.log 2>&1
+for mode in "r" "r small" "z small"; do
+  ( sleep 2; poll 3 ) >> gpurun_out/r6_pw.log &
+  profiles/scripts/micro/mfma_peak 5 $mode >> gpurun_out/r6_pw.log 2>&1
   wait; sleep 2
 done
-python profiles/scripts/power_probe.py >> gpurun_out/r6_pw.log 2>&1

@@ -161,3 +161,35 @@ def test_set_phase_fusion_rejects_bad_modes():
     with pytest.raises(ValueError):
         Fn.set_phase_fusion(3)
     assert Fn.set_phase_fusion(prev) == 1
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+@pytest.mark.parametrize("size", [128, 200])
+def test_fused_phases_at_full_size_repeat_bit_for_bit(fmt, size):
+    """Round 6: at the benchmark's size (8 x 128 -> 128 on a 128^2 map: 1024 fused blocks, two co-resident per CU, every CU's memory pipe
+    backed up) ten launches of g_s_conv3 (+ IGDN) on the same input must be identical to each other and to the one-block-per-phase form.
+    The small shapes above did not catch a store hazard that only shows under that load: a 16-byte buffer store with a REGISTER soffset followed
+    by a VALU write into its data registers (the next store's address) wrote the new contents -- 4 - 17 % wrong pixels, different on every
+    launch (profiles/scripts/tr4_determinism.py).  Also covers the input patch staged once per block (HALO) at a ragged size."""
+    Fn, L, O = _imp()
+    from compressai.layers import GDN
+    from compressai.models.utils import deconv
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[fmt]
+    prev_dt = Fn.compute_dtype() if hasattr(Fn, "compute_dtype") else None
+    hesic_amd.set_compute_dtype(dt)
+    prev = Fn.set_phase_fusion(1)
+    try:
+        x = (rnd(f"full_x{size}", (8, 128, size, size)) * 0.5).to(DEV, dt).contiguous(memory_format=torch.channels_last)
+        layer, g = deconv(128, 128).to(DEV), GDN(128, inverse=True).to(DEV)
+        with torch.no_grad():
+            for f in ((lambda: layer.run_gdn(x, g)), (lambda: layer.run(x))):
+                Fn.set_phase_fusion(1)
+                outs = [f().clone() for _ in range(10)]
+                Fn.set_phase_fusion(0)
+                ref = f().clone()
+                torch.cuda.synchronize()
+                assert all(torch.equal(outs[0], o) for o in outs[1:])
+                assert torch.equal(outs[0], ref)
+    finally:
+        Fn.set_phase_fusion(prev)
+        hesic_amd.set_compute_dtype(prev_dt if prev_dt is not None else torch.float32)
