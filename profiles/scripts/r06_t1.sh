@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r06_t1.log
+python profiles/scripts/memcpy_in_forward.py 2>&1 | grep -v amdgpu.ids | tail -40 > gpurun_out/r06_t1.log
