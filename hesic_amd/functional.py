@@ -1389,7 +1389,8 @@ RESBLOCK_FUSED = True      # module switch: a ResidualBlock is ONE launch at inf
 
 def resblock_c32(x, w1, b1, w2, b2, act=L.ACT_LEAKY, res2=None):
     """act(conv3x3(act(conv3x3(x, w1) + b1), w2) + b2) + x + res2 in one launch (``hesic_resblock_c32_forward``): the ResidualBlock of
-    the enhancement stage at inference (layers.py:125-147), x (B,32,H,W) bf16; bit-identical to two ``conv3x3_c32`` calls."""
+    the enhancement stage at inference (layers.py:125-147), x (B,32,H,W) in the 16-bit format; round 6: agrees with two ``conv3x3_c32`` calls to the last bits, not bit for bit (another summation order:
+    include/hesic_hip.h)."""
     L.require_cuda(x, w1, w2)
     B, _, H, W = x.shape
     x = _nhwc(x)

@@ -496,7 +496,10 @@ int hesic_conv3x3_c32_forward(const void* x, const float* w, const float* bias, 
 /* A whole ResidualBlock of that net in one launch (compressai/layers/layers.py:125-147 with in_ch == out_ch == 32, inference):
  *   y = act(conv(act(conv(x, w1) + b1), w2) + b2) + x + res2
  * x, y, res2 bf16 NHWC (B,H,W,32) (res2 may be NULL: the Enhancement_Block's outer skip, newnet1.py:286), w1 / w2 fp32 (32,32,3,3),
- * b1 / b2 fp32 (32) or NULL.  The intermediate map stays in LDS; results are bit-identical to two hesic_conv3x3_c32_forward calls.
+ * b1 / b2 fp32 (32) or NULL.  The intermediate map stays in LDS.  Round 6 (row-rolling kernel on 16x16x32 MFMAs, a tap's 32 input
+ * channels per instruction): the 288 products of an output value are summed in a different order than by two hesic_conv3x3_c32_forward calls and the
+ * intermediate is rounded once to 16 bits as there -- agreement to <= 2^-8 of the output scale on < 2e-3 of the values (tests/test_gpu_ops.py), the
+ * golden bars of the stage (en_64.npz) unchanged.
  * y must not alias x.                                                                                          */
 int hesic_resblock_c32_forward(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, int act,
                                const void* res2, void* y, int B, int H, int W, void* stream);
