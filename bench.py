@@ -940,6 +940,15 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
     if world > 1:
         dist.barrier()
 
+    # clock / socket power while the timed step repeats (after the timed region; one rank: the sample is the whole board's)
+    pstate = None
+    if world == 1 and not getattr(args, "no_power_state", False):
+        try:
+            n_, wall_, st_ = under_load(lambda: tr.step(x1, x2, Hm), 2.0)
+            pstate = dict(st_ or {}, ms_per_step=round(1e3 * wall_ / n_, 3), power_cap_w=1400.0, nominal_sclk_mhz=2400.0,
+                          how="rocm-smi --showclocks --showpower polled from a thread while the step repeats for 2 s")
+        except Exception as e:
+            print(f"# power_state skipped: {e}", file=sys.stderr)
     if rank == 0:
         pairs = world * args.batch * args.steps
         gflop_pair = 3 * HESIC_GFLOP_PER_PAIR_512 * (x1.shape[-2] * x1.shape[-1] / 512 ** 2)      # fwd + dgrad + wgrad
@@ -956,7 +965,7 @@ def train_main(args, net, P_cpu, batch, rank, world, dev, H_img, W_img):
                        "step": "eager" if (args.eager or not getattr(tr, "capturable", True)) else "HIP graph replay"},
             "model_tflops": round(pairs * gflop_pair / elapsed / 1e3, 2) if args.model == "hsic" else None,
             "mfma_frac_of_step": round(pairs * gflop_pair / elapsed / 1e3 / world / MFMA_BF16_PEAK_TFLOPS, 4) if args.model == "hsic" and args.dtype != "f32" else None,
-            "roofline": roof,
+            "roofline": roof, "power_state_timed_step": pstate,
             "comm": comm,
             "launches_per_step": {"c_abi_calls": sum(census.values()), "note": "C-ABI calls of one eager step (each is 1-2 kernel launches); "
                                   "ATen launches not included -- see profiles/ for the rocprofv3 count"},

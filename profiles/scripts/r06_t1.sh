@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-python profiles/scripts/memcpy_in_forward.py 2>&1 | grep -v amdgpu.ids | tail -40 > gpurun_out/r06_t1.log
+python bench.py --mode train > gpurun_out/r06_train_ps.json 2> gpurun_out/r06_train_ps.err
