@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
     // outside the image are poisoned offsets (zeros = the conv's zero padding).  The next tile's pieces are requested as soon
     // as this tile's are in LDS, so their HBM latency runs under the MFMA phase.
     u32x4 pc[10];
+    // MODE 1, NRES 0: at most three couts, the image this conv refines requested with the halo (below); NRES 1: four couts, in-loop loads
+    constexpr bool PRE = MODE == 1 && NRES == 0;
+    [[maybe_unused]] float rpn[PRE ? TH / 4 : 1][3];
     int cb = 0, cty = 0, ctx = 0;
     auto request = [&](int tile) {
         const uint32_t q = fdiv((uint32_t)tile, a.fd_tx);
@@ -142,12 +145,37 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
             const int chunk = slot ^ ((hp >> 2) & 3);
             c32_load_piece(pc[u], ok ? (int)(((iy * a.W + ix) * 32 + chunk * 8) * 2) : (int)POISON, xr);
         }
+        if constexpr (PRE) {
+            // the fp32 image this conv refines (res1, planar): this lane's values for its four row groups of the tile, requested WITH the halo.
+            // As ordinary loads inside the row loop they were the newest vector-memory operations at every row group's end, and the wait
+            // for them -- the compiler cannot see the halo requests above, so it emitted vmcnt(0) -- waited out the next tile's whole halo
+            // once per row group: 80 us for a launch whose bytes take 35.
+            const u32x4 rr = c32_rsrc((const float*)a.res1 + (int64_t)cb * a.Cout * a.H * a.W);
+#pragma unroll
+            for (int rq = 0; rq < TH / 4; ++rq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int y = cty * TH + wave + 4 * rq, x = ctx * TW + p;
+                    const bool ok = a.res1 && h == 0 && c < a.Cout && y < a.H && x < a.W;
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rpn[rq][c]) : "v"(ok ? ((c * a.H + y) * a.W + x) * 4 : (int)POISON), "s"(rr) : "memory");
+                }
+        }
     };
     int tile = blockIdx.x;
     request(tile < ntiles ? tile : 0);
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = cb, ty = cty, tx = ctx;                     // of the tile whose halo is in `pc`
         c32_wait_pieces(pc);
+        [[maybe_unused]] float rpc[PRE ? TH / 4 : 1][3];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int rq = 0; rq < TH / 4; ++rq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    asm volatile("" : "+v"(rpn[rq][c]));          // defined from here on (c32_wait_pieces waited for every load)
+                    rpc[rq][c] = rpn[rq][c];
+                }
+        }
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int i = tid + 256 * u;
@@ -170,6 +198,11 @@ __global__ __launch_bounds__(256, 2) void c32_conv3x3_kernel(const C32Args a) {
                     r1v[it] = (NRES >= 1 && live) ? *(const u32x4*)((const h16_t*)a.res1 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
                     r2v[it] = (NRES >= 2 && live) ? *(const u32x4*)((const h16_t*)a.res2 + o + 8 * it) : u32x4{0u, 0u, 0u, 0u};
                 }
+            } else if constexpr (PRE) {
+                // (the row loop is `unroll 1`: the row group's values are selected, not indexed)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rp[c] = rq == 0 ? rpc[0][c] : rq == 1 ? rpc[1][c] : rq == 2 ? rpc[2][c] : rpc[3][c];
+                rp[3] = 0.f;
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -683,7 +716,8 @@ extern "C" int hesic_conv3x3_c32_forward(const void* x, const float* w, const fl
         if (a.res2) hipLaunchKernelGGL((c32_conv3x3_kernel<0, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
         else if (a.res1) hipLaunchKernelGGL((c32_conv3x3_kernel<0, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((c32_conv3x3_kernel<0, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    } else hipLaunchKernelGGL((c32_conv3x3_kernel<1, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (a.Cout <= 3) hipLaunchKernelGGL((c32_conv3x3_kernel<1, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((c32_conv3x3_kernel<1, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     HESIC_LAUNCH_RETURN("conv3x3_c32_forward");
 }
 
