@@ -1,7 +1,9 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -q -k "en or c32 or enh or stage2 or Enh" 2>&1 | tail -4 > gpurun_out/r06_t1.log
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/p5 -o e --output-format csv -- python /root/repo/profiles/scripts/en_forward_n.py 5 > /dev/null 2>&1
-head -8 /tmp/p5/e_kernel_stats.csv | cut -c1-200 >> /root/repo/gpurun_out/r06_t1.log
+mkdir -p gpurun_out; : > gpurun_out/r06_t1.log
+cp hesic_amd/libhesic_hip_f16.so /tmp/keep.so
+for rep in 1 2; do for v in base $VARIANTS; do
+  if [ $v = base ]; then cp /tmp/keep.so hesic_amd/libhesic_hip_f16.so; else cp profiles/scripts/micro/libhesic_hip_f16_$v.so hesic_amd/libhesic_hip_f16.so; fi
+  echo -n "$v  " >> gpurun_out/r06_t1.log; python profiles/scripts/en_conv_time.py 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/r06_t1.log
+done; done
+cp /tmp/keep.so hesic_amd/libhesic_hip_f16.so
