@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
     };
 
     // HALO: the phase's last store -- tile rows into registers, barrier (every wave is done with the tile = with both weight buffers), the next
-    // phase's first weight tile requested, then the stores: request and stores travel together, the next phase waits for both (vmcnt(0))
+    // phase's first weight tile requested, then the stores: the request is older than the NST stores, the next phase waits with vmcnt(NST)
     f32x16 acc[MI][NI];
     int gbuf = 0;
     auto store_tile_then_issue = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned char* eb, int ry, int rx, bool more) {
@@ -1354,11 +1354,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tr4_kernel(const IgemmArgs a) {
         // first stage of a later phase: everything but the previous epilogue's stores (the newest vector-memory operations of this wave)
         // has to be back; the lgkmcnt part covers that epilogue's last LDS reads before the barrier hands its buffer to the DMA
         if (ph == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: HALO's patch, written by ds_write)
-        // HALO: the weight tile was requested just in front of the phase's last stores.  A COUNTED wait is not safe here: loads and stores
-        // retire out of order with respect to each other, so vmcnt(NST) can be reached by the stores alone while the tile is still in flight
-        // (measured: 4 - 17 % wrong pixels, different on every launch).  The unfused form's counted wait works because its request is a
-        // whole epilogue older than its stores.
-        else if constexpr (HALO != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // HALO: the weight tile was requested just in front of the phase's last NST stores: everything older than those stores has to be back
+        // (counted, like the unfused form's wait below; vmcnt(0) measured the same -- the stores are as old as the request)
+        else if constexpr (HALO != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else if (GDN && a.y_pre) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
         for (int step = 0; step < nsteps - 1; ++step) {
