@@ -49,12 +49,18 @@ __global__ __launch_bounds__(256, 2) void k(const h8* __restrict__ src, float* _
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
     const bool zeros = argc > 2 && argv[2][0] == 'z';
+    const char* tag = argc > 2 ? argv[2] : "r";
     const bool small = argc > 3;
     h8* src; float* out;
     hipMalloc(&src, 4096 * sizeof(h8)); hipMalloc(&out, 1 << 24);
     _Float16* h = (_Float16*)malloc(4096 * 16);
     srand(1);
     for (int i = 0; i < 4096 * 8; ++i) h[i] = zeros ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 0.25f);
+    // argv[2] = "m<bits>": clear the low <bits> mantissa bits of EVERY operand value (how much of the matrix pipe's power is operand toggling?)
+    if (argc > 2 && argv[2][0] == 'm') {
+        const unsigned short mask = (unsigned short)(0xffffu << atoi(argv[2] + 1));
+        for (int i = 0; i < 4096 * 8; ++i) ((unsigned short*)h)[i] &= mask;
+    }
     hipMemcpy(src, h, 4096 * 16, hipMemcpyHostToDevice);
     const int iters = 4096, blocks = 256 * 2 * 4;          // 8 waves per CU x 4 rounds
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -69,7 +75,7 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&last, e0, e1); total_ms += last; ++n;
     }
     const double flops = (double)blocks * 4 * iters * 16 * 32768.0;
-    printf("%s %s operands: %d launches, last %.3f ms, %.0f TFLOP/s (last launch), %.0f TFLOP/s (average)\n", small ? "16x16x32" : "32x32x16", zeros ? "zero" : "random", n, last,
+    printf("%s %s operands: %d launches, last %.3f ms, %.0f TFLOP/s (last launch), %.0f TFLOP/s (average)\n", small ? "16x16x32" : "32x32x16", zeros ? "zero" : tag, n, last,
            flops / last / 1e9, flops * n / total_ms / 1e9);
     return 0;
 }
