@@ -49,12 +49,9 @@ __device__ __forceinline__ void terms3(float v, uint32_t& t01, uint32_t& t2) {
 // instead of 192 per tile) -- x and the squares stay pairs, w is rounded with error feedback over the taps (the image is smooth: the
 // weight-rounding error of the sum cancels, see pack_weight_shaped_kernel), gamma' single.  CPU study (precision_study.py schemes, 512^2,
 // g_a_conv2 single): 3.97e-4 flipped latents with the full pair arithmetic here, 4.09e-4 with this form.
-// PING (8 waves; experimental, HESIC_N2W_PING=1): the two waves of a SIMD alternate roles across block barriers -- one in its matrix phase (conv + GDN contraction, 136
-// MFMAs) while the other is in its VALU / memory phase (rsqrt, output staging and stores, the next tile's rows split into pairs); waves 4..7
-// enter the rotation one barrier late.  Free-running, the two waves drifted into doing the same phase at the same time and the parts of the
-// kernel added up instead of overlapping (two waves per SIMD were only 1.3x one).  A wave that runs out of tiles exits; the barrier then
-// counts the rest.
-template <int INV, int OUT1, int NW = 8, int PING = 0>
+// (A barrier rotation that put one wave of a SIMD into its matrix phase while the other stored -- PING -- ran 75.5 vs 81.8 us back to back but 0.5 % LESS on
+// the 8-pair step, twice; one wave per SIMD was only 1.3x slower than two.  Both forms left the library in round 6: profiles/experiments/r05_n2w_ping_rotation.patch.)
+template <int INV, int OUT1, int NW = 8>
 __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HArgs a) {
     constexpr int KS = 5, R = 15, NT = NW * 64;
     constexpr bool EARLY_REQ = OUT1 != 0 && NW == 4;
@@ -138,12 +135,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
         }
         ones_b = u32x4{H16_ONE_PAIR, H16_ONE_PAIR & 0xffffu, 0u, 0u};
     }
-    if constexpr (PING) {
-#ifdef N2W_STATIC_PRIO
-        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
-        if (wave >= NW / 2) __builtin_amdgcn_s_barrier();
-    }
     [[maybe_unused]] int it_dbg = -1;
     for (; tile < ntiles; tile += tstride) {
         ++it_dbg;
@@ -166,11 +157,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
         uint32_t pofs = (uint32_t)(fh * 16);
         asm volatile("" : "+v"(pofs));
         N2W_T(1);
-        if constexpr (PING) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         N2W_T(2);
         f32x16 acc[4];
         if constexpr (OUT1) {
@@ -318,11 +304,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void n2w_gdn_hilo_kernel(const HAr
             }
         }
         N2W_T(4);
-        if constexpr (PING) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         N2W_T(5);
         // y = v * rsqrt(nrm) (GDN) / v * sqrt(nrm) (IGDN) in fp32, kept in acc
         if constexpr (DYN_SQ) {
@@ -505,26 +486,6 @@ static int n2w_gdn_hilo_launch(const hesic_sconv_desc* d, const float* x, const 
     }
     const dim3 g(grid), blk(512);
     hipStream_t st = (hipStream_t)stream;
-    constexpr bool one_wave = false;      // experiment: one wave per SIMD (what do the two waves of a SIMD overlap?)
-    // A/B switch, off: back-to-back launches 75.5 vs 81.8 us with the rotation, but the 8-pair step 3620 vs 3638 pairs/s (same box, twice)
-    constexpr bool ping = false;
-    if (ping && out1 && !one_wave) {
-        static bool pattr = false;
-        if (!pattr) {
-            (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 1, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<1, 1, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            pattr = true;
-        }
-        if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 1, 8, 1>), g, blk, lds, st, a);
-        else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1, 8, 1>), g, blk, lds, st, a);
-        HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
-    }
-    if (one_wave && out1 && !inverse) {
-        (void)hipFuncSetAttribute((const void*)n2w_gdn_hilo_kernel<0, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const unsigned g4 = (unsigned)((tiles + 3) / 4 < 256 ? (tiles + 3) / 4 : 256);
-        hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1, 4>), dim3(g4), dim3(256), lds, st, a);
-        HESIC_LAUNCH_RETURN("sconv2d_gdn_forward_hilo");
-    }
     if (out1) {
         if (inverse) hipLaunchKernelGGL((n2w_gdn_hilo_kernel<1, 1>), g, blk, lds, st, a);
         else hipLaunchKernelGGL((n2w_gdn_hilo_kernel<0, 1>), g, blk, lds, st, a);

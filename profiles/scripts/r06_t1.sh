@@ -1,12 +1,5 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out; : > gpurun_out/r06_t1.log
-run() { for sz in 128 256; do for l in deconv3 deconv_plain; do python profiles/scripts/conv_layer_time.py --layer $l --dtype f16 --graph --size $sz 2>&1 | grep -v amdgpu.ids >> gpurun_out/r06_t1.log; done; done; }
-cp hesic_amd/libhesic_hip_f16.so /tmp/keep.so; cp profiles/scripts/micro/libhesic_hip_f16_hdma.so hesic_amd/libhesic_hip_f16.so
-for i in 1 2 3; do python profiles/scripts/tr4_determinism.py 2>&1 | grep "float16" | grep -c "10 / 10   equals unfused: True" >> gpurun_out/r06_t1.log; done
-echo dma >> gpurun_out/r06_t1.log; run
-cp /tmp/keep.so hesic_amd/libhesic_hip_f16.so
-echo regs >> gpurun_out/r06_t1.log; run
-cp profiles/scripts/micro/libhesic_hip_f16_hdma.so hesic_amd/libhesic_hip_f16.so
-echo dma >> gpurun_out/r06_t1.log; run
-cp /tmp/keep.so hesic_amd/libhesic_hip_f16.so
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_f16.py tests/test_gpu_baseline_workloads.py -m gpu -x -q 2>&1 | tail -3 > gpurun_out/r06_t1.log
+python bench.py --no-cpu-baseline --no-secondary --no-power-state --steps 100 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['gpu_metrics_last_batch'], d['roofline']['streaming_kernels']['conv1_3to128_gdn hi/lo (n2w, x3)']['avg_launch_us'])" >> gpurun_out/r06_t1.log
