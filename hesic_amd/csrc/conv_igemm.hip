@@ -524,6 +524,10 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
         }
     };
 
+#ifndef IGEMM_HL_MFMA16
+#define IGEMM_HL_MFMA16 1
+#endif
+    constexpr bool HL16 = IGEMM_HL_MFMA16 && HL != 0 && BK >= 64;      // pair launches on the 16x16x32 instruction (every pair layer of the models: Cin_k % 64 == 0)
     // Main loop.  Fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them (two
     // register sets), and the DMA issue for stage s+NS-1 sits between the first fragment read of stage s and its
     // MFMAs, so neither the LDS latency nor the DMA bookkeeping is exposed in front of the matrix pipe.
@@ -542,6 +546,55 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XT;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
+            if constexpr (HL16) {
+                // hi/lo operands on v_mfma_f32_16x16x32 (round 6): one instruction spans 32 channels, so a 64-wide stage (32 hi channels and their lo
+                // partners) is ONE k-step.  Same fragment bytes and accumulator registers as the 32x32x16 form below (16-row blocks: lane = (row lane & 15,
+                // k-quarter lane >> 4), slot ks2 * 4 + quarter of the hi / lo half), but half the accumulator traffic per flop -- at the board's power cap,
+                // where these launches run, the register-only loop of this instruction holds 1.95 - 2.0 PFLOP/s against 1.73.  The accumulators live in
+                // `acc`'s registers as 16 x 16 tiles (tile (a, b) = registers ((a & 1) * 2 + (b & 1)) * 4 .. + 3 of acc[a >> 1][b >> 1]) and are turned
+                // into the 32 x 32 layout the epilogues read ONCE behind the K loop (hl16_to_32 below).  Summation order per output value: stages as
+                // before, inside a 32-channel step hi hi, hi lo, lo hi -- the same in every tile variant.
+                constexpr int KS32 = BK / 64, LO = CPR / 2, MA = 2 * MI, NB = 2 * NI;
+                const int c16 = lane & 15, q16 = lane >> 4;
+                h16x8 wh[MA], wl[MA], xh[NB], xl[NB];
+                auto ld16 = [&](int ks2) {
+#pragma unroll
+                    for (int i = 0; i < MA; ++i) {
+                        const int r = wm * (BN / WM) + i * 16 + c16;
+                        wh[i] = *(const h16x8*)(ws + off(r, ks2 * 4 + q16));
+                        if constexpr (HL == 1) wl[i] = *(const h16x8*)(ws + off(r, LO + ks2 * 4 + q16));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int r = wn * (BM / WN) + j * 16 + c16;
+                        xh[j] = *(const h16x8*)(xs + off(r, ks2 * 4 + q16));
+                        xl[j] = *(const h16x8*)(xs + off(r, LO + ks2 * 4 + q16));
+                    }
+                };
+                ld16(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + NS - 1 < nsteps) issue(nxt);
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks2 = 0; ks2 < KS32; ++ks2) {
+                    if (ks2) { ld16(ks2); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int i = 0; i < MA; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const int r0 = ((i & 1) * 2 + (j & 1)) * 4;
+                            f32x16& A_ = acc[i >> 1][j >> 1];
+                            f32x4 c = {A_[r0], A_[r0 + 1], A_[r0 + 2], A_[r0 + 3]};
+                            c = mfma_16x16x32_h16(wh[i], xh[j], c, 0, 0, 0);
+                            c = mfma_16x16x32_h16(wh[i], xl[j], c, 0, 0, 0);
+                            if constexpr (HL == 1) c = mfma_16x16x32_h16(wl[i], xh[j], c, 0, 0, 0);
+                            A_[r0] = c[0]; A_[r0 + 1] = c[1]; A_[r0 + 2] = c[2]; A_[r0 + 3] = c[3];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             if constexpr (HL) {
                 // hi/lo operands: per 16-deep k-substep four fragment groups (w_hi, w_lo, x_hi, x_lo) feed 3 * MI * NI MFMAs.
                 // HL == 2 (round 4, the "x3c2" analysis mode's g_a_conv3 / conv4): the weights are SINGLE values rounded with error feedback
@@ -616,6 +669,37 @@ __global__ __launch_bounds__(NW * 64, igemm_waves_per_eu(BMP, BN, BK, NS, NW)) v
     };
     if (a.in_abs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (HL16) {
+        // hl16_to_32: the wave's (BN / WM) x (BM / WN) fp32 tile through its own slice of the (now dead) ring -- written from the 16 x 16 tiles (lane =
+        // pixel lane & 15, couts 4 (lane >> 4) .. + 3 of a 16-cout block), read back in the 32 x 32 layout (lane = pixel lane & 31, couts
+        // 8 g + 4 (lane >> 5) .. + 3 of a 32-cout block); 16-byte slot s of a pixel row at s ^ (pixel & (slots - 1)).  Once per tile: ~2 x 4 MI NI
+        // LDS instructions per lane against thousands of MFMAs.
+        constexpr int CW = BN / WM, PW = BM / WN, SL = CW / 4;             // couts, pixels, 16-byte slots per pixel row of the wave's tile
+        static_assert(NW * CW * PW * 4 <= LDS_BYTES, "the accumulator turn-round needs the wave tiles' fp32 size in LDS");
+        unsigned char* tb = smem + wave * (CW * PW * 4);
+        const int c16 = lane & 15, q16 = lane >> 4;
+        asm volatile("s_barrier" ::: "memory");                            // every wave is done reading the ring
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * NI; ++j) {
+                const int r0 = ((i & 1) * 2 + (j & 1)) * 4, px = j * 16 + c16, sl = i * 4 + q16;
+                const f32x16& A_ = acc[i >> 1][j >> 1];
+                *(f32x4*)(tb + (px * SL + (sl ^ (px & (SL - 1)))) * 16) = f32x4{A_[r0], A_[r0 + 1], A_[r0 + 2], A_[r0 + 3]};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // wave-private: the LDS executes a wave's accesses in order; the compiler must not
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int px = j * 32 + frow, sl = i * 8 + 2 * g + fh;
+                    const f32x4 v = *(const f32x4*)(tb + (px * SL + (sl ^ (px & (SL - 1)))) * 16);
+                    acc[i][j][4 * g] = v[0]; acc[i][j][4 * g + 1] = v[1]; acc[i][j][4 * g + 2] = v[2]; acc[i][j][4 * g + 3] = v[3];
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and the epilogues' own barriers stand before their first LDS write
+    }
     if constexpr (HL != 0) {
         // pair weights packed as (w * 2^s)_hi | (w * 2^s)_lo (binary16: the lo half of an unscaled 0.02 is a subnormal half, the pair then
         // carries 2^-20 instead of 2^-22): the sums come out times 2^s, exactly; one multiply per value here, in front of every epilogue
