@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-python bench.py > gpurun_out/r06_bench_f.json 2> gpurun_out/r06_bench_f.err
+python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/r06_t1.log
