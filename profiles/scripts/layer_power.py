@@ -24,6 +24,12 @@ x32 = (torch.randn(8, 128, 32, 32, device="cuda") * 0.5).half().contiguous(memor
 d3, ig = deconv(128, 128).cuda(), GDN(128, inverse=True).cuda()
 c2, g2 = conv(128, 128).cuda(), GDN(128).cuda()
 hd = conv(128, 960, stride=1, kernel_size=5).cuda()
+from hesic_amd import functional as Fn
+c1, g1 = conv(3, 128).cuda(), GDN(128).cuda()
+img = torch.rand(8, 3, 512, 512, device="cuda")
+pk = Fn.PackedN2wHiLo()
+gp, bp = g1.packer().get(g1.beta, g1.gamma, g1.beta_min)
+probe("conv1 + GDN on pairs (n2w hilo)", lambda: Fn.sconv_gdn_hilo(img, pk.get(c1.weight, g1.gamma), c1.bias, bp, g1.inverse))
 probe("deconv3 + IGDN (tr4, 128^2 -> 256^2)", lambda: d3.run_gdn(x128, ig))
 probe("conv2 + GDN single (256^2 -> 128^2)", lambda: c2.run_gdn(x256, g2))
 probe("head conv 128 -> 960 s1 (32^2)", lambda: hd.run(x32))
