@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-python profiles/scripts/layer_power.py 2>&1 | grep -v amdgpu.ids | tail -6 > gpurun_out/r06_t1.log
+timeout 1500 python bench.py --parity-trained 4 --no-secondary --no-power-state > gpurun_out/r06_trained.json 2> gpurun_out/r06_trained.err
